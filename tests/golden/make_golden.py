@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/*.npz by importing the PyTorch
+reference (jzhangbs/MVSDF @ /root/reference) on CPU.
+
+Runs ONLY in the build container (the reference never travels to the GPU box).
+The fixtures hold inputs' seeds/recipes and the reference's OUTPUTS; weights are
+regenerated from mvsdf_amd.utils.synth (checksummed), never committed.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Shim: stub imageio/skimage/cv2 + numpy.lib.function_base,
+Tensor.cuda -> identity, dict-backed conf object standing in for pyhocon.
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, '..', '..'))
+from mvsdf_amd.utils import synth  # noqa: E402
+
+for n in ('imageio', 'skimage', 'cv2'):
+    sys.modules[n] = types.ModuleType(n)
+fb = types.ModuleType('numpy.lib.function_base')
+fb.diff = np.diff
+sys.modules['numpy.lib.function_base'] = fb
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+sys.path.insert(0, '/root/reference/code')
+
+
+class Conf(dict):
+    def _g(s, k):
+        for p in k.split('.'):
+            s = s[p]
+        return s
+    get_int = lambda s, k: int(s._g(k))
+    get_float = lambda s, k: float(s._g(k))
+    get_config = lambda s, k: Conf(s._g(k))
+
+
+from model.implicit_differentiable_renderer import IDRNetwork  # noqa: E402
+from model.loss import IDRLoss  # noqa: E402
+from model.ray_tracing import RayTracing  # noqa: E402
+from model.sample_network import SampleNetwork  # noqa: E402
+from utils import rend_util  # noqa: E402
+
+torch.set_default_dtype(torch.float32)
+torch.set_num_threads(1)   # reference setting (idr_train.py:21)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def build_model(W, seed, **kw):
+    with quiet():
+        m = IDRNetwork(Conf(synth.model_conf(W, **kw)))
+    sd = synth.make_state_dict(W, seed)
+    m.load_state_dict({k: T(v) for k, v in sd.items()})
+    return m, sd
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+def analytic_sdf(x):
+    """SURVEY.md section 4 tier-0 SDF (elementwise, batch-shape independent)."""
+    r = torch.sqrt(x[:, 0] * x[:, 0] + x[:, 1] * x[:, 1] + x[:, 2] * x[:, 2])
+    return 1.7 * (r - 0.6 + 0.12 * torch.sin(9 * x[:, 0]) * torch.sin(7 * x[:, 1]) * torch.cos(8 * x[:, 2]))
+
+
+# ----------------------------------------------------------------------------------------------
+def g_sdf(W, n, seed):
+    m, sd = build_model(W, seed)
+    rs = np.random.RandomState(seed + 7)
+    x = rs.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    x[: n // 8] *= 1.6           # some points outside the unit cube
+    net = m.implicit_network
+    net.eval()
+    with torch.no_grad():
+        out = net(T(x)).numpy()
+    xg = T(x).clone()
+    g = net.gradient(xg)[:, 0, :].detach().numpy()
+    # folded weights of layer 0/8 as torch computes them (pins the weight-norm fold)
+    w0 = net.lin0.weight.detach().numpy()
+    w8 = net.lin8.weight.detach().numpy()
+    save('sdf_w%d' % W, W=W, seed=seed, x=x, out=out, grad=g, w0=w0, w8_row0=w8[0],
+         checksum=synth.state_checksum(sd))
+
+
+def g_render(W, n, seed):
+    m, sd = build_model(W, seed)
+    rs = np.random.RandomState(seed + 11)
+    pts = rs.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    nrm = rs.normal(size=(n, 3)).astype(np.float32)
+    view = rs.normal(size=(n, 3)).astype(np.float32)
+    view /= np.linalg.norm(view, axis=1, keepdims=True)
+    feat = rs.normal(size=(n, synth.FEAT)).astype(np.float32)
+    with torch.no_grad():
+        rgb = m.rendering_network(T(pts), T(nrm), T(view), T(feat)).numpy()
+    save('render_w%d' % W, W=W, seed=seed, points=pts, normals=nrm, view=view, feat=feat, rgb=rgb,
+         checksum=synth.state_checksum(sd))
+
+
+def g_rays(seed):
+    inp, _ = synth.make_batch(3, 700, 0, seed=seed, focal_scale=0.9, with_features=False)
+    # add a skewed intrinsic to exercise lift()'s skew terms (rend_util.py:96-97)
+    inp['intrinsics'][1, 0, 1] = 3.5
+    with torch.no_grad():
+        dirs, cam_loc = rend_util.get_camera_params(T(inp['uv']), T(inp['pose']), T(inp['intrinsics']))
+        si, mi = rend_util.get_sphere_intersection(cam_loc, dirs, r=1.0)
+    save('rays', seed=seed, uv=inp['uv'], pose=inp['pose'], intrinsics=inp['intrinsics'],
+         ray_dirs=dirs.numpy(), cam_loc=cam_loc.numpy(), sphere_intersections=si.numpy(),
+         mask_intersect=mi.numpy())
+
+
+class CountingSDF:
+    def __init__(self, f):
+        self.f, self.rows = f, []
+
+    def __call__(self, x):
+        self.rows.append(x.shape[0])
+        return self.f(x)
+
+
+def run_tracer(sdf, cam_loc, object_mask, dirs, training, seed, **tr):
+    rt = RayTracing(**tr)
+    rt.train(training)
+    torch.manual_seed(seed)
+    steps = torch.empty(100).uniform_(0.0, 1.0).numpy()     # what minimal_sdf_points will draw first
+    torch.manual_seed(seed)
+    c = CountingSDF(sdf)
+    with torch.no_grad(), quiet():
+        pts, mask, dists = rt(sdf=c, cam_loc=cam_loc, object_mask=object_mask, ray_directions=dirs)
+    return pts.numpy(), mask.numpy(), dists.numpy(), steps, np.array(c.rows, dtype=np.int64)
+
+
+def g_trace_analytic(seed):
+    tr = synth.model_conf(64)['ray_tracer']
+    inp, _ = synth.make_batch(4, 3000, 0, seed=seed, focal_scale=0.9, with_features=False)
+    with torch.no_grad():
+        dirs, cam_loc = rend_util.get_camera_params(T(inp['uv']), T(inp['pose']), T(inp['intrinsics']))
+    rs = np.random.RandomState(seed + 3)
+    omask = rs.uniform(size=(4 * 3000,)) < 0.8                # exercise object_mask paths (use_mask=True style)
+    for training in (False, True):
+        for mname, om in (('ones', np.ones_like(omask)), ('rand', omask)):
+            pts, mask, dists, steps, rows = run_tracer(analytic_sdf, cam_loc, T(om), dirs, training, seed + 5, **tr)
+            save('trace_analytic_%s_%s' % ('train' if training else 'eval', mname), seed=seed,
+                 uv=inp['uv'], pose=inp['pose'], intrinsics=inp['intrinsics'], object_mask=om,
+                 ray_dirs=dirs.numpy(), cam_loc=cam_loc.numpy(),
+                 points=pts, mask=mask, dists=dists, minsdf_steps=steps, rows=rows)
+
+
+def g_trace_mlp(W, B, P, seed):
+    m, sd = build_model(W, seed)
+    tr = synth.model_conf(W)['ray_tracer']
+    inp, _ = synth.make_batch(B, P, 0, seed=seed, focal_scale=1.4, with_features=False)
+    net = m.implicit_network
+    net.eval()
+    with torch.no_grad():
+        dirs, cam_loc = rend_util.get_camera_params(T(inp['uv']), T(inp['pose']), T(inp['intrinsics']))
+    om = np.ones((B * P,), dtype=bool)
+    for training in (False, True):
+        pts, mask, dists, steps, rows = run_tracer(lambda x: net(x)[:, 0], cam_loc, T(om), dirs, training,
+                                                   seed + 5, **tr)
+        with torch.no_grad():
+            sdf_at = net(T(pts))[:, 0].numpy()
+        save('trace_mlp_w%d_%s' % (W, 'train' if training else 'eval'), W=W, seed=seed, B=B, P=P,
+             focal_scale=1.4, ray_dirs=dirs.numpy(), cam_loc=cam_loc.numpy(), points=pts, mask=mask,
+             dists=dists, sdf_at_points=sdf_at, minsdf_steps=steps, rows=rows,
+             checksum=synth.state_checksum(sd))
+
+
+def g_sample_network(seed):
+    rs = np.random.RandomState(seed)
+    n = 200
+    a = {k: rs.normal(size=s).astype(np.float32) for k, s in dict(
+        surface_output=(n, 1), surface_sdf_values=(n, 1), surface_points_grad=(n, 3), surface_dists=(n, 1),
+        surface_cam_loc=(n, 3), surface_ray_dirs=(n, 3)).items()}
+    out = SampleNetwork()(*[T(a[k]) for k in ('surface_output', 'surface_sdf_values', 'surface_points_grad',
+                                               'surface_dists', 'surface_cam_loc', 'surface_ray_dirs')]).numpy()
+    save('sample_network', out=out, **a)
+
+
+SCENE = dict(size=2.6, center=(0.1, -0.2, 0.3), feat_hw=(60, 80), focal_scale=1.4)
+
+
+def g_idr(W, B, P, V, seed, tp):
+    m, sd = build_model(W, seed)
+    inp, gt = synth.make_batch(B, P, V, seed=seed, **SCENE)
+    m.train()
+    torch.manual_seed(seed + 5)
+    mi = {k: T(v) for k, v in inp.items()}
+    with quiet():
+        out = m(mi, tp)
+    res = {}
+    for k, v in out.items():
+        res['out_' + k] = v.detach().numpy()
+    # loss + gradients
+    loss_fn = IDRLoss()
+    gtt = {k: T(v) for k, v in gt.items()}
+    with quiet():
+        lo = loss_fn(out, gtt, tp, B)
+        feat_alone = loss_fn.get_feat_loss_corr(out['diff_surf_pts'], None, gtt['feat'], gtt['cam'], gtt['feat_src'],
+                                                gtt['src_cams'], gtt['size'], gtt['center'],
+                                                out['network_object_mask'], out['object_mask'])
+    for k, v in lo.items():
+        res['loss_' + k] = v.detach().numpy().reshape(-1)[0]
+    res['feat_loss_alone'] = feat_alone.detach().numpy().reshape(-1)[0]
+    m.zero_grad()
+    lo['loss'].backward()
+    rs = np.random.RandomState(1)
+    for k, p in m.named_parameters():
+        g = p.grad.detach().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        res['gnorm_' + k] = np.linalg.norm(g.astype(np.float64))
+        idx = rs.randint(0, g.size, size=8)
+        res['gidx_' + k] = idx
+        res['gval_' + k] = g.reshape(-1)[idx]
+    # the eikonal points drawn inside forward (torch CPU generator), for implementations that take them as input
+    save('idr_w%d_tp%s' % (W, str(tp).replace('.', '')), W=W, B=B, P=P, V=V, seed=seed, tp=tp,
+         scene_size=SCENE['size'], scene_center=np.array(SCENE['center']), feat_hw=np.array(SCENE['feat_hw']),
+         focal_scale=SCENE['focal_scale'], checksum=synth.state_checksum(sd), **res)
+
+
+def g_feat(seed):
+    """get_feat_loss_corr alone on fixed points + d loss / d points."""
+    B, P, V = 2, 300, 3
+    inp, gt = synth.make_batch(B, P, V, seed=seed, **SCENE)
+    rs = np.random.RandomState(seed + 9)
+    hits = rs.uniform(size=(B * P,)) < 0.7
+    n = int(hits.sum())
+    d = rs.normal(size=(n, 3))
+    pts = (0.6 * d / np.linalg.norm(d, axis=1, keepdims=True) + 0.03 * rs.normal(size=(n, 3))).astype(np.float32)
+    p = T(pts).requires_grad_(True)
+    gtt = {k: T(v) for k, v in gt.items()}
+    with quiet():
+        loss = IDRLoss().get_feat_loss_corr(p, None, gtt['feat'], gtt['cam'], gtt['feat_src'], gtt['src_cams'],
+                                            gtt['size'][:1], gtt['center'][:1], T(hits), T(np.ones_like(hits)))
+    loss.backward()
+    save('feat_corr', seed=seed, B=B, P=P, V=V, hits=hits, points=pts, loss=loss.item(), dpoints=p.grad.numpy(),
+         scene_size=SCENE['size'], scene_center=np.array(SCENE['center']), feat_hw=np.array(SCENE['feat_hw']),
+         focal_scale=SCENE['focal_scale'])
+
+
+if __name__ == '__main__':
+    g_sdf(64, 1000, 0)
+    g_sdf(256, 256, 0)
+    g_render(64, 300, 0)
+    g_rays(0)
+    g_trace_analytic(0)
+    g_trace_mlp(64, 4, 1024, 0)
+    g_trace_mlp(256, 2, 512, 0)
+    g_sample_network(0)
+    g_feat(0)
+    g_idr(64, 2, 256, 3, 0, 0.3)
+    g_idr(64, 2, 256, 3, 0, 0.6)
+    g_idr(256, 2, 128, 2, 0, 0.3)
