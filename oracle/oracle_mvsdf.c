@@ -1,0 +1,335 @@
+/* oracle_mvsdf.c -- CPU restatement of the MVSDF hot path (plain C).
+ *
+ * TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library; the product (mvsdf_amd/) never does.  Parity status: PINNED against
+ * golden vectors captured from the PyTorch reference in the build container
+ * (tests/golden/make_golden.py -> tests/golden/<name>.npz, checked by tests/test_oracle_golden.py).
+ * The reference ships no tests/golden vectors of its own.
+ *
+ * Each function cites the reference file:line it restates (paths relative to /root/reference).
+ * Arithmetic: fp32; every Linear is a k-ascending fmaf chain from 0 followed by "+ bias" -- the
+ * order of v_mfma_f32_16x16x4_f32 accumulation -- so that the gfx950 kernels can be compared
+ * bit for bit.  Transcendentals come from det_math.h (deterministic, 1-2 ulp).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma -fopenmp).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "det_math.h"
+
+#define MAXL 16
+#define MAXW 1024
+
+typedef struct {
+    int n_layers;            /* number of Linear layers (9 for the SDF net) */
+    int in[MAXL], out[MAXL]; /* per layer (idr.py:45-51) */
+    int skip_layer;          /* layer whose INPUT is cat([x, PE])/sqrt(2) (idr.py:86-87), or -1 */
+    int multires;            /* PE frequencies (embedder.py:38-50) */
+    const float *W[MAXL];    /* folded weights, row-major [out][in] */
+    const float *b[MAXL];
+} orc_net;
+
+/* ---- weight norm: w = v * (g / ||v||_row)   (idr.py:70-71; torch._weight_norm, dim=0) ---- */
+void orc_fold(const float *v, const float *g, int out, int in, float *w) {
+    for (int j = 0; j < out; ++j) {
+        float ss = 0.0f;
+        for (int k = 0; k < in; ++k) ss = fmaf(v[j * in + k], v[j * in + k], ss);
+        float a = g[j] / sqrtf(ss);
+        for (int k = 0; k < in; ++k) w[j * in + k] = v[j * in + k] * a;
+    }
+}
+
+/* ---- positional encoding [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(m-1) x), cos(2^(m-1) x)]  (embedder.py:10-36) ---- */
+static void pe_row(const float *x, int multires, float *o) {
+    o[0] = x[0]; o[1] = x[1]; o[2] = x[2];
+    float f = 1.0f;
+    for (int m = 0; m < multires; ++m) {
+        for (int c = 0; c < 3; ++c) {
+            float s, co;
+            dm_sincos(x[c] * f, &s, &co);
+            o[3 + 6 * m + c] = s;
+            o[3 + 6 * m + 3 + c] = co;
+        }
+        f *= 2.0f;
+    }
+}
+void orc_pe(const float *x, int n, int multires, float *out) {
+    int d = 3 + 6 * multires;
+    for (int i = 0; i < n; ++i) pe_row(x + 3 * i, multires, out + (size_t)d * i);
+}
+
+/* ---- ImplicitNetwork.forward for one point (idr.py:77-94).  ncols: how many columns of the last layer. ---- */
+static void sdf_row(const orc_net *net, const float *x, int ncols, float *y) {
+    float pe[64], a[MAXW], z[MAXW];
+    int d0 = 3 + 6 * net->multires;
+    pe_row(x, net->multires, pe);
+    int na = d0;
+    memcpy(a, pe, sizeof(float) * d0);
+    for (int l = 0; l < net->n_layers; ++l) {
+        if (l == net->skip_layer) {                      /* x = cat([x, input], 1) / sqrt(2) */
+            for (int k = 0; k < d0; ++k) a[na + k] = pe[k];
+            na += d0;
+            for (int k = 0; k < na; ++k) a[k] = dm_div_sqrt2(a[k]);
+        }
+        int last = (l == net->n_layers - 1);
+        int no = last ? ncols : net->out[l];
+        const float *W = net->W[l];
+        int in = net->in[l];
+        for (int j = 0; j < no; ++j) {
+            float acc = 0.0f;
+            for (int k = 0; k < in; ++k) acc = fmaf(a[k], W[(size_t)j * in + k], acc);
+            z[j] = acc + net->b[l][j];
+        }
+        if (last) { memcpy(y, z, sizeof(float) * no); return; }
+        for (int j = 0; j < no; ++j) a[j] = dm_softplus100(z[j]);   /* Softplus(beta=100), idr.py:75,91-92 */
+        na = no;
+    }
+}
+
+static void make_net(orc_net *net, int n_layers, const int *in, const int *out, int skip_layer, int multires,
+                     const float *Wcat, const float *bcat) {
+    net->n_layers = n_layers; net->skip_layer = skip_layer; net->multires = multires;
+    size_t wo = 0, bo = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        net->in[l] = in[l]; net->out[l] = out[l];
+        net->W[l] = Wcat + wo; net->b[l] = bcat + bo;
+        wo += (size_t)in[l] * out[l]; bo += out[l];
+    }
+}
+
+void orc_sdf_forward(int n_layers, const int *in, const int *out, int skip_layer, int multires,
+                     const float *Wcat, const float *bcat, const float *x, int n, int ncols, float *y) {
+    orc_net net; make_net(&net, n_layers, in, out, skip_layer, multires, Wcat, bcat);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = 0; i < n; ++i) sdf_row(&net, x + 3 * i, ncols, y + (size_t)ncols * i);
+}
+
+/* ---- rend_util.get_camera_params + lift (rend_util.py:48-75, 87-100), pose-matrix branch ---- */
+void orc_camera_rays(const float *uv, const float *pose, const float *K, int B, int P, float *dirs, float *cam_loc) {
+    for (int b = 0; b < B; ++b) {
+        const float *p = pose + 16 * b, *k = K + 16 * b;
+        float fx = k[0], fy = k[5], cx = k[2], cy = k[6], sk = k[1];
+        cam_loc[3 * b + 0] = p[3]; cam_loc[3 * b + 1] = p[7]; cam_loc[3 * b + 2] = p[11];
+        for (int i = 0; i < P; ++i) {
+            float x = uv[((size_t)b * P + i) * 2 + 0] + 0.5f, y = uv[((size_t)b * P + i) * 2 + 1] + 0.5f, z = 1.0f;
+            float xl = (x - cx + cy * sk / fy - sk * y / fy) / fx * z;
+            float yl = (y - cy) / fy * z;
+            float h[4] = {xl, yl, z, 1.0f}, w[3];
+            for (int r = 0; r < 3; ++r) {       /* bmm(p, pts): k-ascending fma chain */
+                float acc = 0.0f;
+                for (int c = 0; c < 4; ++c) acc = fmaf(p[4 * r + c], h[c], acc);
+                w[r] = acc - cam_loc[3 * b + r];
+            }
+            float nn = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);   /* F.normalize: v / max(||v||, 1e-12) */
+            if (nn < 1e-12f) nn = 1e-12f;
+            float *d = dirs + ((size_t)b * P + i) * 3;
+            d[0] = w[0] / nn; d[1] = w[1] / nn; d[2] = w[2] / nn;
+        }
+    }
+}
+
+/* ---- rend_util.get_sphere_intersection (rend_util.py:141-162) for one ray ---- */
+static int sphere_isect(const float *c, const float *d, float r, float *t0, float *t1) {
+    float dot = fmaf(d[2], c[2], fmaf(d[1], c[1], d[0] * c[0]));
+    float nrm = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    float under = dot * dot - (nrm * nrm - r * r);
+    int hit = under > 0.0f;
+    float a = 0.0f, b = 0.0f;
+    if (hit) {
+        float s = sqrtf(under);
+        a = s * -1.0f - dot;
+        b = s * 1.0f - dot;
+    }
+    *t0 = a < 0.0f ? 0.0f : a;      /* clamp_min(0) */
+    *t1 = b < 0.0f ? 0.0f : b;
+    return hit;
+}
+void orc_sphere_intersection(const float *cam_loc, const float *dirs, int B, int P, float r, float *t, uint8_t *mask) {
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < P; ++i) {
+            size_t q = (size_t)b * P + i;
+            mask[q] = (uint8_t)sphere_isect(cam_loc + 3 * b, dirs + 3 * q, r, t + 2 * q, t + 2 * q + 1);
+        }
+}
+
+/* ---- SDF callables ---- */
+typedef struct { const orc_net *net; int analytic; } sdf_ctx;
+
+/* tier-0 analytic SDF of the fixtures (tests/golden/make_golden.py::analytic_sdf): only +,-,* (torch's CPU sqrt is not correctly rounded),
+ * evaluated in exactly the op order of the torch expression, hence bit-reproducible. */
+static float analytic_sdf(const float *p) {
+    float x = p[0], y = p[1], z = p[2];
+    float x2 = x * x, y2 = y * y, z2 = z * z;
+    float r2 = x2 + y2 + z2;
+    float t5 = ((16.0f * x2 - 20.0f) * x2 + 5.0f) * x;
+    float t4 = (8.0f * y2 - 8.0f) * y2 + 1.0f;
+    float t3 = (4.0f * z2 - 3.0f) * z;
+    return 1.4f * (r2 - 0.36f) + 0.2f * (t5 * t4 * t3);
+}
+static float eval_sdf(const sdf_ctx *c, const float *p) {
+    if (c->analytic) return analytic_sdf(p);
+    float y;
+    sdf_row(c->net, p, 1, &y);
+    return y;
+}
+static float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static void point_at(const float *c, const float *d, float t, float *p) {   /* cam_loc + t * dir (mul, then add) */
+    p[0] = c[0] + t * d[0]; p[1] = c[1] + t * d[1]; p[2] = c[2] + t * d[2];
+}
+
+typedef struct {
+    float r, thr, line_search_step; int line_step_iters, st_iters, n_steps, n_secant; float dist_clip;
+} trace_params;
+
+/* ---- RayTracing.forward for ONE ray (ray_tracing.py:27-98), every global loop condition restated as a per-ray
+ * predicate (finished rays are no-ops in the reference's masked updates).
+ * rows[0..3] += sdf evaluations in sphere tracing / sampler / secant / min-sdf. ---- */
+static void trace_ray(const sdf_ctx *sc, const trace_params *tp, const float *c, const float *d, int object_mask,
+                      int training, const float *intervals, const float *minsdf_steps,
+                      float *out_pt, uint8_t *out_mask, float *out_dist, long long *rows) {
+    float t0, t1, p[3];
+    int isect = sphere_isect(c, d, tp->r, &t0, &t1);
+    /* sphere_tracing (ray_tracing.py:101-196) */
+    int unf_s = isect, unf_e = isect;
+    float acc_s = isect ? t0 : 0.0f, acc_e = isect ? t1 : 0.0f;
+    float min_dis = acc_s, max_dis = acc_e;
+    float next_s = 0.0f, next_e = 0.0f;
+    if (unf_s) { point_at(c, d, t0, p); next_s = clampf(eval_sdf(sc, p), -tp->dist_clip, tp->dist_clip); rows[0]++; }
+    if (unf_e) { point_at(c, d, t1, p); next_e = clampf(eval_sdf(sc, p), -tp->dist_clip, tp->dist_clip); rows[0]++; }
+    for (int iters = 0;; ) {
+        float curr_s = unf_s ? next_s : 0.0f, curr_e = unf_e ? next_e : 0.0f;
+        if (curr_s <= tp->thr) curr_s = 0.0f;
+        if (curr_e <= tp->thr) curr_e = 0.0f;
+        unf_s = unf_s && (curr_s > tp->thr);
+        unf_e = unf_e && (curr_e > tp->thr);
+        if ((!unf_s && !unf_e) || iters == tp->st_iters) break;
+        iters++;
+        acc_s = acc_s + curr_s;
+        acc_e = acc_e - curr_e;
+        next_s = 0.0f; next_e = 0.0f;
+        if (unf_s) { point_at(c, d, acc_s, p); next_s = clampf(eval_sdf(sc, p), -tp->dist_clip, tp->dist_clip); rows[0]++; }
+        if (unf_e) { point_at(c, d, acc_e, p); next_e = clampf(eval_sdf(sc, p), -tp->dist_clip, tp->dist_clip); rows[0]++; }
+        int np_s = next_s < 0.0f, np_e = next_e < 0.0f;
+        for (int k = 0; k < tp->line_step_iters && (np_s || np_e); ++k) {
+            float coef = (1.0f - tp->line_search_step) / (float)(1 << k);
+            if (np_s) { acc_s -= coef * curr_s; point_at(c, d, acc_s, p);
+                        next_s = clampf(eval_sdf(sc, p), -tp->dist_clip, tp->dist_clip); rows[0]++; }
+            if (np_e) { acc_e += coef * curr_e; point_at(c, d, acc_e, p);
+                        next_e = clampf(eval_sdf(sc, p), -tp->dist_clip, tp->dist_clip); rows[0]++; }
+            np_s = next_s < 0.0f; np_e = next_e < 0.0f;
+        }
+        unf_s = unf_s && (acc_s < acc_e);
+        unf_e = unf_e && (acc_s < acc_e);
+    }
+    int net_mask = acc_s < acc_e;                         /* ray_tracing.py:41 */
+    int sampler = unf_s;                                  /* ray_tracing.py:44 */
+    float pt[3];
+    point_at(c, d, acc_s, pt);
+    if (sampler) {                                        /* ray_sampler (ray_tracing.py:198-258) */
+        int n = tp->n_steps;
+        float smin = acc_s, smax = acc_e;
+        float zi[512] = {0}, sv[512] = {0};
+        for (int i = 0; i < n; ++i) {
+            zi[i] = smin + intervals[i] * (smax - smin);
+            point_at(c, d, zi[i], p);
+            sv[i] = eval_sdf(sc, p); rows[1]++;
+        }
+        int ind = 0; float best = INFINITY;              /* argmin(sign(sdf) * [n..1]), first minimum */
+        for (int i = 0; i < n; ++i) {
+            float sg = sv[i] > 0.0f ? 1.0f : (sv[i] < 0.0f ? -1.0f : 0.0f);
+            float v = sg * (float)(n - i);
+            if (v < best) { best = v; ind = i; }
+        }
+        float dist = zi[ind];
+        point_at(c, d, dist, pt);
+        int net_surf = sv[ind] < 0.0f, true_surf = object_mask;
+        if (!(true_surf && net_surf)) {                   /* P_out: argmin sdf (ray_tracing.py:229-235) */
+            int i2 = 0; float b2 = INFINITY;
+            for (int i = 0; i < n; ++i) if (sv[i] < b2) { b2 = sv[i]; i2 = i; }
+            dist = zi[i2]; point_at(c, d, dist, pt);
+        }
+        net_mask = net_surf;                              /* ray_tracing.py:237-239, 61 */
+        int do_secant = training ? (net_surf && true_surf) : net_surf;
+        if (do_secant) {                                  /* secant (ray_tracing.py:241-256, 260-278) */
+            int lo = ind - 1; if (lo < 0) lo += n;        /* negative index wraps */
+            float z_high = zi[ind], sdf_high = sv[ind], z_low = zi[lo], sdf_low = sv[lo];
+            float z_pred = -sdf_low * (z_high - z_low) / (sdf_high - sdf_low) + z_low;
+            for (int i = 0; i < tp->n_secant; ++i) {
+                point_at(c, d, z_pred, p);
+                float sm = eval_sdf(sc, p); rows[2]++;
+                if (sm > 0.0f) { z_low = z_pred; sdf_low = sm; }
+                if (sm < 0.0f) { z_high = z_pred; sdf_high = sm; }
+                z_pred = -sdf_low * (z_high - z_low) / (sdf_high - sdf_low) + z_low;
+            }
+            dist = z_pred; point_at(c, d, dist, pt);
+        }
+        acc_s = dist;
+    }
+    if (training) {                                       /* ray_tracing.py:73-94 */
+        int in_mask = !net_mask && object_mask && !sampler;
+        int out_mask = !object_mask && !sampler;
+        if ((in_mask || out_mask) && !isect) {             /* -bmm([n,1,3],[n,3,1]): plain left-to-right mul/add (matches torch bitwise) */
+            float dot = (d[0] * c[0] + d[1] * c[1]) + d[2] * c[2];
+            acc_s = -dot;
+            point_at(c, d, acc_s, pt);
+        }
+        if ((in_mask || out_mask) && isect) {             /* minimal_sdf_points (ray_tracing.py:280-308) */
+            if (net_mask && out_mask) min_dis = acc_s;
+            int n = tp->n_steps, bi = 0; float bv = INFINITY, bz = 0.0f;
+            for (int i = 0; i < n; ++i) {
+                float z = minsdf_steps[i] * (max_dis - min_dis) + min_dis;
+                point_at(c, d, z, p);
+                float v = eval_sdf(sc, p); rows[3]++;
+                if (v < bv) { bv = v; bi = i; bz = z; }
+            }
+            (void)bi;
+            acc_s = bz; point_at(c, d, bz, pt);
+        }
+    }
+    out_pt[0] = pt[0]; out_pt[1] = pt[1]; out_pt[2] = pt[2];
+    *out_mask = (uint8_t)net_mask;
+    *out_dist = acc_s;
+}
+
+/* analytic = 1: tier-0 SDF; else the MLP given by the net arrays.  object_mask: u8[R].  rows: long long[4]. */
+void orc_trace(int analytic, int n_layers, const int *in, const int *out, int skip_layer, int multires,
+               const float *Wcat, const float *bcat,
+               const float *cam_loc, const float *dirs, const uint8_t *object_mask, int B, int P,
+               float r, float thr, float line_search_step, int line_step_iters, int st_iters, int n_steps,
+               int n_secant, float dist_clip, int training, const float *intervals, const float *minsdf_steps,
+               float *points, uint8_t *mask, float *dists, long long *rows) {
+    orc_net net;
+    if (!analytic) make_net(&net, n_layers, in, out, skip_layer, multires, Wcat, bcat);
+    sdf_ctx sc = {&net, analytic};
+    trace_params tp = {r, thr, line_search_step, line_step_iters, st_iters, n_steps, n_secant, dist_clip};
+    long long r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : r0, r1, r2, r3)
+    for (int q = 0; q < B * P; ++q) {
+        long long rr[4] = {0, 0, 0, 0};
+        trace_ray(&sc, &tp, cam_loc + 3 * (q / P), dirs + 3 * (size_t)q, object_mask[q], training, intervals,
+                  minsdf_steps, points + 3 * (size_t)q, mask + q, dists + q, rr);
+        r0 += rr[0]; r1 += rr[1]; r2 += rr[2]; r3 += rr[3];
+    }
+    rows[0] = r0; rows[1] = r1; rows[2] = r2; rows[3] = r3;
+}
+
+void orc_analytic_sdf(const float *x, int n, float *y) {
+    for (int i = 0; i < n; ++i) y[i] = analytic_sdf(x + 3 * i);
+}
+void orc_softplus100(const float *x, int n, float *y) { for (int i = 0; i < n; ++i) y[i] = dm_softplus100(x[i]); }
+void orc_sincos(const float *x, int n, float *s, float *c) { for (int i = 0; i < n; ++i) dm_sincos(x[i], s + i, c + i); }
+void orc_expneg(const float *x, int n, float *y) { for (int i = 0; i < n; ++i) y[i] = dm_expneg(x[i]); }
+void orc_log1p01(const float *x, int n, float *y) { for (int i = 0; i < n; ++i) y[i] = dm_log1p01(x[i]); }
+void orc_div(const float *x, int n, float *y100, float *ysqrt2) {
+    for (int i = 0; i < n; ++i) { y100[i] = dm_div100(x[i]); ysqrt2[i] = dm_div_sqrt2(x[i]); }
+}
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    extern int omp_get_max_threads(void);
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -77,9 +77,16 @@ def save(name, **arrs):
 
 
 def analytic_sdf(x):
-    """SURVEY.md section 4 tier-0 SDF (elementwise, batch-shape independent)."""
-    r = torch.sqrt(x[:, 0] * x[:, 0] + x[:, 1] * x[:, 1] + x[:, 2] * x[:, 2])
-    return 1.7 * (r - 0.6 + 0.12 * torch.sin(9 * x[:, 0]) * torch.sin(7 * x[:, 1]) * torch.cos(8 * x[:, 2]))
+    """Tier-0 SDF (SURVEY.md section 4 idea, polynomial bumps instead of sin/cos): built from
+    +,-,* only (torch's CPU sqrt is not correctly rounded), so the C oracle (oracle_mvsdf.c::analytic_sdf) reproduces it bit for bit.
+    Not 1-Lipschitz on purpose: exercises the line search, the sampler and the secant."""
+    X, Y, Z = x[:, 0], x[:, 1], x[:, 2]
+    x2, y2, z2 = X * X, Y * Y, Z * Z
+    r2 = x2 + y2 + z2
+    t5 = ((16.0 * x2 - 20.0) * x2 + 5.0) * X
+    t4 = (8.0 * y2 - 8.0) * y2 + 1.0
+    t3 = (4.0 * z2 - 3.0) * Z
+    return 1.4 * (r2 - 0.36) + 0.2 * (t5 * t4 * t3)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -145,7 +152,11 @@ def run_tracer(sdf, cam_loc, object_mask, dirs, training, seed, **tr):
     c = CountingSDF(sdf)
     with torch.no_grad(), quiet():
         pts, mask, dists = rt(sdf=c, cam_loc=cam_loc, object_mask=object_mask, ray_directions=dirs)
-    return pts.numpy(), mask.numpy(), dists.numpy(), steps, np.array(c.rows, dtype=np.int64)
+    with torch.no_grad():
+        si, mi = rend_util.get_sphere_intersection(cam_loc, dirs, r=tr.get('object_bounding_sphere', 1.0))
+    extra = dict(intervals=torch.linspace(0, 1, steps=tr.get('n_steps', 100)).numpy(),
+                 sphere_intersections=si.numpy(), mask_intersect=mi.numpy())
+    return pts.numpy(), mask.numpy(), dists.numpy(), steps, np.array(c.rows, dtype=np.int64), extra
 
 
 def g_trace_analytic(seed):
@@ -157,11 +168,11 @@ def g_trace_analytic(seed):
     omask = rs.uniform(size=(4 * 3000,)) < 0.8                # exercise object_mask paths (use_mask=True style)
     for training in (False, True):
         for mname, om in (('ones', np.ones_like(omask)), ('rand', omask)):
-            pts, mask, dists, steps, rows = run_tracer(analytic_sdf, cam_loc, T(om), dirs, training, seed + 5, **tr)
+            pts, mask, dists, steps, rows, extra = run_tracer(analytic_sdf, cam_loc, T(om), dirs, training, seed + 5, **tr)
             save('trace_analytic_%s_%s' % ('train' if training else 'eval', mname), seed=seed,
                  uv=inp['uv'], pose=inp['pose'], intrinsics=inp['intrinsics'], object_mask=om,
                  ray_dirs=dirs.numpy(), cam_loc=cam_loc.numpy(),
-                 points=pts, mask=mask, dists=dists, minsdf_steps=steps, rows=rows)
+                 points=pts, mask=mask, dists=dists, minsdf_steps=steps, rows=rows, **extra)
 
 
 def g_trace_mlp(W, B, P, seed):
@@ -174,13 +185,13 @@ def g_trace_mlp(W, B, P, seed):
         dirs, cam_loc = rend_util.get_camera_params(T(inp['uv']), T(inp['pose']), T(inp['intrinsics']))
     om = np.ones((B * P,), dtype=bool)
     for training in (False, True):
-        pts, mask, dists, steps, rows = run_tracer(lambda x: net(x)[:, 0], cam_loc, T(om), dirs, training,
+        pts, mask, dists, steps, rows, extra = run_tracer(lambda x: net(x)[:, 0], cam_loc, T(om), dirs, training,
                                                    seed + 5, **tr)
         with torch.no_grad():
             sdf_at = net(T(pts))[:, 0].numpy()
         save('trace_mlp_w%d_%s' % (W, 'train' if training else 'eval'), W=W, seed=seed, B=B, P=P,
              focal_scale=1.4, ray_dirs=dirs.numpy(), cam_loc=cam_loc.numpy(), points=pts, mask=mask,
-             dists=dists, sdf_at_points=sdf_at, minsdf_steps=steps, rows=rows,
+             dists=dists, sdf_at_points=sdf_at, minsdf_steps=steps, rows=rows, **extra,
              checksum=synth.state_checksum(sd))
 
 

@@ -1,0 +1,100 @@
+"""CPU oracle (oracle/) pinned against golden vectors captured from the PyTorch reference
+(tests/golden/make_golden.py).  Tolerances follow BASELINE.json north_star: hit masks bit-exact,
+hit depths 1e-4 rel; tier-0 (analytic SDF) tracer outputs bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from mvsdf_amd.utils import synth
+
+
+def _net(O, g):
+    sd = synth.make_state_dict(int(g['W']), int(g['seed']))
+    np.testing.assert_allclose(synth.state_checksum(sd), g['checksum'], rtol=0, atol=0)
+    return O.Net(sd)
+
+
+def test_det_math_accuracy(oracle):
+    rs = np.random.RandomState(0)
+    x = -rs.uniform(0, 90, 200000).astype(np.float32)
+    np.testing.assert_allclose(oracle.expneg(x), np.exp(x.astype(np.float64)), rtol=2.5e-7, atol=1e-44)
+    t = rs.uniform(0, 1, 200000).astype(np.float32)
+    np.testing.assert_allclose(oracle.log1p01(t), np.log1p(t.astype(np.float64)), rtol=2.5e-7)
+    a = rs.uniform(-64, 64, 200000).astype(np.float32)
+    s, c = oracle.sincos(a)
+    assert np.abs(s - np.sin(a.astype(np.float64))).max() < 1.5e-7
+    assert np.abs(c - np.cos(a.astype(np.float64))).max() < 1.5e-7
+    z = rs.uniform(-0.3, 0.3, 200000).astype(np.float32)
+    y = (z * np.float32(100)).astype(np.float64)
+    ref = np.where(y > 20, z, np.log1p(np.exp(y)) / 100)
+    np.testing.assert_allclose(oracle.softplus100(z), ref, rtol=4e-7, atol=1e-44)
+    v = rs.uniform(-50, 50, 200000).astype(np.float32)
+    d100, dsq = oracle.div_consts(v)
+    assert np.array_equal(d100, v / np.float32(100))
+    assert np.array_equal(dsq, v / np.float32(np.sqrt(2)))
+
+
+def test_rays_and_sphere(oracle):
+    g = golden('rays')
+    d, c = oracle.camera_rays(g['uv'], g['pose'], g['intrinsics'])
+    assert np.array_equal(c, g['cam_loc'])
+    assert np.abs(d - g['ray_dirs']).max() <= 1.2e-7          # torch's CPU sqrt is not correctly rounded: 1 ulp
+    t, m = oracle.sphere_intersection(g['cam_loc'], g['ray_dirs'])
+    assert np.array_equal(m, g['mask_intersect'])
+    assert 0.2 < m.mean() < 0.9                                # fixture has both kinds of rays
+    assert np.abs(t - g['sphere_intersections']).max() <= 2.4e-7
+    assert (t == g['sphere_intersections']).mean() > 0.995
+
+
+@pytest.mark.parametrize('W', [64, 256])
+def test_sdf_forward(oracle, W):
+    g = golden('sdf_w%d' % W)
+    net = _net(oracle, g)
+    np.testing.assert_allclose(net.W[0], g['w0'], rtol=5e-7, atol=1e-9)        # weight-norm fold (1-2 ulp: sum order)
+    np.testing.assert_allclose(net.W[8][0], g["w8_row0"], rtol=5e-7, atol=1e-9)
+    y = oracle.sdf_forward(net, g['x'])
+    np.testing.assert_allclose(y, g['out'], rtol=1e-4, atol=3e-6)
+    y0 = oracle.sdf_forward(net, g['x'], ncols=1)
+    assert np.array_equal(y0[:, 0], y[:, 0])
+    pe = oracle.pe(g['x'], 6)
+    assert pe.shape == (g['x'].shape[0], 39)
+    assert np.array_equal(pe[:, :3], g['x'])
+
+
+@pytest.mark.parametrize('name', ['eval_ones', 'eval_rand', 'train_ones', 'train_rand'])
+def test_tracer_tier0_bit_exact(oracle, name):
+    """RayTracing.forward with the analytic SDF: masks, dists, points bit-exact on every ray whose sphere
+    intersection (t0, t1) is bitwise the reference's (torch's sqrt is off by an ulp on <0.7% of inputs)."""
+    g = golden('trace_analytic_' + name)
+    tr = synth.model_conf(64)['ray_tracer']
+    pts, mask, dists, rows = oracle.trace(None, g['cam_loc'], g['ray_dirs'], g['object_mask'], 'train' in name,
+                                          g['minsdf_steps'], g['intervals'], analytic=True, **tr)
+    t, _ = oracle.sphere_intersection(g['cam_loc'], g['ray_dirs'])
+    same = (t == g['sphere_intersections']).all(-1).reshape(-1)
+    assert same.mean() > 0.995
+    assert np.array_equal(mask, g['mask'])
+    assert np.array_equal(dists[same], g['dists'][same])
+    assert np.array_equal(pts[same], g['points'][same])
+    assert np.abs(dists - g['dists']).max() < 1e-5
+    assert rows.sum() == g['rows'].sum()                      # every sdf() row the reference evaluated
+    assert rows[1] > 0 and rows[2] > 0 and (rows[3] > 0) == ('train' in name)
+
+
+@pytest.mark.parametrize('W,mode', [(64, 'eval'), (64, 'train'), (256, 'eval')])
+def test_tracer_mlp(oracle, W, mode):
+    g = golden('trace_mlp_w%d_%s' % (W, mode))
+    net = _net(oracle, g)
+    tr = synth.model_conf(W)['ray_tracer']
+    pts, mask, dists, rows = oracle.trace(net, g['cam_loc'], g['ray_dirs'], np.ones(g['mask'].shape, bool),
+                                          mode == 'train', g['minsdf_steps'], g['intervals'], **tr)
+    assert np.array_equal(mask, g['mask'])                                          # hit masks bit-exact
+    hit = g['mask']
+    rel = np.abs(dists - g['dists']) / np.abs(g['dists']).clip(1e-6)
+    assert rel[hit].max() < 1e-4                                                    # depths 1e-4 rel
+    # non-hit rays: argmin over 100 samples may pick a neighbouring sample: compare SDF there
+    far = (~hit) & (np.abs(dists - g['dists']) > 1e-4)
+    assert far.mean() < 0.02
+    if far.any():
+        s_mine = oracle.sdf_forward(net, pts[far], ncols=1)[:, 0]
+        assert np.abs(s_mine - g['sdf_at_points'][far]).max() < 2e-4
+    assert abs(int(rows.sum()) - int(g['rows'].sum())) <= 8
