@@ -1,0 +1,97 @@
+/* mvsdf_hip.h -- C ABI of libmvsdf_hip.so, the MI355X (gfx950) native hot path of MVSDF.
+ *
+ * The reference (jzhangbs/MVSDF) has no FFI for this path: it is eager PyTorch behind nn.Module classes
+ * (SURVEY.md section 8b).  Each entry point below replaces the PyTorch op sequence of the cited reference
+ * lines; the Python mirror (mvsdf_amd/model/...) binds them with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions: all pointers are DEVICE pointers unless marked host; tensors are dense row-major fp32;
+ * masks are uint8 (0/1); `stream` is a hipStream_t passed as void*; every call is asynchronous on that
+ * stream and returns 0 on success or a nonzero code (hipError_t value, or negative for bad arguments);
+ * mvsdf_last_error() gives a message.  No call allocates or synchronises.
+ */
+#ifndef MVSDF_HIP_H
+#define MVSDF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVSDF_MAX_LAYERS 12
+
+/* A weight-norm-folded MLP in MFMA-packed form (see mvsdf_fold_pack).  host struct, device pointers. */
+typedef struct {
+    int n_layers;
+    int K[MVSDF_MAX_LAYERS];            /* in features per Linear */
+    int N[MVSDF_MAX_LAYERS];            /* out features per Linear */
+    const float* wp[MVSDF_MAX_LAYERS];  /* packed weights, mvsdf_packed_floats(N, K) floats */
+    const float* bias[MVSDF_MAX_LAYERS];
+    int skip_layer;                     /* layer whose input is cat([x, PE(x)])/sqrt(2) (idr.py:86-87), -1 if none */
+    int multires;                       /* positional-encoding frequencies (embedder.py:38-50) */
+} MvsdfNetDesc;
+
+/* RayTracing constructor arguments (ray_tracing.py:7-25) + the hard-coded dist_clip (ray_tracing.py:127-131). */
+typedef struct {
+    float r;                 /* object_bounding_sphere */
+    float thr;               /* sdf_threshold */
+    float line_search_step;
+    int line_step_iters;
+    int st_iters;            /* sphere_tracing_iters */
+    int n_steps;
+    int n_secant;            /* n_secant_steps */
+    float dist_clip;         /* 0.5 (0.05 in IDR_RENDER mode) */
+} MvsdfTraceParams;
+
+/* indices into the uint64 counters[16] array filled by mvsdf_trace (device memory) */
+enum {
+    MVSDF_CNT_ROWS_SPHERE = 0,  /* sdf() rows evaluated by sphere_tracing   (ray_tracing.py:134,137,168,171,185,186) */
+    MVSDF_CNT_ROWS_SAMPLER = 1, /* ... by ray_sampler                       (ray_tracing.py:218) */
+    MVSDF_CNT_ROWS_SECANT = 2,  /* ... by secant                            (ray_tracing.py:266) */
+    MVSDF_CNT_ROWS_MINSDF = 3,  /* ... by minimal_sdf_points                (ray_tracing.py:301) */
+    MVSDF_CNT_ITEMS = 4,        /* rays on the sample work list */
+    MVSDF_CNT_N_SAMPLER = 5,
+    MVSDF_CNT_N_MINSDF = 6
+};
+
+int mvsdf_version(void);
+const char* mvsdf_last_error(void);
+
+/* number of floats of the packed form of an [N][K] Linear (both dims rounded up to 16) */
+size_t mvsdf_packed_floats(int N, int K);
+
+/* weight_norm fold  w = v * (g / ||v||_row)  (idr.py:70-71, torch._weight_norm dim=0) + MFMA packing.
+ * v[N][K], g[N] -> w[N][K] (row-major, may be NULL), wp (packed W, may be NULL), wpT (packed W^T for
+ * contractions over the OUT dimension, may be NULL). */
+int mvsdf_fold_pack(const float* v, const float* g, int N, int K, float* w, float* wp, float* wpT, void* stream);
+/* backward of the fold: dW[N][K] -> dv[N][K], dg[N]    */
+int mvsdf_fold_backward(const float* v, const float* g, const float* dW, int N, int K, float* dv, float* dg, void* stream);
+
+/* ImplicitNetwork.forward(x)[:, 0] (idr.py:77-94) for n points: the tracing MLP alone. */
+int mvsdf_sdf_col0(const MvsdfNetDesc* net, const float* x, int n, float* y, int mt, void* stream);
+
+/* rend_util.get_camera_params + lift, pose-matrix branch (rend_util.py:48-75, 87-100):
+ * uv[B][P][2], pose[B][4][4], intrinsics[B][4][4] -> ray_dirs[B][P][3], cam_loc[B][3]. */
+int mvsdf_camera_rays(const float* uv, const float* pose, const float* intrinsics, int B, int P, float* ray_dirs, float* cam_loc,
+                      void* stream);
+
+/* RayTracing.forward (ray_tracing.py:27-98) with the SDF given by `net`:
+ * cam_loc[B][3], ray_dirs[B][P][3], object_mask[B*P] -> points[B*P][3], mask[B*P], dists[B*P].
+ * intervals[n_steps] = torch.linspace(0, 1, n_steps) (ray_tracing.py:206); minsdf_steps[n_steps] = the uniform draws
+ * of minimal_sdf_points (ray_tracing.py:287), used only when training != 0.
+ * counters: uint64[16], zeroed by the call.  workspace: mvsdf_trace_workspace_bytes(B*P) bytes.
+ * mt: row tiles (16 rows) per workgroup, 1..4; rpw: sample-list rays per workgroup, 1..16. */
+size_t mvsdf_trace_workspace_bytes(int R);
+int mvsdf_trace(const MvsdfNetDesc* net, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
+                const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
+                float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
+                size_t workspace_bytes, int mt, int rpw, void* stream);
+
+/* device self-test of the deterministic math: op 0 softplus100, 1 expneg, 2 log1p01, 3 sincos (y0=sin, y1=cos),
+ * 4 div100 / div_sqrt2 (y0, y1), 5 sqrt / reciprocal (y0, y1). */
+int mvsdf_det_math(int op, const float* x, int n, float* y0, float* y1, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

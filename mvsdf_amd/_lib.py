@@ -1,0 +1,72 @@
+"""ctypes binding of libmvsdf_hip.so (C ABI: include/mvsdf_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, we raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, 'libmvsdf_hip.so')
+MAX_LAYERS = 12
+_lib = None
+
+
+class NetDesc(C.Structure):
+    _fields_ = [('n_layers', C.c_int), ('K', C.c_int * MAX_LAYERS), ('N', C.c_int * MAX_LAYERS),
+                ('wp', C.c_void_p * MAX_LAYERS), ('bias', C.c_void_p * MAX_LAYERS),
+                ('skip_layer', C.c_int), ('multires', C.c_int)]
+
+
+class TraceParams(C.Structure):
+    _fields_ = [('r', C.c_float), ('thr', C.c_float), ('line_search_step', C.c_float), ('line_step_iters', C.c_int),
+                ('st_iters', C.c_int), ('n_steps', C.c_int), ('n_secant', C.c_int), ('dist_clip', C.c_float)]
+
+
+class MvsdfError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library (built in-tree by mvsdf_amd/build.py).  Raises if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise MvsdfError('libmvsdf_hip.so not found at %s -- run `python -c "import __graft_entry__ as g; g.build()"` '
+                             '(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback for the hot path' % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        L.mvsdf_last_error.restype = C.c_char_p
+        L.mvsdf_packed_floats.restype = C.c_size_t
+        L.mvsdf_packed_floats.argtypes = [C.c_int, C.c_int]
+        L.mvsdf_trace_workspace_bytes.restype = C.c_size_t
+        L.mvsdf_trace_workspace_bytes.argtypes = [C.c_int]
+        for name in EXPORTS:
+            getattr(L, name)
+        _lib = L
+    return _lib
+
+
+# every symbol include/mvsdf_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
+EXPORTS = [
+    'mvsdf_version', 'mvsdf_last_error', 'mvsdf_packed_floats', 'mvsdf_fold_pack', 'mvsdf_fold_backward',
+    'mvsdf_sdf_col0', 'mvsdf_camera_rays', 'mvsdf_trace_workspace_bytes', 'mvsdf_trace', 'mvsdf_det_math',
+]
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise MvsdfError('%s failed (code %d): %s' % (what or 'mvsdf call', rc, lib().mvsdf_last_error().decode()))
+
+
+def ptr(t):
+    """device (or host) pointer of a contiguous torch tensor, or None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'tensor must be contiguous'
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    import torch
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(0)

@@ -1,0 +1,176 @@
+// basic.hip -- weight-norm fold + MFMA packing, camera rays, the stand-alone tracing-MLP kernel and the
+// device self-test of det_math.  C ABI entry points for these live at the bottom (see include/mvsdf_hip.h).
+#include "tile_engine.h"
+#include "trace_params.h"
+#include "capi_util.h"
+
+// ---- weight norm (idr.py:70-71): one thread per output row, k-ascending fmaf chain (bit-exact vs the CPU restatement) ----
+__global__ void k_fold(const float* __restrict__ v, const float* __restrict__ g, int N, int K, float* __restrict__ w) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const float* vr = v + (size_t)j * K;
+    float ss = 0.0f;
+    for (int k = 0; k < K; ++k) ss = fmaf(vr[k], vr[k], ss);
+    const float a = g[j] / sqrtf(ss);
+    for (int k = 0; k < K; ++k) w[(size_t)j * K + k] = vr[k] * a;
+}
+
+// wp[ct][kb][lane][s] = W[ct*16 + (lane&15)][kb*16 + 4s + (lane>>4)];  transposed=1 packs W^T ([K][N] seen as out=K, in=N)
+__global__ void k_pack(const float* __restrict__ w, int N, int K, int transposed, float* __restrict__ wp) {
+    const int No = transposed ? K : N, Ko = transposed ? N : K;
+    const int KB = mv_ceil16(Ko) / 16;
+    const size_t total = (size_t)mv_ceil16(No) * mv_ceil16(Ko);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int s = idx & 3, lane = (idx >> 2) & 63;
+        const size_t blk = idx >> 8;
+        const int kb = (int)(blk % KB), ct = (int)(blk / KB);
+        const int o = ct * 16 + (lane & 15), i = kb * 16 + 4 * s + (lane >> 4);
+        float val = 0.0f;
+        if (o < No && i < Ko) val = transposed ? w[(size_t)i * K + o] : w[(size_t)o * K + i];
+        wp[idx] = val;
+    }
+}
+
+// backward of the fold: one wave per row.
+__global__ void k_fold_bwd(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ dW, int N, int K,
+                           float* __restrict__ dv, float* __restrict__ dg) {
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= N) return;
+    const float* vr = v + (size_t)j * K;
+    const float* dr = dW + (size_t)j * K;
+    float ss = 0.f, dot = 0.f;
+    for (int k = lane; k < K; k += 64) { ss = fmaf(vr[k], vr[k], ss); dot = fmaf(dr[k], vr[k], dot); }
+    for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o); dot += __shfl_xor(dot, o); }
+    const float nrm = sqrtf(ss), inv = 1.0f / nrm;
+    const float dgj = dot * inv;                         // dW . v_hat
+    const float a = g[j] * inv;
+    for (int k = lane; k < K; k += 64) dv[(size_t)j * K + k] = a * (dr[k] - dgj * vr[k] * inv);
+    if (lane == 0) dg[j] = dgj;
+}
+
+// ---- rend_util.get_camera_params + lift (rend_util.py:48-75, 87-100) ----
+__global__ void k_camera_rays(const float* __restrict__ uv, const float* __restrict__ pose, const float* __restrict__ Kin, int B, int P,
+                              float* __restrict__ dirs, float* __restrict__ cam_loc) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * P) return;
+    const int b = idx / P;
+    const float* p = pose + 16 * b;
+    const float* k = Kin + 16 * b;
+    const float fx = k[0], fy = k[5], cx = k[2], cy = k[6], sk = k[1];
+    const float cl[3] = {p[3], p[7], p[11]};
+    if (idx == b * P) { cam_loc[3 * b] = cl[0]; cam_loc[3 * b + 1] = cl[1]; cam_loc[3 * b + 2] = cl[2]; }
+    const float x = uv[2 * (size_t)idx] + 0.5f, y = uv[2 * (size_t)idx + 1] + 0.5f, z = 1.0f;
+    const float xl = (x - cx + cy * sk / fy - sk * y / fy) / fx * z;
+    const float yl = (y - cy) / fy * z;
+    const float h[4] = {xl, yl, z, 1.0f};
+    float wv[3];
+    for (int r = 0; r < 3; ++r) {
+        float acc = 0.0f;
+        for (int c = 0; c < 4; ++c) acc = fmaf(p[4 * r + c], h[c], acc);
+        wv[r] = acc - cl[r];
+    }
+    float nn = sqrtf(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]);
+    if (nn < 1e-12f) nn = 1e-12f;
+    dirs[3 * (size_t)idx] = wv[0] / nn;
+    dirs[3 * (size_t)idx + 1] = wv[1] / nn;
+    dirs[3 * (size_t)idx + 2] = wv[2] / nn;
+}
+
+// ---- the tracing MLP alone: y[i] = ImplicitNetwork(x[i])[0] ----
+template <int MT, int NTW>
+__global__ __launch_bounds__(MV_THREADS) void k_sdf_col0(MvNet net, const float* __restrict__ x, int n, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * MT;
+    const int tid = threadIdx.x, d0 = 3 + 6 * net.multires;
+    float* act = smem;
+    float* pe = act + ROWS * net.S;
+    float* pts = pe + ((ROWS * d0 + 3) & ~3);
+    float* out = pts + ROWS * 4;
+    const int row0 = blockIdx.x * ROWS;
+    for (int i = tid; i < ROWS * 3; i += MV_THREADS) {
+        const int row = row0 + i / 3;
+        pts[i] = row < n ? x[3 * (size_t)row0 + i] : 0.0f;
+    }
+    __syncthreads();
+    mv_sdf_eval_col0<MT, NTW>(net, act, pe, pts, out, tid);
+    if (tid < ROWS && row0 + tid < n) y[row0 + tid] = out[tid];
+}
+
+__global__ void k_det_math(int op, const float* __restrict__ x, int n, float* __restrict__ y0, float* __restrict__ y1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    float a = 0.f, b = 0.f;
+    switch (op) {
+        case 0: a = dm_softplus100(v); b = dm_sigmoid100(v); break;
+        case 1: a = dm_expneg(v); break;
+        case 2: a = dm_log1p01(v); break;
+        case 3: dm_sincos(v, &a, &b); break;
+        case 4: a = dm_div100(v); b = dm_div_sqrt2(v); break;
+        default: a = sqrtf(fabsf(v)); b = 1.0f / v; break;
+    }
+    y0[i] = a;
+    if (y1) y1[i] = b;
+}
+
+template <int MT, int NTW>
+static int launch_col0(const MvNet& net, const float* x, int n, float* y, hipStream_t s) {
+    const int rows = 16 * MT, d0 = 3 + 6 * net.multires;
+    const size_t lds = ((size_t)rows * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows) * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)k_sdf_col0<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return mv_check(e, "mvsdf_sdf_col0: LDS attribute");
+    hipLaunchKernelGGL((k_sdf_col0<MT, NTW>), dim3((n + rows - 1) / rows), dim3(MV_THREADS), lds, s, net, x, n, y);
+    return mv_check(hipGetLastError(), "mvsdf_sdf_col0");
+}
+
+// =============================================================================================================
+extern "C" {
+
+int mvsdf_version(void) { return 100; }
+
+size_t mvsdf_packed_floats(int N, int K) { return mv_packed_floats(N, K); }
+
+int mvsdf_fold_pack(const float* v, const float* g, int N, int K, float* w, float* wp, float* wpT, void* stream) {
+    if (!v || !g || N <= 0 || K <= 0 || !w) return mv_fail(-1, "mvsdf_fold_pack: bad arguments (w must be given)");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_fold, dim3((N + 63) / 64), dim3(64), 0, s, v, g, N, K, w);
+    const size_t total = mv_packed_floats(N, K);
+    const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    if (wp) hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, s, w, N, K, 0, wp);
+    if (wpT) hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, s, w, N, K, 1, wpT);
+    return mv_check(hipGetLastError(), "mvsdf_fold_pack");
+}
+
+int mvsdf_fold_backward(const float* v, const float* g, const float* dW, int N, int K, float* dv, float* dg, void* stream) {
+    if (!v || !g || !dW || !dv || !dg || N <= 0 || K <= 0) return mv_fail(-1, "mvsdf_fold_backward: bad arguments");
+    hipLaunchKernelGGL(k_fold_bwd, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, v, g, dW, N, K, dv, dg);
+    return mv_check(hipGetLastError(), "mvsdf_fold_backward");
+}
+
+int mvsdf_camera_rays(const float* uv, const float* pose, const float* intrinsics, int B, int P, float* ray_dirs, float* cam_loc,
+                      void* stream) {
+    if (!uv || !pose || !intrinsics || !ray_dirs || !cam_loc || B <= 0 || P <= 0) return mv_fail(-1, "mvsdf_camera_rays: bad arguments");
+    hipLaunchKernelGGL(k_camera_rays, dim3((B * P + 255) / 256), dim3(256), 0, (hipStream_t)stream, uv, pose, intrinsics, B, P, ray_dirs,
+                       cam_loc);
+    return mv_check(hipGetLastError(), "mvsdf_camera_rays");
+}
+
+int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, int mt, void* stream) {
+    MvNet net;
+    int rc = mv_make_net(desc, &net);
+    if (rc) return rc;
+    if (!x || !y || n <= 0) return mv_fail(-1, "mvsdf_sdf_col0: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (mv_wide(net)) return mt >= 2 ? launch_col0<2, 8>(net, x, n, y, s) : launch_col0<1, 8>(net, x, n, y, s);
+    if (mt >= 4) return launch_col0<4, 4>(net, x, n, y, s);
+    if (mt >= 2) return launch_col0<2, 4>(net, x, n, y, s);
+    return launch_col0<1, 4>(net, x, n, y, s);
+}
+
+int mvsdf_det_math(int op, const float* x, int n, float* y0, float* y1, void* stream) {
+    if (!x || !y0 || n <= 0) return mv_fail(-1, "mvsdf_det_math: bad arguments");
+    hipLaunchKernelGGL(k_det_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, op, x, n, y0, y1);
+    return mv_check(hipGetLastError(), "mvsdf_det_math");
+}
+
+}  // extern "C"

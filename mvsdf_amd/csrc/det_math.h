@@ -1,0 +1,135 @@
+/* det_math.h -- deterministic fp32 elementary functions (PRODUCT COPY, host + gfx950 device).
+ *
+ * Built ONLY from IEEE-754 correctly-rounded primitives (+, -, *, fmaf, compare/select, bit casts) so
+ * that gfx950 kernels and a CPU restatement produce identical bits: the tracer takes discrete decisions
+ * (sdf > 5e-5, sdf < 0, acc_start < acc_end; reference code/model/ray_tracing.py:41,143,150,173,193,227)
+ * on fp32 MLP outputs and "hit masks bit-exact" has to be checkable.  ~1-2 ulp, the class of the Sleef
+ * routines behind torch.exp/log1p/sin/cos.
+ *
+ * Restates nn.Softplus(beta=100) (idr.py:75: x*beta > 20 ? x : log1p(exp(x*beta))/beta), the
+ * Embedder's sin/cos (embedder.py:24-30) and the `/ np.sqrt(2)` of idr.py:87.
+ * Compile with -ffp-contract=off (explicit fmaf only).  tests/test_det_math.py checks this file
+ * bit for bit against the oracle's independent copy.
+ */
+#ifndef MVSDF_DET_MATH_H
+#define MVSDF_DET_MATH_H
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DM_FN __host__ __device__ static inline
+#else
+#define DM_FN static inline
+#endif
+
+DM_FN float dm_from_bits(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f; memcpy(&f, &u, 4); return f;
+#endif
+}
+
+/* round to nearest integer (ties to even), valid for |x| < 2^22 */
+DM_FN float dm_rint(float x) {
+    const float magic = 12582912.0f; /* 1.5 * 2^23 */
+    float t = x + magic;
+    return t - magic;
+}
+
+/* exp(x) for x <= 0 (returns 0 below -104) */
+DM_FN float dm_expneg(float x) {
+    if (!(x >= -104.0f)) return 0.0f;
+    float n = dm_rint(x * 1.4426950216293335f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float e = fmaf(p, r * r, r) + 1.0f;
+    int ni = (int)n;            /* in [-151, 0] */
+    int n1 = ni >> 1;           /* floor(ni/2) */
+    int n2 = ni - n1;
+    e = e * dm_from_bits((uint32_t)(n1 + 127) << 23);
+    return e * dm_from_bits((uint32_t)(n2 + 127) << 23);
+}
+
+/* log1p(t) for t in [0, 1] */
+DM_FN float dm_log1p01(float t) {
+    int k = !(t < 0.4142135679721832f);
+    float f = k ? (t - 1.0f) * 0.5f : t;
+    float q = 7.1513607744e-02f;
+    q = fmaf(q, f, -1.1573007339e-01f);
+    q = fmaf(q, f, 1.1661760853e-01f);
+    q = fmaf(q, f, -1.2410829558e-01f);
+    q = fmaf(q, f, 1.4249891856e-01f);
+    q = fmaf(q, f, -1.6668487893e-01f);
+    q = fmaf(q, f, 2.0000708849e-01f);
+    q = fmaf(q, f, -2.4999988981e-01f);
+    q = fmaf(q, f, 3.3333331185e-01f);
+    float f2 = f * f;
+    float res = fmaf(f2 * f, q, fmaf(-0.5f, f2, f));
+    if (k) res = (res + 1.428606765330187e-06f) + 0.693145751953125f;
+    return res;
+}
+
+/* x / 100 and x / fl32(sqrt(2)) as reciprocal + one fma correction (Markstein): a fixed op
+ * sequence, equal to the correctly rounded quotient for all but pathological inputs. */
+DM_FN float dm_div100(float x) {
+    float q = x * 0.009999999776482582f;
+    float r = fmaf(-100.0f, q, x);
+    return fmaf(r, 0.009999999776482582f, q);
+}
+DM_FN float dm_div_sqrt2(float x) {
+    float q = x * 0.7071067690849304f;
+    float r = fmaf(-1.4142135381698608f, q, x);
+    return fmaf(r, 0.7071067690849304f, q);
+}
+
+/* Softplus(beta=100, threshold=20) */
+DM_FN float dm_softplus100(float z) {
+    float y = z * 100.0f;
+    if (y > 20.0f) return z;
+    float t = dm_expneg(-fabsf(y));
+    float s = fmaxf(y, 0.0f) + dm_log1p01(t);
+    return dm_div100(s);
+}
+
+/* sin(a), cos(a) for |a| < ~1e4 (positional encoding arguments are < 64) */
+DM_FN void dm_sincos(float a, float *s, float *c) {
+    float j = dm_rint(a * 0.6366197466850281f);
+    float r = fmaf(j, -1.5703125f, a);
+    r = fmaf(j, -4.837512969970703125e-4f, r);
+    r = fmaf(j, -7.549790126404332e-08f, r);
+    float r2 = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = fmaf(ps, r2, 8.3321608736e-3f);
+    ps = fmaf(ps, r2, -1.6666654611e-1f);
+    float sr = fmaf(ps * r2, r, r);
+    float pc = 2.443315711809948e-5f;
+    pc = fmaf(pc, r2, -1.388731625493765e-3f);
+    pc = fmaf(pc, r2, 4.166664568298827e-2f);
+    float cr = fmaf(pc, r2 * r2, fmaf(-0.5f, r2, 1.0f));
+    int q = ((int)j) & 3;
+    float ss = (q & 1) ? cr : sr;
+    float cc = (q & 1) ? sr : cr;
+    if (q == 1 || q == 2) cc = -cc;
+    if (q >= 2) ss = -ss;
+    *s = ss;
+    *c = cc;
+}
+
+/* sigmoid(100 z) as used by the softplus derivative (1 where 100 z > 20); tolerance domain. */
+DM_FN float dm_sigmoid100(float z) {
+    float y = z * 100.0f;
+    if (y > 20.0f) return 1.0f;
+    float t = dm_expneg(-fabsf(y));
+    return (y >= 0.0f ? 1.0f : t) / (1.0f + t);
+}
+
+#endif

@@ -1,0 +1,39 @@
+// mlp_common.h -- device-side description of a folded MLP and the MFMA-packed weight layout.
+//
+// Packed layout of one Linear (out = N, in = K), consumed by v_mfma_f32_16x16x4_f32 without any
+// LDS staging of weights: Kp = ceil16(K), Np = ceil16(N),
+//     Wp[ct][kb][lane][s] = W[ct*16 + (lane & 15)][kb*16 + 4*s + (lane >> 4)]      (0 outside N x K)
+// i.e. one 16-byte load per lane (1 KiB per wave, fully coalesced) yields the B operands of the four
+// MFMA k-steps of a 16-wide k-block, and the k-steps are issued in ascending k: the accumulation is a
+// k-ascending fmaf chain from 0, bit-identical to a scalar fmaf loop.
+// The transposed pack (for v = s W, i.e. contraction over the OUT dimension) uses the same formula on W^T.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MV_MAXL 12
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MvLayer {
+    const float4* wp;   // packed [NT][KB][64] float4
+    const float* bias;  // [N]
+    int K, N;           // true in / out
+    int KB, NT;         // k-blocks of 16, column tiles of 16
+};
+
+struct MvNet {
+    MvLayer L[MV_MAXL];
+    int n_layers;
+    int skip_layer;     // layer whose input is cat([x, PE]) / sqrt(2), or -1
+    int multires;       // PE frequencies; d_pe = 3 + 6*multires
+    int S;              // LDS activation row stride in floats (== 8 mod 64: conflict-free ds_read_b128 A fragments)
+};
+
+__host__ __device__ static inline int mv_ceil16(int x) { return (x + 15) & ~15; }
+__host__ __device__ static inline size_t mv_packed_floats(int N, int K) {
+    return (size_t)mv_ceil16(N) * mv_ceil16(K);
+}
+// position of logical column c inside an LDS activation row: 4x4 transpose within each 16-block so that a
+// lane's four consecutive k-steps (k = 4s + q) are one contiguous float4 at 4q..4q+3.
+__host__ __device__ static inline int mv_perm(int c) { return (c & ~15) | ((c & 3) << 2) | ((c >> 2) & 3); }

@@ -1,0 +1,170 @@
+// tile_engine.h -- the MFMA "row-tile x layer" engine shared by every MLP kernel.
+//
+// One 256-thread workgroup (4 waves) owns up to 16*MT activation rows in LDS.  For one Linear:
+//   * wave w computes column tiles [w*ntw, w*ntw + ntw) for ALL row tiles,
+//   * A fragments (activations) come from LDS with one ds_read_b128 per 16-wide k-block (the row is
+//     stored 4x4-transposed inside each 16-block, see mv_perm, so the lane's four k-steps are contiguous),
+//   * B fragments (weights) come straight from the MFMA-packed global array (L2-resident: the whole
+//     8x256 SDF net is 2.1 MB) with one coalesced 16-byte load per lane per k-block, double buffered in
+//     registers -- weights are private to a wave's columns, so staging them in LDS would only add traffic;
+//     every loaded weight is reused by all MT row tiles of the workgroup's rays,
+//   * the product is v_mfma_f32_16x16x4_f32 issued in ascending k: a k-ordered fmaf chain (bit-exact
+//     against the scalar restatement).
+#pragma once
+#include "mlp_common.h"
+#include "det_math.h"
+
+#define MV_THREADS 256
+
+template <int MTc, int NTW>
+__device__ __forceinline__ void mv_zero_acc(f32x4 (&acc)[MTc][NTW]) {
+#pragma unroll
+    for (int a = 0; a < MTc; ++a)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// acc[rt][t] += act[rt*16.., :K] * W[(ct0+t)*16.., :K]^T    for t < ntw (wave-uniform), rt < MTc.
+template <int MTc, int NTW>
+__device__ __forceinline__ void mv_gemm_tiles(const MvLayer& L, const float* __restrict__ act, int S, int ct0, int ntw,
+                                              f32x4 (&acc)[MTc][NTW], int lane) {
+    const int KB = L.KB;
+    const float4* __restrict__ wp = L.wp + (size_t)ct0 * KB * 64 + lane;
+    const float* arow = act + (lane & 15) * S + 4 * (lane >> 4);
+    float4 b0[NTW], b1[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+        if (t < ntw) b0[t] = wp[(size_t)t * KB * 64];
+    for (int kb = 0; kb < KB; kb += 2) {
+        const bool has1 = kb + 1 < KB;
+        if (has1) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+                if (t < ntw) b1[t] = wp[((size_t)t * KB + kb + 1) * 64];
+        }
+        {
+            float4 a[MTc];
+#pragma unroll
+            for (int r = 0; r < MTc; ++r) a[r] = *(const float4*)(arow + r * 16 * S + kb * 16);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t)
+                        if (t < ntw)
+                            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a[r])[s], ((const float*)&b0[t])[s],
+                                                                             acc[r][t], 0, 0, 0);
+        }
+        if (has1) {
+            if (kb + 2 < KB) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+                    if (t < ntw) b0[t] = wp[((size_t)t * KB + kb + 2) * 64];
+            }
+            float4 a[MTc];
+#pragma unroll
+            for (int r = 0; r < MTc; ++r) a[r] = *(const float4*)(arow + r * 16 * S + (kb + 1) * 16);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t)
+                        if (t < ntw)
+                            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a[r])[s], ((const float*)&b1[t])[s],
+                                                                             acc[r][t], 0, 0, 0);
+        }
+    }
+}
+
+// Positional encoding of `rows` points (LDS pts[rows][3]) -> pe[rows][d0] (natural order, kept for the skip
+// connection) and act[rows][S] (permuted, zero padded to ceil16(d0)).  embedder.py:10-36.
+__device__ __forceinline__ void mv_pe_rows(const float* pts, float* pe, float* act, int S, int rows, int multires, int tid) {
+    const int d0 = 3 + 6 * multires, Kp0 = mv_ceil16(d0), T = 3 * multires + 1;
+    for (int task = tid; task < rows * T; task += MV_THREADS) {
+        const int row = task / T, j = task - row * T;
+        const float* x = pts + row * 3;
+        float* pr = pe + row * d0;
+        float* ar = act + row * S;
+        if (j < 3 * multires) {
+            const int m = j / 3, c = j - 3 * m;
+            float s, co;
+            dm_sincos(x[c] * (float)(1 << m), &s, &co);
+            const int cs = 3 + 6 * m + c, cc = cs + 3;
+            pr[cs] = s; pr[cc] = co;
+            ar[mv_perm(cs)] = s; ar[mv_perm(cc)] = co;
+        } else {
+            for (int c = 0; c < 3; ++c) { pr[c] = x[c]; ar[mv_perm(c)] = x[c]; }
+            for (int c = d0; c < Kp0; ++c) ar[mv_perm(c)] = 0.0f;
+        }
+    }
+}
+
+// ImplicitNetwork.forward(...)[:, 0] (idr.py:77-94) for MTc*16 rows whose points sit in LDS `pts`.
+// Result -> LDS out[row].  All 256 threads must call; ends with a barrier.
+template <int MTc, int NTW>
+__device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const float* pts, float* out, int tid) {
+    const int lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int S = net.S, rows = MTc * 16, d0 = 3 + 6 * net.multires;
+    mv_pe_rows(pts, pe, act, S, rows, net.multires, tid);
+    const int nl = net.n_layers;
+    for (int l = 0; l < nl; ++l) {
+        const MvLayer& L = net.L[l];
+        const bool last = (l == nl - 1);
+        const int NT = last ? 1 : L.NT;                       // tracing needs column 0 only
+        const int per = (NT + 3) >> 2;                        // column tiles per wave
+        const int ct0 = w * per;
+        int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
+        f32x4 acc[MTc][NTW];
+        mv_zero_acc<MTc, NTW>(acc);
+        __syncthreads();                                      // inputs of layer l complete
+        if (ntw > 0) mv_gemm_tiles<MTc, NTW>(L, act, S, ct0, ntw, acc, lane);
+        __syncthreads();                                      // every wave done reading act (in-place update)
+        if (last) {
+            if (w == 0 && r == 0) {
+                const float b0 = L.bias[0];
+#pragma unroll
+                for (int a = 0; a < MTc; ++a)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) out[a * 16 + 4 * q + i] = acc[a][0][i] + b0;
+            }
+        } else {
+            const bool to_skip = (l + 1 == net.skip_layer);
+            const int N = L.N;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                if (t < ntw) {
+                    const int col = (ct0 + t) * 16 + r;
+                    if (col < N) {
+                        const float bv = L.bias[col];
+                        const int pos = (ct0 + t) * 16 + ((r & 3) << 2) + (r >> 2);
+#pragma unroll
+                        for (int a = 0; a < MTc; ++a)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                float h = dm_softplus100(acc[a][t][i] + bv);     // Softplus(beta=100), idr.py:91-92
+                                if (to_skip) h = dm_div_sqrt2(h);                // cat([x, input]) / sqrt(2), idr.py:86-87
+                                act[(a * 16 + 4 * q + i) * S + pos] = h;
+                            }
+                    }
+                }
+            }
+            const int Kn = net.L[l + 1].K, Kpn = net.L[l + 1].KB * 16;
+            if (to_skip) {
+                for (int idx = tid; idx < rows * d0; idx += MV_THREADS) {
+                    const int row = idx / d0, j = idx - row * d0;
+                    act[row * S + mv_perm(N + j)] = dm_div_sqrt2(pe[row * d0 + j]);
+                }
+            }
+            if (Kpn > Kn) {
+                const int pad = Kpn - Kn;
+                for (int idx = tid; idx < rows * pad; idx += MV_THREADS) {
+                    const int row = idx / pad, j = idx - row * pad;
+                    act[row * S + mv_perm(Kn + j)] = 0.0f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}

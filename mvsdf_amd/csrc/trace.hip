@@ -1,0 +1,408 @@
+// trace.hip -- RayTracing.forward (reference code/model/ray_tracing.py:27-98) as two persistent-style kernels:
+//
+//   k_sphere_trace : one workgroup owns NR = 8*MT rays = 16*MT "half-rays" (start/end side).  Per-ray state
+//                    lives in wave 0's registers; every round each ray requests 0/1/2 SDF evaluations, the
+//                    requests are compacted with ballot + prefix-popcount into the first n rows of the LDS
+//                    point tile, and the fused 9-layer MLP (tile_engine.h) runs on ceil(n/16) row tiles only --
+//                    converged rays drop out and the MFMA work shrinks with them.  Rays advance independently
+//                    (own iteration and line-search counters): the reference's global loop conditions
+//                    (ray_tracing.py:153,176) are per-ray no-ops for finished rays, so results are identical.
+//                    Also: sphere intersection (rend_util.py:141-162), left-out projection (ray_tracing.py:79-84),
+//                    and appending unfinished / non-hit rays to the sample work list.
+//   k_ray_samples  : ray_sampler + secant (ray_tracing.py:198-278) and minimal_sdf_points (280-308): each work item
+//                    is one ray x n_steps samples; rows of RPW rays are evaluated in full tiles, then one thread per
+//                    ray does the argmin / first-sign-change logic and the (dependent) secant rounds run compacted.
+//
+// No host synchronisation anywhere: list lengths stay on the device, grids are sized for the worst case.
+#include "tile_engine.h"
+#include "trace_params.h"
+
+struct RayCommon {
+    float c[3], d[3];
+};
+
+__device__ __forceinline__ float mv_clamp(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// rend_util.get_sphere_intersection for one ray (same op order as the CPU restatement)
+__device__ __forceinline__ bool mv_sphere_isect(const float* c, const float* d, float r, float& t0, float& t1) {
+    const float dot = fmaf(d[2], c[2], fmaf(d[1], c[1], d[0] * c[0]));
+    const float nrm = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    const float under = dot * dot - (nrm * nrm - r * r);
+    const bool hit = under > 0.0f;
+    float a = 0.0f, b = 0.0f;
+    if (hit) {
+        const float s = sqrtf(under);
+        a = s * -1.0f - dot;
+        b = s * 1.0f - dot;
+    }
+    t0 = a < 0.0f ? 0.0f : a;
+    t1 = b < 0.0f ? 0.0f : b;
+    return hit;
+}
+
+template <int MT, int NTW>
+__device__ __forceinline__ void mv_eval_dispatch(const MvNet& net, int ntiles, float* act, float* pe, const float* pts, float* out, int tid) {
+    if (MT >= 4 && ntiles == 4) mv_sdf_eval_col0<(MT >= 4 ? 4 : MT), NTW>(net, act, pe, pts, out, tid);
+    else if (MT >= 3 && ntiles == 3) mv_sdf_eval_col0<(MT >= 3 ? 3 : MT), NTW>(net, act, pe, pts, out, tid);
+    else if (MT >= 2 && ntiles == 2) mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW>(net, act, pe, pts, out, tid);
+    else mv_sdf_eval_col0<1, NTW>(net, act, pe, pts, out, tid);
+}
+
+// LDS carve shared by both kernels
+struct TraceLds {
+    float* act; float* pe; float* pts; float* sdfv; float* sv; int* misc;
+};
+__device__ __forceinline__ TraceLds mv_carve(float* base, int rows, int S, int d0, int sv_floats) {
+    TraceLds l;
+    l.act = base;
+    l.pe = l.act + rows * S;
+    l.pts = l.pe + ((rows * d0 + 3) & ~3);
+    l.sdfv = l.pts + rows * 4;
+    l.sv = l.sdfv + rows;
+    l.misc = (int*)(l.sv + sv_floats);
+    return l;
+}
+
+template <int MT, int NTW>
+__global__ __launch_bounds__(MV_THREADS) void k_sphere_trace(MvNet net, MvTraceParams tp, const float* __restrict__ cam_loc,
+                                                            const float* __restrict__ dirs, const uint8_t* __restrict__ object_mask,
+                                                            int R, int P, int training, float* __restrict__ o_points,
+                                                            uint8_t* __restrict__ o_mask, float* __restrict__ o_dists,
+                                                            float* __restrict__ w_zmin, float* __restrict__ w_zmax, int* __restrict__ w_list,
+                                                            unsigned long long* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * MT, NR = 8 * MT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    TraceLds lds = mv_carve(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
+    int* s_n = lds.misc;
+
+    // ---- per-ray state (threads 0..NR-1 of wave 0) ----
+    const int gid = blockIdx.x * NR + tid;
+    const bool valid = (tid < NR) && (gid < R);
+    float c[3] = {0, 0, 0}, d[3] = {0, 0, 0};
+    float t0 = 0.f, t1 = 0.f;
+    bool isect = false, om = false;
+    if (valid) {
+        const int b = gid / P;
+        for (int i = 0; i < 3; ++i) { c[i] = cam_loc[3 * b + i]; d[i] = dirs[3 * (size_t)gid + i]; }
+        isect = mv_sphere_isect(c, d, tp.r, t0, t1);
+        om = object_mask[gid] != 0;
+    }
+    bool unf_s = isect, unf_e = isect;
+    float acc_s = isect ? t0 : 0.f, acc_e = isect ? t1 : 0.f;
+    float next_s = 0.f, next_e = 0.f, curr_s = 0.f, curr_e = 0.f;
+    int iters = 0, k = 0, phase = isect ? 0 : 3;          // 0 init, 1 step, 2 line search, 3 done
+    bool req_s = isect, req_e = isect;
+    float ts = acc_s, te = acc_e;
+    unsigned long long nrows_total = 0;
+
+    for (;;) {
+        int row_s = 0, row_e = 0;
+        if (w == 0) {
+            const unsigned long long ms = __ballot(req_s), me = __ballot(req_e);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int ns = __popcll(ms), ne = __popcll(me);
+            row_s = __popcll(ms & lt);
+            row_e = ns + __popcll(me & lt);
+            if (req_s) { float* p = lds.pts + row_s * 3; p[0] = c[0] + ts * d[0]; p[1] = c[1] + ts * d[1]; p[2] = c[2] + ts * d[2]; }
+            if (req_e) { float* p = lds.pts + row_e * 3; p[0] = c[0] + te * d[0]; p[1] = c[1] + te * d[1]; p[2] = c[2] + te * d[2]; }
+            if (lane == 0) *s_n = ns + ne;
+        }
+        __syncthreads();
+        const int n = *s_n;
+        if (n == 0) break;
+        if (tid == 0) nrows_total += (unsigned long long)n;
+        mv_eval_dispatch<MT, NTW>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
+        if (w == 0 && phase != 3) {
+            const float vs = req_s ? mv_clamp(lds.sdfv[row_s], -tp.dist_clip, tp.dist_clip) : 0.f;
+            const float ve = req_e ? mv_clamp(lds.sdfv[row_e], -tp.dist_clip, tp.dist_clip) : 0.f;
+            bool end_iter = false;
+            if (phase == 0) { next_s = vs; next_e = ve; }
+            else if (phase == 1) { next_s = vs; next_e = ve; k = 0; }
+            else { if (req_s) next_s = vs; if (req_e) next_e = ve; k++; }
+            if (phase != 0) {
+                const bool np_s = next_s < 0.f, np_e = next_e < 0.f;
+                if (k < tp.line_step_iters && (np_s || np_e)) {                   // ray_tracing.py:173-191
+                    const float coef = (1.0f - tp.line_search_step) / (float)(1 << k);
+                    req_s = np_s; req_e = np_e;
+                    if (np_s) { acc_s -= coef * curr_s; ts = acc_s; }
+                    if (np_e) { acc_e += coef * curr_e; te = acc_e; }
+                    phase = 2;
+                } else {
+                    end_iter = true;
+                    unf_s = unf_s && (acc_s < acc_e);                           // ray_tracing.py:193-194
+                    unf_e = unf_e && (acc_s < acc_e);
+                }
+            }
+            if (phase == 0 || end_iter) {                                         // top of the while loop, ray_tracing.py:139-171
+                curr_s = unf_s ? next_s : 0.f;
+                curr_e = unf_e ? next_e : 0.f;
+                if (curr_s <= tp.thr) curr_s = 0.f;
+                if (curr_e <= tp.thr) curr_e = 0.f;
+                unf_s = unf_s && (curr_s > tp.thr);
+                unf_e = unf_e && (curr_e > tp.thr);
+                if ((!unf_s && !unf_e) || iters == tp.st_iters) {
+                    phase = 3; req_s = false; req_e = false;
+                } else {
+                    iters++;
+                    acc_s = acc_s + curr_s;
+                    acc_e = acc_e - curr_e;
+                    req_s = unf_s; req_e = unf_e; ts = acc_s; te = acc_e;
+                    phase = 1;
+                }
+            }
+        }
+        // (mv_sdf_eval_col0 ended with a barrier; wave 0 rewrites pts/s_n only after its own reads above)
+    }
+
+    if (tid == 0 && nrows_total) atomicAdd(&counters[MV_CNT_ROWS_SPHERE], nrows_total);
+    if (valid) {
+        bool net_mask = acc_s < acc_e;                                            // ray_tracing.py:41
+        const bool sampler = unf_s;                                               // ray_tracing.py:44
+        float dist = acc_s;
+        bool listed = false;
+        float zmin = acc_s, zmax = acc_e;
+        int kind = 0;
+        if (sampler) { listed = true; kind = MV_ITEM_SAMPLER | (om ? MV_ITEM_OM : 0); }
+        else if (training) {                                                      // ray_tracing.py:73-94
+            const bool in_mask = !net_mask && om;
+            const bool out_mask = !om;
+            if (in_mask || out_mask) {
+                if (!isect) {
+                    const float dot = (d[0] * c[0] + d[1] * c[1]) + d[2] * c[2];  // -bmm(rays, cam), plain order
+                    dist = -dot;
+                } else {
+                    listed = true; kind = MV_ITEM_MINSDF;
+                    zmin = (net_mask && out_mask) ? acc_s : t0;                   // min_dis override, ray_tracing.py:89
+                    zmax = t1;
+                }
+            }
+        }
+        o_mask[gid] = net_mask ? 1 : 0;
+        o_dists[gid] = dist;
+        o_points[3 * (size_t)gid + 0] = c[0] + dist * d[0];
+        o_points[3 * (size_t)gid + 1] = c[1] + dist * d[1];
+        o_points[3 * (size_t)gid + 2] = c[2] + dist * d[2];
+        if (listed) {
+            const unsigned long long idx = atomicAdd(&counters[MV_CNT_ITEMS], 1ull);
+            w_list[idx] = gid | (kind << 28);
+            w_zmin[gid] = zmin;
+            w_zmax[gid] = zmax;
+            atomicAdd(&counters[(kind & MV_ITEM_SAMPLER) ? MV_CNT_N_SAMPLER : MV_CNT_N_MINSDF], 1ull);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT, int NTW>
+__global__ __launch_bounds__(MV_THREADS) void k_ray_samples(MvNet net, MvTraceParams tp, const float* __restrict__ cam_loc,
+                                                           const float* __restrict__ dirs, int R, int P, int training, int RPW,
+                                                           const float* __restrict__ intervals, const float* __restrict__ steps,
+                                                           float* __restrict__ o_points, uint8_t* __restrict__ o_mask,
+                                                           float* __restrict__ o_dists, const float* __restrict__ w_zmin,
+                                                           const float* __restrict__ w_zmax, const int* __restrict__ w_list,
+                                                           unsigned long long* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * MT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n_steps = tp.n_steps;
+    const int n_items_total = (int)counters[MV_CNT_ITEMS];
+    const int item0 = blockIdx.x * RPW;
+    if (item0 >= n_items_total) return;
+    const int n_items = min(RPW, n_items_total - item0);
+    TraceLds lds = mv_carve(smem, ROWS, net.S, 3 + 6 * net.multires, RPW * n_steps);
+    int* s_n = lds.misc;
+    float* s_ray = (float*)(lds.misc + 4);              // per item: c[3], d[3], zmin, zmax  (8 floats)
+    int* s_kind = (int*)(s_ray + 8 * RPW);               // per item: gid | kind << 28
+
+    if (tid < n_items) {
+        const int e = w_list[item0 + tid];
+        const int gid = e & 0x0fffffff;
+        const int b = gid / P;
+        float* rr = s_ray + 8 * tid;
+        for (int i = 0; i < 3; ++i) { rr[i] = cam_loc[3 * b + i]; rr[3 + i] = dirs[3 * (size_t)gid + i]; }
+        rr[6] = w_zmin[gid]; rr[7] = w_zmax[gid];
+        s_kind[tid] = e;
+    }
+    __syncthreads();
+
+    // ---- n_steps samples per item, evaluated ROWS at a time ----
+    const int total = n_items * n_steps;
+    for (int base = 0; base < total; base += ROWS) {
+        const int nr = min(ROWS, total - base);
+        if (tid < nr) {
+            const int row = base + tid, it = row / n_steps, i = row - it * n_steps;
+            const float* rr = s_ray + 8 * it;
+            const bool samp = (s_kind[it] >> 28) & MV_ITEM_SAMPLER;
+            const float zmin = rr[6], zmax = rr[7];
+            const float z = samp ? (zmin + intervals[i] * (zmax - zmin))          // ray_tracing.py:208
+                                 : (steps[i] * (zmax - zmin) + zmin);              // ray_tracing.py:290
+            float* p = lds.pts + tid * 3;
+            p[0] = rr[0] + z * rr[3]; p[1] = rr[1] + z * rr[4]; p[2] = rr[2] + z * rr[5];
+        }
+        __syncthreads();
+        mv_eval_dispatch<MT, NTW>(net, (nr + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
+        if (tid < nr) lds.sv[base + tid] = lds.sdfv[tid];
+        __syncthreads();
+    }
+
+    // ---- per-item reduction (one thread per item), then secant rounds ----
+    bool do_secant = false;
+    float z_low = 0.f, z_high = 0.f, sdf_low = 0.f, sdf_high = 0.f, z_pred = 0.f;
+    float c[3] = {0, 0, 0}, d[3] = {0, 0, 0};
+    int gid = 0;
+    bool is_item = tid < n_items, net_surf = false, samp = false;
+    float dist = 0.f;
+    if (is_item) {
+        const float* rr = s_ray + 8 * tid;
+        for (int i = 0; i < 3; ++i) { c[i] = rr[i]; d[i] = rr[3 + i]; }
+        const int e = s_kind[tid];
+        gid = e & 0x0fffffff;
+        const int kind = e >> 28;
+        samp = kind & MV_ITEM_SAMPLER;
+        const bool om = kind & MV_ITEM_OM;
+        const float zmin = rr[6], zmax = rr[7];
+        const float* sv = lds.sv + tid * n_steps;
+        if (samp) {
+            int ind = 0; float best = INFINITY;                                   // argmin(sign(sdf) * [n..1]), first min
+            for (int i = 0; i < n_steps; ++i) {
+                const float v = sv[i];
+                const float sg = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+                const float tv = sg * (float)(n_steps - i);
+                if (tv < best) { best = tv; ind = i; }
+            }
+            dist = zmin + intervals[ind] * (zmax - zmin);
+            net_surf = sv[ind] < 0.f;
+            if (!(om && net_surf)) {                                              // P_out: argmin sdf, ray_tracing.py:229-235
+                int i2 = 0; float b2 = INFINITY;
+                for (int i = 0; i < n_steps; ++i) if (sv[i] < b2) { b2 = sv[i]; i2 = i; }
+                dist = zmin + intervals[i2] * (zmax - zmin);
+            }
+            do_secant = training ? (net_surf && om) : net_surf;                   // ray_tracing.py:242
+            if (do_secant) {
+                int lo = ind - 1; if (lo < 0) lo += n_steps;                      // negative index wraps
+                z_high = zmin + intervals[ind] * (zmax - zmin); sdf_high = sv[ind];
+                z_low = zmin + intervals[lo] * (zmax - zmin); sdf_low = sv[lo];
+                z_pred = -sdf_low * (z_high - z_low) / (sdf_high - sdf_low) + z_low;
+            }
+        } else {
+            int bi = 0; float bv = INFINITY;                                      // min over the shared random steps
+            for (int i = 0; i < n_steps; ++i) if (sv[i] < bv) { bv = sv[i]; bi = i; }
+            dist = steps[bi] * (zmax - zmin) + zmin;
+        }
+    }
+    unsigned long long sec_rows = 0;
+    for (int it = 0; it < tp.n_secant; ++it) {                                    // secant, ray_tracing.py:260-278
+        int row = 0;
+        if (w == 0) {
+            const unsigned long long m = __ballot(do_secant);
+            row = __popcll(m & ((1ull << lane) - 1ull));
+            if (do_secant) { float* p = lds.pts + row * 3; p[0] = c[0] + z_pred * d[0]; p[1] = c[1] + z_pred * d[1]; p[2] = c[2] + z_pred * d[2]; }
+            if (lane == 0) *s_n = __popcll(m);
+        }
+        __syncthreads();
+        const int n = *s_n;
+        if (n == 0) break;
+        sec_rows += (unsigned long long)n;
+        mv_eval_dispatch<MT, NTW>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
+        if (w == 0 && do_secant) {
+            const float sm = lds.sdfv[row];
+            if (sm > 0.f) { z_low = z_pred; sdf_low = sm; }
+            if (sm < 0.f) { z_high = z_pred; sdf_high = sm; }
+            z_pred = -sdf_low * (z_high - z_low) / (sdf_high - sdf_low) + z_low;
+        }
+    }
+    if (is_item) {
+        if (do_secant) dist = z_pred;
+        o_dists[gid] = dist;
+        o_points[3 * (size_t)gid + 0] = c[0] + dist * d[0];
+        o_points[3 * (size_t)gid + 1] = c[1] + dist * d[1];
+        o_points[3 * (size_t)gid + 2] = c[2] + dist * d[2];
+        if (samp) o_mask[gid] = net_surf ? 1 : 0;                                  // ray_tracing.py:237-239, 61
+    }
+    if (tid == 0) {
+        unsigned long long ns = 0, nm = 0;
+        for (int i = 0; i < n_items; ++i) { if ((s_kind[i] >> 28) & MV_ITEM_SAMPLER) ns++; else nm++; }
+        atomicAdd(&counters[MV_CNT_ROWS_SAMPLER], ns * (unsigned long long)n_steps);
+        atomicAdd(&counters[MV_CNT_ROWS_MINSDF], nm * (unsigned long long)n_steps);
+        if (sec_rows) atomicAdd(&counters[MV_CNT_ROWS_SECANT], sec_rows);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static size_t trace_lds_bytes(const MvNet& net, int MT, int sv_floats, int rpw) {
+    const int rows = 16 * MT, d0 = 3 + 6 * net.multires;
+    size_t f = (size_t)rows * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows + sv_floats;
+    return f * 4 + 16 + (size_t)rpw * (8 * 4 + 4) + 16;
+}
+
+template <int MT, int NTW>
+static hipError_t launch_trace(const MvNet& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, const uint8_t* om,
+                               int B, int P, int training, int rpw, const float* intervals, const float* steps, float* points,
+                               uint8_t* mask, float* dists, float* w_zmin, float* w_zmax, int* w_list, unsigned long long* counters,
+                               hipStream_t stream) {
+    const int R = B * P, NR = 8 * MT;
+    const size_t lds1 = trace_lds_bytes(net, MT, 0, 0), lds2 = trace_lds_bytes(net, MT, rpw * tp.n_steps, rpw);
+    hipError_t e;
+    e = hipFuncSetAttribute((const void*)k_sphere_trace<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_ray_samples<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_sphere_trace<MT, NTW>), dim3((R + NR - 1) / NR), dim3(MV_THREADS), lds1, stream, net, tp, cam_loc, dirs, om, R, P,
+                       training, points, mask, dists, w_zmin, w_zmax, w_list, counters);
+    hipLaunchKernelGGL((k_ray_samples<MT, NTW>), dim3((R + rpw - 1) / rpw), dim3(MV_THREADS), lds2, stream, net, tp, cam_loc, dirs, R, P,
+                       training, rpw, intervals, steps, points, mask, dists, w_zmin, w_zmax, w_list, counters);
+    return hipGetLastError();
+}
+
+hipError_t mv_trace_launch(const MvNet& net, const MvTraceParams& tp, int mt, const float* cam_loc, const float* dirs, const uint8_t* om,
+                           int B, int P, int training, int rpw, const float* intervals, const float* steps, float* points, uint8_t* mask,
+                           float* dists, float* w_zmin, float* w_zmax, int* w_list, unsigned long long* counters, hipStream_t stream) {
+    int maxnt = 0;
+    for (int l = 0; l < net.n_layers - 1; ++l) maxnt = net.L[l].NT > maxnt ? net.L[l].NT : maxnt;
+    const bool wide = maxnt > 16;                               // > 256 columns: 8 column tiles per wave, at most 2 row tiles
+    if (maxnt > 32) return hipErrorInvalidValue;
+#define MV_GO(MT_, NTW_) return launch_trace<MT_, NTW_>(net, tp, cam_loc, dirs, om, B, P, training, rpw, intervals, steps, points, mask, dists, \
+                                                        w_zmin, w_zmax, w_list, counters, stream)
+    if (wide) { if (mt >= 2) MV_GO(2, 8); MV_GO(1, 8); }
+    if (mt >= 4) MV_GO(4, 4);
+    if (mt >= 2) MV_GO(2, 4);
+    MV_GO(1, 4);
+#undef MV_GO
+}
+
+// =============================================================================================================
+#include "capi_util.h"
+extern "C" {
+
+size_t mvsdf_trace_workspace_bytes(int R) { return (size_t)(R > 0 ? R : 0) * 12 + 256; }
+
+int mvsdf_trace(const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
+                const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
+                float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
+                size_t workspace_bytes, int mt, int rpw, void* stream) {
+    MvNet net;
+    int rc = mv_make_net(desc, &net);
+    if (rc) return rc;
+    if (!tp || !cam_loc || !ray_dirs || !object_mask || !intervals || !points || !mask || !dists || !counters || !workspace)
+        return mv_fail(-1, "mvsdf_trace: null argument");
+    if (B <= 0 || P <= 0 || (long long)B * P >= (1 << 28)) return mv_fail(-1, "mvsdf_trace: B*P out of range");
+    if (training && !minsdf_steps) return mv_fail(-1, "mvsdf_trace: training needs minsdf_steps");
+    if (tp->n_steps < 2 || tp->n_steps > 1024 || tp->line_step_iters < 0 || tp->line_step_iters > 30)
+        return mv_fail(-1, "mvsdf_trace: tracer parameters out of range");
+    const int R = B * P;
+    if (workspace_bytes < mvsdf_trace_workspace_bytes(R)) return mv_fail(-1, "mvsdf_trace: workspace too small");
+    if (rpw < 1) rpw = 1;
+    if (rpw > 16) rpw = 16;
+    hipStream_t s = (hipStream_t)stream;
+    float* w_zmin = (float*)workspace;
+    float* w_zmax = w_zmin + R;
+    int* w_list = (int*)(w_zmax + R);
+    hipError_t e = hipMemsetAsync(counters, 0, 16 * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return mv_check(e, "mvsdf_trace: memset");
+    e = mv_trace_launch(net, *tp, mt, cam_loc, ray_dirs, object_mask, B, P, training, rpw, intervals,
+                        minsdf_steps ? minsdf_steps : intervals, points, mask, dists, w_zmin, w_zmax, w_list, counters, s);
+    return mv_check(e, "mvsdf_trace");
+}
+
+}  // extern "C"

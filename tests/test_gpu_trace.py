@@ -1,0 +1,101 @@
+"""GPU parity (pytest -m gpu): HIP kernels through the C ABI vs the CPU oracle, bit for bit, and vs the reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from helpers import sdf_packed_net, t, trace_params
+from mvsdf_amd import ops
+from mvsdf_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_det_math_bitwise(oracle):
+    rs = np.random.RandomState(0)
+    z = np.concatenate([rs.uniform(-0.4, 0.4, 200000), rs.uniform(-0.01, 0.01, 50000), [0.0, 0.2, 0.2000001, -1.0, 5.0]]).astype(np.float32)
+    y0, _ = ops.det_math(0, t(z))
+    assert np.array_equal(y0.cpu().numpy(), oracle.softplus100(z))
+    x = -rs.uniform(0, 110, 200000).astype(np.float32)
+    assert np.array_equal(ops.det_math(1, t(x))[0].cpu().numpy(), oracle.expneg(x))
+    u = rs.uniform(0, 1, 200000).astype(np.float32)
+    assert np.array_equal(ops.det_math(2, t(u))[0].cpu().numpy(), oracle.log1p01(u))
+    a = rs.uniform(-70, 70, 200000).astype(np.float32)
+    s, c = ops.det_math(3, t(a))
+    so, co = oracle.sincos(a)
+    assert np.array_equal(s.cpu().numpy(), so) and np.array_equal(c.cpu().numpy(), co)
+    v = rs.uniform(-50, 50, 200000).astype(np.float32)
+    d0, d1 = ops.det_math(4, t(v))
+    o0, o1 = oracle.div_consts(v)
+    assert np.array_equal(d0.cpu().numpy(), o0) and np.array_equal(d1.cpu().numpy(), o1)
+    # IEEE sqrt and division on the device (used by ray setup / secant)
+    q0, q1 = ops.det_math(5, t(v))
+    assert np.array_equal(q0.cpu().numpy(), np.sqrt(np.abs(v)))
+    assert np.array_equal(q1.cpu().numpy(), (np.float32(1.0) / v).astype(np.float32))
+
+
+@pytest.mark.parametrize('W', [64, 256])
+def test_fold_and_mlp_bitwise(oracle, W):
+    sd = synth.make_state_dict(W, 0)
+    onet = oracle.Net(sd)
+    net = sdf_packed_net(sd)
+    for l, L in enumerate(net.layers):
+        assert np.array_equal(L.w.cpu().numpy(), onet.W[l]), 'fold layer %d' % l
+    rs = np.random.RandomState(3)
+    x = rs.uniform(-1.2, 1.2, size=(1000, 3)).astype(np.float32)
+    ref = oracle.sdf_forward(onet, x, ncols=1)[:, 0]
+    for mt in (1, 2, 4):
+        y = ops.sdf_col0(net, t(x), mt=mt).cpu().numpy()
+        assert np.array_equal(y, ref), 'mt=%d max diff %g' % (mt, np.abs(y - ref).max())
+    g = golden('sdf_w%d' % W)
+    y = ops.sdf_col0(net, t(g['x'])).cpu().numpy()
+    np.testing.assert_allclose(y, g['out'][:, 0], rtol=1e-4, atol=3e-6)          # vs the PyTorch reference
+
+
+def test_camera_rays_bitwise(oracle):
+    g = golden('rays')
+    d, c = ops.camera_rays(t(g['uv']), t(g['pose']), t(g['intrinsics']))
+    do, co = oracle.camera_rays(g['uv'], g['pose'], g['intrinsics'])
+    assert np.array_equal(d.cpu().numpy(), do) and np.array_equal(c.cpu().numpy(), co)
+    assert np.abs(d.cpu().numpy() - g['ray_dirs']).max() <= 1.2e-7
+
+
+@pytest.mark.parametrize('W,mode,mt,rpw', [(64, 'eval', 2, 2), (64, 'train', 2, 3), (64, 'train', 4, 8), (64, 'train', 1, 1),
+                                          (256, 'eval', 2, 2), (256, 'train', 4, 4)])
+def test_trace_bit_exact_vs_oracle_and_golden(oracle, W, mode, mt, rpw):
+    g = golden('trace_mlp_w%d_%s' % (W, mode))
+    sd = synth.make_state_dict(W, int(g['seed']))
+    onet = oracle.Net(sd)
+    net = sdf_packed_net(sd)
+    training = mode == 'train'
+    om = np.ones(g['mask'].shape, bool)
+    tr = synth.model_conf(W)['ray_tracer']
+    p_o, m_o, d_o, rows_o = oracle.trace(onet, g['cam_loc'], g['ray_dirs'], om, training, g['minsdf_steps'], g['intervals'], **tr)
+    pts, mask, dists, cnt = ops.trace(net, t(g['cam_loc']), t(g['ray_dirs']), t(om), trace_params(W), training,
+                                      t(g['intervals']), t(g['minsdf_steps']), mt=mt, rpw=rpw)
+    torch.cuda.synchronize()
+    mask, dists, pts, cnt = mask.cpu().numpy(), dists.cpu().numpy(), pts.cpu().numpy(), cnt.cpu().numpy()
+    assert np.array_equal(mask, m_o)                      # HIP == oracle, bit for bit
+    assert np.array_equal(dists, d_o)
+    assert np.array_equal(pts, p_o)
+    assert np.array_equal(cnt[:4], rows_o)                # device-side row counters T = the rows the reference evaluates
+    assert np.array_equal(mask, g['mask'])                # hit masks bit-exact vs the PyTorch reference
+    hit = g['mask']
+    rel = np.abs(dists - g['dists']) / np.abs(g['dists']).clip(1e-6)
+    assert rel[hit].max() < 1e-4                          # depths within 1e-4 rel
+
+
+def test_trace_object_mask_paths(oracle):
+    """use_mask=True style batches (random object_mask) incl. out_mask / P_out branches, W=64."""
+    g = golden('trace_mlp_w64_train')
+    sd = synth.make_state_dict(64, int(g['seed']))
+    onet, net = oracle.Net(sd), sdf_packed_net(sd)
+    rs = np.random.RandomState(5)
+    om = rs.uniform(size=g['mask'].shape) < 0.7
+    tr = synth.model_conf(64)['ray_tracer']
+    for training in (False, True):
+        p_o, m_o, d_o, rows_o = oracle.trace(onet, g['cam_loc'], g['ray_dirs'], om, training, g['minsdf_steps'], g['intervals'], **tr)
+        pts, mask, dists, cnt = ops.trace(net, t(g['cam_loc']), t(g['ray_dirs']), t(om), trace_params(64), training,
+                                          t(g['intervals']), t(g['minsdf_steps']))
+        assert np.array_equal(mask.cpu().numpy(), m_o) and np.array_equal(dists.cpu().numpy(), d_o)
+        assert np.array_equal(pts.cpu().numpy(), p_o) and np.array_equal(cnt.cpu().numpy()[:4], rows_o)
