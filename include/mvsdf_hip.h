@@ -27,6 +27,7 @@ typedef struct {
     int N[MVSDF_MAX_LAYERS];            /* out features per Linear */
     const float* wp[MVSDF_MAX_LAYERS];  /* packed weights, mvsdf_packed_floats(N, K) floats */
     const float* bias[MVSDF_MAX_LAYERS];
+    const float* w[MVSDF_MAX_LAYERS];   /* folded weights, row-major [N][K] (only the last layer's row 0 is read: u_L = W_L[0,:]); may be NULL when no normals are needed */
     int skip_layer;                     /* layer whose input is cat([x, PE(x)])/sqrt(2) (idr.py:86-87), -1 if none */
     int multires;                       /* positional-encoding frequencies (embedder.py:38-50) */
 } MvsdfNetDesc;
@@ -61,8 +62,8 @@ const char* mvsdf_last_error(void);
 size_t mvsdf_packed_floats(int N, int K);
 
 /* weight_norm fold  w = v * (g / ||v||_row)  (idr.py:70-71, torch._weight_norm dim=0) + MFMA packing.
- * v[N][K], g[N] -> w[N][K] (row-major, may be NULL), wp (packed W, may be NULL), wpT (packed W^T for
- * contractions over the OUT dimension, may be NULL). */
+ * v[N][K], g[N] -> w[N][K] (row-major, required), wp (packed W, mvsdf_packed_floats(N, K) floats, may be NULL),
+ * wpT (packed W^T for contractions over the OUT dimension, mvsdf_packed_floats(K, N) floats, may be NULL). */
 int mvsdf_fold_pack(const float* v, const float* g, int N, int K, float* w, float* wp, float* wpT, void* stream);
 /* backward of the fold: dW[N][K] -> dv[N][K], dg[N]    */
 int mvsdf_fold_backward(const float* v, const float* g, const float* dW, int N, int K, float* dv, float* dg, void* stream);
@@ -86,6 +87,29 @@ int mvsdf_trace(const MvsdfNetDesc* net, const MvsdfTraceParams* tp, const float
                 const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
                 float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
                 size_t workspace_bytes, int mt, int rpw, void* stream);
+
+/* ---- differentiable SDF network: value + normal and their first/second-order backward ----
+ * Replaces ImplicitNetwork.forward / .gradient (idr.py:77-107) and autograd's (double) backward through them.
+ * net: packs of W_l; netT: packs of W_l^T (K and N swapped per layer).  x[M][3].  The first Mg rows also get the normal
+ * n = d out[:,0] / dx (NOT normalised, idr.py:327).  y[M][Nout], nrm[Mg][3].  ctx: mvsdf_sdf_ctx_floats(net, M, Mg) floats,
+ * kept by the caller until the backward.  */
+size_t mvsdf_sdf_ctx_floats(const MvsdfNetDesc* net, int M, int Mg);
+int mvsdf_sdf_forward(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, const float* x, int M, int Mg, float* y, float* nrm, float* ctx,
+                      void* stream);
+/* Backward over the FIRST Mb rows (Mb <= M; Mb <= Mg when dn is given): dy[Mb][Nout], dn[Mb][3] or NULL ->
+ * dW_cat (all layers, row-major [N][K], concatenated), db_cat, dx[Mb][3] or NULL.  ws: mvsdf_sdf_bwd_ws_floats(net, Mb) floats. */
+size_t mvsdf_sdf_bwd_ws_floats(const MvsdfNetDesc* net, int Mb);
+int mvsdf_sdf_backward(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, const float* x, int M, int Mg, int Mb, const float* dy,
+                       const float* dn, const float* ctx, float* dW_cat, float* db_cat, float* dx, float* ws, void* stream);
+
+/* ---- rendering network, mode 'idr' (idr.py:145-167): rgb = tanh(MLP(cat[points, PE(view), normals, feat])) ---- */
+size_t mvsdf_render_ctx_floats(const MvsdfNetDesc* net, int N);
+size_t mvsdf_render_bwd_ws_floats(const MvsdfNetDesc* net, int N);
+int mvsdf_render_forward(const MvsdfNetDesc* net, const float* points, const float* view, const float* normals, const float* feat,
+                         int ldfeat, int N, int multires_view, float* rgb, float* ctx, void* stream);
+/* din[N][K0]: adjoint of the concatenated input (points = [:,0:3], normals = [:,3+dv:6+dv], feat = [:,6+dv:], dv = 3+6*multires_view) */
+int mvsdf_render_backward(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, int N, const float* drgb, const float* ctx, float* dW_cat,
+                          float* db_cat, float* din, float* ws, void* stream);
 
 /* device self-test of the deterministic math: op 0 softplus100, 1 expneg, 2 log1p01, 3 sincos (y0=sin, y1=cos),
  * 4 div100 / div_sqrt2 (y0, y1), 5 sqrt / reciprocal (y0, y1). */

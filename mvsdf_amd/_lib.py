@@ -13,7 +13,7 @@ _lib = None
 
 class NetDesc(C.Structure):
     _fields_ = [('n_layers', C.c_int), ('K', C.c_int * MAX_LAYERS), ('N', C.c_int * MAX_LAYERS),
-                ('wp', C.c_void_p * MAX_LAYERS), ('bias', C.c_void_p * MAX_LAYERS),
+                ('wp', C.c_void_p * MAX_LAYERS), ('bias', C.c_void_p * MAX_LAYERS), ('w', C.c_void_p * MAX_LAYERS),
                 ('skip_layer', C.c_int), ('multires', C.c_int)]
 
 
@@ -39,6 +39,8 @@ def lib():
         L.mvsdf_packed_floats.argtypes = [C.c_int, C.c_int]
         L.mvsdf_trace_workspace_bytes.restype = C.c_size_t
         L.mvsdf_trace_workspace_bytes.argtypes = [C.c_int]
+        for fn in ('mvsdf_sdf_ctx_floats', 'mvsdf_sdf_bwd_ws_floats', 'mvsdf_render_ctx_floats', 'mvsdf_render_bwd_ws_floats'):
+            getattr(L, fn).restype = C.c_size_t
         for name in EXPORTS:
             getattr(L, name)
         _lib = L
@@ -49,6 +51,8 @@ def lib():
 EXPORTS = [
     'mvsdf_version', 'mvsdf_last_error', 'mvsdf_packed_floats', 'mvsdf_fold_pack', 'mvsdf_fold_backward',
     'mvsdf_sdf_col0', 'mvsdf_camera_rays', 'mvsdf_trace_workspace_bytes', 'mvsdf_trace', 'mvsdf_det_math',
+    'mvsdf_sdf_ctx_floats', 'mvsdf_sdf_forward', 'mvsdf_sdf_bwd_ws_floats', 'mvsdf_sdf_backward',
+    'mvsdf_render_ctx_floats', 'mvsdf_render_bwd_ws_floats', 'mvsdf_render_forward', 'mvsdf_render_backward',
 ]
 
 

@@ -18,8 +18,8 @@ __global__ void k_fold(const float* __restrict__ v, const float* __restrict__ g,
 // wp[ct][kb][lane][s] = W[ct*16 + (lane&15)][kb*16 + 4s + (lane>>4)];  transposed=1 packs W^T ([K][N] seen as out=K, in=N)
 __global__ void k_pack(const float* __restrict__ w, int N, int K, int transposed, float* __restrict__ wp) {
     const int No = transposed ? K : N, Ko = transposed ? N : K;
-    const int KB = mv_ceil16(Ko) / 16;
-    const size_t total = (size_t)mv_ceil16(No) * mv_ceil16(Ko);
+    const int KB = mv_kpad(Ko) / 16;
+    const size_t total = (size_t)mv_ceil16(No) * mv_kpad(Ko);
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int s = idx & 3, lane = (idx >> 2) & 63;
         const size_t blk = idx >> 8;

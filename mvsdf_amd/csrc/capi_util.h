@@ -6,7 +6,9 @@
 
 int mv_fail(int code, const char* msg);          // records msg, returns code
 int mv_check(hipError_t e, const char* where);   // 0 on success
-int mv_make_net(const MvsdfNetDesc* d, MvNet* net);
+// mode 0: SDF net (PE input + skip chaining checked); 1: plain chain; 2: transposed packs (no chaining check)
+int mv_make_net_mode(const MvsdfNetDesc* d, MvNet* net, int mode);
+static inline int mv_make_net(const MvsdfNetDesc* d, MvNet* net) { return mv_make_net_mode(d, net, 0); }
 
 static inline bool mv_wide(const MvNet& net) {
     int maxnt = 0;

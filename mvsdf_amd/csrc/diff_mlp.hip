@@ -1,0 +1,483 @@
+// diff_mlp.hip -- differentiable passes of the SDF network (value + normal, first/second-order backward) and of the
+// rendering network, orchestrated on one stream from C++ (no host sync, no allocation).  Math: SURVEY.md App. E.
+// Replaces ImplicitNetwork.forward/.gradient (idr.py:77-107), RenderingNetwork.forward (idr.py:145-167) and what
+// torch.autograd does behind loss.backward() for both (idr_train.py:287).
+#include "layer_kernels.h"
+#include "capi_util.h"
+
+// ------------------------------------------------------------------------------------------------ small kernels
+// H0[row][0..d0) = PE(x[row]); H0[row][d0..ld) = 0       (embedder.py:10-36)
+__global__ void k_pe_global(const float* __restrict__ x, int M, int multires, float* __restrict__ H0, int ld) {
+    const int T = 3 * multires + 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * T) return;
+    const int row = idx / T, j = idx - row * T, d0 = 3 + 6 * multires;
+    const float* xr = x + (size_t)row * 3;
+    float* h = H0 + (size_t)row * ld;
+    if (j < 3 * multires) {
+        const int m = j / 3, c = j - 3 * m;
+        float s, co;
+        dm_sincos(xr[c] * (float)(1 << m), &s, &co);
+        h[3 + 6 * m + c] = s;
+        h[6 + 6 * m + c] = co;
+    } else {
+        for (int c = 0; c < 3; ++c) h[c] = xr[c];
+        for (int c = d0; c < ld; ++c) h[c] = 0.0f;
+    }
+}
+
+// n = J0^T g0   (App. E forward normal, last step)
+__global__ void k_pe_normal(const float* __restrict__ H0, int ldh, const float* __restrict__ G0, int ldg, int Mg, int multires,
+                            float* __restrict__ n) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Mg * 3) return;
+    const int row = idx / 3, c = idx - 3 * row;
+    const float* h = H0 + (size_t)row * ldh;
+    const float* g = G0 + (size_t)row * ldg;
+    float v = g[c];
+    for (int m = 0; m < multires; ++m) {
+        const float f = (float)(1 << m);
+        v += f * (h[6 + 6 * m + c] * g[3 + 6 * m + c] - h[3 + 6 * m + c] * g[6 + 6 * m + c]);
+    }
+    n[idx] = v;
+}
+
+// gbar0 = J0 nbar  -> VB0[row][0..d0) (pad 0), and the PE tail of the skip layer's vbar: VBs[row][tail0 + j] = gbar0[j]/sqrt(2)
+__global__ void k_pe_normal_bwd(const float* __restrict__ H0, int ldh, const float* __restrict__ dn, int Mb, int multires,
+                                float* __restrict__ VB0, int ld0, float* __restrict__ VBs, int lds_, int tail0) {
+    const int T = 3 * multires + 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Mb * T) return;
+    const int row = idx / T, j = idx - row * T, d0 = 3 + 6 * multires;
+    const float* h = H0 + (size_t)row * ldh;
+    const float* nb = dn + (size_t)row * 3;
+    float* o = VB0 + (size_t)row * ld0;
+    float* t = VBs ? VBs + (size_t)row * lds_ + tail0 : nullptr;
+    if (j < 3 * multires) {
+        const int m = j / 3, c = j - 3 * m;
+        const float f = (float)(1 << m);
+        const float a = f * h[6 + 6 * m + c] * nb[c], b = -f * h[3 + 6 * m + c] * nb[c];
+        o[3 + 6 * m + c] = a;
+        o[6 + 6 * m + c] = b;
+        if (t) { t[3 + 6 * m + c] = dm_div_sqrt2(a); t[6 + 6 * m + c] = dm_div_sqrt2(b); }
+    } else {
+        for (int c = 0; c < 3; ++c) { o[c] = nb[c]; if (t) t[c] = dm_div_sqrt2(nb[c]); }
+        for (int c = d0; c < ld0; ++c) o[c] = 0.0f;
+    }
+}
+
+// xbar = J0^T hbar0 + sum_k PE''_k g0[k] nbar[c(k)]        (App. E.3)
+__global__ void k_pe_input_bwd(const float* __restrict__ H0, int ldh, const float* __restrict__ H0B, int ldb, const float* __restrict__ G0,
+                               int ldg, const float* __restrict__ dn, int Mb, int multires, float* __restrict__ dx) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Mb * 3) return;
+    const int row = idx / 3, c = idx - 3 * row;
+    const float* h = H0 + (size_t)row * ldh;
+    const float* hb = H0B + (size_t)row * ldb;
+    float v = hb[c];
+    float second = 0.0f;
+    for (int m = 0; m < multires; ++m) {
+        const float f = (float)(1 << m);
+        const float s = h[3 + 6 * m + c], co = h[6 + 6 * m + c];
+        v += f * (co * hb[3 + 6 * m + c] - s * hb[6 + 6 * m + c]);
+        if (dn) {
+            const float* g = G0 + (size_t)row * ldg;
+            second -= f * f * (s * g[3 + 6 * m + c] + co * g[6 + 6 * m + c]);
+        }
+    }
+    if (dn) v += second * dn[(size_t)row * 3 + c];
+    dx[idx] = v;
+}
+
+__global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+// ------------------------------------------------------------------------------------------------ launch helpers
+template <int PRO, int EPI>
+static hipError_t launch_layer(LayerArgs& a, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    // 32 rows per workgroup (MT = 2): enough workgroups at a few thousand rows, weights reused by two row tiles
+    constexpr int MT = 2;
+    const size_t lds = (size_t)16 * MT * a.S * sizeof(float);
+    static size_t lds_set = 0;                                 // per instantiation: raise the dynamic-LDS cap once per size
+    if (lds > 48 * 1024 && lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_layer<PRO, EPI, MT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL((k_layer<PRO, EPI, MT, 4>), dim3((a.M + 16 * MT - 1) / (16 * MT)), dim3(MV_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+static LayerArgs base_args(const MvLayer& L, int S, int M) {
+    LayerArgs a;
+    memset(&a, 0, sizeof(a));
+    a.L = L; a.S = S; a.M = M;
+    return a;
+}
+
+static int stride_for(const MvNet& a, const MvNet& b) { return a.S > b.S ? a.S : b.S; }
+
+// layout of the forward context / backward workspace (floats)
+struct SdfLayout {
+    int nl, d0, ld0;                 // layers, PE width, padded PE row
+    size_t H0, A[MV_MAXL], Z[MV_MAXL], U[MV_MAXL], E, G0, total;
+};
+static SdfLayout sdf_ctx_layout(const MvNet& net, int M, int Mg) {
+    SdfLayout o;
+    memset(&o, 0, sizeof(o));
+    o.nl = net.n_layers; o.d0 = 3 + 6 * net.multires; o.ld0 = (o.d0 + 3) & ~3;
+    size_t p = 0;
+    o.H0 = p; p += (size_t)M * o.ld0;
+    for (int l = 1; l < o.nl; ++l) { o.A[l] = p; p += (size_t)M * net.L[l].K; }
+    for (int l = 0; l < o.nl - 1; ++l) { o.Z[l] = p; p += (size_t)M * net.L[l].N; }
+    for (int l = 1; l < o.nl - 1; ++l) { o.U[l] = p; p += (size_t)Mg * net.L[l - 1].N; }   // u_l, width out_{l-1}
+    o.E = p; p += (size_t)Mg * o.ld0;
+    o.G0 = p; p += (size_t)Mg * o.ld0;
+    o.total = p;
+    return o;
+}
+struct SdfBwdLayout {
+    size_t VB[MV_MAXL], ZB2[MV_MAXL], ZB[MV_MAXL], HB[2], H0B, slabA, slabB, bslab, total;
+    int nchunks, chunk;
+    size_t maxnk;
+};
+static SdfBwdLayout sdf_bwd_layout(const MvNet& net, int Mb) {
+    SdfBwdLayout o;
+    memset(&o, 0, sizeof(o));
+    const int nl = net.n_layers, ld0 = ((3 + 6 * net.multires) + 3) & ~3;
+    size_t p = 0;
+    int maxw = 0;
+    for (int l = 0; l < nl; ++l) { maxw = net.L[l].K > maxw ? net.L[l].K : maxw; maxw = net.L[l].N > maxw ? net.L[l].N : maxw; }
+    for (int l = 0; l < nl; ++l) { o.VB[l] = p; p += (size_t)Mb * (l == 0 ? ld0 : net.L[l].K); }
+    for (int l = 0; l < nl - 1; ++l) { o.ZB2[l] = p; p += (size_t)Mb * net.L[l].N; }
+    for (int l = 0; l < nl - 1; ++l) { o.ZB[l] = p; p += (size_t)Mb * net.L[l].N; }
+    o.HB[0] = p; p += (size_t)Mb * maxw;
+    o.HB[1] = p; p += (size_t)Mb * maxw;
+    o.H0B = p; p += (size_t)Mb * ld0;
+    o.chunk = 512;
+    o.nchunks = (Mb + o.chunk - 1) / o.chunk;
+    if (o.nchunks < 1) o.nchunks = 1;
+    o.maxnk = 0;
+    for (int l = 0; l < nl; ++l) { const size_t nk = (size_t)net.L[l].N * net.L[l].K; o.maxnk = nk > o.maxnk ? nk : o.maxnk; }
+    o.slabA = p; p += (size_t)o.nchunks * o.maxnk;
+    o.slabB = p; p += (size_t)o.nchunks * o.maxnk;
+    o.bslab = p; p += (size_t)o.nchunks * (maxw + 16);
+    o.total = p;
+    return o;
+}
+
+template <int PMODE>
+static hipError_t launch_wgrad(const float* P, int ldp, const float* U, int ldu, const float* bcast, const float* Q, int ldq, int M, int No,
+                               int Ki, int chunk, int nchunks, float* slab, float* bslab, hipStream_t s) {
+    WgradArgs a;
+    a.P = P; a.ldp = ldp; a.U = U; a.ldu = ldu; a.bcast = bcast; a.Q = Q; a.ldq = ldq; a.M = M; a.No = No; a.Ki = Ki;
+    a.chunk = chunk; a.slab = slab; a.bslab = bslab;
+    hipLaunchKernelGGL((k_wgrad<PMODE>), dim3((Ki + 63) / 64, (No + 63) / 64, nchunks), dim3(MV_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+static hipError_t launch_reduce(const float* sa, const float* sb, int nchunks, size_t n, float* out, hipStream_t s) {
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, s, sa, sb, nchunks, n, out, 0);
+    return hipGetLastError();
+}
+
+#define MV_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mv_check(e_, #expr); } while (0)
+
+extern "C" {
+
+size_t mvsdf_sdf_ctx_floats(const MvsdfNetDesc* d, int M, int Mg) {
+    MvNet net;
+    if (mv_make_net(d, &net)) return 0;
+    return sdf_ctx_layout(net, M, Mg).total;
+}
+size_t mvsdf_sdf_bwd_ws_floats(const MvsdfNetDesc* d, int Mb) {
+    MvNet net;
+    if (mv_make_net(d, &net)) return 0;
+    return sdf_bwd_layout(net, Mb).total;
+}
+
+int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float* x, int M, int Mg, float* y, float* nrm, float* ctx,
+                      void* stream) {
+    MvNet net, netT;
+    int rc = mv_make_net(d, &net);
+    if (rc) return rc;
+    if (!x || !y || !ctx || M <= 0 || Mg < 0 || Mg > M) return mv_fail(-1, "mvsdf_sdf_forward: bad arguments");
+    if (Mg > 0) {
+        rc = mv_make_net_mode(dT, &netT, 2);
+        if (rc) return rc;
+        if (!nrm || !d->w[d->n_layers - 1]) return mv_fail(-1, "mvsdf_sdf_forward: normals requested but nrm / row-major last-layer weights missing");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const SdfLayout lo = sdf_ctx_layout(net, M, Mg);
+    const int nl = lo.nl, S = Mg > 0 ? stride_for(net, netT) : net.S;
+    float* H0 = ctx + lo.H0;
+    hipLaunchKernelGGL(k_pe_global, dim3((M * (3 * net.multires + 1) + 255) / 256), dim3(256), 0, s, x, M, net.multires, H0, lo.ld0);
+    for (int l = 0; l < nl - 1; ++l) {                                            // hidden layers (idr.py:82-92)
+        LayerArgs a = base_args(net.L[l], S, M);
+        a.A = l == 0 ? H0 : ctx + lo.A[l]; a.lda = l == 0 ? lo.ld0 : net.L[l].K;
+        a.out1 = ctx + lo.Z[l]; a.ld1 = net.L[l].N;
+        a.out0 = ctx + lo.A[l + 1]; a.ld0 = net.L[l + 1].K;
+        a.skip_next = (l + 1 == net.skip_layer); a.d0 = lo.d0; a.pe = H0; a.ldpe = lo.ld0;
+        MV_TRY((launch_layer<PRO_PLAIN, EPI_SOFTPLUS>(a, s)));
+    }
+    {
+        LayerArgs a = base_args(net.L[nl - 1], S, M);
+        a.A = ctx + lo.A[nl - 1]; a.lda = net.L[nl - 1].K; a.out0 = y; a.ld0 = net.L[nl - 1].N;
+        MV_TRY((launch_layer<PRO_PLAIN, EPI_BIAS>(a, s)));
+    }
+    if (Mg > 0) {                                                                 // normal = VJP of output 0 (idr.py:96-107)
+        const float* w8 = d->w[nl - 1];                                           // row 0 of the last layer = u_{nl-1}
+        for (int l = nl - 2; l >= 0; --l) {
+            LayerArgs a = base_args(netT.L[l], S, Mg);
+            a.Z = ctx + lo.Z[l]; a.ldz = net.L[l].N;
+            const bool top = (l == nl - 2);
+            if (top) a.bcast = w8; else { a.U = ctx + lo.U[l + 1]; a.ldu = net.L[l].N; }
+            if (l == net.skip_layer) {
+                a.csplit = net.L[l].K - lo.d0; a.scale_sqrt2 = 1;
+                a.out0 = ctx + lo.U[l]; a.ld0 = net.L[l - 1].N;
+                a.out1 = ctx + lo.E; a.ld1 = lo.ld0;
+            } else if (l == 0) {
+                a.csplit = net.L[0].K;
+                if (net.skip_layer > 0) { a.add = ctx + lo.E; a.ldadd = lo.ld0; }
+                a.out0 = ctx + lo.G0; a.ld0 = lo.ld0;
+            } else {
+                a.csplit = net.L[l].K;
+                a.out0 = ctx + lo.U[l]; a.ld0 = net.L[l - 1].N;
+            }
+            if (top) MV_TRY((launch_layer<PRO_SIG_BCAST, EPI_SPLIT>(a, s)));
+            else MV_TRY((launch_layer<PRO_SIG_MUL, EPI_SPLIT>(a, s)));
+        }
+        hipLaunchKernelGGL(k_pe_normal, dim3((Mg * 3 + 255) / 256), dim3(256), 0, s, H0, lo.ld0, ctx + lo.G0, lo.ld0, Mg, net.multires, nrm);
+    }
+    return mv_check(hipGetLastError(), "mvsdf_sdf_forward");
+}
+
+/* Backward over the first Mb rows of a forward context made with (M, Mg).  dy[Mb][Nout] (required), dn[Mb][3] or NULL
+ * (then Mb may exceed Mg).  Outputs: dW_cat / db_cat (all layers concatenated, row-major [N][K]), dx[Mb][3] or NULL. */
+int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float* x, int M, int Mg, int Mb, const float* dy,
+                       const float* dn, const float* ctx, float* dW_cat, float* db_cat, float* dx, float* ws, void* stream) {
+    MvNet net, netT;
+    int rc = mv_make_net(d, &net);
+    if (rc) return rc;
+    rc = mv_make_net_mode(dT, &netT, 2);
+    if (rc) return rc;
+    if (!x || !dy || !ctx || !dW_cat || !db_cat || !ws || Mb <= 0 || Mb > M || (dn && Mb > Mg))
+        return mv_fail(-1, "mvsdf_sdf_backward: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const SdfLayout lo = sdf_ctx_layout(net, M, Mg);
+    const SdfBwdLayout bl = sdf_bwd_layout(net, Mb);
+    const int nl = lo.nl, S = stride_for(net, netT), sk = net.skip_layer;
+    const float* H0 = ctx + lo.H0;
+    const float* w8 = d->w[nl - 1];
+    if (dn && !w8) return mv_fail(-1, "mvsdf_sdf_backward: row-major last-layer weights missing");
+    auto Aof = [&](int l) { return l == 0 ? H0 : ctx + lo.A[l]; };
+    auto ldA = [&](int l) { return l == 0 ? lo.ld0 : net.L[l].K; };
+    // ---- E.1: adjoint of the normal chain (ascending) ----
+    if (dn) {
+        hipLaunchKernelGGL(k_pe_normal_bwd, dim3((Mb * (3 * net.multires + 1) + 255) / 256), dim3(256), 0, s, H0, lo.ld0, dn, Mb,
+                           net.multires, ws + bl.VB[0], lo.ld0, sk > 0 ? ws + bl.VB[sk] : nullptr, sk > 0 ? net.L[sk].K : 0,
+                           sk > 0 ? net.L[sk].K - lo.d0 : 0);
+        for (int l = 0; l < nl - 1; ++l) {
+            LayerArgs a = base_args(net.L[l], S, Mb);
+            a.A = ws + bl.VB[l]; a.lda = ldA(l);
+            a.Z = ctx + lo.Z[l]; a.ldz = net.L[l].N;
+            if (l == nl - 2) a.bcast = w8; else { a.U = ctx + lo.U[l + 1]; a.ldu = net.L[l].N; }
+            a.out0 = ws + bl.VB[l + 1]; a.ld0 = net.L[l + 1].K;
+            a.out1 = ws + bl.ZB2[l]; a.ld1 = net.L[l].N;
+            a.skip_next = (l + 1 == sk);
+            MV_TRY((launch_layer<PRO_PLAIN, EPI_SBAR>(a, s)));
+        }
+    }
+    // ---- E.2: adjoint of the value chain (descending) ----
+    int cur = 0;
+    {
+        LayerArgs a = base_args(netT.L[nl - 1], S, Mb);
+        a.A = dy; a.lda = net.L[nl - 1].N;
+        a.csplit = net.L[nl - 1].K; a.out0 = ws + bl.HB[cur]; a.ld0 = net.L[nl - 1].K;
+        MV_TRY((launch_layer<PRO_PLAIN, EPI_SPLIT>(a, s)));
+    }
+    if (sk <= 0) MV_TRY(hipMemsetAsync(ws + bl.H0B, 0, (size_t)Mb * lo.ld0 * sizeof(float), s));
+    for (int l = nl - 2; l >= 0; --l) {
+        LayerArgs a = base_args(netT.L[l], S, Mb);
+        a.Z = ctx + lo.Z[l]; a.ldz = net.L[l].N;
+        a.U = ws + bl.HB[cur]; a.ldu = net.L[l].N;
+        if (dn) { a.A = ws + bl.ZB2[l]; a.lda = net.L[l].N; a.Mg = Mb; }
+        a.out2 = ws + bl.ZB[l]; a.ld2 = net.L[l].N;
+        if (l == sk) {
+            a.csplit = net.L[l].K - lo.d0; a.scale_sqrt2 = 1;
+            a.out0 = ws + bl.HB[cur ^ 1]; a.ld0 = net.L[l - 1].N;
+            a.out1 = ws + bl.H0B; a.ld1 = lo.ld0;
+        } else if (l == 0) {
+            a.csplit = net.L[0].K;
+            a.add = ws + bl.H0B; a.ldadd = lo.ld0;
+            a.out0 = ws + bl.H0B; a.ld0 = lo.ld0;
+        } else {
+            a.csplit = net.L[l].K;
+            a.out0 = ws + bl.HB[cur ^ 1]; a.ld0 = net.L[l - 1].N;
+        }
+        MV_TRY((launch_layer<PRO_ZBAR, EPI_SPLIT>(a, s)));
+        cur ^= 1;
+    }
+    // ---- weight / bias gradients: W_l += zbar_l^T a_l (+ s_l^T vbar_l)  ----
+    size_t woff = 0, boff = 0;
+    for (int l = 0; l < nl; ++l) {
+        const int No = net.L[l].N, Ki = net.L[l].K;
+        const bool last = (l == nl - 1);
+        const float* P = last ? dy : ws + bl.ZB[l];
+        MV_TRY((launch_wgrad<0>(P, No, nullptr, 0, nullptr, Aof(l), ldA(l), Mb, No, Ki, bl.chunk, bl.nchunks, ws + bl.slabA, ws + bl.bslab, s)));
+        const float* sb = nullptr;
+        if (dn && !last) {
+            if (l == nl - 2) MV_TRY((launch_wgrad<2>(ctx + lo.Z[l], No, nullptr, 0, w8, ws + bl.VB[l], ldA(l), Mb, No, Ki, bl.chunk, bl.nchunks, ws + bl.slabB, nullptr, s)));
+            else MV_TRY((launch_wgrad<1>(ctx + lo.Z[l], No, ctx + lo.U[l + 1], No, nullptr, ws + bl.VB[l], ldA(l), Mb, No, Ki, bl.chunk, bl.nchunks, ws + bl.slabB, nullptr, s)));
+            sb = ws + bl.slabB;
+        }
+        MV_TRY(launch_reduce(ws + bl.slabA, sb, bl.nchunks, (size_t)No * Ki, dW_cat + woff, s));
+        MV_TRY(launch_reduce(ws + bl.bslab, nullptr, bl.nchunks, (size_t)No, db_cat + boff, s));
+        if (last && dn) {                                                          // W_last[0, :] += sum_rows ubar_last   (E.1 end)
+            hipLaunchKernelGGL(k_colsum, dim3((Ki + 63) / 64), dim3(256), 0, s, ws + bl.VB[l], Ki, Mb, Ki, dW_cat + woff, 1);
+        }
+        woff += (size_t)No * Ki; boff += No;
+    }
+    // ---- E.3: input adjoint ----
+    if (dx)
+        hipLaunchKernelGGL(k_pe_input_bwd, dim3((Mb * 3 + 255) / 256), dim3(256), 0, s, H0, lo.ld0, ws + bl.H0B, lo.ld0, ctx + lo.G0, lo.ld0,
+                           dn, Mb, net.multires, dx);
+    return mv_check(hipGetLastError(), "mvsdf_sdf_backward");
+}
+
+}  // extern "C"
+
+// ================================================================================================ rendering network
+struct RenderLayout { size_t A[MV_MAXL], rgb, total; };
+static RenderLayout render_layout(const MvNet& net, int N) {
+    RenderLayout o;
+    memset(&o, 0, sizeof(o));
+    size_t p = 0;
+    for (int l = 0; l < net.n_layers; ++l) { o.A[l] = p; p += (size_t)N * net.L[l].K; }
+    o.rgb = p; p += (size_t)N * net.L[net.n_layers - 1].N;
+    o.total = p;
+    return o;
+}
+struct RenderBwdLayout { size_t ZB[MV_MAXL], slab, bslab, total; int chunk, nchunks; };
+static RenderBwdLayout render_bwd_layout(const MvNet& net, int N) {
+    RenderBwdLayout o;
+    memset(&o, 0, sizeof(o));
+    size_t p = 0, maxnk = 0;
+    int maxw = 0;
+    for (int l = 0; l < net.n_layers; ++l) {
+        o.ZB[l] = p; p += (size_t)N * net.L[l].N;
+        const size_t nk = (size_t)net.L[l].N * net.L[l].K;
+        maxnk = nk > maxnk ? nk : maxnk;
+        maxw = net.L[l].N > maxw ? net.L[l].N : maxw;
+    }
+    o.chunk = 512; o.nchunks = (N + 511) / 512; if (o.nchunks < 1) o.nchunks = 1;
+    o.slab = p; p += (size_t)o.nchunks * maxnk;
+    o.bslab = p; p += (size_t)o.nchunks * (maxw + 16);
+    o.total = p;
+    return o;
+}
+
+// A0[row] = cat[points(3), view(3), sin/cos(2^m view) m<mv, normals(3), feat(F)]   (idr.py:146-150, mode 'idr')
+__global__ void k_render_input(const float* __restrict__ points, const float* __restrict__ view, const float* __restrict__ normals,
+                               const float* __restrict__ feat, int ldfeat, int N, int mv, int K0, float* __restrict__ A0) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * K0) return;
+    const int row = (int)(idx / K0), k = (int)(idx - (size_t)row * K0), dv = 3 + 6 * mv;
+    float v;
+    if (k < 3) v = points[(size_t)row * 3 + k];
+    else if (k < 3 + dv) {
+        const int j = k - 3;
+        if (j < 3) v = view[(size_t)row * 3 + j];
+        else {
+            const int jj = j - 3, m = jj / 6, rem = jj - 6 * m, c = rem % 3;
+            float sn, co;
+            dm_sincos(view[(size_t)row * 3 + c] * (float)(1 << m), &sn, &co);
+            v = rem < 3 ? sn : co;
+        }
+    } else if (k < 6 + dv) v = normals[(size_t)row * 3 + (k - 3 - dv)];
+    else v = feat[(size_t)row * ldfeat + (k - 6 - dv)];
+    A0[idx] = v;
+}
+
+extern "C" {
+
+size_t mvsdf_render_ctx_floats(const MvsdfNetDesc* d, int N) {
+    MvNet net;
+    if (mv_make_net_mode(d, &net, 1)) return 0;
+    return render_layout(net, N).total;
+}
+size_t mvsdf_render_bwd_ws_floats(const MvsdfNetDesc* d, int N) {
+    MvNet net;
+    if (mv_make_net_mode(d, &net, 1)) return 0;
+    return render_bwd_layout(net, N).total;
+}
+
+/* RenderingNetwork.forward, mode 'idr' (idr.py:145-167): rgb = tanh(MLP(cat[points, PE(view), normals, feat])). */
+int mvsdf_render_forward(const MvsdfNetDesc* d, const float* points, const float* view, const float* normals, const float* feat,
+                         int ldfeat, int N, int multires_view, float* rgb, float* ctx, void* stream) {
+    MvNet net;
+    int rc = mv_make_net_mode(d, &net, 1);
+    if (rc) return rc;
+    if (!points || !view || !normals || !feat || !rgb || !ctx || N <= 0) return mv_fail(-1, "mvsdf_render_forward: bad arguments");
+    const int nl = net.n_layers, dv = 3 + 6 * multires_view, K0 = net.L[0].K;
+    if (K0 <= 6 + dv) return mv_fail(-1, "mvsdf_render_forward: first layer too narrow for cat[points, PE(view), normals, feat]");
+    hipStream_t s = (hipStream_t)stream;
+    const RenderLayout lo = render_layout(net, N);
+    const size_t tot = (size_t)N * K0;
+    hipLaunchKernelGGL(k_render_input, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, points, view, normals, feat, ldfeat, N,
+                       multires_view, K0, ctx + lo.A[0]);
+    for (int l = 0; l < nl; ++l) {
+        LayerArgs a = base_args(net.L[l], net.S, N);
+        const bool last = (l == nl - 1);
+        a.A = ctx + lo.A[l]; a.lda = net.L[l].K;
+        a.out0 = last ? ctx + lo.rgb : ctx + lo.A[l + 1]; a.ld0 = net.L[l].N;
+        if (last) MV_TRY((launch_layer<PRO_PLAIN, EPI_TANH>(a, s))); else MV_TRY((launch_layer<PRO_PLAIN, EPI_RELU>(a, s)));
+    }
+    MV_TRY(hipMemcpyAsync(rgb, ctx + lo.rgb, (size_t)N * net.L[nl - 1].N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return mv_check(hipGetLastError(), "mvsdf_render_forward");
+}
+
+/* Backward: drgb[N][3] -> dW_cat, db_cat, din[N][K0] (adjoint of the concatenated input; the caller slices
+ * points = [:, 0:3], normals = [:, 3+dv : 6+dv], feat = [:, 6+dv :]). */
+int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, const float* drgb, const float* ctx, float* dW_cat,
+                          float* db_cat, float* din, float* ws, void* stream) {
+    MvNet net, netT;
+    int rc = mv_make_net_mode(d, &net, 1);
+    if (rc) return rc;
+    rc = mv_make_net_mode(dT, &netT, 2);
+    if (rc) return rc;
+    if (!drgb || !ctx || !dW_cat || !db_cat || !din || !ws || N <= 0) return mv_fail(-1, "mvsdf_render_backward: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int nl = net.n_layers, S = stride_for(net, netT);
+    const RenderLayout lo = render_layout(net, N);
+    const RenderBwdLayout bl = render_bwd_layout(net, N);
+    for (int l = nl - 1; l >= 0; --l) {                      // abar_l = zbar_l W_l ; zbar_{l-1} = abar_l . relu'(z_{l-1})
+        LayerArgs a = base_args(netT.L[l], S, N);
+        const bool last = (l == nl - 1);
+        if (last) { a.A = drgb; a.lda = net.L[l].N; a.U = ctx + lo.rgb; a.ldu = net.L[l].N; a.out2 = ws + bl.ZB[l]; a.ld2 = net.L[l].N; }
+        else { a.A = ws + bl.ZB[l]; a.lda = net.L[l].N; }
+        if (l > 0) {
+            a.add = ctx + lo.A[l]; a.ldadd = net.L[l].K;     // relu mask: stored post-activation > 0
+            a.out0 = ws + bl.ZB[l - 1]; a.ld0 = net.L[l - 1].N;
+            if (last) MV_TRY((launch_layer<PRO_TANH_BWD, EPI_RELU_MASK>(a, s))); else MV_TRY((launch_layer<PRO_PLAIN, EPI_RELU_MASK>(a, s)));
+        } else {
+            a.csplit = net.L[0].K; a.out0 = din; a.ld0 = net.L[0].K;
+            if (last) MV_TRY((launch_layer<PRO_TANH_BWD, EPI_SPLIT>(a, s))); else MV_TRY((launch_layer<PRO_PLAIN, EPI_SPLIT>(a, s)));
+        }
+    }
+    size_t woff = 0, boff = 0;
+    for (int l = 0; l < nl; ++l) {
+        const int No = net.L[l].N, Ki = net.L[l].K;
+        MV_TRY((launch_wgrad<0>(ws + bl.ZB[l], No, nullptr, 0, nullptr, ctx + lo.A[l], Ki, N, No, Ki, bl.chunk, bl.nchunks, ws + bl.slab,
+                                ws + bl.bslab, s)));
+        MV_TRY(launch_reduce(ws + bl.slab, nullptr, bl.nchunks, (size_t)No * Ki, dW_cat + woff, s));
+        MV_TRY(launch_reduce(ws + bl.bslab, nullptr, bl.nchunks, (size_t)No, db_cat + boff, s));
+        woff += (size_t)No * Ki; boff += No;
+    }
+    return mv_check(hipGetLastError(), "mvsdf_render_backward");
+}
+
+}  // extern "C"

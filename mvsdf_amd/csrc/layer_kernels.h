@@ -1,0 +1,251 @@
+// layer_kernels.h -- the differentiable MLP passes as per-layer MFMA kernels built on tile_engine.h.
+//
+//   k_layer<PRO, EPI, MT> : out[rows, N] = EPI( PRO(inputs)[rows, K] x Wpacked )   for one Linear (or its transpose),
+//                           16*MT rows per workgroup; the prologue functor builds the A tile in LDS from global
+//                           tensors (fusing sigmoid/softplus-derivative products), the epilogue functor consumes the
+//                           MFMA accumulators (bias, softplus, masks, splits at the skip connection) and stores.
+//   k_wgrad<PMODE>        : dW[No, Ki] = sum_rows P[row, No]^T Q[row, Ki]  (+ column sums of P for the bias),
+//                           split over row chunks into slabs, reduced in a fixed order (deterministic).
+//
+// Formulas: SURVEY.md Appendix E (value + normal forward, first- and second-order backward), verified there
+// against torch.autograd double backward.  Reference code being replaced: idr.py:77-107 (forward / gradient),
+// idr.py:145-167 (rendering net) and autograd's backward of both.
+#pragma once
+#include "tile_engine.h"
+
+enum {
+    PRO_PLAIN = 0,      // A[row][k]
+    PRO_SIG_MUL,        // sigmoid100(Z[row][k]) * U[row][k]            (s_l = sigma_l . u_{l+1})
+    PRO_SIG_BCAST,      // sigmoid100(Z[row][k]) * bcast[k]             (l = 7: u_8 = W_8[0, :])
+    PRO_ZBAR,           // zb = sigmoid100(Z)*U + (row < Mg ? A[row][k] : 0); also stored to out2     (E.2)
+    PRO_TANH_BWD        // dz = A[row][k] * (1 - U[row][k]^2); also stored to out2
+};
+enum {
+    EPI_SOFTPLUS = 0,   // z = acc + b -> out1 (Z);  h = softplus100(z) (/sqrt2 if skip_next) -> out0 (+ PE tail if skip_next)
+    EPI_BIAS,           // out0 = acc + b
+    EPI_SPLIT,          // col < csplit: out0[row][col] = f(acc) ; else out1[row][col - csplit] = f(acc); f = /sqrt2 if scale; + add[row][col] if add
+    EPI_SBAR,           // sbar = acc: out0 = sigma*sbar (/sqrt2 if skip_next), out1 = u*sbar*sigma'            (E.1)
+    EPI_RELU,           // out0 = max(acc + b, 0)
+    EPI_TANH,           // out0 = tanh(acc + b)
+    EPI_RELU_MASK       // out0 = acc * (add[row][col] > 0)
+};
+
+struct LayerArgs {
+    MvLayer L;                 // packed weights (W or W^T pack) + bias
+    int S;                     // LDS row stride
+    int M, Mg;                 // rows; rows that carry second-order terms (PRO_ZBAR)
+    const float* A; int lda;
+    const float* Z; int ldz;
+    const float* U; int ldu;
+    const float* bcast;
+    const float* add; int ldadd;
+    float* out0; int ld0;
+    float* out1; int ld1;
+    float* out2; int ld2;
+    int csplit;                // EPI_SPLIT
+    int scale_sqrt2;           // divide by sqrt(2)
+    int skip_next;             // EPI_SOFTPLUS / EPI_SBAR: next layer is the skip layer
+    int d0;                    // PE width (skip tail) / view-PE multires for PRO_RENDER_IN
+    const float* pe; int ldpe; // PE rows for the skip tail
+};
+
+__device__ __forceinline__ float mv_sigmoid_prime100(float z, float sig) {      // d/dz sigmoid(100 z) (0 past the threshold)
+    return (z * 100.0f > 20.0f) ? 0.0f : 100.0f * sig * (1.0f - sig);
+}
+
+template <int PRO>
+__device__ __forceinline__ float mv_prologue(const LayerArgs& a, int row, int k) {
+    if (PRO == PRO_PLAIN) return a.A[(size_t)row * a.lda + k];
+    if (PRO == PRO_SIG_MUL) return dm_sigmoid100(a.Z[(size_t)row * a.ldz + k]) * a.U[(size_t)row * a.ldu + k];
+    if (PRO == PRO_SIG_BCAST) return dm_sigmoid100(a.Z[(size_t)row * a.ldz + k]) * a.bcast[k];
+    if (PRO == PRO_ZBAR) {
+        float zb = dm_sigmoid100(a.Z[(size_t)row * a.ldz + k]) * a.U[(size_t)row * a.ldu + k];
+        if (row < a.Mg && a.A) zb += a.A[(size_t)row * a.lda + k];
+        a.out2[(size_t)row * a.ld2 + k] = zb;
+        return zb;
+    }
+    if (PRO == PRO_TANH_BWD) {
+        const float y = a.U[(size_t)row * a.ldu + k];
+        const float dz = a.A[(size_t)row * a.lda + k] * (1.0f - y * y);
+        a.out2[(size_t)row * a.ld2 + k] = dz;
+        return dz;
+    }
+    return 0.0f;
+}
+
+template <int EPI>
+__device__ __forceinline__ void mv_epilogue(const LayerArgs& a, int row, int col, float acc) {
+    if (EPI == EPI_SOFTPLUS) {
+        const float z = acc + a.L.bias[col];
+        a.out1[(size_t)row * a.ld1 + col] = z;
+        float h = dm_softplus100(z);
+        if (a.skip_next) h = dm_div_sqrt2(h);
+        a.out0[(size_t)row * a.ld0 + col] = h;
+    } else if (EPI == EPI_BIAS) {
+        a.out0[(size_t)row * a.ld0 + col] = acc + a.L.bias[col];
+    } else if (EPI == EPI_SPLIT) {
+        float v = acc;
+        if (a.add) v += a.add[(size_t)row * a.ldadd + col];
+        if (a.scale_sqrt2) v = dm_div_sqrt2(v);
+        if (col < a.csplit) a.out0[(size_t)row * a.ld0 + col] = v;
+        else a.out1[(size_t)row * a.ld1 + (col - a.csplit)] = v;
+    } else if (EPI == EPI_SBAR) {
+        const float z = a.Z[(size_t)row * a.ldz + col];
+        const float sig = dm_sigmoid100(z);
+        const float u = a.U ? a.U[(size_t)row * a.ldu + col] : a.bcast[col];
+        float ub = sig * acc;
+        if (a.skip_next) ub = dm_div_sqrt2(ub);
+        a.out0[(size_t)row * a.ld0 + col] = ub;
+        a.out1[(size_t)row * a.ld1 + col] = u * acc * mv_sigmoid_prime100(z, sig);
+    } else if (EPI == EPI_RELU) {
+        a.out0[(size_t)row * a.ld0 + col] = fmaxf(acc + a.L.bias[col], 0.0f);
+    } else if (EPI == EPI_TANH) {
+        a.out0[(size_t)row * a.ld0 + col] = tanhf(acc + a.L.bias[col]);
+    } else if (EPI == EPI_RELU_MASK) {
+        a.out0[(size_t)row * a.ld0 + col] = a.add[(size_t)row * a.ldadd + col] > 0.0f ? acc : 0.0f;
+    }
+}
+
+template <int PRO, int EPI, int MT, int NTW>
+__global__ __launch_bounds__(MV_THREADS) void k_layer(LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * MT;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * ROWS, S = a.S, K = a.L.K, Kp = a.L.KB * 16, N = a.L.N;
+    float* act = smem;
+    for (int idx = tid; idx < ROWS * Kp; idx += MV_THREADS) {
+        const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
+        float v = 0.0f;
+        if (row < a.M && k < K) v = mv_prologue<PRO>(a, row, k);
+        act[rr * S + mv_perm(k)] = v;
+    }
+    __syncthreads();
+    const int NT = a.L.NT;
+    const int per = (NT + 3) >> 2;
+    for (int g0 = 0; g0 < per; g0 += NTW) {                    // column-tile groups of NTW per wave (wide layers)
+        const int ct0 = w * per + g0;
+        int ntw = min(per - g0, NT - ct0);
+        ntw = ntw < 0 ? 0 : (ntw > NTW ? NTW : ntw);
+        f32x4 acc[MT][NTW];
+        mv_zero_acc<MT, NTW>(acc);
+        if (ntw > 0) mv_gemm_dispatch<MT, NTW>(a.L, act, S, ct0, ntw, acc, lane);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            if (t < ntw) {
+                const int col = (ct0 + t) * 16 + r;
+                if (col < N) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = row0 + m * 16 + 4 * q + i;
+                            if (row < a.M) mv_epilogue<EPI>(a, row, col, acc[m][t][i]);
+                        }
+                }
+            }
+        }
+    }
+    if (EPI == EPI_SOFTPLUS || EPI == EPI_SBAR) {
+        if (EPI == EPI_SOFTPLUS && a.skip_next) {              // a_{l+1}[:, N:N+d0] = PE / sqrt(2)   (idr.py:86-87)
+            for (int idx = tid; idx < ROWS * a.d0; idx += MV_THREADS) {
+                const int rr = idx / a.d0, j = idx - rr * a.d0, row = row0 + rr;
+                if (row < a.M) a.out0[(size_t)row * a.ld0 + N + j] = dm_div_sqrt2(a.pe[(size_t)row * a.ldpe + j]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* P; int ldp;       // [Mrows, No]  (or Z for PMODE 1/2)
+    const float* U; int ldu;       // PMODE 1
+    const float* bcast;            // PMODE 2
+    const float* Q; int ldq;       // [Mrows, Ki]
+    int M, No, Ki;
+    int chunk;                     // rows per slab
+    float* slab;                   // [nchunks][No][Ki]
+    float* bslab;                  // [nchunks][No] or null
+};
+
+template <int PMODE>
+__global__ __launch_bounds__(MV_THREADS) void k_wgrad(WgradArgs a) {
+    constexpr int LD = 80;                                       // 64 + 16: conflict-free fragment reads
+    __shared__ __attribute__((aligned(16))) float Pt[64 * LD];
+    __shared__ __attribute__((aligned(16))) float Qt[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+    const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64, ch = blockIdx.z;
+    const int rbeg = ch * a.chunk, rend = min(a.M, rbeg + a.chunk);
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    for (int rb = rbeg; rb < rend; rb += 64) {
+        __syncthreads();
+        for (int idx = tid; idx < 64 * 64; idx += MV_THREADS) {
+            const int rr = idx >> 6, c = idx & 63, row = rb + rr;
+            float pv = 0.0f, qv = 0.0f;
+            if (row < rend) {
+                if (o0 + c < a.No) {
+                    const size_t off = (size_t)row * a.ldp + o0 + c;
+                    if (PMODE == 0) pv = a.P[off];
+                    else if (PMODE == 1) pv = dm_sigmoid100(a.P[off]) * a.U[(size_t)row * a.ldu + o0 + c];
+                    else pv = dm_sigmoid100(a.P[off]) * a.bcast[o0 + c];
+                }
+                if (i0 + c < a.Ki) qv = a.Q[(size_t)row * a.ldq + i0 + c];
+            }
+            Pt[rr * LD + c] = pv;
+            Qt[rr * LD + c] = qv;
+        }
+        __syncthreads();
+        if (a.bslab && blockIdx.x == 0 && tid < 64) {
+            for (int rr = 0; rr < 64; ++rr) bsum += Pt[rr * LD + tid];
+        }
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const float av = Pt[(4 * s + q) * LD + 16 * w + r];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Qt[(4 * s + q) * LD + 16 * t + r], acc[t], 0, 0, 0);
+        }
+    }
+    float* slab = a.slab + (size_t)ch * a.No * a.Ki;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = i0 + 16 * t + r;
+        if (i < a.Ki) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int o = o0 + 16 * w + 4 * q + e;
+                if (o < a.No) slab[(size_t)o * a.Ki + i] = acc[t][e];
+            }
+        }
+    }
+    if (a.bslab && blockIdx.x == 0 && tid < 64 && o0 + tid < a.No) a.bslab[(size_t)ch * a.No + o0 + tid] = bsum;
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_c slabA[c][i] (+ sum_c slabB[c][i])      -- fixed order, deterministic
+__global__ void k_reduce_slabs(const float* __restrict__ sa, const float* __restrict__ sb, int nchunks, size_t n, float* __restrict__ out,
+                               int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = accumulate ? out[i] : 0.0f;
+        for (int c = 0; c < nchunks; ++c) v += sa[(size_t)c * n + i];
+        if (sb)
+            for (int c = 0; c < nchunks; ++c) v += sb[(size_t)c * n + i];
+        out[i] = v;
+    }
+}
+
+// out[c] (+)= sum_rows X[row][c]
+__global__ void k_colsum(const float* __restrict__ X, int ld, int M, int n, float* __restrict__ out, int accumulate) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (c < n)
+        for (int row = g; row < M; row += 4) s += X[(size_t)row * ld + c];
+    part[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && c < n) {
+        const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        out[c] = accumulate ? out[c] + v : v;
+    }
+}

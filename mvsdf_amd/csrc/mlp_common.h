@@ -1,7 +1,7 @@
 // mlp_common.h -- device-side description of a folded MLP and the MFMA-packed weight layout.
 //
 // Packed layout of one Linear (out = N, in = K), consumed by v_mfma_f32_16x16x4_f32 without any
-// LDS staging of weights: Kp = ceil16(K), Np = ceil16(N),
+// LDS staging of weights: Kp = ceil32(K), Np = ceil16(N),
 //     Wp[ct][kb][lane][s] = W[ct*16 + (lane & 15)][kb*16 + 4*s + (lane >> 4)]      (0 outside N x K)
 // i.e. one 16-byte load per lane (1 KiB per wave, fully coalesced) yields the B operands of the four
 // MFMA k-steps of a 16-wide k-block, and the k-steps are issued in ascending k: the accumulation is a
@@ -31,8 +31,10 @@ struct MvNet {
 };
 
 __host__ __device__ static inline int mv_ceil16(int x) { return (x + 15) & ~15; }
+// K is padded to a multiple of 32 (an EVEN number of 16-wide k-blocks) so the 2x-unrolled pipelined loop has no tail
+__host__ __device__ static inline int mv_kpad(int x) { return (x + 31) & ~31; }
 __host__ __device__ static inline size_t mv_packed_floats(int N, int K) {
-    return (size_t)mv_ceil16(N) * mv_ceil16(K);
+    return (size_t)mv_ceil16(N) * mv_kpad(K);
 }
 // position of logical column c inside an LDS activation row: 4x4 transpose within each 16-block so that a
 // lane's four consecutive k-steps (k = 4s + q) are one contiguous float4 at 4q..4q+3.

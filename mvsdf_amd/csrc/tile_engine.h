@@ -24,64 +24,81 @@ __device__ __forceinline__ void mv_zero_acc(f32x4 (&acc)[MTc][NTW]) {
         for (int t = 0; t < NTW; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// acc[rt][t] += act[rt*16.., :K] * W[(ct0+t)*16.., :K]^T    for t < ntw (wave-uniform), rt < MTc.
-template <int MTc, int NTW>
-__device__ __forceinline__ void mv_gemm_tiles(const MvLayer& L, const float* __restrict__ act, int S, int ct0, int ntw,
+// acc[rt][t] += act[rt*16.., :K] * W[(ct0+t)*16.., :K]^T    for t < NT (compile time), rt < MTc.
+// Software pipelined by hand: A (LDS) and B (global/L2) fragments of k-block kb+1 are in flight while the
+// 4*MTc*NT MFMAs of k-block kb issue.  No guards inside: the caller dispatches on the (wave-uniform) tile count.
+template <int MTc, int NT, int NTW>
+__device__ __forceinline__ void mv_gemm_tiles(const MvLayer& L, const float* __restrict__ act, int S, int ct0,
                                               f32x4 (&acc)[MTc][NTW], int lane) {
     const int KB = L.KB;
     const float4* __restrict__ wp = L.wp + (size_t)ct0 * KB * 64 + lane;
     const float* arow = act + (lane & 15) * S + 4 * (lane >> 4);
-    float4 b0[NTW], b1[NTW];
+    float4 b0[NT], b1[NT], a0[MTc], a1[MTc];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t)
-        if (t < ntw) b0[t] = wp[(size_t)t * KB * 64];
-    for (int kb = 0; kb < KB; kb += 2) {
-        const bool has1 = kb + 1 < KB;
-        if (has1) {
+    for (int t = 0; t < NT; ++t) b0[t] = wp[(size_t)t * KB * 64];
 #pragma unroll
-            for (int t = 0; t < NTW; ++t)
-                if (t < ntw) b1[t] = wp[((size_t)t * KB + kb + 1) * 64];
-        }
-        {
-            float4 a[MTc];
+    for (int r = 0; r < MTc; ++r) a0[r] = *(const float4*)(arow + r * 16 * S);
+    for (int kb = 0; kb < KB; kb += 2) {          // KB is even (K padded to 32); all prefetches unconditional
 #pragma unroll
-            for (int r = 0; r < MTc; ++r) a[r] = *(const float4*)(arow + r * 16 * S + kb * 16);
+        for (int t = 0; t < NT; ++t) b1[t] = wp[((size_t)t * KB + kb + 1) * 64];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+        for (int r = 0; r < MTc; ++r) a1[r] = *(const float4*)(arow + r * 16 * S + (kb + 1) * 16);
+        __builtin_amdgcn_sched_barrier(0);            // keep the prefetch ABOVE the MFMA block (the scheduler would sink it)
 #pragma unroll
-                for (int r = 0; r < MTc; ++r)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int t = 0; t < NTW; ++t)
-                        if (t < ntw)
-                            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a[r])[s], ((const float*)&b0[t])[s],
-                                                                             acc[r][t], 0, 0, 0);
-        }
-        if (has1) {
-            if (kb + 2 < KB) {
+            for (int r = 0; r < MTc; ++r)
 #pragma unroll
-                for (int t = 0; t < NTW; ++t)
-                    if (t < ntw) b0[t] = wp[((size_t)t * KB + kb + 2) * 64];
-            }
-            float4 a[MTc];
+                for (int t = 0; t < NT; ++t)
+                    acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a0[r])[s], ((const float*)&b0[t])[s], acc[r][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int kn = (kb + 2 < KB) ? kb + 2 : kb;   // last iteration: harmless re-load
 #pragma unroll
-            for (int r = 0; r < MTc; ++r) a[r] = *(const float4*)(arow + r * 16 * S + (kb + 1) * 16);
+        for (int t = 0; t < NT; ++t) b0[t] = wp[((size_t)t * KB + kn) * 64];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+        for (int r = 0; r < MTc; ++r) a0[r] = *(const float4*)(arow + r * 16 * S + kn * 16);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < MTc; ++r)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int t = 0; t < NTW; ++t)
-                        if (t < ntw)
-                            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a[r])[s], ((const float*)&b1[t])[s],
-                                                                             acc[r][t], 0, 0, 0);
-        }
+            for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a1[r])[s], ((const float*)&b1[t])[s], acc[r][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
+// wave-uniform dispatch on the number of column tiles this wave owns (1..NTW)
+template <int MTc, int NTW>
+__device__ __forceinline__ void mv_gemm_dispatch(const MvLayer& L, const float* __restrict__ act, int S, int ct0, int ntw,
+                                                 f32x4 (&acc)[MTc][NTW], int lane) {
+    if (ntw == NTW) { mv_gemm_tiles<MTc, NTW, NTW>(L, act, S, ct0, acc, lane); return; }
+    if (NTW > 4) {
+        if (ntw >= 4) {      // 4..NTW-1: a group of 4, then the rest one by one (rare shapes)
+            mv_gemm_tiles<MTc, 4, NTW>(L, act, S, ct0, acc, lane);
+            for (int t = 4; t < ntw; ++t) {
+                f32x4 tmp[MTc][NTW];
+#pragma unroll
+                for (int r = 0; r < MTc; ++r) tmp[r][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                mv_gemm_tiles<MTc, 1, NTW>(L, act, S, ct0 + t, tmp, lane);
+#pragma unroll
+                for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                    for (int u = 4; u < NTW; ++u) if (u == t) acc[r][u] = tmp[r][0];
+            }
+            return;
+        }
+    }
+    if (ntw == 3) { mv_gemm_tiles<MTc, (NTW >= 3 ? 3 : 1), NTW>(L, act, S, ct0, acc, lane); return; }
+    if (ntw == 2) { mv_gemm_tiles<MTc, (NTW >= 2 ? 2 : 1), NTW>(L, act, S, ct0, acc, lane); return; }
+    if (ntw == 1) { mv_gemm_tiles<MTc, 1, NTW>(L, act, S, ct0, acc, lane); return; }
+}
+
 // Positional encoding of `rows` points (LDS pts[rows][3]) -> pe[rows][d0] (natural order, kept for the skip
-// connection) and act[rows][S] (permuted, zero padded to ceil16(d0)).  embedder.py:10-36.
+// connection) and act[rows][S] (permuted, zero padded to ceil32(d0)).  embedder.py:10-36.
 __device__ __forceinline__ void mv_pe_rows(const float* pts, float* pe, float* act, int S, int rows, int multires, int tid) {
-    const int d0 = 3 + 6 * multires, Kp0 = mv_ceil16(d0), T = 3 * multires + 1;
+    const int d0 = 3 + 6 * multires, Kp0 = mv_kpad(d0), T = 3 * multires + 1;
     for (int task = tid; task < rows * T; task += MV_THREADS) {
         const int row = task / T, j = task - row * T;
         const float* x = pts + row * 3;
@@ -105,7 +122,7 @@ __device__ __forceinline__ void mv_pe_rows(const float* pts, float* pe, float* a
 // Result -> LDS out[row].  All 256 threads must call; ends with a barrier.
 template <int MTc, int NTW>
 __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const float* pts, float* out, int tid) {
-    const int lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
     const int S = net.S, rows = MTc * 16, d0 = 3 + 6 * net.multires;
     mv_pe_rows(pts, pe, act, S, rows, net.multires, tid);
     const int nl = net.n_layers;
@@ -119,7 +136,7 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
         f32x4 acc[MTc][NTW];
         mv_zero_acc<MTc, NTW>(acc);
         __syncthreads();                                      // inputs of layer l complete
-        if (ntw > 0) mv_gemm_tiles<MTc, NTW>(L, act, S, ct0, ntw, acc, lane);
+        if (ntw > 0) mv_gemm_dispatch<MTc, NTW>(L, act, S, ct0, ntw, acc, lane);
         __syncthreads();                                      // every wave done reading act (in-place update)
         if (last) {
             if (w == 0 && r == 0) {

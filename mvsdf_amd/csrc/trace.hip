@@ -72,7 +72,7 @@ __global__ __launch_bounds__(MV_THREADS) void k_sphere_trace(MvNet net, MvTraceP
                                                             unsigned long long* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT, NR = 8 * MT;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     TraceLds lds = mv_carve(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
     int* s_n = lds.misc;
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(MV_THREADS) void k_ray_samples(MvNet net, MvTracePa
                                                            unsigned long long* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_steps = tp.n_steps;
     const int n_items_total = (int)counters[MV_CNT_ITEMS];
     const int item0 = blockIdx.x * RPW;

@@ -27,21 +27,25 @@ class PackedNet:
         d = NetDesc()
         d.n_layers = len(self.layers)
         for i, L in enumerate(self.layers):
-            d.K[i], d.N[i] = L.K, L.N
+            d.K[i], d.N[i] = (L.N, L.K) if transposed else (L.K, L.N)
             d.wp[i] = (L.wpT if transposed else L.wp).data_ptr()
             d.bias[i] = L.bias.data_ptr()
+            d.w[i] = L.w.data_ptr()
         d.skip_layer, d.multires = self.skip_layer, self.multires
         return d
+
+    def wsizes(self):
+        return [L.N * L.K for L in self.layers], [L.N for L in self.layers]
 
 
 def fold_pack(v, g, want_t=True):
     """weight_norm fold + packing: v[N,K], g[N,1] -> (w[N,K], wp, wpT)  (idr.py:70-71)."""
     v, g = _f32(v), _f32(g).reshape(-1)
     N, K = v.shape
-    n = lib().mvsdf_packed_floats(N, K)
     w = torch.empty_like(v)
-    wp = torch.empty(n, dtype=torch.float32, device=v.device)
-    wpT = torch.empty(n, dtype=torch.float32, device=v.device) if want_t else None
+    wp = torch.empty(lib().mvsdf_packed_floats(N, K), dtype=torch.float32, device=v.device)
+    # the transposed pack pads the OTHER dimension to 32: its size is packed_floats(K, N), not (N, K)
+    wpT = torch.empty(lib().mvsdf_packed_floats(K, N), dtype=torch.float32, device=v.device) if want_t else None
     check(lib().mvsdf_fold_pack(ptr(v), ptr(g), N, K, ptr(w), ptr(wp), ptr(wpT), stream_of(v)), 'mvsdf_fold_pack')
     return w, wp, wpT
 
@@ -109,3 +113,68 @@ def det_math(op, x):
     y0, y1 = torch.empty_like(x), torch.empty_like(x)
     check(lib().mvsdf_det_math(op, ptr(x), x.numel(), ptr(y0), ptr(y1), stream_of(x)), 'mvsdf_det_math')
     return y0, y1
+
+
+def _split_cat(net, dW_cat, db_cat):
+    ws, bs = net.wsizes()
+    dWs = [t.view(L.N, L.K) for t, L in zip(torch.split(dW_cat, ws), net.layers)]
+    dbs = list(torch.split(db_cat, bs))
+    return dWs, dbs
+
+
+def sdf_forward(net, x, Mg):
+    """value + normal: x[M,3] -> y[M,Nout], n[Mg,3] (first Mg rows), ctx (saved activations)."""
+    x = _f32(x)
+    M, dev = x.shape[0], x.device
+    d, dT = net.desc(), net.desc(True)
+    y = torch.empty(M, net.layers[-1].N, dtype=torch.float32, device=dev)
+    n = torch.empty(Mg, 3, dtype=torch.float32, device=dev)
+    ctx = torch.empty(lib().mvsdf_sdf_ctx_floats(C.byref(d), M, Mg), dtype=torch.float32, device=dev)
+    check(lib().mvsdf_sdf_forward(C.byref(d), C.byref(dT), ptr(x), M, Mg, ptr(y), ptr(n) if Mg > 0 else None, ptr(ctx), stream_of(x)),
+          'mvsdf_sdf_forward')
+    return y, n, ctx
+
+
+def sdf_backward(net, x, M, Mg, Mb, dy, dn, ctx, want_dx):
+    """-> (dWs [list per layer], dbs, dx or None) over the first Mb rows."""
+    x, dy = _f32(x), _f32(dy)
+    dev = x.device
+    d, dT = net.desc(), net.desc(True)
+    ws_n, bs_n = net.wsizes()
+    dW = torch.empty(sum(ws_n), dtype=torch.float32, device=dev)
+    db = torch.empty(sum(bs_n), dtype=torch.float32, device=dev)
+    dx = torch.empty(Mb, 3, dtype=torch.float32, device=dev) if want_dx else None
+    ws = torch.empty(lib().mvsdf_sdf_bwd_ws_floats(C.byref(d), Mb), dtype=torch.float32, device=dev)
+    dn = _f32(dn) if dn is not None else None
+    check(lib().mvsdf_sdf_backward(C.byref(d), C.byref(dT), ptr(x), M, Mg, Mb, ptr(dy), ptr(dn), ptr(ctx), ptr(dW), ptr(db), ptr(dx),
+                                   ptr(ws), stream_of(x)), 'mvsdf_sdf_backward')
+    dWs, dbs = _split_cat(net, dW, db)
+    return dWs, dbs, dx
+
+
+def render_forward(net, points, view, normals, feat, multires_view):
+    """feat may be a column slice of a wider row-major tensor (stride(0) = ld)."""
+    points, view, normals = _f32(points), _f32(view), _f32(normals)
+    assert feat.dtype == torch.float32 and feat.is_cuda and feat.stride(1) == 1
+    N, dev = points.shape[0], points.device
+    d = net.desc()
+    rgb = torch.empty(N, net.layers[-1].N, dtype=torch.float32, device=dev)
+    ctx = torch.empty(lib().mvsdf_render_ctx_floats(C.byref(d), N), dtype=torch.float32, device=dev)
+    check(lib().mvsdf_render_forward(C.byref(d), ptr(points), ptr(view), ptr(normals), C.c_void_p(feat.data_ptr()), feat.stride(0), N,
+                                     multires_view, ptr(rgb), ptr(ctx), stream_of(points)), 'mvsdf_render_forward')
+    return rgb, ctx
+
+
+def render_backward(net, N, drgb, ctx):
+    drgb = _f32(drgb)
+    dev = drgb.device
+    d, dT = net.desc(), net.desc(True)
+    ws_n, bs_n = net.wsizes()
+    dW = torch.empty(sum(ws_n), dtype=torch.float32, device=dev)
+    db = torch.empty(sum(bs_n), dtype=torch.float32, device=dev)
+    din = torch.empty(N, net.layers[0].K, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib().mvsdf_render_bwd_ws_floats(C.byref(d), N), dtype=torch.float32, device=dev)
+    check(lib().mvsdf_render_backward(C.byref(d), C.byref(dT), N, ptr(drgb), ptr(ctx), ptr(dW), ptr(db), ptr(din), ptr(ws),
+                                      stream_of(drgb)), 'mvsdf_render_backward')
+    dWs, dbs = _split_cat(net, dW, db)
+    return dWs, dbs, din

@@ -266,6 +266,53 @@ def g_feat(seed):
          focal_scale=SCENE['focal_scale'])
 
 
+def g_sdf_bwd(W, n, seed):
+    """Pins the (double) backward: L = sum(out*dy) + sum(grad*dn) through ImplicitNetwork.forward + .gradient
+    (idr.py:77-107) -> d/d{weight_g, weight_v, bias} of every layer and d/dx."""
+    m, sd = build_model(W, seed)
+    net = m.implicit_network
+    net.train()
+    rs = np.random.RandomState(seed + 21)
+    x = rs.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    dy = (rs.normal(size=(n, 1 + 1 + synth.FEAT)) * 0.1).astype(np.float32)
+    dn = rs.normal(size=(n, 3)).astype(np.float32)
+    xt = T(x).clone().requires_grad_(True)
+    out = net(xt)
+    g = net.gradient(xt)[:, 0, :]
+    L = (out * T(dy)).sum() + (g * T(dn)).sum()
+    params = [p for _, p in net.named_parameters()]
+    grads = torch.autograd.grad(L, [xt] + params)
+    res = dict(W=W, seed=seed, x=x, dy=dy, dn=dn, dx=grads[0].numpy(), checksum=synth.state_checksum(sd))
+    for (k, _), gr in zip(net.named_parameters(), grads[1:]):
+        res['d_' + k] = gr.numpy()
+    # first-order only variant (dn = 0), dx through the value chain alone
+    xt2 = T(x).clone().requires_grad_(True)
+    out2 = net(xt2)
+    res['dx_value_only'] = torch.autograd.grad((out2 * T(dy)).sum(), [xt2])[0].numpy()
+    save('sdf_bwd_w%d' % W, **res)
+
+
+def g_render_bwd(W, n, seed):
+    m, sd = build_model(W, seed)
+    net = m.rendering_network
+    rs = np.random.RandomState(seed + 31)
+    pts = rs.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    nrm = rs.normal(size=(n, 3)).astype(np.float32)
+    view = rs.normal(size=(n, 3)).astype(np.float32)
+    view /= np.linalg.norm(view, axis=1, keepdims=True)
+    feat = rs.normal(size=(n, synth.FEAT)).astype(np.float32)
+    drgb = rs.normal(size=(n, 3)).astype(np.float32)
+    ins = [T(a).clone().requires_grad_(True) for a in (pts, nrm, feat)]
+    rgb = net(ins[0], ins[1], T(view), ins[2])
+    params = [p for _, p in net.named_parameters()]
+    grads = torch.autograd.grad((rgb * T(drgb)).sum(), ins + params)
+    res = dict(W=W, seed=seed, points=pts, normals=nrm, view=view, feat=feat, drgb=drgb, rgb=rgb.detach().numpy(),
+               dpoints=grads[0].numpy(), dnormals=grads[1].numpy(), dfeat=grads[2].numpy(), checksum=synth.state_checksum(sd))
+    for (k, _), gr in zip(net.named_parameters(), grads[3:]):
+        res['d_' + k] = gr.numpy()
+    save('render_bwd_w%d' % W, **res)
+
+
 if __name__ == '__main__':
     g_sdf(64, 1000, 0)
     g_sdf(256, 256, 0)
@@ -276,6 +323,8 @@ if __name__ == '__main__':
     g_trace_mlp(256, 2, 512, 0)
     g_sample_network(0)
     g_feat(0)
+    g_sdf_bwd(64, 150, 0)
+    g_render_bwd(64, 150, 0)
     g_idr(64, 2, 256, 3, 0, 0.3)
     g_idr(64, 2, 256, 3, 0, 0.6)
     g_idr(256, 2, 128, 2, 0, 0.3)

@@ -1,0 +1,106 @@
+"""GPU parity of the differentiable passes (value + normal, double backward, rendering net) vs goldens and the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from helpers import sdf_packed_net, t
+from mvsdf_amd import ops
+from mvsdf_amd.utils import synth
+from oracle import oracle_np as ON
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+def render_packed_net(sd):
+    return sdf_packed_net(sd, prefix='rendering_network', skip_layer=-1, multires=0)
+
+
+@pytest.mark.parametrize('W', [64, 256])
+def test_sdf_value_normal_vs_golden(W):
+    g = golden('sdf_w%d' % W)
+    net = sdf_packed_net(synth.make_state_dict(W, int(g['seed'])))
+    x = t(g['x'])
+    y, n, _ = ops.sdf_forward(net, x, x.shape[0])
+    np.testing.assert_allclose(y.cpu().numpy(), g['out'], rtol=1e-4, atol=3e-6)
+    assert _rel(n, g['grad']) < 5e-5
+    y2, n2, _ = ops.sdf_forward(net, x, 37)                    # normals on a prefix only (ragged last tile)
+    assert torch.equal(y2, y) and torch.equal(n2, n[:37])
+    y3, _, _ = ops.sdf_forward(net, x[:5], 0)
+    assert torch.equal(y3, y[:5])
+
+
+def test_sdf_double_backward_vs_golden():
+    g = golden('sdf_bwd_w64')
+    sd = synth.make_state_dict(64, int(g['seed']))
+    net = sdf_packed_net(sd)
+    x = t(g['x'])
+    M = x.shape[0]
+    y, n, ctx = ops.sdf_forward(net, x, M)
+    dWs, dbs, dx = ops.sdf_backward(net, x, M, M, M, t(g['dy']), t(g['dn']), ctx, True)
+    assert _rel(dx, g['dx']) < 2e-4
+    for l, (dW, db) in enumerate(zip(dWs, dbs)):
+        v = t(sd['implicit_network.lin%d.weight_v' % l]); gg = t(sd['implicit_network.lin%d.weight_g' % l])
+        dv, dg = ops.fold_backward(v, gg, dW.contiguous())
+        assert _rel(dv, g['d_lin%d.weight_v' % l]) < 5e-4, l
+        assert _rel(dg, g['d_lin%d.weight_g' % l]) < 5e-4, l
+        assert _rel(db, g['d_lin%d.bias' % l]) < 5e-4, l
+    # value-only backward (dn = None) and a row prefix
+    _, _, dx1 = ops.sdf_backward(net, x, M, M, M, t(g['dy']), None, ctx, True)
+    assert _rel(dx1, g['dx_value_only']) < 2e-4
+    Mb = 70
+    onet = ON.sdf_net(sd)
+    _, _, cache = ON.sdf_forward(onet, g['x'][:Mb])
+    oW, ob, odx = ON.sdf_backward(onet, cache, g['dy'][:Mb], g['dn'][:Mb])
+    dWs2, dbs2, dx2 = ops.sdf_backward(net, x, M, M, Mb, t(g['dy'][:Mb]), t(g['dn'][:Mb]), ctx, True)
+    assert _rel(dx2, odx) < 2e-4
+    for l in range(len(dWs2)):
+        assert _rel(dWs2[l], oW[l]) < 5e-4 and _rel(dbs2[l], ob[l]) < 5e-4
+
+
+def test_sdf_backward_w256_vs_oracle():
+    sd = synth.make_state_dict(256, 0)
+    net, onet = sdf_packed_net(sd), ON.sdf_net(sd)
+    rs = np.random.RandomState(4)
+    M, Mg = 1100, 700
+    x = rs.uniform(-1, 1, size=(M, 3)).astype(np.float32)
+    dy = (rs.normal(size=(M, 258)) * 0.1).astype(np.float32)
+    dn = rs.normal(size=(Mg, 3)).astype(np.float32)
+    y, n, ctx = ops.sdf_forward(net, t(x), Mg)
+    oy, on, cache = ON.sdf_forward(onet, x)
+    assert _rel(y, oy) < 2e-5 and _rel(n, on[:Mg]) < 5e-5
+    # rows [0, Mg) carry dn; evaluate the oracle in two parts (linearity)
+    dn_full = np.zeros((M, 3)); dn_full[:Mg] = dn
+    oW, ob, odx = ON.sdf_backward(onet, cache, dy, dn_full)
+    dWa, dba, dxa = ops.sdf_backward(net, t(x), M, Mg, Mg, t(dy[:Mg]), t(dn), ctx, True)
+    dy_rest = dy.copy(); dy_rest[:Mg] = 0
+    dWb, dbb, dxb = ops.sdf_backward(net, t(x), M, Mg, M, t(dy_rest), None, ctx, True)
+    for l in range(9):
+        assert _rel(dWa[l] + dWb[l], oW[l]) < 5e-4, l
+        assert _rel(dba[l] + dbb[l], ob[l]) < 5e-4, l
+    dx = dxb.clone(); dx[:Mg] += dxa
+    assert _rel(dx, odx) < 5e-4
+
+
+def test_render_forward_backward_vs_golden():
+    g = golden('render_bwd_w64')
+    sd = synth.make_state_dict(64, int(g['seed']))
+    net = render_packed_net(sd)
+    N = g['points'].shape[0]
+    wide = torch.zeros(N, 258, device='cuda'); wide[:, 2:] = t(g['feat'])         # features as a column slice (ld = 258)
+    rgb, ctx = ops.render_forward(net, t(g['points']), t(g['view']), t(g['normals']), wide[:, 2:], 4)
+    np.testing.assert_allclose(rgb.cpu().numpy(), g['rgb'], rtol=1e-4, atol=2e-6)
+    dWs, dbs, din = ops.render_backward(net, N, t(g['drgb']), ctx)
+    dv = 3 + 6 * 4
+    assert _rel(din[:, :3], g['dpoints']) < 2e-4 and _rel(din[:, 3 + dv:6 + dv], g['dnormals']) < 2e-4
+    assert _rel(din[:, 6 + dv:], g['dfeat']) < 2e-4
+    for l, (dW, db) in enumerate(zip(dWs, dbs)):
+        v = t(sd['rendering_network.lin%d.weight_v' % l]); gg = t(sd['rendering_network.lin%d.weight_g' % l])
+        dvv, dg = ops.fold_backward(v, gg, dW.contiguous())
+        assert _rel(dvv, g['d_lin%d.weight_v' % l]) < 5e-4 and _rel(dg, g['d_lin%d.weight_g' % l]) < 5e-4
+        assert _rel(db, g['d_lin%d.bias' % l]) < 5e-4

@@ -1,0 +1,48 @@
+"""Perf probe of the tracer kernels alone (dev tool): sweeps mt / rpw on the synthetic scene."""
+import argparse
+import sys
+import os
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+from helpers import sdf_packed_net, t, trace_params
+from mvsdf_amd import ops
+from mvsdf_amd.utils import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--W', type=int, default=256)
+ap.add_argument('--B', type=int, default=8)
+ap.add_argument('--P', type=int, default=256)
+ap.add_argument('--iters', type=int, default=10)
+ap.add_argument('--configs', default='1:1,2:2,2:4,4:4,4:8,1:2,2:1')
+a = ap.parse_args()
+sd = synth.make_state_dict(a.W, 0)
+net = sdf_packed_net(sd)
+inp, _ = synth.make_batch(a.B, a.P, 0, seed=0, with_features=False)
+dirs, cam = ops.camera_rays(t(inp['uv']), t(inp['pose']), t(inp['intrinsics']))
+om = torch.ones(a.B * a.P, dtype=torch.bool, device='cuda')
+intervals = torch.linspace(0, 1, 100).cuda()
+torch.manual_seed(0)
+steps = torch.empty(100).uniform_(0, 1).cuda()
+Ft = 2 * sum(i * o for i, o in synth.sdf_layer_dims(a.W)[:-1]) + 2 * synth.sdf_layer_dims(a.W)[-1][0]
+R = a.B * a.P
+for cfg in a.configs.split(','):
+    mt, rpw = [int(v) for v in cfg.split(':')]
+    for training in (True,):
+        for _ in range(2):
+            out = ops.trace(net, cam, dirs, om, trace_params(a.W), training, intervals, steps, mt=mt, rpw=rpw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            out = ops.trace(net, cam, dirs, om, trace_params(a.W), training, intervals, steps, mt=mt, rpw=rpw)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        cnt = out[3].cpu().numpy()
+        T = int(cnt[:4].sum())
+        print('W=%d R=%d mt=%d rpw=%d train=%d: %.3f ms  hit=%.2f rows/ray sphere %.1f sampler %.1f secant %.1f minsdf %.1f  T=%d  %.2f Mrays/s  %.1f TFLOP/s (%.1f%% of 157.3)'
+              % (a.W, R, mt, rpw, training, ms, out[1].float().mean().item(), cnt[0] / R, cnt[1] / R, cnt[2] / R, cnt[3] / R, T,
+                 R / ms / 1e3, T * Ft / ms / 1e9, T * Ft / ms / 1e9 / 157.3 * 100), flush=True)
