@@ -76,6 +76,9 @@ int mvsdf_sdf_col0(const MvsdfNetDesc* net, const float* x, int n, float* y, int
 int mvsdf_camera_rays(const float* uv, const float* pose, const float* intrinsics, int B, int P, float* ray_dirs, float* cam_loc,
                       void* stream);
 
+/* rend_util.get_sphere_intersection (rend_util.py:141-162): -> t[B*P][2] (near, far; clamped at 0), mask[B*P] (disc > 0). */
+int mvsdf_sphere_intersection(const float* cam_loc, const float* ray_dirs, int B, int P, float r, float* t, uint8_t* mask, void* stream);
+
 /* RayTracing.forward (ray_tracing.py:27-98) with the SDF given by `net`:
  * cam_loc[B][3], ray_dirs[B][P][3], object_mask[B*P] -> points[B*P][3], mask[B*P], dists[B*P].
  * intervals[n_steps] = torch.linspace(0, 1, n_steps) (ray_tracing.py:206); minsdf_steps[n_steps] = the uniform draws
@@ -110,6 +113,22 @@ int mvsdf_render_forward(const MvsdfNetDesc* net, const float* points, const flo
 /* din[N][K0]: adjoint of the concatenated input (points = [:,0:3], normals = [:,3+dv:6+dv], feat = [:,6+dv:], dv = 3+6*multires_view) */
 int mvsdf_render_backward(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, int N, const float* drgb, const float* ctx, float* dW_cat,
                           float* db_cat, float* din, float* ws, void* stream);
+
+/* ---- IDRLoss.get_feat_loss_corr (model/loss.py:115-165 + utils/my_utils.py:98-110,152-165 + F.grid_sample) ----
+ * forward AND analytic d(loss)/d(points) in one launch (feature maps are constants).  pts[N][3] = diff_surf_pts (hit points,
+ * view-major); view_start[B+1] (device int32) = prefix sums of per-view hit counts; feat[B][C][H][W], feat_src[B][V][C][H][W]
+ * addressed through element strides (NCHW or channels_last, C <= 32); cam[B][2][4][4], src_cams[B][V][2][4][4], size[1],
+ * center[3] on the device.  loss_pp[N]: per-point terms (their sum is the loss); dpts[N][3]. */
+int mvsdf_feat_corr(const float* pts, int N, const int* view_start, int B, int V, int C, int H, int W, const float* feat,
+                    const long long* feat_strides, const float* feat_src, const long long* src_strides, const float* cam,
+                    const float* src_cams, const float* size, const float* center, float* loss_pp, float* dpts, void* stream);
+
+/* ---- depth-carving target of IDRLoss.get_depth_loss (loss.py:37-63 -> my_utils.py:269-331 carving_t2) ----
+ * pts[M][3] normalised sample points, depths[B][h][w], cams[B][2][4][4] -> dist_r[M], weight[M];
+ * loss = mean(|eikonal_output + dist_r| * weight)  (weight = far/near attenuation * in_range). */
+int mvsdf_depth_carve(const float* pts, int M, const float* depths, int B, int h, int w, const float* cams, const float* size,
+                      const float* center, float out_thresh_perc, float far_thresh, float far_att, float near_thresh, float near_att,
+                      float* dist_r, float* weight, void* stream);
 
 /* device self-test of the deterministic math: op 0 softplus100, 1 expneg, 2 log1p01, 3 sincos (y0=sin, y1=cos),
  * 4 div100 / div_sqrt2 (y0, y1), 5 sqrt / reciprocal (y0, y1). */

@@ -76,6 +76,24 @@ __global__ void k_camera_rays(const float* __restrict__ uv, const float* __restr
     dirs[3 * (size_t)idx + 2] = wv[2] / nn;
 }
 
+// ---- rend_util.get_sphere_intersection (rend_util.py:141-162), same op order as the tracer's fused copy ----
+__global__ void k_sphere_intersection(const float* __restrict__ cam_loc, const float* __restrict__ dirs, int B, int P, float r,
+                                      float* __restrict__ t, uint8_t* __restrict__ mask) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * P) return;
+    const float* c = cam_loc + 3 * (idx / P);
+    const float* d = dirs + 3 * (size_t)idx;
+    const float dot = fmaf(d[2], c[2], fmaf(d[1], c[1], d[0] * c[0]));
+    const float nrm = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    const float under = dot * dot - (nrm * nrm - r * r);
+    const bool hit = under > 0.0f;
+    float a = 0.0f, b = 0.0f;
+    if (hit) { const float s = sqrtf(under); a = s * -1.0f - dot; b = s * 1.0f - dot; }
+    t[2 * (size_t)idx] = a < 0.0f ? 0.0f : a;
+    t[2 * (size_t)idx + 1] = b < 0.0f ? 0.0f : b;
+    mask[idx] = hit ? 1 : 0;
+}
+
 // ---- the tracing MLP alone: y[i] = ImplicitNetwork(x[i])[0] ----
 template <int MT, int NTW>
 __global__ __launch_bounds__(MV_THREADS) void k_sdf_col0(MvNet net, const float* __restrict__ x, int n, float* __restrict__ y) {
@@ -153,6 +171,12 @@ int mvsdf_camera_rays(const float* uv, const float* pose, const float* intrinsic
     hipLaunchKernelGGL(k_camera_rays, dim3((B * P + 255) / 256), dim3(256), 0, (hipStream_t)stream, uv, pose, intrinsics, B, P, ray_dirs,
                        cam_loc);
     return mv_check(hipGetLastError(), "mvsdf_camera_rays");
+}
+
+int mvsdf_sphere_intersection(const float* cam_loc, const float* ray_dirs, int B, int P, float r, float* t, uint8_t* mask, void* stream) {
+    if (!cam_loc || !ray_dirs || !t || !mask || B <= 0 || P <= 0) return mv_fail(-1, "mvsdf_sphere_intersection: bad arguments");
+    hipLaunchKernelGGL(k_sphere_intersection, dim3((B * P + 255) / 256), dim3(256), 0, (hipStream_t)stream, cam_loc, ray_dirs, B, P, r, t, mask);
+    return mv_check(hipGetLastError(), "mvsdf_sphere_intersection");
 }
 
 int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, int mt, void* stream) {

@@ -1,0 +1,269 @@
+// loss_kernels.hip -- multi-view feature consistency (IDRLoss.get_feat_loss_corr, model/loss.py:115-165) and the
+// depth-carving target of get_depth_loss (model/loss.py:37-63 -> utils/my_utils.py:269-331, carving_t2).
+//
+// k_feat_corr: one wave per hit point.  Each 32-lane half owns the 32 feature channels of one source view at a time:
+//   project the point into the reference and the source camera (idx_world2cam / idx_cam2img, my_utils.py:98-110, with
+//   their three "+1e-9" divisions), normalise for grid_sample (my_utils.py:152-156, clamp +-1.1), 4-tap bilinear gather
+//   (align_corners=False, zeros padding; loss.py:145), cosine correlation, masks, and -- in the same pass -- the analytic
+//   gradient of the loss w.r.t. the point (features are constants, scene_dataset.py:139-149), so that backward is a scale.
+//   Feature maps are addressed through element strides: NCHW gathers 128 scattered dwords per (point, view); a
+//   channels_last tensor (same shape, torch.channels_last) makes every tap one 128-byte line.
+// HBM-shaped: 2 * 4 * C * 4 B = 1 KiB of gathered features per (point, source view).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "capi_util.h"
+
+struct Proj {
+    float u, v;          // image coordinates
+    float ju[3], jv[3];  // d(u,v)/d(world point)
+};
+
+// pts_img = idx_cam2img(idx_world2cam(x)), with forward-mode Jacobian w.r.t. the world point
+__device__ __forceinline__ Proj mv_project(const float* __restrict__ cam /*[2][4][4]*/, const float pw[3]) {
+    const float* E = cam;
+    const float* K = cam + 16;
+    float c[4], dc[4][3];
+    for (int r = 0; r < 4; ++r) {
+        c[r] = E[4 * r] * pw[0] + E[4 * r + 1] * pw[1] + E[4 * r + 2] * pw[2] + E[4 * r + 3];
+        for (int j = 0; j < 3; ++j) dc[r][j] = E[4 * r + j];
+    }
+    const float s1 = 1.0f / (c[3] + 1e-9f);                    // idx_cam_homo / (w + 1e-9)          my_utils.py:101
+    float c1[4], dc1[4][3];
+    for (int r = 0; r < 4; ++r) {
+        c1[r] = c[r] * s1;
+        for (int j = 0; j < 3; ++j) dc1[r][j] = dc[r][j] * s1 - c[r] * s1 * s1 * dc[3][j];
+    }
+    const float s2 = 1.0f / (c1[3] + 1e-9f);                   // [:3] / (w + 1e-9)                   my_utils.py:107
+    float c3[3], dc3[3][3];
+    for (int r = 0; r < 3; ++r) {
+        c3[r] = c1[r] * s2;
+        for (int j = 0; j < 3; ++j) dc3[r][j] = dc1[r][j] * s2 - c1[r] * s2 * s2 * dc1[3][j];
+    }
+    float im[3], dim[3][3];
+    for (int r = 0; r < 3; ++r) {                              // K[:3,:3] @ idx_cam                     my_utils.py:108
+        im[r] = K[4 * r] * c3[0] + K[4 * r + 1] * c3[1] + K[4 * r + 2] * c3[2];
+        for (int j = 0; j < 3; ++j) dim[r][j] = K[4 * r] * dc3[0][j] + K[4 * r + 1] * dc3[1][j] + K[4 * r + 2] * dc3[2][j];
+    }
+    const float s3 = 1.0f / (im[2] + 1e-9f);                   // / (z + 1e-9)                          my_utils.py:109
+    Proj p;
+    p.u = im[0] * s3; p.v = im[1] * s3;
+    for (int j = 0; j < 3; ++j) {
+        p.ju[j] = dim[0][j] * s3 - im[0] * s3 * s3 * dim[2][j];
+        p.jv[j] = dim[1][j] * s3 - im[1] * s3 * s3 * dim[2][j];
+    }
+    return p;
+}
+
+struct Sample { float f, fx, fy; };   // value, d/d(gx), d/d(gy) of one channel
+
+// F.grid_sample(bilinear, zeros, align_corners=False) of channel `c` at normalised (gx, gy)
+__device__ __forceinline__ Sample mv_bilinear(const float* __restrict__ map, long long sC, long long sH, long long sW, int c, int H, int W,
+                                              float gx, float gy) {
+    const float ix = ((gx + 1.0f) * W - 1.0f) * 0.5f, iy = ((gy + 1.0f) * H - 1.0f) * 0.5f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float fx = ix - x0f, fy = iy - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float* base = map + (long long)c * sC;
+    auto tap = [&](int yy, int xx) -> float {
+        return (xx >= 0 && xx < W && yy >= 0 && yy < H) ? base[(long long)yy * sH + (long long)xx * sW] : 0.0f;
+    };
+    const float v00 = tap(y0, x0), v01 = tap(y0, x0 + 1), v10 = tap(y0 + 1, x0), v11 = tap(y0 + 1, x0 + 1);
+    Sample s;
+    s.f = v00 * (1.f - fx) * (1.f - fy) + v01 * fx * (1.f - fy) + v10 * (1.f - fx) * fy + v11 * fx * fy;
+    s.fx = ((v01 - v00) * (1.f - fy) + (v11 - v10) * fy) * (0.5f * W);
+    s.fy = ((v10 - v00) * (1.f - fx) + (v11 - v01) * fx) * (0.5f * H);
+    return s;
+}
+
+__device__ __forceinline__ float half_sum(float v) {           // sum over the 32 lanes of this half-wave
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+struct FeatArgs {
+    const float* pts; int N;
+    const int* view_start;     // [B+1] prefix sums of per-view hit counts (device)
+    int B, V, C, H, W;
+    const float* feat; long long fs[4];        // strides (B, C, H, W) in elements
+    const float* feat_src; long long ss[5];    // strides (B, V, C, H, W)
+    const float* cam;          // [B][2][4][4]
+    const float* src_cams;     // [B][V][2][4][4]
+    const float* size;         // [1]
+    const float* center;       // [3]
+    float* loss_pp;            // [N]   per-point loss, already weighted by 1 / (B * V * m_b)
+    float* dpts;               // [N][3] d(total loss)/d(point)
+};
+
+__global__ __launch_bounds__(256) void k_feat_corr(FeatArgs a) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, ch = lane & 31;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.N) return;
+    int b = 0;
+    while (b + 1 < a.B && i >= a.view_start[b + 1]) ++b;
+    const int m_b = a.view_start[b + 1] - a.view_start[b];
+    const float size = a.size[0];
+    float pw[3];
+    for (int j = 0; j < 3; ++j) pw[j] = a.pts[3 * (size_t)i + j] / 2.0f * size + a.center[j];     // loss.py:132
+    const float Wf = (float)a.W, Hf = (float)a.H;
+    // reference view
+    const Proj p0 = mv_project(a.cam + (size_t)b * 32, pw);
+    const float gx0r = (p0.u / 2.0f) / Wf * 2.0f - 1.0f, gy0r = (p0.v / 2.0f) / Hf * 2.0f - 1.0f;  // loss.py:142, my_utils.py:152-156
+    const float gx0 = fminf(fmaxf(gx0r, -1.1f), 1.1f), gy0 = fminf(fmaxf(gy0r, -1.1f), 1.1f);
+    const bool in0 = gx0 <= 1.f && gx0 >= -1.f && gy0 <= 1.f && gy0 >= -1.f;
+    const float kx0 = (gx0r >= -1.1f && gx0r <= 1.1f) ? 1.0f / Wf : 0.0f;                          // d gx / d u (clamp passes inside)
+    const float ky0 = (gy0r >= -1.1f && gy0r <= 1.1f) ? 1.0f / Hf : 0.0f;
+    float loss_acc = 0.f, g[3] = {0.f, 0.f, 0.f};
+    {                                                                                              // C <= 32 (MVSDF: 32): one channel per lane of a half
+        const int c = ch;
+        const bool cok = c < a.C;
+        Sample s0 = {0.f, 0.f, 0.f};
+        if (cok) s0 = mv_bilinear(a.feat + (long long)b * a.fs[0], a.fs[1], a.fs[2], a.fs[3], c, a.H, a.W, gx0, gy0);
+        const float n0sq = half_sum(s0.f * s0.f);
+        for (int v0 = 0; v0 < a.V; v0 += 2) {
+            const int v = v0 + half;
+            const bool vok = v < a.V;
+            const int vv = vok ? v : 0;
+            const Proj pv = mv_project(a.src_cams + ((size_t)b * a.V + vv) * 32, pw);
+            const float gxr = (pv.u / 2.0f) / Wf * 2.0f - 1.0f, gyr = (pv.v / 2.0f) / Hf * 2.0f - 1.0f;
+            const float gx = fminf(fmaxf(gxr, -1.1f), 1.1f), gy = fminf(fmaxf(gyr, -1.1f), 1.1f);
+            const bool inv = gx <= 1.f && gx >= -1.f && gy <= 1.f && gy >= -1.f;
+            const float kx = (gxr >= -1.1f && gxr <= 1.1f) ? 1.0f / Wf : 0.0f, ky = (gyr >= -1.1f && gyr <= 1.1f) ? 1.0f / Hf : 0.0f;
+            Sample sv = {0.f, 0.f, 0.f};
+            if (cok && vok)
+                sv = mv_bilinear(a.feat_src + (long long)b * a.ss[0] + (long long)vv * a.ss[1], a.ss[2], a.ss[3], a.ss[4], c, a.H, a.W, gx, gy);
+            const float dot = half_sum(s0.f * sv.f), nvsq = half_sum(sv.f * sv.f);
+            const float n0 = sqrtf(n0sq), nv = sqrtf(nvsq);
+            const float n0c = fmaxf(n0, 1e-9f), nvc = fmaxf(nv, 1e-9f);
+            const float corr = dot / n0c / nvc;                                                     // loss.py:149-150
+            const float cl = fabsf(1.0f - corr);
+            const bool on = vok && in0 && inv && (cl < 0.5f);                                       // loss.py:144,153,155
+            // d corr / d f0[c], d corr / d fv[c]   (norm clamp: no gradient through a clamped norm)
+            const float a0 = sv.f / (n0c * nvc) - (n0 > 1e-9f ? corr * s0.f / (n0c * n0c) : 0.0f);
+            const float av = s0.f / (n0c * nvc) - (nv > 1e-9f ? corr * sv.f / (nvc * nvc) : 0.0f);
+            const float d_gx0 = half_sum(a0 * s0.fx), d_gy0 = half_sum(a0 * s0.fy);
+            const float d_gxv = half_sum(av * sv.fx), d_gyv = half_sum(av * sv.fy);
+            if (on) {
+                const float sgn = (1.0f - corr) > 0.f ? -1.0f : ((1.0f - corr) < 0.f ? 1.0f : 0.0f);  // d|1-corr|/dcorr
+                loss_acc += cl;
+                for (int j = 0; j < 3; ++j) {
+                    const float dcorr = d_gx0 * kx0 * p0.ju[j] + d_gy0 * ky0 * p0.jv[j] + d_gxv * kx * pv.ju[j] + d_gyv * ky * pv.jv[j];
+                    g[j] += sgn * dcorr;
+                }
+            }
+        }
+    }
+    // combine the two halves (each handled different source views)
+    loss_acc += __shfl_xor(loss_acc, 32);
+    for (int j = 0; j < 3; ++j) g[j] += __shfl_xor(g[j], 32);
+    if (lane == 0) {
+        const float wgt = 1.0f / ((float)a.B * (float)a.V * (float)m_b);                            // mean over [V,1,m,1], then over B
+        a.loss_pp[i] = loss_acc * wgt;
+        for (int j = 0; j < 3; ++j) a.dpts[3 * (size_t)i + j] = g[j] * wgt * (size / 2.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct CarveArgs {
+    const float* pts; int M;          // normalised points [M][3]
+    const float* depths; int B, h, w; // [B][h][w]
+    const float* cams;                // [B][2][4][4]
+    const float* size; const float* center;
+    float out_thresh_perc, far_thresh, far_att, near_thresh, near_att;
+    float* dist_r; float* weight;     // [M]
+};
+
+// carving_t2 (my_utils.py:269-331) + the weighting of get_depth_loss (loss.py:42-60) for one point per thread.
+__global__ void k_carve(CarveArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.M) return;
+    const float size = a.size[0];
+    float pw[3];
+    for (int j = 0; j < 3; ++j) pw[j] = a.pts[3 * (size_t)i + j] / 2.0f * size + a.center[j];       // loss.py:42
+    const float MAXF = 1e30f / (float)a.B;
+    float tot_in = 0.f, tot_valid = 0.f, tot_inside = 0.f, pos_min = INFINITY, neg_max = -INFINITY;
+    for (int v = 0; v < a.B; ++v) {
+        const float* E = a.cams + (size_t)v * 32;
+        const float* K = E + 16;
+        float c[4];
+        for (int r = 0; r < 4; ++r) c[r] = E[4 * r] * pw[0] + E[4 * r + 1] * pw[1] + E[4 * r + 2] * pw[2] + E[4 * r + 3];
+        const float s1 = c[3] + 1e-9f;
+        for (int r = 0; r < 4; ++r) c[r] = c[r] / s1;
+        const float pdepth = c[2];                                                                // my_utils.py:296
+        const float s2 = c[3] + 1e-9f;
+        const float c3[3] = {c[0] / s2, c[1] / s2, c[2] / s2};
+        float im[3];
+        for (int r = 0; r < 3; ++r) im[r] = K[4 * r] * c3[0] + K[4 * r + 1] * c3[1] + K[4 * r + 2] * c3[2];
+        const float u = im[0] / (im[2] + 1e-9f), vv = im[1] / (im[2] + 1e-9f);
+        const float gx = fminf(fmaxf(u / (float)a.w * 2.0f - 1.0f, -1.1f), 1.1f);
+        const float gy = fminf(fmaxf(vv / (float)a.h * 2.0f - 1.0f, -1.1f), 1.1f);
+        const bool in_range = gx <= 1.f && gx >= -1.f && gy <= 1.f && gy >= -1.f;
+        const int ix = (int)nearbyintf(((gx + 1.0f) * a.w - 1.0f) * 0.5f), iy = (int)nearbyintf(((gy + 1.0f) * a.h - 1.0f) * 0.5f);
+        float gd = 0.0f;                                                                          // grid_sample nearest, zeros padding
+        if (ix >= 0 && ix < a.w && iy >= 0 && iy < a.h) gd = a.depths[((size_t)v * a.h + iy) * a.w + ix];
+        const bool valid = (gd > 0.f) && in_range;
+        const bool inside = (pdepth > gd * 0.99f) && valid;
+        const bool outside = valid != inside;
+        const float dist = valid ? (pdepth - gd) : 0.0f;
+        tot_in += in_range; tot_valid += valid; tot_inside += inside;
+        pos_min = fminf(pos_min, inside ? dist : MAXF);
+        neg_max = fmaxf(neg_max, outside ? dist : -MAXF);
+    }
+    auto agg = [&](float res, float sign) {                                                       // RunningTopK(k=1).aggregate, my_utils.py:190-201
+        const bool validm = fabsf(res) < MAXF * .99f;
+        const float num = validm ? 1.f : 0.f;
+        const float ret = (validm ? res : 0.f) / (num + 1e-9f);
+        return ret * (num > 0.5f ? 1.f : 0.f) + MAXF * sign * (num < 0.5f ? 1.f : 0.f);
+    };
+    const float dpos = agg(pos_min, 1.f), dneg = agg(neg_max, -1.f);
+    const float outside_perc = (tot_valid - tot_inside) / (tot_valid + 1e-9f);
+    const bool scene_valid = tot_valid > 0.f;
+    const bool scene_outside = (outside_perc > a.out_thresh_perc) && scene_valid;
+    const bool scene_inside = scene_valid != scene_outside;
+    const float dist = dpos * (scene_inside ? 1.f : 0.f) + dneg * (scene_outside ? 1.f : 0.f);
+    float dr = dist / size * 2.0f + (-1.25f) * (scene_valid ? 0.f : 1.f);                          // loss.py:47
+    dr = fminf(fmaxf(dr, -1.25f), 1.25f);
+    const bool far = fabsf(dr) > a.far_thresh, near = fabsf(dr) < a.near_thresh;
+    const float fw = far ? a.far_att : 1.0f, nw = near ? a.near_att : 1.0f;
+    a.dist_r[i] = dr;
+    a.weight[i] = fw * nw * (scene_valid ? 1.f : 0.f);
+}
+
+extern "C" {
+
+/* IDRLoss.get_feat_loss_corr (loss.py:115-165) forward + analytic d/d(points) in one launch.
+ * pts[N][3]: diff_surf_pts (hit points, view-major); view_start[B+1] (device int32): prefix sums of per-view hit counts.
+ * feat[B][C][H][W] / feat_src[B][V][C][H][W] addressed by element strides (NCHW or channels_last).
+ * cam[B][2][4][4], src_cams[B][V][2][4][4], size[1], center[3] (device).  Outputs: loss_pp[N] (sum = the loss), dpts[N][3]. */
+int mvsdf_feat_corr(const float* pts, int N, const int* view_start, int B, int V, int C, int H, int W, const float* feat,
+                    const long long* feat_strides, const float* feat_src, const long long* src_strides, const float* cam,
+                    const float* src_cams, const float* size, const float* center, float* loss_pp, float* dpts, void* stream) {
+    if (!pts || !view_start || !feat || !feat_src || !cam || !src_cams || !size || !center || !loss_pp || !dpts || !feat_strides || !src_strides)
+        return mv_fail(-1, "mvsdf_feat_corr: null argument");
+    if (N <= 0 || B <= 0 || V <= 0 || H <= 0 || W <= 0) return mv_fail(-1, "mvsdf_feat_corr: bad sizes");
+    if (C <= 0 || C > 32) return mv_fail(-1, "mvsdf_feat_corr: C must be in 1..32 (MVSDF features have 32 channels)");
+    FeatArgs a;
+    a.pts = pts; a.N = N; a.view_start = view_start; a.B = B; a.V = V; a.C = C; a.H = H; a.W = W;
+    a.feat = feat; a.feat_src = feat_src;
+    for (int i = 0; i < 4; ++i) a.fs[i] = feat_strides[i];
+    for (int i = 0; i < 5; ++i) a.ss[i] = src_strides[i];
+    a.cam = cam; a.src_cams = src_cams; a.size = size; a.center = center; a.loss_pp = loss_pp; a.dpts = dpts;
+    hipLaunchKernelGGL(k_feat_corr, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    return mv_check(hipGetLastError(), "mvsdf_feat_corr");
+}
+
+/* Depth-carving target of IDRLoss.get_depth_loss (loss.py:37-63, carving_t2): pts[M][3] normalised sample points,
+ * depths[B][h][w], cams[B][2][4][4] -> dist_r[M], weight[M];  loss = mean(|eikonal_output + dist_r| * weight). */
+int mvsdf_depth_carve(const float* pts, int M, const float* depths, int B, int h, int w, const float* cams, const float* size,
+                      const float* center, float out_thresh_perc, float far_thresh, float far_att, float near_thresh, float near_att,
+                      float* dist_r, float* weight, void* stream) {
+    if (!pts || !depths || !cams || !size || !center || !dist_r || !weight || M <= 0 || B <= 0 || h <= 0 || w <= 0)
+        return mv_fail(-1, "mvsdf_depth_carve: bad arguments");
+    CarveArgs a;
+    a.pts = pts; a.M = M; a.depths = depths; a.B = B; a.h = h; a.w = w; a.cams = cams; a.size = size; a.center = center;
+    a.out_thresh_perc = out_thresh_perc; a.far_thresh = far_thresh; a.far_att = far_att; a.near_thresh = near_thresh; a.near_att = near_att;
+    a.dist_r = dist_r; a.weight = weight;
+    hipLaunchKernelGGL(k_carve, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return mv_check(hipGetLastError(), "mvsdf_depth_carve");
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+"""torch.autograd.Function wrappers around the HIP passes (mvsdf_amd.ops).  All math happens in libmvsdf_hip.so;
+this file only routes tensors and gradients so that `loss.backward()` (idr_train.py:287) drives the hand-written
+backward kernels instead of autograd's op-by-op double backward."""
+import torch
+
+from . import ops
+
+
+class _Fold(torch.autograd.Function):
+    """weight_norm (idr.py:70-71): (weight_v, weight_g) -> folded W; MFMA packs ride along on `holder`."""
+
+    @staticmethod
+    def forward(ctx, v, g, holder):
+        w, wp, wpT = ops.fold_pack(v.detach(), g.detach())
+        holder.w, holder.wp, holder.wpT = w, wp, wpT
+        ctx.save_for_backward(v, g)
+        return w
+
+    @staticmethod
+    def backward(ctx, dW):
+        v, g = ctx.saved_tensors
+        dv, dg = ops.fold_backward(v.detach(), g.detach(), dW.contiguous())
+        return dv, dg.view_as(g), None
+
+
+def fold_network(vs, gs, bs, skip_layer, multires):
+    """-> (PackedNet, [w tensors linked to autograd], [bias params])"""
+    layers, ws = [], []
+    for v, g, b in zip(vs, gs, bs):
+        L = ops.PackedLayer()
+        w = _Fold.apply(v, g, L)
+        L.bias = b.detach()
+        L.N, L.K = v.shape
+        layers.append(L)
+        ws.append(w)
+    return ops.PackedNet(layers, skip_layer, multires), ws, list(bs)
+
+
+class SharedSdfEval:
+    """What one fused evaluation leaves behind for the backward passes and for re-use at the same points."""
+    __slots__ = ('net', 'x', 'M', 'Mg', 'n_active', 'saved', 'y', 'n')
+
+
+class _SdfValueNormal(torch.autograd.Function):
+    """x[M,3] -> y[M, 1+1+F], n[Mg,3]   (ImplicitNetwork.forward + .gradient, idr.py:77-107).
+    Rows >= n_active are known not to receive gradients (non-hit rays): the backward skips them."""
+
+    @staticmethod
+    def forward(ctx, x, shared, *wb):
+        y, n, saved = ops.sdf_forward(shared.net, x.detach(), shared.Mg)
+        shared.x, shared.saved, shared.y, shared.n = x.detach(), saved, y, n
+        ctx.shared = shared
+        ctx.nl = len(wb) // 2
+        ctx.x_needs_grad = x.requires_grad
+        return y, n
+
+    @staticmethod
+    def backward(ctx, dy, dn):
+        sh = ctx.shared
+        Mb = sh.n_active
+        if Mb == 0:
+            return (None, None) + tuple(torch.zeros_like(L.w) for L in sh.net.layers) + tuple(torch.zeros_like(L.bias) for L in sh.net.layers)
+        Nout = sh.net.layers[-1].N
+        dyb = dy[:Mb].contiguous() if dy is not None else torch.zeros(Mb, Nout, device=sh.x.device)
+        dnb = None
+        if dn is not None and sh.Mg > 0:
+            mg = min(Mb, sh.Mg)
+            if mg < Mb:                                  # normals cover a shorter prefix: split by linearity
+                dWa, dba, dxa = ops.sdf_backward(sh.net, sh.x, sh.M, sh.Mg, mg, dyb[:mg].contiguous(), dn[:mg].contiguous(), sh.saved,
+                                                 ctx.x_needs_grad)
+                rest = dyb.clone()
+                rest[:mg] = 0
+                dWb, dbb, dxb = ops.sdf_backward(sh.net, sh.x, sh.M, sh.Mg, Mb, rest, None, sh.saved, ctx.x_needs_grad)
+                dWs = [a + b for a, b in zip(dWa, dWb)]
+                dbs = [a + b for a, b in zip(dba, dbb)]
+                dx = None
+                if ctx.x_needs_grad:
+                    dx = torch.zeros_like(sh.x)
+                    dx[:Mb] = dxb
+                    dx[:mg] += dxa
+                return (dx, None) + tuple(dWs) + tuple(dbs)
+            dnb = dn[:Mb].contiguous()
+        dWs, dbs, dxb = ops.sdf_backward(sh.net, sh.x, sh.M, sh.Mg, Mb, dyb, dnb, sh.saved, ctx.x_needs_grad)
+        dx = None
+        if ctx.x_needs_grad:
+            dx = torch.zeros_like(sh.x)
+            dx[:Mb] = dxb
+        return (dx, None) + tuple(dWs) + tuple(dbs)
+
+
+def sdf_value_normal(net, ws, bs, x, Mg, n_active=None):
+    sh = SharedSdfEval()
+    sh.net, sh.M, sh.Mg = net, x.shape[0], Mg
+    sh.n_active = x.shape[0] if n_active is None else n_active
+    y, n = _SdfValueNormal.apply(x, sh, *ws, *bs)
+    return y, n, sh
+
+
+class _SdfReuse(torch.autograd.Function):
+    """Value + normal at points that are numerically the first N rows of an earlier evaluation (the differentiable
+    surface points x(theta) equal the traced points: sample_network.py:14 with f - f0 == 0).  Forward re-uses the stored
+    outputs; backward runs the full first/second-order backward on those rows, including d/dx (idr.py:325-326)."""
+
+    @staticmethod
+    def forward(ctx, pts, shared, N, *wb):
+        ctx.shared, ctx.N = shared, N
+        return shared.y[:N].clone(), shared.n[:N].clone()
+
+    @staticmethod
+    def backward(ctx, dy, dn):
+        sh, N = ctx.shared, ctx.N
+        Nout = sh.net.layers[-1].N
+        dyb = dy.contiguous() if dy is not None else torch.zeros(N, Nout, device=sh.x.device)
+        dnb = dn.contiguous() if dn is not None else None
+        dWs, dbs, dx = ops.sdf_backward(sh.net, sh.x, sh.M, sh.Mg, N, dyb, dnb, sh.saved, True)
+        return (dx, None, None) + tuple(dWs) + tuple(dbs)
+
+
+def sdf_reuse(shared, ws, bs, pts, N):
+    return _SdfReuse.apply(pts, shared, N, *ws, *bs)
+
+
+class _Render(torch.autograd.Function):
+    """RenderingNetwork.forward, mode 'idr' (idr.py:145-167)."""
+
+    @staticmethod
+    def forward(ctx, points, normals, view, feat, net, multires_view, *wb):
+        N = points.shape[0]
+        fd = feat.detach()
+        if fd.stride(1) != 1:
+            fd = fd.contiguous()
+        rgb, saved = ops.render_forward(net, points.detach(), view.detach(), normals.detach(), fd, multires_view)
+        ctx.net, ctx.saved, ctx.N, ctx.mv = net, saved, N, multires_view
+        ctx.needs = (points.requires_grad, normals.requires_grad, feat.requires_grad)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, drgb):
+        dWs, dbs, din = ops.render_backward(ctx.net, ctx.N, drgb.contiguous(), ctx.saved)
+        dv = 3 + 6 * ctx.mv
+        dp = din[:, 0:3] if ctx.needs[0] else None
+        dn = din[:, 3 + dv:6 + dv] if ctx.needs[1] else None
+        df = din[:, 6 + dv:] if ctx.needs[2] else None
+        return (dp, dn, None, df, None, None) + tuple(dWs) + tuple(dbs)
+
+
+def render(net, ws, bs, points, normals, view, feat, multires_view):
+    return _Render.apply(points, normals, view, feat, net, multires_view, *ws, *bs)
+
+
+class _FeatCorr(torch.autograd.Function):
+    """IDRLoss.get_feat_loss_corr (loss.py:115-165): loss and d/d(points) come out of one kernel launch."""
+
+    @staticmethod
+    def forward(ctx, pts, view_start, feat, feat_src, cam, src_cams, size, center):
+        loss_pp, dpts = ops.feat_corr(pts.detach(), view_start, feat, feat_src, cam, src_cams, size, center)
+        ctx.save_for_backward(dpts)
+        return loss_pp.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpts,) = ctx.saved_tensors
+        return dpts * g, None, None, None, None, None, None, None
+
+
+def feat_corr_loss(pts, view_start, feat, feat_src, cam, src_cams, size, center):
+    return _FeatCorr.apply(pts, view_start, feat, feat_src, cam, src_cams, size, center)

@@ -1,0 +1,290 @@
+"""IDRNetwork / ImplicitNetwork / RenderingNetwork with the reference's constructors, forward signatures, output dict
+and state_dict layout (reference code/model/implicit_differentiable_renderer.py:19-338), executed by HIP kernels.
+
+What differs from the reference internally (results are the same, see tests/):
+  * weight_norm is folded once per forward by a HIP kernel (the reference refolds in each of ~57 network calls);
+  * the whole RayTracing.forward is two kernel launches (csrc/trace.hip);
+  * the five autograd MLP passes of idr.py:202,256,275,325,326 over overlapping point sets are ONE fused
+    value + normal evaluation on rows ordered [hit rays | sample points | non-hit rays]; the re-evaluation at the
+    differentiable surface points (idr.py:325-326) re-uses it, and both backward passes run the hand-written
+    first/second-order backward on row prefixes.
+"""
+import importlib
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from ..utils import rend_util
+from . import conf as _default_conf
+from .ray_tracing import NativeSDF, RayTracing
+from .sample_network import SampleNetwork
+
+conf = _default_conf
+if os.environ.get('IDR_USE_ENV', '0') == '1' and os.environ.get('IDR_CONF', '') != '':
+    print('override conf: ', os.environ.get('IDR_CONF'))
+    conf = importlib.import_module(os.environ.get('IDR_CONF'))
+
+
+class _WNLinear(nn.Module):
+    """Parameters of a weight-normed nn.Linear in torch.nn.utils.weight_norm's layout: bias, weight_g [out,1], weight_v [out,in]."""
+
+    def __init__(self, weight, bias):
+        super().__init__()
+        self.bias = nn.Parameter(bias)
+        self.weight_g = nn.Parameter(weight.norm(dim=1, keepdim=True))
+        self.weight_v = nn.Parameter(weight)
+
+    @property
+    def weight(self):
+        return self.weight_v * (self.weight_g / self.weight_v.norm(dim=1, keepdim=True))
+
+
+def _linear_default_init(in_f, out_f):
+    lin = nn.Linear(in_f, out_f)
+    return lin.weight.detach().clone(), lin.bias.detach().clone()
+
+
+class ImplicitNetwork(nn.Module):
+    def __init__(self, feature_vector_size, d_in, d_out, dims, geometric_init=True, bias=1.0, skip_in=(), weight_norm=True, multires=0):
+        super().__init__()
+        if not weight_norm:
+            raise NotImplementedError('the native path implements weight_norm=True (mvsdf_dtu.conf:28)')
+        if d_in != 3 or multires <= 0:
+            raise NotImplementedError('the native SDF kernels assume d_in=3 with positional encoding (mvsdf_dtu.conf:22,29)')
+        dims = [d_in] + list(dims) + [d_out + 1 + feature_vector_size]
+        self.multires = multires
+        dims[0] = 3 + 6 * multires
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        if len(self.skip_in) > 1:
+            raise NotImplementedError('one skip connection is supported (mvsdf_dtu.conf:27)')
+        self.d_out = d_out
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            w, b = _linear_default_init(dims[l], out_dim)
+            if geometric_init:                                   # idr.py:53-68
+                if l == self.num_layers - 2:
+                    nn.init.normal_(w, mean=np.sqrt(np.pi) / np.sqrt(dims[l]), std=0.0001)
+                    nn.init.constant_(b, -bias)
+                elif l == 0:
+                    nn.init.constant_(b, 0.0)
+                    nn.init.constant_(w[:, 3:], 0.0)
+                    nn.init.normal_(w[:, :3], 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                elif l in self.skip_in:
+                    nn.init.constant_(b, 0.0)
+                    nn.init.normal_(w, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                    nn.init.constant_(w[:, -(dims[0] - 3):], 0.0)
+                else:
+                    nn.init.constant_(b, 0.0)
+                    nn.init.normal_(w, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+            setattr(self, 'lin' + str(l), _WNLinear(w, b))
+
+    def _lins(self):
+        return [getattr(self, 'lin' + str(l)) for l in range(self.num_layers - 1)]
+
+    def fold(self):
+        """-> (PackedNet, folded weights linked to autograd, biases)."""
+        lins = self._lins()
+        return Fn.fold_network([m.weight_v for m in lins], [m.weight_g for m in lins], [m.bias for m in lins],
+                               self.skip_in[0] if self.skip_in else -1, self.multires)
+
+    def native_sdf(self):
+        return NativeSDF(self.fold()[0])
+
+    def forward(self, input, compute_grad=False):
+        net, ws, bs = self.fold()
+        y, _, _ = Fn.sdf_value_normal(net, ws, bs, input, 0)
+        return y
+
+    def gradient(self, x):
+        x.requires_grad_(True)                                  # side effect kept (idr.py:97)
+        net, ws, bs = self.fold()
+        _, n, _ = Fn.sdf_value_normal(net, ws, bs, x, x.shape[0])
+        return n.unsqueeze(1)
+
+
+class RenderingNetwork(nn.Module):
+    def __init__(self, feature_vector_size, mode, d_in, d_out, dims, weight_norm=True, multires_view=0):
+        super().__init__()
+        if mode != 'idr' or not weight_norm:
+            raise NotImplementedError("the native path implements mode='idr', weight_norm=True (mvsdf_dtu.conf:33-37)")
+        self.mode = mode
+        self.multires_view = multires_view
+        dims = [d_in + feature_vector_size] + list(dims) + [d_out]
+        if multires_view > 0:
+            dims[0] += 6 * multires_view
+        self.num_layers = len(dims)
+        for l in range(self.num_layers - 1):
+            w, b = _linear_default_init(dims[l], dims[l + 1])
+            setattr(self, 'lin' + str(l), _WNLinear(w, b))
+
+    def fold(self):
+        lins = [getattr(self, 'lin' + str(l)) for l in range(self.num_layers - 1)]
+        return Fn.fold_network([m.weight_v for m in lins], [m.weight_g for m in lins], [m.bias for m in lins], -1, 0)
+
+    def forward(self, points, normals, view_dirs, feature_vectors, folded=None):
+        net, ws, bs = folded if folded is not None else self.fold()
+        return Fn.render(net, ws, bs, points, normals, view_dirs, feature_vectors, self.multires_view)
+
+
+class IDRNetwork(nn.Module):
+    def __init__(self, conf):
+        super().__init__()
+        self.feature_vector_size = conf.get_int('feature_vector_size')
+        self.implicit_network = ImplicitNetwork(self.feature_vector_size, **conf.get_config('implicit_network'))
+        self.rendering_network = RenderingNetwork(self.feature_vector_size, **conf.get_config('rendering_network'))
+        self.ray_tracer = RayTracing(**conf.get_config('ray_tracer'))
+        self.sample_network = SampleNetwork()
+        self.object_bounding_sphere = conf.get_float('ray_tracer.object_bounding_sphere')
+        self.last_stats = {}
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _dsurf_samples(self, input, n_dsurf_points, bb):
+        """Phase-0 depth-surface sampling (idr.py:226-247): unproject every depth pixel, normalise, jitter, subsample."""
+        from ..utils.my_utils import get_pixel_grids, idx_cam2world, idx_img2cam
+        depths, depth_cams = input['depths'], input['depth_cams']
+        center, size = input['center'][:1], input['size'][:1]
+        depths_pack, cams_pack = [a.view(-1, *a.size()[2:]) for a in (depths, depth_cams)]
+        hom = idx_cam2world(idx_img2cam(get_pixel_grids(*depths.size()[-2:], device=depths.device).unsqueeze(0), depths_pack, cams_pack), cams_pack)
+        pts = hom[depths_pack[:, 0] > 0][:, :3, 0]
+        pts_n = (pts - center) / size * 2
+        jitter_rad = 0.1
+        jit = pts_n + torch.rand_like(pts_n) * jitter_rad * 2 - jitter_rad
+        out = []
+        for ds in (pts_n, jit):
+            inbound = ds[(ds.abs() < bb).float().sum(-1) > 2.9]
+            idx = np.sort(np.random.choice(inbound.size()[0], n_dsurf_points, replace=False))
+            out.append(inbound[torch.from_numpy(idx).to(ds.device)])
+        return out
+
+    def forward(self, input, train_progress=None):
+        intrinsics, uv, pose = input['intrinsics'], input['uv'], input['pose']
+        object_mask_true = input['object_mask'].reshape(-1)
+        object_mask = object_mask_true if conf.use_mask else torch.ones_like(object_mask_true)
+
+        ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
+        batch_size, num_pixels, _ = ray_dirs.shape
+        R = batch_size * num_pixels
+        dev = ray_dirs.device
+
+        net, ws, bs = self.implicit_network.fold()              # one weight-norm fold per step
+        with torch.no_grad():
+            points, network_object_mask, dists = self.ray_tracer(sdf=NativeSDF(net), cam_loc=cam_loc, object_mask=object_mask,
+                                                                 ray_directions=ray_dirs)
+        ray_dirs = ray_dirs.reshape(-1, 3)
+
+        surface_mask = (network_object_mask & object_mask) if self.training else network_object_mask
+        # rows: [surface rays | sample points | the other rays]  (stable order inside each group = the reference's boolean-mask order)
+        perm = torch.sort((~surface_mask).to(torch.int8), stable=True).indices
+        N = int(surface_mask.sum().item())                      # the one host sync of the forward: output shapes depend on it
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(R, device=dev)
+        hit_idx, rest_idx = perm[:N], perm[N:]
+        cam_rays = cam_loc.unsqueeze(1).expand(batch_size, num_pixels, 3).reshape(-1, 3)
+
+        if self.training:
+            assert train_progress is not None
+            bb = self.object_bounding_sphere
+            n_eik_points = R // 2
+            eikonal_points = torch.empty(n_eik_points, 3).uniform_(-bb, bb).to(dev, non_blocking=True)     # idr.py:216-221
+            use_dsurf = any([conf.d_use_dsurf_on(train_progress), conf.d_use_dsurf_jitter(train_progress),
+                             conf.eik_use_dsurf_on(train_progress), conf.eik_use_dsurf_jitter(train_progress)])
+            if use_dsurf:
+                n_dsurf_points = R // 2
+                dsurf_on_sample, dsurf_jitter_sample = self._dsurf_samples(input, n_dsurf_points, bb)
+            else:
+                n_dsurf_points = 0
+                dsurf_on_sample = torch.zeros(0, 3, device=dev)
+                dsurf_jitter_sample = torch.zeros(0, 3, device=dev)
+            E = n_eik_points + 2 * n_dsurf_points
+            x_all = torch.cat([points[hit_idx], eikonal_points, dsurf_on_sample, dsurf_jitter_sample, points[rest_idx]], 0)
+            y_all, n_all, shared = Fn.sdf_value_normal(net, ws, bs, x_all, N + E, n_active=N + E)
+            sdf_output = torch.cat([y_all[:N, :1], y_all[N + E:, :1]], 0)[inv]                               # idr.py:202-203, ray order
+            points_all = x_all[:N + E]
+            output = y_all[N:N + E]
+            surface_output = y_all[:N, :1]
+            surface_sdf_values = surface_output.detach()
+            surface_dists = dists[hit_idx].unsqueeze(-1)
+            surface_ray_dirs = ray_dirs[hit_idx]
+            surface_cam_loc = cam_rays[hit_idx]
+
+            o1, o2 = n_eik_points, n_eik_points + n_dsurf_points
+            eik_out, eik_pts = [], []
+            if conf.d_use_rt_surf(train_progress):
+                eik_out.append(surface_output); eik_pts.append(points_all[:N])
+            if conf.d_use_eik(train_progress):
+                eik_out.append(output[:o1, :1]); eik_pts.append(points_all[N:N + o1])
+            if conf.d_use_dsurf_on(train_progress):
+                eik_out.append(output[o1:o2, :1]); eik_pts.append(points_all[N + o1:N + o2])
+            if conf.d_use_dsurf_jitter(train_progress):
+                eik_out.append(output[o2:o2 + n_dsurf_points, :1]); eik_pts.append(points_all[N + o2:N + o2 + n_dsurf_points])
+            eikonal_output = torch.cat(eik_out, 0).view(1, -1)
+            eikonal_points_hom = torch.cat(eik_pts, 0)
+            eikonal_points_hom = torch.cat([eikonal_points_hom, torch.ones_like(eikonal_points_hom[:, -1:])], -1).view(1, -1, 4, 1)
+
+            surf_indicator_output = torch.cat([y_all[:N, 1][object_mask_true[hit_idx]], output[:n_eik_points, 1]], 0)   # idr.py:272
+
+            g = n_all                                                                                       # idr.py:275
+            surface_points_grad = g[:N].detach()
+            gl = []
+            if conf.eik_use_rt_surf(train_progress):
+                gl.append(g[:N])
+            if conf.eik_use_eik(train_progress):
+                gl.append(g[N:N + o1])
+            if conf.eik_use_dsurf_on(train_progress):
+                gl.append(g[N + o1:N + o2])
+            if conf.eik_use_dsurf_jitter(train_progress):
+                gl.append(g[N + o2:N + o2 + n_dsurf_points])
+            grad_theta = torch.cat(gl, 0)
+
+            differentiable_surface_points = self.sample_network(surface_output, surface_sdf_values, surface_points_grad, surface_dists,
+                                                                surface_cam_loc, surface_ray_dirs)
+        else:
+            x_all = torch.cat([points[hit_idx], points[rest_idx]], 0)
+            y_all, n_all, shared = Fn.sdf_value_normal(net, ws, bs, x_all, N, n_active=N)
+            sdf_output = y_all[:, :1][inv]
+            differentiable_surface_points = x_all[:N]
+            grad_theta = None
+
+        view = -ray_dirs[hit_idx]
+        rgb_values = torch.ones_like(points)
+        if N > 0:
+            rgb = self._rgb_from_shared(shared, ws, bs, differentiable_surface_points, view, N, train_progress)
+            rgb_values = rgb_values.index_put((hit_idx,), rgb)                                               # idr.py:302-304
+
+        out = {
+            'points': points,
+            'diff_surf_pts': differentiable_surface_points,
+            'rgb_values': rgb_values,
+            'sdf_output': sdf_output,
+            'network_object_mask': network_object_mask,
+            'object_mask': object_mask,
+            'object_mask_true': object_mask_true,
+            'grad_theta': grad_theta,
+        }
+        if self.training:
+            out['eikonal_points_hom'] = eikonal_points_hom
+            out['eikonal_output'] = eikonal_output
+            out['surf_indicator_output'] = surf_indicator_output
+        self.last_stats = {'R': R, 'N': N, 'E': (x_all.shape[0] - R), 'counters': self.ray_tracer.last_counters}
+        return out
+
+    def _rgb_from_shared(self, shared, ws, bs, points, view_dirs, N, train_progress):
+        y2, normals = Fn.sdf_reuse(shared, ws, bs, points, N)                                               # idr.py:325-327
+        feature_vectors = y2[:, 2:]
+        if (train_progress is not None and train_progress < conf.phase[0]) or conf.disable_rgb_grad:         # idr.py:331-334
+            points, normals, view_dirs = [a.detach() for a in (points, normals, view_dirs)]
+        return self.rendering_network(points, normals, view_dirs, feature_vectors)
+
+    def get_rbg_value(self, points, view_dirs, train_progress):
+        """Stand-alone form (idr.py:324-338): evaluates the SDF net at `points` afresh."""
+        net, ws, bs = self.implicit_network.fold()
+        N = points.shape[0]
+        y, normals, _ = Fn.sdf_value_normal(net, ws, bs, points, N)
+        feature_vectors = y[:, 2:]
+        if (train_progress is not None and train_progress < conf.phase[0]) or conf.disable_rgb_grad:
+            points, normals, view_dirs = [a.detach() for a in (points, normals, view_dirs)]
+        return self.rendering_network(points, normals, view_dirs, feature_vectors)

@@ -1,0 +1,65 @@
+"""RayTracing with the reference's constructor and forward signature (reference code/model/ray_tracing.py:7-98),
+executed by the HIP tracer (csrc/trace.hip) in one C call: no per-iteration launches, no host syncs."""
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class NativeSDF:
+    """The `sdf` callable handed to RayTracing.forward by IDRNetwork: callable like the reference's lambda
+    (idr.py:194) but also carries the folded, MFMA-packed weights the native tracer needs."""
+
+    def __init__(self, packed_net):
+        self.native_net = packed_net
+
+    def __call__(self, x):
+        return ops.sdf_col0(self.native_net, x)
+
+
+class RayTracing(nn.Module):
+    def __init__(self, object_bounding_sphere=1.0, sdf_threshold=5.0e-5, line_search_step=0.5, line_step_iters=1,
+                 sphere_tracing_iters=10, n_steps=100, n_secant_steps=8):
+        super().__init__()
+        self.object_bounding_sphere = object_bounding_sphere
+        self.sdf_threshold = sdf_threshold
+        self.sphere_tracing_iters = sphere_tracing_iters
+        self.line_step_iters = line_step_iters
+        self.line_search_step = line_search_step
+        self.n_steps = n_steps
+        self.n_secant_steps = n_secant_steps
+        self.last_counters = None           # device int64[16]: MLP rows per stage (include/mvsdf_hip.h MVSDF_CNT_*)
+        self.mt = None                      # row tiles per workgroup (None: pick from the ray count)
+        self.rpw = None
+
+    def _params(self):
+        if os.environ.get('IDR_USE_ENV', '0') == '1' and os.environ.get('IDR_RENDER', '0') == '1':
+            dist_clip, iters = 0.05, 40                                        # ray_tracing.py:127-131
+        else:
+            dist_clip, iters = 0.5, self.sphere_tracing_iters
+        return (self.object_bounding_sphere, self.sdf_threshold, self.line_search_step, self.line_step_iters, iters,
+                self.n_steps, self.n_secant_steps, dist_clip)
+
+    def forward(self, sdf, cam_loc, object_mask, ray_directions, minsdf_steps=None):
+        """-> (points[R,3], network_object_mask[R] bool, dists[R]).
+        minsdf_steps: the n_steps uniform draws of minimal_sdf_points (ray_tracing.py:287); drawn here from torch's CPU
+        generator when not given -- always, whereas the reference draws only if some ray needs them."""
+        net = getattr(sdf, 'native_net', None)
+        if net is None:
+            raise TypeError('the native tracer needs the SDF weights: pass ImplicitNetwork.native_sdf() (a callable carrying the '
+                            'folded MFMA-packed network) instead of an opaque Python callable')
+        dev = ray_directions.device
+        intervals = torch.linspace(0, 1, steps=self.n_steps).to(dev)           # ray_tracing.py:206 (CPU values, like the reference)
+        if self.training and minsdf_steps is None:
+            minsdf_steps = torch.empty(self.n_steps).uniform_(0.0, 1.0)
+        if minsdf_steps is not None:
+            minsdf_steps = minsdf_steps.to(dev, non_blocking=True)
+        R = ray_directions.shape[0] * ray_directions.shape[1]
+        mt = self.mt or (1 if R <= 4096 else 2)
+        rpw = self.rpw or (2 if R <= 4096 else 4)
+        pts, mask, dists, counters = ops.trace(net, cam_loc, ray_directions, object_mask, self._params(), self.training, intervals,
+                                               minsdf_steps, mt=mt, rpw=rpw)
+        self.last_counters = counters
+        return pts, mask, dists

@@ -86,6 +86,16 @@ def camera_rays(uv, pose, intrinsics):
     return dirs, cam
 
 
+def sphere_intersection(cam_loc, ray_dirs, r=1.0):
+    cam_loc, ray_dirs = _f32(cam_loc), _f32(ray_dirs)
+    B, P = ray_dirs.shape[:2]
+    t = torch.empty(B, P, 2, dtype=torch.float32, device=ray_dirs.device)
+    m = torch.empty(B, P, dtype=torch.uint8, device=ray_dirs.device)
+    check(lib().mvsdf_sphere_intersection(ptr(cam_loc), ptr(ray_dirs), B, P, C.c_float(r), ptr(t), ptr(m), stream_of(ray_dirs)),
+          'mvsdf_sphere_intersection')
+    return t, m.bool()
+
+
 def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, minsdf_steps=None, mt=2, rpw=2):
     """RayTracing.forward on the device -> (points[R,3], mask[R] bool, dists[R], counters[16] int64 device tensor)."""
     cam_loc, ray_dirs = _f32(cam_loc), _f32(ray_dirs)
@@ -178,3 +188,34 @@ def render_backward(net, N, drgb, ctx):
                                       stream_of(drgb)), 'mvsdf_render_backward')
     dWs, dbs = _split_cat(net, dW, db)
     return dWs, dbs, din
+
+
+def feat_corr(pts, view_start, feat, feat_src, cam, src_cams, size, center):
+    """-> (loss_pp[N], dpts[N,3]).  feat [B,C,H,W], feat_src [B,V,C,H,W] with any strides (NCHW / channels_last)."""
+    pts = _f32(pts)
+    N, dev = pts.shape[0], pts.device
+    B, Cc, H, W = feat.shape
+    V = feat_src.shape[1]
+    assert feat.dtype == torch.float32 and feat_src.dtype == torch.float32 and feat.is_cuda and feat_src.is_cuda
+    fs = (C.c_longlong * 4)(*feat.stride())
+    ss = (C.c_longlong * 5)(*feat_src.stride())
+    loss_pp = torch.empty(N, dtype=torch.float32, device=dev)
+    dpts = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    vs = view_start.to(torch.int32).contiguous()
+    check(lib().mvsdf_feat_corr(ptr(pts), N, ptr(vs), B, V, Cc, H, W, C.c_void_p(feat.data_ptr()), fs, C.c_void_p(feat_src.data_ptr()), ss,
+                                ptr(_f32(cam)), ptr(_f32(src_cams)), ptr(_f32(size).reshape(-1)), ptr(_f32(center).reshape(-1)),
+                                ptr(loss_pp), ptr(dpts), stream_of(pts)), 'mvsdf_feat_corr')
+    return loss_pp, dpts
+
+
+def depth_carve(pts, depths, cams, size, center, out_thresh_perc, far_thresh, far_att, near_thresh, near_att):
+    """pts [M,3] normalised; depths [B,h,w]; cams [B,2,4,4] -> (dist_r[M], weight[M])."""
+    pts, depths, cams = _f32(pts), _f32(depths), _f32(cams)
+    M, dev = pts.shape[0], pts.device
+    B, h, w = depths.shape
+    dist_r = torch.empty(M, dtype=torch.float32, device=dev)
+    weight = torch.empty(M, dtype=torch.float32, device=dev)
+    check(lib().mvsdf_depth_carve(ptr(pts), M, ptr(depths), B, h, w, ptr(cams), ptr(_f32(size).reshape(-1)), ptr(_f32(center).reshape(-1)),
+                                  C.c_float(out_thresh_perc), C.c_float(far_thresh), C.c_float(far_att), C.c_float(near_thresh),
+                                  C.c_float(near_att), ptr(dist_r), ptr(weight), stream_of(pts)), 'mvsdf_depth_carve')
+    return dist_r, weight
