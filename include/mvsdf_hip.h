@@ -90,6 +90,12 @@ int mvsdf_trace(const MvsdfNetDesc* net, const MvsdfTraceParams* tp, const float
                 const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
                 float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
                 size_t workspace_bytes, int mt, int rpw, void* stream);
+/* the two kernel launches of mvsdf_trace separately (stage 1: sphere tracing, zeroes the counters; stage 2: ray sampler +
+ * secant + min-sdf), same arguments and workspace -- lets a caller bracket each kernel with events. */
+int mvsdf_trace_stage(int stage, const MvsdfNetDesc* net, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
+                      const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
+                      float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
+                      size_t workspace_bytes, int mt, int rpw, void* stream);
 
 /* ---- differentiable SDF network: value + normal and their first/second-order backward ----
  * Replaces ImplicitNetwork.forward / .gradient (idr.py:77-107) and autograd's (double) backward through them.

@@ -33,6 +33,7 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise MvsdfError('libmvsdf_hip.so not found at %s -- run `python -c "import __graft_entry__ as g; g.build()"` '
                              '(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback for the hot path' % SO_PATH)
+        import torch  # noqa: F401  -- load torch's bundled HIP runtime first so this library binds to the same libamdhip64
         L = C.CDLL(SO_PATH)
         L.mvsdf_last_error.restype = C.c_char_p
         L.mvsdf_packed_floats.restype = C.c_size_t
@@ -50,7 +51,7 @@ def lib():
 # every symbol include/mvsdf_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
 EXPORTS = [
     'mvsdf_version', 'mvsdf_last_error', 'mvsdf_packed_floats', 'mvsdf_fold_pack', 'mvsdf_fold_backward',
-    'mvsdf_sdf_col0', 'mvsdf_camera_rays', 'mvsdf_sphere_intersection', 'mvsdf_trace_workspace_bytes', 'mvsdf_trace', 'mvsdf_det_math',
+    'mvsdf_sdf_col0', 'mvsdf_camera_rays', 'mvsdf_sphere_intersection', 'mvsdf_trace_workspace_bytes', 'mvsdf_trace', 'mvsdf_trace_stage', 'mvsdf_det_math',
     'mvsdf_sdf_ctx_floats', 'mvsdf_sdf_forward', 'mvsdf_sdf_bwd_ws_floats', 'mvsdf_sdf_backward',
     'mvsdf_feat_corr', 'mvsdf_depth_carve',
     'mvsdf_render_ctx_floats', 'mvsdf_render_bwd_ws_floats', 'mvsdf_render_forward', 'mvsdf_render_backward',

@@ -4,15 +4,23 @@
 #include "trace_params.h"
 #include "capi_util.h"
 
-// ---- weight norm (idr.py:70-71): one thread per output row, k-ascending fmaf chain (bit-exact vs the CPU restatement) ----
-__global__ void k_fold(const float* __restrict__ v, const float* __restrict__ g, int N, int K, float* __restrict__ w) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- weight norm (idr.py:70-71): one wave per output row.  The row is loaded coalesced; lane 0 then walks it through
+// v_readlane in ascending k -- the SAME k-ascending fmaf chain as the CPU restatement (bit-exact), at ~1 us per row. ----
+__global__ __launch_bounds__(256) void k_fold(const float* __restrict__ v, const float* __restrict__ g, int N, int K, float* __restrict__ w) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= N) return;
     const float* vr = v + (size_t)j * K;
     float ss = 0.0f;
-    for (int k = 0; k < K; ++k) ss = fmaf(vr[k], vr[k], ss);
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const float mine = (k0 + lane < K) ? vr[k0 + lane] : 0.0f;
+        const int n = min(64, K - k0);
+        for (int i = 0; i < n; ++i) {
+            const float x = __shfl(mine, i);
+            ss = fmaf(x, x, ss);
+        }
+    }
     const float a = g[j] / sqrtf(ss);
-    for (int k = 0; k < K; ++k) w[(size_t)j * K + k] = vr[k] * a;
+    for (int k = lane; k < K; k += 64) w[(size_t)j * K + k] = vr[k] * a;
 }
 
 // wp[ct][kb][lane][s] = W[ct*16 + (lane&15)][kb*16 + 4s + (lane>>4)];  transposed=1 packs W^T ([K][N] seen as out=K, in=N)
@@ -151,7 +159,7 @@ size_t mvsdf_packed_floats(int N, int K) { return mv_packed_floats(N, K); }
 int mvsdf_fold_pack(const float* v, const float* g, int N, int K, float* w, float* wp, float* wpT, void* stream) {
     if (!v || !g || N <= 0 || K <= 0 || !w) return mv_fail(-1, "mvsdf_fold_pack: bad arguments (w must be given)");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_fold, dim3((N + 63) / 64), dim3(64), 0, s, v, g, N, K, w);
+    hipLaunchKernelGGL(k_fold, dim3((N + 3) / 4), dim3(256), 0, s, v, g, N, K, w);
     const size_t total = mv_packed_floats(N, K);
     const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     if (wp) hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, s, w, N, K, 0, wp);

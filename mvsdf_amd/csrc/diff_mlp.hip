@@ -123,7 +123,7 @@ static int stride_for(const MvNet& a, const MvNet& b) { return a.S > b.S ? a.S :
 // layout of the forward context / backward workspace (floats)
 struct SdfLayout {
     int nl, d0, ld0;                 // layers, PE width, padded PE row
-    size_t H0, A[MV_MAXL], Z[MV_MAXL], U[MV_MAXL], E, G0, total;
+    size_t H0, A[MV_MAXL], Z[MV_MAXL], U[MV_MAXL], Sg[MV_MAXL], E, G0, total;
 };
 static SdfLayout sdf_ctx_layout(const MvNet& net, int M, int Mg) {
     SdfLayout o;
@@ -134,6 +134,7 @@ static SdfLayout sdf_ctx_layout(const MvNet& net, int M, int Mg) {
     for (int l = 1; l < o.nl; ++l) { o.A[l] = p; p += (size_t)M * net.L[l].K; }
     for (int l = 0; l < o.nl - 1; ++l) { o.Z[l] = p; p += (size_t)M * net.L[l].N; }
     for (int l = 1; l < o.nl - 1; ++l) { o.U[l] = p; p += (size_t)Mg * net.L[l - 1].N; }   // u_l, width out_{l-1}
+    for (int l = 0; l < o.nl - 1; ++l) { o.Sg[l] = p; p += (size_t)Mg * net.L[l].N; }      // s_l = sigma_l . u_{l+1}
     o.E = p; p += (size_t)Mg * o.ld0;
     o.G0 = p; p += (size_t)Mg * o.ld0;
     o.total = p;
@@ -157,30 +158,34 @@ static SdfBwdLayout sdf_bwd_layout(const MvNet& net, int Mb) {
     o.HB[0] = p; p += (size_t)Mb * maxw;
     o.HB[1] = p; p += (size_t)Mb * maxw;
     o.H0B = p; p += (size_t)Mb * ld0;
-    o.chunk = 512;
+    o.chunk = 128;
     o.nchunks = (Mb + o.chunk - 1) / o.chunk;
     if (o.nchunks < 1) o.nchunks = 1;
     o.maxnk = 0;
     for (int l = 0; l < nl; ++l) { const size_t nk = (size_t)net.L[l].N * net.L[l].K; o.maxnk = nk > o.maxnk ? nk : o.maxnk; }
-    o.slabA = p; p += (size_t)o.nchunks * o.maxnk;
-    o.slabB = p; p += (size_t)o.nchunks * o.maxnk;
+    o.slabA = p; p += (size_t)2 * o.nchunks * o.maxnk;           // both pairs' chunks in one slab array
+    o.slabB = p;                                                  // (unused; kept for layout stability)
     o.bslab = p; p += (size_t)o.nchunks * (maxw + 16);
     o.total = p;
     return o;
 }
 
-template <int PMODE>
-static hipError_t launch_wgrad(const float* P, int ldp, const float* U, int ldu, const float* bcast, const float* Q, int ldq, int M, int No,
-                               int Ki, int chunk, int nchunks, float* slab, float* bslab, hipStream_t s) {
+static hipError_t launch_wgrad(const float* P1, int ldp1, const float* Q1, int ldq1, int M1, const float* P2, int ldp2, const float* Q2,
+                               int ldq2, int M2, int No, int Ki, int chunk, float* slab, float* bslab, int* nchunks_total, hipStream_t s) {
     WgradArgs a;
-    a.P = P; a.ldp = ldp; a.U = U; a.ldu = ldu; a.bcast = bcast; a.Q = Q; a.ldq = ldq; a.M = M; a.No = No; a.Ki = Ki;
-    a.chunk = chunk; a.slab = slab; a.bslab = bslab;
-    hipLaunchKernelGGL((k_wgrad<PMODE>), dim3((Ki + 63) / 64, (No + 63) / 64, nchunks), dim3(MV_THREADS), 0, s, a);
+    a.P1 = P1; a.ldp1 = ldp1; a.Q1 = Q1; a.ldq1 = ldq1; a.M1 = M1;
+    a.P2 = P2; a.ldp2 = ldp2; a.Q2 = Q2; a.ldq2 = ldq2; a.M2 = P2 ? M2 : 0;
+    a.No = No; a.Ki = Ki; a.chunk = chunk;
+    a.nchunks1 = (M1 + chunk - 1) / chunk;
+    const int n2 = a.M2 > 0 ? (a.M2 + chunk - 1) / chunk : 0;
+    a.slab = slab; a.bslab = bslab;
+    *nchunks_total = a.nchunks1 + n2;
+    hipLaunchKernelGGL(k_wgrad, dim3((Ki + 63) / 64, (No + 63) / 64, a.nchunks1 + n2), dim3(MV_THREADS), 0, s, a);
     return hipGetLastError();
 }
-static hipError_t launch_reduce(const float* sa, const float* sb, int nchunks, size_t n, float* out, hipStream_t s) {
+static hipError_t launch_reduce(const float* sa, int nchunks, size_t n, float* out, int accumulate, hipStream_t s) {
     const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, s, sa, sb, nchunks, n, out, 0);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, s, sa, (const float*)nullptr, nchunks, n, out, accumulate);
     return hipGetLastError();
 }
 
@@ -235,6 +240,7 @@ int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float
             a.Z = ctx + lo.Z[l]; a.ldz = net.L[l].N;
             const bool top = (l == nl - 2);
             if (top) a.bcast = w8; else { a.U = ctx + lo.U[l + 1]; a.ldu = net.L[l].N; }
+            a.out2 = ctx + lo.Sg[l]; a.ld2 = net.L[l].N;                            // keep s_l for the weight gradient
             if (l == net.skip_layer) {
                 a.csplit = net.L[l].K - lo.d0; a.scale_sqrt2 = 1;
                 a.out0 = ctx + lo.U[l]; a.ld0 = net.L[l - 1].N;
@@ -321,23 +327,21 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         MV_TRY((launch_layer<PRO_ZBAR, EPI_SPLIT>(a, s)));
         cur ^= 1;
     }
-    // ---- weight / bias gradients: W_l += zbar_l^T a_l (+ s_l^T vbar_l)  ----
+    // ---- weight / bias gradients: W_l = zbar_l^T a_l (+ s_l^T vbar_l), one launch per layer ----
     size_t woff = 0, boff = 0;
     for (int l = 0; l < nl; ++l) {
         const int No = net.L[l].N, Ki = net.L[l].K;
         const bool last = (l == nl - 1);
         const float* P = last ? dy : ws + bl.ZB[l];
-        MV_TRY((launch_wgrad<0>(P, No, nullptr, 0, nullptr, Aof(l), ldA(l), Mb, No, Ki, bl.chunk, bl.nchunks, ws + bl.slabA, ws + bl.bslab, s)));
-        const float* sb = nullptr;
-        if (dn && !last) {
-            if (l == nl - 2) MV_TRY((launch_wgrad<2>(ctx + lo.Z[l], No, nullptr, 0, w8, ws + bl.VB[l], ldA(l), Mb, No, Ki, bl.chunk, bl.nchunks, ws + bl.slabB, nullptr, s)));
-            else MV_TRY((launch_wgrad<1>(ctx + lo.Z[l], No, ctx + lo.U[l + 1], No, nullptr, ws + bl.VB[l], ldA(l), Mb, No, Ki, bl.chunk, bl.nchunks, ws + bl.slabB, nullptr, s)));
-            sb = ws + bl.slabB;
-        }
-        MV_TRY(launch_reduce(ws + bl.slabA, sb, bl.nchunks, (size_t)No * Ki, dW_cat + woff, s));
-        MV_TRY(launch_reduce(ws + bl.bslab, nullptr, bl.nchunks, (size_t)No, db_cat + boff, s));
+        const bool two = dn && !last;
+        int nch = 0;
+        MV_TRY(launch_wgrad(P, No, Aof(l), ldA(l), Mb, two ? ctx + lo.Sg[l] : nullptr, No, two ? ws + bl.VB[l] : nullptr, ldA(l), Mb, No, Ki,
+                            bl.chunk, ws + bl.slabA, ws + bl.bslab, &nch, s));
+        MV_TRY(launch_reduce(ws + bl.slabA, nch, (size_t)No * Ki, dW_cat + woff, 0, s));
+        MV_TRY(launch_reduce(ws + bl.bslab, bl.nchunks, (size_t)No, db_cat + boff, 0, s));
         if (last && dn) {                                                          // W_last[0, :] += sum_rows ubar_last   (E.1 end)
-            hipLaunchKernelGGL(k_colsum, dim3((Ki + 63) / 64), dim3(256), 0, s, ws + bl.VB[l], Ki, Mb, Ki, dW_cat + woff, 1);
+            hipLaunchKernelGGL(k_colsum, dim3((Ki + 63) / 64, bl.nchunks), dim3(256), 0, s, ws + bl.VB[l], Ki, Mb, Ki, bl.chunk, ws + bl.slabA);
+            MV_TRY(launch_reduce(ws + bl.slabA, bl.nchunks, (size_t)Ki, dW_cat + woff, 1, s));
         }
         woff += (size_t)No * Ki; boff += No;
     }
@@ -373,7 +377,7 @@ static RenderBwdLayout render_bwd_layout(const MvNet& net, int N) {
         maxnk = nk > maxnk ? nk : maxnk;
         maxw = net.L[l].N > maxw ? net.L[l].N : maxw;
     }
-    o.chunk = 512; o.nchunks = (N + 511) / 512; if (o.nchunks < 1) o.nchunks = 1;
+    o.chunk = 128; o.nchunks = (N + 127) / 128; if (o.nchunks < 1) o.nchunks = 1;
     o.slab = p; p += (size_t)o.nchunks * maxnk;
     o.bslab = p; p += (size_t)o.nchunks * (maxw + 16);
     o.total = p;
@@ -471,10 +475,10 @@ int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, 
     size_t woff = 0, boff = 0;
     for (int l = 0; l < nl; ++l) {
         const int No = net.L[l].N, Ki = net.L[l].K;
-        MV_TRY((launch_wgrad<0>(ws + bl.ZB[l], No, nullptr, 0, nullptr, ctx + lo.A[l], Ki, N, No, Ki, bl.chunk, bl.nchunks, ws + bl.slab,
-                                ws + bl.bslab, s)));
-        MV_TRY(launch_reduce(ws + bl.slab, nullptr, bl.nchunks, (size_t)No * Ki, dW_cat + woff, s));
-        MV_TRY(launch_reduce(ws + bl.bslab, nullptr, bl.nchunks, (size_t)No, db_cat + boff, s));
+        int nch = 0;
+        MV_TRY(launch_wgrad(ws + bl.ZB[l], No, ctx + lo.A[l], Ki, N, nullptr, 0, nullptr, 0, 0, No, Ki, bl.chunk, ws + bl.slab, ws + bl.bslab, &nch, s));
+        MV_TRY(launch_reduce(ws + bl.slab, nch, (size_t)No * Ki, dW_cat + woff, 0, s));
+        MV_TRY(launch_reduce(ws + bl.bslab, bl.nchunks, (size_t)No, db_cat + boff, 0, s));
         woff += (size_t)No * Ki; boff += No;
     }
     return mv_check(hipGetLastError(), "mvsdf_render_backward");

@@ -56,8 +56,12 @@ __device__ __forceinline__ float mv_sigmoid_prime100(float z, float sig) {      
 template <int PRO>
 __device__ __forceinline__ float mv_prologue(const LayerArgs& a, int row, int k) {
     if (PRO == PRO_PLAIN) return a.A[(size_t)row * a.lda + k];
-    if (PRO == PRO_SIG_MUL) return dm_sigmoid100(a.Z[(size_t)row * a.ldz + k]) * a.U[(size_t)row * a.ldu + k];
-    if (PRO == PRO_SIG_BCAST) return dm_sigmoid100(a.Z[(size_t)row * a.ldz + k]) * a.bcast[k];
+    if (PRO == PRO_SIG_MUL || PRO == PRO_SIG_BCAST) {
+        const float u = PRO == PRO_SIG_MUL ? a.U[(size_t)row * a.ldu + k] : a.bcast[k];
+        const float sv = dm_sigmoid100(a.Z[(size_t)row * a.ldz + k]) * u;
+        if (a.out2) a.out2[(size_t)row * a.ld2 + k] = sv;                       // s_l, kept for the weight gradient (E.1)
+        return sv;
+    }
     if (PRO == PRO_ZBAR) {
         float zb = dm_sigmoid100(a.Z[(size_t)row * a.ldz + k]) * a.U[(size_t)row * a.ldu + k];
         if (row < a.Mg && a.A) zb += a.A[(size_t)row * a.lda + k];
@@ -73,8 +77,20 @@ __device__ __forceinline__ float mv_prologue(const LayerArgs& a, int row, int k)
     return 0.0f;
 }
 
+// side inputs of an epilogue element, loaded for ALL of a lane's outputs before any store (stores to possibly-aliasing
+// pointers would otherwise serialise every load behind the previous store)
+struct EpiIn { float z, u, add; };
 template <int EPI>
-__device__ __forceinline__ void mv_epilogue(const LayerArgs& a, int row, int col, float acc) {
+__device__ __forceinline__ EpiIn mv_epilogue_load(const LayerArgs& a, int row, int col) {
+    EpiIn e = {0.f, 0.f, 0.f};
+    if (EPI == EPI_SPLIT) { if (a.add) e.add = a.add[(size_t)row * a.ldadd + col]; }
+    else if (EPI == EPI_SBAR) { e.z = a.Z[(size_t)row * a.ldz + col]; e.u = a.U ? a.U[(size_t)row * a.ldu + col] : a.bcast[col]; }
+    else if (EPI == EPI_RELU_MASK) e.add = a.add[(size_t)row * a.ldadd + col];
+    return e;
+}
+
+template <int EPI>
+__device__ __forceinline__ void mv_epilogue(const LayerArgs& a, int row, int col, float acc, const EpiIn& in) {
     if (EPI == EPI_SOFTPLUS) {
         const float z = acc + a.L.bias[col];
         a.out1[(size_t)row * a.ld1 + col] = z;
@@ -85,14 +101,14 @@ __device__ __forceinline__ void mv_epilogue(const LayerArgs& a, int row, int col
         a.out0[(size_t)row * a.ld0 + col] = acc + a.L.bias[col];
     } else if (EPI == EPI_SPLIT) {
         float v = acc;
-        if (a.add) v += a.add[(size_t)row * a.ldadd + col];
+        if (a.add) v += in.add;
         if (a.scale_sqrt2) v = dm_div_sqrt2(v);
         if (col < a.csplit) a.out0[(size_t)row * a.ld0 + col] = v;
         else a.out1[(size_t)row * a.ld1 + (col - a.csplit)] = v;
     } else if (EPI == EPI_SBAR) {
-        const float z = a.Z[(size_t)row * a.ldz + col];
+        const float z = in.z;
         const float sig = dm_sigmoid100(z);
-        const float u = a.U ? a.U[(size_t)row * a.ldu + col] : a.bcast[col];
+        const float u = in.u;
         float ub = sig * acc;
         if (a.skip_next) ub = dm_div_sqrt2(ub);
         a.out0[(size_t)row * a.ld0 + col] = ub;
@@ -102,7 +118,7 @@ __device__ __forceinline__ void mv_epilogue(const LayerArgs& a, int row, int col
     } else if (EPI == EPI_TANH) {
         a.out0[(size_t)row * a.ld0 + col] = tanhf(acc + a.L.bias[col]);
     } else if (EPI == EPI_RELU_MASK) {
-        a.out0[(size_t)row * a.ld0 + col] = a.add[(size_t)row * a.ldadd + col] > 0.0f ? acc : 0.0f;
+        a.out0[(size_t)row * a.ld0 + col] = in.add > 0.0f ? acc : 0.0f;
     }
 }
 
@@ -113,11 +129,21 @@ __global__ __launch_bounds__(MV_THREADS) void k_layer(LayerArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
     const int row0 = blockIdx.x * ROWS, S = a.S, K = a.L.K, Kp = a.L.KB * 16, N = a.L.N;
     float* act = smem;
-    for (int idx = tid; idx < ROWS * Kp; idx += MV_THREADS) {
-        const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
-        float v = 0.0f;
-        if (row < a.M && k < K) v = mv_prologue<PRO>(a, row, k);
-        act[rr * S + mv_perm(k)] = v;
+    for (int base = 0; base < ROWS * Kp; base += MV_THREADS * 8) {          // 8 independent elements per thread in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * MV_THREADS + tid;
+            const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
+            v[u] = 0.0f;
+            if (idx < ROWS * Kp && row < a.M && k < K) v[u] = mv_prologue<PRO>(a, row, k);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * MV_THREADS + tid;
+            const int rr = idx / Kp, k = idx - rr * Kp;
+            if (idx < ROWS * Kp) act[rr * S + mv_perm(k)] = v[u];
+        }
     }
     __syncthreads();
     const int NT = a.L.NT;
@@ -134,12 +160,21 @@ __global__ __launch_bounds__(MV_THREADS) void k_layer(LayerArgs a) {
             if (t < ntw) {
                 const int col = (ct0 + t) * 16 + r;
                 if (col < N) {
+                    EpiIn in[MT][4];
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int row = row0 + m * 16 + 4 * q + i;
-                            if (row < a.M) mv_epilogue<EPI>(a, row, col, acc[m][t][i]);
+                            in[m][i] = EpiIn{0.f, 0.f, 0.f};
+                            if (row < a.M) in[m][i] = mv_epilogue_load<EPI>(a, row, col);
+                        }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = row0 + m * 16 + 4 * q + i;
+                            if (row < a.M) mv_epilogue<EPI>(a, row, col, acc[m][t][i], in[m][i]);
                         }
                 }
             }
@@ -156,48 +191,81 @@ __global__ __launch_bounds__(MV_THREADS) void k_layer(LayerArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// dW[No][Ki] = P1^T Q1 (+ P2^T Q2): a GEMM whose contraction runs over ROWS.  Split over 128-row chunks (one workgroup per
+// 64x64 output block per chunk; chunks of the second pair follow those of the first), partial blocks go to slabs that
+// k_reduce_slabs sums in a fixed order (deterministic, no atomics).  Tiles are staged through LDS with 16-byte loads.
 struct WgradArgs {
-    const float* P; int ldp;       // [Mrows, No]  (or Z for PMODE 1/2)
-    const float* U; int ldu;       // PMODE 1
-    const float* bcast;            // PMODE 2
-    const float* Q; int ldq;       // [Mrows, Ki]
-    int M, No, Ki;
-    int chunk;                     // rows per slab
-    float* slab;                   // [nchunks][No][Ki]
-    float* bslab;                  // [nchunks][No] or null
+    const float* P1; int ldp1; const float* Q1; int ldq1; int M1;      // [M1, No], [M1, Ki]
+    const float* P2; int ldp2; const float* Q2; int ldq2; int M2;      // optional second pair (E.1 term), M2 = 0 if absent
+    int No, Ki;
+    int chunk, nchunks1;           // rows per slab; number of chunks of pair 1
+    float* slab;                   // [nchunks1 + nchunks2][No][Ki]
+    float* bslab;                  // [nchunks1][No] column sums of P1 (bias gradient) or null
 };
 
-template <int PMODE>
+__device__ __forceinline__ void wg_stage(const float* __restrict__ src, int ld, int row_lo, int row_hi, int c0, int ncols, float* __restrict__ dst,
+                                         int LD, int tid) {
+    // 64 rows x 64 cols -> LDS; 16-byte global loads when the source allows it
+    const bool vec = ((ld & 3) == 0) && ((c0 & 3) == 0) && ((((size_t)src) & 15) == 0);
+    if (vec) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = u * MV_THREADS + tid, rr = idx >> 4, c4 = (idx & 15) * 4, row = row_lo + rr;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < row_hi) {
+                if (c0 + c4 + 3 < ncols) v[u] = *(const float4*)(src + (size_t)row * ld + c0 + c4);
+                else {
+                    float t[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int e = 0; e < 4; ++e) if (c0 + c4 + e < ncols) t[e] = src[(size_t)row * ld + c0 + c4 + e];
+                    v[u] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = u * MV_THREADS + tid, rr = idx >> 4, c4 = (idx & 15) * 4;
+            *(float4*)(dst + rr * LD + c4) = v[u];
+        }
+    } else {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = u * MV_THREADS + tid, rr = idx >> 6, c = idx & 63, row = row_lo + rr;
+            v[u] = (row < row_hi && c0 + c < ncols) ? src[(size_t)row * ld + c0 + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = u * MV_THREADS + tid, rr = idx >> 6, c = idx & 63;
+            dst[rr * LD + c] = v[u];
+        }
+    }
+}
+
 __global__ __launch_bounds__(MV_THREADS) void k_wgrad(WgradArgs a) {
-    constexpr int LD = 80;                                       // 64 + 16: conflict-free fragment reads
+    constexpr int LD = 80;                                       // 64 + 16: conflict-free fragment reads, 16-byte aligned rows
     __shared__ __attribute__((aligned(16))) float Pt[64 * LD];
     __shared__ __attribute__((aligned(16))) float Qt[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-    const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64, ch = blockIdx.z;
-    const int rbeg = ch * a.chunk, rend = min(a.M, rbeg + a.chunk);
+    const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
+    int ch = blockIdx.z;
+    const bool second = ch >= a.nchunks1;
+    const float* P = second ? a.P2 : a.P1;
+    const float* Q = second ? a.Q2 : a.Q1;
+    const int ldp = second ? a.ldp2 : a.ldp1, ldq = second ? a.ldq2 : a.ldq1, M = second ? a.M2 : a.M1;
+    const int lch = second ? ch - a.nchunks1 : ch;
+    const int rbeg = lch * a.chunk, rend = min(M, rbeg + a.chunk);
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
+    const bool do_bias = a.bslab && !second && blockIdx.x == 0;
     for (int rb = rbeg; rb < rend; rb += 64) {
         __syncthreads();
-        for (int idx = tid; idx < 64 * 64; idx += MV_THREADS) {
-            const int rr = idx >> 6, c = idx & 63, row = rb + rr;
-            float pv = 0.0f, qv = 0.0f;
-            if (row < rend) {
-                if (o0 + c < a.No) {
-                    const size_t off = (size_t)row * a.ldp + o0 + c;
-                    if (PMODE == 0) pv = a.P[off];
-                    else if (PMODE == 1) pv = dm_sigmoid100(a.P[off]) * a.U[(size_t)row * a.ldu + o0 + c];
-                    else pv = dm_sigmoid100(a.P[off]) * a.bcast[o0 + c];
-                }
-                if (i0 + c < a.Ki) qv = a.Q[(size_t)row * a.ldq + i0 + c];
-            }
-            Pt[rr * LD + c] = pv;
-            Qt[rr * LD + c] = qv;
-        }
+        wg_stage(P, ldp, rb, rend, o0, a.No, Pt, LD, tid);
+        wg_stage(Q, ldq, rb, rend, i0, a.Ki, Qt, LD, tid);
         __syncthreads();
-        if (a.bslab && blockIdx.x == 0 && tid < 64) {
+        if (do_bias && tid < 64) {
             for (int rr = 0; rr < 64; ++rr) bsum += Pt[rr * LD + tid];
         }
 #pragma unroll 4
@@ -220,7 +288,7 @@ __global__ __launch_bounds__(MV_THREADS) void k_wgrad(WgradArgs a) {
             }
         }
     }
-    if (a.bslab && blockIdx.x == 0 && tid < 64 && o0 + tid < a.No) a.bslab[(size_t)ch * a.No + o0 + tid] = bsum;
+    if (do_bias && tid < 64 && o0 + tid < a.No) a.bslab[(size_t)ch * a.No + o0 + tid] = bsum;
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_c slabA[c][i] (+ sum_c slabB[c][i])      -- fixed order, deterministic
@@ -235,17 +303,15 @@ __global__ void k_reduce_slabs(const float* __restrict__ sa, const float* __rest
     }
 }
 
-// out[c] (+)= sum_rows X[row][c]
-__global__ void k_colsum(const float* __restrict__ X, int ld, int M, int n, float* __restrict__ out, int accumulate) {
-    __shared__ float part[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+// part[chunk][c] = sum over the chunk's rows of X[row][c]   (then k_reduce_slabs with accumulate)
+__global__ void k_colsum(const float* __restrict__ X, int ld, int M, int n, int chunk, float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, ch = blockIdx.y;
+    const int rbeg = ch * chunk, rend = min(M, rbeg + chunk);
     float s = 0.0f;
     if (c < n)
-        for (int row = g; row < M; row += 4) s += X[(size_t)row * ld + c];
-    part[g][threadIdx.x & 63] = s;
+        for (int row = rbeg + g; row < rend; row += 4) s += X[(size_t)row * ld + c];
+    red[g][threadIdx.x & 63] = s;
     __syncthreads();
-    if (g == 0 && c < n) {
-        const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-        out[c] = accumulate ? out[c] + v : v;
-    }
+    if (g == 0 && c < n) part[(size_t)ch * n + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }

@@ -337,32 +337,43 @@ static size_t trace_lds_bytes(const MvNet& net, int MT, int sv_floats, int rpw) 
 }
 
 template <int MT, int NTW>
-static hipError_t launch_trace(const MvNet& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, const uint8_t* om,
+static hipError_t launch_trace(int stages, const MvNet& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, const uint8_t* om,
                                int B, int P, int training, int rpw, const float* intervals, const float* steps, float* points,
                                uint8_t* mask, float* dists, float* w_zmin, float* w_zmax, int* w_list, unsigned long long* counters,
                                hipStream_t stream) {
     const int R = B * P, NR = 8 * MT;
     const size_t lds1 = trace_lds_bytes(net, MT, 0, 0), lds2 = trace_lds_bytes(net, MT, rpw * tp.n_steps, rpw);
+    static size_t set1 = 0, set2 = 0;                           // raise the dynamic-LDS cap once per size (per instantiation)
     hipError_t e;
-    e = hipFuncSetAttribute((const void*)k_sphere_trace<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_ray_samples<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_sphere_trace<MT, NTW>), dim3((R + NR - 1) / NR), dim3(MV_THREADS), lds1, stream, net, tp, cam_loc, dirs, om, R, P,
-                       training, points, mask, dists, w_zmin, w_zmax, w_list, counters);
-    hipLaunchKernelGGL((k_ray_samples<MT, NTW>), dim3((R + rpw - 1) / rpw), dim3(MV_THREADS), lds2, stream, net, tp, cam_loc, dirs, R, P,
-                       training, rpw, intervals, steps, points, mask, dists, w_zmin, w_zmax, w_list, counters);
+    if (stages & 1) {
+        if (lds1 > set1) {
+            e = hipFuncSetAttribute((const void*)k_sphere_trace<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+            if (e != hipSuccess) return e;
+            set1 = lds1;
+        }
+        hipLaunchKernelGGL((k_sphere_trace<MT, NTW>), dim3((R + NR - 1) / NR), dim3(MV_THREADS), lds1, stream, net, tp, cam_loc, dirs, om, R, P,
+                           training, points, mask, dists, w_zmin, w_zmax, w_list, counters);
+    }
+    if (stages & 2) {
+        if (lds2 > set2) {
+            e = hipFuncSetAttribute((const void*)k_ray_samples<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            if (e != hipSuccess) return e;
+            set2 = lds2;
+        }
+        hipLaunchKernelGGL((k_ray_samples<MT, NTW>), dim3((R + rpw - 1) / rpw), dim3(MV_THREADS), lds2, stream, net, tp, cam_loc, dirs, R, P,
+                           training, rpw, intervals, steps, points, mask, dists, w_zmin, w_zmax, w_list, counters);
+    }
     return hipGetLastError();
 }
 
-hipError_t mv_trace_launch(const MvNet& net, const MvTraceParams& tp, int mt, const float* cam_loc, const float* dirs, const uint8_t* om,
+hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp, int mt, const float* cam_loc, const float* dirs, const uint8_t* om,
                            int B, int P, int training, int rpw, const float* intervals, const float* steps, float* points, uint8_t* mask,
                            float* dists, float* w_zmin, float* w_zmax, int* w_list, unsigned long long* counters, hipStream_t stream) {
     int maxnt = 0;
     for (int l = 0; l < net.n_layers - 1; ++l) maxnt = net.L[l].NT > maxnt ? net.L[l].NT : maxnt;
     const bool wide = maxnt > 16;                               // > 256 columns: 8 column tiles per wave, at most 2 row tiles
     if (maxnt > 32) return hipErrorInvalidValue;
-#define MV_GO(MT_, NTW_) return launch_trace<MT_, NTW_>(net, tp, cam_loc, dirs, om, B, P, training, rpw, intervals, steps, points, mask, dists, \
+#define MV_GO(MT_, NTW_) return launch_trace<MT_, NTW_>(stages, net, tp, cam_loc, dirs, om, B, P, training, rpw, intervals, steps, points, mask, dists, \
                                                         w_zmin, w_zmax, w_list, counters, stream)
     if (wide) { if (mt >= 2) MV_GO(2, 8); MV_GO(1, 8); }
     if (mt >= 4) MV_GO(4, 4);
@@ -377,10 +388,10 @@ extern "C" {
 
 size_t mvsdf_trace_workspace_bytes(int R) { return (size_t)(R > 0 ? R : 0) * 12 + 256; }
 
-int mvsdf_trace(const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
-                const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
-                float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
-                size_t workspace_bytes, int mt, int rpw, void* stream) {
+static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
+                      const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
+                      float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
+                      size_t workspace_bytes, int mt, int rpw, void* stream) {
     MvNet net;
     int rc = mv_make_net(desc, &net);
     if (rc) return rc;
@@ -398,11 +409,31 @@ int mvsdf_trace(const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const floa
     float* w_zmin = (float*)workspace;
     float* w_zmax = w_zmin + R;
     int* w_list = (int*)(w_zmax + R);
-    hipError_t e = hipMemsetAsync(counters, 0, 16 * sizeof(unsigned long long), s);
+    hipError_t e = hipSuccess;
+    if (stages & 1) e = hipMemsetAsync(counters, 0, 16 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return mv_check(e, "mvsdf_trace: memset");
-    e = mv_trace_launch(net, *tp, mt, cam_loc, ray_dirs, object_mask, B, P, training, rpw, intervals,
+    e = mv_trace_launch(stages, net, *tp, mt, cam_loc, ray_dirs, object_mask, B, P, training, rpw, intervals,
                         minsdf_steps ? minsdf_steps : intervals, points, mask, dists, w_zmin, w_zmax, w_list, counters, s);
     return mv_check(e, "mvsdf_trace");
+}
+
+int mvsdf_trace(const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
+                const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
+                float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
+                size_t workspace_bytes, int mt, int rpw, void* stream) {
+    return trace_impl(3, desc, tp, cam_loc, ray_dirs, object_mask, B, P, training, intervals, minsdf_steps, points, mask, dists, counters,
+                      workspace, workspace_bytes, mt, rpw, stream);
+}
+
+/* The two launches of mvsdf_trace separately (same arguments, same workspace): stage 1 = sphere tracing (zeroes the counters),
+ * stage 2 = ray sampler + secant + min-sdf.  Lets a caller bracket each kernel with events. */
+int mvsdf_trace_stage(int stage, const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
+                      const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
+                      float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
+                      size_t workspace_bytes, int mt, int rpw, void* stream) {
+    if (stage != 1 && stage != 2) return mv_fail(-1, "mvsdf_trace_stage: stage must be 1 or 2");
+    return trace_impl(stage, desc, tp, cam_loc, ray_dirs, object_mask, B, P, training, intervals, minsdf_steps, points, mask, dists, counters,
+                      workspace, workspace_bytes, mt, rpw, stream);
 }
 
 }  // extern "C"

@@ -33,6 +33,7 @@ class RayTracing(nn.Module):
         self.last_counters = None           # device int64[16]: MLP rows per stage (include/mvsdf_hip.h MVSDF_CNT_*)
         self.mt = None                      # row tiles per workgroup (None: pick from the ray count)
         self.rpw = None
+        self.events = None                  # set to a list to have per-kernel (start, mid, end) events appended each call
 
     def _params(self):
         if os.environ.get('IDR_USE_ENV', '0') == '1' and os.environ.get('IDR_RENDER', '0') == '1':
@@ -60,6 +61,6 @@ class RayTracing(nn.Module):
         mt = self.mt or (1 if R <= 4096 else 2)
         rpw = self.rpw or (2 if R <= 4096 else 4)
         pts, mask, dists, counters = ops.trace(net, cam_loc, ray_directions, object_mask, self._params(), self.training, intervals,
-                                               minsdf_steps, mt=mt, rpw=rpw)
+                                               minsdf_steps, mt=mt, rpw=rpw, events=self.events)
         self.last_counters = counters
         return pts, mask, dists

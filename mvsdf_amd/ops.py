@@ -96,8 +96,10 @@ def sphere_intersection(cam_loc, ray_dirs, r=1.0):
     return t, m.bool()
 
 
-def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, minsdf_steps=None, mt=2, rpw=2):
-    """RayTracing.forward on the device -> (points[R,3], mask[R] bool, dists[R], counters[16] int64 device tensor)."""
+def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, minsdf_steps=None, mt=2, rpw=2, events=None):
+    """RayTracing.forward on the device -> (points[R,3], mask[R] bool, dists[R], counters[16] int64 device tensor).
+    events: optional list; when given the two kernels are launched by separate C calls and (start, mid, end) torch events
+    recorded on the current stream are appended (per-kernel timing for bench.py's roofline)."""
     cam_loc, ray_dirs = _f32(cam_loc), _f32(ray_dirs)
     B, P = ray_dirs.shape[:2]
     R = B * P
@@ -111,10 +113,20 @@ def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, mins
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     tp = TraceParams(*params)
     d = net.desc()
-    check(lib().mvsdf_trace(C.byref(d), C.byref(tp), ptr(cam_loc), ptr(ray_dirs), ptr(om), B, P, 1 if training else 0,
-                            ptr(_f32(intervals)), ptr(_f32(minsdf_steps)) if minsdf_steps is not None else None,
-                            ptr(pts), ptr(mask), ptr(dists), ptr(counters), ptr(ws), C.c_size_t(wsb), mt, rpw,
-                            stream_of(ray_dirs)), 'mvsdf_trace')
+    iv = _f32(intervals)
+    st = _f32(minsdf_steps) if minsdf_steps is not None else None
+    args = (C.byref(d), C.byref(tp), ptr(cam_loc), ptr(ray_dirs), ptr(om), B, P, 1 if training else 0, ptr(iv), ptr(st),
+            ptr(pts), ptr(mask), ptr(dists), ptr(counters), ptr(ws), C.c_size_t(wsb), mt, rpw, stream_of(ray_dirs))
+    if events is None:
+        check(lib().mvsdf_trace(*args), 'mvsdf_trace')
+    else:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        check(lib().mvsdf_trace_stage(1, *args), 'mvsdf_trace_stage(1)')
+        ev[1].record()
+        check(lib().mvsdf_trace_stage(2, *args), 'mvsdf_trace_stage(2)')
+        ev[2].record()
+        events.append(tuple(ev))
     return pts, mask.bool(), dists, counters
 
 

@@ -1,0 +1,63 @@
+"""Data-parallel ray sharding: one process per GPU, ONE all-reduce (RCCL over xGMI; gloo in the CPU tests) on a flat
+fp32 gradient bucket per step.  The reference is single-GPU (exp_runner.py:24-28); this layer is new.
+
+Rays are independent; the only coupling is the parameter gradient.  Views are sharded across ranks (B views -> B/world each);
+`.grad` of every parameter is a VIEW into one flat buffer, so backward accumulates straight into the bucket and the
+collective needs no packing.  Loss normalisation: gradients are AVERAGED over ranks (mean of per-rank losses), the
+DDP convention; it equals the single-process loss for the per-view / per-ray means and is a mean-of-means for the
+count-normalised terms (eikonal / depth / surface BCE) -- see DESIGN.md."""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradBucket:
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        p0 = self.params[0]
+        self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)          # autograd accumulates in place into the bucket
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+        off = 0
+        for p in self.params:                                   # re-attach (an optimizer's zero_grad(set_to_none) would detach)
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat[off:off + n].data_ptr():
+                p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def all_reduce_mean(self):
+        """One collective for all gradients; no-op without an initialised process group."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+
+    def grad_norm(self):
+        return self.flat.norm()
+
+    def clip_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_ on the bucket (idr_train.py:291-294): one norm, one scale."""
+        total = self.flat.norm()
+        coef = (max_norm / (total + 1e-6)).clamp(max=1.0)
+        self.flat.mul_(coef)
+        return total
+
+
+def shard_views(batch, rank, world):
+    """Slice every [B, ...] tensor of a model-input / ground-truth dict to this rank's views (B must divide by world).
+    Depth maps are NOT sliced: the depth loss carves every sample point against all B views (loss.py:39-40)."""
+    out = {}
+    for k, v in batch.items():
+        if torch.is_tensor(v) and v.dim() >= 1 and k not in ('depths', 'depth_cams'):
+            B = v.shape[0]
+            assert B % world == 0, 'views must divide evenly across ranks'
+            per = B // world
+            out[k] = v[rank * per:(rank + 1) * per]
+        else:
+            out[k] = v
+    return out
