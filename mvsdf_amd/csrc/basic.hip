@@ -1,5 +1,6 @@
 // basic.hip -- weight-norm fold + MFMA packing, camera rays, the stand-alone tracing-MLP kernel and the
 // device self-test of det_math.  C ABI entry points for these live at the bottom (see include/mvsdf_hip.h).
+#include <stdlib.h>
 #include "tile_engine.h"
 #include "trace_params.h"
 #include "capi_util.h"
@@ -103,8 +104,8 @@ __global__ void k_sphere_intersection(const float* __restrict__ cam_loc, const f
 }
 
 // ---- the tracing MLP alone: y[i] = ImplicitNetwork(x[i])[0] ----
-template <int MT, int NTW>
-__global__ __launch_bounds__(MV_THREADS) void k_sdf_col0(MvNet net, const float* __restrict__ x, int n, float* __restrict__ y) {
+template <int MT, int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_sdf_col0(MvNet net, const float* __restrict__ x, int n, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT;
     const int tid = threadIdx.x, d0 = 3 + 6 * net.multires;
@@ -113,12 +114,12 @@ __global__ __launch_bounds__(MV_THREADS) void k_sdf_col0(MvNet net, const float*
     float* pts = pe + ((ROWS * d0 + 3) & ~3);
     float* out = pts + ROWS * 4;
     const int row0 = blockIdx.x * ROWS;
-    for (int i = tid; i < ROWS * 3; i += MV_THREADS) {
+    for (int i = tid; i < ROWS * 3; i += 64 * NW) {
         const int row = row0 + i / 3;
         pts[i] = row < n ? x[3 * (size_t)row0 + i] : 0.0f;
     }
     __syncthreads();
-    mv_sdf_eval_col0<MT, NTW>(net, act, pe, pts, out, tid);
+    mv_sdf_eval_col0<MT, NTW, NW>(net, act, pe, pts, out, tid);
     if (tid < ROWS && row0 + tid < n) y[row0 + tid] = out[tid];
 }
 
@@ -139,13 +140,13 @@ __global__ void k_det_math(int op, const float* __restrict__ x, int n, float* __
     if (y1) y1[i] = b;
 }
 
-template <int MT, int NTW>
+template <int MT, int NTW, int NW>
 static int launch_col0(const MvNet& net, const float* x, int n, float* y, hipStream_t s) {
     const int rows = 16 * MT, d0 = 3 + 6 * net.multires;
     const size_t lds = ((size_t)rows * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows) * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)k_sdf_col0<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_sdf_col0<MT, NTW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return mv_check(e, "mvsdf_sdf_col0: LDS attribute");
-    hipLaunchKernelGGL((k_sdf_col0<MT, NTW>), dim3((n + rows - 1) / rows), dim3(MV_THREADS), lds, s, net, x, n, y);
+    hipLaunchKernelGGL((k_sdf_col0<MT, NTW, NW>), dim3((n + rows - 1) / rows), dim3(64 * NW), lds, s, net, x, n, y);
     return mv_check(hipGetLastError(), "mvsdf_sdf_col0");
 }
 
@@ -193,10 +194,21 @@ int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, in
     if (rc) return rc;
     if (!x || !y || n <= 0) return mv_fail(-1, "mvsdf_sdf_col0: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (mv_wide(net)) return mt >= 2 ? launch_col0<2, 8>(net, x, n, y, s) : launch_col0<1, 8>(net, x, n, y, s);
-    if (mt >= 4) return launch_col0<4, 4>(net, x, n, y, s);
-    if (mt >= 2) return launch_col0<2, 4>(net, x, n, y, s);
-    return launch_col0<1, 4>(net, x, n, y, s);
+    const char* e = getenv("MVSDF_NW");
+    const int nw_env = e ? atoi(e) : 0;
+    int maxnt = 0;
+    for (int l = 0; l < net.n_layers - 1; ++l) maxnt = net.L[l].NT > maxnt ? net.L[l].NT : maxnt;
+    const bool eight = (nw_env == 8) || (nw_env != 4 && maxnt >= 16);
+    if (eight) {
+        if (mv_wide(net)) return mt >= 2 ? launch_col0<2, 4, 8>(net, x, n, y, s) : launch_col0<1, 4, 8>(net, x, n, y, s);
+        if (mt >= 4) return launch_col0<4, 2, 8>(net, x, n, y, s);
+        if (mt >= 2) return launch_col0<2, 2, 8>(net, x, n, y, s);
+        return launch_col0<1, 2, 8>(net, x, n, y, s);
+    }
+    if (mv_wide(net)) return mt >= 2 ? launch_col0<2, 8, 4>(net, x, n, y, s) : launch_col0<1, 8, 4>(net, x, n, y, s);
+    if (mt >= 4) return launch_col0<4, 4, 4>(net, x, n, y, s);
+    if (mt >= 2) return launch_col0<2, 4, 4>(net, x, n, y, s);
+    return launch_col0<1, 4, 4>(net, x, n, y, s);
 }
 
 int mvsdf_det_math(int op, const float* x, int n, float* y0, float* y1, void* stream) {

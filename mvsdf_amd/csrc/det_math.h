@@ -32,6 +32,14 @@ DM_FN float dm_from_bits(uint32_t u) {
 #endif
 }
 
+DM_FN uint32_t dm_to_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    uint32_t u; memcpy(&u, &f, 4); return u;
+#endif
+}
+
 /* round to nearest integer (ties to even), valid for |x| < 2^22 */
 DM_FN float dm_rint(float x) {
     const float magic = 12582912.0f; /* 1.5 * 2^23 */
@@ -39,10 +47,13 @@ DM_FN float dm_rint(float x) {
     return t - magic;
 }
 
-/* exp(x) for x <= 0 (returns 0 below -104) */
+/* exp(x) for x <= 0, clamped at x = -86 (exp(-86) = 4.4e-38, still a normal float: the 2^n scaling below is a plain
+ * exponent add).  The magic-number rounding leaves n in the low mantissa bits of t, so (bits(t) << 23) == n << 23. */
 DM_FN float dm_expneg(float x) {
-    if (!(x >= -104.0f)) return 0.0f;
-    float n = dm_rint(x * 1.4426950216293335f);
+    x = fmaxf(x, -86.0f);
+    const float magic = 12582912.0f; /* 1.5 * 2^23 */
+    float t = fmaf(x, 1.4426950216293335f, magic);
+    float n = t - magic;
     float r = fmaf(n, -0.693359375f, x);
     r = fmaf(n, 2.12194440e-4f, r);
     float p = 1.9875691500e-4f;
@@ -52,17 +63,13 @@ DM_FN float dm_expneg(float x) {
     p = fmaf(p, r, 1.6666665459e-1f);
     p = fmaf(p, r, 5.0000001201e-1f);
     float e = fmaf(p, r * r, r) + 1.0f;
-    int ni = (int)n;            /* in [-151, 0] */
-    int n1 = ni >> 1;           /* floor(ni/2) */
-    int n2 = ni - n1;
-    e = e * dm_from_bits((uint32_t)(n1 + 127) << 23);
-    return e * dm_from_bits((uint32_t)(n2 + 127) << 23);
+    return dm_from_bits(dm_to_bits(e) + (dm_to_bits(t) << 23));
 }
 
 /* log1p(t) for t in [0, 1] */
 DM_FN float dm_log1p01(float t) {
     int k = !(t < 0.4142135679721832f);
-    float f = k ? (t - 1.0f) * 0.5f : t;
+    float f = k ? fmaf(t, 0.5f, -0.5f) : t;          /* 1 + t = 2 (1 + f) on the upper branch */
     float q = 7.1513607744e-02f;
     q = fmaf(q, f, -1.1573007339e-01f);
     q = fmaf(q, f, 1.1661760853e-01f);
@@ -74,22 +81,12 @@ DM_FN float dm_log1p01(float t) {
     q = fmaf(q, f, 3.3333331185e-01f);
     float f2 = f * f;
     float res = fmaf(f2 * f, q, fmaf(-0.5f, f2, f));
-    if (k) res = (res + 1.428606765330187e-06f) + 0.693145751953125f;
-    return res;
+    return res + (k ? 0.6931471805599453f : 0.0f);
 }
 
-/* x / 100 and x / fl32(sqrt(2)) as reciprocal + one fma correction (Markstein): a fixed op
- * sequence, equal to the correctly rounded quotient for all but pathological inputs. */
-DM_FN float dm_div100(float x) {
-    float q = x * 0.009999999776482582f;
-    float r = fmaf(-100.0f, q, x);
-    return fmaf(r, 0.009999999776482582f, q);
-}
-DM_FN float dm_div_sqrt2(float x) {
-    float q = x * 0.7071067690849304f;
-    float r = fmaf(-1.4142135381698608f, q, x);
-    return fmaf(r, 0.7071067690849304f, q);
-}
+/* x / 100 and x / fl32(sqrt(2)) as one multiplication by the rounded reciprocal (<= 1 ulp from the true quotient). */
+DM_FN float dm_div100(float x) { return x * 0.009999999776482582f; }
+DM_FN float dm_div_sqrt2(float x) { return x * 0.7071067690849304f; }
 
 /* Softplus(beta=100, threshold=20) */
 DM_FN float dm_softplus100(float z) {

@@ -97,9 +97,10 @@ __device__ __forceinline__ void mv_gemm_dispatch(const MvLayer& L, const float* 
 
 // Positional encoding of `rows` points (LDS pts[rows][3]) -> pe[rows][d0] (natural order, kept for the skip
 // connection) and act[rows][S] (permuted, zero padded to ceil32(d0)).  embedder.py:10-36.
+template <int NTHREADS>
 __device__ __forceinline__ void mv_pe_rows(const float* pts, float* pe, float* act, int S, int rows, int multires, int tid) {
     const int d0 = 3 + 6 * multires, Kp0 = mv_kpad(d0), T = 3 * multires + 1;
-    for (int task = tid; task < rows * T; task += MV_THREADS) {
+    for (int task = tid; task < rows * T; task += NTHREADS) {
         const int row = task / T, j = task - row * T;
         const float* x = pts + row * 3;
         float* pr = pe + row * d0;
@@ -119,18 +120,20 @@ __device__ __forceinline__ void mv_pe_rows(const float* pts, float* pe, float* a
 }
 
 // ImplicitNetwork.forward(...)[:, 0] (idr.py:77-94) for MTc*16 rows whose points sit in LDS `pts`.
-// Result -> LDS out[row].  All 256 threads must call; ends with a barrier.
-template <int MTc, int NTW>
+// Result -> LDS out[row].  All 64*NW threads must call; ends with a barrier.  NW waves share the column tiles
+// (NW = 8 puts two waves on every SIMD: one wave's LDS / L2 latency and epilogue hide behind the other's MFMAs).
+template <int MTc, int NTW, int NW = 4>
 __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const float* pts, float* out, int tid) {
+    constexpr int NTHREADS = 64 * NW;
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
     const int S = net.S, rows = MTc * 16, d0 = 3 + 6 * net.multires;
-    mv_pe_rows(pts, pe, act, S, rows, net.multires, tid);
+    mv_pe_rows<NTHREADS>(pts, pe, act, S, rows, net.multires, tid);
     const int nl = net.n_layers;
     for (int l = 0; l < nl; ++l) {
         const MvLayer& L = net.L[l];
         const bool last = (l == nl - 1);
         const int NT = last ? 1 : L.NT;                       // tracing needs column 0 only
-        const int per = (NT + 3) >> 2;                        // column tiles per wave
+        const int per = (NT + NW - 1) / NW;                   // column tiles per wave
         const int ct0 = w * per;
         int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
         f32x4 acc[MTc][NTW];
@@ -169,14 +172,14 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
             }
             const int Kn = net.L[l + 1].K, Kpn = net.L[l + 1].KB * 16;
             if (to_skip) {
-                for (int idx = tid; idx < rows * d0; idx += MV_THREADS) {
+                for (int idx = tid; idx < rows * d0; idx += NTHREADS) {
                     const int row = idx / d0, j = idx - row * d0;
                     act[row * S + mv_perm(N + j)] = dm_div_sqrt2(pe[row * d0 + j]);
                 }
             }
             if (Kpn > Kn) {
                 const int pad = Kpn - Kn;
-                for (int idx = tid; idx < rows * pad; idx += MV_THREADS) {
+                for (int idx = tid; idx < rows * pad; idx += NTHREADS) {
                     const int row = idx / pad, j = idx - row * pad;
                     act[row * S + mv_perm(Kn + j)] = 0.0f;
                 }

@@ -14,6 +14,7 @@
 //                    ray does the argmin / first-sign-change logic and the (dependent) secant rounds run compacted.
 //
 // No host synchronisation anywhere: list lengths stay on the device, grids are sized for the worst case.
+#include <stdlib.h>
 #include "tile_engine.h"
 #include "trace_params.h"
 
@@ -40,12 +41,12 @@ __device__ __forceinline__ bool mv_sphere_isect(const float* c, const float* d, 
     return hit;
 }
 
-template <int MT, int NTW>
+template <int MT, int NTW, int NW>
 __device__ __forceinline__ void mv_eval_dispatch(const MvNet& net, int ntiles, float* act, float* pe, const float* pts, float* out, int tid) {
-    if (MT >= 4 && ntiles == 4) mv_sdf_eval_col0<(MT >= 4 ? 4 : MT), NTW>(net, act, pe, pts, out, tid);
-    else if (MT >= 3 && ntiles == 3) mv_sdf_eval_col0<(MT >= 3 ? 3 : MT), NTW>(net, act, pe, pts, out, tid);
-    else if (MT >= 2 && ntiles == 2) mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW>(net, act, pe, pts, out, tid);
-    else mv_sdf_eval_col0<1, NTW>(net, act, pe, pts, out, tid);
+    if (MT >= 4 && ntiles == 4) mv_sdf_eval_col0<(MT >= 4 ? 4 : MT), NTW, NW>(net, act, pe, pts, out, tid);
+    else if (MT >= 3 && ntiles == 3) mv_sdf_eval_col0<(MT >= 3 ? 3 : MT), NTW, NW>(net, act, pe, pts, out, tid);
+    else if (MT >= 2 && ntiles == 2) mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW, NW>(net, act, pe, pts, out, tid);
+    else mv_sdf_eval_col0<1, NTW, NW>(net, act, pe, pts, out, tid);
 }
 
 // LDS carve shared by both kernels
@@ -63,8 +64,8 @@ __device__ __forceinline__ TraceLds mv_carve(float* base, int rows, int S, int d
     return l;
 }
 
-template <int MT, int NTW>
-__global__ __launch_bounds__(MV_THREADS) void k_sphere_trace(MvNet net, MvTraceParams tp, const float* __restrict__ cam_loc,
+template <int MT, int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_sphere_trace(MvNet net, MvTraceParams tp, const float* __restrict__ cam_loc,
                                                             const float* __restrict__ dirs, const uint8_t* __restrict__ object_mask,
                                                             int R, int P, int training, float* __restrict__ o_points,
                                                             uint8_t* __restrict__ o_mask, float* __restrict__ o_dists,
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(MV_THREADS) void k_sphere_trace(MvNet net, MvTraceP
         const int n = *s_n;
         if (n == 0) break;
         if (tid == 0) nrows_total += (unsigned long long)n;
-        mv_eval_dispatch<MT, NTW>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
+        mv_eval_dispatch<MT, NTW, NW>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
         if (w == 0 && phase != 3) {
             const float vs = req_s ? mv_clamp(lds.sdfv[row_s], -tp.dist_clip, tp.dist_clip) : 0.f;
             const float ve = req_e ? mv_clamp(lds.sdfv[row_e], -tp.dist_clip, tp.dist_clip) : 0.f;
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(MV_THREADS) void k_sphere_trace(MvNet net, MvTraceP
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int MT, int NTW>
-__global__ __launch_bounds__(MV_THREADS) void k_ray_samples(MvNet net, MvTraceParams tp, const float* __restrict__ cam_loc,
+template <int MT, int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_ray_samples(MvNet net, MvTraceParams tp, const float* __restrict__ cam_loc,
                                                            const float* __restrict__ dirs, int R, int P, int training, int RPW,
                                                            const float* __restrict__ intervals, const float* __restrict__ steps,
                                                            float* __restrict__ o_points, uint8_t* __restrict__ o_mask,
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(MV_THREADS) void k_ray_samples(MvNet net, MvTracePa
             p[0] = rr[0] + z * rr[3]; p[1] = rr[1] + z * rr[4]; p[2] = rr[2] + z * rr[5];
         }
         __syncthreads();
-        mv_eval_dispatch<MT, NTW>(net, (nr + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
+        mv_eval_dispatch<MT, NTW, NW>(net, (nr + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
         if (tid < nr) lds.sv[base + tid] = lds.sdfv[tid];
         __syncthreads();
     }
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(MV_THREADS) void k_ray_samples(MvNet net, MvTracePa
         const int n = *s_n;
         if (n == 0) break;
         sec_rows += (unsigned long long)n;
-        mv_eval_dispatch<MT, NTW>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
+        mv_eval_dispatch<MT, NTW, NW>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
         if (w == 0 && do_secant) {
             const float sm = lds.sdfv[row];
             if (sm > 0.f) { z_low = z_pred; sdf_low = sm; }
@@ -336,7 +337,7 @@ static size_t trace_lds_bytes(const MvNet& net, int MT, int sv_floats, int rpw) 
     return f * 4 + 16 + (size_t)rpw * (8 * 4 + 4) + 16;
 }
 
-template <int MT, int NTW>
+template <int MT, int NTW, int NW>
 static hipError_t launch_trace(int stages, const MvNet& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, const uint8_t* om,
                                int B, int P, int training, int rpw, const float* intervals, const float* steps, float* points,
                                uint8_t* mask, float* dists, float* w_zmin, float* w_zmax, int* w_list, unsigned long long* counters,
@@ -347,20 +348,20 @@ static hipError_t launch_trace(int stages, const MvNet& net, const MvTraceParams
     hipError_t e;
     if (stages & 1) {
         if (lds1 > set1) {
-            e = hipFuncSetAttribute((const void*)k_sphere_trace<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+            e = hipFuncSetAttribute((const void*)k_sphere_trace<MT, NTW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
             if (e != hipSuccess) return e;
             set1 = lds1;
         }
-        hipLaunchKernelGGL((k_sphere_trace<MT, NTW>), dim3((R + NR - 1) / NR), dim3(MV_THREADS), lds1, stream, net, tp, cam_loc, dirs, om, R, P,
+        hipLaunchKernelGGL((k_sphere_trace<MT, NTW, NW>), dim3((R + NR - 1) / NR), dim3(64 * NW), lds1, stream, net, tp, cam_loc, dirs, om, R, P,
                            training, points, mask, dists, w_zmin, w_zmax, w_list, counters);
     }
     if (stages & 2) {
         if (lds2 > set2) {
-            e = hipFuncSetAttribute((const void*)k_ray_samples<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            e = hipFuncSetAttribute((const void*)k_ray_samples<MT, NTW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             if (e != hipSuccess) return e;
             set2 = lds2;
         }
-        hipLaunchKernelGGL((k_ray_samples<MT, NTW>), dim3((R + rpw - 1) / rpw), dim3(MV_THREADS), lds2, stream, net, tp, cam_loc, dirs, R, P,
+        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3((R + rpw - 1) / rpw), dim3(64 * NW), lds2, stream, net, tp, cam_loc, dirs, R, P,
                            training, rpw, intervals, steps, points, mask, dists, w_zmin, w_zmax, w_list, counters);
     }
     return hipGetLastError();
@@ -371,14 +372,23 @@ hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp
                            float* dists, float* w_zmin, float* w_zmax, int* w_list, unsigned long long* counters, hipStream_t stream) {
     int maxnt = 0;
     for (int l = 0; l < net.n_layers - 1; ++l) maxnt = net.L[l].NT > maxnt ? net.L[l].NT : maxnt;
-    const bool wide = maxnt > 16;                               // > 256 columns: 8 column tiles per wave, at most 2 row tiles
     if (maxnt > 32) return hipErrorInvalidValue;
-#define MV_GO(MT_, NTW_) return launch_trace<MT_, NTW_>(stages, net, tp, cam_loc, dirs, om, B, P, training, rpw, intervals, steps, points, mask, dists, \
-                                                        w_zmin, w_zmax, w_list, counters, stream)
-    if (wide) { if (mt >= 2) MV_GO(2, 8); MV_GO(1, 8); }
-    if (mt >= 4) MV_GO(4, 4);
-    if (mt >= 2) MV_GO(2, 4);
-    MV_GO(1, 4);
+    // waves per workgroup: 8 (two per SIMD) once there are >= 2 column tiles per wave to share; MVSDF_NW=4 forces 4 (A/B runs)
+    static int nw_env = -1;
+    if (nw_env < 0) { const char* e = getenv("MVSDF_NW"); nw_env = e ? atoi(e) : 0; }
+    const bool eight = (nw_env == 8) || (nw_env != 4 && maxnt >= 16);
+#define MV_GO(MT_, NTW_, NW_) return launch_trace<MT_, NTW_, NW_>(stages, net, tp, cam_loc, dirs, om, B, P, training, rpw, intervals, steps, points, mask, dists, \
+                                                             w_zmin, w_zmax, w_list, counters, stream)
+    if (eight) {
+        if (maxnt > 16) { if (mt >= 2) MV_GO(2, 4, 8); MV_GO(1, 4, 8); }
+        if (mt >= 4) MV_GO(4, 2, 8);
+        if (mt >= 2) MV_GO(2, 2, 8);
+        MV_GO(1, 2, 8);
+    }
+    if (maxnt > 16) { if (mt >= 2) MV_GO(2, 8, 4); MV_GO(1, 8, 4); }
+    if (mt >= 4) MV_GO(4, 4, 4);
+    if (mt >= 2) MV_GO(2, 4, 4);
+    MV_GO(1, 4, 4);
 #undef MV_GO
 }
 
