@@ -50,9 +50,9 @@ enum {
     MVSDF_CNT_ROWS_SAMPLER = 1, /* ... by ray_sampler                       (ray_tracing.py:218) */
     MVSDF_CNT_ROWS_SECANT = 2,  /* ... by secant                            (ray_tracing.py:266) */
     MVSDF_CNT_ROWS_MINSDF = 3,  /* ... by minimal_sdf_points                (ray_tracing.py:301) */
-    MVSDF_CNT_ITEMS = 4,        /* rays on the sample work list */
-    MVSDF_CNT_N_SAMPLER = 5,
-    MVSDF_CNT_N_MINSDF = 6
+    MVSDF_CNT_N_SECANT = 4,     /* rays that ran the secant */
+    MVSDF_CNT_N_SAMPLER = 5,    /* rays on the sampler work list */
+    MVSDF_CNT_N_MINSDF = 6      /* rays on the min-sdf work list */
 };
 
 int mvsdf_version(void);

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, 'libmvsdf_hip.so')
+SO_PATH = os.environ.get('MVSDF_LIB') or os.path.join(_HERE, 'libmvsdf_hip.so')   # MVSDF_LIB: dev override (ablation builds)
 MAX_LAYERS = 12
 _lib = None
 

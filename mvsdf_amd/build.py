@@ -18,18 +18,20 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=(), tag=''):
+    """tag != '': a side build (objects / .so get the suffix; used for ablation experiments only)."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    so_path = SO if not tag else SO.replace('.so', '_%s.so' % tag)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     headers.append(os.path.join(HERE, '..', 'include', 'mvsdf_hip.h'))
     objs = []
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace('.hip', '.o'))
+        o = os.path.join(CSRC, src.replace('.hip', (tag and '_' + tag) + '.o'))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            cmd = [hipcc] + FLAGS + list(extra_flags) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -40,10 +42,10 @@ def build(force=False, verbose=False):
             raise RuntimeError('hipcc failed on %s' % src)
         if verbose and out:
             print(out.decode())
-    if force or procs or _stale(SO, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', SO] + objs
+    if force or procs or _stale(so_path, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', so_path] + objs
         subprocess.check_call(cmd)
-    return SO
+    return so_path
 
 
 if __name__ == '__main__':

@@ -16,6 +16,12 @@
 
 #define MV_THREADS 256
 
+// dev-only ablation switches (never set in the shipped build): 1 = softplus -> identity, 2 = skip the GEMM
+#ifndef MV_ABLATE
+#define MV_ABLATE 0
+#endif
+__device__ __forceinline__ float mv_act(float z) { return (MV_ABLATE & 1) ? z * 0.5f : dm_softplus100(z); }
+
 template <int MTc, int NTW>
 __device__ __forceinline__ void mv_zero_acc(f32x4 (&acc)[MTc][NTW]) {
 #pragma unroll
@@ -25,48 +31,52 @@ __device__ __forceinline__ void mv_zero_acc(f32x4 (&acc)[MTc][NTW]) {
 }
 
 // acc[rt][t] += act[rt*16.., :K] * W[(ct0+t)*16.., :K]^T    for t < NT (compile time), rt < MTc.
-// Software pipelined by hand: A (LDS) and B (global/L2) fragments of k-block kb+1 are in flight while the
-// 4*MTc*NT MFMAs of k-block kb issue.  No guards inside: the caller dispatches on the (wave-uniform) tile count.
-template <int MTc, int NT, int NTW>
-__device__ __forceinline__ void mv_gemm_tiles(const MvLayer& L, const float* __restrict__ act, int S, int ct0,
-                                              f32x4 (&acc)[MTc][NTW], int lane) {
+// Software pipelined by hand with a ring of PD stages: the A (LDS) and B (global/L2) fragments of k-blocks kb+1..kb+PD-1 are
+// in flight while the 4*MTc*NT MFMAs of k-block kb issue; a stage is refilled right after its MFMAs.  KB % PD == 0.
+// No guards inside: the caller dispatches on the (wave-uniform) tile count.  sched_barrier pins the order (the scheduler
+// would otherwise sink the prefetches below the MFMAs to save registers).
+template <int MTc, int NT, int NTW, int PD>
+__device__ __forceinline__ void mv_gemm_ring(const MvLayer& L, const float* __restrict__ act, int S, int ct0,
+                                             f32x4 (&acc)[MTc][NTW], int lane) {
     const int KB = L.KB;
     const float4* __restrict__ wp = L.wp + (size_t)ct0 * KB * 64 + lane;
     const float* arow = act + (lane & 15) * S + 4 * (lane >> 4);
-    float4 b0[NT], b1[NT], a0[MTc], a1[MTc];
+    float4 b[PD][NT], a[PD][MTc];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) b0[t] = wp[(size_t)t * KB * 64];
+    for (int d = 0; d < PD; ++d) {
 #pragma unroll
-    for (int r = 0; r < MTc; ++r) a0[r] = *(const float4*)(arow + r * 16 * S);
-    for (int kb = 0; kb < KB; kb += 2) {          // KB is even (K padded to 32); all prefetches unconditional
+        for (int t = 0; t < NT; ++t) b[d][t] = wp[((size_t)t * KB + d) * 64];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b1[t] = wp[((size_t)t * KB + kb + 1) * 64];
-#pragma unroll
-        for (int r = 0; r < MTc; ++r) a1[r] = *(const float4*)(arow + r * 16 * S + (kb + 1) * 16);
-        __builtin_amdgcn_sched_barrier(0);            // keep the prefetch ABOVE the MFMA block (the scheduler would sink it)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int r = 0; r < MTc; ++r)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a0[r])[s], ((const float*)&b0[t])[s], acc[r][t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        const int kn = (kb + 2 < KB) ? kb + 2 : kb;   // last iteration: harmless re-load
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b0[t] = wp[((size_t)t * KB + kn) * 64];
-#pragma unroll
-        for (int r = 0; r < MTc; ++r) a0[r] = *(const float4*)(arow + r * 16 * S + kn * 16);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int r = 0; r < MTc; ++r)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a1[r])[s], ((const float*)&b1[t])[s], acc[r][t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < MTc; ++r) a[d][r] = *(const float4*)(arow + r * 16 * S + d * 16);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kb0 = 0; kb0 < KB; kb0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a[d][r])[s], ((const float*)&b[d][t])[s], acc[r][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = (kb0 + d + PD < KB) ? kb0 + d + PD : kb0 + d;      // tail: harmless re-load of the same block
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[d][t] = wp[((size_t)t * KB + kn) * 64];
+#pragma unroll
+            for (int r = 0; r < MTc; ++r) a[d][r] = *(const float4*)(arow + r * 16 * S + kn * 16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int MTc, int NT, int NTW>
+__device__ __forceinline__ void mv_gemm_tiles(const MvLayer& L, const float* __restrict__ act, int S, int ct0,
+                                              f32x4 (&acc)[MTc][NTW], int lane) {
+    // deep ring when a k-block is short (few row tiles) and the register budget allows it
+    if (MTc * NT <= 8 && (L.KB & 3) == 0) mv_gemm_ring<MTc, NT, NTW, 4>(L, act, S, ct0, acc, lane);
+    else mv_gemm_ring<MTc, NT, NTW, 2>(L, act, S, ct0, acc, lane);
 }
 
 // wave-uniform dispatch on the number of column tiles this wave owns (1..NTW)
@@ -139,7 +149,7 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
         f32x4 acc[MTc][NTW];
         mv_zero_acc<MTc, NTW>(acc);
         __syncthreads();                                      // inputs of layer l complete
-        if (ntw > 0) mv_gemm_dispatch<MTc, NTW>(L, act, S, ct0, ntw, acc, lane);
+        if (ntw > 0 && !(MV_ABLATE & 2)) mv_gemm_dispatch<MTc, NTW>(L, act, S, ct0, ntw, acc, lane);
         __syncthreads();                                      // every wave done reading act (in-place update)
         if (last) {
             if (w == 0 && r == 0) {
@@ -163,7 +173,7 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
                         for (int a = 0; a < MTc; ++a)
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                float h = dm_softplus100(acc[a][t][i] + bv);     // Softplus(beta=100), idr.py:91-92
+                                float h = mv_act(acc[a][t][i] + bv);              // Softplus(beta=100), idr.py:91-92
                                 if (to_skip) h = dm_div_sqrt2(h);                // cat([x, input]) / sqrt(2), idr.py:86-87
                                 act[(a * 16 + 4 * q + i) * S + pos] = h;
                             }
@@ -187,4 +197,89 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
         }
     }
     __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Phase-staggered two-group evaluation (8 waves = 512 threads).  Group 0 (waves 0-3) owns rows [0, 16*MTg), group 1
+// (waves 4-7) rows [16*MTg, 32*MTg).  Every phase one group runs the GEMM of a layer (MFMA pipe) while the other runs
+// the softplus epilogue of ITS previous GEMM (VALU pipe): each SIMD hosts one wave of each group, so matrix and vector
+// work of different rows overlap and the MFMA pipe stays busy.  Phases are separated by ordinary workgroup barriers:
+//     phase p : group 0 -> (p even ? GEMM(p/2) : EPI((p-1)/2)),   group 1 -> the same one phase later.
+// Same arithmetic, same order as mv_sdf_eval_col0 (bit-exact).  LDS: act[2][16*MTg][S], pe[2][16*MTg][d0],
+// pts[32*MTg][3], out[32*MTg].  ntiles (1..2*MTg) row tiles are valid; group g is active iff it owns a valid tile.
+template <int MTg, int NTW>
+__device__ void mv_sdf_eval_col0_2g(const MvNet& net, float* act, float* pe, const float* pts, float* out, int ntiles, int tid) {
+    constexpr int NTH = 256;                                    // threads per group
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = w >> 2, wl = w & 3, gt = tid & 255;
+    const int r = lane & 15, q = lane >> 4;
+    const int S = net.S, rows = MTg * 16, d0 = 3 + 6 * net.multires, nl = net.n_layers;
+    const bool active = (g == 0) || (ntiles > MTg);
+    float* actg = act + g * rows * S;
+    float* peg = pe + g * rows * d0;
+    const float* ptsg = pts + g * rows * 3;
+    float* outg = out + g * rows;
+    if (active) mv_pe_rows<NTH>(ptsg, peg, actg, S, rows, net.multires, gt);
+    __syncthreads();
+    f32x4 acc[MTg][NTW];
+    int ct0 = 0, ntw = 0;
+    for (int ph = 0; ph <= 2 * nl; ++ph) {
+        const int my = ph - g;
+        if (active && my >= 0 && my < 2 * nl) {
+            const int l = my >> 1;
+            const MvLayer& L = net.L[l];
+            const bool last = (l == nl - 1);
+            if ((my & 1) == 0) {                                 // ---- GEMM(l)
+                const int NT = last ? 1 : L.NT;
+                const int per = (NT + 3) >> 2;
+                ct0 = wl * per;
+                ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
+                mv_zero_acc<MTg, NTW>(acc);
+                if (ntw > 0) mv_gemm_dispatch<MTg, NTW>(L, actg, S, ct0, ntw, acc, lane);
+            } else if (last) {                                   // ---- EPI(last): column 0 + bias
+                if (wl == 0 && r == 0) {
+                    const float b0 = L.bias[0];
+#pragma unroll
+                    for (int a = 0; a < MTg; ++a)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) outg[a * 16 + 4 * q + i] = acc[a][0][i] + b0;
+                }
+            } else {                                             // ---- EPI(l): softplus, in place (this group's rows only)
+                const bool to_skip = (l + 1 == net.skip_layer);
+                const int N = L.N;
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    if (t < ntw) {
+                        const int col = (ct0 + t) * 16 + r;
+                        if (col < N) {
+                            const float bv = L.bias[col];
+                            const int pos = (ct0 + t) * 16 + ((r & 3) << 2) + (r >> 2);
+#pragma unroll
+                            for (int a = 0; a < MTg; ++a)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    float h = mv_act(acc[a][t][i] + bv);
+                                    if (to_skip) h = dm_div_sqrt2(h);
+                                    actg[(a * 16 + 4 * q + i) * S + pos] = h;
+                                }
+                        }
+                    }
+                }
+                const int Kn = net.L[l + 1].K, Kpn = net.L[l + 1].KB * 16;
+                if (to_skip) {
+                    for (int idx = gt; idx < rows * d0; idx += NTH) {
+                        const int row = idx / d0, j = idx - row * d0;
+                        actg[row * S + mv_perm(N + j)] = dm_div_sqrt2(peg[row * d0 + j]);
+                    }
+                }
+                if (Kpn > Kn) {
+                    const int pad = Kpn - Kn;
+                    for (int idx = gt; idx < rows * pad; idx += NTH) {
+                        const int row = idx / pad, j = idx - row * pad;
+                        actg[row * S + mv_perm(Kn + j)] = 0.0f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
 }

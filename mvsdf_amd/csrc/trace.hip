@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(MvNet net, MvTracePara
                                                             int R, int P, int training, float* __restrict__ o_points,
                                                             uint8_t* __restrict__ o_mask, float* __restrict__ o_dists,
                                                             float* __restrict__ w_zmin, float* __restrict__ w_zmax, int* __restrict__ w_list,
-                                                            unsigned long long* __restrict__ counters) {
+                                                            int* __restrict__ w_list_min, unsigned long long* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT, NR = 8 * MT;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -184,50 +184,51 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(MvNet net, MvTracePara
         o_points[3 * (size_t)gid + 0] = c[0] + dist * d[0];
         o_points[3 * (size_t)gid + 1] = c[1] + dist * d[1];
         o_points[3 * (size_t)gid + 2] = c[2] + dist * d[2];
-        if (listed) {
-            const unsigned long long idx = atomicAdd(&counters[MV_CNT_ITEMS], 1ull);
-            w_list[idx] = gid | (kind << 28);
+        if (listed) {                                                             // two work lists: sampler rays / min-sdf rays
+            const bool smp = kind & MV_ITEM_SAMPLER;
+            const unsigned long long idx = atomicAdd(&counters[smp ? MV_CNT_N_SAMPLER : MV_CNT_N_MINSDF], 1ull);
+            (smp ? w_list : w_list_min)[idx] = gid | (kind << 28);
             w_zmin[gid] = zmin;
             w_zmax[gid] = zmax;
-            atomicAdd(&counters[(kind & MV_ITEM_SAMPLER) ? MV_CNT_N_SAMPLER : MV_CNT_N_MINSDF], 1ull);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+struct SampleCtx {
+    const float* cam_loc; const float* dirs; int R, P, training, RPW;
+    const float* intervals; const float* steps;
+    float* o_points; uint8_t* o_mask; float* o_dists;
+    const float* w_zmin; const float* w_zmax;
+    float* sec_state;                 // [4][R]: z_low, z_high, sdf_low, sdf_high of secant rays
+    int* sec_list;                    // gids of rays that need the secant
+    unsigned long long* counters;
+};
+
+// n_steps samples for RPW listed rays (sampler rays: ray_tracing.py:198-239; min-sdf rays: 280-308), evaluated ROWS at a time,
+// then one thread per ray reduces.  Sampler rays with a sign change are handed to the batched secant stage.
 template <int MT, int NTW, int NW>
-__global__ __launch_bounds__(64 * NW) void k_ray_samples(MvNet net, MvTraceParams tp, const float* __restrict__ cam_loc,
-                                                           const float* __restrict__ dirs, int R, int P, int training, int RPW,
-                                                           const float* __restrict__ intervals, const float* __restrict__ steps,
-                                                           float* __restrict__ o_points, uint8_t* __restrict__ o_mask,
-                                                           float* __restrict__ o_dists, const float* __restrict__ w_zmin,
-                                                           const float* __restrict__ w_zmax, const int* __restrict__ w_list,
-                                                           unsigned long long* __restrict__ counters) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ void mv_sample_items(const MvNet& net, const MvTraceParams& tp, const SampleCtx& c, const int* __restrict__ list, int n_list,
+                                int block, float* smem) {
     constexpr int ROWS = 16 * MT;
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_steps = tp.n_steps;
-    const int n_items_total = (int)counters[MV_CNT_ITEMS];
-    const int item0 = blockIdx.x * RPW;
-    if (item0 >= n_items_total) return;
-    const int n_items = min(RPW, n_items_total - item0);
+    const int tid = threadIdx.x;
+    const int n_steps = tp.n_steps, RPW = c.RPW;
+    const int item0 = block * RPW;
+    if (item0 >= n_list) return;
+    const int n_items = min(RPW, n_list - item0);
     TraceLds lds = mv_carve(smem, ROWS, net.S, 3 + 6 * net.multires, RPW * n_steps);
-    int* s_n = lds.misc;
     float* s_ray = (float*)(lds.misc + 4);              // per item: c[3], d[3], zmin, zmax  (8 floats)
     int* s_kind = (int*)(s_ray + 8 * RPW);               // per item: gid | kind << 28
-
     if (tid < n_items) {
-        const int e = w_list[item0 + tid];
+        const int e = list[item0 + tid];
         const int gid = e & 0x0fffffff;
-        const int b = gid / P;
+        const int b = gid / c.P;
         float* rr = s_ray + 8 * tid;
-        for (int i = 0; i < 3; ++i) { rr[i] = cam_loc[3 * b + i]; rr[3 + i] = dirs[3 * (size_t)gid + i]; }
-        rr[6] = w_zmin[gid]; rr[7] = w_zmax[gid];
+        for (int i = 0; i < 3; ++i) { rr[i] = c.cam_loc[3 * b + i]; rr[3 + i] = c.dirs[3 * (size_t)gid + i]; }
+        rr[6] = c.w_zmin[gid]; rr[7] = c.w_zmax[gid];
         s_kind[tid] = e;
     }
     __syncthreads();
-
-    // ---- n_steps samples per item, evaluated ROWS at a time ----
     const int total = n_items * n_steps;
     for (int base = 0; base < total; base += ROWS) {
         const int nr = min(ROWS, total - base);
@@ -236,8 +237,8 @@ __global__ __launch_bounds__(64 * NW) void k_ray_samples(MvNet net, MvTraceParam
             const float* rr = s_ray + 8 * it;
             const bool samp = (s_kind[it] >> 28) & MV_ITEM_SAMPLER;
             const float zmin = rr[6], zmax = rr[7];
-            const float z = samp ? (zmin + intervals[i] * (zmax - zmin))          // ray_tracing.py:208
-                                 : (steps[i] * (zmax - zmin) + zmin);              // ray_tracing.py:290
+            const float z = samp ? (zmin + c.intervals[i] * (zmax - zmin))        // ray_tracing.py:208
+                                 : (c.steps[i] * (zmax - zmin) + zmin);            // ray_tracing.py:290
             float* p = lds.pts + tid * 3;
             p[0] = rr[0] + z * rr[3]; p[1] = rr[1] + z * rr[4]; p[2] = rr[2] + z * rr[5];
         }
@@ -246,24 +247,16 @@ __global__ __launch_bounds__(64 * NW) void k_ray_samples(MvNet net, MvTraceParam
         if (tid < nr) lds.sv[base + tid] = lds.sdfv[tid];
         __syncthreads();
     }
-
-    // ---- per-item reduction (one thread per item), then secant rounds ----
-    bool do_secant = false;
-    float z_low = 0.f, z_high = 0.f, sdf_low = 0.f, sdf_high = 0.f, z_pred = 0.f;
-    float c[3] = {0, 0, 0}, d[3] = {0, 0, 0};
-    int gid = 0;
-    bool is_item = tid < n_items, net_surf = false, samp = false;
-    float dist = 0.f;
-    if (is_item) {
+    if (tid < n_items) {
         const float* rr = s_ray + 8 * tid;
-        for (int i = 0; i < 3; ++i) { c[i] = rr[i]; d[i] = rr[3 + i]; }
+        float cc[3], d[3];
+        for (int i = 0; i < 3; ++i) { cc[i] = rr[i]; d[i] = rr[3 + i]; }
         const int e = s_kind[tid];
-        gid = e & 0x0fffffff;
-        const int kind = e >> 28;
-        samp = kind & MV_ITEM_SAMPLER;
-        const bool om = kind & MV_ITEM_OM;
+        const int gid = e & 0x0fffffff, kind = e >> 28;
+        const bool samp = kind & MV_ITEM_SAMPLER, om = kind & MV_ITEM_OM;
         const float zmin = rr[6], zmax = rr[7];
         const float* sv = lds.sv + tid * n_steps;
+        float dist;
         if (samp) {
             int ind = 0; float best = INFINITY;                                   // argmin(sign(sdf) * [n..1]), first min
             for (int i = 0; i < n_steps; ++i) {
@@ -272,61 +265,95 @@ __global__ __launch_bounds__(64 * NW) void k_ray_samples(MvNet net, MvTraceParam
                 const float tv = sg * (float)(n_steps - i);
                 if (tv < best) { best = tv; ind = i; }
             }
-            dist = zmin + intervals[ind] * (zmax - zmin);
-            net_surf = sv[ind] < 0.f;
+            dist = zmin + c.intervals[ind] * (zmax - zmin);
+            const bool net_surf = sv[ind] < 0.f;
             if (!(om && net_surf)) {                                              // P_out: argmin sdf, ray_tracing.py:229-235
                 int i2 = 0; float b2 = INFINITY;
                 for (int i = 0; i < n_steps; ++i) if (sv[i] < b2) { b2 = sv[i]; i2 = i; }
-                dist = zmin + intervals[i2] * (zmax - zmin);
+                dist = zmin + c.intervals[i2] * (zmax - zmin);
             }
-            do_secant = training ? (net_surf && om) : net_surf;                   // ray_tracing.py:242
+            c.o_mask[gid] = net_surf ? 1 : 0;                                      // ray_tracing.py:237-239, 61
+            const bool do_secant = c.training ? (net_surf && om) : net_surf;       // ray_tracing.py:242
             if (do_secant) {
                 int lo = ind - 1; if (lo < 0) lo += n_steps;                      // negative index wraps
-                z_high = zmin + intervals[ind] * (zmax - zmin); sdf_high = sv[ind];
-                z_low = zmin + intervals[lo] * (zmax - zmin); sdf_low = sv[lo];
-                z_pred = -sdf_low * (z_high - z_low) / (sdf_high - sdf_low) + z_low;
+                const unsigned long long k = atomicAdd(&c.counters[MV_CNT_N_SECANT], 1ull);
+                c.sec_list[k] = gid;
+                c.sec_state[gid] = zmin + c.intervals[lo] * (zmax - zmin);
+                c.sec_state[(size_t)c.R + gid] = zmin + c.intervals[ind] * (zmax - zmin);
+                c.sec_state[2 * (size_t)c.R + gid] = sv[lo];
+                c.sec_state[3 * (size_t)c.R + gid] = sv[ind];
             }
         } else {
             int bi = 0; float bv = INFINITY;                                      // min over the shared random steps
             for (int i = 0; i < n_steps; ++i) if (sv[i] < bv) { bv = sv[i]; bi = i; }
-            dist = steps[bi] * (zmax - zmin) + zmin;
+            dist = c.steps[bi] * (zmax - zmin) + zmin;
         }
+        c.o_dists[gid] = dist;                                                     // secant rays are overwritten by the secant stage
+        c.o_points[3 * (size_t)gid + 0] = cc[0] + dist * d[0];
+        c.o_points[3 * (size_t)gid + 1] = cc[1] + dist * d[1];
+        c.o_points[3 * (size_t)gid + 2] = cc[2] + dist * d[2];
     }
-    unsigned long long sec_rows = 0;
-    for (int it = 0; it < tp.n_secant; ++it) {                                    // secant, ray_tracing.py:260-278
-        int row = 0;
-        if (w == 0) {
-            const unsigned long long m = __ballot(do_secant);
-            row = __popcll(m & ((1ull << lane) - 1ull));
-            if (do_secant) { float* p = lds.pts + row * 3; p[0] = c[0] + z_pred * d[0]; p[1] = c[1] + z_pred * d[1]; p[2] = c[2] + z_pred * d[2]; }
-            if (lane == 0) *s_n = __popcll(m);
-        }
+    if (tid == 0) {
+        unsigned long long ns = 0, nm = 0;
+        for (int i = 0; i < n_items; ++i) { if ((s_kind[i] >> 28) & MV_ITEM_SAMPLER) ns++; else nm++; }
+        if (ns) atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER], ns * (unsigned long long)n_steps);
+        if (nm) atomicAdd(&c.counters[MV_CNT_ROWS_MINSDF], nm * (unsigned long long)n_steps);
+    }
+}
+
+// secant (ray_tracing.py:260-278) for 16*MT listed rays per workgroup: n_secant dependent rounds, every round one evaluation of
+// all the workgroup's rays (rows are full tiles instead of one or two rows per workgroup).
+template <int MT, int NTW, int NW>
+__device__ void mv_secant_rays(const MvNet& net, const MvTraceParams& tp, const SampleCtx& c, int n_list, int block, float* smem) {
+    constexpr int ROWS = 16 * MT;
+    const int tid = threadIdx.x;
+    const int r0 = block * ROWS;
+    if (r0 >= n_list) return;
+    const int n = min(ROWS, n_list - r0);
+    TraceLds lds = mv_carve(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
+    const bool mine = tid < n;
+    int gid = 0;
+    float cc[3] = {0, 0, 0}, d[3] = {0, 0, 0}, z_low = 0, z_high = 0, sdf_low = 0, sdf_high = 1, z_pred = 0;
+    if (mine) {
+        gid = c.sec_list[r0 + tid];
+        const int b = gid / c.P;
+        for (int i = 0; i < 3; ++i) { cc[i] = c.cam_loc[3 * b + i]; d[i] = c.dirs[3 * (size_t)gid + i]; }
+        z_low = c.sec_state[gid]; z_high = c.sec_state[(size_t)c.R + gid];
+        sdf_low = c.sec_state[2 * (size_t)c.R + gid]; sdf_high = c.sec_state[3 * (size_t)c.R + gid];
+        z_pred = -sdf_low * (z_high - z_low) / (sdf_high - sdf_low) + z_low;
+    }
+    for (int it = 0; it < tp.n_secant; ++it) {
+        if (tid < ROWS) { float* p = lds.pts + tid * 3; p[0] = cc[0] + z_pred * d[0]; p[1] = cc[1] + z_pred * d[1]; p[2] = cc[2] + z_pred * d[2]; }
         __syncthreads();
-        const int n = *s_n;
-        if (n == 0) break;
-        sec_rows += (unsigned long long)n;
         mv_eval_dispatch<MT, NTW, NW>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
-        if (w == 0 && do_secant) {
-            const float sm = lds.sdfv[row];
+        if (mine) {
+            const float sm = lds.sdfv[tid];
             if (sm > 0.f) { z_low = z_pred; sdf_low = sm; }
             if (sm < 0.f) { z_high = z_pred; sdf_high = sm; }
             z_pred = -sdf_low * (z_high - z_low) / (sdf_high - sdf_low) + z_low;
         }
     }
-    if (is_item) {
-        if (do_secant) dist = z_pred;
-        o_dists[gid] = dist;
-        o_points[3 * (size_t)gid + 0] = c[0] + dist * d[0];
-        o_points[3 * (size_t)gid + 1] = c[1] + dist * d[1];
-        o_points[3 * (size_t)gid + 2] = c[2] + dist * d[2];
-        if (samp) o_mask[gid] = net_surf ? 1 : 0;                                  // ray_tracing.py:237-239, 61
+    if (mine) {
+        c.o_dists[gid] = z_pred;
+        c.o_points[3 * (size_t)gid + 0] = cc[0] + z_pred * d[0];
+        c.o_points[3 * (size_t)gid + 1] = cc[1] + z_pred * d[1];
+        c.o_points[3 * (size_t)gid + 2] = cc[2] + z_pred * d[2];
     }
-    if (tid == 0) {
-        unsigned long long ns = 0, nm = 0;
-        for (int i = 0; i < n_items; ++i) { if ((s_kind[i] >> 28) & MV_ITEM_SAMPLER) ns++; else nm++; }
-        atomicAdd(&counters[MV_CNT_ROWS_SAMPLER], ns * (unsigned long long)n_steps);
-        atomicAdd(&counters[MV_CNT_ROWS_MINSDF], nm * (unsigned long long)n_steps);
-        if (sec_rows) atomicAdd(&counters[MV_CNT_ROWS_SECANT], sec_rows);
+    if (tid == 0) atomicAdd(&c.counters[MV_CNT_ROWS_SECANT], (unsigned long long)n * (unsigned long long)tp.n_secant);
+}
+
+// stage 2a: samples of the sampler rays.   stage 2b: secant workgroups (first sec_blocks blocks) + min-sdf samples (the rest):
+// the dependent secant chains of a few dozen workgroups overlap with the throughput-shaped min-sdf sampling.
+template <int MT, int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_ray_samples(MvNet net, MvTraceParams tp, SampleCtx c, const int* __restrict__ list_s,
+                                                        const int* __restrict__ list_m, int stage, int sec_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (stage == 0) {
+        mv_sample_items<MT, NTW, NW>(net, tp, c, list_s, (int)c.counters[MV_CNT_N_SAMPLER], blockIdx.x, smem);
+    } else if ((int)blockIdx.x < sec_blocks) {
+        mv_secant_rays<MT, NTW, NW>(net, tp, c, (int)c.counters[MV_CNT_N_SECANT], blockIdx.x, smem);
+    } else {
+        mv_sample_items<MT, NTW, NW>(net, tp, c, list_m, (int)c.counters[MV_CNT_N_MINSDF], blockIdx.x - sec_blocks, smem);
     }
 }
 
@@ -340,9 +367,14 @@ static size_t trace_lds_bytes(const MvNet& net, int MT, int sv_floats, int rpw) 
 template <int MT, int NTW, int NW>
 static hipError_t launch_trace(int stages, const MvNet& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, const uint8_t* om,
                                int B, int P, int training, int rpw, const float* intervals, const float* steps, float* points,
-                               uint8_t* mask, float* dists, float* w_zmin, float* w_zmax, int* w_list, unsigned long long* counters,
-                               hipStream_t stream) {
-    const int R = B * P, NR = 8 * MT;
+                               uint8_t* mask, float* dists, float* ws, unsigned long long* counters, hipStream_t stream) {
+    const int R = B * P, NR = 8 * MT, ROWS = 16 * MT;
+    float* w_zmin = ws;
+    float* w_zmax = w_zmin + R;
+    float* sec_state = w_zmax + R;                               // [4][R]
+    int* w_list = (int*)(sec_state + 4 * (size_t)R);
+    int* w_list_min = w_list + R;
+    int* sec_list = w_list_min + R;
     const size_t lds1 = trace_lds_bytes(net, MT, 0, 0), lds2 = trace_lds_bytes(net, MT, rpw * tp.n_steps, rpw);
     static size_t set1 = 0, set2 = 0;                           // raise the dynamic-LDS cap once per size (per instantiation)
     hipError_t e;
@@ -353,7 +385,7 @@ static hipError_t launch_trace(int stages, const MvNet& net, const MvTraceParams
             set1 = lds1;
         }
         hipLaunchKernelGGL((k_sphere_trace<MT, NTW, NW>), dim3((R + NR - 1) / NR), dim3(64 * NW), lds1, stream, net, tp, cam_loc, dirs, om, R, P,
-                           training, points, mask, dists, w_zmin, w_zmax, w_list, counters);
+                           training, points, mask, dists, w_zmin, w_zmax, w_list, w_list_min, counters);
     }
     if (stages & 2) {
         if (lds2 > set2) {
@@ -361,15 +393,21 @@ static hipError_t launch_trace(int stages, const MvNet& net, const MvTraceParams
             if (e != hipSuccess) return e;
             set2 = lds2;
         }
-        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3((R + rpw - 1) / rpw), dim3(64 * NW), lds2, stream, net, tp, cam_loc, dirs, R, P,
-                           training, rpw, intervals, steps, points, mask, dists, w_zmin, w_zmax, w_list, counters);
+        SampleCtx c;
+        c.cam_loc = cam_loc; c.dirs = dirs; c.R = R; c.P = P; c.training = training; c.RPW = rpw; c.intervals = intervals; c.steps = steps;
+        c.o_points = points; c.o_mask = mask; c.o_dists = dists; c.w_zmin = w_zmin; c.w_zmax = w_zmax; c.sec_state = sec_state;
+        c.sec_list = sec_list; c.counters = counters;
+        const int item_blocks = (R + rpw - 1) / rpw, sec_blocks = (R + ROWS - 1) / ROWS;
+        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(item_blocks), dim3(64 * NW), lds2, stream, net, tp, c, w_list, w_list_min, 0, 0);
+        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(sec_blocks + (training ? item_blocks : 0)), dim3(64 * NW), lds2, stream, net, tp, c,
+                           w_list, w_list_min, 1, sec_blocks);
     }
     return hipGetLastError();
 }
 
 hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp, int mt, const float* cam_loc, const float* dirs, const uint8_t* om,
                            int B, int P, int training, int rpw, const float* intervals, const float* steps, float* points, uint8_t* mask,
-                           float* dists, float* w_zmin, float* w_zmax, int* w_list, unsigned long long* counters, hipStream_t stream) {
+                           float* dists, float* ws, unsigned long long* counters, hipStream_t stream) {
     int maxnt = 0;
     for (int l = 0; l < net.n_layers - 1; ++l) maxnt = net.L[l].NT > maxnt ? net.L[l].NT : maxnt;
     if (maxnt > 32) return hipErrorInvalidValue;
@@ -378,7 +416,7 @@ hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp
     if (nw_env < 0) { const char* e = getenv("MVSDF_NW"); nw_env = e ? atoi(e) : 0; }
     const bool eight = (nw_env == 8) || (nw_env != 4 && maxnt >= 16);
 #define MV_GO(MT_, NTW_, NW_) return launch_trace<MT_, NTW_, NW_>(stages, net, tp, cam_loc, dirs, om, B, P, training, rpw, intervals, steps, points, mask, dists, \
-                                                             w_zmin, w_zmax, w_list, counters, stream)
+                                                             ws, counters, stream)
     if (eight) {
         if (maxnt > 16) { if (mt >= 2) MV_GO(2, 4, 8); MV_GO(1, 4, 8); }
         if (mt >= 4) MV_GO(4, 2, 8);
@@ -396,7 +434,7 @@ hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp
 #include "capi_util.h"
 extern "C" {
 
-size_t mvsdf_trace_workspace_bytes(int R) { return (size_t)(R > 0 ? R : 0) * 12 + 256; }
+size_t mvsdf_trace_workspace_bytes(int R) { return (size_t)(R > 0 ? R : 0) * 36 + 256; }
 
 static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
                       const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
@@ -416,14 +454,11 @@ static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTracePara
     if (rpw < 1) rpw = 1;
     if (rpw > 16) rpw = 16;
     hipStream_t s = (hipStream_t)stream;
-    float* w_zmin = (float*)workspace;
-    float* w_zmax = w_zmin + R;
-    int* w_list = (int*)(w_zmax + R);
     hipError_t e = hipSuccess;
     if (stages & 1) e = hipMemsetAsync(counters, 0, 16 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return mv_check(e, "mvsdf_trace: memset");
     e = mv_trace_launch(stages, net, *tp, mt, cam_loc, ray_dirs, object_mask, B, P, training, rpw, intervals,
-                        minsdf_steps ? minsdf_steps : intervals, points, mask, dists, w_zmin, w_zmax, w_list, counters, s);
+                        minsdf_steps ? minsdf_steps : intervals, points, mask, dists, (float*)workspace, counters, s);
     return mv_check(e, "mvsdf_trace");
 }
 

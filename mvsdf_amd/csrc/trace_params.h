@@ -6,7 +6,7 @@ typedef MvsdfTraceParams MvTraceParams;
 #define MV_CNT_ROWS_SAMPLER MVSDF_CNT_ROWS_SAMPLER
 #define MV_CNT_ROWS_SECANT MVSDF_CNT_ROWS_SECANT
 #define MV_CNT_ROWS_MINSDF MVSDF_CNT_ROWS_MINSDF
-#define MV_CNT_ITEMS MVSDF_CNT_ITEMS
+#define MV_CNT_N_SECANT MVSDF_CNT_N_SECANT
 #define MV_CNT_N_SAMPLER MVSDF_CNT_N_SAMPLER
 #define MV_CNT_N_MINSDF MVSDF_CNT_N_MINSDF
 #define MV_ITEM_SAMPLER 1
