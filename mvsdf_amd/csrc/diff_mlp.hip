@@ -2,6 +2,7 @@
 // rendering network, orchestrated on one stream from C++ (no host sync, no allocation).  Math: SURVEY.md App. E.
 // Replaces ImplicitNetwork.forward/.gradient (idr.py:77-107), RenderingNetwork.forward (idr.py:145-167) and what
 // torch.autograd does behind loss.backward() for both (idr_train.py:287).
+#include <stdlib.h>
 #include "layer_kernels.h"
 #include "capi_util.h"
 
@@ -95,11 +96,8 @@ __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ launch helpers
-template <int PRO, int EPI>
-static hipError_t launch_layer(LayerArgs& a, hipStream_t s) {
-    if (a.M <= 0) return hipSuccess;
-    // 32 rows per workgroup (MT = 2): enough workgroups at a few thousand rows, weights reused by two row tiles
-    constexpr int MT = 2;
+template <int PRO, int EPI, int MT>
+static hipError_t launch_layer_mt(LayerArgs& a, hipStream_t s) {
     const size_t lds = (size_t)16 * MT * a.S * sizeof(float);
     static size_t lds_set = 0;                                 // per instantiation: raise the dynamic-LDS cap once per size
     if (lds > 48 * 1024 && lds > lds_set) {
@@ -109,6 +107,17 @@ static hipError_t launch_layer(LayerArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL((k_layer<PRO, EPI, MT, 4>), dim3((a.M + 16 * MT - 1) / (16 * MT)), dim3(MV_THREADS), lds, s, a);
     return hipGetLastError();
+}
+
+template <int PRO, int EPI>
+static hipError_t launch_layer(LayerArgs& a, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    // rows per workgroup: 16 while that still leaves the chip under-subscribed (one workgroup per CU), else 32 (weights
+    // reused by two row tiles).  MVSDF_LAYER_MT overrides (dev).
+    static int mt_env = -1;
+    if (mt_env < 0) { const char* e = getenv("MVSDF_LAYER_MT"); mt_env = e ? atoi(e) : 0; }
+    const bool small = mt_env ? (mt_env == 1) : (a.M <= 16 * 512);
+    return small ? launch_layer_mt<PRO, EPI, 1>(a, s) : launch_layer_mt<PRO, EPI, 2>(a, s);
 }
 
 static LayerArgs base_args(const MvLayer& L, int S, int M) {
