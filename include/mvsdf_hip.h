@@ -83,19 +83,22 @@ int mvsdf_sphere_intersection(const float* cam_loc, const float* ray_dirs, int B
  * cam_loc[B][3], ray_dirs[B][P][3], object_mask[B*P] -> points[B*P][3], mask[B*P], dists[B*P].
  * intervals[n_steps] = torch.linspace(0, 1, n_steps) (ray_tracing.py:206); minsdf_steps[n_steps] = the uniform draws
  * of minimal_sdf_points (ray_tracing.py:287), used only when training != 0.
- * counters: uint64[16], zeroed by the call.  workspace: mvsdf_trace_workspace_bytes(B*P) bytes.
- * mt: row tiles (16 rows) per workgroup, 1..4; rpw: sample-list rays per workgroup, 1..16. */
+ * counters: uint64[16], zeroed by the call.  workspace: mvsdf_trace_workspace_bytes(B*P) bytes (n_steps <= 128) or
+ * mvsdf_trace_workspace_bytes_n(B*P, n_steps).
+ * mt: row tiles (16 rows) per workgroup of the sphere-tracing kernel (8*mt rays), 1..4;
+ * mt_samples: row tiles per chunk of the flattened sample-row kernels (sampler / min-sdf), 1..4. */
 size_t mvsdf_trace_workspace_bytes(int R);
+size_t mvsdf_trace_workspace_bytes_n(int R, int n_steps);
 int mvsdf_trace(const MvsdfNetDesc* net, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
                 const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
                 float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
-                size_t workspace_bytes, int mt, int rpw, void* stream);
+                size_t workspace_bytes, int mt, int mt_samples, void* stream);
 /* the two kernel launches of mvsdf_trace separately (stage 1: sphere tracing, zeroes the counters; stage 2: ray sampler +
  * secant + min-sdf), same arguments and workspace -- lets a caller bracket each kernel with events. */
 int mvsdf_trace_stage(int stage, const MvsdfNetDesc* net, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
                       const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
                       float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
-                      size_t workspace_bytes, int mt, int rpw, void* stream);
+                      size_t workspace_bytes, int mt, int mt_samples, void* stream);
 
 /* ---- differentiable SDF network: value + normal and their first/second-order backward ----
  * Replaces ImplicitNetwork.forward / .gradient (idr.py:77-107) and autograd's (double) backward through them.

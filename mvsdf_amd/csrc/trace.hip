@@ -202,103 +202,96 @@ struct SampleCtx {
     const float* w_zmin; const float* w_zmax;
     float* sec_state;                 // [4][R]: z_low, z_high, sdf_low, sdf_high of secant rays
     int* sec_list;                    // gids of rays that need the secant
+    float* sv;                        // [n_list * n_steps] sample values of the list being processed
     unsigned long long* counters;
 };
 
-// n_steps samples for RPW listed rays (sampler rays: ray_tracing.py:198-239; min-sdf rays: 280-308), evaluated ROWS at a time,
-// then one thread per ray reduces.  Sampler rays with a sign change are handed to the batched secant stage.
+// Sample rows of a work list, FLATTENED over rays: global row q = item * n_steps + i.  A workgroup evaluates one chunk of
+// 16*MT consecutive rows (always full tiles, evenly spread over the chip) and stores the SDF values; the per-ray logic runs in
+// k_reduce_items.  Sampler rays: ray_tracing.py:206-219; min-sdf rays: ray_tracing.py:287-301.
 template <int MT, int NTW, int NW>
-__device__ void mv_sample_items(const MvNet& net, const MvTraceParams& tp, const SampleCtx& c, const int* __restrict__ list, int n_list,
-                                int block, float* smem) {
+__device__ void mv_eval_rows(const MvNet& net, const MvTraceParams& tp, const SampleCtx& c, const int* __restrict__ list, int n_list, int chunk,
+                             float* smem) {
     constexpr int ROWS = 16 * MT;
     const int tid = threadIdx.x;
-    const int n_steps = tp.n_steps, RPW = c.RPW;
-    const int item0 = block * RPW;
-    if (item0 >= n_list) return;
-    const int n_items = min(RPW, n_list - item0);
-    TraceLds lds = mv_carve(smem, ROWS, net.S, 3 + 6 * net.multires, RPW * n_steps);
-    float* s_ray = (float*)(lds.misc + 4);              // per item: c[3], d[3], zmin, zmax  (8 floats)
-    int* s_kind = (int*)(s_ray + 8 * RPW);               // per item: gid | kind << 28
-    if (tid < n_items) {
-        const int e = list[item0 + tid];
-        const int gid = e & 0x0fffffff;
-        const int b = gid / c.P;
-        float* rr = s_ray + 8 * tid;
-        for (int i = 0; i < 3; ++i) { rr[i] = c.cam_loc[3 * b + i]; rr[3 + i] = c.dirs[3 * (size_t)gid + i]; }
-        rr[6] = c.w_zmin[gid]; rr[7] = c.w_zmax[gid];
-        s_kind[tid] = e;
-    }
-    __syncthreads();
-    const int total = n_items * n_steps;
-    for (int base = 0; base < total; base += ROWS) {
-        const int nr = min(ROWS, total - base);
+    const int n_steps = tp.n_steps;
+    const long long total = (long long)n_list * n_steps;
+    const long long q0 = (long long)chunk * ROWS;
+    if (q0 >= total) return;
+    const int nr = (int)min((long long)ROWS, total - q0);
+    TraceLds lds = mv_carve(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
+    if (tid < ROWS) {
+        float* p = lds.pts + tid * 3;
         if (tid < nr) {
-            const int row = base + tid, it = row / n_steps, i = row - it * n_steps;
-            const float* rr = s_ray + 8 * it;
-            const bool samp = (s_kind[it] >> 28) & MV_ITEM_SAMPLER;
-            const float zmin = rr[6], zmax = rr[7];
+            const long long q = q0 + tid;
+            const int it = (int)(q / n_steps), i = (int)(q - (long long)it * n_steps);
+            const int e = list[it];
+            const int gid = e & 0x0fffffff;
+            const bool samp = (e >> 28) & MV_ITEM_SAMPLER;
+            const float* cc = c.cam_loc + 3 * (gid / c.P);
+            const float* d = c.dirs + 3 * (size_t)gid;
+            const float zmin = c.w_zmin[gid], zmax = c.w_zmax[gid];
             const float z = samp ? (zmin + c.intervals[i] * (zmax - zmin))        // ray_tracing.py:208
                                  : (c.steps[i] * (zmax - zmin) + zmin);            // ray_tracing.py:290
-            float* p = lds.pts + tid * 3;
-            p[0] = rr[0] + z * rr[3]; p[1] = rr[1] + z * rr[4]; p[2] = rr[2] + z * rr[5];
+            p[0] = cc[0] + z * d[0]; p[1] = cc[1] + z * d[1]; p[2] = cc[2] + z * d[2];
+        } else { p[0] = 0.f; p[1] = 0.f; p[2] = 0.f; }
+    }
+    __syncthreads();
+    mv_eval_dispatch<MT, NTW, NW>(net, (nr + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
+    if (tid < nr) c.sv[q0 + tid] = lds.sdfv[tid];
+}
+
+// Per-ray reduction of the stored sample values (one thread per listed ray): first sign change / P_out argmin and the secant
+// hand-off for sampler rays (ray_tracing.py:221-256), argmin for min-sdf rays (ray_tracing.py:303-307).
+__global__ void k_reduce_items(MvTraceParams tp, SampleCtx c, const int* __restrict__ list, int cnt_index) {
+    const int n_list = (int)c.counters[cnt_index];
+    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= n_list) return;
+    const int n_steps = tp.n_steps;
+    const int e = list[it];
+    const int gid = e & 0x0fffffff, kind = e >> 28;
+    const bool samp = kind & MV_ITEM_SAMPLER, om = kind & MV_ITEM_OM;
+    const float* cc = c.cam_loc + 3 * (gid / c.P);
+    const float* d = c.dirs + 3 * (size_t)gid;
+    const float zmin = c.w_zmin[gid], zmax = c.w_zmax[gid];
+    const float* sv = c.sv + (size_t)it * n_steps;
+    float dist;
+    if (samp) {
+        int ind = 0; float best = INFINITY;                                       // argmin(sign(sdf) * [n..1]), first min
+        for (int i = 0; i < n_steps; ++i) {
+            const float v = sv[i];
+            const float sg = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+            const float tv = sg * (float)(n_steps - i);
+            if (tv < best) { best = tv; ind = i; }
         }
-        __syncthreads();
-        mv_eval_dispatch<MT, NTW, NW>(net, (nr + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
-        if (tid < nr) lds.sv[base + tid] = lds.sdfv[tid];
-        __syncthreads();
-    }
-    if (tid < n_items) {
-        const float* rr = s_ray + 8 * tid;
-        float cc[3], d[3];
-        for (int i = 0; i < 3; ++i) { cc[i] = rr[i]; d[i] = rr[3 + i]; }
-        const int e = s_kind[tid];
-        const int gid = e & 0x0fffffff, kind = e >> 28;
-        const bool samp = kind & MV_ITEM_SAMPLER, om = kind & MV_ITEM_OM;
-        const float zmin = rr[6], zmax = rr[7];
-        const float* sv = lds.sv + tid * n_steps;
-        float dist;
-        if (samp) {
-            int ind = 0; float best = INFINITY;                                   // argmin(sign(sdf) * [n..1]), first min
-            for (int i = 0; i < n_steps; ++i) {
-                const float v = sv[i];
-                const float sg = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
-                const float tv = sg * (float)(n_steps - i);
-                if (tv < best) { best = tv; ind = i; }
-            }
-            dist = zmin + c.intervals[ind] * (zmax - zmin);
-            const bool net_surf = sv[ind] < 0.f;
-            if (!(om && net_surf)) {                                              // P_out: argmin sdf, ray_tracing.py:229-235
-                int i2 = 0; float b2 = INFINITY;
-                for (int i = 0; i < n_steps; ++i) if (sv[i] < b2) { b2 = sv[i]; i2 = i; }
-                dist = zmin + c.intervals[i2] * (zmax - zmin);
-            }
-            c.o_mask[gid] = net_surf ? 1 : 0;                                      // ray_tracing.py:237-239, 61
-            const bool do_secant = c.training ? (net_surf && om) : net_surf;       // ray_tracing.py:242
-            if (do_secant) {
-                int lo = ind - 1; if (lo < 0) lo += n_steps;                      // negative index wraps
-                const unsigned long long k = atomicAdd(&c.counters[MV_CNT_N_SECANT], 1ull);
-                c.sec_list[k] = gid;
-                c.sec_state[gid] = zmin + c.intervals[lo] * (zmax - zmin);
-                c.sec_state[(size_t)c.R + gid] = zmin + c.intervals[ind] * (zmax - zmin);
-                c.sec_state[2 * (size_t)c.R + gid] = sv[lo];
-                c.sec_state[3 * (size_t)c.R + gid] = sv[ind];
-            }
-        } else {
-            int bi = 0; float bv = INFINITY;                                      // min over the shared random steps
-            for (int i = 0; i < n_steps; ++i) if (sv[i] < bv) { bv = sv[i]; bi = i; }
-            dist = c.steps[bi] * (zmax - zmin) + zmin;
+        dist = zmin + c.intervals[ind] * (zmax - zmin);
+        const bool net_surf = sv[ind] < 0.f;
+        if (!(om && net_surf)) {                                                  // P_out: argmin sdf, ray_tracing.py:229-235
+            int i2 = 0; float b2 = INFINITY;
+            for (int i = 0; i < n_steps; ++i) if (sv[i] < b2) { b2 = sv[i]; i2 = i; }
+            dist = zmin + c.intervals[i2] * (zmax - zmin);
         }
-        c.o_dists[gid] = dist;                                                     // secant rays are overwritten by the secant stage
-        c.o_points[3 * (size_t)gid + 0] = cc[0] + dist * d[0];
-        c.o_points[3 * (size_t)gid + 1] = cc[1] + dist * d[1];
-        c.o_points[3 * (size_t)gid + 2] = cc[2] + dist * d[2];
+        c.o_mask[gid] = net_surf ? 1 : 0;                                          // ray_tracing.py:237-239, 61
+        const bool do_secant = c.training ? (net_surf && om) : net_surf;           // ray_tracing.py:242
+        if (do_secant) {
+            int lo = ind - 1; if (lo < 0) lo += n_steps;                          // negative index wraps
+            const unsigned long long k = atomicAdd(&c.counters[MV_CNT_N_SECANT], 1ull);
+            c.sec_list[k] = gid;
+            c.sec_state[gid] = zmin + c.intervals[lo] * (zmax - zmin);
+            c.sec_state[(size_t)c.R + gid] = zmin + c.intervals[ind] * (zmax - zmin);
+            c.sec_state[2 * (size_t)c.R + gid] = sv[lo];
+            c.sec_state[3 * (size_t)c.R + gid] = sv[ind];
+        }
+    } else {
+        int bi = 0; float bv = INFINITY;                                          // min over the shared random steps
+        for (int i = 0; i < n_steps; ++i) if (sv[i] < bv) { bv = sv[i]; bi = i; }
+        dist = c.steps[bi] * (zmax - zmin) + zmin;
     }
-    if (tid == 0) {
-        unsigned long long ns = 0, nm = 0;
-        for (int i = 0; i < n_items; ++i) { if ((s_kind[i] >> 28) & MV_ITEM_SAMPLER) ns++; else nm++; }
-        if (ns) atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER], ns * (unsigned long long)n_steps);
-        if (nm) atomicAdd(&c.counters[MV_CNT_ROWS_MINSDF], nm * (unsigned long long)n_steps);
-    }
+    c.o_dists[gid] = dist;                                                         // secant rays are overwritten by the secant stage
+    c.o_points[3 * (size_t)gid + 0] = cc[0] + dist * d[0];
+    c.o_points[3 * (size_t)gid + 1] = cc[1] + dist * d[1];
+    c.o_points[3 * (size_t)gid + 2] = cc[2] + dist * d[2];
+    if (it == 0) atomicAdd(&c.counters[samp ? MV_CNT_ROWS_SAMPLER : MV_CNT_ROWS_MINSDF], (unsigned long long)n_list * (unsigned long long)n_steps);
 }
 
 // secant (ray_tracing.py:260-278) for 16*MT listed rays per workgroup: n_secant dependent rounds, every round one evaluation of
@@ -342,18 +335,18 @@ __device__ void mv_secant_rays(const MvNet& net, const MvTraceParams& tp, const 
     if (tid == 0) atomicAdd(&c.counters[MV_CNT_ROWS_SECANT], (unsigned long long)n * (unsigned long long)tp.n_secant);
 }
 
-// stage 2a: samples of the sampler rays.   stage 2b: secant workgroups (first sec_blocks blocks) + min-sdf samples (the rest):
-// the dependent secant chains of a few dozen workgroups overlap with the throughput-shaped min-sdf sampling.
+// stage 2a: sample rows of the sampler rays.   stage 2b: secant workgroups (first sec_blocks blocks) + sample rows of the min-sdf
+// rays (the rest): the dependent secant chains of a few dozen workgroups overlap with the throughput-shaped min-sdf sampling.
 template <int MT, int NTW, int NW>
 __global__ __launch_bounds__(64 * NW) void k_ray_samples(MvNet net, MvTraceParams tp, SampleCtx c, const int* __restrict__ list_s,
                                                         const int* __restrict__ list_m, int stage, int sec_blocks) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (stage == 0) {
-        mv_sample_items<MT, NTW, NW>(net, tp, c, list_s, (int)c.counters[MV_CNT_N_SAMPLER], blockIdx.x, smem);
+        mv_eval_rows<MT, NTW, NW>(net, tp, c, list_s, (int)c.counters[MV_CNT_N_SAMPLER], blockIdx.x, smem);
     } else if ((int)blockIdx.x < sec_blocks) {
-        mv_secant_rays<MT, NTW, NW>(net, tp, c, (int)c.counters[MV_CNT_N_SECANT], blockIdx.x, smem);
+        mv_secant_rays<(MT > 1 ? 1 : MT), NTW, NW>(net, tp, c, (int)c.counters[MV_CNT_N_SECANT], blockIdx.x, smem);
     } else {
-        mv_sample_items<MT, NTW, NW>(net, tp, c, list_m, (int)c.counters[MV_CNT_N_MINSDF], blockIdx.x - sec_blocks, smem);
+        mv_eval_rows<MT, NTW, NW>(net, tp, c, list_m, (int)c.counters[MV_CNT_N_MINSDF], blockIdx.x - sec_blocks, smem);
     }
 }
 
@@ -365,49 +358,63 @@ static size_t trace_lds_bytes(const MvNet& net, int MT, int sv_floats, int rpw) 
 }
 
 template <int MT, int NTW, int NW>
-static hipError_t launch_trace(int stages, const MvNet& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, const uint8_t* om,
-                               int B, int P, int training, int rpw, const float* intervals, const float* steps, float* points,
-                               uint8_t* mask, float* dists, float* ws, unsigned long long* counters, hipStream_t stream) {
-    const int R = B * P, NR = 8 * MT, ROWS = 16 * MT;
+static hipError_t launch_stage1(const MvNet& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, const uint8_t* om, int B, int P,
+                                int training, float* points, uint8_t* mask, float* dists, float* ws, unsigned long long* counters,
+                                hipStream_t stream) {
+    const int R = B * P, NR = 8 * MT;
+    float* w_zmin = ws;
+    float* w_zmax = w_zmin + R;
+    int* w_list = (int*)(w_zmax + 5 * (size_t)R);
+    int* w_list_min = w_list + R;
+    const size_t lds1 = trace_lds_bytes(net, MT, 0, 0);
+    static size_t set1 = 0;                                     // raise the dynamic-LDS cap once per size (per instantiation)
+    if (lds1 > set1) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_sphere_trace<MT, NTW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e != hipSuccess) return e;
+        set1 = lds1;
+    }
+    hipLaunchKernelGGL((k_sphere_trace<MT, NTW, NW>), dim3((R + NR - 1) / NR), dim3(64 * NW), lds1, stream, net, tp, cam_loc, dirs, om, R, P,
+                       training, points, mask, dists, w_zmin, w_zmax, w_list, w_list_min, counters);
+    return hipGetLastError();
+}
+
+template <int MT, int NTW, int NW>
+static hipError_t launch_stage2(const MvNet& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, int B, int P, int training,
+                                const float* intervals, const float* steps, float* points, uint8_t* mask, float* dists, float* ws,
+                                unsigned long long* counters, hipStream_t stream) {
+    const int R = B * P, ROWS = 16 * MT;
     float* w_zmin = ws;
     float* w_zmax = w_zmin + R;
     float* sec_state = w_zmax + R;                               // [4][R]
     int* w_list = (int*)(sec_state + 4 * (size_t)R);
     int* w_list_min = w_list + R;
     int* sec_list = w_list_min + R;
-    const size_t lds1 = trace_lds_bytes(net, MT, 0, 0), lds2 = trace_lds_bytes(net, MT, rpw * tp.n_steps, rpw);
-    static size_t set1 = 0, set2 = 0;                           // raise the dynamic-LDS cap once per size (per instantiation)
-    hipError_t e;
-    if (stages & 1) {
-        if (lds1 > set1) {
-            e = hipFuncSetAttribute((const void*)k_sphere_trace<MT, NTW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-            if (e != hipSuccess) return e;
-            set1 = lds1;
-        }
-        hipLaunchKernelGGL((k_sphere_trace<MT, NTW, NW>), dim3((R + NR - 1) / NR), dim3(64 * NW), lds1, stream, net, tp, cam_loc, dirs, om, R, P,
-                           training, points, mask, dists, w_zmin, w_zmax, w_list, w_list_min, counters);
+    float* sv = (float*)(sec_list + R);                          // [R * n_steps]
+    const size_t lds2 = trace_lds_bytes(net, MT, 0, 0);
+    static size_t set2 = 0;
+    if (lds2 > set2) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ray_samples<MT, NTW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+        set2 = lds2;
     }
-    if (stages & 2) {
-        if (lds2 > set2) {
-            e = hipFuncSetAttribute((const void*)k_ray_samples<MT, NTW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            if (e != hipSuccess) return e;
-            set2 = lds2;
-        }
-        SampleCtx c;
-        c.cam_loc = cam_loc; c.dirs = dirs; c.R = R; c.P = P; c.training = training; c.RPW = rpw; c.intervals = intervals; c.steps = steps;
-        c.o_points = points; c.o_mask = mask; c.o_dists = dists; c.w_zmin = w_zmin; c.w_zmax = w_zmax; c.sec_state = sec_state;
-        c.sec_list = sec_list; c.counters = counters;
-        const int item_blocks = (R + rpw - 1) / rpw, sec_blocks = (R + ROWS - 1) / ROWS;
-        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(item_blocks), dim3(64 * NW), lds2, stream, net, tp, c, w_list, w_list_min, 0, 0);
-        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(sec_blocks + (training ? item_blocks : 0)), dim3(64 * NW), lds2, stream, net, tp, c,
-                           w_list, w_list_min, 1, sec_blocks);
-    }
+    SampleCtx c;
+    c.cam_loc = cam_loc; c.dirs = dirs; c.R = R; c.P = P; c.training = training; c.RPW = 0; c.intervals = intervals; c.steps = steps;
+    c.o_points = points; c.o_mask = mask; c.o_dists = dists; c.w_zmin = w_zmin; c.w_zmax = w_zmax; c.sec_state = sec_state;
+    c.sec_list = sec_list; c.sv = sv; c.counters = counters;
+    // worst-case grids (every ray listed); blocks beyond the device-side counts exit at once
+    const int row_blocks = (int)(((long long)R * tp.n_steps + ROWS - 1) / ROWS), sec_blocks = (R + 15) / 16, red_blocks = (R + 63) / 64;
+    hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(row_blocks), dim3(64 * NW), lds2, stream, net, tp, c, w_list, w_list_min, 0, 0);
+    hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list, (int)MV_CNT_N_SAMPLER);
+    hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(sec_blocks + (training ? row_blocks : 0)), dim3(64 * NW), lds2, stream, net, tp, c,
+                       w_list, w_list_min, 1, sec_blocks);
+    if (training) hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list_min, (int)MV_CNT_N_MINSDF);
     return hipGetLastError();
 }
 
-hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp, int mt, const float* cam_loc, const float* dirs, const uint8_t* om,
-                           int B, int P, int training, int rpw, const float* intervals, const float* steps, float* points, uint8_t* mask,
-                           float* dists, float* ws, unsigned long long* counters, hipStream_t stream) {
+// mt1: row tiles per workgroup of the sphere-tracing kernel (8*mt1 rays); mt2: row tiles per chunk of the sample-row kernels.
+hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp, int mt1, int mt2, const float* cam_loc, const float* dirs,
+                           const uint8_t* om, int B, int P, int training, const float* intervals, const float* steps, float* points,
+                           uint8_t* mask, float* dists, float* ws, unsigned long long* counters, hipStream_t stream) {
     int maxnt = 0;
     for (int l = 0; l < net.n_layers - 1; ++l) maxnt = net.L[l].NT > maxnt ? net.L[l].NT : maxnt;
     if (maxnt > 32) return hipErrorInvalidValue;
@@ -415,26 +422,40 @@ hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp
     static int nw_env = -1;
     if (nw_env < 0) { const char* e = getenv("MVSDF_NW"); nw_env = e ? atoi(e) : 0; }
     const bool eight = (nw_env == 8) || (nw_env != 4 && maxnt >= 16);
-#define MV_GO(MT_, NTW_, NW_) return launch_trace<MT_, NTW_, NW_>(stages, net, tp, cam_loc, dirs, om, B, P, training, rpw, intervals, steps, points, mask, dists, \
-                                                             ws, counters, stream)
-    if (eight) {
-        if (maxnt > 16) { if (mt >= 2) MV_GO(2, 4, 8); MV_GO(1, 4, 8); }
-        if (mt >= 4) MV_GO(4, 2, 8);
-        if (mt >= 2) MV_GO(2, 2, 8);
-        MV_GO(1, 2, 8);
+    const bool wide = maxnt > 16;
+    hipError_t e = hipSuccess;
+#define MV_S1(MT_, NTW_, NW_) e = launch_stage1<MT_, NTW_, NW_>(net, tp, cam_loc, dirs, om, B, P, training, points, mask, dists, ws, counters, stream)
+#define MV_S2(MT_, NTW_, NW_) e = launch_stage2<MT_, NTW_, NW_>(net, tp, cam_loc, dirs, B, P, training, intervals, steps, points, mask, dists, ws, counters, stream)
+    if (stages & 1) {
+        if (eight) {
+            if (wide) { if (mt1 >= 2) MV_S1(2, 4, 8); else MV_S1(1, 4, 8); }
+            else if (mt1 >= 4) MV_S1(4, 2, 8); else if (mt1 >= 2) MV_S1(2, 2, 8); else MV_S1(1, 2, 8);
+        } else {
+            if (wide) { if (mt1 >= 2) MV_S1(2, 8, 4); else MV_S1(1, 8, 4); }
+            else if (mt1 >= 4) MV_S1(4, 4, 4); else if (mt1 >= 2) MV_S1(2, 4, 4); else MV_S1(1, 4, 4);
+        }
+        if (e != hipSuccess) return e;
     }
-    if (maxnt > 16) { if (mt >= 2) MV_GO(2, 8, 4); MV_GO(1, 8, 4); }
-    if (mt >= 4) MV_GO(4, 4, 4);
-    if (mt >= 2) MV_GO(2, 4, 4);
-    MV_GO(1, 4, 4);
-#undef MV_GO
+    if (stages & 2) {
+        if (eight) {
+            if (wide) { if (mt2 >= 2) MV_S2(2, 4, 8); else MV_S2(1, 4, 8); }
+            else if (mt2 >= 4) MV_S2(4, 2, 8); else if (mt2 >= 2) MV_S2(2, 2, 8); else MV_S2(1, 2, 8);
+        } else {
+            if (wide) { if (mt2 >= 2) MV_S2(2, 8, 4); else MV_S2(1, 8, 4); }
+            else if (mt2 >= 4) MV_S2(4, 4, 4); else if (mt2 >= 2) MV_S2(2, 4, 4); else MV_S2(1, 4, 4);
+        }
+    }
+#undef MV_S1
+#undef MV_S2
+    return e;
 }
 
 // =============================================================================================================
 #include "capi_util.h"
 extern "C" {
 
-size_t mvsdf_trace_workspace_bytes(int R) { return (size_t)(R > 0 ? R : 0) * 36 + 256; }
+size_t mvsdf_trace_workspace_bytes_n(int R, int n_steps) { return (size_t)(R > 0 ? R : 0) * (36 + 4 * (size_t)(n_steps > 0 ? n_steps : 0)) + 256; }
+size_t mvsdf_trace_workspace_bytes(int R) { return mvsdf_trace_workspace_bytes_n(R, 128); }
 
 static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
                       const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
@@ -450,14 +471,13 @@ static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTracePara
     if (tp->n_steps < 2 || tp->n_steps > 1024 || tp->line_step_iters < 0 || tp->line_step_iters > 30)
         return mv_fail(-1, "mvsdf_trace: tracer parameters out of range");
     const int R = B * P;
-    if (workspace_bytes < mvsdf_trace_workspace_bytes(R)) return mv_fail(-1, "mvsdf_trace: workspace too small");
+    if (workspace_bytes < mvsdf_trace_workspace_bytes_n(R, tp->n_steps)) return mv_fail(-1, "mvsdf_trace: workspace too small");
     if (rpw < 1) rpw = 1;
-    if (rpw > 16) rpw = 16;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
     if (stages & 1) e = hipMemsetAsync(counters, 0, 16 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return mv_check(e, "mvsdf_trace: memset");
-    e = mv_trace_launch(stages, net, *tp, mt, cam_loc, ray_dirs, object_mask, B, P, training, rpw, intervals,
+    e = mv_trace_launch(stages, net, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,
                         minsdf_steps ? minsdf_steps : intervals, points, mask, dists, (float*)workspace, counters, s);
     return mv_check(e, "mvsdf_trace");
 }

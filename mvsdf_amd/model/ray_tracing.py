@@ -31,8 +31,8 @@ class RayTracing(nn.Module):
         self.n_steps = n_steps
         self.n_secant_steps = n_secant_steps
         self.last_counters = None           # device int64[16]: MLP rows per stage (include/mvsdf_hip.h MVSDF_CNT_*)
-        self.mt = None                      # row tiles per workgroup (None: pick from the ray count)
-        self.rpw = None
+        self.mt = None                      # row tiles per sphere-tracing workgroup (None: pick from the ray count)
+        self.mt_samples = None              # row tiles per chunk of the sample-row kernels
         self.events = None                  # set to a list to have per-kernel (start, mid, end) events appended each call
 
     def _params(self):
@@ -59,8 +59,8 @@ class RayTracing(nn.Module):
             minsdf_steps = minsdf_steps.to(dev, non_blocking=True)
         R = ray_directions.shape[0] * ray_directions.shape[1]
         mt = self.mt or (1 if R <= 4096 else 2)
-        rpw = self.rpw or (2 if R <= 4096 else 4)
+        mt_samples = self.mt_samples or 4
         pts, mask, dists, counters = ops.trace(net, cam_loc, ray_directions, object_mask, self._params(), self.training, intervals,
-                                               minsdf_steps, mt=mt, rpw=rpw, events=self.events)
+                                               minsdf_steps, mt=mt, mt_samples=mt_samples, events=self.events)
         self.last_counters = counters
         return pts, mask, dists

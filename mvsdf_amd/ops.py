@@ -96,8 +96,9 @@ def sphere_intersection(cam_loc, ray_dirs, r=1.0):
     return t, m.bool()
 
 
-def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, minsdf_steps=None, mt=2, rpw=2, events=None):
+def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, minsdf_steps=None, mt=1, mt_samples=4, events=None):
     """RayTracing.forward on the device -> (points[R,3], mask[R] bool, dists[R], counters[16] int64 device tensor).
+    mt: row tiles per sphere-tracing workgroup (8*mt rays); mt_samples: row tiles per chunk of the sample-row kernels.
     events: optional list; when given the two kernels are launched by separate C calls and (start, mid, end) torch events
     recorded on the current stream are appended (per-kernel timing for bench.py's roofline)."""
     cam_loc, ray_dirs = _f32(cam_loc), _f32(ray_dirs)
@@ -109,14 +110,14 @@ def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, mins
     mask = torch.empty(R, dtype=torch.uint8, device=dev)
     dists = torch.empty(R, dtype=torch.float32, device=dev)
     counters = torch.empty(16, dtype=torch.int64, device=dev)
-    wsb = lib().mvsdf_trace_workspace_bytes(R)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     tp = TraceParams(*params)
+    wsb = lib().mvsdf_trace_workspace_bytes_n(R, tp.n_steps)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     d = net.desc()
     iv = _f32(intervals)
     st = _f32(minsdf_steps) if minsdf_steps is not None else None
     args = (C.byref(d), C.byref(tp), ptr(cam_loc), ptr(ray_dirs), ptr(om), B, P, 1 if training else 0, ptr(iv), ptr(st),
-            ptr(pts), ptr(mask), ptr(dists), ptr(counters), ptr(ws), C.c_size_t(wsb), mt, rpw, stream_of(ray_dirs))
+            ptr(pts), ptr(mask), ptr(dists), ptr(counters), ptr(ws), C.c_size_t(wsb), mt, mt_samples, stream_of(ray_dirs))
     if events is None:
         check(lib().mvsdf_trace(*args), 'mvsdf_trace')
     else:

@@ -26,7 +26,7 @@ def test_c2_tracer_bit_exact_vs_oracle(oracle):
     iv = torch.linspace(0, 1, 100)
     steps = np.random.RandomState(1).uniform(size=100).astype(np.float32)
     om = np.ones(2048, bool)
-    pts, mask, dists, cnt = ops.trace(net, cam, dirs, t(om), trace_params(256), True, iv.cuda(), t(steps), mt=1, rpw=2)
+    pts, mask, dists, cnt = ops.trace(net, cam, dirs, t(om), trace_params(256), True, iv.cuda(), t(steps), mt=1, mt_samples=2)
     p_o, m_o, d_o, rows = oracle.trace(onet, cam.cpu().numpy(), dirs.cpu().numpy(), om, True, steps, iv.numpy(), **synth.model_conf(256)['ray_tracer'])
     assert np.array_equal(mask.cpu().numpy(), m_o) and np.array_equal(dists.cpu().numpy(), d_o) and np.array_equal(pts.cpu().numpy(), p_o)
     assert np.array_equal(cnt.cpu().numpy()[:4], rows)
@@ -45,9 +45,9 @@ def test_tracer_properties_full_size(B, P):
     steps = torch.empty(100).uniform_(0, 1).cuda()
     om = torch.ones(R, dtype=torch.bool, device='cuda')
     tp = trace_params(256)
-    ref = ops.trace(net, cam, dirs, om, tp, True, iv, steps, mt=1, rpw=2)
+    ref = ops.trace(net, cam, dirs, om, tp, True, iv, steps, mt=1, mt_samples=2)
     for mt, rpw in ((2, 4), (4, 8), (2, 3)):
-        o = ops.trace(net, cam, dirs, om, tp, True, iv, steps, mt=mt, rpw=rpw)
+        o = ops.trace(net, cam, dirs, om, tp, True, iv, steps, mt=mt, mt_samples=rpw)
         assert torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2]) and torch.equal(o[0], ref[0]) and torch.equal(o[3][:4], ref[3][:4])
     # (2) per-view split: each view traced alone
     for b in (0, B - 1):

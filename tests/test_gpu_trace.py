@@ -72,7 +72,7 @@ def test_trace_bit_exact_vs_oracle_and_golden(oracle, W, mode, mt, rpw):
     tr = synth.model_conf(W)['ray_tracer']
     p_o, m_o, d_o, rows_o = oracle.trace(onet, g['cam_loc'], g['ray_dirs'], om, training, g['minsdf_steps'], g['intervals'], **tr)
     pts, mask, dists, cnt = ops.trace(net, t(g['cam_loc']), t(g['ray_dirs']), t(om), trace_params(W), training,
-                                      t(g['intervals']), t(g['minsdf_steps']), mt=mt, rpw=rpw)
+                                      t(g['intervals']), t(g['minsdf_steps']), mt=mt, mt_samples=rpw)
     torch.cuda.synchronize()
     mask, dists, pts, cnt = mask.cpu().numpy(), dists.cpu().numpy(), pts.cpu().numpy(), cnt.cpu().numpy()
     assert np.array_equal(mask, m_o)                      # HIP == oracle, bit for bit

@@ -32,12 +32,12 @@ for cfg in a.configs.split(','):
     mt, rpw = [int(v) for v in cfg.split(':')]
     for training in (True,):
         for _ in range(2):
-            out = ops.trace(net, cam, dirs, om, trace_params(a.W), training, intervals, steps, mt=mt, rpw=rpw)
+            out = ops.trace(net, cam, dirs, om, trace_params(a.W), training, intervals, steps, mt=mt, mt_samples=rpw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.iters):
-            out = ops.trace(net, cam, dirs, om, trace_params(a.W), training, intervals, steps, mt=mt, rpw=rpw)
+            out = ops.trace(net, cam, dirs, om, trace_params(a.W), training, intervals, steps, mt=mt, mt_samples=rpw)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
