@@ -97,61 +97,88 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(MvNet net, MvTracePara
     float ts = acc_s, te = acc_e;
     unsigned long long nrows_total = 0;
 
+    const float coef0 = (1.0f - tp.line_search_step);          // first back-off of the line search (ray_tracing.py:178)
     for (;;) {
-        int row_s = 0, row_e = 0;
+        int row_s = 0, row_e = 0, row_ss = 0, row_se = 0;
+        bool sp_s = false, sp_e = false;
         if (w == 0) {
             const unsigned long long ms = __ballot(req_s), me = __ballot(req_e);
             const unsigned long long lt = (1ull << lane) - 1ull;
             const int ns = __popcll(ms), ne = __popcll(me);
             row_s = __popcll(ms & lt);
             row_e = ns + __popcll(me & lt);
+            // Speculative line search: a side that steps this round also evaluates its FIRST back-off point (known in advance:
+            // acc -/+ 0.5*curr) whenever that fits into the row tiles that run anyway -- one dependent evaluation per iteration
+            // instead of two.  Identical results; unused speculative rows are not counted.
+            const unsigned long long qs = __ballot(req_s && phase == 1), qe = __ballot(req_e && phase == 1);
+            const int nqs = __popcll(qs), nqe = __popcll(qe);
+            const bool spec = tp.line_step_iters > 0 && (nqs + nqe) > 0 && (ns + ne + nqs + nqe) <= ((ns + ne + 15) & ~15);
             if (req_s) { float* p = lds.pts + row_s * 3; p[0] = c[0] + ts * d[0]; p[1] = c[1] + ts * d[1]; p[2] = c[2] + ts * d[2]; }
             if (req_e) { float* p = lds.pts + row_e * 3; p[0] = c[0] + te * d[0]; p[1] = c[1] + te * d[1]; p[2] = c[2] + te * d[2]; }
-            if (lane == 0) *s_n = ns + ne;
+            if (spec) {
+                sp_s = req_s && phase == 1; sp_e = req_e && phase == 1;
+                row_ss = ns + ne + __popcll(qs & lt);
+                row_se = ns + ne + nqs + __popcll(qe & lt);
+                if (sp_s) { const float z = acc_s - coef0 * curr_s; float* p = lds.pts + row_ss * 3; p[0] = c[0] + z * d[0]; p[1] = c[1] + z * d[1]; p[2] = c[2] + z * d[2]; }
+                if (sp_e) { const float z = acc_e + coef0 * curr_e; float* p = lds.pts + row_se * 3; p[0] = c[0] + z * d[0]; p[1] = c[1] + z * d[1]; p[2] = c[2] + z * d[2]; }
+            }
+            if (lane == 0) { s_n[0] = ns + ne + (spec ? nqs + nqe : 0); s_n[1] = ns + ne; }
         }
         __syncthreads();
-        const int n = *s_n;
+        const int n = s_n[0];
         if (n == 0) break;
-        if (tid == 0) nrows_total += (unsigned long long)n;
+        if (tid == 0) nrows_total += (unsigned long long)s_n[1];
         mv_eval_dispatch<MT, NTW, NW>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
-        if (w == 0 && phase != 3) {
-            const float vs = req_s ? mv_clamp(lds.sdfv[row_s], -tp.dist_clip, tp.dist_clip) : 0.f;
-            const float ve = req_e ? mv_clamp(lds.sdfv[row_e], -tp.dist_clip, tp.dist_clip) : 0.f;
-            bool end_iter = false;
-            if (phase == 0) { next_s = vs; next_e = ve; }
-            else if (phase == 1) { next_s = vs; next_e = ve; k = 0; }
-            else { if (req_s) next_s = vs; if (req_e) next_e = ve; k++; }
-            if (phase != 0) {
-                const bool np_s = next_s < 0.f, np_e = next_e < 0.f;
-                if (k < tp.line_step_iters && (np_s || np_e)) {                   // ray_tracing.py:173-191
-                    const float coef = (1.0f - tp.line_search_step) / (float)(1 << k);
-                    req_s = np_s; req_e = np_e;
-                    if (np_s) { acc_s -= coef * curr_s; ts = acc_s; }
-                    if (np_e) { acc_e += coef * curr_e; te = acc_e; }
-                    phase = 2;
-                } else {
-                    end_iter = true;
-                    unf_s = unf_s && (acc_s < acc_e);                           // ray_tracing.py:193-194
-                    unf_e = unf_e && (acc_s < acc_e);
+        if (w == 0) {
+            bool used_s = false, used_e = false;
+            if (phase != 3) {
+                const float vs = req_s ? mv_clamp(lds.sdfv[row_s], -tp.dist_clip, tp.dist_clip) : 0.f;
+                const float ve = req_e ? mv_clamp(lds.sdfv[row_e], -tp.dist_clip, tp.dist_clip) : 0.f;
+                bool end_iter = false;
+                if (phase == 0) { next_s = vs; next_e = ve; }
+                else if (phase == 1) {
+                    next_s = vs; next_e = ve; k = 0;
+                    if ((sp_s || sp_e) && (next_s < 0.f || next_e < 0.f)) {          // line-search iteration 0, answered by the speculative rows
+                        if (next_s < 0.f) { acc_s -= coef0 * curr_s; next_s = mv_clamp(lds.sdfv[row_ss], -tp.dist_clip, tp.dist_clip); used_s = true; }
+                        if (next_e < 0.f) { acc_e += coef0 * curr_e; next_e = mv_clamp(lds.sdfv[row_se], -tp.dist_clip, tp.dist_clip); used_e = true; }
+                        k = 1;
+                    }
+                }
+                else { if (req_s) next_s = vs; if (req_e) next_e = ve; k++; }
+                if (phase != 0) {
+                    const bool np_s = next_s < 0.f, np_e = next_e < 0.f;
+                    if (k < tp.line_step_iters && (np_s || np_e)) {                   // ray_tracing.py:173-191
+                        const float coef = (1.0f - tp.line_search_step) / (float)(1 << k);
+                        req_s = np_s; req_e = np_e;
+                        if (np_s) { acc_s -= coef * curr_s; ts = acc_s; }
+                        if (np_e) { acc_e += coef * curr_e; te = acc_e; }
+                        phase = 2;
+                    } else {
+                        end_iter = true;
+                        unf_s = unf_s && (acc_s < acc_e);                           // ray_tracing.py:193-194
+                        unf_e = unf_e && (acc_s < acc_e);
+                    }
+                }
+                if (phase == 0 || end_iter) {                                         // top of the while loop, ray_tracing.py:139-171
+                    curr_s = unf_s ? next_s : 0.f;
+                    curr_e = unf_e ? next_e : 0.f;
+                    if (curr_s <= tp.thr) curr_s = 0.f;
+                    if (curr_e <= tp.thr) curr_e = 0.f;
+                    unf_s = unf_s && (curr_s > tp.thr);
+                    unf_e = unf_e && (curr_e > tp.thr);
+                    if ((!unf_s && !unf_e) || iters == tp.st_iters) {
+                        phase = 3; req_s = false; req_e = false;
+                    } else {
+                        iters++;
+                        acc_s = acc_s + curr_s;
+                        acc_e = acc_e - curr_e;
+                        req_s = unf_s; req_e = unf_e; ts = acc_s; te = acc_e;
+                        phase = 1;
+                    }
                 }
             }
-            if (phase == 0 || end_iter) {                                         // top of the while loop, ray_tracing.py:139-171
-                curr_s = unf_s ? next_s : 0.f;
-                curr_e = unf_e ? next_e : 0.f;
-                if (curr_s <= tp.thr) curr_s = 0.f;
-                if (curr_e <= tp.thr) curr_e = 0.f;
-                unf_s = unf_s && (curr_s > tp.thr);
-                unf_e = unf_e && (curr_e > tp.thr);
-                if ((!unf_s && !unf_e) || iters == tp.st_iters) {
-                    phase = 3; req_s = false; req_e = false;
-                } else {
-                    iters++;
-                    acc_s = acc_s + curr_s;
-                    acc_e = acc_e - curr_e;
-                    req_s = unf_s; req_e = unf_e; ts = acc_s; te = acc_e;
-                    phase = 1;
-                }
-            }
+            const int nused = __popcll(__ballot(used_s)) + __popcll(__ballot(used_e));   // speculative rows the reference would have evaluated
+            if (lane == 0) nrows_total += (unsigned long long)nused;
         }
         // (mv_sdf_eval_col0 ended with a barrier; wave 0 rewrites pts/s_n only after its own reads above)
     }
