@@ -161,6 +161,7 @@ def main():
         ms_sphere = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
         ms_samples = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
         rows_samples = int(cnt[1] + cnt[2] + cnt[3])
+        n_launch = 2                                            # k_ray_samples runs twice per step (sampler rows; secant || min-sdf rows)
         ach = rows_samples * f_t / (ms_samples * 1e-3) / 1e12
         res = {
             'metric': 'traced rays/sec (fwd+bwd, 10 sphere iters, 4 src views)', 'value': world * R * a.steps / dt, 'unit': 'rays/s',
@@ -169,9 +170,10 @@ def main():
             'config': {'workload': 'DTU-scan24-shaped synthetic scene, %d rays/GPU (%d views x %d px), %d src views, 8x%d SDF MLP, full fwd+loss+bwd+clip+Adam(lr=0)'
                                    % (R, B, P, V, W), 'rays_per_gpu': R, 'src_views': V, 'sdf_width': W, 'train_progress': TP,
                        'feature_maps': '32x%dx%d' % FEAT_HW, 'parallelism': 'ray-sharded dp%d, one all-reduce on a flat grad bucket' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_ray_samples (tracing MLP on sampler+secant+min-sdf rows)', 'achieved': ach,
+            'roofline': {'bound': 'mfma', 'kernel': 'k_ray_samples (fused 9-layer tracing MLP on the sampler / secant / min-sdf rows)', 'achieved': ach,
                          'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA, 'traffic': None,
-                         'rows_per_launch': rows_samples, 'flop_per_row': f_t, 'avg_launch_ms': ms_samples,
+                         'rows_per_launch': rows_samples / n_launch, 'flop_per_row': f_t, 'avg_launch_ms': ms_samples / n_launch,
+                         'launches_per_step': n_launch,
                          'k_sphere_trace': {'rows_per_launch': int(cnt[0]), 'avg_launch_ms': ms_sphere,
                                             'achieved': int(cnt[0]) * f_t / (ms_sphere * 1e-3) / 1e12},
                          'step': {'T_trace_rows': T, 'R': R, 'E': E, 'N_hit': N, 'flops_step': flops_step,

@@ -65,6 +65,12 @@ size_t mvsdf_packed_floats(int N, int K);
  * v[N][K], g[N] -> w[N][K] (row-major, required), wp (packed W, mvsdf_packed_floats(N, K) floats, may be NULL),
  * wpT (packed W^T for contractions over the OUT dimension, mvsdf_packed_floats(K, N) floats, may be NULL). */
 int mvsdf_fold_pack(const float* v, const float* g, int N, int K, float* w, float* wp, float* wpT, void* stream);
+/* all layers of a network at once (one fold launch + one pack launch).  The pointer arrays are HOST arrays of n_layers device
+ * pointers; wp[l] / wpT[l] may be NULL. */
+int mvsdf_fold_pack_net(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w,
+                        float* const* wp, float* const* wpT, void* stream);
+int mvsdf_fold_backward_net(int n_layers, const float* const* v, const float* const* g, const float* const* dW, const int* N, const int* K,
+                            float* const* dv, float* const* dg, void* stream);
 /* backward of the fold: dW[N][K] -> dv[N][K], dg[N]    */
 int mvsdf_fold_backward(const float* v, const float* g, const float* dW, int N, int K, float* dv, float* dg, void* stream);
 
@@ -109,7 +115,7 @@ size_t mvsdf_sdf_ctx_floats(const MvsdfNetDesc* net, int M, int Mg);
 int mvsdf_sdf_forward(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, const float* x, int M, int Mg, float* y, float* nrm, float* ctx,
                       void* stream);
 /* Backward over the FIRST Mb rows (Mb <= M; Mb <= Mg when dn is given): dy[Mb][Nout], dn[Mb][3] or NULL ->
- * dW_cat (all layers, row-major [N][K], concatenated), db_cat, dx[Mb][3] or NULL.  ws: mvsdf_sdf_bwd_ws_floats(net, Mb) floats. */
+ * dW_cat (all layers, row-major [N][K], concatenated), db_cat (both NULL: input adjoint only), dx[Mb][3] or NULL.  ws: mvsdf_sdf_bwd_ws_floats(net, Mb) floats. */
 size_t mvsdf_sdf_bwd_ws_floats(const MvsdfNetDesc* net, int Mb);
 int mvsdf_sdf_backward(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, const float* x, int M, int Mg, int Mb, const float* dy,
                        const float* dn, const float* ctx, float* dW_cat, float* db_cat, float* dx, float* ws, void* stream);

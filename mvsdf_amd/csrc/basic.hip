@@ -1,6 +1,7 @@
 // basic.hip -- weight-norm fold + MFMA packing, camera rays, the stand-alone tracing-MLP kernel and the
 // device self-test of det_math.  C ABI entry points for these live at the bottom (see include/mvsdf_hip.h).
 #include <stdlib.h>
+#include <string.h>
 #include "tile_engine.h"
 #include "trace_params.h"
 #include "capi_util.h"
@@ -16,7 +17,7 @@ __global__ __launch_bounds__(256) void k_fold(const float* __restrict__ v, const
         const float mine = (k0 + lane < K) ? vr[k0 + lane] : 0.0f;
         const int n = min(64, K - k0);
         for (int i = 0; i < n; ++i) {
-            const float x = __shfl(mine, i);
+            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), i));   // uniform i -> v_readlane
             ss = fmaf(x, x, ss);
         }
     }
@@ -38,6 +39,69 @@ __global__ void k_pack(const float* __restrict__ w, int N, int K, int transposed
         if (o < No && i < Ko) val = transposed ? w[(size_t)i * K + o] : w[(size_t)o * K + i];
         wp[idx] = val;
     }
+}
+
+// ---- whole-network variants: one launch folds / packs every layer (blockIdx.y selects the layer) ----
+struct FoldNetArgs {
+    int n_layers;
+    const float* v[MV_MAXL]; const float* g[MV_MAXL]; const float* dW[MV_MAXL];
+    float* w[MV_MAXL]; float* wp[MV_MAXL]; float* wpT[MV_MAXL]; float* dv[MV_MAXL]; float* dg[MV_MAXL];
+    int N[MV_MAXL], K[MV_MAXL];
+};
+
+__global__ __launch_bounds__(256) void k_fold_net(FoldNetArgs a) {
+    const int l = blockIdx.y, N = a.N[l], K = a.K[l];
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= N) return;
+    const float* vr = a.v[l] + (size_t)j * K;
+    float ss = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const float mine = (k0 + lane < K) ? vr[k0 + lane] : 0.0f;
+        const int n = min(64, K - k0);
+        for (int i = 0; i < n; ++i) {
+            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), i));
+            ss = fmaf(x, x, ss);
+        }
+    }
+    const float s = a.g[l][j] / sqrtf(ss);
+    float* wr = a.w[l] + (size_t)j * K;
+    for (int k = lane; k < K; k += 64) wr[k] = vr[k] * s;
+}
+
+__global__ void k_pack_net(FoldNetArgs a) {
+    const int l = blockIdx.y >> 1, transposed = blockIdx.y & 1;
+    float* wp = transposed ? a.wpT[l] : a.wp[l];
+    if (!wp) return;
+    const float* w = a.w[l];
+    const int N = a.N[l], K = a.K[l];
+    const int No = transposed ? K : N, Ko = transposed ? N : K;
+    const int KB = mv_kpad(Ko) / 16;
+    const size_t total = (size_t)mv_ceil16(No) * mv_kpad(Ko);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int s = idx & 3, lane = (idx >> 2) & 63;
+        const size_t blk = idx >> 8;
+        const int kb = (int)(blk % KB), ct = (int)(blk / KB);
+        const int o = ct * 16 + (lane & 15), i = kb * 16 + 4 * s + (lane >> 4);
+        float val = 0.0f;
+        if (o < No && i < Ko) val = transposed ? w[(size_t)i * K + o] : w[(size_t)o * K + i];
+        wp[idx] = val;
+    }
+}
+
+__global__ void k_fold_bwd_net(FoldNetArgs a) {
+    const int l = blockIdx.y, N = a.N[l], K = a.K[l];
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= N) return;
+    const float* vr = a.v[l] + (size_t)j * K;
+    const float* dr = a.dW[l] + (size_t)j * K;
+    float ss = 0.f, dot = 0.f;
+    for (int k = lane; k < K; k += 64) { ss = fmaf(vr[k], vr[k], ss); dot = fmaf(dr[k], vr[k], dot); }
+    for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o); dot += __shfl_xor(dot, o); }
+    const float inv = 1.0f / sqrtf(ss);
+    const float dgj = dot * inv, s = a.g[l][j] * inv;
+    float* dvr = a.dv[l] + (size_t)j * K;
+    for (int k = lane; k < K; k += 64) dvr[k] = s * (dr[k] - dgj * vr[k] * inv);
+    if (lane == 0) a.dg[l][j] = dgj;
 }
 
 // backward of the fold: one wave per row.
@@ -197,6 +261,56 @@ int mvsdf_fold_pack(const float* v, const float* g, int N, int K, float* w, floa
     if (wp) hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, s, w, N, K, 0, wp);
     if (wpT) hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, s, w, N, K, 1, wpT);
     return mv_check(hipGetLastError(), "mvsdf_fold_pack");
+}
+
+static int fill_fold_args(FoldNetArgs& a, int n_layers, const int* N, const int* K, int* maxN, size_t* maxTot) {
+    if (n_layers < 1 || n_layers > MV_MAXL || !N || !K) return mv_fail(-1, "fold (net): bad layer count / dims");
+    memset(&a, 0, sizeof(a));
+    a.n_layers = n_layers;
+    *maxN = 0; *maxTot = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (N[l] <= 0 || K[l] <= 0) return mv_fail(-1, "fold (net): bad dims");
+        a.N[l] = N[l]; a.K[l] = K[l];
+        if (N[l] > *maxN) *maxN = N[l];
+        const size_t t = mv_packed_floats(N[l], K[l]) > mv_packed_floats(K[l], N[l]) ? mv_packed_floats(N[l], K[l]) : mv_packed_floats(K[l], N[l]);
+        if (t > *maxTot) *maxTot = t;
+    }
+    return 0;
+}
+
+/* every layer of a network in one call: fold (one launch) + pack W and W^T (one launch).  Pointer arrays are HOST arrays of
+ * device pointers; wp / wpT entries may be NULL. */
+int mvsdf_fold_pack_net(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w,
+                        float* const* wp, float* const* wpT, void* stream) {
+    FoldNetArgs a;
+    int maxN; size_t maxTot;
+    int rc = fill_fold_args(a, n_layers, N, K, &maxN, &maxTot);
+    if (rc) return rc;
+    if (!v || !g || !w || !wp || !wpT) return mv_fail(-1, "mvsdf_fold_pack_net: null argument");
+    for (int l = 0; l < n_layers; ++l) {
+        if (!v[l] || !g[l] || !w[l]) return mv_fail(-1, "mvsdf_fold_pack_net: null layer pointer");
+        a.v[l] = v[l]; a.g[l] = g[l]; a.w[l] = w[l]; a.wp[l] = wp[l]; a.wpT[l] = wpT[l];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_fold_net, dim3((maxN + 3) / 4, n_layers), dim3(256), 0, s, a);
+    const int blocks = (int)((maxTot + 255) / 256 < 256 ? (maxTot + 255) / 256 : 256);
+    hipLaunchKernelGGL(k_pack_net, dim3(blocks, 2 * n_layers), dim3(256), 0, s, a);
+    return mv_check(hipGetLastError(), "mvsdf_fold_pack_net");
+}
+
+int mvsdf_fold_backward_net(int n_layers, const float* const* v, const float* const* g, const float* const* dW, const int* N, const int* K,
+                            float* const* dv, float* const* dg, void* stream) {
+    FoldNetArgs a;
+    int maxN; size_t maxTot;
+    int rc = fill_fold_args(a, n_layers, N, K, &maxN, &maxTot);
+    if (rc) return rc;
+    if (!v || !g || !dW || !dv || !dg) return mv_fail(-1, "mvsdf_fold_backward_net: null argument");
+    for (int l = 0; l < n_layers; ++l) {
+        if (!v[l] || !g[l] || !dW[l] || !dv[l] || !dg[l]) return mv_fail(-1, "mvsdf_fold_backward_net: null layer pointer");
+        a.v[l] = v[l]; a.g[l] = g[l]; a.dW[l] = dW[l]; a.dv[l] = dv[l]; a.dg[l] = dg[l];
+    }
+    hipLaunchKernelGGL(k_fold_bwd_net, dim3((maxN + 3) / 4, n_layers), dim3(256), 0, (hipStream_t)stream, a);
+    return mv_check(hipGetLastError(), "mvsdf_fold_backward_net");
 }
 
 int mvsdf_fold_backward(const float* v, const float* g, const float* dW, int N, int K, float* dv, float* dg, void* stream) {

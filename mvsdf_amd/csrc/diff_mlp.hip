@@ -279,7 +279,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
     if (rc) return rc;
     rc = mv_make_net_mode(dT, &netT, 2);
     if (rc) return rc;
-    if (!x || !dy || !ctx || !dW_cat || !db_cat || !ws || Mb <= 0 || Mb > M || (dn && Mb > Mg))
+    if (!x || !dy || !ctx || !ws || Mb <= 0 || Mb > M || (dn && Mb > Mg) || ((dW_cat == nullptr) != (db_cat == nullptr)))
         return mv_fail(-1, "mvsdf_sdf_backward: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const SdfLayout lo = sdf_ctx_layout(net, M, Mg);
@@ -338,7 +338,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
     }
     // ---- weight / bias gradients: W_l = zbar_l^T a_l (+ s_l^T vbar_l), one launch per layer ----
     size_t woff = 0, boff = 0;
-    for (int l = 0; l < nl; ++l) {
+    for (int l = 0; l < nl && dW_cat; ++l) {                                      // dW_cat == NULL: input adjoint only
         const int No = net.L[l].N, Ki = net.L[l].K;
         const bool last = (l == nl - 1);
         const float* P = last ? dy : ws + bl.ZB[l];

@@ -23,22 +23,44 @@ class _Fold(torch.autograd.Function):
         return dv, dg.view_as(g), None
 
 
+class _FoldNet(torch.autograd.Function):
+    """weight_norm of a whole network in one C call (one fold launch + one pack launch): (*weight_v, *weight_g) -> *W."""
+
+    @staticmethod
+    def forward(ctx, holders, *vg):
+        n = len(vg) // 2
+        vs, gs = [t.detach() for t in vg[:n]], [t.detach() for t in vg[n:]]
+        ws, wps, wpTs = ops.fold_pack_net(vs, gs)
+        for L, w, wp, wpT in zip(holders, ws, wps, wpTs):
+            L.w, L.wp, L.wpT = w, wp, wpT
+        ctx.save_for_backward(*vg)
+        return tuple(ws)
+
+    @staticmethod
+    def backward(ctx, *dWs):
+        vg = ctx.saved_tensors
+        n = len(vg) // 2
+        vs, gs = [t.detach() for t in vg[:n]], [t.detach() for t in vg[n:]]
+        dWs = [d.contiguous() if d is not None else torch.zeros_like(v) for d, v in zip(dWs, vs)]
+        dvs, dgs = ops.fold_backward_net(vs, gs, dWs)
+        return (None,) + tuple(dvs) + tuple(dg.view_as(g) for dg, g in zip(dgs, vg[n:]))
+
+
 def fold_network(vs, gs, bs, skip_layer, multires):
     """-> (PackedNet, [w tensors linked to autograd], [bias params])"""
-    layers, ws = [], []
-    for v, g, b in zip(vs, gs, bs):
+    layers = []
+    for v, b in zip(vs, bs):
         L = ops.PackedLayer()
-        w = _Fold.apply(v, g, L)
         L.bias = b.detach()
         L.N, L.K = v.shape
         layers.append(L)
-        ws.append(w)
-    return ops.PackedNet(layers, skip_layer, multires), ws, list(bs)
+    ws = _FoldNet.apply(layers, *vs, *gs)
+    return ops.PackedNet(layers, skip_layer, multires), list(ws), list(bs)
 
 
 class SharedSdfEval:
     """What one fused evaluation leaves behind for the backward passes and for re-use at the same points."""
-    __slots__ = ('net', 'x', 'M', 'Mg', 'n_active', 'saved', 'y', 'n')
+    __slots__ = ('net', 'x', 'M', 'Mg', 'n_active', 'saved', 'y', 'n', 'stash')
 
 
 class _SdfValueNormal(torch.autograd.Function):
@@ -62,6 +84,18 @@ class _SdfValueNormal(torch.autograd.Function):
             return (None, None) + tuple(torch.zeros_like(L.w) for L in sh.net.layers) + tuple(torch.zeros_like(L.bias) for L in sh.net.layers)
         Nout = sh.net.layers[-1].N
         dyb = dy[:Mb].contiguous() if dy is not None else torch.zeros(Mb, Nout, device=sh.x.device)
+        if sh.stash is not None:                         # upstream grads of the re-use at the surface points (same rows, same weights):
+            n0, sdy, sdn = sh.stash                      # by linearity their weight gradients are computed here, once
+            sh.stash = None
+            if dyb.data_ptr() == (dy.data_ptr() if dy is not None else 0):
+                dyb = dyb.clone()
+            dyb[:n0] += sdy
+            if sdn is not None:
+                if dn is None:
+                    dn = torch.zeros(sh.Mg, 3, device=sh.x.device)
+                else:
+                    dn = dn.clone()
+                dn[:n0] += sdn
         dnb = None
         if dn is not None and sh.Mg > 0:
             mg = min(Mb, sh.Mg)
@@ -92,6 +126,7 @@ def sdf_value_normal(net, ws, bs, x, Mg, n_active=None):
     sh = SharedSdfEval()
     sh.net, sh.M, sh.Mg = net, x.shape[0], Mg
     sh.n_active = x.shape[0] if n_active is None else n_active
+    sh.stash = None
     y, n = _SdfValueNormal.apply(x, sh, *ws, *bs)
     return y, n, sh
 
@@ -102,8 +137,8 @@ class _SdfReuse(torch.autograd.Function):
     outputs; backward runs the full first/second-order backward on those rows, including d/dx (idr.py:325-326)."""
 
     @staticmethod
-    def forward(ctx, pts, shared, N, *wb):
-        ctx.shared, ctx.N = shared, N
+    def forward(ctx, pts, shared, N, defer_dw, *wb):
+        ctx.shared, ctx.N, ctx.defer_dw = shared, N, defer_dw
         return shared.y[:N].clone(), shared.n[:N].clone()
 
     @staticmethod
@@ -112,12 +147,20 @@ class _SdfReuse(torch.autograd.Function):
         Nout = sh.net.layers[-1].N
         dyb = dy.contiguous() if dy is not None else torch.zeros(N, Nout, device=sh.x.device)
         dnb = dn.contiguous() if dn is not None else None
+        if ctx.defer_dw:
+            # only d/dx is computed here; (dy, dn) are stashed and folded into the main evaluation's backward, which autograd runs
+            # later (its outputs feed sample_network -> these points), so the weight gradients of both uses come from ONE pass
+            _, _, dx = ops.sdf_backward(sh.net, sh.x, sh.M, sh.Mg, N, dyb, dnb, sh.saved, True, want_dw=False)
+            sh.stash = (N, dyb, dnb)
+            return (dx, None, None, None) + (None,) * (2 * len(sh.net.layers))
         dWs, dbs, dx = ops.sdf_backward(sh.net, sh.x, sh.M, sh.Mg, N, dyb, dnb, sh.saved, True)
-        return (dx, None, None) + tuple(dWs) + tuple(dbs)
+        return (dx, None, None, None) + tuple(dWs) + tuple(dbs)
 
 
-def sdf_reuse(shared, ws, bs, pts, N):
-    return _SdfReuse.apply(pts, shared, N, *ws, *bs)
+def sdf_reuse(shared, ws, bs, pts, N, defer_dw=False):
+    """defer_dw: True only when `pts` is a differentiable function of the main evaluation's outputs (training: sample_network),
+    so that the main backward is guaranteed to run after this one and can take over the weight gradients."""
+    return _SdfReuse.apply(pts, shared, N, defer_dw, *ws, *bs)
 
 
 class _Render(torch.autograd.Function):

@@ -273,7 +273,8 @@ class IDRNetwork(nn.Module):
         return out
 
     def _rgb_from_shared(self, shared, ws, bs, points, view_dirs, N, train_progress):
-        y2, normals = Fn.sdf_reuse(shared, ws, bs, points, N)                                               # idr.py:325-327
+        defer = self.training and points.requires_grad and points.grad_fn is not None
+        y2, normals = Fn.sdf_reuse(shared, ws, bs, points, N, defer_dw=defer)                               # idr.py:325-327
         feature_vectors = y2[:, 2:]
         if (train_progress is not None and train_progress < conf.phase[0]) or conf.disable_rgb_grad:         # idr.py:331-334
             points, normals, view_dirs = [a.detach() for a in (points, normals, view_dirs)]

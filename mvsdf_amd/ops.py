@@ -58,6 +58,43 @@ def fold_backward(v, g, dW):
     return dv, dg.reshape(-1, 1)
 
 
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t_ in enumerate(tensors):
+        arr[i] = t_.data_ptr() if t_ is not None else None
+    return arr
+
+
+def fold_pack_net(vs, gs):
+    """All layers in one C call -> lists (w, wp, wpT)."""
+    vs = [_f32(v) for v in vs]
+    gs = [_f32(g).reshape(-1) for g in gs]
+    dev = vs[0].device
+    n = len(vs)
+    N = (C.c_int * n)(*[v.shape[0] for v in vs])
+    K = (C.c_int * n)(*[v.shape[1] for v in vs])
+    ws = [torch.empty_like(v) for v in vs]
+    wps = [torch.empty(lib().mvsdf_packed_floats(v.shape[0], v.shape[1]), dtype=torch.float32, device=dev) for v in vs]
+    wpTs = [torch.empty(lib().mvsdf_packed_floats(v.shape[1], v.shape[0]), dtype=torch.float32, device=dev) for v in vs]
+    check(lib().mvsdf_fold_pack_net(n, _ptr_array(vs), _ptr_array(gs), N, K, _ptr_array(ws), _ptr_array(wps), _ptr_array(wpTs),
+                                    stream_of(vs[0])), 'mvsdf_fold_pack_net')
+    return ws, wps, wpTs
+
+
+def fold_backward_net(vs, gs, dWs):
+    vs = [_f32(v) for v in vs]
+    gs = [_f32(g).reshape(-1) for g in gs]
+    dWs = [_f32(d) for d in dWs]
+    n = len(vs)
+    N = (C.c_int * n)(*[v.shape[0] for v in vs])
+    K = (C.c_int * n)(*[v.shape[1] for v in vs])
+    dvs = [torch.empty_like(v) for v in vs]
+    dgs = [torch.empty_like(g) for g in gs]
+    check(lib().mvsdf_fold_backward_net(n, _ptr_array(vs), _ptr_array(gs), _ptr_array(dWs), N, K, _ptr_array(dvs), _ptr_array(dgs),
+                                        stream_of(vs[0])), 'mvsdf_fold_backward_net')
+    return dvs, [g.reshape(-1, 1) for g in dgs]
+
+
 def pack_net(vs, gs, biases, skip_layer, multires, want_t=True):
     layers = []
     for v, g, b in zip(vs, gs, biases):
@@ -158,19 +195,21 @@ def sdf_forward(net, x, Mg):
     return y, n, ctx
 
 
-def sdf_backward(net, x, M, Mg, Mb, dy, dn, ctx, want_dx):
-    """-> (dWs [list per layer], dbs, dx or None) over the first Mb rows."""
+def sdf_backward(net, x, M, Mg, Mb, dy, dn, ctx, want_dx, want_dw=True):
+    """-> (dWs [list per layer], dbs, dx or None) over the first Mb rows (dWs = dbs = None when want_dw is False)."""
     x, dy = _f32(x), _f32(dy)
     dev = x.device
     d, dT = net.desc(), net.desc(True)
     ws_n, bs_n = net.wsizes()
-    dW = torch.empty(sum(ws_n), dtype=torch.float32, device=dev)
-    db = torch.empty(sum(bs_n), dtype=torch.float32, device=dev)
+    dW = torch.empty(sum(ws_n), dtype=torch.float32, device=dev) if want_dw else None
+    db = torch.empty(sum(bs_n), dtype=torch.float32, device=dev) if want_dw else None
     dx = torch.empty(Mb, 3, dtype=torch.float32, device=dev) if want_dx else None
     ws = torch.empty(lib().mvsdf_sdf_bwd_ws_floats(C.byref(d), Mb), dtype=torch.float32, device=dev)
     dn = _f32(dn) if dn is not None else None
     check(lib().mvsdf_sdf_backward(C.byref(d), C.byref(dT), ptr(x), M, Mg, Mb, ptr(dy), ptr(dn), ptr(ctx), ptr(dW), ptr(db), ptr(dx),
                                    ptr(ws), stream_of(x)), 'mvsdf_sdf_backward')
+    if not want_dw:
+        return None, None, dx
     dWs, dbs = _split_cat(net, dW, db)
     return dWs, dbs, dx
 
