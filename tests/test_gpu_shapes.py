@@ -1,0 +1,124 @@
+"""Other shapes a user of the reference hits: width 512 (the shipped mvsdf_dtu.conf), training phase 0 (depth-surface sampling),
+the c3 batch shape (8192 rays, 8 source views), channels_last feature maps, empty / ragged inputs."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import sdf_packed_net, t, trace_params
+from mvsdf_amd import ops
+from mvsdf_amd.model.implicit_differentiable_renderer import IDRNetwork
+from mvsdf_amd.model.loss import IDRLoss
+from mvsdf_amd.utils import synth
+from mvsdf_amd.utils.config import ConfigDict
+from oracle import oracle_np as ON
+
+pytestmark = pytest.mark.gpu
+
+
+def test_width_512_bit_exact_and_grads(oracle):
+    W = 512
+    sd = synth.make_state_dict(W, 0)
+    onet, net = oracle.Net(sd), sdf_packed_net(sd)
+    rs = np.random.RandomState(2)
+    x = rs.uniform(-1, 1, size=(200, 3)).astype(np.float32)
+    ref = oracle.sdf_forward(onet, x, ncols=1)[:, 0]
+    for mt in (1, 2):
+        assert np.array_equal(ops.sdf_col0(net, t(x), mt=mt).cpu().numpy(), ref)
+    # tracer at W=512, small batch, bit-exact vs oracle
+    inp, _ = synth.make_batch(1, 96, 0, seed=2, with_features=False, focal_scale=1.4)
+    dirs, cam = ops.camera_rays(t(inp['uv']), t(inp['pose']), t(inp['intrinsics']))
+    iv = torch.linspace(0, 1, 100)
+    steps = rs.uniform(size=100).astype(np.float32)
+    om = np.ones(96, bool)
+    pts, mask, dists, cnt = ops.trace(net, cam, dirs, t(om), trace_params(W), True, iv.cuda(), t(steps))
+    p_o, m_o, d_o, rows = oracle.trace(onet, cam.cpu().numpy(), dirs.cpu().numpy(), om, True, steps, iv.numpy(), **synth.model_conf(W)['ray_tracer'])
+    assert np.array_equal(mask.cpu().numpy(), m_o) and np.array_equal(dists.cpu().numpy(), d_o) and np.array_equal(cnt.cpu().numpy()[:4], rows)
+    # differentiable passes vs the numpy oracle
+    nnet = ON.sdf_net(sd)
+    M = 90
+    dy = (rs.normal(size=(M, 258)) * 0.1).astype(np.float32)
+    dn = rs.normal(size=(M, 3)).astype(np.float32)
+    y, n, ctx = ops.sdf_forward(net, t(x[:M]), M)
+    oy, on, cache = ON.sdf_forward(nnet, x[:M])
+    rel = lambda a, b: float(np.abs(a.detach().cpu().numpy() - b).max() / max(np.abs(b).max(), 1e-12))
+    assert rel(y, oy) < 3e-5 and rel(n, on) < 1e-4
+    oW, ob, odx = ON.sdf_backward(nnet, cache, dy, dn)
+    dWs, dbs, dx = ops.sdf_backward(net, t(x[:M]), M, M, M, t(dy), t(dn), ctx, True)
+    assert rel(dx, odx) < 5e-4
+    for l in range(9):
+        assert rel(dWs[l], oW[l]) < 1e-3 and rel(dbs[l], ob[l]) < 1e-3, l
+
+
+def _model(W):
+    m = IDRNetwork(ConfigDict(synth.model_conf(W)))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(W, 0).items()})
+    return m.cuda().train()
+
+
+def test_phase0_training_step_runs():
+    """train_progress < 1/6: depth-surface samples (idr.py:226-251) join the eikonal / depth terms; feat + surf losses are off."""
+    m = _model(64)
+    B, P = 2, 128
+    inp, gt = synth.make_batch(B, P, 2, seed=4, feat_hw=(60, 80), focal_scale=1.4, size=2.0)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    out = m({k: t(v) for k, v in inp.items()}, 0.05)
+    R, N = B * P, int(out['network_object_mask'].sum())
+    n_extra = R // 2 + 2 * (R // 2)
+    assert out['grad_theta'].shape == (N + n_extra, 3) and out['eikonal_output'].shape == (1, N + n_extra)
+    lo = IDRLoss()(out, {k: t(v) for k, v in gt.items()}, 0.05, B)
+    assert float(lo['feat_loss']) == 0.0 and float(lo['surf_loss']) == 0.0 and torch.isfinite(lo['loss'])
+    lo['loss'].backward()
+    g = torch.cat([p.grad.flatten() for p in m.parameters()])
+    assert torch.isfinite(g).all() and float(g.norm()) > 0
+    # phase 0 detaches points / normals / view dirs in front of the rendering net (idr.py:331-334): the rgb term reaches theta only via features
+
+
+def test_c3_shape_and_channels_last():
+    """8 views x 1024 px = 8192 rays, 8 source views (BASELINE config 3); channels_last features give the same loss / grads."""
+    m = _model(64)
+    B, P, V = 8, 1024, 8
+    inp, gt = synth.make_batch(B, P, V, seed=1, feat_hw=(75, 100))
+    gtt = {k: t(v) for k, v in gt.items()}
+    res = []
+    for cl in (False, True):
+        g2 = dict(gtt)
+        if cl:
+            g2['feat'] = gtt['feat'].contiguous(memory_format=torch.channels_last)
+            g2['feat_src'] = gtt['feat_src'].permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)      # same shape, C innermost
+            assert g2['feat_src'].shape == gtt['feat_src'].shape and g2['feat_src'].stride(2) == 1
+        torch.manual_seed(0)
+        m.zero_grad()
+        out = m({k: t(v) for k, v in inp.items()}, 0.3)
+        lo = IDRLoss()(out, g2, 0.3, B)
+        lo['loss'].backward()
+        res.append((float(lo['feat_loss']), torch.cat([p.grad.flatten() for p in m.parameters()]).clone()))
+    assert out['rgb_values'].shape == (B * P, 3) and res[0][0] > 0
+    assert abs(res[0][0] - res[1][0]) < 1e-6 and torch.allclose(res[0][1], res[1][1], rtol=1e-4, atol=1e-6)
+
+
+def test_empty_and_ragged_inputs():
+    sd = synth.make_state_dict(64, 0)
+    net = sdf_packed_net(sd)
+    # all rays miss the bounding sphere: no hits, no sampler work, nothing blows up
+    cam = torch.tensor([[0.0, 0.0, 5.0]], device='cuda')
+    dirs = torch.tensor([[[1.0, 0.0, 0.0]] * 7], device='cuda')
+    iv = torch.linspace(0, 1, 100).cuda()
+    pts, mask, dists, cnt = ops.trace(net, cam, dirs, torch.ones(7, dtype=torch.bool, device='cuda'), trace_params(64), True, iv, torch.rand(100).cuda())
+    assert not bool(mask.any()) and int(cnt[:4].sum()) == 0
+    assert torch.allclose(dists, torch.zeros(7, device='cuda'))                 # left-out projection: -(d . c) = 0 here (ray_tracing.py:79-84)
+    # a zero-hit training batch goes through model + loss + backward (loss.py:22-23,31-32,117-118 short-circuits)
+    m = _model(64)
+    inp, gt = synth.make_batch(1, 33, 2, seed=0, feat_hw=(30, 40))
+    inp['pose'][0, :3, 3] = [0.0, 0.0, 9.0]
+    inp['pose'][0, :3, :3] = np.eye(3)                                           # looking away from the origin
+    out = m({k: t(v) for k, v in inp.items()}, 0.3)
+    assert int(out['network_object_mask'].sum()) == 0 and out['diff_surf_pts'].shape == (0, 3)
+    lo = IDRLoss()(out, {k: t(v) for k, v in gt.items()}, 0.3, 1)
+    assert float(lo['rgb_loss']) == 0.0 and float(lo['feat_loss']) == 0.0 and torch.isfinite(lo['loss'])
+    lo['loss'].backward()
+    # ragged row counts through the MLP kernels (1 row, 17 rows)
+    for n in (1, 17):
+        x = torch.rand(n, 3, device='cuda')
+        y, nn_, _ = ops.sdf_forward(net, x, n)
+        assert y.shape == (n, 258) and nn_.shape == (n, 3) and torch.isfinite(y).all()
