@@ -117,7 +117,8 @@ def main():
     model = model.to(dev).train()
     loss_fn = IDRLoss()
     bucket = FlatGradBucket(model.parameters())
-    opt = torch.optim.Adam(model.parameters(), lr=0.0)          # frozen weights: a step on random GT collapses the scene
+    # frozen weights (lr = 0): a step on random GT collapses the scene; fused = one multi-tensor kernel
+    opt = torch.optim.Adam(model.parameters(), lr=0.0, fused=os.environ.get('MVSDF_FUSED_ADAM', '1') == '1')
     inp, gt = make_inputs(dev, seed=rank)
     events = []
     model.ray_tracer.events = events

@@ -179,11 +179,11 @@ class IDRNetwork(nn.Module):
         surface_mask = (network_object_mask & object_mask) if self.training else network_object_mask
         # rows: [surface rays | sample points | the other rays]  (stable order inside each group = the reference's boolean-mask order)
         perm = torch.sort((~surface_mask).to(torch.int8), stable=True).indices
-        N = int(surface_mask.sum().item())                      # the one host sync of the forward: output shapes depend on it
+        n_hit_dev = surface_mask.sum()
         inv = torch.empty_like(perm)
         inv[perm] = torch.arange(R, device=dev)
-        hit_idx, rest_idx = perm[:N], perm[N:]
         cam_rays = cam_loc.unsqueeze(1).expand(batch_size, num_pixels, 3).reshape(-1, 3)
+        pts_sorted = points[perm]                                # hit rays first, then the others
 
         if self.training:
             assert train_progress is not None
@@ -200,8 +200,17 @@ class IDRNetwork(nn.Module):
                 dsurf_on_sample = torch.zeros(0, 3, device=dev)
                 dsurf_jitter_sample = torch.zeros(0, 3, device=dev)
             E = n_eik_points + 2 * n_dsurf_points
-            x_all = torch.cat([points[hit_idx], eikonal_points, dsurf_on_sample, dsurf_jitter_sample, points[rest_idx]], 0)
-            y_all, n_all, shared = Fn.sdf_value_normal(net, ws, bs, x_all, N + E, n_active=N + E)
+            # One fused value + normal evaluation, launched BEFORE the host learns the hit count N (its shapes do not depend on N):
+            # rows [all rays, hit ones first | sample points]; normals on every row (those of non-hit rays are never read).
+            x_eval = torch.cat([pts_sorted, eikonal_points, dsurf_on_sample, dsurf_jitter_sample], 0)
+            y_eval, n_eval, shared = Fn.sdf_value_normal(net, ws, bs, x_eval, R + E)
+            N = int(n_hit_dev.item())                            # the one host sync of the forward: output shapes depend on it
+            shared.n_active = R + E
+            hit_idx, rest_idx = perm[:N], perm[N:]
+            # logical order of the reference: [hit | samples | non-hit]
+            x_all = torch.cat([x_eval[:N], x_eval[R:], x_eval[N:R]], 0)
+            y_all = torch.cat([y_eval[:N], y_eval[R:], y_eval[N:R]], 0)
+            n_all = torch.cat([n_eval[:N], n_eval[R:]], 0)
             sdf_output = torch.cat([y_all[:N, :1], y_all[N + E:, :1]], 0)[inv]                               # idr.py:202-203, ray order
             points_all = x_all[:N + E]
             output = y_all[N:N + E]
@@ -243,8 +252,10 @@ class IDRNetwork(nn.Module):
             differentiable_surface_points = self.sample_network(surface_output, surface_sdf_values, surface_points_grad, surface_dists,
                                                                 surface_cam_loc, surface_ray_dirs)
         else:
-            x_all = torch.cat([points[hit_idx], points[rest_idx]], 0)
-            y_all, n_all, shared = Fn.sdf_value_normal(net, ws, bs, x_all, N, n_active=N)
+            y_all, n_all, shared = Fn.sdf_value_normal(net, ws, bs, pts_sorted, R)
+            N = int(n_hit_dev.item())
+            hit_idx, rest_idx = perm[:N], perm[N:]
+            x_all = pts_sorted
             sdf_output = y_all[:, :1][inv]
             differentiable_surface_points = x_all[:N]
             grad_theta = None
