@@ -1,0 +1,28 @@
+"""Chunked evaluation helpers of the reference's eval / plot loops (reference code/utils/general.py:23-53): split a full-image
+model input into pixel chunks and merge the per-chunk outputs back.  Used by callers that render whole images through
+IDRNetwork.forward in eval mode (eval.py:145-151, idr_train.py:221-230)."""
+import torch
+
+
+def split_input(model_input, total_pixels, n_pixels=10000):
+    """-> list of model-input dicts, each with at most n_pixels pixels of uv / object_mask (general.py:23-37)."""
+    out = []
+    for idx in torch.split(torch.arange(total_pixels, device=model_input['uv'].device), n_pixels, dim=0):
+        d = dict(model_input)
+        d['uv'] = torch.index_select(model_input['uv'], 1, idx)
+        d['object_mask'] = torch.index_select(model_input['object_mask'], 1, idx)
+        out.append(d)
+    return out
+
+
+def merge_output(res, total_pixels, batch_size):
+    """Concatenate per-chunk output dicts back to full-image tensors (general.py:39-53); None entries are dropped."""
+    merged = {}
+    for k in res[0]:
+        if res[0][k] is None:
+            continue
+        parts = [r[k].reshape(batch_size, -1, 1) if r[k].dim() == 1 else r[k].reshape(batch_size, -1, r[k].shape[-1]) for r in res]
+        merged[k] = torch.cat(parts, 1).reshape(batch_size * total_pixels, -1 if parts[0].shape[-1] > 1 else 1)
+        if parts[0].shape[-1] == 1:
+            merged[k] = merged[k].reshape(batch_size * total_pixels)
+    return merged

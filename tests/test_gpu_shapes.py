@@ -122,3 +122,28 @@ def test_empty_and_ragged_inputs():
         x = torch.rand(n, 3, device='cuda')
         y, nn_, _ = ops.sdf_forward(net, x, n)
         assert y.shape == (n, 258) and nn_.shape == (n, 3) and torch.isfinite(y).all()
+
+
+def test_chunked_eval_render_matches_unchunked():
+    """eval.py-style rendering: image split into pixel chunks (general.split_input) == one shot; IDR_RENDER switches to 40 iterations."""
+    import os
+    from mvsdf_amd.utils.general import merge_output, split_input
+    m = _model(64).eval()
+    inp, _ = synth.make_batch(1, 900, 0, seed=5, with_features=False, focal_scale=1.4)
+    full = {k: t(v) for k, v in inp.items() if k in ('uv', 'pose', 'intrinsics', 'object_mask')}
+    with torch.no_grad():
+        ref = m(full)
+        res = []
+        for s in split_input(full, 900, n_pixels=256):
+            o = m(s)
+            res.append({'rgb_values': o['rgb_values'].detach(), 'network_object_mask': o['network_object_mask'], 'sdf_output': o['sdf_output'].detach()})
+        mo = merge_output(res, 900, 1)
+    assert torch.equal(mo['network_object_mask'].bool(), ref['network_object_mask'])
+    assert torch.allclose(mo['rgb_values'], ref['rgb_values'], atol=1e-5)
+    os.environ['IDR_USE_ENV'], os.environ['IDR_RENDER'] = '1', '1'
+    try:
+        with torch.no_grad():
+            hq = m(full)
+        assert int(m.ray_tracer.last_counters[0]) > 0 and hq['rgb_values'].shape == (900, 3)
+    finally:
+        os.environ.pop('IDR_USE_ENV'); os.environ.pop('IDR_RENDER')
