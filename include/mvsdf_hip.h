@@ -114,10 +114,10 @@ int mvsdf_trace_stage(int stage, const MvsdfNetDesc* net, const MvsdfTraceParams
 size_t mvsdf_sdf_ctx_floats(const MvsdfNetDesc* net, int M, int Mg);
 int mvsdf_sdf_forward(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, const float* x, int M, int Mg, float* y, float* nrm, float* ctx,
                       void* stream);
-/* Backward over the FIRST Mb rows (Mb <= M; Mb <= Mg when dn is given): dy[Mb][Nout], dn[Mb][3] or NULL ->
+/* Backward over rows [row0, row0 + Mb) (inside [0, M); inside [0, Mg) when dn is given): dy[Mb][Nout], dn[Mb][3] or NULL ->
  * dW_cat (all layers, row-major [N][K], concatenated), db_cat (both NULL: input adjoint only), dx[Mb][3] or NULL.  ws: mvsdf_sdf_bwd_ws_floats(net, Mb) floats. */
 size_t mvsdf_sdf_bwd_ws_floats(const MvsdfNetDesc* net, int Mb);
-int mvsdf_sdf_backward(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, const float* x, int M, int Mg, int Mb, const float* dy,
+int mvsdf_sdf_backward(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, const float* x, int M, int Mg, int row0, int Mb, const float* dy,
                        const float* dn, const float* ctx, float* dW_cat, float* db_cat, float* dx, float* ws, void* stream);
 
 /* ---- rendering network, mode 'idr' (idr.py:145-167): rgb = tanh(MLP(cat[points, PE(view), normals, feat])) ---- */

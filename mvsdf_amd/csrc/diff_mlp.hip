@@ -270,26 +270,32 @@ int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float
     return mv_check(hipGetLastError(), "mvsdf_sdf_forward");
 }
 
-/* Backward over the first Mb rows of a forward context made with (M, Mg).  dy[Mb][Nout] (required), dn[Mb][3] or NULL
- * (then Mb may exceed Mg).  Outputs: dW_cat / db_cat (all layers concatenated, row-major [N][K]), dx[Mb][3] or NULL. */
-int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float* x, int M, int Mg, int Mb, const float* dy,
+/* Backward over rows [row0, row0 + Mb) of a forward context made with (M, Mg).  dy[Mb][Nout] (required), dn[Mb][3] or NULL
+ * (rows must lie inside [0, Mg) when dn is given).  Outputs: dW_cat / db_cat (all layers concatenated, row-major [N][K]; both NULL
+ * = input adjoint only), dx[Mb][3] or NULL. */
+int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float* x, int M, int Mg, int row0, int Mb, const float* dy,
                        const float* dn, const float* ctx, float* dW_cat, float* db_cat, float* dx, float* ws, void* stream) {
     MvNet net, netT;
     int rc = mv_make_net(d, &net);
     if (rc) return rc;
     rc = mv_make_net_mode(dT, &netT, 2);
     if (rc) return rc;
-    if (!x || !dy || !ctx || !ws || Mb <= 0 || Mb > M || (dn && Mb > Mg) || ((dW_cat == nullptr) != (db_cat == nullptr)))
+    if (!x || !dy || !ctx || !ws || Mb <= 0 || row0 < 0 || row0 + Mb > M || (dn && row0 + Mb > Mg) || ((dW_cat == nullptr) != (db_cat == nullptr)))
         return mv_fail(-1, "mvsdf_sdf_backward: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const SdfLayout lo = sdf_ctx_layout(net, M, Mg);
     const SdfBwdLayout bl = sdf_bwd_layout(net, Mb);
     const int nl = lo.nl, S = stride_for(net, netT), sk = net.skip_layer;
-    const float* H0 = ctx + lo.H0;
+    const size_t r0 = (size_t)row0;
+    const float* H0 = ctx + lo.H0 + r0 * lo.ld0;                 // every context tensor is [rows][width]: a row offset is a pointer offset
     const float* w8 = d->w[nl - 1];
     if (dn && !w8) return mv_fail(-1, "mvsdf_sdf_backward: row-major last-layer weights missing");
-    auto Aof = [&](int l) { return l == 0 ? H0 : ctx + lo.A[l]; };
+    auto Aof = [&](int l) { return l == 0 ? H0 : ctx + lo.A[l] + r0 * net.L[l].K; };
     auto ldA = [&](int l) { return l == 0 ? lo.ld0 : net.L[l].K; };
+    auto Zof = [&](int l) { return ctx + lo.Z[l] + r0 * net.L[l].N; };
+    auto Uof = [&](int l) { return ctx + lo.U[l] + r0 * net.L[l - 1].N; };       // u_l has width out_{l-1}
+    auto Sof = [&](int l) { return ctx + lo.Sg[l] + r0 * net.L[l].N; };
+    const float* G0 = ctx + lo.G0 + r0 * lo.ld0;
     // ---- E.1: adjoint of the normal chain (ascending) ----
     if (dn) {
         hipLaunchKernelGGL(k_pe_normal_bwd, dim3((Mb * (3 * net.multires + 1) + 255) / 256), dim3(256), 0, s, H0, lo.ld0, dn, Mb,
@@ -298,8 +304,8 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         for (int l = 0; l < nl - 1; ++l) {
             LayerArgs a = base_args(net.L[l], S, Mb);
             a.A = ws + bl.VB[l]; a.lda = ldA(l);
-            a.Z = ctx + lo.Z[l]; a.ldz = net.L[l].N;
-            if (l == nl - 2) a.bcast = w8; else { a.U = ctx + lo.U[l + 1]; a.ldu = net.L[l].N; }
+            a.Z = Zof(l); a.ldz = net.L[l].N;
+            if (l == nl - 2) a.bcast = w8; else { a.U = Uof(l + 1); a.ldu = net.L[l].N; }
             a.out0 = ws + bl.VB[l + 1]; a.ld0 = net.L[l + 1].K;
             a.out1 = ws + bl.ZB2[l]; a.ld1 = net.L[l].N;
             a.skip_next = (l + 1 == sk);
@@ -317,7 +323,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
     if (sk <= 0) MV_TRY(hipMemsetAsync(ws + bl.H0B, 0, (size_t)Mb * lo.ld0 * sizeof(float), s));
     for (int l = nl - 2; l >= 0; --l) {
         LayerArgs a = base_args(netT.L[l], S, Mb);
-        a.Z = ctx + lo.Z[l]; a.ldz = net.L[l].N;
+        a.Z = Zof(l); a.ldz = net.L[l].N;
         a.U = ws + bl.HB[cur]; a.ldu = net.L[l].N;
         if (dn) { a.A = ws + bl.ZB2[l]; a.lda = net.L[l].N; a.Mg = Mb; }
         a.out2 = ws + bl.ZB[l]; a.ld2 = net.L[l].N;
@@ -344,7 +350,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         const float* P = last ? dy : ws + bl.ZB[l];
         const bool two = dn && !last;
         int nch = 0;
-        MV_TRY(launch_wgrad(P, No, Aof(l), ldA(l), Mb, two ? ctx + lo.Sg[l] : nullptr, No, two ? ws + bl.VB[l] : nullptr, ldA(l), Mb, No, Ki,
+        MV_TRY(launch_wgrad(P, No, Aof(l), ldA(l), Mb, two ? Sof(l) : nullptr, No, two ? ws + bl.VB[l] : nullptr, ldA(l), Mb, No, Ki,
                             bl.chunk, ws + bl.slabA, ws + bl.bslab, &nch, s));
         MV_TRY(launch_reduce(ws + bl.slabA, nch, (size_t)No * Ki, dW_cat + woff, 0, s));
         MV_TRY(launch_reduce(ws + bl.bslab, bl.nchunks, (size_t)No, db_cat + boff, 0, s));
@@ -356,7 +362,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
     }
     // ---- E.3: input adjoint ----
     if (dx)
-        hipLaunchKernelGGL(k_pe_input_bwd, dim3((Mb * 3 + 255) / 256), dim3(256), 0, s, H0, lo.ld0, ws + bl.H0B, lo.ld0, ctx + lo.G0, lo.ld0,
+        hipLaunchKernelGGL(k_pe_input_bwd, dim3((Mb * 3 + 255) / 256), dim3(256), 0, s, H0, lo.ld0, ws + bl.H0B, lo.ld0, G0, lo.ld0,
                            dn, Mb, net.multires, dx);
     return mv_check(hipGetLastError(), "mvsdf_sdf_backward");
 }

@@ -85,17 +85,17 @@ class _SdfValueNormal(torch.autograd.Function):
         Nout = sh.net.layers[-1].N
         dyb = dy[:Mb].contiguous() if dy is not None else torch.zeros(Mb, Nout, device=sh.x.device)
         if sh.stash is not None:                         # upstream grads of the re-use at the surface points (same rows, same weights):
-            n0, sdy, sdn = sh.stash                      # by linearity their weight gradients are computed here, once
+            r0, n0, sdy, sdn = sh.stash                  # by linearity their weight gradients are computed here, once
             sh.stash = None
             if dyb.data_ptr() == (dy.data_ptr() if dy is not None else 0):
                 dyb = dyb.clone()
-            dyb[:n0] += sdy
+            dyb[r0:r0 + n0] += sdy
             if sdn is not None:
                 if dn is None:
                     dn = torch.zeros(sh.Mg, 3, device=sh.x.device)
                 else:
                     dn = dn.clone()
-                dn[:n0] += sdn
+                dn[r0:r0 + n0] += sdn
         dnb = None
         if dn is not None and sh.Mg > 0:
             mg = min(Mb, sh.Mg)
@@ -132,35 +132,35 @@ def sdf_value_normal(net, ws, bs, x, Mg, n_active=None):
 
 
 class _SdfReuse(torch.autograd.Function):
-    """Value + normal at points that are numerically the first N rows of an earlier evaluation (the differentiable
+    """Value + normal at points that are numerically rows [row0, row0 + N) of an earlier evaluation (the differentiable
     surface points x(theta) equal the traced points: sample_network.py:14 with f - f0 == 0).  Forward re-uses the stored
     outputs; backward runs the full first/second-order backward on those rows, including d/dx (idr.py:325-326)."""
 
     @staticmethod
-    def forward(ctx, pts, shared, N, defer_dw, *wb):
-        ctx.shared, ctx.N, ctx.defer_dw = shared, N, defer_dw
-        return shared.y[:N].clone(), shared.n[:N].clone()
+    def forward(ctx, pts, shared, row0, N, defer_dw, *wb):
+        ctx.shared, ctx.row0, ctx.N, ctx.defer_dw = shared, row0, N, defer_dw
+        return shared.y[row0:row0 + N].clone(), shared.n[row0:row0 + N].clone()
 
     @staticmethod
     def backward(ctx, dy, dn):
-        sh, N = ctx.shared, ctx.N
+        sh, N, r0 = ctx.shared, ctx.N, ctx.row0
         Nout = sh.net.layers[-1].N
         dyb = dy.contiguous() if dy is not None else torch.zeros(N, Nout, device=sh.x.device)
         dnb = dn.contiguous() if dn is not None else None
         if ctx.defer_dw:
             # only d/dx is computed here; (dy, dn) are stashed and folded into the main evaluation's backward, which autograd runs
             # later (its outputs feed sample_network -> these points), so the weight gradients of both uses come from ONE pass
-            _, _, dx = ops.sdf_backward(sh.net, sh.x, sh.M, sh.Mg, N, dyb, dnb, sh.saved, True, want_dw=False)
-            sh.stash = (N, dyb, dnb)
-            return (dx, None, None, None) + (None,) * (2 * len(sh.net.layers))
-        dWs, dbs, dx = ops.sdf_backward(sh.net, sh.x, sh.M, sh.Mg, N, dyb, dnb, sh.saved, True)
-        return (dx, None, None, None) + tuple(dWs) + tuple(dbs)
+            _, _, dx = ops.sdf_backward(sh.net, sh.x, sh.M, sh.Mg, N, dyb, dnb, sh.saved, True, want_dw=False, row0=r0)
+            sh.stash = (r0, N, dyb, dnb)
+            return (dx, None, None, None, None) + (None,) * (2 * len(sh.net.layers))
+        dWs, dbs, dx = ops.sdf_backward(sh.net, sh.x, sh.M, sh.Mg, N, dyb, dnb, sh.saved, True, row0=r0)
+        return (dx, None, None, None, None) + tuple(dWs) + tuple(dbs)
 
 
-def sdf_reuse(shared, ws, bs, pts, N, defer_dw=False):
+def sdf_reuse(shared, ws, bs, pts, N, defer_dw=False, row0=0):
     """defer_dw: True only when `pts` is a differentiable function of the main evaluation's outputs (training: sample_network),
     so that the main backward is guaranteed to run after this one and can take over the weight gradients."""
-    return _SdfReuse.apply(pts, shared, N, defer_dw, *ws, *bs)
+    return _SdfReuse.apply(pts, shared, row0, N, defer_dw, *ws, *bs)
 
 
 class _Render(torch.autograd.Function):

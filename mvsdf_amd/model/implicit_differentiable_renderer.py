@@ -201,16 +201,18 @@ class IDRNetwork(nn.Module):
                 dsurf_jitter_sample = torch.zeros(0, 3, device=dev)
             E = n_eik_points + 2 * n_dsurf_points
             # One fused value + normal evaluation, launched BEFORE the host learns the hit count N (its shapes do not depend on N):
-            # rows [all rays, hit ones first | sample points]; normals on every row (those of non-hit rays are never read).
-            x_eval = torch.cat([pts_sorted, eikonal_points, dsurf_on_sample, dsurf_jitter_sample], 0)
+            # rows [sample points | all rays, hit ones first]; normals on every row (those of non-hit rays are never read).
+            # Rows that receive gradients form the prefix [0, E + N): the backward skips the non-hit rays.
+            x_eval = torch.cat([eikonal_points, dsurf_on_sample, dsurf_jitter_sample, pts_sorted], 0)
             y_eval, n_eval, shared = Fn.sdf_value_normal(net, ws, bs, x_eval, R + E)
             N = int(n_hit_dev.item())                            # the one host sync of the forward: output shapes depend on it
-            shared.n_active = R + E
+            shared.n_active = E + N
+            row0 = E
             hit_idx, rest_idx = perm[:N], perm[N:]
             # logical order of the reference: [hit | samples | non-hit]
-            x_all = torch.cat([x_eval[:N], x_eval[R:], x_eval[N:R]], 0)
-            y_all = torch.cat([y_eval[:N], y_eval[R:], y_eval[N:R]], 0)
-            n_all = torch.cat([n_eval[:N], n_eval[R:]], 0)
+            x_all = torch.cat([x_eval[E:E + N], x_eval[:E], x_eval[E + N:]], 0)
+            y_all = torch.cat([y_eval[E:E + N], y_eval[:E], y_eval[E + N:]], 0)
+            n_all = torch.cat([n_eval[E:E + N], n_eval[:E]], 0)
             sdf_output = torch.cat([y_all[:N, :1], y_all[N + E:, :1]], 0)[inv]                               # idr.py:202-203, ray order
             points_all = x_all[:N + E]
             output = y_all[N:N + E]
@@ -256,6 +258,7 @@ class IDRNetwork(nn.Module):
             N = int(n_hit_dev.item())
             hit_idx, rest_idx = perm[:N], perm[N:]
             x_all = pts_sorted
+            row0 = 0
             sdf_output = y_all[:, :1][inv]
             differentiable_surface_points = x_all[:N]
             grad_theta = None
@@ -263,7 +266,7 @@ class IDRNetwork(nn.Module):
         view = -ray_dirs[hit_idx]
         rgb_values = torch.ones_like(points)
         if N > 0:
-            rgb = self._rgb_from_shared(shared, ws, bs, differentiable_surface_points, view, N, train_progress)
+            rgb = self._rgb_from_shared(shared, ws, bs, differentiable_surface_points, view, N, train_progress, row0)
             rgb_values = rgb_values.index_put((hit_idx,), rgb)                                               # idr.py:302-304
 
         out = {
@@ -283,9 +286,9 @@ class IDRNetwork(nn.Module):
         self.last_stats = {'R': R, 'N': N, 'E': (x_all.shape[0] - R), 'counters': self.ray_tracer.last_counters}
         return out
 
-    def _rgb_from_shared(self, shared, ws, bs, points, view_dirs, N, train_progress):
+    def _rgb_from_shared(self, shared, ws, bs, points, view_dirs, N, train_progress, row0=0):
         defer = self.training and points.requires_grad and points.grad_fn is not None
-        y2, normals = Fn.sdf_reuse(shared, ws, bs, points, N, defer_dw=defer)                               # idr.py:325-327
+        y2, normals = Fn.sdf_reuse(shared, ws, bs, points, N, defer_dw=defer, row0=row0)                               # idr.py:325-327
         feature_vectors = y2[:, 2:]
         if (train_progress is not None and train_progress < conf.phase[0]) or conf.disable_rgb_grad:         # idr.py:331-334
             points, normals, view_dirs = [a.detach() for a in (points, normals, view_dirs)]

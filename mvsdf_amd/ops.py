@@ -195,8 +195,9 @@ def sdf_forward(net, x, Mg):
     return y, n, ctx
 
 
-def sdf_backward(net, x, M, Mg, Mb, dy, dn, ctx, want_dx, want_dw=True):
-    """-> (dWs [list per layer], dbs, dx or None) over the first Mb rows (dWs = dbs = None when want_dw is False)."""
+def sdf_backward(net, x, M, Mg, Mb, dy, dn, ctx, want_dx, want_dw=True, row0=0):
+    """-> (dWs [list per layer], dbs, dx or None) over rows [row0, row0 + Mb) (dWs = dbs = None when want_dw is False).
+    x is the full [M,3] point tensor of the forward; dy / dn hold Mb rows."""
     x, dy = _f32(x), _f32(dy)
     dev = x.device
     d, dT = net.desc(), net.desc(True)
@@ -206,7 +207,8 @@ def sdf_backward(net, x, M, Mg, Mb, dy, dn, ctx, want_dx, want_dw=True):
     dx = torch.empty(Mb, 3, dtype=torch.float32, device=dev) if want_dx else None
     ws = torch.empty(lib().mvsdf_sdf_bwd_ws_floats(C.byref(d), Mb), dtype=torch.float32, device=dev)
     dn = _f32(dn) if dn is not None else None
-    check(lib().mvsdf_sdf_backward(C.byref(d), C.byref(dT), ptr(x), M, Mg, Mb, ptr(dy), ptr(dn), ptr(ctx), ptr(dW), ptr(db), ptr(dx),
+    xr = x[row0:] if row0 else x
+    check(lib().mvsdf_sdf_backward(C.byref(d), C.byref(dT), ptr(xr), M, Mg, row0, Mb, ptr(dy), ptr(dn), ptr(ctx), ptr(dW), ptr(db), ptr(dx),
                                    ptr(ws), stream_of(x)), 'mvsdf_sdf_backward')
     if not want_dw:
         return None, None, dx
