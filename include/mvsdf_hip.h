@@ -145,6 +145,16 @@ int mvsdf_depth_carve(const float* pts, int M, const float* depths, int B, int h
                       const float* center, float out_thresh_perc, float far_thresh, float far_att, float near_thresh, float near_att,
                       float* dist_r, float* weight, void* stream);
 
+/* ---- the elementwise terms of IDRLoss.forward + weighted total (loss.py:21-35, 58-61, 167-174, 206-210), one launch ----
+ * rgb[R][3], rgb_gt[R][3], rgb_mask[R] (network_object_mask & object_mask); grad_theta[n_eik][3]; eik_out / dist_r / dweight[n_depth]
+ * (dist_r, dweight from mvsdf_depth_carve); surf[n_surf] logits with targets (i < *n_pos); feat_pp[n_feat] from mvsdf_feat_corr or NULL.
+ * out[6] = {loss, rgb_loss, eikonal_loss, depth_loss, feat_loss, surf_loss}; d_*: unit gradients of each term w.r.t. its input. */
+int mvsdf_loss_terms(const float* rgb, const float* rgb_gt, const uint8_t* rgb_mask, int R, const float* grad_theta, int n_eik,
+                     const float* eik_out, const float* dist_r, const float* dweight, int n_depth, const float* surf, int n_surf,
+                     const long long* n_pos, const float* feat_pp, int n_feat, float w_rgb, float w_eik, float w_surf, float w_feat,
+                     float w_depth, int surf_on, int feat_on, float* out, float* d_rgb, float* d_grad, float* d_eik_out, float* d_surf,
+                     void* stream);
+
 /* device self-test of the deterministic math: op 0 softplus100, 1 expneg, 2 log1p01, 3 sincos (y0=sin, y1=cos),
  * 4 div100 / div_sqrt2 (y0, y1), 5 sqrt / reciprocal (y0, y1). */
 int mvsdf_det_math(int op, const float* x, int n, float* y0, float* y1, void* stream);

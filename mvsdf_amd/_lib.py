@@ -55,7 +55,7 @@ EXPORTS = [
     'mvsdf_version', 'mvsdf_last_error', 'mvsdf_packed_floats', 'mvsdf_fold_pack', 'mvsdf_fold_backward', 'mvsdf_fold_pack_net', 'mvsdf_fold_backward_net',
     'mvsdf_sdf_col0', 'mvsdf_camera_rays', 'mvsdf_sphere_intersection', 'mvsdf_trace_workspace_bytes', 'mvsdf_trace_workspace_bytes_n', 'mvsdf_trace', 'mvsdf_trace_stage', 'mvsdf_det_math',
     'mvsdf_sdf_ctx_floats', 'mvsdf_sdf_forward', 'mvsdf_sdf_bwd_ws_floats', 'mvsdf_sdf_backward',
-    'mvsdf_feat_corr', 'mvsdf_depth_carve',
+    'mvsdf_feat_corr', 'mvsdf_depth_carve', 'mvsdf_loss_terms',
     'mvsdf_render_ctx_floats', 'mvsdf_render_bwd_ws_floats', 'mvsdf_render_forward', 'mvsdf_render_backward',
 ]
 

@@ -228,7 +228,117 @@ __global__ void k_carve(CarveArgs a) {
     a.weight[i] = fw * nw * (scene_valid ? 1.f : 0.f);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The elementwise terms of IDRLoss.forward (model/loss.py:21-35, 58-61, 167-174, 206-210) in ONE single-workgroup launch:
+// rgb L1, eikonal, weighted depth L1, surface BCE-with-logits, the feature-loss sum and the weighted total -- plus the
+// unit gradients of each term w.r.t. its network input, so that backward is four scalings.  Reductions are LDS trees in a fixed
+// order (deterministic).  ~20 k elements at 2048 rays: one workgroup is enough and keeps it to a single launch.
+struct LossArgs {
+    const float* rgb; const float* rgb_gt; const uint8_t* rgb_mask; int R;          // rgb_values[R][3], gt[R][3], mask[R]
+    const float* grad_theta; int n_eik;                                              // [n_eik][3]
+    const float* eik_out; const float* dist_r; const float* dweight; int n_depth;    // [n_depth]
+    const float* surf; int n_surf; const long long* n_pos;                           // logits[n_surf], targets = (i < *n_pos)
+    const float* feat_pp; int n_feat;                                                // per-point feature-loss terms (may be null)
+    float w_rgb, w_eik, w_surf, w_feat, w_depth; int surf_on, feat_on;
+    float* out;                                                                      // [6]: loss, rgb, eikonal, depth, feat, surf
+    float* d_rgb; float* d_grad; float* d_eik_out; float* d_surf;                    // unit gradients (same shapes as the inputs)
+};
+
+__device__ float block_sum_1024(float v, float* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
+    __shared__ float red[1024];
+    const int tid = threadIdx.x;
+    // rgb: L1Loss(reduction='sum')(rgb[mask], gt[mask]) / R                                      loss.py:21-28
+    float s = 0.f;
+    const float invR = 1.0f / (float)a.R;
+    for (int i = tid; i < a.R * 3; i += 1024) {
+        const bool m = a.rgb_mask[i / 3] != 0;
+        const float df = a.rgb[i] - a.rgb_gt[i];
+        if (m) s += fabsf(df);
+        a.d_rgb[i] = m ? (df > 0.f ? invR : (df < 0.f ? -invR : 0.f)) : 0.f;
+    }
+    const float rgb_loss = block_sum_1024(s, red) * invR;
+    // eikonal: mean((||g|| - 1)^2)                                                               loss.py:30-35
+    s = 0.f;
+    const float invE = a.n_eik > 0 ? 1.0f / (float)a.n_eik : 0.f;
+    for (int i = tid; i < a.n_eik; i += 1024) {
+        const float gx = a.grad_theta[3 * i], gy = a.grad_theta[3 * i + 1], gz = a.grad_theta[3 * i + 2];
+        const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+        const float e = nrm - 1.0f;
+        s += e * e;
+        const float k = nrm > 0.f ? 2.0f * e / nrm * invE : 0.f;
+        a.d_grad[3 * i] = k * gx; a.d_grad[3 * i + 1] = k * gy; a.d_grad[3 * i + 2] = k * gz;
+    }
+    const float eik_loss = block_sum_1024(s, red) * invE;
+    // depth: mean(|eikonal_output + dist_r| * weight)                                            loss.py:58-61
+    s = 0.f;
+    const float invD = a.n_depth > 0 ? 1.0f / (float)a.n_depth : 0.f;
+    for (int i = tid; i < a.n_depth; i += 1024) {
+        const float df = a.eik_out[i] + a.dist_r[i], wgt = a.dweight[i];
+        s += fabsf(df) * wgt;
+        a.d_eik_out[i] = (df > 0.f ? wgt : (df < 0.f ? -wgt : 0.f)) * invD;
+    }
+    const float depth_loss = block_sum_1024(s, red) * invD;
+    // surface indicator: BCEWithLogits(mean) against [1]*n_pos + [0]*rest                        loss.py:167-174
+    s = 0.f;
+    float surf_loss = 0.f;
+    if (a.surf_on) {
+        const long long npos = *a.n_pos;
+        const float invS = a.n_surf > 0 ? 1.0f / (float)a.n_surf : 0.f;
+        for (int i = tid; i < a.n_surf; i += 1024) {
+            const float x = a.surf[i], t = (long long)i < npos ? 1.0f : 0.0f;
+            s += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+            a.d_surf[i] = (1.0f / (1.0f + expf(-x)) - t) * invS;
+        }
+        surf_loss = block_sum_1024(s, red) * invS;
+    } else {
+        for (int i = tid; i < a.n_surf; i += 1024) a.d_surf[i] = 0.f;
+    }
+    // feature consistency: sum of the per-point terms of k_feat_corr
+    s = 0.f;
+    float feat_loss = 0.f;
+    if (a.feat_on && a.feat_pp) {
+        for (int i = tid; i < a.n_feat; i += 1024) s += a.feat_pp[i];
+        feat_loss = block_sum_1024(s, red);
+    }
+    if (tid == 0) {
+        a.out[1] = rgb_loss; a.out[2] = eik_loss; a.out[3] = depth_loss; a.out[4] = feat_loss; a.out[5] = surf_loss;
+        a.out[0] = rgb_loss * a.w_rgb + eik_loss * a.w_eik + surf_loss * a.w_surf + feat_loss * a.w_feat + depth_loss * a.w_depth;   // loss.py:206-210
+    }
+}
+
 extern "C" {
+
+/* IDRLoss.forward's elementwise terms + weighted total (loss.py:21-35, 58-61, 167-174, 206-210) and their unit gradients.
+ * out[6] = {loss, rgb_loss, eikonal_loss, depth_loss, feat_loss, surf_loss}. */
+int mvsdf_loss_terms(const float* rgb, const float* rgb_gt, const uint8_t* rgb_mask, int R, const float* grad_theta, int n_eik,
+                     const float* eik_out, const float* dist_r, const float* dweight, int n_depth, const float* surf, int n_surf,
+                     const long long* n_pos, const float* feat_pp, int n_feat, float w_rgb, float w_eik, float w_surf, float w_feat,
+                     float w_depth, int surf_on, int feat_on, float* out, float* d_rgb, float* d_grad, float* d_eik_out, float* d_surf,
+                     void* stream) {
+    if (!rgb || !rgb_gt || !rgb_mask || R <= 0 || !out || !d_rgb || (n_eik > 0 && (!grad_theta || !d_grad)) ||
+        (n_depth > 0 && (!eik_out || !dist_r || !dweight || !d_eik_out)) || (n_surf > 0 && (!surf || !d_surf || !n_pos)))
+        return mv_fail(-1, "mvsdf_loss_terms: bad arguments");
+    LossArgs a;
+    a.rgb = rgb; a.rgb_gt = rgb_gt; a.rgb_mask = rgb_mask; a.R = R; a.grad_theta = grad_theta; a.n_eik = n_eik;
+    a.eik_out = eik_out; a.dist_r = dist_r; a.dweight = dweight; a.n_depth = n_depth; a.surf = surf; a.n_surf = n_surf; a.n_pos = n_pos;
+    a.feat_pp = feat_pp; a.n_feat = n_feat; a.w_rgb = w_rgb; a.w_eik = w_eik; a.w_surf = w_surf; a.w_feat = w_feat; a.w_depth = w_depth;
+    a.surf_on = surf_on; a.feat_on = feat_on; a.out = out; a.d_rgb = d_rgb; a.d_grad = d_grad; a.d_eik_out = d_eik_out; a.d_surf = d_surf;
+    hipLaunchKernelGGL(k_loss_terms, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    return mv_check(hipGetLastError(), "mvsdf_loss_terms");
+}
 
 /* IDRLoss.get_feat_loss_corr (loss.py:115-165) forward + analytic d/d(points) in one launch.
  * pts[N][3]: diff_surf_pts (hit points, view-major); view_start[B+1] (device int32): prefix sums of per-view hit counts.

@@ -208,3 +208,55 @@ class _FeatCorr(torch.autograd.Function):
 
 def feat_corr_loss(pts, view_start, feat, feat_src, cam, src_cams, size, center):
     return _FeatCorr.apply(pts, view_start, feat, feat_src, cam, src_cams, size, center)
+
+
+class _FeatCorrPP(torch.autograd.Function):
+    """Per-point terms of the feature-consistency loss (their sum is the loss); backward scales the stored analytic gradient."""
+
+    @staticmethod
+    def forward(ctx, pts, view_start, feat, feat_src, cam, src_cams, size, center):
+        loss_pp, dpts = ops.feat_corr(pts.detach(), view_start, feat, feat_src, cam, src_cams, size, center)
+        ctx.save_for_backward(dpts)
+        return loss_pp
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpts,) = ctx.saved_tensors
+        return dpts * g.unsqueeze(-1), None, None, None, None, None, None, None
+
+
+class _LossTerms(torch.autograd.Function):
+    """rgb L1 + eikonal + depth L1 + surface BCE + feature sum + weighted total in one launch (loss.py:176-219).
+    Returns the 6-vector [loss, rgb, eikonal, depth, feat, surf]; backward = the stored unit gradients times
+    (d/d loss * weight + d/d term)."""
+
+    @staticmethod
+    def forward(ctx, rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r, dweight, n_pos, weights, surf_on, feat_on):
+        out, d_rgb, d_grad, d_eo, d_sf = ops.loss_terms(rgb.detach(), rgb_gt, rgb_mask, grad_theta.detach() if grad_theta is not None else None,
+                                                        eik_out.detach(), dist_r, dweight, surf.detach() if surf is not None else None, n_pos,
+                                                        feat_pp.detach() if feat_pp is not None else None, weights, surf_on, feat_on)
+        ctx.saved = (d_rgb, d_grad, d_eo, d_sf)
+        ctx.weights, ctx.shapes = weights, (eik_out.shape, feat_pp.shape if feat_pp is not None else None)
+        ctx.on = (surf_on, feat_on)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d_rgb, d_grad, d_eo, d_sf = ctx.saved
+        w = ctx.weights
+        c_rgb, c_eik, c_depth = g[0] * w[0] + g[1], g[0] * w[1] + g[2], g[0] * w[4] + g[3]
+        c_surf, c_feat = g[0] * w[2] + g[5], g[0] * w[3] + g[4]
+        g_rgb = d_rgb * c_rgb
+        g_grad = d_grad * c_eik if d_grad is not None else None
+        g_eo = (d_eo * c_depth).view(ctx.shapes[0])
+        g_sf = d_sf * c_surf if (d_sf is not None and ctx.on[0]) else None
+        g_fp = c_feat.expand(ctx.shapes[1]) if (ctx.shapes[1] is not None and ctx.on[1]) else None
+        return g_rgb, g_grad, g_eo, g_sf, g_fp, None, None, None, None, None, None, None, None
+
+
+def feat_corr_terms(pts, view_start, feat, feat_src, cam, src_cams, size, center):
+    return _FeatCorrPP.apply(pts, view_start, feat, feat_src, cam, src_cams, size, center)
+
+
+def loss_terms(rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r, dweight, n_pos, weights, surf_on, feat_on):
+    return _LossTerms.apply(rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r, dweight, n_pos, weights, surf_on, feat_on)

@@ -62,7 +62,18 @@ class IDRLoss(nn.Module):
         gt = (torch.arange(n, device=surf_indicator_output.device) < N).to(surf_indicator_output.dtype)    # [1]*N + [0]*rest
         return F.binary_cross_entropy_with_logits(surf_indicator_output, gt, reduction='mean')
 
+    def _carve(self, eikonal_points_hom, depths, cams, size, center, train_progress):
+        pts = eikonal_points_hom.detach()[0, :, :3, 0]
+        B = depths.shape[0]
+        dist_r, weight = ops.depth_carve(pts, depths.reshape(B, depths.shape[-2], depths.shape[-1]), cams.reshape(B, 2, 4, 4), size, center,
+                                         conf.out_thresh_perc, conf.far_thresh, float(conf.far_att(train_progress)), conf.near_thresh,
+                                         float(conf.near_att(train_progress)))
+        eikonal_points_hom.detach()[:, :, :3, 0] = pts / 2 * size.view(1, 1, 1) + center.view(1, 1, 3)      # side effect of loss.py:38,42
+        return dist_r, weight
+
     def forward(self, model_outputs, ground_truth, train_progress, n_img):
+        """Same outputs as the reference (loss.py:176-219).  The feature term and the depth-carving target are HIP kernels; the
+        remaining elementwise terms and the weighted sum are ONE more launch (csrc/loss_kernels.hip::k_loss_terms)."""
         dev = model_outputs['rgb_values'].device
         rgb_gt = ground_truth['rgb'].to(dev)
         network_object_mask = model_outputs['network_object_mask']
@@ -70,29 +81,26 @@ class IDRLoss(nn.Module):
 
         ground_truth['size'] = ground_truth['size'][:1]                            # side effects kept (loss.py:181-182)
         ground_truth['center'] = ground_truth['center'][:1]
+        if conf.smooth(train_progress) is not None or conf.use_invalid or not conf.enable_rgb:
+            raise NotImplementedError('smooth / use_invalid / enable_rgb=False are off in the reference conf (model/conf.py:17-25)')
 
-        if conf.enable_rgb:
-            rgb_loss = self.get_rgb_loss(model_outputs['rgb_values'], rgb_gt, network_object_mask, object_mask)
-        else:
-            rgb_loss = torch.zeros(1, device=dev)
-        eikonal_loss = self.get_eikonal_loss(model_outputs['grad_theta'])
-        depth_loss = self.get_depth_loss(model_outputs['eikonal_points_hom'], model_outputs['eikonal_output'], ground_truth['depths'],
-                                         ground_truth['depth_cams'], ground_truth['size'], ground_truth['center'],
-                                         far_thresh=conf.far_thresh, far_att=conf.far_att(train_progress),
-                                         near_thresh=conf.near_thresh, near_att=conf.near_att(train_progress),
-                                         smooth=conf.smooth(train_progress))
-        if conf.phase[0] <= train_progress and conf.enable_feat:
-            feat_loss = self.get_feat_loss_corr(model_outputs['diff_surf_pts'], model_outputs.get('uncerts'),
-                                                *[ground_truth[a] for a in ['feat', 'cam', 'feat_src', 'src_cams', 'size', 'center']],
-                                                network_object_mask, object_mask)
-        else:
-            feat_loss = torch.zeros(1, device=dev)
-        if conf.phase[0] <= train_progress:
-            surf_loss = self.get_surf_loss(model_outputs['surf_indicator_output'], network_object_mask, model_outputs['object_mask_true'])
-        else:
-            surf_loss = torch.zeros(1, device=dev)
-
-        loss = rgb_loss * conf.rgb_weight(train_progress) + eikonal_loss * conf.eikonal_weight + surf_loss * conf.surf_weight + \
-            feat_loss * conf.feat_weight(train_progress) + depth_loss * conf.depth_weight(train_progress)
-        return {'loss': loss, 'rgb_loss': rgb_loss, 'eikonal_loss': eikonal_loss, 'depth_loss': depth_loss, 'feat_loss': feat_loss,
-                'surf_loss': surf_loss}
+        phase1 = conf.phase[0] <= train_progress
+        feat_on = bool(phase1 and conf.enable_feat)
+        feat_pp = None
+        pts = model_outputs['diff_surf_pts']
+        if feat_on and pts.shape[0] > 0:
+            if model_outputs.get('uncerts') is not None:
+                raise NotImplementedError('uncerts is always None in the reference (loss.py:197)')
+            counts = (network_object_mask & object_mask).view(ground_truth['feat'].size()[0], -1).sum(-1)
+            view_start = torch.cat([torch.zeros(1, dtype=counts.dtype, device=dev), counts.cumsum(0)]).to(torch.int32)
+            feat_pp = Fn.feat_corr_terms(pts, view_start, ground_truth['feat'], ground_truth['feat_src'], ground_truth['cam'],
+                                         ground_truth['src_cams'], ground_truth['size'], ground_truth['center'])
+        dist_r, dweight = self._carve(model_outputs['eikonal_points_hom'], ground_truth['depths'], ground_truth['depth_cams'],
+                                      ground_truth['size'], ground_truth['center'], train_progress)
+        n_pos = (network_object_mask & model_outputs['object_mask_true']).sum()
+        weights = (conf.rgb_weight(train_progress), conf.eikonal_weight, conf.surf_weight, conf.feat_weight(train_progress),
+                   conf.depth_weight(train_progress))
+        out = Fn.loss_terms(model_outputs['rgb_values'], model_outputs['grad_theta'], model_outputs['eikonal_output'],
+                            model_outputs['surf_indicator_output'], feat_pp, rgb_gt, network_object_mask & object_mask, dist_r, dweight,
+                            n_pos, weights, bool(phase1), feat_on)
+        return {'loss': out[0], 'rgb_loss': out[1], 'eikonal_loss': out[2], 'depth_loss': out[3], 'feat_loss': out[4], 'surf_loss': out[5]}

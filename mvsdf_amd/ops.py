@@ -273,3 +273,28 @@ def depth_carve(pts, depths, cams, size, center, out_thresh_perc, far_thresh, fa
                                   C.c_float(out_thresh_perc), C.c_float(far_thresh), C.c_float(far_att), C.c_float(near_thresh),
                                   C.c_float(near_att), ptr(dist_r), ptr(weight), stream_of(pts)), 'mvsdf_depth_carve')
     return dist_r, weight
+
+
+def loss_terms(rgb, rgb_gt, rgb_mask, grad_theta, eik_out, dist_r, dweight, surf, n_pos, feat_pp, weights, surf_on, feat_on):
+    """-> (out[6] = loss, rgb, eikonal, depth, feat, surf; d_rgb, d_grad, d_eik_out, d_surf).  One launch."""
+    rgb, rgb_gt = _f32(rgb), _f32(rgb_gt).reshape(-1, 3)
+    dev = rgb.device
+    R = rgb.shape[0]
+    m = rgb_mask.to(torch.uint8).contiguous()
+    gt_ = _f32(grad_theta) if grad_theta is not None and grad_theta.shape[0] > 0 else None
+    eo = _f32(eik_out).reshape(-1)
+    sf = _f32(surf).reshape(-1) if surf is not None else None
+    out = torch.empty(6, dtype=torch.float32, device=dev)
+    d_rgb = torch.empty_like(rgb)
+    d_grad = torch.empty_like(gt_) if gt_ is not None else None
+    d_eo = torch.empty_like(eo)
+    d_sf = torch.empty_like(sf) if sf is not None else None
+    npos = n_pos.to(torch.int64).reshape(1).contiguous() if n_pos is not None else None
+    fp = _f32(feat_pp) if feat_pp is not None else None
+    w = [float(x) for x in weights]
+    check(lib().mvsdf_loss_terms(ptr(rgb), ptr(rgb_gt), ptr(m), R, ptr(gt_), gt_.shape[0] if gt_ is not None else 0, ptr(eo), ptr(_f32(dist_r)),
+                                 ptr(_f32(dweight)), eo.numel(), ptr(sf), sf.numel() if sf is not None else 0, ptr(npos), ptr(fp),
+                                 fp.numel() if fp is not None else 0, C.c_float(w[0]), C.c_float(w[1]), C.c_float(w[2]), C.c_float(w[3]),
+                                 C.c_float(w[4]), 1 if surf_on else 0, 1 if feat_on else 0, ptr(out), ptr(d_rgb), ptr(d_grad), ptr(d_eo),
+                                 ptr(d_sf), stream_of(rgb)), 'mvsdf_loss_terms')
+    return out, d_rgb, d_grad, d_eo, d_sf
