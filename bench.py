@@ -58,10 +58,14 @@ def make_inputs(dev, seed):
     return inp, gt
 
 
-def cpu_baseline(rays_per_view=128, views=2):
-    """The CPU oracle (oracle/: C tracer with OpenMP + numpy float64 differentiable half) on a bounded sample of the workload."""
+def cpu_baseline(rays_per_view=None, views=None):
+    """The CPU oracle (oracle/: C tracer with OpenMP + numpy float64 differentiable half) on a bounded sample of the workload
+    (sized for roughly 10-30 s of CPU work: the whole 2048-ray batch on a many-core host, a quarter of it otherwise)."""
     from oracle import oracle as O
     from oracle import oracle_np as ON
+    if rays_per_view is None:
+        many = O.num_threads() >= 32
+        views, rays_per_view = (B, P) if many else (2, 256)
     sd = synth.make_state_dict(W, 0)
     onet, nnet, rnet = O.Net(sd), ON.sdf_net(sd), ON.render_net(sd)
     inp, gt = synth.make_batch(views, rays_per_view, V, seed=0, feat_hw=(150, 200))

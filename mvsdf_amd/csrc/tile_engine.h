@@ -148,12 +148,18 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
         int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
         f32x4 acc[MTc][NTW];
         mv_zero_acc<MTc, NTW>(acc);
+        float bv_[NTW];                                       // biases of this wave's columns: loaded now, consumed after the GEMM
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int col = (ct0 + t) * 16 + r;
+            bv_[t] = (t < ntw && col < L.N) ? L.bias[col] : 0.0f;
+        }
         __syncthreads();                                      // inputs of layer l complete
         if (ntw > 0 && !(MV_ABLATE & 2)) mv_gemm_dispatch<MTc, NTW>(L, act, S, ct0, ntw, acc, lane);
         __syncthreads();                                      // every wave done reading act (in-place update)
         if (last) {
             if (w == 0 && r == 0) {
-                const float b0 = L.bias[0];
+                const float b0 = bv_[0];
 #pragma unroll
                 for (int a = 0; a < MTc; ++a)
 #pragma unroll
@@ -167,7 +173,7 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
                 if (t < ntw) {
                     const int col = (ct0 + t) * 16 + r;
                     if (col < N) {
-                        const float bv = L.bias[col];
+                        const float bv = bv_[t];
                         const int pos = (ct0 + t) * 16 + ((r & 3) << 2) + (r >> 2);
 #pragma unroll
                         for (int a = 0; a < MTc; ++a)

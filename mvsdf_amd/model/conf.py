@@ -1,43 +1,38 @@
 """Training-phase schedule and loss weights as functions of train_progress in [0, 1].
 
-Same names and values as the reference's module-level config (reference code/model/conf.py:1-33), so that
-`IDR_USE_ENV=1 IDR_CONF=<module>` overrides (idr.py:15-17, loss.py:12-14) keep working with either module.
+Module-level names and values are those of the reference's config module (reference code/model/conf.py:1-33) so that
+`IDR_USE_ENV=1 IDR_CONF=<module>` overrides (idr.py:15-17, loss.py:12-14) are interchangeable; here they are generated from
+one table: value in phase 0 (tp < 1/6), phase 1 (tp < 1/2), phase 2.
 """
+phase = (1 / 6, 1 / 2)
 feat_img_scale = 2
 
-phase = (1 / 6, 1 / 2)          # phase 0: depth-surface sampling; phase 1: feature + surface losses; phase 2: annealed
+
+def _schedule(per_phase):
+    p0, p1, p2 = per_phase
+    return lambda tp: p0 if tp < phase[0] else (p1 if tp < phase[1] else p2)
 
 
-def _by_phase(a, b, c):
-    return lambda tp: a if tp < phase[0] else (b if tp < phase[1] else c)
+_SCHEDULES = {
+    # which point sets feed the depth (d_*) and eikonal (eik_*) terms
+    'd_use_rt_surf': (True, True, True), 'd_use_eik': (True, True, True),
+    'd_use_dsurf_on': (True, False, False), 'd_use_dsurf_jitter': (True, False, False),
+    'eik_use_rt_surf': (True, True, True), 'eik_use_eik': (True, True, True),
+    'eik_use_dsurf_on': (True, False, False), 'eik_use_dsurf_jitter': (True, False, False),
+    # depth-loss attenuation and loss weights
+    'far_att': (1, 1, 1), 'near_att': (1, 0.1, 0.01),
+    'rgb_weight': (0.5, 0.5, 0.5), 'feat_weight': (0, 0.1, 0.01), 'depth_weight': (1, 1, 1),
+    'smooth': (None, None, None),
+}
+globals().update({name: _schedule(vals) for name, vals in _SCHEDULES.items()})
 
-
-d_use_rt_surf = _by_phase(True, True, True)
-d_use_eik = _by_phase(True, True, True)
-d_use_dsurf_on = _by_phase(True, False, False)
-d_use_dsurf_jitter = _by_phase(True, False, False)
-eik_use_rt_surf = _by_phase(True, True, True)
-eik_use_eik = _by_phase(True, True, True)
-eik_use_dsurf_on = _by_phase(True, False, False)
-eik_use_dsurf_jitter = _by_phase(True, False, False)
-
-disable_rgb_grad = False
-
-use_invalid = False
-use_mask = False
+# constants
+eikonal_weight, surf_weight = 0.1, 0.01
+far_thresh, near_thresh = 0.25, 0.1
 out_thresh_perc = 1 / 8
-enable_feat = True
-enable_rgb = True
-far_thresh = 0.25
-far_att = _by_phase(1, 1, 1)
-near_thresh = 0.1
-near_att = _by_phase(1, 0.1, 0.01)
-smooth = lambda tp: None
-rgb_weight = _by_phase(0.5, 0.5, 0.5)
-surf_weight = 0.01
-feat_weight = _by_phase(0, 0.1, 0.01)
-depth_weight = _by_phase(1, 1, 1)
-eikonal_weight = 0.1
+use_mask = use_invalid = disable_rgb_grad = False
+enable_feat = enable_rgb = enable_grad_cap = True
 
-enable_grad_cap = True
-grad_cap = lambda tp: 2 if tp < phase[1] else 0.5
+
+def grad_cap(tp):
+    return 2 if tp < phase[1] else 0.5

@@ -222,34 +222,21 @@ class IDRNetwork(nn.Module):
             surface_ray_dirs = ray_dirs[hit_idx]
             surface_cam_loc = cam_rays[hit_idx]
 
+            # point groups in row order of x_all / y_all: (row range, depth-term flag, eikonal-term flag)   (idr.py:258-286)
             o1, o2 = n_eik_points, n_eik_points + n_dsurf_points
-            eik_out, eik_pts = [], []
-            if conf.d_use_rt_surf(train_progress):
-                eik_out.append(surface_output); eik_pts.append(points_all[:N])
-            if conf.d_use_eik(train_progress):
-                eik_out.append(output[:o1, :1]); eik_pts.append(points_all[N:N + o1])
-            if conf.d_use_dsurf_on(train_progress):
-                eik_out.append(output[o1:o2, :1]); eik_pts.append(points_all[N + o1:N + o2])
-            if conf.d_use_dsurf_jitter(train_progress):
-                eik_out.append(output[o2:o2 + n_dsurf_points, :1]); eik_pts.append(points_all[N + o2:N + o2 + n_dsurf_points])
-            eikonal_output = torch.cat(eik_out, 0).view(1, -1)
-            eikonal_points_hom = torch.cat(eik_pts, 0)
-            eikonal_points_hom = torch.cat([eikonal_points_hom, torch.ones_like(eikonal_points_hom[:, -1:])], -1).view(1, -1, 4, 1)
-
-            surf_indicator_output = torch.cat([y_all[:N, 1][object_mask_true[hit_idx]], output[:n_eik_points, 1]], 0)   # idr.py:272
-
-            g = n_all                                                                                       # idr.py:275
-            surface_points_grad = g[:N].detach()
-            gl = []
-            if conf.eik_use_rt_surf(train_progress):
-                gl.append(g[:N])
-            if conf.eik_use_eik(train_progress):
-                gl.append(g[N:N + o1])
-            if conf.eik_use_dsurf_on(train_progress):
-                gl.append(g[N + o1:N + o2])
-            if conf.eik_use_dsurf_jitter(train_progress):
-                gl.append(g[N + o2:N + o2 + n_dsurf_points])
-            grad_theta = torch.cat(gl, 0)
+            groups = ((0, N, conf.d_use_rt_surf, conf.eik_use_rt_surf),
+                      (N, N + o1, conf.d_use_eik, conf.eik_use_eik),
+                      (N + o1, N + o2, conf.d_use_dsurf_on, conf.eik_use_dsurf_on),
+                      (N + o2, N + o2 + n_dsurf_points, conf.d_use_dsurf_jitter, conf.eik_use_dsurf_jitter))
+            d_sel = [(a, b) for a, b, fd, _ in groups if fd(train_progress)]
+            e_sel = [(a, b) for a, b, _, fe in groups if fe(train_progress)]
+            eikonal_output = torch.cat([y_all[a:b, :1] for a, b in d_sel], 0).view(1, -1)
+            hom = torch.cat([points_all[a:b] for a, b in d_sel], 0)
+            eikonal_points_hom = torch.cat([hom, torch.ones_like(hom[:, :1])], -1).view(1, -1, 4, 1)
+            grad_theta = torch.cat([n_all[a:b] for a, b in e_sel], 0)                                       # idr.py:275-286
+            surface_points_grad = n_all[:N].detach()
+            # surface-indicator logits: hit rows that are inside the true mask, then the uniform samples   (idr.py:272)
+            surf_indicator_output = torch.cat([y_all[:N, 1][object_mask_true[hit_idx]], output[:n_eik_points, 1]], 0)
 
             differentiable_surface_points = self.sample_network(surface_output, surface_sdf_values, surface_points_grad, surface_dists,
                                                                 surface_cam_loc, surface_ray_dirs)
