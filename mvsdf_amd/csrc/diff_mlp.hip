@@ -313,6 +313,21 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         }
     }
     // ---- E.2: adjoint of the value chain (descending) ----
+    static int fuse_env = -1;
+    if (fuse_env < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_env = e ? atoi(e) : 1; }
+    const bool wide = mv_wide(net);
+    if (fuse_env && !wide) {                                    // all layers in one launch, the running adjoint stays in LDS
+        ChainArgs c;
+        memset(&c, 0, sizeof(c));
+        c.net = net; c.netT = netT; c.S = S; c.M = Mb; c.row_ld0 = lo.ld0;
+        c.dy = dy; c.ld_dy = net.L[nl - 1].N;
+        for (int l = 0; l < nl - 1; ++l) { c.Z[l] = Zof(l); c.ZB2[l] = dn ? ws + bl.ZB2[l] : nullptr; c.ZB[l] = ws + bl.ZB[l]; }
+        c.H0B = ws + bl.H0B;
+        constexpr int MTC = 1, NWC = 8;
+        const size_t lds = (size_t)16 * MTC * (S + lo.d0) * sizeof(float);
+        hipLaunchKernelGGL((k_chain_e2<MTC, 2, NWC>), dim3((Mb + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, c);
+        MV_TRY(hipGetLastError());
+    } else {
     int cur = 0;
     {
         LayerArgs a = base_args(netT.L[nl - 1], S, Mb);
@@ -341,6 +356,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         }
         MV_TRY((launch_layer<PRO_ZBAR, EPI_SPLIT>(a, s)));
         cur ^= 1;
+    }
     }
     // ---- weight / bias gradients: W_l = zbar_l^T a_l (+ s_l^T vbar_l), one launch per layer ----
     size_t woff = 0, boff = 0;

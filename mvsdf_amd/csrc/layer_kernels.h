@@ -315,3 +315,96 @@ __global__ void k_colsum(const float* __restrict__ X, int ld, int M, int n, int 
     __syncthreads();
     if (g == 0 && c < n) part[(size_t)ch * n + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused chains: all layers of one backward chain in ONE launch, the running activation tile never leaves LDS.
+// 16*MT rows per workgroup, NW waves.  Same arithmetic as the per-layer kernels (k_layer) they replace.
+struct ChainArgs {
+    MvNet net;                 // packs of W_l   (E.1)
+    MvNet netT;                // packs of W_l^T (E.2)
+    int S, M, row_ld0;         // LDS stride; rows; padded PE row length (ld0)
+    const float* dy; int ld_dy;                // E.2: upstream of the outputs [M][Nout]
+    const float* Z[MV_MAXL]; const float* U[MV_MAXL];       // forward context (already offset to the first row): Z_l [M][N_l], u_l [M][N_{l-1}]
+    const float* w_last_row0;                  // u_L = W_L[0, :]
+    const float* ZB2[MV_MAXL];                 // E.1 -> E.2: second-order terms [M][N_l] (null: none)
+    float* ZB[MV_MAXL];                        // E.2 out: zbar_l [M][N_l]
+    float* H0B;                                // E.2 out: adjoint of the PE input [M][ld0]
+    const float* VB0;                          // E.1 in: gbar_0 [M][ld0]
+    float* VB[MV_MAXL];                        // E.1 out: vbar_l [M][K_l] (l >= 1)
+    float* ZB2o[MV_MAXL];                      // E.1 out
+};
+
+// E.2 (descending): hb_L = dy W_L;  for l = L-1..0: zb_l = sigma_l . hb_{l+1} + zb2_l (stored), ab_l = zb_l W_l, split at the skip layer.
+template <int MT, int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_chain_e2(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * MT, NTH = 64 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers, sk = a.net.skip_layer, d0 = 3 + 6 * a.net.multires;
+    float* act = smem;
+    float* pe_adj = smem + ROWS * S;                             // [ROWS][d0]: PE adjoint contributed by the skip layer, added at l = 0
+    for (int i = tid; i < ROWS * d0; i += NTH) pe_adj[i] = 0.0f;
+    for (int l = nl - 1; l >= 0; --l) {
+        const MvLayer& L = a.netT.L[l];                          // contraction over out_l (K), produces in_l columns (N)
+        const int K = L.K, Kp = L.KB * 16, N = L.N;
+        // ---- prologue: build the A tile (zbar_l, or dy for the last layer) in LDS
+        for (int base = 0; base < ROWS * Kp; base += NTH * 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NTH + tid;
+                const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
+                v[u] = 0.0f;
+                if (idx < ROWS * Kp && row < a.M && k < K) {
+                    if (l == nl - 1) v[u] = a.dy[(size_t)row * a.ld_dy + k];
+                    else {
+                        float zb = dm_sigmoid100(a.Z[l][(size_t)row * K + k]) * act[rr * S + mv_perm(k)];
+                        if (a.ZB2[l]) zb += a.ZB2[l][(size_t)row * K + k];
+                        a.ZB[l][(size_t)row * K + k] = zb;
+                        v[u] = zb;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NTH + tid;
+                const int rr = idx / Kp, k = idx - rr * Kp;
+                if (idx < ROWS * Kp) act[rr * S + mv_perm(k)] = v[u];
+            }
+        }
+        __syncthreads();
+        // ---- GEMM
+        const int NT = L.NT, per = (NT + NW - 1) / NW, ct0 = w * per;
+        int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
+        f32x4 acc[MT][NTW];
+        mv_zero_acc<MT, NTW>(acc);
+        if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
+        __syncthreads();
+        // ---- epilogue: hb for the next (lower) layer stays in LDS; PE adjoint goes to global
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            if (t < ntw) {
+                const int col = (ct0 + t) * 16 + r;
+                if (col < N) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int rr = m * 16 + 4 * q + i, row = row0 + rr;
+                            float v = acc[m][t][i];
+                            if (l == sk) {
+                                v = dm_div_sqrt2(v);
+                                if (col < N - d0) act[rr * S + mv_perm(col)] = v;
+                                else pe_adj[rr * d0 + (col - (N - d0))] = v;
+                            } else if (l == 0) {
+                                if (row < a.M) a.H0B[(size_t)row * a.row_ld0 + col] = pe_adj[rr * d0 + col] + v;
+                            } else {
+                                act[rr * S + mv_perm(col)] = v;
+                            }
+                        }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
