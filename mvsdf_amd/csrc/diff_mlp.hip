@@ -301,6 +301,24 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         hipLaunchKernelGGL(k_pe_normal_bwd, dim3((Mb * (3 * net.multires + 1) + 255) / 256), dim3(256), 0, s, H0, lo.ld0, dn, Mb,
                            net.multires, ws + bl.VB[0], lo.ld0, sk > 0 ? ws + bl.VB[sk] : nullptr, sk > 0 ? net.L[sk].K : 0,
                            sk > 0 ? net.L[sk].K - lo.d0 : 0);
+        static int fuse1_env = -1;
+        if (fuse1_env < 0) { const char* e = getenv("MVSDF_FUSE"); fuse1_env = e ? atoi(e) : 1; }
+        if (fuse1_env && !mv_wide(net)) {                        // the whole ascending chain in one launch
+            ChainArgs c;
+            memset(&c, 0, sizeof(c));
+            c.net = net; c.netT = netT; c.S = S; c.M = Mb; c.row_ld0 = lo.ld0;
+            c.VB0 = ws + bl.VB[0]; c.w_last_row0 = w8;
+            for (int l = 0; l < nl - 1; ++l) {
+                c.Z[l] = Zof(l);
+                if (l + 1 < nl - 1) c.U[l + 1] = Uof(l + 1);
+                c.VB[l + 1] = ws + bl.VB[l + 1];
+                c.ZB2o[l] = ws + bl.ZB2[l];
+            }
+            constexpr int MTC = 1, NWC = 8;
+            const size_t lds = (size_t)16 * MTC * (S + lo.d0) * sizeof(float);
+            hipLaunchKernelGGL((k_chain_e1<MTC, 2, NWC>), dim3((Mb + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, c);
+            MV_TRY(hipGetLastError());
+        } else
         for (int l = 0; l < nl - 1; ++l) {
             LayerArgs a = base_args(net.L[l], S, Mb);
             a.A = ws + bl.VB[l]; a.lda = ldA(l);

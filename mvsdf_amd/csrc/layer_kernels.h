@@ -408,3 +408,87 @@ __global__ __launch_bounds__(64 * NW) void k_chain_e2(ChainArgs a) {
         __syncthreads();
     }
 }
+
+// E.1 (ascending): vbar_0 = gbar_0;  for l = 0..L-2: sbar_l = vbar_l W_l^T;  vbar_{l+1} = sigma_l . sbar_l (stored; /sqrt2 + PE tail at the
+// skip layer);  zb2_l = u_{l+1} . sbar_l . sigma'_l (stored).
+template <int MT, int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_chain_e1(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * MT, NTH = 64 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers, sk = a.net.skip_layer, d0 = 3 + 6 * a.net.multires;
+    float* act = smem;
+    float* g0s = smem + ROWS * S;                                // [ROWS][d0]: gbar_0, re-enters at the skip layer
+    {
+        const int Kp0 = a.net.L[0].KB * 16;
+        for (int idx = tid; idx < ROWS * Kp0; idx += NTH) {
+            const int rr = idx / Kp0, k = idx - rr * Kp0, row = row0 + rr;
+            const float v = (row < a.M && k < d0) ? a.VB0[(size_t)row * a.row_ld0 + k] : 0.0f;
+            act[rr * S + mv_perm(k)] = v;
+            if (k < d0) g0s[rr * d0 + k] = v;
+        }
+    }
+    for (int l = 0; l < nl - 1; ++l) {
+        const MvLayer& L = a.net.L[l];
+        const int N = L.N;
+        const bool top = (l == nl - 2), to_skip = (l + 1 == sk);
+        const int NT = L.NT, per = (NT + NW - 1) / NW, ct0 = w * per;
+        int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
+        f32x4 acc[MT][NTW];
+        mv_zero_acc<MT, NTW>(acc);
+        __syncthreads();
+        if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
+        __syncthreads();
+        const int ldn = a.net.L[l + 1].K;                        // row length of vbar_{l+1}
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            if (t < ntw) {
+                const int col = (ct0 + t) * 16 + r;
+                if (col < N) {
+                    float zz[MT][4], uu[MT][4];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = row0 + m * 16 + 4 * q + i;
+                            zz[m][i] = 0.f; uu[m][i] = 0.f;
+                            if (row < a.M) {
+                                zz[m][i] = a.Z[l][(size_t)row * N + col];
+                                uu[m][i] = top ? a.w_last_row0[col] : a.U[l + 1][(size_t)row * N + col];
+                            }
+                        }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int rr = m * 16 + 4 * q + i, row = row0 + rr;
+                            const float sb = acc[m][t][i];
+                            const float sig = dm_sigmoid100(zz[m][i]);
+                            float ub = sig * sb;
+                            if (to_skip) ub = dm_div_sqrt2(ub);
+                            act[rr * S + mv_perm(col)] = ub;
+                            if (row < a.M) {
+                                a.VB[l + 1][(size_t)row * ldn + col] = ub;
+                                a.ZB2o[l][(size_t)row * N + col] = uu[m][i] * sb * mv_sigmoid_prime100(zz[m][i], sig);
+                            }
+                        }
+                }
+            }
+        }
+        if (l + 1 < nl - 1 || true) {
+            const int Kn = a.net.L[l + 1].K, Kpn = a.net.L[l + 1].KB * 16;
+            if (to_skip)
+                for (int idx = tid; idx < ROWS * d0; idx += NTH) {
+                    const int rr = idx / d0, j = idx - rr * d0;
+                    act[rr * S + mv_perm(N + j)] = dm_div_sqrt2(g0s[rr * d0 + j]);
+                }
+            if (Kpn > Kn) {
+                const int pad = Kpn - Kn;
+                for (int idx = tid; idx < ROWS * pad; idx += NTH) {
+                    const int rr = idx / pad, j = idx - rr * pad;
+                    act[rr * S + mv_perm(Kn + j)] = 0.0f;
+                }
+            }
+        }
+    }
+}
