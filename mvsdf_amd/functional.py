@@ -260,3 +260,101 @@ def feat_corr_terms(pts, view_start, feat, feat_src, cam, src_cams, size, center
 
 def loss_terms(rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r, dweight, n_pos, weights, surf_on, feat_on):
     return _LossTerms.apply(rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r, dweight, n_pos, weights, surf_on, feat_on)
+
+
+class StepState:
+    """Everything the fused training step needs besides the (folded) parameters."""
+    __slots__ = ('net', 'rnet', 'x_eval', 'y_eval', 'n_eval', 'saved', 'R', 'E', 'N', 'hit_idx', 'inv', 'dists', 'cam_rays', 'ray_dirs',
+                 'true_idx', 'n_eik', 'd_ranges', 'e_ranges', 'detach_geo', 'multires_view', 'rsaved')
+
+
+class _IdrStep(torch.autograd.Function):
+    """Post-trace half of IDRNetwork.forward in training mode as ONE autograd node (idr.py:202-304): from the fused value + normal
+    evaluation `state.y_eval / n_eval` (rows [samples | rays, hit first]) it produces diff_surf_pts, rgb_values, grad_theta,
+    eikonal_output, surf_indicator_output; backward chains the rendering-net backward, the input adjoint at the surface points,
+    SampleNetwork's scalar and a single first/second-order SDF backward -- no autograd glue in between."""
+
+    @staticmethod
+    def forward(ctx, st, *params):
+        R, E, N = st.R, st.E, st.N
+        dev = st.x_eval.device
+        y_hit, n_hit = st.y_eval[E:E + N], st.n_eval[E:E + N]
+        x_hit = st.x_eval[E:E + N]
+        view = -st.ray_dirs[st.hit_idx]
+        rgb_values = torch.ones(R, 3, dtype=torch.float32, device=dev)
+        st.rsaved = None
+        if N > 0:
+            rgb_hit, st.rsaved = ops.render_forward(st.rnet, x_hit, view, n_hit, y_hit[:, 2:], st.multires_view)
+            rgb_values[st.hit_idx] = rgb_hit
+        # logical row order of the reference: [hit | samples]
+        def rows(a, b, t_hit, t_smp):
+            return t_hit[a:b] if b <= N else t_smp[a - N:b - N]
+        y_smp, n_smp = st.y_eval[:E], st.n_eval[:E]
+        eik_out = torch.cat([rows(a, b, y_hit, y_smp)[:, :1] for a, b in st.d_ranges], 0).view(1, -1)
+        grad_theta = torch.cat([rows(a, b, n_hit, n_smp) for a, b in st.e_ranges], 0)
+        surf = torch.cat([y_hit[:, 1][st.true_idx], y_smp[:st.n_eik, 1]], 0)
+        diff_pts = x_hit.clone()
+        ctx.st = st
+        return diff_pts, rgb_values, grad_theta, eik_out, surf
+
+    @staticmethod
+    def backward(ctx, d_diff, d_rgbv, d_gth, d_eo, d_si):
+        st = ctx.st
+        R, E, N = st.R, st.E, st.N
+        dev = st.x_eval.device
+        net, rnet = st.net, st.rnet
+        M = R + E
+        Nout = net.layers[-1].N
+        Mb = E + N
+        dy = torch.zeros(Mb, Nout, dtype=torch.float32, device=dev)
+        dn = torch.zeros(Mb, 3, dtype=torch.float32, device=dev)
+        dWr = dbr = None
+        if N > 0:
+            xbar = d_diff.clone() if d_diff is not None else torch.zeros(N, 3, dtype=torch.float32, device=dev)
+            if d_rgbv is not None and st.rsaved is not None:
+                dWr, dbr, din = ops.render_backward(rnet, N, d_rgbv[st.hit_idx].contiguous(), st.rsaved)
+                dv = 3 + 6 * st.multires_view
+                dy[E:, 2:] = din[:, 6 + dv:]                                       # features always carry the rgb gradient (idr.py:329-336)
+                dn_hit = None
+                if not st.detach_geo:
+                    xbar += din[:, 0:3]
+                    dn_hit = din[:, 3 + dv:6 + dv].contiguous()
+                # adjoint of the surface points through features (+ normals): input adjoint only, rows [E, E+N)
+                _, _, dx = ops.sdf_backward(net, st.x_eval, M, M, N, dy[E:], dn_hit, st.saved, True, want_dw=False, row0=E)
+                xbar += dx
+                if dn_hit is not None:
+                    dn[E:] += dn_hit
+            # SampleNetwork (sample_network.py:10-20): x = c + (t - (f - f0)/(grad f0 . v)) v  =>  fbar = -(xbar . v)/(grad f0 . v)
+            v = st.ray_dirs[st.hit_idx]
+            dot = (st.n_eval[E:E + N] * v).sum(-1)
+            dy[E:, 0] += -(xbar * v).sum(-1) / dot
+        # value heads: eikonal_output (col 0), surf_indicator_output (col 1); normals: grad_theta
+        def add_rows(target, col, a, b, src):
+            if b <= N:
+                if col is None: target[E + a:E + b] += src
+                else: target[E + a:E + b, col] += src
+            else:
+                if col is None: target[a - N:b - N] += src
+                else: target[a - N:b - N, col] += src
+        if d_eo is not None:
+            flat, o = d_eo.reshape(-1), 0
+            for a, b in st.d_ranges:
+                add_rows(dy, 0, a, b, flat[o:o + (b - a)]); o += b - a
+        if d_gth is not None:
+            o = 0
+            for a, b in st.e_ranges:
+                add_rows(dn, None, a, b, d_gth[o:o + (b - a)]); o += b - a
+        if d_si is not None:
+            k = st.true_idx.shape[0]
+            if k > 0:
+                dy[E:, 1].index_add_(0, st.true_idx, d_si[:k])
+            dy[:st.n_eik, 1] += d_si[k:]
+        dWs, dbs, _ = ops.sdf_backward(net, st.x_eval, M, M, Mb, dy, dn, st.saved, False)
+        if dWr is None:
+            dWr = [torch.zeros_like(L.w) for L in rnet.layers]
+            dbr = [torch.zeros_like(L.bias) for L in rnet.layers]
+        return (None,) + tuple(dWs) + tuple(dbs) + tuple(dWr) + tuple(dbr)
+
+
+def idr_step(state, ws, bs, rws, rbs):
+    return _IdrStep.apply(state, *ws, *bs, *rws, *rbs)

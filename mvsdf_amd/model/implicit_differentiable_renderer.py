@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import ops
 from ..utils import rend_util
 from . import conf as _default_conf
 from .ray_tracing import NativeSDF, RayTracing
@@ -204,42 +205,30 @@ class IDRNetwork(nn.Module):
             # rows [sample points | all rays, hit ones first]; normals on every row (those of non-hit rays are never read).
             # Rows that receive gradients form the prefix [0, E + N): the backward skips the non-hit rays.
             x_eval = torch.cat([eikonal_points, dsurf_on_sample, dsurf_jitter_sample, pts_sorted], 0)
-            y_eval, n_eval, shared = Fn.sdf_value_normal(net, ws, bs, x_eval, R + E)
+            y_eval, n_eval, saved = ops.sdf_forward(net, x_eval, R + E)
             N = int(n_hit_dev.item())                            # the one host sync of the forward: output shapes depend on it
-            shared.n_active = E + N
-            row0 = E
-            hit_idx, rest_idx = perm[:N], perm[N:]
-            # logical order of the reference: [hit | samples | non-hit]
-            x_all = torch.cat([x_eval[E:E + N], x_eval[:E], x_eval[E + N:]], 0)
-            y_all = torch.cat([y_eval[E:E + N], y_eval[:E], y_eval[E + N:]], 0)
-            n_all = torch.cat([n_eval[E:E + N], n_eval[:E]], 0)
-            sdf_output = torch.cat([y_all[:N, :1], y_all[N + E:, :1]], 0)[inv]                               # idr.py:202-203, ray order
-            points_all = x_all[:N + E]
-            output = y_all[N:N + E]
-            surface_output = y_all[:N, :1]
-            surface_sdf_values = surface_output.detach()
-            surface_dists = dists[hit_idx].unsqueeze(-1)
-            surface_ray_dirs = ray_dirs[hit_idx]
-            surface_cam_loc = cam_rays[hit_idx]
-
-            # point groups in row order of x_all / y_all: (row range, depth-term flag, eikonal-term flag)   (idr.py:258-286)
+            hit_idx = perm[:N]
+            st = Fn.StepState()
+            st.net, st.x_eval, st.y_eval, st.n_eval, st.saved = net, x_eval, y_eval, n_eval, saved
+            st.R, st.E, st.N, st.hit_idx, st.ray_dirs, st.n_eik = R, E, N, hit_idx, ray_dirs, n_eik_points
+            st.true_idx = torch.nonzero(object_mask_true[hit_idx]).flatten()                                  # idr.py:272 (second sync)
+            # point groups in the reference's row order [hit | samples]: (row range, depth-term flag, eikonal-term flag)   idr.py:258-286
             o1, o2 = n_eik_points, n_eik_points + n_dsurf_points
             groups = ((0, N, conf.d_use_rt_surf, conf.eik_use_rt_surf),
                       (N, N + o1, conf.d_use_eik, conf.eik_use_eik),
                       (N + o1, N + o2, conf.d_use_dsurf_on, conf.eik_use_dsurf_on),
                       (N + o2, N + o2 + n_dsurf_points, conf.d_use_dsurf_jitter, conf.eik_use_dsurf_jitter))
-            d_sel = [(a, b) for a, b, fd, _ in groups if fd(train_progress)]
-            e_sel = [(a, b) for a, b, _, fe in groups if fe(train_progress)]
-            eikonal_output = torch.cat([y_all[a:b, :1] for a, b in d_sel], 0).view(1, -1)
-            hom = torch.cat([points_all[a:b] for a, b in d_sel], 0)
+            st.d_ranges = [(a, b) for a, b, fd, _ in groups if fd(train_progress) and b > a]
+            st.e_ranges = [(a, b) for a, b, _, fe in groups if fe(train_progress) and b > a]
+            st.detach_geo = bool(train_progress < conf.phase[0] or conf.disable_rgb_grad)                     # idr.py:331-334
+            rnet, rws, rbs = self.rendering_network.fold()
+            st.rnet, st.multires_view = rnet, self.rendering_network.multires_view
+            differentiable_surface_points, rgb_values, grad_theta, eikonal_output, surf_indicator_output = Fn.idr_step(st, ws, bs, rws, rbs)
+            y_rays = y_eval[E:, :1]                              # rays in sorted order -> ray order (no gradient: the loss never reads it)
+            sdf_output = y_rays[inv]
+            hom = torch.cat([(x_eval[E + a:E + b] if b <= N else x_eval[a - N:b - N]) for a, b in st.d_ranges], 0)
             eikonal_points_hom = torch.cat([hom, torch.ones_like(hom[:, :1])], -1).view(1, -1, 4, 1)
-            grad_theta = torch.cat([n_all[a:b] for a, b in e_sel], 0)                                       # idr.py:275-286
-            surface_points_grad = n_all[:N].detach()
-            # surface-indicator logits: hit rows that are inside the true mask, then the uniform samples   (idr.py:272)
-            surf_indicator_output = torch.cat([y_all[:N, 1][object_mask_true[hit_idx]], output[:n_eik_points, 1]], 0)
-
-            differentiable_surface_points = self.sample_network(surface_output, surface_sdf_values, surface_points_grad, surface_dists,
-                                                                surface_cam_loc, surface_ray_dirs)
+            x_all, shared, row0 = x_eval, None, E
         else:
             y_all, n_all, shared = Fn.sdf_value_normal(net, ws, bs, pts_sorted, R)
             N = int(n_hit_dev.item())
@@ -250,11 +239,12 @@ class IDRNetwork(nn.Module):
             differentiable_surface_points = x_all[:N]
             grad_theta = None
 
-        view = -ray_dirs[hit_idx]
-        rgb_values = torch.ones_like(points)
-        if N > 0:
-            rgb = self._rgb_from_shared(shared, ws, bs, differentiable_surface_points, view, N, train_progress, row0)
-            rgb_values = rgb_values.index_put((hit_idx,), rgb)                                               # idr.py:302-304
+        if not self.training:
+            view = -ray_dirs[hit_idx]
+            rgb_values = torch.ones_like(points)
+            if N > 0:
+                rgb = self._rgb_from_shared(shared, ws, bs, differentiable_surface_points, view, N, train_progress, row0)
+                rgb_values = rgb_values.index_put((hit_idx,), rgb)                                           # idr.py:302-304
 
         out = {
             'points': points,
