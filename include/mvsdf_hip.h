@@ -69,8 +69,12 @@ int mvsdf_fold_pack(const float* v, const float* g, int N, int K, float* w, floa
  * pointers; wp[l] / wpT[l] may be NULL. */
 int mvsdf_fold_pack_net(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w,
                         float* const* wp, float* const* wpT, void* stream);
-int mvsdf_fold_backward_net(int n_layers, const float* const* v, const float* const* g, const float* const* dW, const int* N, const int* K,
-                            float* const* dv, float* const* dg, void* stream);
+/* backward of every fold in one launch.  db / dbias (both NULL or both given; entries may be NULL pairwise) route the bias
+ * gradients db[l][N_l] to dbias[l] in the same launch; accumulate != 0 adds into dv / dg / dbias (the targets may be the
+ * parameters' .grad buffers: what autograd's AccumulateGrad would do with ~3 launches per layer). */
+int mvsdf_fold_backward_net(int n_layers, const float* const* v, const float* const* g, const float* const* dW, const float* const* db,
+                            const int* N, const int* K, float* const* dv, float* const* dg, float* const* dbias, int accumulate,
+                            void* stream);
 /* backward of the fold: dW[N][K] -> dv[N][K], dg[N]    */
 int mvsdf_fold_backward(const float* v, const float* g, const float* dW, int N, int K, float* dv, float* dg, void* stream);
 

@@ -46,7 +46,9 @@ struct FoldNetArgs {
     int n_layers;
     const float* v[MV_MAXL]; const float* g[MV_MAXL]; const float* dW[MV_MAXL];
     float* w[MV_MAXL]; float* wp[MV_MAXL]; float* wpT[MV_MAXL]; float* dv[MV_MAXL]; float* dg[MV_MAXL];
+    const float* db[MV_MAXL]; float* dbias[MV_MAXL];      // backward only: bias gradients routed to their sink (optional)
     int N[MV_MAXL], K[MV_MAXL];
+    int accumulate;                                       // backward only: add into dv / dg / dbias instead of overwriting
 };
 
 __global__ __launch_bounds__(256) void k_fold_net(FoldNetArgs a) {
@@ -100,8 +102,15 @@ __global__ void k_fold_bwd_net(FoldNetArgs a) {
     const float inv = 1.0f / sqrtf(ss);
     const float dgj = dot * inv, s = a.g[l][j] * inv;
     float* dvr = a.dv[l] + (size_t)j * K;
-    for (int k = lane; k < K; k += 64) dvr[k] = s * (dr[k] - dgj * vr[k] * inv);
-    if (lane == 0) a.dg[l][j] = dgj;
+    const bool acc = a.accumulate != 0;
+    for (int k = lane; k < K; k += 64) {
+        const float t = s * (dr[k] - dgj * vr[k] * inv);
+        dvr[k] = acc ? dvr[k] + t : t;
+    }
+    if (lane == 0) {
+        a.dg[l][j] = acc ? a.dg[l][j] + dgj : dgj;
+        if (a.db[l]) a.dbias[l][j] = acc ? a.dbias[l][j] + a.db[l][j] : a.db[l][j];
+    }
 }
 
 // backward of the fold: one wave per row.
@@ -298,16 +307,22 @@ int mvsdf_fold_pack_net(int n_layers, const float* const* v, const float* const*
     return mv_check(hipGetLastError(), "mvsdf_fold_pack_net");
 }
 
-int mvsdf_fold_backward_net(int n_layers, const float* const* v, const float* const* g, const float* const* dW, const int* N, const int* K,
-                            float* const* dv, float* const* dg, void* stream) {
+int mvsdf_fold_backward_net(int n_layers, const float* const* v, const float* const* g, const float* const* dW, const float* const* db,
+                            const int* N, const int* K, float* const* dv, float* const* dg, float* const* dbias, int accumulate,
+                            void* stream) {
     FoldNetArgs a;
     int maxN; size_t maxTot;
     int rc = fill_fold_args(a, n_layers, N, K, &maxN, &maxTot);
     if (rc) return rc;
-    if (!v || !g || !dW || !dv || !dg) return mv_fail(-1, "mvsdf_fold_backward_net: null argument");
+    if (!v || !g || !dW || !dv || !dg || ((db == nullptr) != (dbias == nullptr))) return mv_fail(-1, "mvsdf_fold_backward_net: null argument");
+    a.accumulate = accumulate;
     for (int l = 0; l < n_layers; ++l) {
         if (!v[l] || !g[l] || !dW[l] || !dv[l] || !dg[l]) return mv_fail(-1, "mvsdf_fold_backward_net: null layer pointer");
         a.v[l] = v[l]; a.g[l] = g[l]; a.dW[l] = dW[l]; a.dv[l] = dv[l]; a.dg[l] = dg[l];
+        if (db) {
+            if ((db[l] == nullptr) != (dbias[l] == nullptr)) return mv_fail(-1, "mvsdf_fold_backward_net: db / dbias must pair up");
+            a.db[l] = db[l]; a.dbias[l] = dbias[l];
+        }
     }
     hipLaunchKernelGGL(k_fold_bwd_net, dim3((maxN + 3) / 4, n_layers), dim3(256), 0, (hipStream_t)stream, a);
     return mv_check(hipGetLastError(), "mvsdf_fold_backward_net");

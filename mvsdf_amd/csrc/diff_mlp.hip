@@ -154,6 +154,16 @@ struct SdfBwdLayout {
     int nchunks, chunk;
     size_t maxnk;
 };
+static size_t wgrad_net_slab_floats(const MvNet& net, int nchunks) {
+    size_t t = 0;
+    for (int l = 0; l < net.n_layers; ++l) t += (size_t)nchunks * net.L[l].N * net.L[l].K;
+    return t;
+}
+static size_t wgrad_net_bslab_floats(const MvNet& net, int nchunks) {
+    size_t t = 0;
+    for (int l = 0; l < net.n_layers; ++l) t += (size_t)nchunks * net.L[l].N;
+    return t;
+}
 static SdfBwdLayout sdf_bwd_layout(const MvNet& net, int Mb) {
     SdfBwdLayout o;
     memset(&o, 0, sizeof(o));
@@ -172,9 +182,9 @@ static SdfBwdLayout sdf_bwd_layout(const MvNet& net, int Mb) {
     if (o.nchunks < 1) o.nchunks = 1;
     o.maxnk = 0;
     for (int l = 0; l < nl; ++l) { const size_t nk = (size_t)net.L[l].N * net.L[l].K; o.maxnk = nk > o.maxnk ? nk : o.maxnk; }
-    o.slabA = p; p += (size_t)2 * o.nchunks * o.maxnk;           // both pairs' chunks in one slab array
-    o.slabB = p;                                                  // (unused; kept for layout stability)
-    o.bslab = p; p += (size_t)o.nchunks * (maxw + 16);
+    o.slabA = p; p += wgrad_net_slab_floats(net, o.nchunks);     // one slab per (layer, chunk)
+    o.slabB = p; p += (size_t)o.nchunks * maxw;                   // column sums of ubar_last (E.1 end)
+    o.bslab = p; p += wgrad_net_bslab_floats(net, o.nchunks);
     o.total = p;
     return o;
 }
@@ -195,6 +205,28 @@ static hipError_t launch_wgrad(const float* P1, int ldp1, const float* Q1, int l
 static hipError_t launch_reduce(const float* sa, int nchunks, size_t n, float* out, int accumulate, hipStream_t s) {
     const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, s, sa, (const float*)nullptr, nchunks, n, out, accumulate);
+    return hipGetLastError();
+}
+
+// all layers' weight / bias gradients: one k_wgrad_net launch + one k_reduce_net launch.  a.L[*].{P1,Q1,P2,Q2,ld*,No,Ki} filled by the caller.
+static hipError_t launch_wgrad_net(WgradNetArgs& a, hipStream_t s) {
+    int blk = 0;
+    size_t so = 0, bo = 0, wo = 0, b2 = 0;
+    for (int l = 0; l < a.n_layers; ++l) {
+        WgradLayer& L = a.L[l];
+        L.nbx = (L.Ki + 63) / 64; L.nby = (L.No + 63) / 64;
+        L.blk0 = blk; blk += L.nbx * L.nby * a.nchunks;
+        L.slab_off = (unsigned)so; so += (size_t)a.nchunks * L.No * L.Ki;
+        L.bslab_off = (unsigned)bo; bo += (size_t)a.nchunks * L.No;
+        L.woff = (unsigned)wo; wo += (size_t)L.No * L.Ki;
+        L.boff = (unsigned)b2; b2 += L.No;
+    }
+    if (so >= 0xffffffffull) return hipErrorInvalidValue;
+    a.wtotal = (unsigned)wo; a.btotal = (unsigned)b2;
+    hipLaunchKernelGGL(k_wgrad_net, dim3(blk), dim3(MV_THREADS), 0, s, a);
+    const unsigned total = a.wtotal + a.btotal;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_reduce_net, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -376,23 +408,27 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         cur ^= 1;
     }
     }
-    // ---- weight / bias gradients: W_l = zbar_l^T a_l (+ s_l^T vbar_l), one launch per layer ----
-    size_t woff = 0, boff = 0;
-    for (int l = 0; l < nl && dW_cat; ++l) {                                      // dW_cat == NULL: input adjoint only
-        const int No = net.L[l].N, Ki = net.L[l].K;
-        const bool last = (l == nl - 1);
-        const float* P = last ? dy : ws + bl.ZB[l];
-        const bool two = dn && !last;
-        int nch = 0;
-        MV_TRY(launch_wgrad(P, No, Aof(l), ldA(l), Mb, two ? Sof(l) : nullptr, No, two ? ws + bl.VB[l] : nullptr, ldA(l), Mb, No, Ki,
-                            bl.chunk, ws + bl.slabA, ws + bl.bslab, &nch, s));
-        MV_TRY(launch_reduce(ws + bl.slabA, nch, (size_t)No * Ki, dW_cat + woff, 0, s));
-        MV_TRY(launch_reduce(ws + bl.bslab, bl.nchunks, (size_t)No, db_cat + boff, 0, s));
-        if (last && dn) {                                                          // W_last[0, :] += sum_rows ubar_last   (E.1 end)
-            hipLaunchKernelGGL(k_colsum, dim3((Ki + 63) / 64, bl.nchunks), dim3(256), 0, s, ws + bl.VB[l], Ki, Mb, Ki, bl.chunk, ws + bl.slabA);
-            MV_TRY(launch_reduce(ws + bl.slabA, bl.nchunks, (size_t)Ki, dW_cat + woff, 1, s));
+    // ---- weight / bias gradients: W_l = zbar_l^T a_l (+ s_l^T vbar_l), every layer in one launch + one reduction ----
+    if (dW_cat) {                                                                  // dW_cat == NULL: input adjoint only
+        WgradNetArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.n_layers = nl; wa.M = Mb; wa.chunk = bl.chunk; wa.nchunks = bl.nchunks;
+        for (int l = 0; l < nl; ++l) {
+            WgradLayer& L = wa.L[l];
+            const bool last = (l == nl - 1);
+            L.No = net.L[l].N; L.Ki = net.L[l].K;
+            L.P1 = last ? dy : ws + bl.ZB[l]; L.ldp1 = L.No;
+            L.Q1 = Aof(l); L.ldq1 = ldA(l);
+            if (dn && !last) { L.P2 = Sof(l); L.ldp2 = L.No; L.Q2 = ws + bl.VB[l]; L.ldq2 = ldA(l); }
         }
-        woff += (size_t)No * Ki; boff += No;
+        wa.slab = ws + bl.slabA; wa.bslab = ws + bl.bslab;
+        wa.dW = dW_cat; wa.db = db_cat;
+        if (dn) {                                                                  // W_last[0, :] += sum_rows ubar_last   (E.1 end)
+            const int Ki = net.L[nl - 1].K;
+            hipLaunchKernelGGL(k_colsum, dim3((Ki + 63) / 64, bl.nchunks), dim3(256), 0, s, ws + bl.VB[nl - 1], Ki, Mb, Ki, bl.chunk, ws + bl.slabB);
+            wa.colslab = ws + bl.slabB; wa.col_n = Ki;
+        }
+        MV_TRY(launch_wgrad_net(wa, s));
     }
     // ---- E.3: input adjoint ----
     if (dx)
@@ -427,8 +463,8 @@ static RenderBwdLayout render_bwd_layout(const MvNet& net, int N) {
         maxw = net.L[l].N > maxw ? net.L[l].N : maxw;
     }
     o.chunk = 128; o.nchunks = (N + 127) / 128; if (o.nchunks < 1) o.nchunks = 1;
-    o.slab = p; p += (size_t)o.nchunks * maxnk;
-    o.bslab = p; p += (size_t)o.nchunks * (maxw + 16);
+    o.slab = p; p += wgrad_net_slab_floats(net, o.nchunks);
+    o.bslab = p; p += wgrad_net_bslab_floats(net, o.nchunks);
     o.total = p;
     return o;
 }
@@ -521,15 +557,18 @@ int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, 
             if (last) MV_TRY((launch_layer<PRO_TANH_BWD, EPI_SPLIT>(a, s))); else MV_TRY((launch_layer<PRO_PLAIN, EPI_SPLIT>(a, s)));
         }
     }
-    size_t woff = 0, boff = 0;
+    WgradNetArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.n_layers = nl; wa.M = N; wa.chunk = bl.chunk; wa.nchunks = bl.nchunks;
     for (int l = 0; l < nl; ++l) {
-        const int No = net.L[l].N, Ki = net.L[l].K;
-        int nch = 0;
-        MV_TRY(launch_wgrad(ws + bl.ZB[l], No, ctx + lo.A[l], Ki, N, nullptr, 0, nullptr, 0, 0, No, Ki, bl.chunk, ws + bl.slab, ws + bl.bslab, &nch, s));
-        MV_TRY(launch_reduce(ws + bl.slab, nch, (size_t)No * Ki, dW_cat + woff, 0, s));
-        MV_TRY(launch_reduce(ws + bl.bslab, bl.nchunks, (size_t)No, db_cat + boff, 0, s));
-        woff += (size_t)No * Ki; boff += No;
+        WgradLayer& L = wa.L[l];
+        L.No = net.L[l].N; L.Ki = net.L[l].K;
+        L.P1 = ws + bl.ZB[l]; L.ldp1 = L.No;
+        L.Q1 = ctx + lo.A[l]; L.ldq1 = L.Ki;
     }
+    wa.slab = ws + bl.slab; wa.bslab = ws + bl.bslab;
+    wa.dW = dW_cat; wa.db = db_cat;
+    MV_TRY(launch_wgrad_net(wa, s));
     return mv_check(hipGetLastError(), "mvsdf_render_backward");
 }
 

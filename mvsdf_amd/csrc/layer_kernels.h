@@ -303,6 +303,108 @@ __global__ void k_reduce_slabs(const float* __restrict__ sa, const float* __rest
     }
 }
 
+// ---- network-wide variants: the weight gradients of EVERY layer in one launch, then one reduction launch ----
+// Workgroup = (layer, 128-row chunk, 64x64 output block); both pairs of a layer (E.2 term zbar^T a and E.1 term s^T vbar) accumulate
+// in the same registers, so a layer needs one slab per chunk.
+struct WgradLayer {
+    const float* P1; const float* Q1; const float* P2; const float* Q2;   // [M, No], [M, Ki]; P2 null: single pair
+    int ldp1, ldq1, ldp2, ldq2;
+    int No, Ki, nbx, nby;
+    int blk0;                      // first workgroup of this layer
+    unsigned slab_off, bslab_off;  // floats, into slab / bslab
+    unsigned woff, boff;           // floats, into dW_cat / db_cat
+};
+struct WgradNetArgs {
+    int n_layers, M, chunk, nchunks;
+    WgradLayer L[MV_MAXL];
+    float* slab; float* bslab;
+    // reduction
+    const float* colslab; int col_n;           // optional [nchunks][col_n]: added to row 0 of the LAST layer (E.1 end: W_last[0,:] += sum ubar)
+    float* dW; float* db; unsigned wtotal, btotal;
+};
+
+__global__ __launch_bounds__(MV_THREADS) void k_wgrad_net(WgradNetArgs a) {
+    constexpr int LD = 80;
+    __shared__ __attribute__((aligned(16))) float Pt[64 * LD];
+    __shared__ __attribute__((aligned(16))) float Qt[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+    int l = 0;
+    while (l + 1 < a.n_layers && (int)blockIdx.x >= a.L[l + 1].blk0) ++l;
+    const WgradLayer& L = a.L[l];
+    const int local = blockIdx.x - L.blk0, nb = L.nbx * L.nby;
+    const int ch = local / nb, rem = local - ch * nb, by = rem / L.nbx, bx = rem - by * L.nbx;
+    const int i0 = bx * 64, o0 = by * 64, No = L.No, Ki = L.Ki;
+    const int rbeg = ch * a.chunk, rend = min(a.M, rbeg + a.chunk);
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    const bool do_bias = bx == 0;
+    const int npairs = L.P2 ? 2 : 1;
+    for (int pair = 0; pair < npairs; ++pair) {
+        const float* P = pair ? L.P2 : L.P1;
+        const float* Q = pair ? L.Q2 : L.Q1;
+        const int ldp = pair ? L.ldp2 : L.ldp1, ldq = pair ? L.ldq2 : L.ldq1;
+        for (int rb = rbeg; rb < rend; rb += 64) {
+            __syncthreads();
+            wg_stage(P, ldp, rb, rend, o0, No, Pt, LD, tid);
+            wg_stage(Q, ldq, rb, rend, i0, Ki, Qt, LD, tid);
+            __syncthreads();
+            if (do_bias && pair == 0 && tid < 64) {
+                for (int rr = 0; rr < 64; ++rr) bsum += Pt[rr * LD + tid];
+            }
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+                const float av = Pt[(4 * s + q) * LD + 16 * w + r];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Qt[(4 * s + q) * LD + 16 * t + r], acc[t], 0, 0, 0);
+            }
+        }
+    }
+    float* slab = a.slab + L.slab_off + (size_t)ch * No * Ki;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = i0 + 16 * t + r;
+        if (i < Ki) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int o = o0 + 16 * w + 4 * q + e;
+                if (o < No) slab[(size_t)o * Ki + i] = acc[t][e];
+            }
+        }
+    }
+    if (do_bias && tid < 64 && o0 + tid < No) a.bslab[L.bslab_off + (size_t)ch * No + o0 + tid] = bsum;
+}
+
+// dW_cat / db_cat = sum over chunks of the slabs, fixed order (deterministic)
+__global__ void k_reduce_net(WgradNetArgs a) {
+    const unsigned total = a.wtotal + a.btotal;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const bool isb = i >= a.wtotal;
+        const unsigned k = isb ? i - a.wtotal : i;
+        int l = 0;
+        if (isb) { while (l + 1 < a.n_layers && k >= a.L[l + 1].boff) ++l; }
+        else { while (l + 1 < a.n_layers && k >= a.L[l + 1].woff) ++l; }
+        const WgradLayer& L = a.L[l];
+        float v = 0.0f;
+        if (isb) {
+            const unsigned j = k - L.boff;
+            const float* sp = a.bslab + L.bslab_off + j;
+            for (int c = 0; c < a.nchunks; ++c) v += sp[(size_t)c * L.No];
+            a.db[k] = v;
+        } else {
+            const unsigned j = k - L.woff;
+            const size_t nk = (size_t)L.No * L.Ki;
+            const float* sp = a.slab + L.slab_off + j;
+            for (int c = 0; c < a.nchunks; ++c) v += sp[(size_t)c * nk];
+            if (a.colslab && l == a.n_layers - 1 && j < (unsigned)a.col_n)
+                for (int c = 0; c < a.nchunks; ++c) v += a.colslab[(size_t)c * a.col_n + j];
+            a.dW[k] = v;
+        }
+    }
+}
+
 // part[chunk][c] = sum over the chunk's rows of X[row][c]   (then k_reduce_slabs with accumulate)
 __global__ void k_colsum(const float* __restrict__ X, int ld, int M, int n, int chunk, float* __restrict__ part) {
     __shared__ float red[4][64];

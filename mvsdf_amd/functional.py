@@ -24,38 +24,48 @@ class _Fold(torch.autograd.Function):
 
 
 class _FoldNet(torch.autograd.Function):
-    """weight_norm of a whole network in one C call (one fold launch + one pack launch): (*weight_v, *weight_g) -> *W."""
+    """weight_norm of a whole network in one C call (one fold launch + one pack launch): (*weight_v, *weight_g, *bias) -> (*W, *bias).
+    Biases pass through so that the backward sees every gradient of the network: when the parameters carry the `_mv_grad_sink`
+    mark (set by parallel.FlatGradBucket: their .grad buffers are persistent views of one flat buffer) the single backward launch
+    ADDS dv, dg and db straight into those buffers and returns no gradients -- the work of ~3 AccumulateGrad launches per layer."""
 
     @staticmethod
-    def forward(ctx, holders, *vg):
-        n = len(vg) // 2
-        vs, gs = [t.detach() for t in vg[:n]], [t.detach() for t in vg[n:]]
+    def forward(ctx, holders, *vgb):
+        n = len(vgb) // 3
+        vs, gs = [t.detach() for t in vgb[:n]], [t.detach() for t in vgb[n:2 * n]]
         ws, wps, wpTs = ops.fold_pack_net(vs, gs)
         for L, w, wp, wpT in zip(holders, ws, wps, wpTs):
             L.w, L.wp, L.wpT = w, wp, wpT
-        ctx.save_for_backward(*vg)
-        return tuple(ws)
+        ctx.params = vgb
+        ctx.n = n
+        return tuple(ws) + tuple(b.view_as(b) for b in vgb[2 * n:])
 
     @staticmethod
-    def backward(ctx, *dWs):
-        vg = ctx.saved_tensors
-        n = len(vg) // 2
-        vs, gs = [t.detach() for t in vg[:n]], [t.detach() for t in vg[n:]]
-        dWs = [d.contiguous() if d is not None else torch.zeros_like(v) for d, v in zip(dWs, vs)]
-        dvs, dgs = ops.fold_backward_net(vs, gs, dWs)
-        return (None,) + tuple(dvs) + tuple(dg.view_as(g) for dg, g in zip(dgs, vg[n:]))
+    def backward(ctx, *grads):
+        n, vgb = ctx.n, ctx.params
+        vs, gs, bs = vgb[:n], vgb[n:2 * n], vgb[2 * n:]
+        dWs = [d.contiguous() if d is not None else torch.zeros_like(v) for d, v in zip(grads[:n], vs)]
+        dbs = [d.contiguous() if d is not None else torch.zeros_like(b) for d, b in zip(grads[n:], bs)]
+        vd, gd = [t.detach() for t in vs], [t.detach() for t in gs]
+        direct = all(getattr(p, '_mv_grad_sink', False) and p.grad is not None and p.grad.is_contiguous() and p.requires_grad for p in vgb)
+        if direct:
+            ops.fold_backward_net(vd, gd, dWs, dbs, sinks=([p.grad for p in vs], [p.grad for p in gs], [p.grad for p in bs]))
+            return (None,) * (1 + 3 * n)
+        dvs, dgs = ops.fold_backward_net(vd, gd, dWs)
+        return (None,) + tuple(dvs) + tuple(dg.view_as(g) for dg, g in zip(dgs, gs)) + tuple(dbs)
 
 
 def fold_network(vs, gs, bs, skip_layer, multires):
-    """-> (PackedNet, [w tensors linked to autograd], [bias params])"""
+    """-> (PackedNet, [w tensors linked to autograd], [biases linked to autograd])"""
     layers = []
     for v, b in zip(vs, bs):
         L = ops.PackedLayer()
         L.bias = b.detach()
         L.N, L.K = v.shape
         layers.append(L)
-    ws = _FoldNet.apply(layers, *vs, *gs)
-    return ops.PackedNet(layers, skip_layer, multires), list(ws), list(bs)
+    n = len(vs)
+    out = _FoldNet.apply(layers, *vs, *gs, *bs)
+    return ops.PackedNet(layers, skip_layer, multires), list(out[:n]), list(out[n:])
 
 
 class SharedSdfEval:

@@ -81,17 +81,27 @@ def fold_pack_net(vs, gs):
     return ws, wps, wpTs
 
 
-def fold_backward_net(vs, gs, dWs):
+def fold_backward_net(vs, gs, dWs, dbs=None, sinks=None):
+    """-> (dvs, dgs).  With `sinks` = (dv_targets, dg_targets, db_targets) the results (and the bias gradients dbs) are ADDED into
+    those tensors instead (the parameters' .grad buffers) and nothing is returned."""
     vs = [_f32(v) for v in vs]
     gs = [_f32(g).reshape(-1) for g in gs]
     dWs = [_f32(d) for d in dWs]
     n = len(vs)
     N = (C.c_int * n)(*[v.shape[0] for v in vs])
     K = (C.c_int * n)(*[v.shape[1] for v in vs])
+    if sinks is not None:
+        tv, tg, tb = sinks
+        for t in list(tv) + list(tg) + list(tb):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        dbs = [_f32(d) for d in dbs]
+        check(lib().mvsdf_fold_backward_net(n, _ptr_array(vs), _ptr_array(gs), _ptr_array(dWs), _ptr_array(dbs), N, K, _ptr_array(tv),
+                                            _ptr_array(tg), _ptr_array(tb), 1, stream_of(vs[0])), 'mvsdf_fold_backward_net')
+        return None
     dvs = [torch.empty_like(v) for v in vs]
     dgs = [torch.empty_like(g) for g in gs]
-    check(lib().mvsdf_fold_backward_net(n, _ptr_array(vs), _ptr_array(gs), _ptr_array(dWs), N, K, _ptr_array(dvs), _ptr_array(dgs),
-                                        stream_of(vs[0])), 'mvsdf_fold_backward_net')
+    check(lib().mvsdf_fold_backward_net(n, _ptr_array(vs), _ptr_array(gs), _ptr_array(dWs), None, N, K, _ptr_array(dvs), _ptr_array(dgs),
+                                        None, 0, stream_of(vs[0])), 'mvsdf_fold_backward_net')
     return dvs, [g.reshape(-1, 1) for g in dgs]
 
 

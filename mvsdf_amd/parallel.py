@@ -20,6 +20,7 @@ class FlatGradBucket:
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)          # autograd accumulates in place into the bucket
+            p._mv_grad_sink = True                              # functional._FoldNet may add into p.grad directly
             off += n
 
     def zero(self):

@@ -94,3 +94,38 @@ def test_eval_mode_and_public_methods():
     assert y.shape == (N, 258) and gr.shape == (N, 1, 3) and x.requires_grad
     rgb2 = model.get_rbg_value(x.detach(), -t(inp['uv']).new_zeros(N, 3) + 0.5, None)
     assert rgb2.shape == (N, 3)
+
+
+def test_grad_bucket_direct_sink_matches_autograd_accumulation():
+    """parallel.FlatGradBucket marks the parameters as gradient sinks: the fold backward then ADDS dv / dg / db into .grad in one
+    launch instead of returning them to autograd.  Same numbers as the plain path, and a second backward accumulates."""
+    from mvsdf_amd.parallel import FlatGradBucket
+    g = golden('idr_w64_tp03')
+    W, B, P, V, seed, tp = int(g['W']), int(g['B']), int(g['P']), int(g['V']), int(g['seed']), float(g['tp'])
+    inp, gt = synth.make_batch(B, P, V, seed=seed, size=float(g['scene_size']), center=tuple(g['scene_center']),
+                               feat_hw=tuple(int(v) for v in g['feat_hw']), focal_scale=float(g['focal_scale']))
+    inp, gt = {k: t(v) for k, v in inp.items()}, {k: t(v) for k, v in gt.items()}
+
+    def run(model, times):
+        for _ in range(times):
+            torch.manual_seed(seed + 5)
+            np.random.seed(seed + 5)
+            out = model(inp, tp)
+            IDRLoss()(out, dict(gt), tp, B)['loss'].backward()
+        return [p.grad.detach().clone() for p in model.parameters()]
+
+    plain, _ = build(W, seed)
+    plain.train()
+    ref1 = run(plain, 1)
+    sink, _ = build(W, seed)
+    sink.train()
+    bucket = FlatGradBucket(sink.parameters())
+    got1 = run(sink, 1)
+    for a, b, (k, _) in zip(got1, ref1, plain.named_parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7 * float(b.abs().max()) + 1e-12), k
+    assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in sink.parameters())        # still views of the bucket
+    got2 = run(sink, 1)                                                                         # no zeroing: accumulates
+    for a, b, (k, _) in zip(got2, ref1, plain.named_parameters()):
+        assert torch.allclose(a, 2 * b, rtol=1e-4, atol=1e-6 * float(b.abs().max()) + 1e-12), k
+    bucket.zero()
+    assert float(bucket.flat.abs().max()) == 0.0

@@ -1,0 +1,40 @@
+"""Host-side time per section of one training step (no extra syncs): where the CPU thread spends its time."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from mvsdf_amd.model.implicit_differentiable_renderer import IDRNetwork
+from mvsdf_amd.model.loss import IDRLoss
+from mvsdf_amd.parallel import FlatGradBucket
+from mvsdf_amd.utils import synth
+from mvsdf_amd.utils.config import ConfigDict
+dev = torch.device('cuda', 0)
+model = IDRNetwork(ConfigDict(synth.model_conf(bench.W)))
+model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(bench.W, 0).items()})
+model = model.to(dev).train()
+loss_fn = IDRLoss(); bucket = FlatGradBucket(model.parameters()); opt = torch.optim.Adam(model.parameters(), lr=0.0, fused=True)
+inp, gt = bench.make_inputs(dev, 0)
+acc = {}
+def tick(name, t0):
+    t = time.perf_counter(); acc[name] = acc.get(name, 0.0) + (t - t0); return t
+_item = torch.Tensor.item
+def timed_item(self):
+    t0 = time.perf_counter(); r = _item(self); acc['  (item wait)'] = acc.get('  (item wait)', 0.0) + time.perf_counter() - t0; return r
+def step():
+    t = time.perf_counter()
+    bucket.zero(); t = tick('zero', t)
+    out = model(inp, bench.TP); t = tick('forward (incl. item wait)', t)
+    lo = loss_fn(out, dict(gt), bench.TP, bench.B); t = tick('loss', t)
+    lo['loss'].backward(); t = tick('backward', t)
+    bucket.all_reduce_mean(); bucket.clip_(2.0); t = tick('allreduce+clip', t)
+    opt.step(); t = tick('adam', t)
+for _ in range(10): step()
+torch.cuda.synchronize(); acc.clear()
+torch.Tensor.item = timed_item
+n = 50
+t0 = time.perf_counter()
+for _ in range(n): step()
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+for k, v in acc.items(): print(f'{k:32s} {v / n * 1e3:7.3f} ms')
+print(f'host loop {(t1 - t0) / n * 1e3:.3f} ms/step, final drain {(t2 - t1) * 1e3:.3f} ms')
