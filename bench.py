@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 from mvsdf_amd.model.implicit_differentiable_renderer import IDRNetwork  # noqa: E402
 from mvsdf_amd.model.loss import IDRLoss  # noqa: E402
-from mvsdf_amd.parallel import FlatGradBucket  # noqa: E402
+from mvsdf_amd.optim import FlatAdam  # noqa: E402
 from mvsdf_amd.utils import synth  # noqa: E402
 from mvsdf_amd.utils.config import ConfigDict  # noqa: E402
 
@@ -120,21 +120,20 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(W, 0).items()})
     model = model.to(dev).train()
     loss_fn = IDRLoss()
-    bucket = FlatGradBucket(model.parameters())
-    # frozen weights (lr = 0): a step on random GT collapses the scene; fused = one multi-tensor kernel
-    opt = torch.optim.Adam(model.parameters(), lr=0.0, fused=os.environ.get('MVSDF_FUSED_ADAM', '1') == '1')
+    # frozen weights (lr = 0): a step on random GT collapses the scene.  Parameters, gradients and Adam moments
+    # live in flat buffers: one memset, one all-reduce, two launches for grad-norm + clip + Adam.
+    opt = FlatAdam(model.parameters(), lr=0.0)
     inp, gt = make_inputs(dev, seed=rank)
     events = []
     model.ray_tracer.events = events
 
     def step():
-        bucket.zero()
+        opt.zero_grad()
         out = model(inp, TP)
         lo = loss_fn(out, dict(gt), TP, B)
         lo['loss'].backward()
-        bucket.all_reduce_mean()
-        bucket.clip_(2.0)                                        # grad-norm + clip (idr_train.py:289-294, conf.grad_cap)
-        opt.step()
+        opt.all_reduce_mean()
+        opt.step(grad_cap=2.0)                                   # grad-norm + clip + Adam (idr_train.py:289-302, conf.grad_cap)
         return lo
 
     torch.manual_seed(rank)

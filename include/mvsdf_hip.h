@@ -159,6 +159,14 @@ int mvsdf_loss_terms(const float* rgb, const float* rgb_gt, const uint8_t* rgb_m
                      float w_depth, int surf_on, int feat_on, float* out, float* d_rgb, float* d_grad, float* d_eik_out, float* d_surf,
                      void* stream);
 
+/* ---- optimiser tail on flat buffers (idr_train.py:289-302: all_norm, clip_grad_norm_(grad_cap), Adam.step), two launches ----
+ * p, g, m, v: flat fp32 buffers of n elements (parameters, gradients, exp_avg, exp_avg_sq).  step >= 1 is the Adam step count AFTER
+ * this update.  max_norm <= 0 disables clipping; otherwise g is scaled in place by min(1, max_norm / (||g|| + 1e-6)).
+ * norm_out (device, 2 floats, may be NULL) receives {||g||, clip coefficient}; ws: mvsdf_adam_ws_floats() floats. */
+size_t mvsdf_adam_ws_floats(void);
+int mvsdf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step, float max_norm,
+                    float* norm_out, float* ws, void* stream);
+
 /* device self-test of the deterministic math: op 0 softplus100, 1 expneg, 2 log1p01, 3 sincos (y0=sin, y1=cos),
  * 4 div100 / div_sqrt2 (y0, y1), 5 sqrt / reciprocal (y0, y1). */
 int mvsdf_det_math(int op, const float* x, int n, float* y0, float* y1, void* stream);

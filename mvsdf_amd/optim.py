@@ -1,0 +1,102 @@
+"""Optimiser tail of the training step on flat buffers.
+
+Reference (code/training/idr_train.py:113,289-302): torch.optim.Adam(model.parameters(), lr) preceded by an all-parameter gradient
+norm and, once train_progress >= phase[0], torch.nn.utils.clip_grad_norm_(model.parameters(), grad_cap).  Here the parameters,
+gradients and both Adam moments each live in ONE flat fp32 buffer (every Parameter / .grad / state tensor is a view into it), so the
+whole tail is two HIP launches (mvsdf_adam_step) and the data-parallel all-reduce needs no packing.
+
+`FlatAdam` is a torch.optim.Optimizer: lr schedulers (MultiStepLR, idr_train.py:119) drive `param_groups[0]['lr']`, and
+state_dict() / load_state_dict() use torch.optim.Adam's layout (per-parameter 'step', 'exp_avg', 'exp_avg_sq'), so the reference's
+OptimizerParameters/*.pth checkpoints (idr_train.py:171-177) load and save unchanged."""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from ._lib import lib, check
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        params = [p for p in params if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        assert len(self.param_groups) == 1, 'FlatAdam keeps one parameter group (the reference has one, idr_train.py:113)'
+        ps = self.param_groups[0]['params']
+        p0 = ps[0]
+        assert all(p.is_cuda and p.dtype == torch.float32 and p.device == p0.device for p in ps), 'fp32 parameters on one GPU expected'
+        total = sum(p.numel() for p in ps)
+        self.flat_p = torch.empty(total, dtype=torch.float32, device=p0.device)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self._ws = torch.empty(lib().mvsdf_adam_ws_floats(), dtype=torch.float32, device=p0.device)
+        self.norm_and_coef = torch.zeros(2, dtype=torch.float32, device=p0.device)     # {||grad||, clip coefficient} of the last step
+        self._t = 0
+        self._slices = []
+        off = 0
+        for p in ps:
+            n = p.numel()
+            self._slices.append((off, n))
+            self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.flat_p[off:off + n].view(p.shape)                             # the Parameter now lives in the flat buffer
+            off += n
+        self._attach_grads()
+        self._attach_state()
+
+    # ---- views
+    def _attach_grads(self):
+        for p, (off, n) in zip(self.param_groups[0]['params'], self._slices):
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                p.grad = self.flat_g[off:off + n].view(p.shape)
+            p._mv_grad_sink = True                                                      # functional._FoldNet adds into p.grad directly
+
+    def _attach_state(self):
+        for p, (off, n) in zip(self.param_groups[0]['params'], self._slices):
+            self.state[p] = {'step': torch.tensor(float(self._t)), 'exp_avg': self.flat_m[off:off + n].view(p.shape),
+                             'exp_avg_sq': self.flat_v[off:off + n].view(p.shape)}
+
+    # ---- the step
+    def zero_grad(self, set_to_none=False):
+        """One memset of the flat gradient buffer; gradients stay attached (views) whatever `set_to_none` says."""
+        self.flat_g.zero_()
+        self._attach_grads()
+
+    def all_reduce_mean(self):
+        """The step's one collective (RCCL over xGMI): gradients averaged over ranks.  No-op without a process group."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+            self.flat_g.div_(dist.get_world_size())
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_cap=None):
+        """grad-norm + optional clip_grad_norm_(grad_cap) + Adam in two launches.  `norm_and_coef` holds the norm afterwards."""
+        assert closure is None
+        g = self.param_groups[0]
+        self._t += 1
+        check(lib().mvsdf_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                                    self.flat_p.numel(), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+                                    self._t, float(grad_cap) if grad_cap else 0.0, self.norm_and_coef.data_ptr(), self._ws.data_ptr(),
+                                    C.c_void_p(torch.cuda.current_stream(self.flat_p.device).cuda_stream)), 'mvsdf_adam_step')
+
+    def grad_norm(self):
+        return self.norm_and_coef[0]
+
+    # ---- torch.optim.Adam checkpoint layout
+    def state_dict(self):
+        for st in self.state.values():
+            st['step'] = torch.tensor(float(self._t))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)                  # leaves fresh (non-view) state tensors behind: copy them into the flat buffers
+        ps = self.param_groups[0]['params']
+        steps = set()
+        for p, (off, n) in zip(ps, self._slices):
+            st = self.state.get(p)
+            if st:
+                self.flat_m[off:off + n].copy_(st['exp_avg'].reshape(-1))
+                self.flat_v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+                steps.add(int(float(st['step'])))
+        assert len(steps) <= 1, 'per-parameter step counts differ'
+        self._t = steps.pop() if steps else 0
+        self._attach_state()

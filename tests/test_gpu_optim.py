@@ -1,0 +1,69 @@
+"""FlatAdam (grad-norm + clip + Adam on flat buffers) vs torch.optim.Adam + clip_grad_norm_ (idr_train.py:113,289-302)."""
+import copy
+
+import pytest
+import torch
+
+from mvsdf_amd.optim import FlatAdam
+
+pytestmark = pytest.mark.gpu
+
+
+def _models():
+    torch.manual_seed(3)
+    a = torch.nn.Sequential(torch.nn.Linear(37, 64), torch.nn.Softplus(beta=100), torch.nn.Linear(64, 5)).cuda()
+    return a, copy.deepcopy(a)
+
+
+@pytest.mark.parametrize('cap', [None, 0.05, 1e6])
+def test_flat_adam_matches_torch_adam(cap):
+    ref, mine = _models()
+    o_ref = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    o_mine = FlatAdam(mine.parameters(), lr=1e-3)
+    s_ref = torch.optim.lr_scheduler.MultiStepLR(o_ref, [3], gamma=0.5)
+    s_mine = torch.optim.lr_scheduler.MultiStepLR(o_mine, [3], gamma=0.5)       # schedulers drive param_groups like any Optimizer
+    x = torch.randn(128, 37, device='cuda')
+    for it in range(6):
+        for m, o in ((ref, o_ref), (mine, o_mine)):
+            o.zero_grad()
+            (m(x) ** 2).mean().backward()
+        norm_ref = torch.cat([p.grad.flatten() for p in ref.parameters()]).norm()
+        if cap:
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), cap)
+        o_ref.step()
+        o_mine.step(grad_cap=cap)
+        assert abs(float(o_mine.grad_norm()) - float(norm_ref)) <= 1e-5 * float(norm_ref)
+        for p, q in zip(ref.parameters(), mine.parameters()):
+            assert torch.allclose(p, q, rtol=0, atol=2e-6), it
+            assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-9)           # clipped gradients are written back
+        s_ref.step(); s_mine.step()
+    assert o_mine.param_groups[0]['lr'] == o_ref.param_groups[0]['lr'] == 5e-4
+
+
+def test_flat_adam_checkpoint_layout_round_trip():
+    ref, mine = _models()
+    o_ref = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    o_mine = FlatAdam(mine.parameters(), lr=1e-3)
+    x = torch.randn(64, 37, device='cuda')
+    for m, o in ((ref, o_ref), (mine, o_mine)):
+        for _ in range(2):
+            o.zero_grad(); (m(x) ** 2).mean().backward(); o.step()
+    sd = o_mine.state_dict()
+    assert sd['state'].keys() == o_ref.state_dict()['state'].keys()
+    assert set(sd['state'][0].keys()) == {'step', 'exp_avg', 'exp_avg_sq'} and float(sd['state'][0]['step']) == 2.0
+    # a torch.optim.Adam checkpoint loads into FlatAdam and continues identically
+    ref2, mine2 = _models()
+    for dst, src in ((ref2, ref), (mine2, ref)):
+        dst.load_state_dict(src.state_dict())
+    o_ref2 = torch.optim.Adam(ref2.parameters(), lr=1e-3)
+    o_mine2 = FlatAdam(mine2.parameters(), lr=1e-3)
+    o_ref2.load_state_dict(o_ref.state_dict())
+    o_mine2.load_state_dict(o_ref.state_dict())
+    for m, o in ((ref2, o_ref2), (mine2, o_mine2)):
+        o.zero_grad(); (m(x) ** 2).mean().backward(); o.step()
+    for p, q in zip(ref2.parameters(), mine2.parameters()):
+        assert torch.allclose(p, q, rtol=0, atol=2e-6)
+    # parameters still live in the flat buffer after load_state_dict of the MODEL
+    mine2.load_state_dict(ref.state_dict())
+    base = o_mine2.flat_p.data_ptr()
+    assert all(base <= p.data_ptr() < base + 4 * o_mine2.flat_p.numel() for p in mine2.parameters())

@@ -6,14 +6,14 @@ sys.path.insert(0, ROOT)
 import bench
 from mvsdf_amd.model.implicit_differentiable_renderer import IDRNetwork
 from mvsdf_amd.model.loss import IDRLoss
-from mvsdf_amd.parallel import FlatGradBucket
+from mvsdf_amd.optim import FlatAdam
 from mvsdf_amd.utils import synth
 from mvsdf_amd.utils.config import ConfigDict
 dev = torch.device('cuda', 0)
 model = IDRNetwork(ConfigDict(synth.model_conf(bench.W)))
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(bench.W, 0).items()})
 model = model.to(dev).train()
-loss_fn = IDRLoss(); bucket = FlatGradBucket(model.parameters()); opt = torch.optim.Adam(model.parameters(), lr=0.0, fused=True)
+loss_fn = IDRLoss(); opt = FlatAdam(model.parameters(), lr=0.0)
 inp, gt = bench.make_inputs(dev, 0)
 acc = {}
 def tick(name, t0):
@@ -23,12 +23,11 @@ def timed_item(self):
     t0 = time.perf_counter(); r = _item(self); acc['  (item wait)'] = acc.get('  (item wait)', 0.0) + time.perf_counter() - t0; return r
 def step():
     t = time.perf_counter()
-    bucket.zero(); t = tick('zero', t)
+    opt.zero_grad(); t = tick('zero', t)
     out = model(inp, bench.TP); t = tick('forward (incl. item wait)', t)
     lo = loss_fn(out, dict(gt), bench.TP, bench.B); t = tick('loss', t)
     lo['loss'].backward(); t = tick('backward', t)
-    bucket.all_reduce_mean(); bucket.clip_(2.0); t = tick('allreduce+clip', t)
-    opt.step(); t = tick('adam', t)
+    opt.all_reduce_mean(); opt.step(grad_cap=2.0); t = tick('allreduce+clip+adam', t)
 for _ in range(10): step()
 torch.cuda.synchronize(); acc.clear()
 torch.Tensor.item = timed_item
