@@ -163,7 +163,7 @@ def main():
         T, N, E = int(cnt[:4].sum()), st['N'], R // 2
         flops_step = T * f_t + ((R + E) + 2 * (N + E)) * f_s + 3 * (N + E) * f_t + 3 * N * f_r
         ms_sphere = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-        ms_samples = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+        ms_samples = float(np.mean([e[1].elapsed_time(e[2]) + e[3].elapsed_time(e[4]) if len(e) == 5 else e[1].elapsed_time(e[2]) for e in events]))
         rows_samples = int(cnt[1] + cnt[2] + cnt[3])
         n_launch = 2                                            # k_ray_samples runs twice per step (sampler rows; secant || min-sdf rows)
         ach = rows_samples * f_t / (ms_samples * 1e-3) / 1e12

@@ -103,8 +103,10 @@ int mvsdf_trace(const MvsdfNetDesc* net, const MvsdfTraceParams* tp, const float
                 const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
                 float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
                 size_t workspace_bytes, int mt, int mt_samples, void* stream);
-/* the two kernel launches of mvsdf_trace separately (stage 1: sphere tracing, zeroes the counters; stage 2: ray sampler +
- * secant + min-sdf), same arguments and workspace -- lets a caller bracket each kernel with events. */
+/* the launches of mvsdf_trace separately, same arguments and workspace.  stage 1: sphere tracing (zeroes the counters);
+ * stage 2: ray sampler + secant + min-sdf; or stage 3: ray sampler rows only -- `mask` is FINAL after it (ray_tracing.py:61) --
+ * followed by stage 4: secant + min-sdf (only points / dists still change, ray_tracing.py:63-96).  Lets a caller bracket each
+ * kernel with events, and fetch the hit count to the host while stage 4 still runs. */
 int mvsdf_trace_stage(int stage, const MvsdfNetDesc* net, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
                       const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
                       float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,

@@ -408,7 +408,8 @@ static hipError_t launch_stage1(const MvNet& net, const MvTraceParams& tp, const
 template <int MT, int NTW, int NW>
 static hipError_t launch_stage2(const MvNet& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, int B, int P, int training,
                                 const float* intervals, const float* steps, float* points, uint8_t* mask, float* dists, float* ws,
-                                unsigned long long* counters, hipStream_t stream) {
+                                unsigned long long* counters, int parts, hipStream_t stream) {
+    // parts bit 0: sampler rows + their reduction (the hit mask is FINAL after it); bit 1: secant + min-sdf rows
     const int R = B * P, ROWS = 16 * MT;
     float* w_zmin = ws;
     float* w_zmax = w_zmin + R;
@@ -430,11 +431,15 @@ static hipError_t launch_stage2(const MvNet& net, const MvTraceParams& tp, const
     c.sec_list = sec_list; c.sv = sv; c.counters = counters;
     // worst-case grids (every ray listed); blocks beyond the device-side counts exit at once
     const int row_blocks = (int)(((long long)R * tp.n_steps + ROWS - 1) / ROWS), sec_blocks = (R + 15) / 16, red_blocks = (R + 63) / 64;
-    hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(row_blocks), dim3(64 * NW), lds2, stream, net, tp, c, w_list, w_list_min, 0, 0);
-    hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list, (int)MV_CNT_N_SAMPLER);
-    hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(sec_blocks + (training ? row_blocks : 0)), dim3(64 * NW), lds2, stream, net, tp, c,
-                       w_list, w_list_min, 1, sec_blocks);
-    if (training) hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list_min, (int)MV_CNT_N_MINSDF);
+    if (parts & 1) {
+        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(row_blocks), dim3(64 * NW), lds2, stream, net, tp, c, w_list, w_list_min, 0, 0);
+        hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list, (int)MV_CNT_N_SAMPLER);
+    }
+    if (parts & 2) {
+        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(sec_blocks + (training ? row_blocks : 0)), dim3(64 * NW), lds2, stream, net, tp, c,
+                           w_list, w_list_min, 1, sec_blocks);
+        if (training) hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list_min, (int)MV_CNT_N_MINSDF);
+    }
     return hipGetLastError();
 }
 
@@ -452,7 +457,7 @@ hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp
     const bool wide = maxnt > 16;
     hipError_t e = hipSuccess;
 #define MV_S1(MT_, NTW_, NW_) e = launch_stage1<MT_, NTW_, NW_>(net, tp, cam_loc, dirs, om, B, P, training, points, mask, dists, ws, counters, stream)
-#define MV_S2(MT_, NTW_, NW_) e = launch_stage2<MT_, NTW_, NW_>(net, tp, cam_loc, dirs, B, P, training, intervals, steps, points, mask, dists, ws, counters, stream)
+#define MV_S2(MT_, NTW_, NW_) e = launch_stage2<MT_, NTW_, NW_>(net, tp, cam_loc, dirs, B, P, training, intervals, steps, points, mask, dists, ws, counters, (stages >> 1) & 3, stream)
     if (stages & 1) {
         if (eight) {
             if (wide) { if (mt1 >= 2) MV_S1(2, 4, 8); else MV_S1(1, 4, 8); }
@@ -463,7 +468,7 @@ hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp
         }
         if (e != hipSuccess) return e;
     }
-    if (stages & 2) {
+    if (stages & 6) {
         if (eight) {
             if (wide) { if (mt2 >= 2) MV_S2(2, 4, 8); else MV_S2(1, 4, 8); }
             else if (mt2 >= 4) MV_S2(4, 2, 8); else if (mt2 >= 2) MV_S2(2, 2, 8); else MV_S2(1, 2, 8);
@@ -513,18 +518,21 @@ int mvsdf_trace(const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const floa
                 const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
                 float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
                 size_t workspace_bytes, int mt, int rpw, void* stream) {
-    return trace_impl(3, desc, tp, cam_loc, ray_dirs, object_mask, B, P, training, intervals, minsdf_steps, points, mask, dists, counters,
+    return trace_impl(7, desc, tp, cam_loc, ray_dirs, object_mask, B, P, training, intervals, minsdf_steps, points, mask, dists, counters,
                       workspace, workspace_bytes, mt, rpw, stream);
 }
 
-/* The two launches of mvsdf_trace separately (same arguments, same workspace): stage 1 = sphere tracing (zeroes the counters),
- * stage 2 = ray sampler + secant + min-sdf.  Lets a caller bracket each kernel with events. */
+/* The launches of mvsdf_trace separately (same arguments, same workspace): stage 1 = sphere tracing (zeroes the counters),
+ * stage 2 = ray sampler + secant + min-sdf; or stage 3 = ray sampler rows only (`mask` is final after it) followed by
+ * stage 4 = secant + min-sdf (only points / dists still change).  Lets a caller bracket each kernel with events and read the
+ * hit count while the last stage still runs. */
 int mvsdf_trace_stage(int stage, const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
                       const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
                       float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
                       size_t workspace_bytes, int mt, int rpw, void* stream) {
-    if (stage != 1 && stage != 2) return mv_fail(-1, "mvsdf_trace_stage: stage must be 1 or 2");
-    return trace_impl(stage, desc, tp, cam_loc, ray_dirs, object_mask, B, P, training, intervals, minsdf_steps, points, mask, dists, counters,
+    if (stage < 1 || stage > 4) return mv_fail(-1, "mvsdf_trace_stage: stage must be 1..4");
+    static const int bits[5] = {0, 1, 6, 2, 4};
+    return trace_impl(bits[stage], desc, tp, cam_loc, ray_dirs, object_mask, B, P, training, intervals, minsdf_steps, points, mask, dists, counters,
                       workspace, workspace_bytes, mt, rpw, stream);
 }
 

@@ -141,6 +141,8 @@ class IDRNetwork(nn.Module):
         self.sample_network = SampleNetwork()
         self.object_bounding_sphere = conf.get_float('ray_tracer.object_bounding_sphere')
         self.last_stats = {}
+        self._counts_host = None                                 # pinned [N hit, N hit & true mask], filled while the tracer still runs
+        self._counts_event = None
 
     # ------------------------------------------------------------------------------------------------------------
     def _dsurf_samples(self, input, n_dsurf_points, bb):
@@ -172,9 +174,23 @@ class IDRNetwork(nn.Module):
         dev = ray_dirs.device
 
         net, ws, bs = self.implicit_network.fold()              # one weight-norm fold per step
+        # The hit mask is final once the ray sampler has run; the secant / min-sdf launch that follows only moves points.  In training
+        # the hit counts are copied to pinned host memory between the two, so the host learns them while that launch (and the fused
+        # evaluation enqueued behind it) still runs.
+        sync = {}
+
+        def on_mask(net_mask):
+            sm = net_mask & object_mask
+            sync['counts'] = torch.stack([sm.sum(), (sm & object_mask_true).sum()])
+            if self._counts_host is None:
+                self._counts_host = torch.empty(2, dtype=torch.int64).pin_memory()
+                self._counts_event = torch.cuda.Event()
+            self._counts_host.copy_(sync['counts'], non_blocking=True)
+            self._counts_event.record()
+
         with torch.no_grad():
             points, network_object_mask, dists = self.ray_tracer(sdf=NativeSDF(net), cam_loc=cam_loc, object_mask=object_mask,
-                                                                 ray_directions=ray_dirs)
+                                                                 ray_directions=ray_dirs, mask_ready=on_mask if self.training else None)
         ray_dirs = ray_dirs.reshape(-1, 3)
 
         surface_mask = (network_object_mask & object_mask) if self.training else network_object_mask
@@ -206,12 +222,15 @@ class IDRNetwork(nn.Module):
             # Rows that receive gradients form the prefix [0, E + N): the backward skips the non-hit rays.
             x_eval = torch.cat([eikonal_points, dsurf_on_sample, dsurf_jitter_sample, pts_sorted], 0)
             y_eval, n_eval, saved = ops.sdf_forward(net, x_eval, R + E)
-            N = int(n_hit_dev.item())                            # the one host sync of the forward: output shapes depend on it
+            # sorted-row indices of the hit rays that are also inside the true object mask (idr.py:272), in ray order, without a sync
+            true_rows = torch.sort((~(surface_mask & object_mask_true))[perm].to(torch.int8), stable=True).indices
+            self._counts_event.synchronize()                     # the one host wait of the forward: output shapes depend on the counts
+            N, n_true = int(self._counts_host[0]), int(self._counts_host[1])
             hit_idx = perm[:N]
             st = Fn.StepState()
             st.net, st.x_eval, st.y_eval, st.n_eval, st.saved = net, x_eval, y_eval, n_eval, saved
             st.R, st.E, st.N, st.hit_idx, st.ray_dirs, st.n_eik = R, E, N, hit_idx, ray_dirs, n_eik_points
-            st.true_idx = torch.nonzero(object_mask_true[hit_idx]).flatten()                                  # idr.py:272 (second sync)
+            st.true_idx = true_rows[:n_true]
             # point groups in the reference's row order [hit | samples]: (row range, depth-term flag, eikonal-term flag)   idr.py:258-286
             o1, o2 = n_eik_points, n_eik_points + n_dsurf_points
             groups = ((0, N, conf.d_use_rt_surf, conf.eik_use_rt_surf),

@@ -43,10 +43,12 @@ class RayTracing(nn.Module):
         return (self.object_bounding_sphere, self.sdf_threshold, self.line_search_step, self.line_step_iters, iters,
                 self.n_steps, self.n_secant_steps, dist_clip)
 
-    def forward(self, sdf, cam_loc, object_mask, ray_directions, minsdf_steps=None):
+    def forward(self, sdf, cam_loc, object_mask, ray_directions, minsdf_steps=None, mask_ready=None):
         """-> (points[R,3], network_object_mask[R] bool, dists[R]).
         minsdf_steps: the n_steps uniform draws of minimal_sdf_points (ray_tracing.py:287); drawn here from torch's CPU
-        generator when not given -- always, whereas the reference draws only if some ray needs them."""
+        generator when not given -- always, whereas the reference draws only if some ray needs them.
+        mask_ready: optional callable(network_object_mask) run once the mask is final, before the secant / min-sdf launch is enqueued
+        (IDRNetwork uses it to fetch the hit count while that launch runs)."""
         net = getattr(sdf, 'native_net', None)
         if net is None:
             raise TypeError('the native tracer needs the SDF weights: pass ImplicitNetwork.native_sdf() (a callable carrying the '
@@ -61,6 +63,7 @@ class RayTracing(nn.Module):
         mt = self.mt or (1 if R <= 4096 else 2)
         mt_samples = self.mt_samples or 2
         pts, mask, dists, counters = ops.trace(net, cam_loc, ray_directions, object_mask, self._params(), self.training, intervals,
-                                               minsdf_steps, mt=mt, mt_samples=mt_samples, events=self.events)
+                                               minsdf_steps, mt=mt, mt_samples=mt_samples, events=self.events,
+                                               mask_ready=mask_ready)
         self.last_counters = counters
         return pts, mask, dists

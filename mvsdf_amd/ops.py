@@ -143,11 +143,14 @@ def sphere_intersection(cam_loc, ray_dirs, r=1.0):
     return t, m.bool()
 
 
-def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, minsdf_steps=None, mt=1, mt_samples=4, events=None):
+def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, minsdf_steps=None, mt=1, mt_samples=4, events=None,
+          mask_ready=None):
     """RayTracing.forward on the device -> (points[R,3], mask[R] bool, dists[R], counters[16] int64 device tensor).
     mt: row tiles per sphere-tracing workgroup (8*mt rays); mt_samples: row tiles per chunk of the sample-row kernels.
     events: optional list; when given the two kernels are launched by separate C calls and (start, mid, end) torch events
-    recorded on the current stream are appended (per-kernel timing for bench.py's roofline)."""
+    recorded on the current stream are appended (per-kernel timing for bench.py's roofline).
+    mask_ready: optional callable(mask_bool) invoked (on the host) after the launch that finalises the hit mask and BEFORE the secant /
+    min-sdf launch is enqueued: whatever it enqueues (e.g. an async copy of the hit count) completes while that last launch runs."""
     cam_loc, ray_dirs = _f32(cam_loc), _f32(ray_dirs)
     B, P = ray_dirs.shape[:2]
     R = B * P
@@ -165,6 +168,22 @@ def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, mins
     st = _f32(minsdf_steps) if minsdf_steps is not None else None
     args = (C.byref(d), C.byref(tp), ptr(cam_loc), ptr(ray_dirs), ptr(om), B, P, 1 if training else 0, ptr(iv), ptr(st),
             ptr(pts), ptr(mask), ptr(dists), ptr(counters), ptr(ws), C.c_size_t(wsb), mt, mt_samples, stream_of(ray_dirs))
+    if mask_ready is not None:
+        # events: (start, after sphere tracing, after the sampler rows, before secant / min-sdf, end)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if events is not None else None
+        if ev: ev[0].record()
+        check(lib().mvsdf_trace_stage(1, *args), 'mvsdf_trace_stage(1)')
+        if ev: ev[1].record()
+        check(lib().mvsdf_trace_stage(3, *args), 'mvsdf_trace_stage(3)')
+        if ev: ev[2].record()
+        mask_b = mask.bool()
+        mask_ready(mask_b)
+        if ev: ev[3].record()
+        check(lib().mvsdf_trace_stage(4, *args), 'mvsdf_trace_stage(4)')
+        if ev:
+            ev[4].record()
+            events.append(tuple(ev))
+        return pts, mask_b, dists, counters
     if events is None:
         check(lib().mvsdf_trace(*args), 'mvsdf_trace')
     else:
