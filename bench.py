@@ -160,12 +160,14 @@ def main():
         f_t, f_s, f_r = flops_per_row(W)
         st = model.last_stats
         cnt = st['counters'].cpu().numpy()
-        T, N, E = int(cnt[:4].sum()), st['N'], R // 2
+        # tracer rows actually evaluated: counters[8] = ray-sampler rows up to each ray's first sign change (the reference also
+        # evaluates the samples behind it, counters[1], which no output reads)
+        T, T_ref, N, E = int(cnt[0] + cnt[8] + cnt[2] + cnt[3]), int(cnt[:4].sum()), st['N'], R // 2
         flops_step = T * f_t + ((R + E) + 2 * (N + E)) * f_s + 3 * (N + E) * f_t + 3 * N * f_r
         ms_sphere = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
         ms_samples = float(np.mean([e[1].elapsed_time(e[2]) + e[3].elapsed_time(e[4]) if len(e) == 5 else e[1].elapsed_time(e[2]) for e in events]))
-        rows_samples = int(cnt[1] + cnt[2] + cnt[3])
-        n_launch = 2                                            # k_ray_samples runs twice per step (sampler rows; secant || min-sdf rows)
+        rows_samples = int(cnt[8] + cnt[2] + cnt[3])
+        n_launch = 3                    # k_ray_samples per step: sampler rows (first window), sampler rows (open rays), secant || min-sdf rows
         ach = rows_samples * f_t / (ms_samples * 1e-3) / 1e12
         res = {
             'metric': 'traced rays/sec (fwd+bwd, 10 sphere iters, 4 src views)', 'value': world * R * a.steps / dt, 'unit': 'rays/s',
@@ -183,7 +185,7 @@ def main():
                          'launches_per_step': n_launch,
                          'k_sphere_trace': {'rows_per_launch': int(cnt[0]), 'avg_launch_ms': ms_sphere,
                                             'achieved': int(cnt[0]) * f_t / (ms_sphere * 1e-3) / 1e12},
-                         'step': {'T_trace_rows': T, 'R': R, 'E': E, 'N_hit': N, 'flops_step': flops_step,
+                         'step': {'T_trace_rows': T, 'T_reference_rows': T_ref, 'R': R, 'E': E, 'N_hit': N, 'flops_step': flops_step,
                                   'achieved': flops_step / (dt / a.steps) / 1e12, 'frac': flops_step / (dt / a.steps) / 1e12 / PEAK_F32_MFMA}},
             'loss': float(lo['loss'].detach()),
         }

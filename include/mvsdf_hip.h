@@ -52,7 +52,11 @@ enum {
     MVSDF_CNT_ROWS_MINSDF = 3,  /* ... by minimal_sdf_points                (ray_tracing.py:301) */
     MVSDF_CNT_N_SECANT = 4,     /* rays that ran the secant */
     MVSDF_CNT_N_SAMPLER = 5,    /* rays on the sampler work list */
-    MVSDF_CNT_N_MINSDF = 6      /* rays on the min-sdf work list */
+    MVSDF_CNT_N_MINSDF = 6,     /* rays on the min-sdf work list */
+    MVSDF_CNT_N_SAMPLER_REST = 7,    /* sampler rays whose first sample window did not settle them (no sign change yet) */
+    MVSDF_CNT_ROWS_SAMPLER_EVAL = 8  /* ray_sampler rows actually evaluated here: the samples AFTER a ray's first sign change cannot
+                                      * influence any output (ray_tracing.py:221-256 reads only sdf_val[ind-1], sdf_val[ind]) and are
+                                      * skipped.  counters[1] keeps the reference's count (n_rays * n_steps). */
 };
 
 int mvsdf_version(void);
@@ -97,7 +101,7 @@ int mvsdf_sphere_intersection(const float* cam_loc, const float* ray_dirs, int B
  * mvsdf_trace_workspace_bytes_n(B*P, n_steps).
  * mt: row tiles (16 rows) per workgroup of the sphere-tracing kernel (8*mt rays), 1..4;
  * mt_samples: row tiles per chunk of the flattened sample-row kernels (sampler / min-sdf), 1..4. */
-size_t mvsdf_trace_workspace_bytes(int R);
+size_t mvsdf_trace_workspace_bytes(int R);   /* = mvsdf_trace_workspace_bytes_n(R, 128) */
 size_t mvsdf_trace_workspace_bytes_n(int R, int n_steps);
 int mvsdf_trace(const MvsdfNetDesc* net, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
                 const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,

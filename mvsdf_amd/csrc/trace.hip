@@ -229,30 +229,36 @@ struct SampleCtx {
     const float* w_zmin; const float* w_zmax;
     float* sec_state;                 // [4][R]: z_low, z_high, sdf_low, sdf_high of secant rays
     int* sec_list;                    // gids of rays that need the secant
-    float* sv;                        // [n_list * n_steps] sample values of the list being processed
+    float* sv;                        // [n_items * n_steps] sample values, row = item index on its ORIGINAL list
+    int* list_rest; int* src_rest;    // sampler rays the first sample window left open: list entry, sv row
+    int n_first;                      // size of the first sampler window (n_steps: single pass)
     unsigned long long* counters;
 };
 
-// Sample rows of a work list, FLATTENED over rays: global row q = item * n_steps + i.  A workgroup evaluates one chunk of
-// 16*MT consecutive rows (always full tiles, evenly spread over the chip) and stores the SDF values; the per-ray logic runs in
-// k_reduce_items.  Sampler rays: ray_tracing.py:206-219; min-sdf rays: ray_tracing.py:287-301.
+// one segment of sample rows: the samples [i0, i0 + ni) of every item of a device-side list
+struct RowSeg { const int* list; const int* src; int cnt_index, i0, ni, blocks; };
+
+// Sample rows of a work list, FLATTENED over rays: global row q = item * ni + j (sample i0 + j).  A workgroup evaluates one chunk
+// of 16*MT consecutive rows (always full tiles, evenly spread over the chip) and stores the SDF values; the per-ray logic runs
+// in k_reduce_items.  Sampler rays: ray_tracing.py:206-219; min-sdf rays: ray_tracing.py:287-301.
 template <int MT, int NTW, int NW>
-__device__ void mv_eval_rows(const MvNet& net, const MvTraceParams& tp, const SampleCtx& c, const int* __restrict__ list, int n_list, int chunk,
-                             float* smem) {
+__device__ void mv_eval_rows(const MvNet& net, const MvTraceParams& tp, const SampleCtx& c, const RowSeg& sg, int chunk, float* smem) {
     constexpr int ROWS = 16 * MT;
     const int tid = threadIdx.x;
-    const int n_steps = tp.n_steps;
-    const long long total = (long long)n_list * n_steps;
+    const int n_steps = tp.n_steps, ni = sg.ni;
+    const int n_list = (int)c.counters[sg.cnt_index];
+    const long long total = (long long)n_list * ni;
     const long long q0 = (long long)chunk * ROWS;
     if (q0 >= total) return;
     const int nr = (int)min((long long)ROWS, total - q0);
     TraceLds lds = mv_carve(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
+    long long svi = 0;
     if (tid < ROWS) {
         float* p = lds.pts + tid * 3;
         if (tid < nr) {
             const long long q = q0 + tid;
-            const int it = (int)(q / n_steps), i = (int)(q - (long long)it * n_steps);
-            const int e = list[it];
+            const int it = (int)(q / ni), i = sg.i0 + (int)(q - (long long)it * ni);
+            const int e = sg.list[it];
             const int gid = e & 0x0fffffff;
             const bool samp = (e >> 28) & MV_ITEM_SAMPLER;
             const float* cc = c.cam_loc + 3 * (gid / c.P);
@@ -261,29 +267,62 @@ __device__ void mv_eval_rows(const MvNet& net, const MvTraceParams& tp, const Sa
             const float z = samp ? (zmin + c.intervals[i] * (zmax - zmin))        // ray_tracing.py:208
                                  : (c.steps[i] * (zmax - zmin) + zmin);            // ray_tracing.py:290
             p[0] = cc[0] + z * d[0]; p[1] = cc[1] + z * d[1]; p[2] = cc[2] + z * d[2];
+            svi = (long long)(sg.src ? sg.src[it] : it) * n_steps + i;
         } else { p[0] = 0.f; p[1] = 0.f; p[2] = 0.f; }
     }
     __syncthreads();
     mv_eval_dispatch<MT, NTW, NW>(net, (nr + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
-    if (tid < nr) c.sv[q0 + tid] = lds.sdfv[tid];
+    if (tid < nr) c.sv[svi] = lds.sdfv[tid];
 }
 
-// Per-ray reduction of the stored sample values (one thread per listed ray): first sign change / P_out argmin and the secant
-// hand-off for sampler rays (ray_tracing.py:221-256), argmin for min-sdf rays (ray_tracing.py:303-307).
-__global__ void k_reduce_items(MvTraceParams tp, SampleCtx c, const int* __restrict__ list, int cnt_index) {
+// Per-ray reduction of the stored sample values (one thread per listed ray).
+//   mode 0: sampler rays after their FIRST window of n_first samples.  A ray inside the object mask whose first negative sample
+//           lies in the window at index >= 1 is settled: ray_tracing.py:221-256 reads only sdf_val[ind - 1] and sdf_val[ind] of it
+//           (mask, secant hand-off), whatever the later samples are.  Every other ray goes on the rest list.
+//   mode 1: sampler rays of the rest list, all n_steps values present: first sign change / P_out argmin / secant hand-off.
+//   mode 2: min-sdf rays: argmin (ray_tracing.py:303-307).
+__global__ void k_reduce_items(MvTraceParams tp, SampleCtx c, const int* __restrict__ list, const int* __restrict__ src, int cnt_index, int mode) {
     const int n_list = (int)c.counters[cnt_index];
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= n_list) return;
     const int n_steps = tp.n_steps;
     const int e = list[it];
     const int gid = e & 0x0fffffff, kind = e >> 28;
-    const bool samp = kind & MV_ITEM_SAMPLER, om = kind & MV_ITEM_OM;
+    const bool om = kind & MV_ITEM_OM;
     const float* cc = c.cam_loc + 3 * (gid / c.P);
     const float* d = c.dirs + 3 * (size_t)gid;
     const float zmin = c.w_zmin[gid], zmax = c.w_zmax[gid];
-    const float* sv = c.sv + (size_t)it * n_steps;
+    const int row = src ? src[it] : it;
+    const float* sv = c.sv + (size_t)row * n_steps;
     float dist;
-    if (samp) {
+    if (mode == 0 && c.n_first < n_steps) {
+        if (it == 0) {
+            atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER], (unsigned long long)n_list * (unsigned long long)n_steps);
+            atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER_EVAL], (unsigned long long)n_list * (unsigned long long)c.n_first);
+        }
+        int ind = -1;
+        for (int i = 0; i < c.n_first; ++i) if (sv[i] < 0.f) { ind = i; break; }
+        if (!(om && ind >= 1)) {                                                   // open: needs the other samples (ind == 0 wraps to the last one)
+            const unsigned long long k = atomicAdd(&c.counters[MV_CNT_N_SAMPLER_REST], 1ull);
+            c.list_rest[k] = e; c.src_rest[k] = it;
+            return;
+        }
+        dist = zmin + c.intervals[ind] * (zmax - zmin);
+        c.o_mask[gid] = 1;
+        const unsigned long long k = atomicAdd(&c.counters[MV_CNT_N_SECANT], 1ull);
+        c.sec_list[k] = gid;
+        c.sec_state[gid] = zmin + c.intervals[ind - 1] * (zmax - zmin);
+        c.sec_state[(size_t)c.R + gid] = dist;
+        c.sec_state[2 * (size_t)c.R + gid] = sv[ind - 1];
+        c.sec_state[3 * (size_t)c.R + gid] = sv[ind];
+    } else if (mode <= 1) {
+        if (it == 0) {
+            if (mode == 0) {
+                atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER], (unsigned long long)n_list * (unsigned long long)n_steps);
+                atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER_EVAL], (unsigned long long)n_list * (unsigned long long)n_steps);
+            } else
+                atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER_EVAL], (unsigned long long)n_list * (unsigned long long)(n_steps - c.n_first));
+        }
         int ind = 0; float best = INFINITY;                                       // argmin(sign(sdf) * [n..1]), first min
         for (int i = 0; i < n_steps; ++i) {
             const float v = sv[i];
@@ -310,6 +349,7 @@ __global__ void k_reduce_items(MvTraceParams tp, SampleCtx c, const int* __restr
             c.sec_state[3 * (size_t)c.R + gid] = sv[ind];
         }
     } else {
+        if (it == 0) atomicAdd(&c.counters[MV_CNT_ROWS_MINSDF], (unsigned long long)n_list * (unsigned long long)n_steps);
         int bi = 0; float bv = INFINITY;                                          // min over the shared random steps
         for (int i = 0; i < n_steps; ++i) if (sv[i] < bv) { bv = sv[i]; bi = i; }
         dist = c.steps[bi] * (zmax - zmin) + zmin;
@@ -318,7 +358,6 @@ __global__ void k_reduce_items(MvTraceParams tp, SampleCtx c, const int* __restr
     c.o_points[3 * (size_t)gid + 0] = cc[0] + dist * d[0];
     c.o_points[3 * (size_t)gid + 1] = cc[1] + dist * d[1];
     c.o_points[3 * (size_t)gid + 2] = cc[2] + dist * d[2];
-    if (it == 0) atomicAdd(&c.counters[samp ? MV_CNT_ROWS_SAMPLER : MV_CNT_ROWS_MINSDF], (unsigned long long)n_list * (unsigned long long)n_steps);
 }
 
 // secant (ray_tracing.py:260-278) for 16*MT listed rays per workgroup: n_secant dependent rounds, every round one evaluation of
@@ -362,19 +401,19 @@ __device__ void mv_secant_rays(const MvNet& net, const MvTraceParams& tp, const 
     if (tid == 0) atomicAdd(&c.counters[MV_CNT_ROWS_SECANT], (unsigned long long)n * (unsigned long long)tp.n_secant);
 }
 
-// stage 2a: sample rows of the sampler rays.   stage 2b: secant workgroups (first sec_blocks blocks) + sample rows of the min-sdf
-// rays (the rest): the dependent secant chains of a few dozen workgroups overlap with the throughput-shaped min-sdf sampling.
+// The first sec_blocks workgroups run secant chains, the others evaluate sample rows of up to two row segments: the dependent
+// secant chains of a few dozen workgroups overlap with the throughput-shaped sampling.
 template <int MT, int NTW, int NW>
-__global__ __launch_bounds__(64 * NW) void k_ray_samples(MvNet net, MvTraceParams tp, SampleCtx c, const int* __restrict__ list_s,
-                                                        const int* __restrict__ list_m, int stage, int sec_blocks) {
+__global__ __launch_bounds__(64 * NW) void k_ray_samples(MvNet net, MvTraceParams tp, SampleCtx c, RowSeg s0, RowSeg s1, int sec_blocks) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (stage == 0) {
-        mv_eval_rows<MT, NTW, NW>(net, tp, c, list_s, (int)c.counters[MV_CNT_N_SAMPLER], blockIdx.x, smem);
-    } else if ((int)blockIdx.x < sec_blocks) {
-        mv_secant_rays<(MT > 1 ? 1 : MT), NTW, NW>(net, tp, c, (int)c.counters[MV_CNT_N_SECANT], blockIdx.x, smem);
-    } else {
-        mv_eval_rows<MT, NTW, NW>(net, tp, c, list_m, (int)c.counters[MV_CNT_N_MINSDF], blockIdx.x - sec_blocks, smem);
+    int b = blockIdx.x;
+    if (b < sec_blocks) {
+        mv_secant_rays<(MT > 1 ? 1 : MT), NTW, NW>(net, tp, c, (int)c.counters[MV_CNT_N_SECANT], b, smem);
+        return;
     }
+    b -= sec_blocks;
+    if (b < s0.blocks) mv_eval_rows<MT, NTW, NW>(net, tp, c, s0, b, smem);
+    else if (b - s0.blocks < s1.blocks) mv_eval_rows<MT, NTW, NW>(net, tp, c, s1, b - s0.blocks, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -425,20 +464,34 @@ static hipError_t launch_stage2(const MvNet& net, const MvTraceParams& tp, const
         if (e != hipSuccess) return e;
         set2 = lds2;
     }
+    static int nf_env = -1;
+    if (nf_env < 0) { const char* e = getenv("MVSDF_NFIRST"); nf_env = e ? atoi(e) : 16; if (nf_env < 2) nf_env = 2; }
+    const int n = tp.n_steps, nf = nf_env < n ? nf_env : n;
     SampleCtx c;
     c.cam_loc = cam_loc; c.dirs = dirs; c.R = R; c.P = P; c.training = training; c.RPW = 0; c.intervals = intervals; c.steps = steps;
     c.o_points = points; c.o_mask = mask; c.o_dists = dists; c.w_zmin = w_zmin; c.w_zmax = w_zmax; c.sec_state = sec_state;
     c.sec_list = sec_list; c.sv = sv; c.counters = counters;
+    c.list_rest = (int*)(sv + (size_t)R * n); c.src_rest = c.list_rest + R; c.n_first = nf;
     // worst-case grids (every ray listed); blocks beyond the device-side counts exit at once
-    const int row_blocks = (int)(((long long)R * tp.n_steps + ROWS - 1) / ROWS), sec_blocks = (R + 15) / 16, red_blocks = (R + 63) / 64;
+    auto blocks_for = [&](int per_item) { return (int)(((long long)R * per_item + ROWS - 1) / ROWS); };
+    const int sec_blocks = (R + 15) / 16, red_blocks = (R + 63) / 64;
+    const RowSeg none = {nullptr, nullptr, 0, 0, 1, 0};
     if (parts & 1) {
-        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(row_blocks), dim3(64 * NW), lds2, stream, net, tp, c, w_list, w_list_min, 0, 0);
-        hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list, (int)MV_CNT_N_SAMPLER);
+        // sampler rays: first window of nf samples, then the other samples of the rays the window left open
+        const RowSeg first = {w_list, nullptr, (int)MV_CNT_N_SAMPLER, 0, nf, blocks_for(nf)};
+        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(first.blocks), dim3(64 * NW), lds2, stream, net, tp, c, first, none, 0);
+        hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list, (const int*)nullptr, (int)MV_CNT_N_SAMPLER, 0);
+        if (nf < n) {
+            const RowSeg rest = {c.list_rest, c.src_rest, (int)MV_CNT_N_SAMPLER_REST, nf, n - nf, blocks_for(n - nf)};
+            hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(rest.blocks), dim3(64 * NW), lds2, stream, net, tp, c, rest, none, 0);
+            hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, c.list_rest, c.src_rest, (int)MV_CNT_N_SAMPLER_REST, 1);
+        }
     }
     if (parts & 2) {
-        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(sec_blocks + (training ? row_blocks : 0)), dim3(64 * NW), lds2, stream, net, tp, c,
-                           w_list, w_list_min, 1, sec_blocks);
-        if (training) hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list_min, (int)MV_CNT_N_MINSDF);
+        const RowSeg minsdf = {w_list_min, nullptr, (int)MV_CNT_N_MINSDF, 0, n, training ? blocks_for(n) : 0};
+        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(sec_blocks + minsdf.blocks), dim3(64 * NW), lds2, stream, net, tp, c, minsdf, none,
+                           sec_blocks);
+        if (training) hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
     }
     return hipGetLastError();
 }
@@ -486,7 +539,7 @@ hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp
 #include "capi_util.h"
 extern "C" {
 
-size_t mvsdf_trace_workspace_bytes_n(int R, int n_steps) { return (size_t)(R > 0 ? R : 0) * (36 + 4 * (size_t)(n_steps > 0 ? n_steps : 0)) + 256; }
+size_t mvsdf_trace_workspace_bytes_n(int R, int n_steps) { return (size_t)(R > 0 ? R : 0) * (44 + 4 * (size_t)(n_steps > 0 ? n_steps : 0)) + 256; }
 size_t mvsdf_trace_workspace_bytes(int R) { return mvsdf_trace_workspace_bytes_n(R, 128); }
 
 static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
