@@ -281,9 +281,31 @@ __device__ void mv_eval_rows(const MvNet& net, const MvTraceParams& tp, const Sa
 //           (mask, secant hand-off), whatever the later samples are.  Every other ray goes on the rest list.
 //   mode 1: sampler rays of the rest list, all n_steps values present: first sign change / P_out argmin / secant hand-off.
 //   mode 2: min-sdf rays: argmin (ray_tracing.py:303-307).
-__global__ void k_reduce_items(MvTraceParams tp, SampleCtx c, const int* __restrict__ list, const int* __restrict__ src, int cnt_index, int mode) {
+// One WAVE per listed ray: lane l holds the samples l, l + 64, ...; ballots find the first negative / zero sample, a shuffle
+// reduction the first minimum (same results as the serial scans of the reference: argmin returns the first minimal index).
+__device__ __forceinline__ int mv_first_where(const float* __restrict__ sv, int n, int lane, int what) {   // what 0: v < 0, 1: sign(v) == 0
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const float v = i < n ? sv[i] : 1.0f;
+        const unsigned long long m = __ballot(what == 0 ? (v < 0.f) : (!(v > 0.f) && !(v < 0.f)));   // sign() of a NaN counts as 0
+        if (m) return base + __builtin_ctzll(m);
+    }
+    return -1;
+}
+__device__ __forceinline__ int mv_first_argmin(const float* __restrict__ sv, int n, int lane) {
+    float bv = INFINITY; int bi = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) { const float v = sv[i]; if (v < bv) { bv = v; bi = i; } }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+        if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    return bi == 0x7fffffff ? 0 : bi;                           // nothing below +inf: the serial scan keeps index 0
+}
+
+__global__ __launch_bounds__(64) void k_reduce_items(MvTraceParams tp, SampleCtx c, const int* __restrict__ list, const int* __restrict__ src,
+                                                     int cnt_index, int mode) {
     const int n_list = (int)c.counters[cnt_index];
-    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    const int it = blockIdx.x, lane = threadIdx.x;
     if (it >= n_list) return;
     const int n_steps = tp.n_steps;
     const int e = list[it];
@@ -294,14 +316,15 @@ __global__ void k_reduce_items(MvTraceParams tp, SampleCtx c, const int* __restr
     const float zmin = c.w_zmin[gid], zmax = c.w_zmax[gid];
     const int row = src ? src[it] : it;
     const float* sv = c.sv + (size_t)row * n_steps;
+    const bool lead = lane == 0;
     float dist;
     if (mode == 0 && c.n_first < n_steps) {
-        if (it == 0) {
+        if (it == 0 && lead) {
             atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER], (unsigned long long)n_list * (unsigned long long)n_steps);
             atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER_EVAL], (unsigned long long)n_list * (unsigned long long)c.n_first);
         }
-        int ind = -1;
-        for (int i = 0; i < c.n_first; ++i) if (sv[i] < 0.f) { ind = i; break; }
+        const int ind = mv_first_where(sv, c.n_first, lane, 0);
+        if (!lead) return;
         if (!(om && ind >= 1)) {                                                   // open: needs the other samples (ind == 0 wraps to the last one)
             const unsigned long long k = atomicAdd(&c.counters[MV_CNT_N_SAMPLER_REST], 1ull);
             c.list_rest[k] = e; c.src_rest[k] = it;
@@ -316,27 +339,21 @@ __global__ void k_reduce_items(MvTraceParams tp, SampleCtx c, const int* __restr
         c.sec_state[2 * (size_t)c.R + gid] = sv[ind - 1];
         c.sec_state[3 * (size_t)c.R + gid] = sv[ind];
     } else if (mode <= 1) {
-        if (it == 0) {
+        if (it == 0 && lead) {
             if (mode == 0) {
                 atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER], (unsigned long long)n_list * (unsigned long long)n_steps);
                 atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER_EVAL], (unsigned long long)n_list * (unsigned long long)n_steps);
             } else
                 atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER_EVAL], (unsigned long long)n_list * (unsigned long long)(n_steps - c.n_first));
         }
-        int ind = 0; float best = INFINITY;                                       // argmin(sign(sdf) * [n..1]), first min
-        for (int i = 0; i < n_steps; ++i) {
-            const float v = sv[i];
-            const float sg = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
-            const float tv = sg * (float)(n_steps - i);
-            if (tv < best) { best = tv; ind = i; }
-        }
-        dist = zmin + c.intervals[ind] * (zmax - zmin);
+        // argmin(sign(sdf) * [n..1]) (ray_tracing.py:221-222), first minimum: the first negative sample, else the first exact zero, else the last
+        int ind = mv_first_where(sv, n_steps, lane, 0);
+        if (ind < 0) ind = mv_first_where(sv, n_steps, lane, 1);
+        if (ind < 0) ind = n_steps - 1;
         const bool net_surf = sv[ind] < 0.f;
-        if (!(om && net_surf)) {                                                  // P_out: argmin sdf, ray_tracing.py:229-235
-            int i2 = 0; float b2 = INFINITY;
-            for (int i = 0; i < n_steps; ++i) if (sv[i] < b2) { b2 = sv[i]; i2 = i; }
-            dist = zmin + c.intervals[i2] * (zmax - zmin);
-        }
+        const int i2 = (om && net_surf) ? 0 : mv_first_argmin(sv, n_steps, lane);   // P_out: argmin sdf, ray_tracing.py:229-235
+        if (!lead) return;
+        dist = zmin + c.intervals[(om && net_surf) ? ind : i2] * (zmax - zmin);
         c.o_mask[gid] = net_surf ? 1 : 0;                                          // ray_tracing.py:237-239, 61
         const bool do_secant = c.training ? (net_surf && om) : net_surf;           // ray_tracing.py:242
         if (do_secant) {
@@ -349,9 +366,9 @@ __global__ void k_reduce_items(MvTraceParams tp, SampleCtx c, const int* __restr
             c.sec_state[3 * (size_t)c.R + gid] = sv[ind];
         }
     } else {
-        if (it == 0) atomicAdd(&c.counters[MV_CNT_ROWS_MINSDF], (unsigned long long)n_list * (unsigned long long)n_steps);
-        int bi = 0; float bv = INFINITY;                                          // min over the shared random steps
-        for (int i = 0; i < n_steps; ++i) if (sv[i] < bv) { bv = sv[i]; bi = i; }
+        if (it == 0 && lead) atomicAdd(&c.counters[MV_CNT_ROWS_MINSDF], (unsigned long long)n_list * (unsigned long long)n_steps);
+        const int bi = mv_first_argmin(sv, n_steps, lane);                         // min over the shared random steps
+        if (!lead) return;
         dist = c.steps[bi] * (zmax - zmin) + zmin;
     }
     c.o_dists[gid] = dist;                                                         // secant rays are overwritten by the secant stage
@@ -474,7 +491,7 @@ static hipError_t launch_stage2(const MvNet& net, const MvTraceParams& tp, const
     c.list_rest = (int*)(sv + (size_t)R * n); c.src_rest = c.list_rest + R; c.n_first = nf;
     // worst-case grids (every ray listed); blocks beyond the device-side counts exit at once
     auto blocks_for = [&](int per_item) { return (int)(((long long)R * per_item + ROWS - 1) / ROWS); };
-    const int sec_blocks = (R + 15) / 16, red_blocks = (R + 63) / 64;
+    const int sec_blocks = (R + 15) / 16, red_blocks = R;                        // one wave per listed ray
     const RowSeg none = {nullptr, nullptr, 0, 0, 1, 0};
     if (parts & 1) {
         // sampler rays: first window of nf samples, then the other samples of the rays the window left open
