@@ -260,6 +260,22 @@ int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float
     const SdfLayout lo = sdf_ctx_layout(net, M, Mg);
     const int nl = lo.nl, S = Mg > 0 ? stride_for(net, netT) : net.S;
     float* H0 = ctx + lo.H0;
+    static int fuse_fwd = -1;
+    if (fuse_fwd < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_fwd = e ? atoi(e) : 1; }
+    if (fuse_fwd && !mv_wide(net) && net.L[nl - 1].NT <= 64) {                     // value + normal of a row tile in one launch
+        FwdArgs f;
+        memset(&f, 0, sizeof(f));
+        f.net = net; if (Mg > 0) f.netT = netT;
+        f.S = S; f.M = M; f.Mg = Mg; f.ld0 = lo.ld0; f.x = x; f.H0 = H0;
+        for (int l = 1; l < nl; ++l) f.A[l] = ctx + lo.A[l];
+        for (int l = 0; l < nl - 1; ++l) { f.Z[l] = ctx + lo.Z[l]; f.Sg[l] = ctx + lo.Sg[l]; }
+        for (int l = 1; l < nl - 1; ++l) f.U[l] = ctx + lo.U[l];
+        f.G0 = ctx + lo.G0; f.y = y; f.ldy = net.L[nl - 1].N; f.w_last_row0 = d->w[nl - 1]; f.nrm = nrm;
+        constexpr int MTC = 1, NWC = 8;
+        const size_t lds = ((size_t)16 * MTC * S + 2 * ((16 * MTC * lo.d0 + 3) & ~3) + 16 * MTC * 4) * sizeof(float);
+        hipLaunchKernelGGL((k_chain_fwd<MTC, 2, NWC>), dim3((M + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, f);
+        return mv_check(hipGetLastError(), "mvsdf_sdf_forward");
+    }
     hipLaunchKernelGGL(k_pe_global, dim3((M * (3 * net.multires + 1) + 255) / 256), dim3(256), 0, s, x, M, net.multires, H0, lo.ld0);
     for (int l = 0; l < nl - 1; ++l) {                                            // hidden layers (idr.py:82-92)
         LayerArgs a = base_args(net.L[l], S, M);

@@ -594,3 +594,202 @@ __global__ __launch_bounds__(64 * NW) void k_chain_e1(ChainArgs a) {
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward value + normal of the SDF network for 16*MT rows per workgroup in ONE launch (replaces 1 + 9 + 8 + 1 launches):
+//   value  (ascending, idr.py:77-94):  PE -> [Linear, Softplus(100)] x (L-1) -> Linear; stores H0, A_l, Z_l, y;
+//   normal (descending, idr.py:96-107 = VJP of output 0): u_L = W_L[0,:]; s_l = sigma(100 z_l) . u_{l+1}; u_l = s_l W_l (split and
+//           /sqrt2 at the skip layer); g_0 = u_0 (+ PE part of the skip layer); n = J_PE^T g_0; stores Sg_l, U_l, G0, n.
+// The running activation / adjoint tile never leaves LDS.  Same arithmetic as the per-layer kernels it replaces.
+struct FwdArgs {
+    MvNet net, netT;
+    int S, M, Mg, ld0;
+    const float* x;                            // [M][3]
+    float* H0;                                 // [M][ld0]
+    float* A[MV_MAXL]; float* Z[MV_MAXL];      // A_l [M][K_l] (l >= 1), Z_l [M][N_l]
+    float* U[MV_MAXL]; float* Sg[MV_MAXL];     // u_l [Mg][N_{l-1}] (1 <= l <= L-2), s_l [Mg][N_l]
+    float* G0;                                 // [Mg][ld0]
+    float* y; int ldy;                         // [M][Nout]
+    const float* w_last_row0;                  // W_L[0, :]
+    float* nrm;                                // [Mg][3]
+};
+
+template <int MT, int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * MT, NTH = 64 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers, sk = a.net.skip_layer, d0 = 3 + 6 * a.net.multires;
+    float* act = smem;
+    float* pe = act + ROWS * S;                                  // [ROWS][d0] natural order
+    float* padj = pe + ((ROWS * d0 + 3) & ~3);                   // [ROWS][d0] PE adjoint of the skip layer, then g_0
+    float* pts = padj + ((ROWS * d0 + 3) & ~3);                  // [ROWS][3]
+    for (int i = tid; i < ROWS * 3; i += NTH) {
+        const int row = row0 + i / 3;
+        pts[i] = row < a.M ? a.x[3 * (size_t)row0 + i] : 0.0f;
+    }
+    __syncthreads();
+    mv_pe_rows<NTH>(pts, pe, act, S, ROWS, a.net.multires, tid);
+    __syncthreads();
+    for (int idx = tid; idx < ROWS * a.ld0; idx += NTH) {
+        const int rr = idx / a.ld0, k = idx - rr * a.ld0, row = row0 + rr;
+        if (row < a.M) a.H0[(size_t)row * a.ld0 + k] = k < d0 ? pe[rr * d0 + k] : 0.0f;
+    }
+    // ---- value chain
+    for (int l = 0; l < nl - 1; ++l) {
+        const MvLayer& L = a.net.L[l];
+        const int N = L.N, NT = L.NT, per = (NT + NW - 1) / NW, ct0 = w * per;
+        int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
+        const bool to_skip = (l + 1 == sk);
+        const int Kn = a.net.L[l + 1].K, Kpn = a.net.L[l + 1].KB * 16;
+        f32x4 acc[MT][NTW];
+        mv_zero_acc<MT, NTW>(acc);
+        __syncthreads();
+        if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            if (t < ntw) {
+                const int col = (ct0 + t) * 16 + r;
+                if (col < N) {
+                    const float bv = L.bias[col];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int rr = m * 16 + 4 * q + i, row = row0 + rr;
+                            const float z = acc[m][t][i] + bv;
+                            float h = dm_softplus100(z);
+                            if (to_skip) h = dm_div_sqrt2(h);
+                            act[rr * S + mv_perm(col)] = h;
+                            if (row < a.M) {
+                                a.Z[l][(size_t)row * N + col] = z;
+                                a.A[l + 1][(size_t)row * Kn + col] = h;
+                            }
+                        }
+                }
+            }
+        }
+        if (to_skip)
+            for (int idx = tid; idx < ROWS * d0; idx += NTH) {
+                const int rr = idx / d0, j = idx - rr * d0, row = row0 + rr;
+                const float v = dm_div_sqrt2(pe[rr * d0 + j]);
+                act[rr * S + mv_perm(N + j)] = v;
+                if (row < a.M) a.A[l + 1][(size_t)row * Kn + N + j] = v;
+            }
+        if (Kpn > Kn) {
+            const int pad = Kpn - Kn;
+            for (int idx = tid; idx < ROWS * pad; idx += NTH) {
+                const int rr = idx / pad, j = idx - rr * pad;
+                act[rr * S + mv_perm(Kn + j)] = 0.0f;
+            }
+        }
+    }
+    {   // last layer: every output column, groups of NTW column tiles per wave
+        const MvLayer& L = a.net.L[nl - 1];
+        const int N = L.N, NT = L.NT, per = (NT + NW - 1) / NW;
+        __syncthreads();
+        for (int g0 = 0; g0 < per; g0 += NTW) {
+            const int ct0 = w * per + g0;
+            int ntw = min(per - g0, NT - ct0);
+            ntw = ntw < 0 ? 0 : (ntw > NTW ? NTW : ntw);
+            f32x4 acc[MT][NTW];
+            mv_zero_acc<MT, NTW>(acc);
+            if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                if (t < ntw) {
+                    const int col = (ct0 + t) * 16 + r;
+                    if (col < N) {
+                        const float bv = L.bias[col];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int row = row0 + m * 16 + 4 * q + i;
+                                if (row < a.M) a.y[(size_t)row * a.ldy + col] = acc[m][t][i] + bv;
+                            }
+                    }
+                }
+            }
+        }
+    }
+    if (row0 >= a.Mg) return;                                    // workgroup-uniform: no normals for these rows
+    // ---- normal chain (rows >= Mg inside the tile carry zeros)
+    for (int i = tid; i < ROWS * d0; i += NTH) padj[i] = 0.0f;
+    for (int l = nl - 2; l >= 0; --l) {
+        const MvLayer& L = a.netT.L[l];                          // contraction over out_l (K), produces in_l columns (N)
+        const int K = L.K, Kp = L.KB * 16, N = L.N;
+        const bool top = (l == nl - 2);
+        __syncthreads();                                         // Z_l of this tile written (value chain) / previous epilogue done
+        for (int base = 0; base < ROWS * Kp; base += NTH * 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NTH + tid;
+                const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
+                v[u] = 0.0f;
+                if (idx < ROWS * Kp && row < a.Mg && k < K) {
+                    const float uu = top ? a.w_last_row0[k] : act[rr * S + mv_perm(k)];
+                    v[u] = dm_sigmoid100(a.Z[l][(size_t)row * K + k]) * uu;
+                    a.Sg[l][(size_t)row * K + k] = v[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NTH + tid;
+                const int rr = idx / Kp, k = idx - rr * Kp;
+                if (idx < ROWS * Kp) act[rr * S + mv_perm(k)] = v[u];
+            }
+        }
+        __syncthreads();
+        const int NT = L.NT, per = (NT + NW - 1) / NW, ct0 = w * per;
+        int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
+        f32x4 acc[MT][NTW];
+        mv_zero_acc<MT, NTW>(acc);
+        if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            if (t < ntw) {
+                const int col = (ct0 + t) * 16 + r;
+                if (col < N) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int rr = m * 16 + 4 * q + i, row = row0 + rr;
+                            float v = acc[m][t][i];
+                            if (l == sk) {
+                                v = dm_div_sqrt2(v);
+                                if (col < N - d0) {
+                                    act[rr * S + mv_perm(col)] = v;
+                                    if (row < a.Mg) a.U[l][(size_t)row * (N - d0) + col] = v;
+                                } else padj[rr * d0 + (col - (N - d0))] = v;
+                            } else if (l == 0) {
+                                const float g = (sk > 0 ? padj[rr * d0 + col] : 0.0f) + v;
+                                padj[rr * d0 + col] = g;
+                                if (row < a.Mg) a.G0[(size_t)row * a.ld0 + col] = g;
+                            } else {
+                                act[rr * S + mv_perm(col)] = v;
+                                if (row < a.Mg) a.U[l][(size_t)row * N + col] = v;
+                            }
+                        }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < ROWS * 3; idx += NTH) {            // n = J_PE^T g_0
+        const int rr = idx / 3, c = idx - 3 * rr, row = row0 + rr;
+        if (row >= a.Mg) continue;
+        const float* h = pe + rr * d0;
+        const float* g = padj + rr * d0;
+        float v = g[c];
+        for (int m = 0; m < a.net.multires; ++m) {
+            const float f = (float)(1 << m);
+            v += f * (h[6 + 6 * m + c] * g[3 + 6 * m + c] - h[3 + 6 * m + c] * g[6 + 6 * m + c]);
+        }
+        a.nrm[(size_t)row * 3 + c] = v;
+    }
+}
