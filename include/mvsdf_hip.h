@@ -165,6 +165,32 @@ int mvsdf_loss_terms(const float* rgb, const float* rgb_gt, const uint8_t* rgb_m
                      float w_depth, int surf_on, int feat_on, float* out, float* d_rgb, float* d_grad, float* d_eik_out, float* d_surf,
                      void* stream);
 
+/* ---- bookkeeping of one training step of IDRNetwork.forward (idr.py:202-304) between the big kernels ----
+ * mvsdf_partition_rays: stable partition of the R rays by surface = net_mask & object_mask (object_mask / true_mask may be NULL = all
+ * ones): perm[R] = [surface rays in ray order | the others in ray order], inv[R] its inverse, true_rows[R] = ranks among the surface
+ * rays of those inside true_mask (first counts[1] entries valid), counts[2] = {#surface, #surface & true}; view_sorted[R][3]
+ * (may be NULL) = -ray_dirs[perm[r]].  Replaces the boolean-mask indexing of idr.py:202-213, 272 (which syncs the host per mask). */
+int mvsdf_partition_rays(const uint8_t* net_mask, const uint8_t* object_mask, const uint8_t* true_mask, const float* ray_dirs, int R,
+                         long long* perm, long long* inv, long long* true_rows, long long* counts, float* view_sorted, void* stream);
+/* Output tensors of the training forward gathered from ONE fused evaluation over the rows [E sample points | R rays sorted, hit first]
+ * (x_eval[E+R][3], y_eval[E+R][Nout], n_eval[E+R][3]): rgb_values[R][3] (rgb_hit[N][3] scattered, 1 elsewhere; idr.py:302-304),
+ * sdf_output[R], diff_pts[N][3], and for the row ranges (d_src[i], d_cnt[i]) / (e_src[i], e_cnt[i]) of the evaluation (<= 4 each,
+ * idr.py:258-286): eik_out, points_hom[.][4] (x, 1) and grad_theta[.][3]; surf[n_true + n_eik] = column 1 at the true-mask hit rows, then
+ * at the first n_eik sample rows (idr.py:270-276). */
+int mvsdf_step_outputs(int R, int E, int N, int Nout, int n_true, int n_eik, const float* x_eval, const float* y_eval, const float* n_eval,
+                       const long long* perm, const long long* inv, const long long* true_rows, const float* rgb_hit, int nd, const int* d_src,
+                       const int* d_cnt, int ne, const int* e_src, const int* e_cnt, float* rgb_values, float* sdf_output, float* diff_pts,
+                       float* eik_out, float* points_hom, float* grad_theta, float* surf, void* stream);
+/* Upstream gradients dy[E+N][Nout], dn[E+N][3] of the fused SDF backward.  stage 0: zero + the rendering net's input adjoint din[N][din_ld]
+ * (features from column din_feat0 -> dy[:, 2:], normals from din_nrm0 -> dn when use_geo).  stage 1 (after the input-adjoint pass produced
+ * dx[N][3]): SampleNetwork's scalar -(xbar . v)/(n . v), xbar = d_diff + din[:, 0:3] (use_geo) + dx (sample_network.py:10-20), added to
+ * dy[E+i][0]; d_eo / d_gth / d_si (upstream of eikonal_output / grad_theta / surf_indicator_output, any may be NULL) scattered over the
+ * same row ranges as mvsdf_step_outputs. */
+int mvsdf_step_backward_inputs(int stage, int E, int N, int Nout, int n_true, int n_eik, const float* din, int din_ld, int din_feat0,
+                               int din_nrm0, int use_geo, const float* d_diff, const float* dx, const float* view_sorted, const float* n_eval,
+                               const long long* true_rows, const float* d_eo, const float* d_gth, const float* d_si, int nd, const int* d_src,
+                               const int* d_cnt, int ne, const int* e_src, const int* e_cnt, float* dy, float* dn, void* stream);
+
 /* ---- optimiser tail on flat buffers (idr_train.py:289-302: all_norm, clip_grad_norm_(grad_cap), Adam.step), two launches ----
  * p, g, m, v: flat fp32 buffers of n elements (parameters, gradients, exp_avg, exp_avg_sq).  step >= 1 is the Adam step count AFTER
  * this update.  max_norm <= 0 disables clipping; otherwise g is scaled in place by min(1, max_norm / (||g|| + 1e-6)).

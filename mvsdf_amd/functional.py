@@ -274,36 +274,26 @@ def loss_terms(rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r
 
 class StepState:
     """Everything the fused training step needs besides the (folded) parameters."""
-    __slots__ = ('net', 'rnet', 'x_eval', 'y_eval', 'n_eval', 'saved', 'R', 'E', 'N', 'hit_idx', 'inv', 'dists', 'cam_rays', 'ray_dirs',
-                 'true_idx', 'n_eik', 'd_ranges', 'e_ranges', 'detach_geo', 'multires_view', 'rsaved')
+    __slots__ = ('net', 'rnet', 'x_eval', 'y_eval', 'n_eval', 'saved', 'R', 'E', 'N', 'n_true', 'n_eik', 'perm', 'inv', 'true_rows', 'view_sorted',
+                 'd_ranges', 'e_ranges', 'detach_geo', 'multires_view', 'rsaved', 'sdf_output', 'points_hom')
 
 
 class _IdrStep(torch.autograd.Function):
     """Post-trace half of IDRNetwork.forward in training mode as ONE autograd node (idr.py:202-304): from the fused value + normal
     evaluation `state.y_eval / n_eval` (rows [samples | rays, hit first]) it produces diff_surf_pts, rgb_values, grad_theta,
     eikonal_output, surf_indicator_output; backward chains the rendering-net backward, the input adjoint at the surface points,
-    SampleNetwork's scalar and a single first/second-order SDF backward -- no autograd glue in between."""
+    SampleNetwork's scalar and a single first/second-order SDF backward -- no autograd glue in between.
+    d_ranges / e_ranges: (first evaluation row, count) of the point groups entering the depth / eikonal terms."""
 
     @staticmethod
     def forward(ctx, st, *params):
         R, E, N = st.R, st.E, st.N
-        dev = st.x_eval.device
-        y_hit, n_hit = st.y_eval[E:E + N], st.n_eval[E:E + N]
-        x_hit = st.x_eval[E:E + N]
-        view = -st.ray_dirs[st.hit_idx]
-        rgb_values = torch.ones(R, 3, dtype=torch.float32, device=dev)
-        st.rsaved = None
+        rgb_hit, st.rsaved = None, None
         if N > 0:
-            rgb_hit, st.rsaved = ops.render_forward(st.rnet, x_hit, view, n_hit, y_hit[:, 2:], st.multires_view)
-            rgb_values[st.hit_idx] = rgb_hit
-        # logical row order of the reference: [hit | samples]
-        def rows(a, b, t_hit, t_smp):
-            return t_hit[a:b] if b <= N else t_smp[a - N:b - N]
-        y_smp, n_smp = st.y_eval[:E], st.n_eval[:E]
-        eik_out = torch.cat([rows(a, b, y_hit, y_smp)[:, :1] for a, b in st.d_ranges], 0).view(1, -1)
-        grad_theta = torch.cat([rows(a, b, n_hit, n_smp) for a, b in st.e_ranges], 0)
-        surf = torch.cat([y_hit[:, 1][st.true_idx], y_smp[:st.n_eik, 1]], 0)
-        diff_pts = x_hit.clone()
+            rgb_hit, st.rsaved = ops.render_forward(st.rnet, st.x_eval[E:E + N], st.view_sorted[:N], st.n_eval[E:E + N],
+                                                    st.y_eval[E:E + N, 2:], st.multires_view)
+        rgb_values, st.sdf_output, diff_pts, eik_out, st.points_hom, grad_theta, surf = ops.step_outputs(
+            R, E, N, st.n_true, st.n_eik, st.x_eval, st.y_eval, st.n_eval, st.perm, st.inv, st.true_rows, rgb_hit, st.d_ranges, st.e_ranges)
         ctx.st = st
         return diff_pts, rgb_values, grad_theta, eik_out, surf
 
@@ -313,52 +303,21 @@ class _IdrStep(torch.autograd.Function):
         R, E, N = st.R, st.E, st.N
         dev = st.x_eval.device
         net, rnet = st.net, st.rnet
-        M = R + E
-        Nout = net.layers[-1].N
-        Mb = E + N
-        dy = torch.zeros(Mb, Nout, dtype=torch.float32, device=dev)
-        dn = torch.zeros(Mb, 3, dtype=torch.float32, device=dev)
-        dWr = dbr = None
-        if N > 0:
-            xbar = d_diff.clone() if d_diff is not None else torch.zeros(N, 3, dtype=torch.float32, device=dev)
-            if d_rgbv is not None and st.rsaved is not None:
-                dWr, dbr, din = ops.render_backward(rnet, N, d_rgbv[st.hit_idx].contiguous(), st.rsaved)
-                dv = 3 + 6 * st.multires_view
-                dy[E:, 2:] = din[:, 6 + dv:]                                       # features always carry the rgb gradient (idr.py:329-336)
-                dn_hit = None
-                if not st.detach_geo:
-                    xbar += din[:, 0:3]
-                    dn_hit = din[:, 3 + dv:6 + dv].contiguous()
-                # adjoint of the surface points through features (+ normals): input adjoint only, rows [E, E+N)
-                _, _, dx = ops.sdf_backward(net, st.x_eval, M, M, N, dy[E:], dn_hit, st.saved, True, want_dw=False, row0=E)
-                xbar += dx
-                if dn_hit is not None:
-                    dn[E:] += dn_hit
-            # SampleNetwork (sample_network.py:10-20): x = c + (t - (f - f0)/(grad f0 . v)) v  =>  fbar = -(xbar . v)/(grad f0 . v)
-            v = st.ray_dirs[st.hit_idx]
-            dot = (st.n_eval[E:E + N] * v).sum(-1)
-            dy[E:, 0] += -(xbar * v).sum(-1) / dot
-        # value heads: eikonal_output (col 0), surf_indicator_output (col 1); normals: grad_theta
-        def add_rows(target, col, a, b, src):
-            if b <= N:
-                if col is None: target[E + a:E + b] += src
-                else: target[E + a:E + b, col] += src
-            else:
-                if col is None: target[a - N:b - N] += src
-                else: target[a - N:b - N, col] += src
-        if d_eo is not None:
-            flat, o = d_eo.reshape(-1), 0
-            for a, b in st.d_ranges:
-                add_rows(dy, 0, a, b, flat[o:o + (b - a)]); o += b - a
-        if d_gth is not None:
-            o = 0
-            for a, b in st.e_ranges:
-                add_rows(dn, None, a, b, d_gth[o:o + (b - a)]); o += b - a
-        if d_si is not None:
-            k = st.true_idx.shape[0]
-            if k > 0:
-                dy[E:, 1].index_add_(0, st.true_idx, d_si[:k])
-            dy[:st.n_eik, 1] += d_si[k:]
+        M, Mb, Nout = R + E, E + N, net.layers[-1].N
+        dy = torch.empty(Mb, Nout, dtype=torch.float32, device=dev)
+        dn = torch.empty(Mb, 3, dtype=torch.float32, device=dev)
+        dWr = dbr = din = dx = None
+        use_geo = not st.detach_geo                                               # idr.py:329-336: features always carry the rgb gradient
+        dv = 3 + 6 * st.multires_view
+        if N > 0 and d_rgbv is not None and st.rsaved is not None:
+            dWr, dbr, din = ops.render_backward(rnet, N, d_rgbv[st.perm[:N]], st.rsaved)
+        common = (E, N, Nout, st.n_true, st.n_eik, din, 6 + dv, 3 + dv, use_geo)
+        ops.step_backward_inputs(0, *common, None, None, st.view_sorted, st.n_eval, st.true_rows, None, None, None, st.d_ranges, st.e_ranges, dy, dn)
+        if din is not None:
+            # adjoint of the surface points through features (+ normals): input adjoint only, rows [E, E+N)
+            _, _, dx = ops.sdf_backward(net, st.x_eval, M, M, N, dy[E:], dn[E:] if use_geo else None, st.saved, True, want_dw=False, row0=E)
+        ops.step_backward_inputs(1, *common, d_diff, dx, st.view_sorted, st.n_eval, st.true_rows, d_eo, d_gth, d_si, st.d_ranges, st.e_ranges,
+                                 dy, dn)
         dWs, dbs, _ = ops.sdf_backward(net, st.x_eval, M, M, Mb, dy, dn, st.saved, False)
         if dWr is None:
             dWr = [torch.zeros_like(L.w) for L in rnet.layers]

@@ -180,12 +180,12 @@ class IDRNetwork(nn.Module):
         sync = {}
 
         def on_mask(net_mask):
-            sm = net_mask & object_mask
-            sync['counts'] = torch.stack([sm.sum(), (sm & object_mask_true).sum()])
+            # stable row partition (hit rays first) + both counts in one launch; the counts travel to pinned memory right away
+            sync['part'] = ops.partition_rays(net_mask, object_mask if conf.use_mask else None, object_mask_true, ray_dirs)
             if self._counts_host is None:
                 self._counts_host = torch.empty(2, dtype=torch.int64).pin_memory()
                 self._counts_event = torch.cuda.Event()
-            self._counts_host.copy_(sync['counts'], non_blocking=True)
+            self._counts_host.copy_(sync['part'][3], non_blocking=True)
             self._counts_event.record()
 
         with torch.no_grad():
@@ -193,13 +193,16 @@ class IDRNetwork(nn.Module):
                                                                  ray_directions=ray_dirs, mask_ready=on_mask if self.training else None)
         ray_dirs = ray_dirs.reshape(-1, 3)
 
-        surface_mask = (network_object_mask & object_mask) if self.training else network_object_mask
-        # rows: [surface rays | sample points | the other rays]  (stable order inside each group = the reference's boolean-mask order)
-        perm = torch.sort((~surface_mask).to(torch.int8), stable=True).indices
-        n_hit_dev = surface_mask.sum()
-        inv = torch.empty_like(perm)
-        inv[perm] = torch.arange(R, device=dev)
         cam_rays = cam_loc.unsqueeze(1).expand(batch_size, num_pixels, 3).reshape(-1, 3)
+        if self.training:
+            perm, inv, true_rows, _, view_sorted = sync['part']
+        else:
+            # rows: [surface rays | the other rays]  (stable order inside each group = the reference's boolean-mask order)
+            surface_mask = network_object_mask
+            perm = torch.sort((~surface_mask).to(torch.int8), stable=True).indices
+            n_hit_dev = surface_mask.sum()
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(R, device=dev)
         pts_sorted = points[perm]                                # hit rays first, then the others
 
         if self.training:
@@ -222,31 +225,27 @@ class IDRNetwork(nn.Module):
             # Rows that receive gradients form the prefix [0, E + N): the backward skips the non-hit rays.
             x_eval = torch.cat([eikonal_points, dsurf_on_sample, dsurf_jitter_sample, pts_sorted], 0)
             y_eval, n_eval, saved = ops.sdf_forward(net, x_eval, R + E)
-            # sorted-row indices of the hit rays that are also inside the true object mask (idr.py:272), in ray order, without a sync
-            true_rows = torch.sort((~(surface_mask & object_mask_true))[perm].to(torch.int8), stable=True).indices
+            rnet, rws, rbs = self.rendering_network.fold()       # independent of N: enqueued before the wait
             self._counts_event.synchronize()                     # the one host wait of the forward: output shapes depend on the counts
             N, n_true = int(self._counts_host[0]), int(self._counts_host[1])
             hit_idx = perm[:N]
             st = Fn.StepState()
             st.net, st.x_eval, st.y_eval, st.n_eval, st.saved = net, x_eval, y_eval, n_eval, saved
-            st.R, st.E, st.N, st.hit_idx, st.ray_dirs, st.n_eik = R, E, N, hit_idx, ray_dirs, n_eik_points
-            st.true_idx = true_rows[:n_true]
-            # point groups in the reference's row order [hit | samples]: (row range, depth-term flag, eikonal-term flag)   idr.py:258-286
+            st.R, st.E, st.N, st.n_true, st.n_eik = R, E, N, n_true, n_eik_points
+            st.perm, st.inv, st.true_rows, st.view_sorted = perm, inv, true_rows, view_sorted
+            # point groups in the reference's row order [hit | samples]: (logical row range, depth-term flag, eikonal-term flag)   idr.py:258-286
             o1, o2 = n_eik_points, n_eik_points + n_dsurf_points
             groups = ((0, N, conf.d_use_rt_surf, conf.eik_use_rt_surf),
                       (N, N + o1, conf.d_use_eik, conf.eik_use_eik),
                       (N + o1, N + o2, conf.d_use_dsurf_on, conf.eik_use_dsurf_on),
                       (N + o2, N + o2 + n_dsurf_points, conf.d_use_dsurf_jitter, conf.eik_use_dsurf_jitter))
-            st.d_ranges = [(a, b) for a, b, fd, _ in groups if fd(train_progress) and b > a]
-            st.e_ranges = [(a, b) for a, b, _, fe in groups if fe(train_progress) and b > a]
+            ev_row = lambda a, b: (E + a, b - a) if b <= N else (a - N, b - a)       # logical range -> (first evaluation row, count)
+            st.d_ranges = [ev_row(a, b) for a, b, fd, _ in groups if fd(train_progress) and b > a]
+            st.e_ranges = [ev_row(a, b) for a, b, _, fe in groups if fe(train_progress) and b > a]
             st.detach_geo = bool(train_progress < conf.phase[0] or conf.disable_rgb_grad)                     # idr.py:331-334
-            rnet, rws, rbs = self.rendering_network.fold()
             st.rnet, st.multires_view = rnet, self.rendering_network.multires_view
             differentiable_surface_points, rgb_values, grad_theta, eikonal_output, surf_indicator_output = Fn.idr_step(st, ws, bs, rws, rbs)
-            y_rays = y_eval[E:, :1]                              # rays in sorted order -> ray order (no gradient: the loss never reads it)
-            sdf_output = y_rays[inv]
-            hom = torch.cat([(x_eval[E + a:E + b] if b <= N else x_eval[a - N:b - N]) for a, b in st.d_ranges], 0)
-            eikonal_points_hom = torch.cat([hom, torch.ones_like(hom[:, :1])], -1).view(1, -1, 4, 1)
+            sdf_output, eikonal_points_hom = st.sdf_output, st.points_hom           # no gradient: the loss never differentiates them
             x_all, shared, row0 = x_eval, None, E
         else:
             y_all, n_all, shared = Fn.sdf_value_normal(net, ws, bs, pts_sorted, R)

@@ -327,3 +327,50 @@ def loss_terms(rgb, rgb_gt, rgb_mask, grad_theta, eik_out, dist_r, dweight, surf
                                  C.c_float(w[4]), 1 if surf_on else 0, 1 if feat_on else 0, ptr(out), ptr(d_rgb), ptr(d_grad), ptr(d_eo),
                                  ptr(d_sf), stream_of(rgb)), 'mvsdf_loss_terms')
     return out, d_rgb, d_grad, d_eo, d_sf
+
+
+# ---- bookkeeping of one training step (csrc/step_kernels.hip)
+def partition_rays(net_mask, object_mask, true_mask, ray_dirs):
+    """-> (perm, inv, true_rows, counts[2] device int64, view_sorted[R,3]); see mvsdf_partition_rays."""
+    R, dev = net_mask.numel(), net_mask.device
+    u8 = lambda m: None if m is None else (m if m.dtype == torch.uint8 else m.view(torch.uint8)).contiguous()
+    nm, om, tm = u8(net_mask.reshape(-1)), u8(object_mask), u8(true_mask)
+    perm = torch.empty(R, dtype=torch.int64, device=dev)
+    inv, true_rows = torch.empty_like(perm), torch.empty_like(perm)
+    counts = torch.empty(2, dtype=torch.int64, device=dev)
+    view = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    rd = _f32(ray_dirs.reshape(-1, 3))
+    check(lib().mvsdf_partition_rays(ptr(nm), ptr(om), ptr(tm), ptr(rd), R, ptr(perm), ptr(inv), ptr(true_rows), ptr(counts), ptr(view),
+                                     stream_of(rd)), 'mvsdf_partition_rays')
+    return perm, inv, true_rows, counts, view
+
+
+def _ranges(rs):
+    n = len(rs)
+    return n, (C.c_int * 4)(*[r[0] for r in rs]), (C.c_int * 4)(*[r[1] for r in rs])
+
+
+def step_outputs(R, E, N, n_true, n_eik, x_eval, y_eval, n_eval, perm, inv, true_rows, rgb_hit, d_ranges, e_ranges):
+    """d_ranges / e_ranges: lists of (first evaluation row, count).  -> rgb_values, sdf_output, diff_pts, eik_out, points_hom, grad_theta, surf"""
+    dev, Nout = x_eval.device, y_eval.shape[1]
+    nd_rows, ne_rows = sum(c for _, c in d_ranges), sum(c for _, c in e_ranges)
+    f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    rgb_values, sdf_output, diff_pts = f(R, 3), f(R, 1), f(N, 3)
+    eik_out, hom, gth, surf = f(1, nd_rows), f(1, nd_rows, 4, 1), f(ne_rows, 3), f(n_true + n_eik)
+    nd, ds, dc = _ranges(d_ranges)
+    ne, es, ec = _ranges(e_ranges)
+    check(lib().mvsdf_step_outputs(R, E, N, Nout, n_true, n_eik, ptr(x_eval), ptr(y_eval), ptr(n_eval), ptr(perm), ptr(inv), ptr(true_rows),
+                                   ptr(rgb_hit) if N > 0 else None, nd, ds, dc, ne, es, ec, ptr(rgb_values), ptr(sdf_output), ptr(diff_pts),
+                                   ptr(eik_out), ptr(hom), ptr(gth), ptr(surf), stream_of(x_eval)), 'mvsdf_step_outputs')
+    return rgb_values, sdf_output, diff_pts, eik_out, hom, gth, surf
+
+
+def step_backward_inputs(stage, E, N, Nout, n_true, n_eik, din, din_feat0, din_nrm0, use_geo, d_diff, dx, view_sorted, n_eval, true_rows,
+                         d_eo, d_gth, d_si, d_ranges, e_ranges, dy, dn):
+    nd, ds, dc = _ranges(d_ranges)
+    ne, es, ec = _ranges(e_ranges)
+    o = lambda t: None if t is None else ptr(_f32(t))
+    check(lib().mvsdf_step_backward_inputs(stage, E, N, Nout, n_true, n_eik, o(din), din.shape[1] if din is not None else 0, din_feat0, din_nrm0,
+                                           1 if use_geo else 0, o(d_diff), o(dx), ptr(view_sorted), ptr(n_eval), ptr(true_rows), o(d_eo),
+                                           o(d_gth), o(d_si), nd, ds, dc, ne, es, ec, ptr(dy), ptr(dn), stream_of(dy)),
+          'mvsdf_step_backward_inputs')
