@@ -61,7 +61,7 @@ class RayTracing(nn.Module):
             minsdf_steps = minsdf_steps.to(dev, non_blocking=True)
         R = ray_directions.shape[0] * ray_directions.shape[1]
         mt = self.mt or (1 if R <= 4096 else 2)
-        mt_samples = self.mt_samples or 2
+        mt_samples = self.mt_samples or int(os.environ.get('MVSDF_MT_SAMPLES', '2'))
         pts, mask, dists, counters = ops.trace(net, cam_loc, ray_directions, object_mask, self._params(), self.training, intervals,
                                                minsdf_steps, mt=mt, mt_samples=mt_samples, events=self.events,
                                                mask_ready=mask_ready)
