@@ -200,7 +200,7 @@ int mvsdf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, 
                     float* norm_out, float* ws, void* stream);
 
 /* device self-test of the deterministic math: op 0 softplus100, 1 expneg, 2 log1p01, 3 sincos (y0=sin, y1=cos),
- * 4 div100 / div_sqrt2 (y0, y1), 5 sqrt / reciprocal (y0, y1). */
+ * 4 div100 / div_sqrt2 (y0, y1), 5 sqrt / reciprocal (y0, y1), 6 two-wide softplus100 (y0 = f(x), y1 = f(-x)). */
 int mvsdf_det_math(int op, const float* x, int n, float* y0, float* y1, void* stream);
 
 #ifdef __cplusplus

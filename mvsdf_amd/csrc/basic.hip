@@ -5,6 +5,7 @@
 #include "tile_engine.h"
 #include "trace_params.h"
 #include "capi_util.h"
+#include "det_math_pk.h"
 
 // ---- weight norm (idr.py:70-71): one wave per output row.  The row is loaded coalesced; lane 0 then walks it through
 // v_readlane in ascending k -- the SAME k-ascending fmaf chain as the CPU restatement (bit-exact), at ~1 us per row. ----
@@ -238,6 +239,7 @@ __global__ void k_det_math(int op, const float* __restrict__ x, int n, float* __
         case 2: a = dm_log1p01(v); break;
         case 3: dm_sincos(v, &a, &b); break;
         case 4: a = dm_div100(v); b = dm_div_sqrt2(v); break;
+        case 6: { const dm_f2 h = dm2_softplus100(dm_f2{v, -v}); a = h.x; b = h.y; break; }   // two-wide softplus: y0 = f(x), y1 = f(-x)
         default: a = sqrtf(fabsf(v)); b = 1.0f / v; break;
     }
     y0[i] = a;

@@ -13,6 +13,7 @@
 #pragma once
 #include "mlp_common.h"
 #include "det_math.h"
+#include "det_math_pk.h"
 
 #define MV_THREADS 256
 
@@ -21,6 +22,7 @@
 #define MV_ABLATE 0
 #endif
 __device__ __forceinline__ float mv_act(float z) { return (MV_ABLATE & 1) ? z * 0.5f : dm_softplus100(z); }
+__device__ __forceinline__ dm_f2 mv_act2(dm_f2 z) { return (MV_ABLATE & 1) ? z * dm2_s(0.5f) : dm2_softplus100(z); }
 
 template <int MTc, int NTW>
 __device__ __forceinline__ void mv_zero_acc(f32x4 (&acc)[MTc][NTW]) {
@@ -62,10 +64,14 @@ __device__ __forceinline__ void mv_gemm_ring(const MvLayer& L, const float* __re
                         acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a[d][r])[s], ((const float*)&b[d][t])[s], acc[r][t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             const int kn = (kb0 + d + PD < KB) ? kb0 + d + PD : kb0 + d;      // tail: harmless re-load of the same block
+            if (!(MV_ABLATE & 8)) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) b[d][t] = wp[((size_t)t * KB + kn) * 64];
+                for (int t = 0; t < NT; ++t) b[d][t] = wp[((size_t)t * KB + kn) * 64];
+            }
+            if (!(MV_ABLATE & 4)) {
 #pragma unroll
-            for (int r = 0; r < MTc; ++r) a[d][r] = *(const float4*)(arow + r * 16 * S + kn * 16);
+                for (int r = 0; r < MTc; ++r) a[d][r] = *(const float4*)(arow + r * 16 * S + kn * 16);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -178,10 +184,11 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
 #pragma unroll
                         for (int a = 0; a < MTc; ++a)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                float h = mv_act(acc[a][t][i] + bv);              // Softplus(beta=100), idr.py:91-92
-                                if (to_skip) h = dm_div_sqrt2(h);                // cat([x, input]) / sqrt(2), idr.py:86-87
-                                act[(a * 16 + 4 * q + i) * S + pos] = h;
+                            for (int i = 0; i < 4; i += 2) {                      // two activations per packed-fp32 instruction
+                                dm_f2 h = mv_act2(dm_f2{acc[a][t][i] + bv, acc[a][t][i + 1] + bv});   // Softplus(beta=100), idr.py:91-92
+                                if (to_skip) h = h * dm2_s(0.7071067690849304f);  // cat([x, input]) / sqrt(2), idr.py:86-87 (dm_div_sqrt2)
+                                act[(a * 16 + 4 * q + i) * S + pos] = h.x;
+                                act[(a * 16 + 4 * q + i + 1) * S + pos] = h.y;
                             }
                     }
                 }

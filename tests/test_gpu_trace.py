@@ -99,3 +99,13 @@ def test_trace_object_mask_paths(oracle):
                                           t(g['intervals']), t(g['minsdf_steps']))
         assert np.array_equal(mask.cpu().numpy(), m_o) and np.array_equal(dists.cpu().numpy(), d_o)
         assert np.array_equal(pts.cpu().numpy(), p_o) and np.array_equal(cnt.cpu().numpy()[:4], rows_o)
+
+
+def test_two_wide_softplus_bitwise(oracle):
+    """det_math_pk.h (packed fp32 FMA epilogues) == the scalar deterministic softplus, bit for bit."""
+    rs = np.random.RandomState(7)
+    z = np.concatenate([rs.uniform(-0.5, 0.5, 200000), rs.uniform(-0.02, 0.02, 100000), rs.uniform(-3, 3, 50000),
+                        [0, 0.2, -0.2, 0.2000001, -2, 3, 1e-30, -1e-30]]).astype(np.float32)
+    y0, y1 = ops.det_math(6, torch.from_numpy(z).cuda())
+    assert np.array_equal(y0.cpu().numpy(), oracle.softplus100(z))
+    assert np.array_equal(y1.cpu().numpy(), oracle.softplus100(-z))
