@@ -147,3 +147,29 @@ def test_chunked_eval_render_matches_unchunked():
         assert int(m.ray_tracer.last_counters[0]) > 0 and hq['rgb_values'].shape == (900, 3)
     finally:
         os.environ.pop('IDR_USE_ENV'); os.environ.pop('IDR_RENDER')
+
+
+def test_partial_object_mask_selects_true_hits_for_the_surface_indicator():
+    """object_mask with holes (idr.py:270-276): surf_indicator_output = [column 1 at the hit rays inside the TRUE mask, in ray order |
+    column 1 at the eikonal samples]; with use_mask off the hit set itself ignores the mask."""
+    m = _model(64)
+    B, P = 2, 200
+    inp, gt = synth.make_batch(B, P, 2, seed=3, feat_hw=(60, 80))
+    rs = np.random.RandomState(5)
+    inp['object_mask'] = rs.rand(B, P) < 0.6
+    torch.manual_seed(0)
+    out = m({k: t(v) for k, v in inp.items()}, 0.3)
+    hit = out['network_object_mask'] & out['object_mask']
+    true = out['object_mask_true']
+    assert bool((~true).any()) and int((hit & true).sum()) < int(hit.sum())
+    n_true, n_eik = int((hit & true).sum()), (B * P) // 2
+    assert out['surf_indicator_output'].shape == (n_true + n_eik,)
+    with torch.no_grad():
+        y = m.implicit_network(out['points'][hit & true])
+    assert torch.allclose(out['surf_indicator_output'][:n_true], y[:, 1], rtol=1e-5, atol=1e-6)
+    N = int(hit.sum())
+    assert out['diff_surf_pts'].shape == (N, 3) and torch.equal(out['diff_surf_pts'], out['points'][hit])
+    lo = IDRLoss()(out, {k: t(v) for k, v in gt.items()}, 0.3, B)
+    lo['loss'].backward()
+    g = torch.cat([p.grad.flatten() for p in m.parameters()])
+    assert torch.isfinite(g).all() and float(g.norm()) > 0
