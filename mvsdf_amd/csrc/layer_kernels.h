@@ -538,40 +538,45 @@ __global__ __launch_bounds__(64 * NW) void k_chain_e1(ChainArgs a) {
         int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
         f32x4 acc[MT][NTW];
         mv_zero_acc<MT, NTW>(acc);
-        __syncthreads();
+        // side inputs of the epilogue (z_l, u_{l+1}): requested BEFORE the GEMM so their latency hides behind it
+        float zz[NTW][MT][4], uu[NTW][MT][4];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int col = (ct0 + t) * 16 + r;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = row0 + m * 16 + 4 * q + i;
+                    zz[t][m][i] = 0.f; uu[t][m][i] = 0.f;
+                    if (t < ntw && col < N && row < a.M) {
+                        zz[t][m][i] = a.Z[l][(size_t)row * N + col];
+                        uu[t][m][i] = top ? a.w_last_row0[col] : a.U[l + 1][(size_t)row * N + col];
+                    }
+                }
+        }
+        mv_barrier_lds();                                        // the tile lives in LDS; the side loads above stay in flight
         if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
-        __syncthreads();
+        mv_barrier_lds();
         const int ldn = a.net.L[l + 1].K;                        // row length of vbar_{l+1}
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             if (t < ntw) {
                 const int col = (ct0 + t) * 16 + r;
                 if (col < N) {
-                    float zz[MT][4], uu[MT][4];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int row = row0 + m * 16 + 4 * q + i;
-                            zz[m][i] = 0.f; uu[m][i] = 0.f;
-                            if (row < a.M) {
-                                zz[m][i] = a.Z[l][(size_t)row * N + col];
-                                uu[m][i] = top ? a.w_last_row0[col] : a.U[l + 1][(size_t)row * N + col];
-                            }
-                        }
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int rr = m * 16 + 4 * q + i, row = row0 + rr;
                             const float sb = acc[m][t][i];
-                            const float sig = dm_sigmoid100(zz[m][i]);
+                            const float sig = dm_sigmoid100(zz[t][m][i]);
                             float ub = sig * sb;
                             if (to_skip) ub = dm_div_sqrt2(ub);
                             act[rr * S + mv_perm(col)] = ub;
                             if (row < a.M) {
                                 a.VB[l + 1][(size_t)row * ldn + col] = ub;
-                                a.ZB2o[l][(size_t)row * N + col] = uu[m][i] * sb * mv_sigmoid_prime100(zz[m][i], sig);
+                                a.ZB2o[l][(size_t)row * N + col] = uu[t][m][i] * sb * mv_sigmoid_prime100(zz[t][m][i], sig);
                             }
                         }
                 }

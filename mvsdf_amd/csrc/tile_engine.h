@@ -24,6 +24,11 @@
 __device__ __forceinline__ float mv_act(float z) { return (MV_ABLATE & 1) ? z * 0.5f : dm_softplus100(z); }
 __device__ __forceinline__ dm_f2 mv_act2(dm_f2 z) { return (MV_ABLATE & 1) ? z * dm2_s(0.5f) : dm2_softplus100(z); }
 
+// Workgroup barrier that orders LDS traffic only: waits for this wave's outstanding LDS operations (lgkmcnt), NOT for its global loads /
+// stores.  __syncthreads() also drains vmcnt, which forces global loads issued early (to overlap a GEMM) to land before the barrier.
+// Use only where the data exchanged between the waves at this point lives in LDS.
+__device__ __forceinline__ void mv_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int MTc, int NTW>
 __device__ __forceinline__ void mv_zero_acc(f32x4 (&acc)[MTc][NTW]) {
 #pragma unroll
