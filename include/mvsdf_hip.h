@@ -191,6 +191,20 @@ int mvsdf_step_backward_inputs(int stage, int E, int N, int Nout, int n_true, in
                                const long long* true_rows, const float* d_eo, const float* d_gth, const float* d_si, int nd, const int* d_src,
                                const int* d_cnt, int ne, const int* e_src, const int* e_cnt, float* dy, float* dn, void* stream);
 
+/* ---- phase-0 depth-surface sampling of IDRNetwork.forward (idr.py:226-247, my_utils.py:71-95) ----
+ * Two uniformly random n-subsets (without replacement) of the depth pixels (depths[N][H][W] > 0) whose unprojected, normalised point
+ * -- set 0 -- or jittered point (+U(-jitter_rad, jitter_rad)^3) -- set 1 -- lies inside the box |x| < bb: the kernel visits the
+ * pixels in a keyed random order and unprojects only the candidates it visits.  kinv[N][3][3] / einv[N][4][4]: inverse intrinsics /
+ * extrinsics of the depth cameras; size[1], center[3] on the device.  idx[2][n] (pre-filled by the caller with a value >= N*H*W)
+ * receives the pixel indices in visiting order, counts[2] how many were found (n unless the image holds fewer valid pixels).
+ * mvsdf_dsurf_points turns the SORTED indices (the reference sorts, np.sort) into the points pts_on[n][3], pts_jit[n][3]; same
+ * seed = same jitter as during the selection. */
+int mvsdf_dsurf_select(const float* depths, const float* kinv, const float* einv, int N, int H, int W, const float* size, const float* center,
+                       float bb, float jitter_rad, unsigned long long seed, int n, long long* idx, long long* counts, void* stream);
+int mvsdf_dsurf_points(const float* depths, const float* kinv, const float* einv, int N, int H, int W, const float* size, const float* center,
+                       float bb, float jitter_rad, unsigned long long seed, int n, const long long* idx_sorted, const long long* counts,
+                       float* pts_on, float* pts_jit, void* stream);
+
 /* ---- optimiser tail on flat buffers (idr_train.py:289-302: all_norm, clip_grad_norm_(grad_cap), Adam.step), two launches ----
  * p, g, m, v: flat fp32 buffers of n elements (parameters, gradients, exp_avg, exp_avg_sq).  step >= 1 is the Adam step count AFTER
  * this update.  max_norm <= 0 disables clipping; otherwise g is scaled in place by min(1, max_norm / (||g|| + 1e-6)).

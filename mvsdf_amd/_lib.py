@@ -58,7 +58,7 @@ EXPORTS = [
     'mvsdf_sdf_col0', 'mvsdf_camera_rays', 'mvsdf_sphere_intersection', 'mvsdf_trace_workspace_bytes', 'mvsdf_trace_workspace_bytes_n', 'mvsdf_trace', 'mvsdf_trace_stage', 'mvsdf_det_math',
     'mvsdf_sdf_ctx_floats', 'mvsdf_sdf_forward', 'mvsdf_sdf_bwd_ws_floats', 'mvsdf_sdf_backward',
     'mvsdf_feat_corr', 'mvsdf_depth_carve', 'mvsdf_loss_terms', 'mvsdf_adam_ws_floats', 'mvsdf_adam_step',
-    'mvsdf_partition_rays', 'mvsdf_step_outputs', 'mvsdf_step_backward_inputs',
+    'mvsdf_partition_rays', 'mvsdf_step_outputs', 'mvsdf_step_backward_inputs', 'mvsdf_dsurf_select', 'mvsdf_dsurf_points',
     'mvsdf_render_ctx_floats', 'mvsdf_render_bwd_ws_floats', 'mvsdf_render_forward', 'mvsdf_render_backward',
 ]
 

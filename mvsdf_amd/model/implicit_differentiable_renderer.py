@@ -146,22 +146,17 @@ class IDRNetwork(nn.Module):
 
     # ------------------------------------------------------------------------------------------------------------
     def _dsurf_samples(self, input, n_dsurf_points, bb):
-        """Phase-0 depth-surface sampling (idr.py:226-247): unproject every depth pixel, normalise, jitter, subsample."""
-        from ..utils.my_utils import get_pixel_grids, idx_cam2world, idx_img2cam
+        """Phase-0 depth-surface sampling (idr.py:226-247): two random n-subsets of the depth pixels whose unprojected (resp. jittered)
+        point lies in the eikonal box, sorted by pixel.  -> (on-surface [n,3], jittered [n,3], counts [2] on the device).
+        One selection launch + a sort + one unprojection launch (csrc/sample_kernels.hip) instead of unprojecting every pixel and a
+        host-side np.random.choice; the seed comes from torch's CPU generator (torch.manual_seed reproduces a run)."""
         depths, depth_cams = input['depths'], input['depth_cams']
-        center, size = input['center'][:1], input['size'][:1]
-        depths_pack, cams_pack = [a.view(-1, *a.size()[2:]) for a in (depths, depth_cams)]
-        hom = idx_cam2world(idx_img2cam(get_pixel_grids(*depths.size()[-2:], device=depths.device).unsqueeze(0), depths_pack, cams_pack), cams_pack)
-        pts = hom[depths_pack[:, 0] > 0][:, :3, 0]
-        pts_n = (pts - center) / size * 2
-        jitter_rad = 0.1
-        jit = pts_n + torch.rand_like(pts_n) * jitter_rad * 2 - jitter_rad
-        out = []
-        for ds in (pts_n, jit):
-            inbound = ds[(ds.abs() < bb).float().sum(-1) > 2.9]
-            idx = np.sort(np.random.choice(inbound.size()[0], n_dsurf_points, replace=False))
-            out.append(inbound[torch.from_numpy(idx).to(ds.device)])
-        return out
+        depths_pack = depths.reshape(-1, depths.shape[-2], depths.shape[-1])
+        cams_pack = depth_cams.reshape(-1, 2, 4, 4)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        jitter_rad = 0.1                                         # hard-coded in the reference (idr.py:228)
+        on, jit, counts, _ = ops.dsurf_samples(depths_pack, cams_pack, input['size'][:1], input['center'][:1], bb, jitter_rad, seed, n_dsurf_points)
+        return on, jit, counts
 
     def forward(self, input, train_progress=None):
         intrinsics, uv, pose = input['intrinsics'], input['uv'], input['pose']
@@ -174,6 +169,13 @@ class IDRNetwork(nn.Module):
         dev = ray_dirs.device
 
         net, ws, bs = self.implicit_network.fold()              # one weight-norm fold per step
+        n_dsurf_points, dsurf = 0, None
+        if self.training:
+            assert train_progress is not None
+            if any([conf.d_use_dsurf_on(train_progress), conf.d_use_dsurf_jitter(train_progress),
+                    conf.eik_use_dsurf_on(train_progress), conf.eik_use_dsurf_jitter(train_progress)]):
+                n_dsurf_points = R // 2                          # independent of the tracer: enqueued ahead of it
+                dsurf = self._dsurf_samples(input, n_dsurf_points, self.object_bounding_sphere)
         # The hit mask is final once the ray sampler has run; the secant / min-sdf launch that follows only moves points.  In training
         # the hit counts are copied to pinned host memory between the two, so the host learns them while that launch (and the fused
         # evaluation enqueued behind it) still runs.
@@ -183,9 +185,12 @@ class IDRNetwork(nn.Module):
             # stable row partition (hit rays first) + both counts in one launch; the counts travel to pinned memory right away
             sync['part'] = ops.partition_rays(net_mask, object_mask if conf.use_mask else None, object_mask_true, ray_dirs)
             if self._counts_host is None:
-                self._counts_host = torch.empty(2, dtype=torch.int64).pin_memory()
+                self._counts_host = torch.empty(4, dtype=torch.int64).pin_memory()
                 self._counts_event = torch.cuda.Event()
-            self._counts_host.copy_(sync['part'][3], non_blocking=True)
+            if dsurf is None:
+                self._counts_host[:2].copy_(sync['part'][3], non_blocking=True)
+            else:                                                # + how many depth-surface samples each set found
+                self._counts_host.copy_(torch.cat([sync['part'][3], dsurf[2]]), non_blocking=True)
             self._counts_event.record()
 
         with torch.no_grad():
@@ -206,17 +211,12 @@ class IDRNetwork(nn.Module):
         pts_sorted = points[perm]                                # hit rays first, then the others
 
         if self.training:
-            assert train_progress is not None
             bb = self.object_bounding_sphere
             n_eik_points = R // 2
             eikonal_points = torch.empty(n_eik_points, 3).uniform_(-bb, bb).to(dev, non_blocking=True)     # idr.py:216-221
-            use_dsurf = any([conf.d_use_dsurf_on(train_progress), conf.d_use_dsurf_jitter(train_progress),
-                             conf.eik_use_dsurf_on(train_progress), conf.eik_use_dsurf_jitter(train_progress)])
-            if use_dsurf:
-                n_dsurf_points = R // 2
-                dsurf_on_sample, dsurf_jitter_sample = self._dsurf_samples(input, n_dsurf_points, bb)
+            if dsurf is not None:
+                dsurf_on_sample, dsurf_jitter_sample = dsurf[0], dsurf[1]
             else:
-                n_dsurf_points = 0
                 dsurf_on_sample = torch.zeros(0, 3, device=dev)
                 dsurf_jitter_sample = torch.zeros(0, 3, device=dev)
             E = n_eik_points + 2 * n_dsurf_points
@@ -228,6 +228,8 @@ class IDRNetwork(nn.Module):
             rnet, rws, rbs = self.rendering_network.fold()       # independent of N: enqueued before the wait
             self._counts_event.synchronize()                     # the one host wait of the forward: output shapes depend on the counts
             N, n_true = int(self._counts_host[0]), int(self._counts_host[1])
+            if dsurf is not None and min(int(self._counts_host[2]), int(self._counts_host[3])) < n_dsurf_points:
+                raise ValueError("Cannot take a larger sample than population when 'replace=False'")       # np.random.choice, idr.py:244
             hit_idx = perm[:N]
             st = Fn.StepState()
             st.net, st.x_eval, st.y_eval, st.n_eval, st.saved = net, x_eval, y_eval, n_eval, saved

@@ -374,3 +374,24 @@ def step_backward_inputs(stage, E, N, Nout, n_true, n_eik, din, din_feat0, din_n
                                            1 if use_geo else 0, o(d_diff), o(dx), ptr(view_sorted), ptr(n_eval), ptr(true_rows), o(d_eo),
                                            o(d_gth), o(d_si), nd, ds, dc, ne, es, ec, ptr(dy), ptr(dn), stream_of(dy)),
           'mvsdf_step_backward_inputs')
+
+
+# ---- phase-0 depth-surface sampling (csrc/sample_kernels.hip)
+def dsurf_samples(depths, depth_cams, size, center, bb, jitter_rad, seed, n):
+    """depths [N,1,H,W] (or [N,H,W]), depth_cams [N,2,4,4] -> (pts_on [n,3], pts_jit [n,3], counts [2] device int64, idx_sorted [2,n]).
+    counts[s] < n means the depth maps hold fewer than n valid in-box pixels for set s (the reference's np.random.choice raises there)."""
+    depths = _f32(depths.reshape(depths.shape[0], depths.shape[-2], depths.shape[-1]))
+    N, H, W = depths.shape
+    dev = depths.device
+    kinv = torch.linalg.inv(depth_cams[:, 1, :3, :3]).contiguous()                # my_utils.py:84
+    einv = torch.linalg.inv(depth_cams[:, 0]).contiguous()                        # my_utils.py:93
+    size, center = _f32(size.reshape(-1)[:1]), _f32(center.reshape(-1)[:3])
+    idx = torch.full((2, n), 1 << 62, dtype=torch.int64, device=dev)
+    counts = torch.empty(2, dtype=torch.int64, device=dev)
+    geo = (ptr(depths), ptr(kinv), ptr(einv), N, H, W, ptr(size), ptr(center), C.c_float(bb), C.c_float(jitter_rad), C.c_ulonglong(seed), n)
+    check(lib().mvsdf_dsurf_select(*geo, ptr(idx), ptr(counts), stream_of(depths)), 'mvsdf_dsurf_select')
+    idx_sorted = torch.sort(idx, dim=1).values                                    # reference: np.sort(sample_idx)
+    pts_on = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    pts_jit = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    check(lib().mvsdf_dsurf_points(*geo, ptr(idx_sorted), ptr(counts), ptr(pts_on), ptr(pts_jit), stream_of(depths)), 'mvsdf_dsurf_points')
+    return pts_on, pts_jit, counts, idx_sorted

@@ -359,3 +359,25 @@ def depth_loss(eik_points, eik_output, depths, depth_cams, size, center, far_thr
     near = np.abs(dist_r) < near_thresh
     w = (far * far_att + ~far) * (near * near_att + ~near) * in_range
     return (np.abs(np.asarray(eik_output, np.float64) + dist_r) * w).mean(), dist_r, w
+
+
+def dsurf_unproject(depths, depth_cams, size, center):
+    """Phase-0 depth-surface points (reference idr.py:234-238 with my_utils.py:71-95): every depth pixel (b, y, x) unprojected through
+    the inverse intrinsics / extrinsics of its depth camera and normalised with (p - center) / size * 2.
+    depths [N,H,W], depth_cams [N,2,4,4] -> (points [N,H,W,3] float64, valid [N,H,W] = depth > 0)."""
+    depths = np.asarray(depths, np.float64)
+    cams = np.asarray(depth_cams, np.float64)
+    N, H, W = depths.shape
+    xs, ys = np.meshgrid(np.arange(W) + 0.5, np.arange(H) + 0.5)               # get_pixel_grids
+    pix = np.stack([xs, ys, np.ones_like(xs)], -1)                             # H W 3
+    out = np.zeros((N, H, W, 3))
+    for n in range(N):
+        kinv = np.linalg.inv(cams[n, 1, :3, :3])
+        einv = np.linalg.inv(cams[n, 0])
+        ic = pix @ kinv.T                                                      # idx_img2cam
+        ic = ic / (ic[..., 2:3] + 1e-9) * depths[n][..., None]
+        hom = np.concatenate([ic, np.ones_like(ic[..., :1])], -1)
+        w = hom @ einv.T                                                       # idx_cam2world
+        w = w / (w[..., 3:4] + 1e-9)
+        out[n] = (w[..., :3] - np.asarray(center, np.float64).reshape(-1)[:3]) / float(np.asarray(size).reshape(-1)[0]) * 2
+    return out, depths > 0

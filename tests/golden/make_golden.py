@@ -313,7 +313,33 @@ def g_render_bwd(W, n, seed):
     save('render_bwd_w%d' % W, **res)
 
 
+def g_dsurf(seed):
+    """Phase-0 depth-surface points (idr.py:234-238): every depth pixel unprojected with the reference's my_utils helpers + the
+    in-box tests of idr.py:242 (on-surface points; the jitter is RNG-driven and checked distributionally in the GPU test)."""
+    from utils.my_utils import get_pixel_grids, idx_cam2world, idx_img2cam
+    B, hw = 3, (24, 32)
+    inp, _ = synth.make_batch(B, 8, 1, seed=seed, feat_hw=hw, with_features=False)
+    rs = np.random.RandomState(seed + 77)
+    depths = inp['depths'].copy()                                              # [B,1,1,h,w]
+    depths *= rs.uniform(0.6, 1.4, size=depths.shape).astype(np.float32)       # a bumpy surface: some points leave the box
+    depths[rs.rand(*depths.shape) < 0.3] = 0.0                                 # holes (depth <= 0 is invalid)
+    d, c = T(depths), T(inp['depth_cams'])
+    center, size = T(inp['center'])[:1], T(inp['size'])[:1]
+    dp, cp = [a.view(-1, *a.size()[2:]) for a in (d, c)]
+    hom = idx_cam2world(idx_img2cam(get_pixel_grids(*d.size()[-2:], cuda=False).unsqueeze(0), dp, cp), cp)   # N h w 4 1
+    pts_all = (hom[..., :3, 0] - center) / size * 2                            # N h w 3 (normalised, every pixel)
+    valid = dp[:, 0] > 0
+    bb = 1.0
+    inbound = ((pts_all.abs() < bb).float().sum(-1) > 2.9) & valid
+    save('dsurf_unproject', seed=seed, depths=depths, depth_cams=inp['depth_cams'], size=inp['size'], center=inp['center'], bb=bb,
+         pts_norm=pts_all.numpy(), valid=valid.numpy(), inbound=inbound.numpy())
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1:                                                       # python make_golden.py g_dsurf 0  (one fixture)
+        globals()[sys.argv[1]](*[int(v) for v in sys.argv[2:]])
+        sys.exit(0)
+    g_dsurf(0)
     g_sdf(64, 1000, 0)
     g_sdf(256, 256, 0)
     g_render(64, 300, 0)

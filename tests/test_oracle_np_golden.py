@@ -86,3 +86,15 @@ def test_feat_corr_loss_and_gradient():
             p2[i, c] -= eps
             fd = (f(p1) - f(p2)) / (2 * eps)
             assert abs(fd - g['dpoints'][i, c]) < 2e-3 * max(1.0, abs(g['dpoints'][i, c])) + 2e-6, (i, c, fd, g['dpoints'][i, c])
+
+
+def test_dsurf_unprojection_vs_reference_golden():
+    """oracle_np.dsurf_unproject == the reference's idx_img2cam / idx_cam2world chain (idr.py:234-238) on every pixel."""
+    g = golden('dsurf_unproject')
+    d = g['depths'].reshape(-1, *g['depths'].shape[-2:])
+    pts, valid = ON.dsurf_unproject(d, g['depth_cams'].reshape(-1, 2, 4, 4), g['size'][:1], g['center'][:1])
+    assert np.array_equal(valid, g['valid'])
+    ref = g['pts_norm']
+    assert np.abs(pts[valid] - ref[valid]).max() < 2e-5 * max(1.0, np.abs(ref[valid]).max())
+    inb = (np.abs(pts) < float(g['bb'])).all(-1) & valid
+    assert (inb != g['inbound']).sum() <= 2                                     # only points within fp32 rounding of the box face may differ
