@@ -173,3 +173,19 @@ def test_partial_object_mask_selects_true_hits_for_the_surface_indicator():
     lo['loss'].backward()
     g = torch.cat([p.grad.flatten() for p in m.parameters()])
     assert torch.isfinite(g).all() and float(g.norm()) > 0
+
+
+def test_sdf_grid_for_mesh_extraction_matches_pointwise_eval(oracle):
+    """utils/plots.sdf_on_uniform_grid (plots.py:112-119, 294-307): same values, same point order as evaluating get_grid_uniform's
+    point list; bit-exact vs the CPU oracle of the tracing MLP on a sample."""
+    from mvsdf_amd.utils.plots import get_grid_uniform, sdf_on_uniform_grid
+    m = _model(64).eval()
+    sdf = m.implicit_network.native_sdf()
+    res = 24
+    z = sdf_on_uniform_grid(sdf, res, chunk=5000)
+    pts = get_grid_uniform(res)['grid_points']
+    assert z.shape == (res ** 3,) and np.array_equal(z, sdf(pts).cpu().numpy())
+    sd = synth.make_state_dict(64, 0)
+    sel = np.random.RandomState(0).choice(res ** 3, 500, replace=False)
+    want = oracle.sdf_forward(oracle.Net(sd), pts.cpu().numpy()[sel], ncols=1)[:, 0]
+    assert np.array_equal(z[sel], want)
