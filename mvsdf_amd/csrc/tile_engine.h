@@ -165,9 +165,9 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
             const int col = (ct0 + t) * 16 + r;
             bv_[t] = (t < ntw && col < L.N) ? L.bias[col] : 0.0f;
         }
-        __syncthreads();                                      // inputs of layer l complete
+        mv_barrier_lds();                                     // inputs of layer l complete (LDS); the bias loads stay in flight
         if (ntw > 0 && !(MV_ABLATE & 2)) mv_gemm_dispatch<MTc, NTW>(L, act, S, ct0, ntw, acc, lane);
-        __syncthreads();                                      // every wave done reading act (in-place update)
+        mv_barrier_lds();                                     // every wave done reading act (in-place update)
         if (last) {
             if (w == 0 && r == 0) {
                 const float b0 = bv_[0];
