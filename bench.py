@@ -99,8 +99,8 @@ def cpu_baseline(rays_per_view=None, views=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)          # ~3 ms per step: the default run still takes seconds
+    ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     a = ap.parse_args()
 

@@ -21,6 +21,9 @@ def tick(name, t0):
 _item = torch.Tensor.item
 def timed_item(self):
     t0 = time.perf_counter(); r = _item(self); acc['  (item wait)'] = acc.get('  (item wait)', 0.0) + time.perf_counter() - t0; return r
+_evs = torch.cuda.Event.synchronize
+def timed_evs(self):
+    t0 = time.perf_counter(); r = _evs(self); acc['  (count-event wait)'] = acc.get('  (count-event wait)', 0.0) + time.perf_counter() - t0; return r
 def step():
     t = time.perf_counter()
     opt.zero_grad(); t = tick('zero', t)
@@ -31,6 +34,7 @@ def step():
 for _ in range(10): step()
 torch.cuda.synchronize(); acc.clear()
 torch.Tensor.item = timed_item
+torch.cuda.Event.synchronize = timed_evs
 n = 50
 t0 = time.perf_counter()
 for _ in range(n): step()
