@@ -48,8 +48,10 @@ def make_inputs(dev, seed):
     inp, gt = synth.make_batch(B, P, V, seed=seed, feat_hw=FEAT_HW, with_features=False)
     g = torch.Generator(device=dev).manual_seed(1234 + seed)
     base = torch.randn(1, 1, 32, 1, 1, generator=g, device=dev)
-    noise = torch.randn(B * (1 + V), 32, FEAT_HW[0] + 4, FEAT_HW[1] + 4, generator=g, device=dev)
-    f = torch.nn.functional.avg_pool2d(noise, 5, stride=1).view(B, 1 + V, 32, *FEAT_HW) * 2.4 + base
+    f = torch.empty(B, 1 + V, 32, *FEAT_HW, device=dev)
+    for b in range(B):                                         # per view: keeps every op below 2^31 elements at the larger configs
+        noise = torch.randn(1 + V, 32, FEAT_HW[0] + 4, FEAT_HW[1] + 4, generator=g, device=dev)
+        f[b] = torch.nn.functional.avg_pool2d(noise, 5, stride=1) * 2.4 + base[0]
     del noise
     to = lambda d: {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in d.items()}
     inp, gt = to(inp), to(gt)

@@ -60,7 +60,9 @@ class RayTracing(nn.Module):
         if minsdf_steps is not None:
             minsdf_steps = minsdf_steps.to(dev, non_blocking=True)
         R = ray_directions.shape[0] * ray_directions.shape[1]
-        mt = self.mt or (1 if R <= 4096 else 2)
+        # rays per sphere-tracing workgroup = 8 * mt: one row tile per CU while the batch is small (latency-shaped), 4 tiles once the
+        # chip is over-subscribed (finer compaction of the rays still active; measured +6 % at 8k-32k rays)
+        mt = self.mt or int(os.environ.get('MVSDF_MT', '0')) or (1 if R <= 4096 else 4)
         mt_samples = self.mt_samples or int(os.environ.get('MVSDF_MT_SAMPLES', '2'))
         pts, mask, dists, counters = ops.trace(net, cam_loc, ray_directions, object_mask, self._params(), self.training, intervals,
                                                minsdf_steps, mt=mt, mt_samples=mt_samples, events=self.events,
