@@ -135,9 +135,11 @@ size_t mvsdf_render_ctx_floats(const MvsdfNetDesc* net, int N);
 size_t mvsdf_render_bwd_ws_floats(const MvsdfNetDesc* net, int N);
 int mvsdf_render_forward(const MvsdfNetDesc* net, const float* points, const float* view, const float* normals, const float* feat,
                          int ldfeat, int N, int multires_view, float* rgb, float* ctx, void* stream);
-/* din[N][K0]: adjoint of the concatenated input (points = [:,0:3], normals = [:,3+dv:6+dv], feat = [:,6+dv:], dv = 3+6*multires_view) */
-int mvsdf_render_backward(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, int N, const float* drgb, const float* ctx, float* dW_cat,
-                          float* db_cat, float* din, float* ws, void* stream);
+/* din[N][K0]: adjoint of the concatenated input (points = [:,0:3], normals = [:,3+dv:6+dv], feat = [:,6+dv:], dv = 3+6*multires_view).
+ * ctx was made by mvsdf_render_forward over Nctx >= N rows; the backward covers its first N rows (a training step renders every sorted
+ * ray before the host knows how many of them hit). */
+int mvsdf_render_backward(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, int N, int Nctx, const float* drgb, const float* ctx,
+                          float* dW_cat, float* db_cat, float* din, float* ws, void* stream);
 
 /* ---- IDRLoss.get_feat_loss_corr (model/loss.py:115-165 + utils/my_utils.py:98-110,152-165 + F.grid_sample) ----
  * forward AND analytic d(loss)/d(points) in one launch (feature maps are constants).  pts[N][3] = diff_surf_pts (hit points,
@@ -173,23 +175,27 @@ int mvsdf_loss_terms(const float* rgb, const float* rgb_gt, const uint8_t* rgb_m
 int mvsdf_partition_rays(const uint8_t* net_mask, const uint8_t* object_mask, const uint8_t* true_mask, const float* ray_dirs, int R,
                          long long* perm, long long* inv, long long* true_rows, long long* counts, float* view_sorted, void* stream);
 /* Output tensors of the training forward gathered from ONE fused evaluation over the rows [E sample points | R rays sorted, hit first]
- * (x_eval[E+R][3], y_eval[E+R][Nout], n_eval[E+R][3]): rgb_values[R][3] (rgb_hit[N][3] scattered, 1 elsewhere; idr.py:302-304),
- * sdf_output[R], diff_pts[N][3], and for the row ranges (d_src[i], d_cnt[i]) / (e_src[i], e_cnt[i]) of the evaluation (<= 4 each,
- * idr.py:258-286): eik_out, points_hom[.][4] (x, 1) and grad_theta[.][3]; surf[n_true + n_eik] = column 1 at the true-mask hit rows, then
- * at the first n_eik sample rows (idr.py:270-276). */
-int mvsdf_step_outputs(int R, int E, int N, int Nout, int n_true, int n_eik, const float* x_eval, const float* y_eval, const float* n_eval,
-                       const long long* perm, const long long* inv, const long long* true_rows, const float* rgb_hit, int nd, const int* d_src,
-                       const int* d_cnt, int ne, const int* e_src, const int* e_cnt, float* rgb_values, float* sdf_output, float* diff_pts,
-                       float* eik_out, float* points_hom, float* grad_theta, float* surf, void* stream);
-/* Upstream gradients dy[E+N][Nout], dn[E+N][3] of the fused SDF backward.  stage 0: zero + the rendering net's input adjoint din[N][din_ld]
- * (features from column din_feat0 -> dy[:, 2:], normals from din_nrm0 -> dn when use_geo).  stage 1 (after the input-adjoint pass produced
- * dx[N][3]): SampleNetwork's scalar -(xbar . v)/(n . v), xbar = d_diff + din[:, 0:3] (use_geo) + dx (sample_network.py:10-20), added to
- * dy[E+i][0]; d_eo / d_gth / d_si (upstream of eikonal_output / grad_theta / surf_indicator_output, any may be NULL) scattered over the
- * same row ranges as mvsdf_step_outputs. */
-int mvsdf_step_backward_inputs(int stage, int E, int N, int Nout, int n_true, int n_eik, const float* din, int din_ld, int din_feat0,
+ * (x_eval[E+R][3], y_eval[E+R][Nout], n_eval[E+R][3]).  The sample rows are [n_eik eikonal | n_ds on-surface | n_ds jittered]
+ * (E = n_eik + 2 n_ds).  Point groups in the reference's order: 0 = hit rays, 1 = eikonal, 2 = on-surface, 3 = jittered;
+ * d_mask / e_mask (bit g = group g) select the groups of the depth term (eikonal_output, eikonal_points_hom) and of the eikonal term
+ * (grad_theta), idr.py:258-286.  counts (DEVICE, {N, n_true} from mvsdf_partition_rays): the kernel reads the hit counts there, so it
+ * can be enqueued before the host knows them; every output is sized for the worst case (N = R) and the first
+ * [N + selected samples] rows are valid.  rgb_values[R][3] (rgb_sorted[r] for sorted rows r < N, 1 elsewhere; idr.py:302-304),
+ * sdf_output[R], diff_pts[R][3], eik_out[.], points_hom[.][4] (x, 1), grad_theta[.][3], surf[R + n_eik] = column 1 at the true-mask hit
+ * rows, then at the n_eik eikonal rows (idr.py:270-276). */
+int mvsdf_step_outputs(int R, int n_eik, int n_ds, int Nout, const long long* counts, const float* x_eval, const float* y_eval,
+                       const float* n_eval, const long long* inv, const long long* true_rows, const float* rgb_sorted, int d_mask,
+                       int e_mask, float* rgb_values, float* sdf_output, float* diff_pts, float* eik_out, float* points_hom, float* grad_theta,
+                       float* surf, void* stream);
+/* Upstream gradients dy[E+N][Nout], dn[E+N][3] of the fused SDF backward (N, n_true known on the host by now).  stage 0: zero + the
+ * rendering net's input adjoint din[N][din_ld] (features from column din_feat0 -> dy[:, 2:], normals from din_nrm0 -> dn when use_geo).
+ * stage 1 (after the input-adjoint pass produced dx[N][3]): SampleNetwork's scalar -(xbar . v)/(n . v), xbar = d_diff + din[:, 0:3]
+ * (use_geo) + dx (sample_network.py:10-20), added to dy[E+i][0]; d_eo / d_gth / d_si (upstream of eikonal_output / grad_theta /
+ * surf_indicator_output, any may be NULL) scattered over the same groups as mvsdf_step_outputs. */
+int mvsdf_step_backward_inputs(int stage, int n_eik, int n_ds, int N, int Nout, int n_true, const float* din, int din_ld, int din_feat0,
                                int din_nrm0, int use_geo, const float* d_diff, const float* dx, const float* view_sorted, const float* n_eval,
-                               const long long* true_rows, const float* d_eo, const float* d_gth, const float* d_si, int nd, const int* d_src,
-                               const int* d_cnt, int ne, const int* e_src, const int* e_cnt, float* dy, float* dn, void* stream);
+                               const long long* true_rows, const float* d_eo, const float* d_gth, const float* d_si, int d_mask, int e_mask,
+                               float* dy, float* dn, void* stream);
 
 /* ---- phase-0 depth-surface sampling of IDRNetwork.forward (idr.py:226-247, my_utils.py:71-95) ----
  * Two uniformly random n-subsets (without replacement) of the depth pixels (depths[N][H][W] > 0) whose unprojected, normalised point

@@ -547,17 +547,17 @@ int mvsdf_render_forward(const MvsdfNetDesc* d, const float* points, const float
 
 /* Backward: drgb[N][3] -> dW_cat, db_cat, din[N][K0] (adjoint of the concatenated input; the caller slices
  * points = [:, 0:3], normals = [:, 3+dv : 6+dv], feat = [:, 6+dv :]). */
-int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, const float* drgb, const float* ctx, float* dW_cat,
+int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, int Nctx, const float* drgb, const float* ctx, float* dW_cat,
                           float* db_cat, float* din, float* ws, void* stream) {
     MvNet net, netT;
     int rc = mv_make_net_mode(d, &net, 1);
     if (rc) return rc;
     rc = mv_make_net_mode(dT, &netT, 2);
     if (rc) return rc;
-    if (!drgb || !ctx || !dW_cat || !db_cat || !din || !ws || N <= 0) return mv_fail(-1, "mvsdf_render_backward: bad arguments");
+    if (!drgb || !ctx || !dW_cat || !db_cat || !din || !ws || N <= 0 || Nctx < N) return mv_fail(-1, "mvsdf_render_backward: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int nl = net.n_layers, S = stride_for(net, netT);
-    const RenderLayout lo = render_layout(net, N);
+    const RenderLayout lo = render_layout(net, Nctx);        // the forward context holds Nctx rows; the backward covers the first N
     const RenderBwdLayout bl = render_bwd_layout(net, N);
     for (int l = nl - 1; l >= 0; --l) {                      // abar_l = zbar_l W_l ; zbar_{l-1} = abar_l . relu'(z_{l-1})
         LayerArgs a = base_args(netT.L[l], S, N);

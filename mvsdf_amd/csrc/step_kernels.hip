@@ -60,52 +60,61 @@ __global__ __launch_bounds__(1024) void k_partition_rays(const uint8_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Outputs of the training forward gathered from the fused evaluation (rows [samples (E) | rays sorted, hit first]):
-struct StepRanges { int n; int src[4]; int cnt[4]; };   // row ranges of the fused evaluation, concatenated in this order
+// Point groups of a training step in the reference's order (idr.py:253-257): 0 = hit rays (N, evaluation rows E..E+N),
+// 1 = eikonal samples (rows 0..n_eik), 2 = on-surface samples, 3 = jittered samples (n_ds rows each).  A term selects groups by mask.
+struct StepGroups { int n_eik, n_ds, E, N, mask; };
+__device__ __forceinline__ int mv_group_total(const StepGroups& g) {
+    return ((g.mask & 1) ? g.N : 0) + ((g.mask & 2) ? g.n_eik : 0) + ((g.mask & 4) ? g.n_ds : 0) + ((g.mask & 8) ? g.n_ds : 0);
+}
+// i-th row of the concatenation of the selected groups -> evaluation row
+__device__ __forceinline__ int mv_group_row(const StepGroups& g, int i) {
+    if (g.mask & 1) { if (i < g.N) return g.E + i; i -= g.N; }
+    if (g.mask & 2) { if (i < g.n_eik) return i; i -= g.n_eik; }
+    if (g.mask & 4) { if (i < g.n_ds) return g.n_eik + i; i -= g.n_ds; }
+    return g.n_eik + g.n_ds + i;
+}
+
+// Outputs of the training forward gathered from the fused evaluation (rows [samples (E) | rays sorted, hit first]).  N / n_true come
+// from DEVICE memory, so the launch does not wait for the host to learn them.
 struct StepOutArgs {
-    int R, E, N, Nout, n_true, n_eik;
+    int R, E, n_eik, n_ds, Nout, d_mask, e_mask;
+    const long long* counts;                                            // {N, n_true}
     const float* x_eval; const float* y_eval; const float* n_eval;      // [E+R][3], [E+R][Nout], [E+R][3]
-    const long long* perm; const long long* inv; const long long* true_rows;
-    const float* rgb_hit;                                               // [N][3] or null
-    StepRanges d, e;                                                    // depth-term rows (eikonal_output / eikonal_points_hom), eikonal-term rows
+    const long long* inv; const long long* true_rows;
+    const float* rgb_sorted;                                            // [R][3]: rendering-net output of every sorted ray row
     float* rgb_values;      // [R][3]
     float* sdf_output;      // [R]
-    float* diff_pts;        // [N][3]
-    float* eik_out;         // [sum d.cnt]
-    float* points_hom;      // [sum d.cnt][4]
-    float* grad_theta;      // [sum e.cnt][3]
-    float* surf;            // [n_true + n_eik]
+    float* diff_pts;        // [R][3], first N valid
+    float* eik_out;         // first (N if selected) + samples valid
+    float* points_hom;      // [.][4]
+    float* grad_theta;      // [.][3]
+    float* surf;            // first n_true + n_eik valid
 };
-__device__ __forceinline__ int mv_range_src(const StepRanges& g, int i) {
-    int o = 0;
-    for (int k = 0; k < g.n; ++k) { if (i < o + g.cnt[k]) return g.src[k] + (i - o); o += g.cnt[k]; }
-    return -1;
-}
 __global__ void k_step_outputs(StepOutArgs a) {
-    int nd = 0, ne = 0;
-    for (int k = 0; k < a.d.n; ++k) nd += a.d.cnt[k];
-    for (int k = 0; k < a.e.n; ++k) ne += a.e.cnt[k];
-    const int seg0 = a.R, seg1 = seg0 + a.N, seg2 = seg1 + nd, seg3 = seg2 + ne, seg4 = seg3 + a.n_true + a.n_eik;
+    const int N = (int)a.counts[0], n_true = (int)a.counts[1];
+    const StepGroups gd = {a.n_eik, a.n_ds, a.E, N, a.d_mask}, ge = {a.n_eik, a.n_ds, a.E, N, a.e_mask};
+    const int nd = mv_group_total(gd), ne = mv_group_total(ge);
+    const int seg0 = a.R, seg1 = seg0 + N, seg2 = seg1 + nd, seg3 = seg2 + ne, seg4 = seg3 + n_true + a.n_eik;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < seg4; i += gridDim.x * blockDim.x) {
         if (i < seg0) {                                                     // per ray: rgb (1 where not hit, idr.py:302-304), sdf_output
             const int pos = (int)a.inv[i];
-            const bool hit = pos < a.N && a.rgb_hit;
-            for (int c = 0; c < 3; ++c) a.rgb_values[3 * (size_t)i + c] = hit ? a.rgb_hit[3 * (size_t)pos + c] : 1.0f;
+            const bool hit = pos < N;
+            for (int c = 0; c < 3; ++c) a.rgb_values[3 * (size_t)i + c] = hit ? a.rgb_sorted[3 * (size_t)pos + c] : 1.0f;
             a.sdf_output[i] = a.y_eval[(size_t)(a.E + pos) * a.Nout];
         } else if (i < seg1) {
             const int k = i - seg0;
             for (int c = 0; c < 3; ++c) a.diff_pts[3 * (size_t)k + c] = a.x_eval[3 * (size_t)(a.E + k) + c];
         } else if (i < seg2) {
-            const int k = i - seg1, row = mv_range_src(a.d, k);
+            const int k = i - seg1, row = mv_group_row(gd, k);
             a.eik_out[k] = a.y_eval[(size_t)row * a.Nout];
             for (int c = 0; c < 3; ++c) a.points_hom[4 * (size_t)k + c] = a.x_eval[3 * (size_t)row + c];
             a.points_hom[4 * (size_t)k + 3] = 1.0f;
         } else if (i < seg3) {
-            const int k = i - seg2, row = mv_range_src(a.e, k);
+            const int k = i - seg2, row = mv_group_row(ge, k);
             for (int c = 0; c < 3; ++c) a.grad_theta[3 * (size_t)k + c] = a.n_eval[3 * (size_t)row + c];
         } else {
             const int k = i - seg3;
-            const int row = k < a.n_true ? a.E + (int)a.true_rows[k] : (k - a.n_true);
+            const int row = k < n_true ? a.E + (int)a.true_rows[k] : (k - n_true);
             a.surf[k] = a.y_eval[(size_t)row * a.Nout + 1];
         }
     }
@@ -117,14 +126,13 @@ __global__ void k_step_outputs(StepOutArgs a) {
 //   stage 1 (after it): SampleNetwork's scalar fbar_i = -(xbar_i . v_i) / (n_i . v_i) with xbar = d_diff + dp + dx (sample_network.py:10-20)
 //            added to dy[E+i][0]; d(eikonal_output) -> column 0, d(surf_indicator_output) -> column 1, d(grad_theta) -> dn.
 struct StepBwdArgs {
-    int E, N, Nout, Mb, n_true, n_eik, din_ld, din_feat0, din_nrm0, use_geo;
+    int E, N, Nout, Mb, n_true, n_eik, n_ds, d_mask, e_mask, din_ld, din_feat0, din_nrm0, use_geo;
     const float* din;                     // [N][din_ld] adjoint of the rendering net's input (null: none)
     const float* d_diff; const float* dx; // [N][3] (either may be null)
     const float* view_sorted;             // [R][3] = -ray direction of sorted row
     const float* n_eval;                  // [E+R][3]
     const long long* true_rows;
     const float* d_eo; const float* d_gth; const float* d_si;          // upstream of eikonal_output / grad_theta / surf (null: none)
-    StepRanges d, e;
     float* dy; float* dn;                 // [Mb][Nout], [Mb][3]
 };
 __global__ void k_step_bwd_stage0(StepBwdArgs a) {
@@ -144,12 +152,11 @@ __global__ void k_step_bwd_stage0(StepBwdArgs a) {
     }
 }
 __global__ void k_step_bwd_stage1(StepBwdArgs a) {
-    int nd = 0, ne = 0;
-    for (int k = 0; k < a.d.n; ++k) nd += a.d.cnt[k];
-    for (int k = 0; k < a.e.n; ++k) ne += a.e.cnt[k];
+    const StepGroups gd = {a.n_eik, a.n_ds, a.E, a.N, a.d_mask}, ge = {a.n_eik, a.n_ds, a.E, a.N, a.e_mask};
+    const int nd = mv_group_total(gd), ne = mv_group_total(ge);
     const int seg0 = a.N, seg1 = seg0 + (a.d_eo ? nd : 0), seg2 = seg1 + (a.d_gth ? ne : 0), seg3 = seg2 + (a.d_si ? a.n_true + a.n_eik : 0);
-    // the four groups touch disjoint (row, column) cells except fbar / d_eo on column 0 of the hit rows: fbar first (separate launch order
-    // is not available inside one kernel), so the hit-row d_eo cells are folded into the fbar thread instead.
+    // the groups touch disjoint (row, column) cells except fbar / d_eo on column 0 of the hit rows: the hit-row d_eo cells are folded
+    // into the fbar thread.
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < seg3; i += gridDim.x * blockDim.x) {
         if (i < seg0) {
             const int k = i, row = a.E + k;
@@ -162,16 +169,13 @@ __global__ void k_step_bwd_stage1(StepBwdArgs a) {
             }
             for (int c = 0; c < 3; ++c) { num += xb[c] * v[c]; dot += a.n_eval[3 * (size_t)row + c] * v[c]; }
             float add = -num / dot;
-            if (a.d_eo) {                                                    // the hit group of eikonal_output, if selected, starts at src = E
-                int o = 0;
-                for (int g = 0; g < a.d.n; ++g) { if (a.d.src[g] == a.E && k < a.d.cnt[g]) add += a.d_eo[o + k]; o += a.d.cnt[g]; }
-            }
+            if (a.d_eo && (a.d_mask & 1)) add += a.d_eo[k];                  // the hit group leads eikonal_output when selected
             a.dy[(size_t)row * a.Nout] += add;
         } else if (i < seg1) {
-            const int k = i - seg0, row = mv_range_src(a.d, k);
+            const int k = i - seg0, row = mv_group_row(gd, k);
             if (row < a.E) a.dy[(size_t)row * a.Nout] += a.d_eo[k];         // hit rows were handled above
         } else if (i < seg2) {
-            const int k = i - seg1, row = mv_range_src(a.e, k);
+            const int k = i - seg1, row = mv_group_row(ge, k);
             for (int c = 0; c < 3; ++c) a.dn[3 * (size_t)row + c] += a.d_gth[3 * (size_t)k + c];
         } else {
             const int k = i - seg2;
@@ -192,43 +196,35 @@ int mvsdf_partition_rays(const uint8_t* net_mask, const uint8_t* object_mask, co
     return mv_check(hipGetLastError(), "mvsdf_partition_rays");
 }
 
-static int fill_ranges(StepRanges& g, int n, const int* src, const int* cnt) {
-    if (n < 0 || n > 4 || (n > 0 && (!src || !cnt))) return -1;
-    g.n = n;
-    for (int k = 0; k < 4; ++k) { g.src[k] = k < n ? src[k] : 0; g.cnt[k] = k < n ? cnt[k] : 0; }
-    return 0;
-}
-
-int mvsdf_step_outputs(int R, int E, int N, int Nout, int n_true, int n_eik, const float* x_eval, const float* y_eval, const float* n_eval,
-                       const long long* perm, const long long* inv, const long long* true_rows, const float* rgb_hit, int nd, const int* d_src,
-                       const int* d_cnt, int ne, const int* e_src, const int* e_cnt, float* rgb_values, float* sdf_output, float* diff_pts,
-                       float* eik_out, float* points_hom, float* grad_theta, float* surf, void* stream) {
+int mvsdf_step_outputs(int R, int n_eik, int n_ds, int Nout, const long long* counts, const float* x_eval, const float* y_eval,
+                       const float* n_eval, const long long* inv, const long long* true_rows, const float* rgb_sorted, int d_mask,
+                       int e_mask, float* rgb_values, float* sdf_output, float* diff_pts, float* eik_out, float* points_hom, float* grad_theta,
+                       float* surf, void* stream) {
+    if (R <= 0 || n_eik < 0 || n_ds < 0 || !counts || !x_eval || !y_eval || !n_eval || !inv || !true_rows || !rgb_sorted || !rgb_values ||
+        !sdf_output || !diff_pts || !eik_out || !points_hom || !grad_theta || !surf || (d_mask & ~15) || (e_mask & ~15))
+        return mv_fail(-1, "mvsdf_step_outputs: bad arguments");
     StepOutArgs a;
     memset(&a, 0, sizeof(a));
-    if (fill_ranges(a.d, nd, d_src, d_cnt) || fill_ranges(a.e, ne, e_src, e_cnt)) return mv_fail(-1, "mvsdf_step_outputs: bad row ranges");
-    if (R <= 0 || E < 0 || N < 0 || N > R || !x_eval || !y_eval || !n_eval || !inv || !true_rows || !rgb_values || !sdf_output || (N > 0 && !rgb_hit))
-        return mv_fail(-1, "mvsdf_step_outputs: bad arguments");
-    a.R = R; a.E = E; a.N = N; a.Nout = Nout; a.n_true = n_true; a.n_eik = n_eik;
-    a.x_eval = x_eval; a.y_eval = y_eval; a.n_eval = n_eval; a.perm = perm; a.inv = inv; a.true_rows = true_rows; a.rgb_hit = rgb_hit;
+    a.R = R; a.E = n_eik + 2 * n_ds; a.n_eik = n_eik; a.n_ds = n_ds; a.Nout = Nout; a.d_mask = d_mask; a.e_mask = e_mask; a.counts = counts;
+    a.x_eval = x_eval; a.y_eval = y_eval; a.n_eval = n_eval; a.inv = inv; a.true_rows = true_rows; a.rgb_sorted = rgb_sorted;
     a.rgb_values = rgb_values; a.sdf_output = sdf_output; a.diff_pts = diff_pts; a.eik_out = eik_out; a.points_hom = points_hom;
     a.grad_theta = grad_theta; a.surf = surf;
-    int total = R + N + n_true + n_eik;
-    for (int k = 0; k < nd; ++k) total += d_cnt[k];
-    for (int k = 0; k < ne; ++k) total += e_cnt[k];
-    hipLaunchKernelGGL(k_step_outputs, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    const long long worst = 5ll * R + 3ll * a.E + n_eik;                  // rays + diff_pts + two group lists + surf at N = R
+    hipLaunchKernelGGL(k_step_outputs, dim3((unsigned)((worst + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return mv_check(hipGetLastError(), "mvsdf_step_outputs");
 }
 
-int mvsdf_step_backward_inputs(int stage, int E, int N, int Nout, int n_true, int n_eik, const float* din, int din_ld, int din_feat0,
+int mvsdf_step_backward_inputs(int stage, int n_eik, int n_ds, int N, int Nout, int n_true, const float* din, int din_ld, int din_feat0,
                                int din_nrm0, int use_geo, const float* d_diff, const float* dx, const float* view_sorted, const float* n_eval,
-                               const long long* true_rows, const float* d_eo, const float* d_gth, const float* d_si, int nd, const int* d_src,
-                               const int* d_cnt, int ne, const int* e_src, const int* e_cnt, float* dy, float* dn, void* stream) {
+                               const long long* true_rows, const float* d_eo, const float* d_gth, const float* d_si, int d_mask, int e_mask,
+                               float* dy, float* dn, void* stream) {
+    const int E = n_eik + 2 * n_ds;
+    if (n_eik < 0 || n_ds < 0 || N < 0 || E + N <= 0 || !dy || !dn || (stage != 0 && stage != 1) || (stage == 1 && N > 0 && (!view_sorted || !n_eval)) ||
+        (d_mask & ~15) || (e_mask & ~15))
+        return mv_fail(-1, "mvsdf_step_backward_inputs: bad arguments");
     StepBwdArgs a;
     memset(&a, 0, sizeof(a));
-    if (fill_ranges(a.d, nd, d_src, d_cnt) || fill_ranges(a.e, ne, e_src, e_cnt)) return mv_fail(-1, "mvsdf_step_backward_inputs: bad row ranges");
-    if (E < 0 || N < 0 || E + N <= 0 || !dy || !dn || (stage != 0 && stage != 1) || (stage == 1 && N > 0 && (!view_sorted || !n_eval)))
-        return mv_fail(-1, "mvsdf_step_backward_inputs: bad arguments");
-    a.E = E; a.N = N; a.Nout = Nout; a.Mb = E + N; a.n_true = n_true; a.n_eik = n_eik;
+    a.E = E; a.N = N; a.Nout = Nout; a.Mb = E + N; a.n_true = n_true; a.n_eik = n_eik; a.n_ds = n_ds; a.d_mask = d_mask; a.e_mask = e_mask;
     a.din = din; a.din_ld = din_ld; a.din_feat0 = din_feat0; a.din_nrm0 = din_nrm0; a.use_geo = use_geo;
     a.d_diff = d_diff; a.dx = dx; a.view_sorted = view_sorted; a.n_eval = n_eval; a.true_rows = true_rows;
     a.d_eo = d_eo; a.d_gth = d_gth; a.d_si = d_si; a.dy = dy; a.dn = dn;
@@ -238,9 +234,7 @@ int mvsdf_step_backward_inputs(int stage, int E, int N, int Nout, int n_true, in
         const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
         hipLaunchKernelGGL(k_step_bwd_stage0, dim3(blocks), dim3(256), 0, s, a);
     } else {
-        int total = N + n_true + n_eik;
-        for (int k = 0; k < nd; ++k) total += d_cnt[k];
-        for (int k = 0; k < ne; ++k) total += e_cnt[k];
+        const int total = 3 * N + 2 * (n_eik + 2 * n_ds) + n_true + n_eik;    // upper bound of the work items
         if (total > 0) hipLaunchKernelGGL(k_step_bwd_stage1, dim3((total + 255) / 256), dim3(256), 0, s, a);
     }
     return mv_check(hipGetLastError(), "mvsdf_step_backward_inputs");

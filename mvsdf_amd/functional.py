@@ -274,8 +274,9 @@ def loss_terms(rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r
 
 class StepState:
     """Everything the fused training step needs besides the (folded) parameters."""
-    __slots__ = ('net', 'rnet', 'x_eval', 'y_eval', 'n_eval', 'saved', 'R', 'E', 'N', 'n_true', 'n_eik', 'perm', 'inv', 'true_rows', 'view_sorted',
-                 'd_ranges', 'e_ranges', 'detach_geo', 'multires_view', 'rsaved', 'sdf_output', 'points_hom')
+    __slots__ = ('net', 'rnet', 'x_eval', 'y_eval', 'n_eval', 'saved', 'R', 'E', 'N', 'n_true', 'n_eik', 'n_ds', 'inv', 'perm', 'true_rows',
+                 'view_sorted', 'counts_dev', 'wait_counts', 'd_mask', 'e_mask', 'detach_geo', 'multires_view', 'rsaved', 'sdf_output',
+                 'points_hom')
 
 
 class _IdrStep(torch.autograd.Function):
@@ -283,19 +284,25 @@ class _IdrStep(torch.autograd.Function):
     evaluation `state.y_eval / n_eval` (rows [samples | rays, hit first]) it produces diff_surf_pts, rgb_values, grad_theta,
     eikonal_output, surf_indicator_output; backward chains the rendering-net backward, the input adjoint at the surface points,
     SampleNetwork's scalar and a single first/second-order SDF backward -- no autograd glue in between.
-    d_ranges / e_ranges: (first evaluation row, count) of the point groups entering the depth / eikonal terms."""
+
+    The forward enqueues its kernels BEFORE the host knows the hit count N: the rendering net runs on every sorted ray row and the
+    gather kernel reads N from device memory into worst-case sized outputs.  Only then does the host wait for the counts
+    (`state.wait_counts()`) and narrow the outputs to their N-dependent shapes (views, no kernels)."""
 
     @staticmethod
     def forward(ctx, st, *params):
-        R, E, N = st.R, st.E, st.N
-        rgb_hit, st.rsaved = None, None
-        if N > 0:
-            rgb_hit, st.rsaved = ops.render_forward(st.rnet, st.x_eval[E:E + N], st.view_sorted[:N], st.n_eval[E:E + N],
-                                                    st.y_eval[E:E + N, 2:], st.multires_view)
-        rgb_values, st.sdf_output, diff_pts, eik_out, st.points_hom, grad_theta, surf = ops.step_outputs(
-            R, E, N, st.n_true, st.n_eik, st.x_eval, st.y_eval, st.n_eval, st.perm, st.inv, st.true_rows, rgb_hit, st.d_ranges, st.e_ranges)
+        R, E = st.R, st.E
+        rgb_sorted, st.rsaved = ops.render_forward(st.rnet, st.x_eval[E:], st.view_sorted, st.n_eval[E:], st.y_eval[E:, 2:], st.multires_view)
+        rgb_values, sdf_output, diff_pts, eik_out, hom, gth, surf = ops.step_outputs(
+            R, st.n_eik, st.n_ds, st.counts_dev, st.x_eval, st.y_eval, st.n_eval, st.inv, st.true_rows, rgb_sorted, st.d_mask, st.e_mask)
+        N, n_true = st.wait_counts()                             # the one host wait of the training forward
+        st.N, st.n_true = N, n_true
+        sizes = (N, st.n_eik, st.n_ds, st.n_ds)
+        nd = sum(c for g, c in enumerate(sizes) if st.d_mask >> g & 1)
+        ne = sum(c for g, c in enumerate(sizes) if st.e_mask >> g & 1)
+        st.sdf_output, st.points_hom = sdf_output, hom[:nd].view(1, nd, 4, 1)
         ctx.st = st
-        return diff_pts, rgb_values, grad_theta, eik_out, surf
+        return diff_pts[:N], rgb_values, gth[:ne], eik_out[:nd].view(1, nd), surf[:n_true + st.n_eik]
 
     @staticmethod
     def backward(ctx, d_diff, d_rgbv, d_gth, d_eo, d_si):
@@ -309,14 +316,14 @@ class _IdrStep(torch.autograd.Function):
         dWr = dbr = din = dx = None
         use_geo = not st.detach_geo                                               # idr.py:329-336: features always carry the rgb gradient
         dv = 3 + 6 * st.multires_view
-        if N > 0 and d_rgbv is not None and st.rsaved is not None:
-            dWr, dbr, din = ops.render_backward(rnet, N, d_rgbv[st.perm[:N]], st.rsaved)
-        common = (E, N, Nout, st.n_true, st.n_eik, din, 6 + dv, 3 + dv, use_geo)
-        ops.step_backward_inputs(0, *common, None, None, st.view_sorted, st.n_eval, st.true_rows, None, None, None, st.d_ranges, st.e_ranges, dy, dn)
+        if N > 0 and d_rgbv is not None:
+            dWr, dbr, din = ops.render_backward(rnet, N, d_rgbv[st.perm[:N]], st.rsaved, n_ctx=R)
+        common = (st.n_eik, st.n_ds, N, Nout, st.n_true, din, 6 + dv, 3 + dv, use_geo)
+        ops.step_backward_inputs(0, *common, None, None, st.view_sorted, st.n_eval, st.true_rows, None, None, None, st.d_mask, st.e_mask, dy, dn)
         if din is not None:
             # adjoint of the surface points through features (+ normals): input adjoint only, rows [E, E+N)
             _, _, dx = ops.sdf_backward(net, st.x_eval, M, M, N, dy[E:], dn[E:] if use_geo else None, st.saved, True, want_dw=False, row0=E)
-        ops.step_backward_inputs(1, *common, d_diff, dx, st.view_sorted, st.n_eval, st.true_rows, d_eo, d_gth, d_si, st.d_ranges, st.e_ranges,
+        ops.step_backward_inputs(1, *common, d_diff, dx, st.view_sorted, st.n_eval, st.true_rows, d_eo, d_gth, d_si, st.d_mask, st.e_mask,
                                  dy, dn)
         dWs, dbs, _ = ops.sdf_backward(net, st.x_eval, M, M, Mb, dy, dn, st.saved, False)
         if dWr is None:

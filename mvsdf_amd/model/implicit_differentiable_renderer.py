@@ -226,27 +226,29 @@ class IDRNetwork(nn.Module):
             x_eval = torch.cat([eikonal_points, dsurf_on_sample, dsurf_jitter_sample, pts_sorted], 0)
             y_eval, n_eval, saved = ops.sdf_forward(net, x_eval, R + E)
             rnet, rws, rbs = self.rendering_network.fold()       # independent of N: enqueued before the wait
-            self._counts_event.synchronize()                     # the one host wait of the forward: output shapes depend on the counts
-            N, n_true = int(self._counts_host[0]), int(self._counts_host[1])
-            if dsurf is not None and min(int(self._counts_host[2]), int(self._counts_host[3])) < n_dsurf_points:
-                raise ValueError("Cannot take a larger sample than population when 'replace=False'")       # np.random.choice, idr.py:244
-            hit_idx = perm[:N]
             st = Fn.StepState()
             st.net, st.x_eval, st.y_eval, st.n_eval, st.saved = net, x_eval, y_eval, n_eval, saved
-            st.R, st.E, st.N, st.n_true, st.n_eik = R, E, N, n_true, n_eik_points
-            st.perm, st.inv, st.true_rows, st.view_sorted = perm, inv, true_rows, view_sorted
-            # point groups in the reference's row order [hit | samples]: (logical row range, depth-term flag, eikonal-term flag)   idr.py:258-286
-            o1, o2 = n_eik_points, n_eik_points + n_dsurf_points
-            groups = ((0, N, conf.d_use_rt_surf, conf.eik_use_rt_surf),
-                      (N, N + o1, conf.d_use_eik, conf.eik_use_eik),
-                      (N + o1, N + o2, conf.d_use_dsurf_on, conf.eik_use_dsurf_on),
-                      (N + o2, N + o2 + n_dsurf_points, conf.d_use_dsurf_jitter, conf.eik_use_dsurf_jitter))
-            ev_row = lambda a, b: (E + a, b - a) if b <= N else (a - N, b - a)       # logical range -> (first evaluation row, count)
-            st.d_ranges = [ev_row(a, b) for a, b, fd, _ in groups if fd(train_progress) and b > a]
-            st.e_ranges = [ev_row(a, b) for a, b, _, fe in groups if fe(train_progress) and b > a]
+            st.R, st.E, st.n_eik, st.n_ds = R, E, n_eik_points, n_dsurf_points
+            st.perm, st.inv, st.true_rows, st.view_sorted, st.counts_dev = perm, inv, true_rows, view_sorted, sync['part'][3]
+            # point groups in the reference's row order [hit | eikonal | on-surface | jittered] (idr.py:253-257): bit g of a mask selects
+            # group g for the depth term / the eikonal term (idr.py:258-286)
+            d_flags = (conf.d_use_rt_surf, conf.d_use_eik, conf.d_use_dsurf_on, conf.d_use_dsurf_jitter)
+            e_flags = (conf.eik_use_rt_surf, conf.eik_use_eik, conf.eik_use_dsurf_on, conf.eik_use_dsurf_jitter)
+            has = (True, n_eik_points > 0, n_dsurf_points > 0, n_dsurf_points > 0)
+            st.d_mask = sum(1 << g for g in range(4) if has[g] and d_flags[g](train_progress))
+            st.e_mask = sum(1 << g for g in range(4) if has[g] and e_flags[g](train_progress))
             st.detach_geo = bool(train_progress < conf.phase[0] or conf.disable_rgb_grad)                     # idr.py:331-334
             st.rnet, st.multires_view = rnet, self.rendering_network.multires_view
+
+            def wait_counts():
+                self._counts_event.synchronize()                 # output shapes depend on the counts
+                if dsurf is not None and min(int(self._counts_host[2]), int(self._counts_host[3])) < n_dsurf_points:
+                    raise ValueError("Cannot take a larger sample than population when 'replace=False'")   # np.random.choice, idr.py:244
+                return int(self._counts_host[0]), int(self._counts_host[1])
+            st.wait_counts = wait_counts
             differentiable_surface_points, rgb_values, grad_theta, eikonal_output, surf_indicator_output = Fn.idr_step(st, ws, bs, rws, rbs)
+            N = st.N
+            hit_idx = perm[:N]
             sdf_output, eikonal_points_hom = st.sdf_output, st.points_hom           # no gradient: the loss never differentiates them
             x_all, shared, row0 = x_eval, None, E
         else:

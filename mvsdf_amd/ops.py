@@ -258,7 +258,8 @@ def render_forward(net, points, view, normals, feat, multires_view):
     return rgb, ctx
 
 
-def render_backward(net, N, drgb, ctx):
+def render_backward(net, N, drgb, ctx, n_ctx=None):
+    """n_ctx: rows the forward context was made with (default N); the backward covers its first N rows."""
     drgb = _f32(drgb)
     dev = drgb.device
     d, dT = net.desc(), net.desc(True)
@@ -267,8 +268,8 @@ def render_backward(net, N, drgb, ctx):
     db = torch.empty(sum(bs_n), dtype=torch.float32, device=dev)
     din = torch.empty(N, net.layers[0].K, dtype=torch.float32, device=dev)
     ws = torch.empty(lib().mvsdf_render_bwd_ws_floats(C.byref(d), N), dtype=torch.float32, device=dev)
-    check(lib().mvsdf_render_backward(C.byref(d), C.byref(dT), N, ptr(drgb), ptr(ctx), ptr(dW), ptr(db), ptr(din), ptr(ws),
-                                      stream_of(drgb)), 'mvsdf_render_backward')
+    check(lib().mvsdf_render_backward(C.byref(d), C.byref(dT), N, N if n_ctx is None else n_ctx, ptr(drgb), ptr(ctx), ptr(dW), ptr(db),
+                                      ptr(din), ptr(ws), stream_of(drgb)), 'mvsdf_render_backward')
     dWs, dbs = _split_cat(net, dW, db)
     return dWs, dbs, din
 
@@ -345,34 +346,25 @@ def partition_rays(net_mask, object_mask, true_mask, ray_dirs):
     return perm, inv, true_rows, counts, view
 
 
-def _ranges(rs):
-    n = len(rs)
-    return n, (C.c_int * 4)(*[r[0] for r in rs]), (C.c_int * 4)(*[r[1] for r in rs])
-
-
-def step_outputs(R, E, N, n_true, n_eik, x_eval, y_eval, n_eval, perm, inv, true_rows, rgb_hit, d_ranges, e_ranges):
-    """d_ranges / e_ranges: lists of (first evaluation row, count).  -> rgb_values, sdf_output, diff_pts, eik_out, points_hom, grad_theta, surf"""
-    dev, Nout = x_eval.device, y_eval.shape[1]
-    nd_rows, ne_rows = sum(c for _, c in d_ranges), sum(c for _, c in e_ranges)
+def step_outputs(R, n_eik, n_ds, counts, x_eval, y_eval, n_eval, inv, true_rows, rgb_sorted, d_mask, e_mask):
+    """Worst-case sized outputs (N = R); the caller narrows them once the host knows N / n_true (see mvsdf_step_outputs).
+    -> rgb_values [R,3], sdf_output [R,1], diff_pts [R,3], eik_out [R+E], points_hom [R+E,4], grad_theta [R+E,3], surf [R+n_eik]"""
+    dev, Nout, E = x_eval.device, y_eval.shape[1], n_eik + 2 * n_ds
     f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-    rgb_values, sdf_output, diff_pts = f(R, 3), f(R, 1), f(N, 3)
-    eik_out, hom, gth, surf = f(1, nd_rows), f(1, nd_rows, 4, 1), f(ne_rows, 3), f(n_true + n_eik)
-    nd, ds, dc = _ranges(d_ranges)
-    ne, es, ec = _ranges(e_ranges)
-    check(lib().mvsdf_step_outputs(R, E, N, Nout, n_true, n_eik, ptr(x_eval), ptr(y_eval), ptr(n_eval), ptr(perm), ptr(inv), ptr(true_rows),
-                                   ptr(rgb_hit) if N > 0 else None, nd, ds, dc, ne, es, ec, ptr(rgb_values), ptr(sdf_output), ptr(diff_pts),
-                                   ptr(eik_out), ptr(hom), ptr(gth), ptr(surf), stream_of(x_eval)), 'mvsdf_step_outputs')
+    rgb_values, sdf_output, diff_pts = f(R, 3), f(R, 1), f(R, 3)
+    eik_out, hom, gth, surf = f(R + E), f(R + E, 4), f(R + E, 3), f(R + n_eik)
+    check(lib().mvsdf_step_outputs(R, n_eik, n_ds, Nout, ptr(counts), ptr(x_eval), ptr(y_eval), ptr(n_eval), ptr(inv), ptr(true_rows),
+                                   ptr(rgb_sorted), d_mask, e_mask, ptr(rgb_values), ptr(sdf_output), ptr(diff_pts), ptr(eik_out), ptr(hom),
+                                   ptr(gth), ptr(surf), stream_of(x_eval)), 'mvsdf_step_outputs')
     return rgb_values, sdf_output, diff_pts, eik_out, hom, gth, surf
 
 
-def step_backward_inputs(stage, E, N, Nout, n_true, n_eik, din, din_feat0, din_nrm0, use_geo, d_diff, dx, view_sorted, n_eval, true_rows,
-                         d_eo, d_gth, d_si, d_ranges, e_ranges, dy, dn):
-    nd, ds, dc = _ranges(d_ranges)
-    ne, es, ec = _ranges(e_ranges)
+def step_backward_inputs(stage, n_eik, n_ds, N, Nout, n_true, din, din_feat0, din_nrm0, use_geo, d_diff, dx, view_sorted, n_eval, true_rows,
+                         d_eo, d_gth, d_si, d_mask, e_mask, dy, dn):
     o = lambda t: None if t is None else ptr(_f32(t))
-    check(lib().mvsdf_step_backward_inputs(stage, E, N, Nout, n_true, n_eik, o(din), din.shape[1] if din is not None else 0, din_feat0, din_nrm0,
-                                           1 if use_geo else 0, o(d_diff), o(dx), ptr(view_sorted), ptr(n_eval), ptr(true_rows), o(d_eo),
-                                           o(d_gth), o(d_si), nd, ds, dc, ne, es, ec, ptr(dy), ptr(dn), stream_of(dy)),
+    check(lib().mvsdf_step_backward_inputs(stage, n_eik, n_ds, N, Nout, n_true, o(din), din.shape[1] if din is not None else 0, din_feat0,
+                                           din_nrm0, 1 if use_geo else 0, o(d_diff), o(dx), ptr(view_sorted), ptr(n_eval), ptr(true_rows),
+                                           o(d_eo), o(d_gth), o(d_si), d_mask, e_mask, ptr(dy), ptr(dn), stream_of(dy)),
           'mvsdf_step_backward_inputs')
 
 
