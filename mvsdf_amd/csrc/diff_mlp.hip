@@ -531,6 +531,20 @@ int mvsdf_render_forward(const MvsdfNetDesc* d, const float* points, const float
     if (K0 <= 6 + dv) return mv_fail(-1, "mvsdf_render_forward: first layer too narrow for cat[points, PE(view), normals, feat]");
     hipStream_t s = (hipStream_t)stream;
     const RenderLayout lo = render_layout(net, N);
+    static int fuse_r = -1;
+    if (fuse_r < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_r = e ? atoi(e) : 1; }
+    if (fuse_r && !mv_wide(net) && net.L[nl - 1].NT <= 2) {                        // the whole network in one launch per row tile
+        RenderChainArgs c;
+        memset(&c, 0, sizeof(c));
+        c.net = net; c.S = net.S; c.N = N; c.mv = multires_view; c.K0 = K0;
+        c.points = points; c.view = view; c.normals = normals; c.feat = feat; c.ldfeat = ldfeat;
+        for (int l = 0; l < nl; ++l) c.A[l] = ctx + lo.A[l];
+        c.rgb_ctx = ctx + lo.rgb; c.rgb = rgb;
+        constexpr int MTC = 1, NWC = 8;
+        hipLaunchKernelGGL((k_render_chain_fwd<MTC, 2, NWC>), dim3((N + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC),
+                           (size_t)16 * MTC * net.S * sizeof(float), s, c);
+        return mv_check(hipGetLastError(), "mvsdf_render_forward");
+    }
     const size_t tot = (size_t)N * K0;
     hipLaunchKernelGGL(k_render_input, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, points, view, normals, feat, ldfeat, N,
                        multires_view, K0, ctx + lo.A[0]);
@@ -559,6 +573,21 @@ int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, 
     const int nl = net.n_layers, S = stride_for(net, netT);
     const RenderLayout lo = render_layout(net, Nctx);        // the forward context holds Nctx rows; the backward covers the first N
     const RenderBwdLayout bl = render_bwd_layout(net, N);
+    static int fuse_rb = -1;
+    if (fuse_rb < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_rb = e ? atoi(e) : 1; }
+    bool fused_bwd = fuse_rb && !mv_wide(net);
+    for (int l = 1; l < nl; ++l) fused_bwd = fused_bwd && netT.L[l].NT <= 16;   // one column-tile group per wave above the first layer
+    if (fused_bwd) {
+        RenderChainArgs c;
+        memset(&c, 0, sizeof(c));
+        c.net = net; c.netT = netT; c.S = S; c.N = N; c.K0 = net.L[0].K;
+        c.drgb = drgb; c.rgbc = ctx + lo.rgb; c.din = din;
+        for (int l = 0; l < nl; ++l) { c.Ac[l] = ctx + lo.A[l]; c.ZB[l] = ws + bl.ZB[l]; }
+        constexpr int MTC = 1, NWC = 8;
+        hipLaunchKernelGGL((k_render_chain_bwd<MTC, 2, NWC>), dim3((N + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC),
+                           (size_t)16 * MTC * S * sizeof(float), s, c);
+        MV_TRY(hipGetLastError());
+    } else
     for (int l = nl - 1; l >= 0; --l) {                      // abar_l = zbar_l W_l ; zbar_{l-1} = abar_l . relu'(z_{l-1})
         LayerArgs a = base_args(netT.L[l], S, N);
         const bool last = (l == nl - 1);

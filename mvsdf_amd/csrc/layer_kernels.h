@@ -798,3 +798,168 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
         a.nrm[(size_t)row * 3 + c] = v;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rendering network (idr.py:145-167, mode 'idr') as one forward and one backward launch per 16*MT rows.
+//   forward : a_0 = cat[points, view, PE(view), normals, feat]; a_{l+1} = relu(a_l W_l^T + b_l); rgb = tanh(a_L W_L^T + b_L); stores a_l, rgb
+//   backward: zb_L = drgb (1 - rgb^2); ab_l = zb_l W_l; zb_{l-1} = ab_l [a_l > 0]; stores zb_l (for the weight gradients) and din = ab_0
+struct RenderChainArgs {
+    MvNet net, netT;
+    int S, N, mv, K0;
+    const float* points; const float* view; const float* normals; const float* feat; int ldfeat;   // forward inputs
+    float* A[MV_MAXL]; float* rgb_ctx; float* rgb;                                                   // forward outputs
+    const float* drgb; const float* Ac[MV_MAXL]; const float* rgbc; float* ZB[MV_MAXL]; float* din;  // backward
+};
+
+__device__ __forceinline__ float mv_render_input(const RenderChainArgs& a, int row, int k) {
+    const int dv = 3 + 6 * a.mv;
+    if (k < 3) return a.points[(size_t)row * 3 + k];
+    if (k < 3 + dv) {
+        const int j = k - 3;
+        if (j < 3) return a.view[(size_t)row * 3 + j];
+        const int jj = j - 3, m = jj / 6, rem = jj - 6 * m, c = rem % 3;
+        float sn, co;
+        dm_sincos(a.view[(size_t)row * 3 + c] * (float)(1 << m), &sn, &co);
+        return rem < 3 ? sn : co;
+    }
+    if (k < 6 + dv) return a.normals[(size_t)row * 3 + (k - 3 - dv)];
+    return a.feat[(size_t)row * a.ldfeat + (k - 6 - dv)];
+}
+
+template <int MT, int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_render_chain_fwd(RenderChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * MT, NTH = 64 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers;
+    float* act = smem;
+    {
+        const int K0 = a.K0, Kp0 = a.net.L[0].KB * 16;
+        for (int idx = tid; idx < ROWS * Kp0; idx += NTH) {
+            const int rr = idx / Kp0, k = idx - rr * Kp0, row = row0 + rr;
+            float v = 0.0f;
+            if (row < a.N && k < K0) { v = mv_render_input(a, row, k); a.A[0][(size_t)row * K0 + k] = v; }
+            act[rr * S + mv_perm(k)] = v;
+        }
+    }
+    for (int l = 0; l < nl; ++l) {
+        const MvLayer& L = a.net.L[l];
+        const bool last = (l == nl - 1);
+        const int N = L.N, NT = L.NT, per = (NT + NW - 1) / NW;
+        __syncthreads();
+        for (int g0 = 0; g0 < per; g0 += NTW) {
+            const int ct0 = w * per + g0;
+            int ntw = min(per - g0, NT - ct0);
+            ntw = ntw < 0 ? 0 : (ntw > NTW ? NTW : ntw);
+            f32x4 acc[MT][NTW];
+            mv_zero_acc<MT, NTW>(acc);
+            if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
+            if (per > NTW || !last) __syncthreads();             // every wave done reading act before the in-place update
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                if (t < ntw) {
+                    const int col = (ct0 + t) * 16 + r;
+                    if (col < N) {
+                        const float bv = L.bias[col];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int rr = m * 16 + 4 * q + i, row = row0 + rr;
+                                const float z = acc[m][t][i] + bv;
+                                if (last) {
+                                    const float y = tanhf(z);
+                                    if (row < a.N) { a.rgb[(size_t)row * N + col] = y; a.rgb_ctx[(size_t)row * N + col] = y; }
+                                } else {
+                                    const float h = fmaxf(z, 0.0f);
+                                    if (row < a.N) a.A[l + 1][(size_t)row * N + col] = h;
+                                    act[rr * S + mv_perm(col)] = h;
+                                }
+                            }
+                    }
+                }
+            }
+        }
+        if (!last) {
+            const int Kn = a.net.L[l + 1].K, Kpn = a.net.L[l + 1].KB * 16;
+            if (Kpn > Kn) {
+                const int pad = Kpn - Kn;
+                for (int idx = tid; idx < ROWS * pad; idx += NTH) {
+                    const int rr = idx / pad, j = idx - rr * pad;
+                    act[rr * S + mv_perm(Kn + j)] = 0.0f;
+                }
+            }
+        }
+    }
+}
+
+template <int MT, int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_render_chain_bwd(RenderChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * MT, NTH = 64 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers;
+    float* act = smem;
+    {   // zb_L = drgb (1 - rgb^2)
+        const int K = a.net.L[nl - 1].N, Kp = a.netT.L[nl - 1].KB * 16;
+        for (int idx = tid; idx < ROWS * Kp; idx += NTH) {
+            const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
+            float v = 0.0f;
+            if (row < a.N && k < K) {
+                const float y = a.rgbc[(size_t)row * K + k];
+                v = a.drgb[(size_t)row * K + k] * (1.0f - y * y);
+                a.ZB[nl - 1][(size_t)row * K + k] = v;
+            }
+            act[rr * S + mv_perm(k)] = v;
+        }
+    }
+    for (int l = nl - 1; l >= 0; --l) {
+        const MvLayer& L = a.netT.L[l];                          // contraction over out_l (K), produces in_l columns (N)
+        const int N = L.N, NT = L.NT, per = (NT + NW - 1) / NW;
+        __syncthreads();
+        // the layer's outputs overwrite the tile the GEMM reads: with several column-tile groups per wave they are staged in registers
+        // group by group only when one group suffices; otherwise (first layer, N = K0 > 256) the outputs go to global memory only.
+        for (int g0 = 0; g0 < per; g0 += NTW) {
+            const int ct0 = w * per + g0;
+            int ntw = min(per - g0, NT - ct0);
+            ntw = ntw < 0 ? 0 : (ntw > NTW ? NTW : ntw);
+            f32x4 acc[MT][NTW];
+            mv_zero_acc<MT, NTW>(acc);
+            if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
+            if (l > 0) __syncthreads();                          // (l > 0 has a single group: per <= NTW, checked by the launcher)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                if (t < ntw) {
+                    const int col = (ct0 + t) * 16 + r;
+                    if (col < N) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int rr = m * 16 + 4 * q + i, row = row0 + rr;
+                                const float ab = acc[m][t][i];
+                                if (l > 0) {
+                                    float zb = 0.0f;
+                                    if (row < a.N) {
+                                        zb = a.Ac[l][(size_t)row * N + col] > 0.0f ? ab : 0.0f;      // relu mask: stored post-activation > 0
+                                        a.ZB[l - 1][(size_t)row * N + col] = zb;
+                                    }
+                                    act[rr * S + mv_perm(col)] = zb;
+                                } else if (row < a.N) a.din[(size_t)row * N + col] = ab;
+                            }
+                    }
+                }
+            }
+        }
+        if (l > 0) {
+            const int Kn = a.netT.L[l - 1].K, Kpn = a.netT.L[l - 1].KB * 16;
+            if (Kpn > Kn) {
+                const int pad = Kpn - Kn;
+                for (int idx = tid; idx < ROWS * pad; idx += NTH) {
+                    const int rr = idx / pad, j = idx - rr * pad;
+                    act[rr * S + mv_perm(Kn + j)] = 0.0f;
+                }
+            }
+        }
+    }
+}
