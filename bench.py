@@ -183,7 +183,7 @@ def main():
                          # HBM bytes per launch from PMC passes of this command (profiles/r01_pmc_summary.csv), mean of the three launches:
                          # 2 x FETCH_SIZE (gfx950 correction for wide coalesced reads; FETCH_SIZE in KB = 1024 B) + WRITE_SIZE.  Not
                          # measurable from inside the process.  ~8.6x the 1.84 MB weight set: each of the 8 XCD L2s pulls its own copy.
-                         'traffic': (2 * 7681.0 + 100.0) * 1024 if (W, B, P) == (256, 8, 256) else None,
+                         'traffic': (2 * 7678.5 + 100.8) * 1024 if (W, B, P) == (256, 8, 256) else None,
                          'rows_per_launch': rows_samples / n_launch, 'flop_per_row': f_t, 'avg_launch_ms': ms_samples / n_launch,
                          'launches_per_step': n_launch,
                          'k_sphere_trace': {'rows_per_launch': int(cnt[0]), 'avg_launch_ms': ms_sphere,
