@@ -109,3 +109,37 @@ def test_two_wide_softplus_bitwise(oracle):
     y0, y1 = ops.det_math(6, torch.from_numpy(z).cuda())
     assert np.array_equal(y0.cpu().numpy(), oracle.softplus100(z))
     assert np.array_equal(y1.cpu().numpy(), oracle.softplus100(-z))
+
+
+@pytest.mark.parametrize('seed', [11, 12, 13, 14])
+def test_trace_fuzz_bit_exact_vs_oracle(oracle, seed):
+    """Randomised scenes / cameras / masks / tracer parameters: HIP tracer == CPU oracle bit for bit (outputs and reference-equivalent
+    row counters), in training and eval mode, with different chunkings.  Exercises the sampler's early exit (first negative sample
+    inside / outside the first window, at index 0 -> wraps, no sign change) with odd n_steps and few sphere iterations."""
+    rs = np.random.RandomState(seed)
+    W = 64
+    sd = synth.make_state_dict(W, seed)
+    onet, net = oracle.Net(sd), sdf_packed_net(sd)
+    B, P = int(rs.randint(1, 4)), int(rs.randint(40, 300))
+    inp, _ = synth.make_batch(B, P, 0, seed=seed, radius=float(rs.uniform(1.6, 3.0)), height=float(rs.uniform(-0.5, 1.2)),
+                              focal_scale=float(rs.uniform(0.8, 2.5)), with_features=False)
+    dirs, cam = oracle.camera_rays(inp['uv'], inp['pose'], inp['intrinsics'])
+    om = rs.uniform(size=B * P) < rs.choice([1.1, 0.6])
+    tr = dict(synth.model_conf(W)['ray_tracer'])
+    tr['n_steps'] = int(rs.choice([100, 37, 16, 9]))
+    tr['sphere_tracing_iters'] = int(rs.choice([10, 3, 1]))
+    tr['n_secant_steps'] = int(rs.choice([8, 3]))
+    tr['line_step_iters'] = int(rs.choice([3, 1, 0]))
+    iv = torch.linspace(0, 1, steps=tr['n_steps']).numpy()
+    steps = rs.uniform(size=tr['n_steps']).astype(np.float32)
+    params = (tr['object_bounding_sphere'], tr['sdf_threshold'], tr['line_search_step'], tr['line_step_iters'], tr['sphere_tracing_iters'],
+              tr['n_steps'], tr['n_secant_steps'], 0.5)
+    for training in (True, False):
+        p_o, m_o, d_o, rows_o = oracle.trace(onet, cam, dirs, om, training, steps, iv, **tr)
+        for mt, mts in ((1, 1), (2, 2), (4, 4)):
+            pts, mask, dists, cnt = ops.trace(net, t(cam), t(dirs), t(om), params, training, t(iv), t(steps), mt=mt, mt_samples=mts)
+            assert np.array_equal(mask.cpu().numpy(), m_o), (training, mt)
+            assert np.array_equal(dists.cpu().numpy(), d_o), (training, mt)
+            assert np.array_equal(pts.cpu().numpy(), p_o), (training, mt)
+            c = cnt.cpu().numpy()
+            assert np.array_equal(c[:4], rows_o) and c[8] <= c[1]
