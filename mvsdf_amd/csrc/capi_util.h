@@ -10,6 +10,14 @@ int mv_check(hipError_t e, const char* where);   // 0 on success
 int mv_make_net_mode(const MvsdfNetDesc* d, MvNet* net, int mode);
 static inline int mv_make_net(const MvsdfNetDesc* d, MvNet* net) { return mv_make_net_mode(d, net, 0); }
 
+// column tiles per wave the fused chain kernels need for this network (8 waves per workgroup): 2 up to width 256, 4 up to 512,
+// 0 = too wide for them (per-layer kernels take over)
+static inline int mv_chain_ntw(const MvNet& net) {
+    int maxnt = 0;
+    for (int l = 0; l < net.n_layers - 1; ++l) maxnt = net.L[l].NT > maxnt ? net.L[l].NT : maxnt;
+    return maxnt <= 16 ? 2 : (maxnt <= 32 ? 4 : 0);
+}
+
 static inline bool mv_wide(const MvNet& net) {
     int maxnt = 0;
     for (int l = 0; l < net.n_layers - 1; ++l) maxnt = net.L[l].NT > maxnt ? net.L[l].NT : maxnt;

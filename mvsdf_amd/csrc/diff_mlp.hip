@@ -262,7 +262,8 @@ int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float
     float* H0 = ctx + lo.H0;
     static int fuse_fwd = -1;
     if (fuse_fwd < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_fwd = e ? atoi(e) : 1; }
-    if (fuse_fwd && !mv_wide(net) && net.L[nl - 1].NT <= 64) {                     // value + normal of a row tile in one launch
+    const int ntw_f = mv_chain_ntw(net);
+    if (fuse_fwd && ntw_f && net.L[nl - 1].NT <= 8 * ntw_f * 4) {                  // value + normal of a row tile in one launch
         FwdArgs f;
         memset(&f, 0, sizeof(f));
         f.net = net; if (Mg > 0) f.netT = netT;
@@ -273,7 +274,8 @@ int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float
         f.G0 = ctx + lo.G0; f.y = y; f.ldy = net.L[nl - 1].N; f.w_last_row0 = d->w[nl - 1]; f.nrm = nrm;
         constexpr int MTC = 1, NWC = 8;
         const size_t lds = ((size_t)16 * MTC * S + 2 * ((16 * MTC * lo.d0 + 3) & ~3) + 16 * MTC * 4) * sizeof(float);
-        hipLaunchKernelGGL((k_chain_fwd<MTC, 2, NWC>), dim3((M + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, f);
+        if (ntw_f == 2) hipLaunchKernelGGL((k_chain_fwd<MTC, 2, NWC>), dim3((M + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, f);
+        else hipLaunchKernelGGL((k_chain_fwd<MTC, 4, NWC>), dim3((M + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, f);
         return mv_check(hipGetLastError(), "mvsdf_sdf_forward");
     }
     hipLaunchKernelGGL(k_pe_global, dim3((M * (3 * net.multires + 1) + 255) / 256), dim3(256), 0, s, x, M, net.multires, H0, lo.ld0);
@@ -351,7 +353,8 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
                            sk > 0 ? net.L[sk].K - lo.d0 : 0);
         static int fuse1_env = -1;
         if (fuse1_env < 0) { const char* e = getenv("MVSDF_FUSE"); fuse1_env = e ? atoi(e) : 1; }
-        if (fuse1_env && !mv_wide(net)) {                        // the whole ascending chain in one launch
+        const int ntw_1 = mv_chain_ntw(net);
+        if (fuse1_env && ntw_1) {                                // the whole ascending chain in one launch
             ChainArgs c;
             memset(&c, 0, sizeof(c));
             c.net = net; c.netT = netT; c.S = S; c.M = Mb; c.row_ld0 = lo.ld0;
@@ -364,7 +367,8 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
             }
             constexpr int MTC = 1, NWC = 8;
             const size_t lds = (size_t)16 * MTC * (S + lo.d0) * sizeof(float);
-            hipLaunchKernelGGL((k_chain_e1<MTC, 2, NWC>), dim3((Mb + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, c);
+            if (ntw_1 == 2) hipLaunchKernelGGL((k_chain_e1<MTC, 2, NWC>), dim3((Mb + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, c);
+            else hipLaunchKernelGGL((k_chain_e1<MTC, 4, NWC>), dim3((Mb + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, c);
             MV_TRY(hipGetLastError());
         } else
         for (int l = 0; l < nl - 1; ++l) {
@@ -381,8 +385,8 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
     // ---- E.2: adjoint of the value chain (descending) ----
     static int fuse_env = -1;
     if (fuse_env < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_env = e ? atoi(e) : 1; }
-    const bool wide = mv_wide(net);
-    if (fuse_env && !wide) {                                    // all layers in one launch, the running adjoint stays in LDS
+    const int ntw_2 = mv_chain_ntw(net);
+    if (fuse_env && ntw_2) {                                    // all layers in one launch, the running adjoint stays in LDS
         ChainArgs c;
         memset(&c, 0, sizeof(c));
         c.net = net; c.netT = netT; c.S = S; c.M = Mb; c.row_ld0 = lo.ld0;
@@ -391,7 +395,8 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         c.H0B = ws + bl.H0B;
         constexpr int MTC = 1, NWC = 8;
         const size_t lds = (size_t)16 * MTC * (S + lo.d0) * sizeof(float);
-        hipLaunchKernelGGL((k_chain_e2<MTC, 2, NWC>), dim3((Mb + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, c);
+        if (ntw_2 == 2) hipLaunchKernelGGL((k_chain_e2<MTC, 2, NWC>), dim3((Mb + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, c);
+        else hipLaunchKernelGGL((k_chain_e2<MTC, 4, NWC>), dim3((Mb + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, c);
         MV_TRY(hipGetLastError());
     } else {
     int cur = 0;
@@ -533,7 +538,8 @@ int mvsdf_render_forward(const MvsdfNetDesc* d, const float* points, const float
     const RenderLayout lo = render_layout(net, N);
     static int fuse_r = -1;
     if (fuse_r < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_r = e ? atoi(e) : 1; }
-    if (fuse_r && !mv_wide(net) && net.L[nl - 1].NT <= 2) {                        // the whole network in one launch per row tile
+    const int ntw_r = mv_chain_ntw(net);
+    if (fuse_r && ntw_r && net.L[nl - 1].NT <= 2) {                                // the whole network in one launch per row tile
         RenderChainArgs c;
         memset(&c, 0, sizeof(c));
         c.net = net; c.S = net.S; c.N = N; c.mv = multires_view; c.K0 = K0;
@@ -541,8 +547,10 @@ int mvsdf_render_forward(const MvsdfNetDesc* d, const float* points, const float
         for (int l = 0; l < nl; ++l) c.A[l] = ctx + lo.A[l];
         c.rgb_ctx = ctx + lo.rgb; c.rgb = rgb;
         constexpr int MTC = 1, NWC = 8;
-        hipLaunchKernelGGL((k_render_chain_fwd<MTC, 2, NWC>), dim3((N + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC),
-                           (size_t)16 * MTC * net.S * sizeof(float), s, c);
+        if (ntw_r == 2) hipLaunchKernelGGL((k_render_chain_fwd<MTC, 2, NWC>), dim3((N + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC),
+                                           (size_t)16 * MTC * net.S * sizeof(float), s, c);
+        else hipLaunchKernelGGL((k_render_chain_fwd<MTC, 4, NWC>), dim3((N + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC),
+                                (size_t)16 * MTC * net.S * sizeof(float), s, c);
         return mv_check(hipGetLastError(), "mvsdf_render_forward");
     }
     const size_t tot = (size_t)N * K0;
@@ -575,8 +583,9 @@ int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, 
     const RenderBwdLayout bl = render_bwd_layout(net, N);
     static int fuse_rb = -1;
     if (fuse_rb < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_rb = e ? atoi(e) : 1; }
-    bool fused_bwd = fuse_rb && !mv_wide(net);
-    for (int l = 1; l < nl; ++l) fused_bwd = fused_bwd && netT.L[l].NT <= 16;   // one column-tile group per wave above the first layer
+    const int ntw_rb = mv_chain_ntw(net);
+    bool fused_bwd = fuse_rb && ntw_rb;
+    for (int l = 1; l < nl; ++l) fused_bwd = fused_bwd && netT.L[l].NT <= 8 * ntw_rb;   // one column-tile group per wave above the first layer
     if (fused_bwd) {
         RenderChainArgs c;
         memset(&c, 0, sizeof(c));
@@ -584,8 +593,10 @@ int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, 
         c.drgb = drgb; c.rgbc = ctx + lo.rgb; c.din = din;
         for (int l = 0; l < nl; ++l) { c.Ac[l] = ctx + lo.A[l]; c.ZB[l] = ws + bl.ZB[l]; }
         constexpr int MTC = 1, NWC = 8;
-        hipLaunchKernelGGL((k_render_chain_bwd<MTC, 2, NWC>), dim3((N + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC),
-                           (size_t)16 * MTC * S * sizeof(float), s, c);
+        if (ntw_rb == 2) hipLaunchKernelGGL((k_render_chain_bwd<MTC, 2, NWC>), dim3((N + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC),
+                                            (size_t)16 * MTC * S * sizeof(float), s, c);
+        else hipLaunchKernelGGL((k_render_chain_bwd<MTC, 4, NWC>), dim3((N + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC),
+                                (size_t)16 * MTC * S * sizeof(float), s, c);
         MV_TRY(hipGetLastError());
     } else
     for (int l = nl - 1; l >= 0; --l) {                      // abar_l = zbar_l W_l ; zbar_{l-1} = abar_l . relu'(z_{l-1})
