@@ -151,11 +151,13 @@ int mvsdf_feat_corr(const float* pts, int N, const int* view_start, int B, int V
                     const float* src_cams, const float* size, const float* center, float* loss_pp, float* dpts, void* stream);
 
 /* ---- depth-carving target of IDRLoss.get_depth_loss (loss.py:37-63 -> my_utils.py:269-331 carving_t2) ----
- * pts[M][3] normalised sample points, depths[B][h][w], cams[B][2][4][4] -> dist_r[M], weight[M];
+ * pts[M][pts_ld] (first 3 columns: normalised sample points, e.g. eikonal_points_hom with pts_ld = 4), depths[B][h][w],
+ * cams[B][2][4][4] -> dist_r[M], weight[M]; pts_world (may be NULL, may alias pts, same row stride) receives the points rescaled to
+ * world coordinates -- the reference does that in place on eikonal_points_hom (loss.py:38,42);
  * loss = mean(|eikonal_output + dist_r| * weight)  (weight = far/near attenuation * in_range). */
-int mvsdf_depth_carve(const float* pts, int M, const float* depths, int B, int h, int w, const float* cams, const float* size,
+int mvsdf_depth_carve(const float* pts, int pts_ld, int M, const float* depths, int B, int h, int w, const float* cams, const float* size,
                       const float* center, float out_thresh_perc, float far_thresh, float far_att, float near_thresh, float near_att,
-                      float* dist_r, float* weight, void* stream);
+                      float* dist_r, float* weight, float* pts_world, void* stream);
 
 /* ---- the elementwise terms of IDRLoss.forward + weighted total (loss.py:21-35, 58-61, 167-174, 206-210), one launch ----
  * rgb[R][3], rgb_gt[R][3], rgb_mask[R] (network_object_mask & object_mask); grad_theta[n_eik][3]; eik_out / dist_r / dweight[n_depth]

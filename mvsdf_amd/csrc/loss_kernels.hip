@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) void k_feat_corr(FeatArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------
 struct CarveArgs {
-    const float* pts; int M;          // normalised points [M][3]
+    const float* pts; int M, pts_ld;  // normalised points [M][pts_ld >= 3]
+    float* pts_world;                 // optional [M][pts_ld]: receives the world-space points (may alias pts: loss.py:42 rescales in place)
     const float* depths; int B, h, w; // [B][h][w]
     const float* cams;                // [B][2][4][4]
     const float* size; const float* center;
@@ -178,7 +179,8 @@ __global__ void k_carve(CarveArgs a) {
     if (i >= a.M) return;
     const float size = a.size[0];
     float pw[3];
-    for (int j = 0; j < 3; ++j) pw[j] = a.pts[3 * (size_t)i + j] / 2.0f * size + a.center[j];       // loss.py:42
+    for (int j = 0; j < 3; ++j) pw[j] = a.pts[(size_t)a.pts_ld * i + j] / 2.0f * size + a.center[j];       // loss.py:42
+    if (a.pts_world) for (int j = 0; j < 3; ++j) a.pts_world[(size_t)a.pts_ld * i + j] = pw[j];
     const float MAXF = 1e30f / (float)a.B;
     float tot_in = 0.f, tot_valid = 0.f, tot_inside = 0.f, pos_min = INFINITY, neg_max = -INFINITY;
     for (int v = 0; v < a.B; ++v) {
@@ -363,13 +365,13 @@ int mvsdf_feat_corr(const float* pts, int N, const int* view_start, int B, int V
 
 /* Depth-carving target of IDRLoss.get_depth_loss (loss.py:37-63, carving_t2): pts[M][3] normalised sample points,
  * depths[B][h][w], cams[B][2][4][4] -> dist_r[M], weight[M];  loss = mean(|eikonal_output + dist_r| * weight). */
-int mvsdf_depth_carve(const float* pts, int M, const float* depths, int B, int h, int w, const float* cams, const float* size,
+int mvsdf_depth_carve(const float* pts, int pts_ld, int M, const float* depths, int B, int h, int w, const float* cams, const float* size,
                       const float* center, float out_thresh_perc, float far_thresh, float far_att, float near_thresh, float near_att,
-                      float* dist_r, float* weight, void* stream) {
-    if (!pts || !depths || !cams || !size || !center || !dist_r || !weight || M <= 0 || B <= 0 || h <= 0 || w <= 0)
+                      float* dist_r, float* weight, float* pts_world, void* stream) {
+    if (!pts || pts_ld < 3 || !depths || !cams || !size || !center || !dist_r || !weight || M <= 0 || B <= 0 || h <= 0 || w <= 0)
         return mv_fail(-1, "mvsdf_depth_carve: bad arguments");
     CarveArgs a;
-    a.pts = pts; a.M = M; a.depths = depths; a.B = B; a.h = h; a.w = w; a.cams = cams; a.size = size; a.center = center;
+    a.pts = pts; a.M = M; a.pts_ld = pts_ld; a.pts_world = pts_world; a.depths = depths; a.B = B; a.h = h; a.w = w; a.cams = cams; a.size = size; a.center = center;
     a.out_thresh_perc = out_thresh_perc; a.far_thresh = far_thresh; a.far_att = far_att; a.near_thresh = near_thresh; a.near_att = near_att;
     a.dist_r = dist_r; a.weight = weight;
     hipLaunchKernelGGL(k_carve, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);

@@ -198,7 +198,6 @@ class IDRNetwork(nn.Module):
                                                                  ray_directions=ray_dirs, mask_ready=on_mask if self.training else None)
         ray_dirs = ray_dirs.reshape(-1, 3)
 
-        cam_rays = cam_loc.unsqueeze(1).expand(batch_size, num_pixels, 3).reshape(-1, 3)
         if self.training:
             perm, inv, true_rows, _, view_sorted = sync['part']
         else:

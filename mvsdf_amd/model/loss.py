@@ -63,12 +63,16 @@ class IDRLoss(nn.Module):
         return F.binary_cross_entropy_with_logits(surf_indicator_output, gt, reduction='mean')
 
     def _carve(self, eikonal_points_hom, depths, cams, size, center, train_progress):
-        pts = eikonal_points_hom.detach()[0, :, :3, 0]
+        hom = eikonal_points_hom.detach()
         B = depths.shape[0]
-        dist_r, weight = ops.depth_carve(pts, depths.reshape(B, depths.shape[-2], depths.shape[-1]), cams.reshape(B, 2, 4, 4), size, center,
-                                         conf.out_thresh_perc, conf.far_thresh, float(conf.far_att(train_progress)), conf.near_thresh,
-                                         float(conf.near_att(train_progress)))
-        eikonal_points_hom.detach()[:, :, :3, 0] = pts / 2 * size.view(1, 1, 1) + center.view(1, 1, 3)      # side effect of loss.py:38,42
+        args = (depths.reshape(B, depths.shape[-2], depths.shape[-1]), cams.reshape(B, 2, 4, 4), size, center, conf.out_thresh_perc,
+                conf.far_thresh, float(conf.far_att(train_progress)), conf.near_thresh, float(conf.near_att(train_progress)))
+        if hom.is_contiguous() and hom.dtype == torch.float32 and hom.is_cuda:
+            # the kernel reads the [n, 4] rows in place and writes the world-space points back: the side effect of loss.py:38,42
+            return ops.depth_carve(hom.view(-1, 4), *args, world_inplace=True)
+        pts = hom[0, :, :3, 0]
+        dist_r, weight = ops.depth_carve(pts, *args)
+        hom[:, :, :3, 0] = pts / 2 * size.view(1, 1, 1) + center.view(1, 1, 3)
         return dist_r, weight
 
     def forward(self, model_outputs, ground_truth, train_progress, n_img):
@@ -84,6 +88,7 @@ class IDRLoss(nn.Module):
         if conf.smooth(train_progress) is not None or conf.use_invalid or not conf.enable_rgb:
             raise NotImplementedError('smooth / use_invalid / enable_rgb=False are off in the reference conf (model/conf.py:17-25)')
 
+        hit_mask = network_object_mask & object_mask
         phase1 = conf.phase[0] <= train_progress
         feat_on = bool(phase1 and conf.enable_feat)
         feat_pp = None
@@ -91,7 +96,7 @@ class IDRLoss(nn.Module):
         if feat_on and pts.shape[0] > 0:
             if model_outputs.get('uncerts') is not None:
                 raise NotImplementedError('uncerts is always None in the reference (loss.py:197)')
-            counts = (network_object_mask & object_mask).view(ground_truth['feat'].size()[0], -1).sum(-1)
+            counts = hit_mask.view(ground_truth['feat'].size()[0], -1).sum(-1)
             view_start = torch.cat([torch.zeros(1, dtype=counts.dtype, device=dev), counts.cumsum(0)]).to(torch.int32)
             feat_pp = Fn.feat_corr_terms(pts, view_start, ground_truth['feat'], ground_truth['feat_src'], ground_truth['cam'],
                                          ground_truth['src_cams'], ground_truth['size'], ground_truth['center'])
@@ -101,6 +106,6 @@ class IDRLoss(nn.Module):
         weights = (conf.rgb_weight(train_progress), conf.eikonal_weight, conf.surf_weight, conf.feat_weight(train_progress),
                    conf.depth_weight(train_progress))
         out = Fn.loss_terms(model_outputs['rgb_values'], model_outputs['grad_theta'], model_outputs['eikonal_output'],
-                            model_outputs['surf_indicator_output'], feat_pp, rgb_gt, network_object_mask & object_mask, dist_r, dweight,
+                            model_outputs['surf_indicator_output'], feat_pp, rgb_gt, hit_mask, dist_r, dweight,
                             n_pos, weights, bool(phase1), feat_on)
         return {'loss': out[0], 'rgb_loss': out[1], 'eikonal_loss': out[2], 'depth_loss': out[3], 'feat_loss': out[4], 'surf_loss': out[5]}

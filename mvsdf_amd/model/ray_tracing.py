@@ -33,6 +33,7 @@ class RayTracing(nn.Module):
         self.last_counters = None           # device int64[16]: MLP rows per stage (include/mvsdf_hip.h MVSDF_CNT_*)
         self.mt = None                      # row tiles per sphere-tracing workgroup (None: pick from the ray count)
         self.mt_samples = None              # row tiles per chunk of the sample-row kernels
+        self._intervals = None
         self.events = None                  # set to a list to have per-kernel (start, mid, end) events appended each call
 
     def _params(self):
@@ -54,7 +55,10 @@ class RayTracing(nn.Module):
             raise TypeError('the native tracer needs the SDF weights: pass ImplicitNetwork.native_sdf() (a callable carrying the '
                             'folded MFMA-packed network) instead of an opaque Python callable')
         dev = ray_directions.device
-        intervals = torch.linspace(0, 1, steps=self.n_steps).to(dev)           # ray_tracing.py:206 (CPU values, like the reference)
+        key = (self.n_steps, str(dev))
+        if self._intervals is None or self._intervals[0] != key:               # constant per (n_steps, device): uploaded once
+            self._intervals = (key, torch.linspace(0, 1, steps=self.n_steps).to(dev))   # ray_tracing.py:206 (CPU values, like the reference)
+        intervals = self._intervals[1]
         if self.training and minsdf_steps is None:
             minsdf_steps = torch.empty(self.n_steps).uniform_(0.0, 1.0)
         if minsdf_steps is not None:

@@ -155,7 +155,8 @@ def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, mins
     B, P = ray_dirs.shape[:2]
     R = B * P
     dev = ray_dirs.device
-    om = object_mask.reshape(-1).to(torch.uint8).contiguous()
+    om = object_mask.reshape(-1).contiguous()
+    om = om.view(torch.uint8) if om.dtype == torch.bool else om.to(torch.uint8)       # bool storage is one byte 0/1: no copy
     pts = torch.empty(R, 3, dtype=torch.float32, device=dev)
     mask = torch.empty(R, dtype=torch.uint8, device=dev)
     dists = torch.empty(R, dtype=torch.float32, device=dev)
@@ -176,7 +177,7 @@ def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, mins
         if ev: ev[1].record()
         check(lib().mvsdf_trace_stage(3, *args), 'mvsdf_trace_stage(3)')
         if ev: ev[2].record()
-        mask_b = mask.bool()
+        mask_b = mask.view(torch.bool)                           # the kernels write 0 / 1 bytes
         mask_ready(mask_b)
         if ev: ev[3].record()
         check(lib().mvsdf_trace_stage(4, *args), 'mvsdf_trace_stage(4)')
@@ -194,7 +195,7 @@ def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, mins
         check(lib().mvsdf_trace_stage(2, *args), 'mvsdf_trace_stage(2)')
         ev[2].record()
         events.append(tuple(ev))
-    return pts, mask.bool(), dists, counters
+    return pts, mask.view(torch.bool), dists, counters
 
 
 def det_math(op, x):
@@ -292,16 +293,18 @@ def feat_corr(pts, view_start, feat, feat_src, cam, src_cams, size, center):
     return loss_pp, dpts
 
 
-def depth_carve(pts, depths, cams, size, center, out_thresh_perc, far_thresh, far_att, near_thresh, near_att):
-    """pts [M,3] normalised; depths [B,h,w]; cams [B,2,4,4] -> (dist_r[M], weight[M])."""
+def depth_carve(pts, depths, cams, size, center, out_thresh_perc, far_thresh, far_att, near_thresh, near_att, world_inplace=False):
+    """pts [M,3] or [M,4] (hom, contiguous) normalised; depths [B,h,w]; cams [B,2,4,4] -> (dist_r[M], weight[M]).
+    world_inplace: also overwrite pts[:, :3] with the world-space points (the reference's side effect, loss.py:38,42)."""
     pts, depths, cams = _f32(pts), _f32(depths), _f32(cams)
     M, dev = pts.shape[0], pts.device
     B, h, w = depths.shape
     dist_r = torch.empty(M, dtype=torch.float32, device=dev)
     weight = torch.empty(M, dtype=torch.float32, device=dev)
-    check(lib().mvsdf_depth_carve(ptr(pts), M, ptr(depths), B, h, w, ptr(cams), ptr(_f32(size).reshape(-1)), ptr(_f32(center).reshape(-1)),
-                                  C.c_float(out_thresh_perc), C.c_float(far_thresh), C.c_float(far_att), C.c_float(near_thresh),
-                                  C.c_float(near_att), ptr(dist_r), ptr(weight), stream_of(pts)), 'mvsdf_depth_carve')
+    check(lib().mvsdf_depth_carve(ptr(pts), pts.shape[1], M, ptr(depths), B, h, w, ptr(cams), ptr(_f32(size).reshape(-1)),
+                                  ptr(_f32(center).reshape(-1)), C.c_float(out_thresh_perc), C.c_float(far_thresh), C.c_float(far_att),
+                                  C.c_float(near_thresh), C.c_float(near_att), ptr(dist_r), ptr(weight), ptr(pts) if world_inplace else None,
+                                  stream_of(pts)), 'mvsdf_depth_carve')
     return dist_r, weight
 
 
