@@ -221,6 +221,17 @@ size_t mvsdf_adam_ws_floats(void);
 int mvsdf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step, float max_norm,
                     float* norm_out, float* ws, void* stream);
 
+/* masks -> what IDRLoss.forward needs from them, one launch: hit[R] = network_object_mask & object_mask (loss.py:21,206), view_start[B+1]
+ * = prefix sums of the per-view hit counts (rows of diff_surf_pts per view, loss.py:119-127; R = B * P rays, view-major),
+ * n_pos = #(network_object_mask & object_mask_true) (positives of the surface-indicator BCE, loss.py:167-173). */
+int mvsdf_loss_prep(const uint8_t* net_mask, const uint8_t* obj_mask, const uint8_t* true_mask, int R, int B, uint8_t* hit, int* view_start,
+                    long long* n_pos, void* stream);
+/* backward of the weighted total of mvsdf_loss_terms: g[6] = upstream of {loss, rgb, eikonal, depth, feat, surf} (device); every unit
+ * gradient tensor is scaled by (g[0] * weight + g[term]) into its output; coef_feat[1] (may be NULL) = g[0] * w_feat + g[4]. */
+int mvsdf_loss_scale(const float* g, float w_rgb, float w_eik, float w_surf, float w_feat, float w_depth, const float* d_rgb, float* g_rgb,
+                     int n_rgb, const float* d_grad, float* g_grad, int n_grad, const float* d_eo, float* g_eo, int n_eo, const float* d_sf,
+                     float* g_sf, int n_sf, float* coef_feat, void* stream);
+
 /* device self-test of the deterministic math: op 0 softplus100, 1 expneg, 2 log1p01, 3 sincos (y0=sin, y1=cos),
  * 4 div100 / div_sqrt2 (y0, y1), 5 sqrt / reciprocal (y0, y1), 6 two-wide softplus100 (y0 = f(x), y1 = f(-x)). */
 int mvsdf_det_math(int op, const float* x, int n, float* y0, float* y1, void* stream);

@@ -379,3 +379,89 @@ int mvsdf_depth_carve(const float* pts, int pts_ld, int M, const float* depths, 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Bookkeeping of IDRLoss.forward / backward as two launches instead of ~25 framework ops.
+//   k_loss_prep : hit = network_object_mask & object_mask (loss.py:21,206); per-view hit counts -> prefix sums view_start[B+1]
+//                 (which rows of diff_surf_pts belong to which view, loss.py:119-127); n_pos = #(network_object_mask & object_mask_true)
+//                 (the positives of the surface-indicator BCE, loss.py:167-173).
+//   k_loss_scale: backward of the weighted total: every stored unit gradient times (dL/dloss * weight + dL/dterm).
+__global__ __launch_bounds__(1024) void k_loss_prep(const uint8_t* __restrict__ net_mask, const uint8_t* __restrict__ obj_mask,
+                                                    const uint8_t* __restrict__ true_mask, int R, int B, uint8_t* __restrict__ hit,
+                                                    int* __restrict__ view_start, long long* __restrict__ n_pos) {
+    __shared__ int red[2][16];
+    __shared__ int run;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, P = R / B;
+    if (tid == 0) { run = 0; view_start[0] = 0; }
+    int pos_local = 0;
+    __syncthreads();
+    for (int b = 0; b < B; ++b) {
+        int c = 0;
+        for (int i = tid; i < P; i += 1024) {
+            const int r = b * P + i;
+            const bool h = net_mask[r] && obj_mask[r];
+            hit[r] = h ? 1 : 0;
+            c += h ? 1 : 0;
+            pos_local += (net_mask[r] && true_mask[r]) ? 1 : 0;
+        }
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) red[0][w] = c;
+        __syncthreads();
+        if (tid == 0) { int s = 0; for (int k = 0; k < 16; ++k) s += red[0][k]; run += s; view_start[b + 1] = run; }
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) pos_local += __shfl_xor(pos_local, o);
+    if (lane == 0) red[1][w] = pos_local;
+    __syncthreads();
+    if (tid == 0) { long long s = 0; for (int k = 0; k < 16; ++k) s += red[1][k]; *n_pos = s; }
+}
+
+struct LossScaleArgs {
+    const float* g;                       // [6] upstream of {loss, rgb, eikonal, depth, feat, surf}
+    float w_rgb, w_eik, w_surf, w_feat, w_depth;
+    const float* src[4]; float* dst[4]; int n[4];      // unit gradients of rgb / grad_theta / eikonal_output / surf -> scaled copies
+    float* coef_feat;                     // [1]: dL/d(sum of the per-point feature terms)
+};
+__global__ void k_loss_scale(LossScaleArgs a) {
+    const float g0 = a.g[0];
+    const float c[4] = {g0 * a.w_rgb + a.g[1], g0 * a.w_eik + a.g[2], g0 * a.w_depth + a.g[3], g0 * a.w_surf + a.g[5]};
+    const int total = a.n[0] + a.n[1] + a.n[2] + a.n[3];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int k = i, t = 0;
+        while (t < 3 && k >= a.n[t]) { k -= a.n[t]; ++t; }
+        a.dst[t][k] = a.src[t][k] * c[t];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.coef_feat) a.coef_feat[0] = g0 * a.w_feat + a.g[4];
+}
+
+extern "C" {
+
+int mvsdf_loss_prep(const uint8_t* net_mask, const uint8_t* obj_mask, const uint8_t* true_mask, int R, int B, uint8_t* hit, int* view_start,
+                    long long* n_pos, void* stream) {
+    if (!net_mask || !obj_mask || !true_mask || !hit || !view_start || !n_pos || R <= 0 || B <= 0 || R % B)
+        return mv_fail(-1, "mvsdf_loss_prep: bad arguments");
+    hipLaunchKernelGGL(k_loss_prep, dim3(1), dim3(1024), 0, (hipStream_t)stream, net_mask, obj_mask, true_mask, R, B, hit, view_start, n_pos);
+    return mv_check(hipGetLastError(), "mvsdf_loss_prep");
+}
+
+int mvsdf_loss_scale(const float* g, float w_rgb, float w_eik, float w_surf, float w_feat, float w_depth, const float* d_rgb, float* g_rgb,
+                     int n_rgb, const float* d_grad, float* g_grad, int n_grad, const float* d_eo, float* g_eo, int n_eo, const float* d_sf,
+                     float* g_sf, int n_sf, float* coef_feat, void* stream) {
+    if (!g || n_rgb < 0 || n_grad < 0 || n_eo < 0 || n_sf < 0) return mv_fail(-1, "mvsdf_loss_scale: bad arguments");
+    LossScaleArgs a;
+    a.g = g; a.w_rgb = w_rgb; a.w_eik = w_eik; a.w_surf = w_surf; a.w_feat = w_feat; a.w_depth = w_depth;
+    const float* src[4] = {d_rgb, d_grad, d_eo, d_sf};
+    float* dst[4] = {g_rgb, g_grad, g_eo, g_sf};
+    const int n[4] = {n_rgb, n_grad, n_eo, n_sf};
+    int total = 0;
+    for (int t = 0; t < 4; ++t) {
+        if (n[t] > 0 && (!src[t] || !dst[t])) return mv_fail(-1, "mvsdf_loss_scale: null tensor with a positive count");
+        a.src[t] = src[t]; a.dst[t] = dst[t]; a.n[t] = n[t]; total += n[t];
+    }
+    a.coef_feat = coef_feat;
+    const int blocks = total > 0 ? (total + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_loss_scale, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return mv_check(hipGetLastError(), "mvsdf_loss_scale");
+}
+
+}  // extern "C"

@@ -253,15 +253,10 @@ class _LossTerms(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         d_rgb, d_grad, d_eo, d_sf = ctx.saved
-        w = ctx.weights
-        c_rgb, c_eik, c_depth = g[0] * w[0] + g[1], g[0] * w[1] + g[2], g[0] * w[4] + g[3]
-        c_surf, c_feat = g[0] * w[2] + g[5], g[0] * w[3] + g[4]
-        g_rgb = d_rgb * c_rgb
-        g_grad = d_grad * c_eik if d_grad is not None else None
-        g_eo = (d_eo * c_depth).view(ctx.shapes[0])
-        g_sf = d_sf * c_surf if (d_sf is not None and ctx.on[0]) else None
+        use_sf = d_sf is not None and ctx.on[0]
+        (g_rgb, g_grad, g_eo, g_sf), c_feat = ops.loss_scale(g, ctx.weights, [d_rgb, d_grad, d_eo, d_sf if use_sf else None])   # one launch
         g_fp = c_feat.expand(ctx.shapes[1]) if (ctx.shapes[1] is not None and ctx.on[1]) else None
-        return g_rgb, g_grad, g_eo, g_sf, g_fp, None, None, None, None, None, None, None, None
+        return g_rgb, g_grad, g_eo.view(ctx.shapes[0]), g_sf, g_fp, None, None, None, None, None, None, None, None
 
 
 def feat_corr_terms(pts, view_start, feat, feat_src, cam, src_cams, size, center):

@@ -88,7 +88,9 @@ class IDRLoss(nn.Module):
         if conf.smooth(train_progress) is not None or conf.use_invalid or not conf.enable_rgb:
             raise NotImplementedError('smooth / use_invalid / enable_rgb=False are off in the reference conf (model/conf.py:17-25)')
 
-        hit_mask = network_object_mask & object_mask
+        # masks -> hit mask, per-view row ranges of diff_surf_pts, number of BCE positives: one launch (csrc/loss_kernels.hip::k_loss_prep)
+        n_views = ground_truth['feat'].size()[0] if 'feat' in ground_truth else 1
+        hit_mask, view_start, n_pos = ops.loss_prep(network_object_mask, object_mask, model_outputs['object_mask_true'], n_views)
         phase1 = conf.phase[0] <= train_progress
         feat_on = bool(phase1 and conf.enable_feat)
         feat_pp = None
@@ -96,13 +98,10 @@ class IDRLoss(nn.Module):
         if feat_on and pts.shape[0] > 0:
             if model_outputs.get('uncerts') is not None:
                 raise NotImplementedError('uncerts is always None in the reference (loss.py:197)')
-            counts = hit_mask.view(ground_truth['feat'].size()[0], -1).sum(-1)
-            view_start = torch.cat([torch.zeros(1, dtype=counts.dtype, device=dev), counts.cumsum(0)]).to(torch.int32)
             feat_pp = Fn.feat_corr_terms(pts, view_start, ground_truth['feat'], ground_truth['feat_src'], ground_truth['cam'],
                                          ground_truth['src_cams'], ground_truth['size'], ground_truth['center'])
         dist_r, dweight = self._carve(model_outputs['eikonal_points_hom'], ground_truth['depths'], ground_truth['depth_cams'],
                                       ground_truth['size'], ground_truth['center'], train_progress)
-        n_pos = (network_object_mask & model_outputs['object_mask_true']).sum()
         weights = (conf.rgb_weight(train_progress), conf.eikonal_weight, conf.surf_weight, conf.feat_weight(train_progress),
                    conf.depth_weight(train_progress))
         out = Fn.loss_terms(model_outputs['rgb_values'], model_outputs['grad_theta'], model_outputs['eikonal_output'],

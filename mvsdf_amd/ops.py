@@ -390,3 +390,31 @@ def dsurf_samples(depths, depth_cams, size, center, bb, jitter_rad, seed, n):
     pts_jit = torch.empty(n, 3, dtype=torch.float32, device=dev)
     check(lib().mvsdf_dsurf_points(*geo, ptr(idx_sorted), ptr(counts), ptr(pts_on), ptr(pts_jit), stream_of(depths)), 'mvsdf_dsurf_points')
     return pts_on, pts_jit, counts, idx_sorted
+
+
+# ---- loss bookkeeping (csrc/loss_kernels.hip)
+def loss_prep(net_mask, obj_mask, true_mask, B):
+    """-> (hit bool [R], view_start int32 [B+1], n_pos int64 scalar tensor); see mvsdf_loss_prep."""
+    u8 = lambda m: (m.reshape(-1).contiguous().view(torch.uint8) if m.dtype == torch.bool else m.reshape(-1).to(torch.uint8).contiguous())
+    nm, om, tm = u8(net_mask), u8(obj_mask), u8(true_mask)
+    R, dev = nm.numel(), nm.device
+    hit = torch.empty(R, dtype=torch.uint8, device=dev)
+    vs = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    n_pos = torch.empty((), dtype=torch.int64, device=dev)
+    check(lib().mvsdf_loss_prep(ptr(nm), ptr(om), ptr(tm), R, B, ptr(hit), ptr(vs), ptr(n_pos), stream_of(nm)), 'mvsdf_loss_prep')
+    return hit.view(torch.bool), vs, n_pos
+
+
+def loss_scale(g, weights, unit_grads):
+    """unit_grads: [d_rgb, d_grad, d_eo, d_sf] (None allowed) -> (scaled copies in the same order, coef_feat [1]).  weights =
+    (w_rgb, w_eik, w_surf, w_feat, w_depth) as in loss_terms."""
+    g = _f32(g)
+    outs = [torch.empty_like(t) if t is not None else None for t in unit_grads]
+    coef = torch.empty(1, dtype=torch.float32, device=g.device)
+    a = []
+    for t, o in zip(unit_grads, outs):
+        a += [ptr(t) if t is not None else None, ptr(o) if o is not None else None, t.numel() if t is not None else 0]
+    w = [float(v) for v in weights]
+    check(lib().mvsdf_loss_scale(g.data_ptr(), w[0], w[1], w[2], w[3], w[4], *[x.value if hasattr(x, 'value') else x for x in a],
+                                 coef.data_ptr(), stream_of(g).value), 'mvsdf_loss_scale')
+    return outs, coef
