@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from ..utils.general import PinnedUniform
 from .. import ops
 from ..utils import rend_util
 from . import conf as _default_conf
@@ -143,6 +144,7 @@ class IDRNetwork(nn.Module):
         self.last_stats = {}
         self._counts_host = None                                 # pinned [N hit, N hit & true mask], filled while the tracer still runs
         self._counts_event = None
+        self._draw = PinnedUniform()
 
     # ------------------------------------------------------------------------------------------------------------
     def _dsurf_samples(self, input, n_dsurf_points, bb):
@@ -212,7 +214,7 @@ class IDRNetwork(nn.Module):
         if self.training:
             bb = self.object_bounding_sphere
             n_eik_points = R // 2
-            eikonal_points = torch.empty(n_eik_points, 3).uniform_(-bb, bb).to(dev, non_blocking=True)     # idr.py:216-221
+            eikonal_points = self._draw((n_eik_points, 3), -bb, bb, dev)            # idr.py:216-221 (CPU generator, async copy)
             if dsurf is not None:
                 dsurf_on_sample, dsurf_jitter_sample = dsurf[0], dsurf[1]
             else:

@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..utils.general import PinnedUniform
 
 
 class NativeSDF:
@@ -34,6 +35,7 @@ class RayTracing(nn.Module):
         self.mt = None                      # row tiles per sphere-tracing workgroup (None: pick from the ray count)
         self.mt_samples = None              # row tiles per chunk of the sample-row kernels
         self._intervals = None
+        self._draw = PinnedUniform()
         self.events = None                  # set to a list to have per-kernel (start, mid, end) events appended each call
 
     def _params(self):
@@ -60,8 +62,8 @@ class RayTracing(nn.Module):
             self._intervals = (key, torch.linspace(0, 1, steps=self.n_steps).to(dev))   # ray_tracing.py:206 (CPU values, like the reference)
         intervals = self._intervals[1]
         if self.training and minsdf_steps is None:
-            minsdf_steps = torch.empty(self.n_steps).uniform_(0.0, 1.0)
-        if minsdf_steps is not None:
+            minsdf_steps = self._draw((self.n_steps,), 0.0, 1.0, dev)           # CPU generator, pinned staging, async copy
+        elif minsdf_steps is not None:
             minsdf_steps = minsdf_steps.to(dev, non_blocking=True)
         R = ray_directions.shape[0] * ray_directions.shape[1]
         # rays per sphere-tracing workgroup = 8 * mt: one row tile per CU while the batch is small (latency-shaped), 4 tiles once the

@@ -26,3 +26,30 @@ def merge_output(res, total_pixels, batch_size):
         if parts[0].shape[-1] == 1:
             merged[k] = merged[k].reshape(batch_size * total_pixels)
     return merged
+
+
+class PinnedUniform:
+    """Uniform draws from torch's CPU generator (the reference draws eikonal points and min-sdf steps on the CPU, idr.py:216-221,
+    ray_tracing.py:287) delivered to the device WITHOUT a blocking copy: the values are drawn straight into one of two pinned
+    staging buffers (same RNG stream, same values as torch.empty(shape).uniform_(lo, hi)) and copied asynchronously.  Two buffers
+    alternate; a buffer is only redrawn once the copy that last read it has completed (an event per buffer, normally long done)."""
+
+    def __init__(self):
+        self._bufs, self._k = {}, 0
+
+    def __call__(self, shape, lo, hi, device):
+        shape = tuple(shape)
+        key = (shape, self._k & 1)
+        self._k += 1
+        slot = self._bufs.get(key)
+        if slot is None:
+            slot = self._bufs[key] = [torch.empty(shape).pin_memory(), None]
+        buf, ev = slot
+        if ev is not None:
+            ev.synchronize()
+        buf.uniform_(lo, hi)
+        out = buf.to(device, non_blocking=True)
+        if out.is_cuda:
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+        return out
