@@ -66,9 +66,10 @@ class RayTracing(nn.Module):
         elif minsdf_steps is not None:
             minsdf_steps = minsdf_steps.to(dev, non_blocking=True)
         R = ray_directions.shape[0] * ray_directions.shape[1]
-        # rays per sphere-tracing workgroup = 8 * mt: one row tile per CU while the batch is small (latency-shaped), 4 tiles once the
-        # chip is over-subscribed (finer compaction of the rays still active; measured +6 % at 8k-32k rays)
-        mt = self.mt or int(os.environ.get('MVSDF_MT', '0')) or (1 if R <= 4096 else 4)
+        # rays per sphere-tracing workgroup = 8 * mt: one workgroup per CU (256 of them) while the batch allows it -- the kernel is a chain
+        # of dependent evaluations, so fewer, fuller workgroups beat two contending ones per CU (4096 rays: 4.17 -> 3.97 ms per step with
+        # mt = 2); 4 tiles once the chip is over-subscribed anyway (finer compaction of the rays still active; +6 % at 8k-32k rays)
+        mt = self.mt or int(os.environ.get('MVSDF_MT', '0')) or (1 if R <= 2048 else (2 if R <= 4096 else 4))
         mt_samples = self.mt_samples or int(os.environ.get('MVSDF_MT_SAMPLES', '2'))
         pts, mask, dists, counters = ops.trace(net, cam_loc, ray_directions, object_mask, self._params(), self.training, intervals,
                                                minsdf_steps, mt=mt, mt_samples=mt_samples, events=self.events,
