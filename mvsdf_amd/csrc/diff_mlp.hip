@@ -346,8 +346,32 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
     auto Uof = [&](int l) { return ctx + lo.U[l] + r0 * net.L[l - 1].N; };       // u_l has width out_{l-1}
     auto Sof = [&](int l) { return ctx + lo.Sg[l] + r0 * net.L[l].N; };
     const float* G0 = ctx + lo.G0 + r0 * lo.ld0;
+    // ---- the whole pass in one launch per row tile (gbar_0, E.1, E.2, input adjoint) when the chain kernels fit the network ----
+    static int fuse_all = -1;
+    if (fuse_all < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_all = e ? atoi(e) : 1; if (getenv("MVSDF_SPLIT_CHAINS")) fuse_all = 0; }
+    const int ntw_b = mv_chain_ntw(net);
+    bool chains_done = false;
+    if (fuse_all >= 1 && ntw_b) {                               // MVSDF_SPLIT_CHAINS=1: the separate E.1 / E.2 launches (dev A/B)
+        ChainArgs c;
+        memset(&c, 0, sizeof(c));
+        c.net = net; c.netT = netT; c.S = S; c.M = Mb; c.row_ld0 = lo.ld0;
+        c.dy = dy; c.ld_dy = net.L[nl - 1].N; c.w_last_row0 = w8;
+        for (int l = 0; l < nl - 1; ++l) {
+            c.Z[l] = Zof(l); c.ZB[l] = ws + bl.ZB[l];
+            c.ZB2[l] = dn ? ws + bl.ZB2[l] : nullptr; c.ZB2o[l] = ws + bl.ZB2[l];
+            if (l + 1 < nl - 1) c.U[l + 1] = Uof(l + 1);
+            c.VB[l + 1] = ws + bl.VB[l + 1];
+        }
+        c.H0B = ws + bl.H0B; c.H0 = H0; c.G0 = G0; c.dn_in = dn; c.VB0w = ws + bl.VB[0]; c.dx = dx;
+        constexpr int MTC = 1, NWC = 8;
+        const size_t lds = (size_t)16 * MTC * (S + lo.d0) * sizeof(float);
+        if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd<MTC, 2, NWC>), dim3((Mb + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, c);
+        else hipLaunchKernelGGL((k_chain_bwd<MTC, 4, NWC>), dim3((Mb + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, c);
+        MV_TRY(hipGetLastError());
+        chains_done = true;
+    }
     // ---- E.1: adjoint of the normal chain (ascending) ----
-    if (dn) {
+    if (dn && !chains_done) {
         hipLaunchKernelGGL(k_pe_normal_bwd, dim3((Mb * (3 * net.multires + 1) + 255) / 256), dim3(256), 0, s, H0, lo.ld0, dn, Mb,
                            net.multires, ws + bl.VB[0], lo.ld0, sk > 0 ? ws + bl.VB[sk] : nullptr, sk > 0 ? net.L[sk].K : 0,
                            sk > 0 ? net.L[sk].K - lo.d0 : 0);
@@ -383,6 +407,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         }
     }
     // ---- E.2: adjoint of the value chain (descending) ----
+    if (!chains_done) {
     static int fuse_env = -1;
     if (fuse_env < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_env = e ? atoi(e) : 1; }
     const int ntw_2 = mv_chain_ntw(net);
@@ -429,6 +454,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         cur ^= 1;
     }
     }
+    }   // !chains_done
     // ---- weight / bias gradients: W_l = zbar_l^T a_l (+ s_l^T vbar_l), every layer in one launch + one reduction ----
     if (dW_cat) {                                                                  // dW_cat == NULL: input adjoint only
         WgradNetArgs wa;
@@ -452,7 +478,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         MV_TRY(launch_wgrad_net(wa, s));
     }
     // ---- E.3: input adjoint ----
-    if (dx)
+    if (dx && !chains_done)
         hipLaunchKernelGGL(k_pe_input_bwd, dim3((Mb * 3 + 255) / 256), dim3(256), 0, s, H0, lo.ld0, ws + bl.H0B, lo.ld0, G0, lo.ld0,
                            dn, Mb, net.multires, dx);
     return mv_check(hipGetLastError(), "mvsdf_sdf_backward");

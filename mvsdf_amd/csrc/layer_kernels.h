@@ -434,6 +434,11 @@ struct ChainArgs {
     const float* VB0;                          // E.1 in: gbar_0 [M][ld0]
     float* VB[MV_MAXL];                        // E.1 out: vbar_l [M][K_l] (l >= 1)
     float* ZB2o[MV_MAXL];                      // E.1 out
+    // k_chain_bwd (whole pass in one launch)
+    const float* H0; const float* G0;          // PE values / forward g_0 [M][row_ld0]
+    const float* dn_in;                        // [M][3] upstream of the normals (null: E.2 only)
+    float* VB0w;                               // vbar_0 out [M][row_ld0]
+    float* dx;                                 // [M][3] input adjoint (null: not needed)
 };
 
 // E.2 (descending): hb_L = dy W_L;  for l = L-1..0: zb_l = sigma_l . hb_{l+1} + zb2_l (stored), ab_l = zb_l W_l, split at the skip layer.
@@ -596,6 +601,202 @@ __global__ __launch_bounds__(64 * NW) void k_chain_e1(ChainArgs a) {
                     act[rr * S + mv_perm(Kn + j)] = 0.0f;
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One backward pass of the SDF network per row tile in ONE launch: gbar_0 = J_PE nbar (k_pe_normal_bwd), the ascending E.1 chain, the
+// descending E.2 chain and the input adjoint xbar = J_PE^T hbar_0 + second-order PE term (k_pe_input_bwd, App. E.3).  Same arithmetic
+// as those four launches; z_l bar 2 (E.1 -> E.2) goes through global memory of the same workgroup (L2-hot).  dn_in == NULL: E.2 only.
+template <int MT, int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_chain_bwd(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * MT, NTH = 64 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers, sk = a.net.skip_layer, d0 = 3 + 6 * a.net.multires;
+    float* act = smem;
+    float* g0s = smem + ROWS * S;                                // [ROWS][d0]: gbar_0 (E.1), then the PE adjoint (E.2)
+    float* pe_adj = g0s;
+    if (a.dn_in) {
+        {   // gbar_0 = J_PE nbar
+            const int Kp0 = a.net.L[0].KB * 16;
+            for (int idx = tid; idx < ROWS * Kp0; idx += NTH) {
+                const int rr = idx / Kp0, k = idx - rr * Kp0, row = row0 + rr;
+                float v = 0.0f;
+                if (row < a.M && k < d0) {
+                    const float* h = a.H0 + (size_t)row * a.row_ld0;
+                    const float* nb = a.dn_in + (size_t)row * 3;
+                    if (k < 3) v = nb[k];
+                    else {
+                        const int jj = k - 3, m = jj / 6, rem = jj - 6 * m, c = rem % 3;
+                        const float f = (float)(1 << m);
+                        v = rem < 3 ? f * h[6 + 6 * m + c] * nb[c] : -f * h[3 + 6 * m + c] * nb[c];
+                    }
+                }
+                if (row < a.M && k < a.row_ld0) a.VB0w[(size_t)row * a.row_ld0 + k] = v;    // vbar_0 for the weight gradient
+                act[rr * S + mv_perm(k)] = v;
+                if (k < d0) g0s[rr * d0 + k] = v;
+            }
+        }
+        for (int l = 0; l < nl - 1; ++l) {
+            const MvLayer& L = a.net.L[l];
+            const int N = L.N;
+            const bool top = (l == nl - 2), to_skip = (l + 1 == sk);
+            const int NT = L.NT, per = (NT + NW - 1) / NW, ct0 = w * per;
+            int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
+            f32x4 acc[MT][NTW];
+            mv_zero_acc<MT, NTW>(acc);
+            // side inputs of the epilogue (z_l, u_{l+1}): requested BEFORE the GEMM so their latency hides behind it
+            float zz[NTW][MT][4], uu[NTW][MT][4];
+    #pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int col = (ct0 + t) * 16 + r;
+    #pragma unroll
+                for (int m = 0; m < MT; ++m)
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = row0 + m * 16 + 4 * q + i;
+                        zz[t][m][i] = 0.f; uu[t][m][i] = 0.f;
+                        if (t < ntw && col < N && row < a.M) {
+                            zz[t][m][i] = a.Z[l][(size_t)row * N + col];
+                            uu[t][m][i] = top ? a.w_last_row0[col] : a.U[l + 1][(size_t)row * N + col];
+                        }
+                    }
+            }
+            mv_barrier_lds();                                        // the tile lives in LDS; the side loads above stay in flight
+            if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
+            mv_barrier_lds();
+            const int ldn = a.net.L[l + 1].K;                        // row length of vbar_{l+1}
+    #pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                if (t < ntw) {
+                    const int col = (ct0 + t) * 16 + r;
+                    if (col < N) {
+    #pragma unroll
+                        for (int m = 0; m < MT; ++m)
+    #pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int rr = m * 16 + 4 * q + i, row = row0 + rr;
+                                const float sb = acc[m][t][i];
+                                const float sig = dm_sigmoid100(zz[t][m][i]);
+                                float ub = sig * sb;
+                                if (to_skip) ub = dm_div_sqrt2(ub);
+                                act[rr * S + mv_perm(col)] = ub;
+                                if (row < a.M) {
+                                    a.VB[l + 1][(size_t)row * ldn + col] = ub;
+                                    a.ZB2o[l][(size_t)row * N + col] = uu[t][m][i] * sb * mv_sigmoid_prime100(zz[t][m][i], sig);
+                                }
+                            }
+                    }
+                }
+            }
+            if (l + 1 < nl - 1 || true) {
+                const int Kn = a.net.L[l + 1].K, Kpn = a.net.L[l + 1].KB * 16;
+                if (to_skip)
+                    for (int idx = tid; idx < ROWS * d0; idx += NTH) {
+                        const int rr = idx / d0, j = idx - rr * d0, row = row0 + rr;
+                        const float tv = dm_div_sqrt2(g0s[rr * d0 + j]);
+                        act[rr * S + mv_perm(N + j)] = tv;
+                        if (row < a.M) a.VB[l + 1][(size_t)row * ldn + N + j] = tv;     // PE tail of the skip layer's vbar
+                    }
+                if (Kpn > Kn) {
+                    const int pad = Kpn - Kn;
+                    for (int idx = tid; idx < ROWS * pad; idx += NTH) {
+                        const int rr = idx / pad, j = idx - rr * pad;
+                        act[rr * S + mv_perm(Kn + j)] = 0.0f;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                         // zbar2 of this tile written (global) before E.2 reads it
+    }
+    for (int i = tid; i < ROWS * d0; i += NTH) pe_adj[i] = 0.0f;
+    for (int l = nl - 1; l >= 0; --l) {
+        const MvLayer& L = a.netT.L[l];                          // contraction over out_l (K), produces in_l columns (N)
+        const int K = L.K, Kp = L.KB * 16, N = L.N;
+        // ---- prologue: build the A tile (zbar_l, or dy for the last layer) in LDS
+        for (int base = 0; base < ROWS * Kp; base += NTH * 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NTH + tid;
+                const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
+                v[u] = 0.0f;
+                if (idx < ROWS * Kp && row < a.M && k < K) {
+                    if (l == nl - 1) v[u] = a.dy[(size_t)row * a.ld_dy + k];
+                    else {
+                        float zb = dm_sigmoid100(a.Z[l][(size_t)row * K + k]) * act[rr * S + mv_perm(k)];
+                        if (a.ZB2[l]) zb += a.ZB2[l][(size_t)row * K + k];
+                        a.ZB[l][(size_t)row * K + k] = zb;
+                        v[u] = zb;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NTH + tid;
+                const int rr = idx / Kp, k = idx - rr * Kp;
+                if (idx < ROWS * Kp) act[rr * S + mv_perm(k)] = v[u];
+            }
+        }
+        __syncthreads();
+        // ---- GEMM
+        const int NT = L.NT, per = (NT + NW - 1) / NW, ct0 = w * per;
+        int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
+        f32x4 acc[MT][NTW];
+        mv_zero_acc<MT, NTW>(acc);
+        if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
+        __syncthreads();
+        // ---- epilogue: hb for the next (lower) layer stays in LDS; PE adjoint goes to global
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            if (t < ntw) {
+                const int col = (ct0 + t) * 16 + r;
+                if (col < N) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int rr = m * 16 + 4 * q + i, row = row0 + rr;
+                            float v = acc[m][t][i];
+                            if (l == sk) {
+                                v = dm_div_sqrt2(v);
+                                if (col < N - d0) act[rr * S + mv_perm(col)] = v;
+                                else pe_adj[rr * d0 + (col - (N - d0))] = v;
+                            } else if (l == 0) {
+                                const float hb0 = pe_adj[rr * d0 + col] + v;
+                                pe_adj[rr * d0 + col] = hb0;                       // kept for the input adjoint below
+                                if (row < a.M) a.H0B[(size_t)row * a.row_ld0 + col] = hb0;
+                            } else {
+                                act[rr * S + mv_perm(col)] = v;
+                            }
+                        }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (a.dx) {
+        __syncthreads();
+        for (int idx = tid; idx < ROWS * 3; idx += NTH) {        // xbar = J_PE^T hbar_0 + sum_k PE''_k g0[k] nbar[c(k)]
+            const int rr = idx / 3, c = idx - 3 * rr, row = row0 + rr;
+            if (row >= a.M) continue;
+            const float* h = a.H0 + (size_t)row * a.row_ld0;
+            const float* hb = pe_adj + rr * d0;
+            float v = hb[c], second = 0.0f;
+            for (int m = 0; m < a.net.multires; ++m) {
+                const float f = (float)(1 << m);
+                const float sn = h[3 + 6 * m + c], co = h[6 + 6 * m + c];
+                v += f * (co * hb[3 + 6 * m + c] - sn * hb[6 + 6 * m + c]);
+                if (a.dn_in) {
+                    const float* g = a.G0 + (size_t)row * a.row_ld0;
+                    second -= f * f * (sn * g[3 + 6 * m + c] + co * g[6 + 6 * m + c]);
+                }
+            }
+            if (a.dn_in) v += second * a.dn_in[(size_t)row * 3 + c];
+            a.dx[(size_t)row * 3 + c] = v;
         }
     }
 }
