@@ -11,9 +11,9 @@ OptimizerParameters/*.pth checkpoints (idr_train.py:171-177) load and save uncha
 import ctypes as C
 
 import torch
-import torch.distributed as dist
 
 from ._lib import lib, check
+from .parallel import all_reduce_mean_
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -63,9 +63,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     def all_reduce_mean(self):
         """The step's one collective (RCCL over xGMI): gradients averaged over ranks.  No-op without a process group."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
-            self.flat_g.div_(dist.get_world_size())
+        all_reduce_mean_(self.flat_g)
 
     @torch.no_grad()
     def step(self, closure=None, grad_cap=None):

@@ -10,6 +10,15 @@ import torch
 import torch.distributed as dist
 
 
+def all_reduce_mean_(flat):
+    """The step's one collective: SUM all-reduce of a flat gradient buffer + division by the world size (RCCL over xGMI with the
+    `nccl` backend; gloo in the CPU tests).  No-op without an initialised process group.  Shared by FlatGradBucket and optim.FlatAdam."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+    return flat
+
+
 class FlatGradBucket:
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
@@ -34,9 +43,7 @@ class FlatGradBucket:
 
     def all_reduce_mean(self):
         """One collective for all gradients; no-op without an initialised process group."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(dist.get_world_size())
+        all_reduce_mean_(self.flat)
 
     def grad_norm(self):
         return self.flat.norm()
