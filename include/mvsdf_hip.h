@@ -69,8 +69,8 @@ size_t mvsdf_packed_floats(int N, int K);
  * v[N][K], g[N] -> w[N][K] (row-major, required), wp (packed W, mvsdf_packed_floats(N, K) floats, may be NULL),
  * wpT (packed W^T for contractions over the OUT dimension, mvsdf_packed_floats(K, N) floats, may be NULL). */
 int mvsdf_fold_pack(const float* v, const float* g, int N, int K, float* w, float* wp, float* wpT, void* stream);
-/* all layers of a network at once (one fold launch + one pack launch).  The pointer arrays are HOST arrays of n_layers device
- * pointers; wp[l] / wpT[l] may be NULL. */
+/* all layers of a network -- or of several networks, up to 24 layers in total -- at once (one fold launch + one pack launch).  The
+ * pointer arrays are HOST arrays of n_layers device pointers; wp[l] / wpT[l] may be NULL. */
 int mvsdf_fold_pack_net(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w,
                         float* const* wp, float* const* wpT, void* stream);
 /* backward of every fold in one launch.  db / dbias (both NULL or both given; entries may be NULL pairwise) route the bias

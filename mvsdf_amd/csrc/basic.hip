@@ -42,13 +42,15 @@ __global__ void k_pack(const float* __restrict__ w, int N, int K, int transposed
     }
 }
 
-// ---- whole-network variants: one launch folds / packs every layer (blockIdx.y selects the layer) ----
+// ---- whole-network variants: one launch folds / packs every layer (blockIdx.y selects the layer); the layer list may span several
+// networks (SDF + rendering net of a step: 9 + 5 layers) ----
+#define MV_FOLD_MAXL 24
 struct FoldNetArgs {
     int n_layers;
-    const float* v[MV_MAXL]; const float* g[MV_MAXL]; const float* dW[MV_MAXL];
-    float* w[MV_MAXL]; float* wp[MV_MAXL]; float* wpT[MV_MAXL]; float* dv[MV_MAXL]; float* dg[MV_MAXL];
-    const float* db[MV_MAXL]; float* dbias[MV_MAXL];      // backward only: bias gradients routed to their sink (optional)
-    int N[MV_MAXL], K[MV_MAXL];
+    const float* v[MV_FOLD_MAXL]; const float* g[MV_FOLD_MAXL]; const float* dW[MV_FOLD_MAXL];
+    float* w[MV_FOLD_MAXL]; float* wp[MV_FOLD_MAXL]; float* wpT[MV_FOLD_MAXL]; float* dv[MV_FOLD_MAXL]; float* dg[MV_FOLD_MAXL];
+    const float* db[MV_FOLD_MAXL]; float* dbias[MV_FOLD_MAXL];      // backward only: bias gradients routed to their sink (optional)
+    int N[MV_FOLD_MAXL], K[MV_FOLD_MAXL];
     int accumulate;                                       // backward only: add into dv / dg / dbias instead of overwriting
 };
 
@@ -275,7 +277,7 @@ int mvsdf_fold_pack(const float* v, const float* g, int N, int K, float* w, floa
 }
 
 static int fill_fold_args(FoldNetArgs& a, int n_layers, const int* N, const int* K, int* maxN, size_t* maxTot) {
-    if (n_layers < 1 || n_layers > MV_MAXL || !N || !K) return mv_fail(-1, "fold (net): bad layer count / dims");
+    if (n_layers < 1 || n_layers > MV_FOLD_MAXL || !N || !K) return mv_fail(-1, "fold (net): bad layer count / dims");
     memset(&a, 0, sizeof(a));
     a.n_layers = n_layers;
     *maxN = 0; *maxTot = 0;

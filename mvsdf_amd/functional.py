@@ -55,6 +55,27 @@ class _FoldNet(torch.autograd.Function):
         return (None,) + tuple(dvs) + tuple(dg.view_as(g) for dg, g in zip(dgs, gs)) + tuple(dbs)
 
 
+def fold_networks(specs):
+    """Several networks folded by ONE autograd node (one fold launch + one pack launch forward, one launch backward).
+    specs: list of (vs, gs, bs, skip_layer, multires) -> list of (PackedNet, [w linked to autograd], [biases linked to autograd])."""
+    layers, vs_all, gs_all, bs_all, cuts = [], [], [], [], []
+    for vs, gs, bs, _, _ in specs:
+        for v, b in zip(vs, bs):
+            L = ops.PackedLayer()
+            L.bias = b.detach()
+            L.N, L.K = v.shape
+            layers.append(L)
+        vs_all += list(vs); gs_all += list(gs); bs_all += list(bs)
+        cuts.append(len(layers))
+    n = len(layers)
+    out = _FoldNet.apply(layers, *vs_all, *gs_all, *bs_all)
+    res, lo = [], 0
+    for (vs, gs, bs, skip_layer, multires), hi in zip(specs, cuts):
+        res.append((ops.PackedNet(layers[lo:hi], skip_layer, multires), list(out[lo:hi]), list(out[n + lo:n + hi])))
+        lo = hi
+    return res
+
+
 def fold_network(vs, gs, bs, skip_layer, multires):
     """-> (PackedNet, [w tensors linked to autograd], [biases linked to autograd])"""
     layers = []

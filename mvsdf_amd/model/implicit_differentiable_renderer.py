@@ -87,11 +87,14 @@ class ImplicitNetwork(nn.Module):
     def _lins(self):
         return [getattr(self, 'lin' + str(l)) for l in range(self.num_layers - 1)]
 
+    def fold_spec(self):
+        lins = self._lins()
+        return ([m.weight_v for m in lins], [m.weight_g for m in lins], [m.bias for m in lins], self.skip_in[0] if self.skip_in else -1,
+                self.multires)
+
     def fold(self):
         """-> (PackedNet, folded weights linked to autograd, biases)."""
-        lins = self._lins()
-        return Fn.fold_network([m.weight_v for m in lins], [m.weight_g for m in lins], [m.bias for m in lins],
-                               self.skip_in[0] if self.skip_in else -1, self.multires)
+        return Fn.fold_network(*self.fold_spec())
 
     def native_sdf(self):
         return NativeSDF(self.fold()[0])
@@ -123,9 +126,12 @@ class RenderingNetwork(nn.Module):
             w, b = _linear_default_init(dims[l], dims[l + 1])
             setattr(self, 'lin' + str(l), _WNLinear(w, b))
 
-    def fold(self):
+    def fold_spec(self):
         lins = [getattr(self, 'lin' + str(l)) for l in range(self.num_layers - 1)]
-        return Fn.fold_network([m.weight_v for m in lins], [m.weight_g for m in lins], [m.bias for m in lins], -1, 0)
+        return ([m.weight_v for m in lins], [m.weight_g for m in lins], [m.bias for m in lins], -1, 0)
+
+    def fold(self):
+        return Fn.fold_network(*self.fold_spec())
 
     def forward(self, points, normals, view_dirs, feature_vectors, folded=None):
         net, ws, bs = folded if folded is not None else self.fold()
@@ -170,7 +176,8 @@ class IDRNetwork(nn.Module):
         R = batch_size * num_pixels
         dev = ray_dirs.device
 
-        net, ws, bs = self.implicit_network.fold()              # one weight-norm fold per step
+        # one weight-norm fold per step, both networks in one launch pair (and one backward launch)
+        (net, ws, bs), (rnet, rws, rbs) = Fn.fold_networks([self.implicit_network.fold_spec(), self.rendering_network.fold_spec()])
         n_dsurf_points, dsurf = 0, None
         if self.training:
             assert train_progress is not None
@@ -226,7 +233,6 @@ class IDRNetwork(nn.Module):
             # Rows that receive gradients form the prefix [0, E + N): the backward skips the non-hit rays.
             x_eval = torch.cat([eikonal_points, dsurf_on_sample, dsurf_jitter_sample, pts_sorted], 0)
             y_eval, n_eval, saved = ops.sdf_forward(net, x_eval, R + E)
-            rnet, rws, rbs = self.rendering_network.fold()       # independent of N: enqueued before the wait
             st = Fn.StepState()
             st.net, st.x_eval, st.y_eval, st.n_eval, st.saved = net, x_eval, y_eval, n_eval, saved
             st.R, st.E, st.n_eik, st.n_ds = R, E, n_eik_points, n_dsurf_points
@@ -266,7 +272,8 @@ class IDRNetwork(nn.Module):
             view = -ray_dirs[hit_idx]
             rgb_values = torch.ones_like(points)
             if N > 0:
-                rgb = self._rgb_from_shared(shared, ws, bs, differentiable_surface_points, view, N, train_progress, row0)
+                rgb = self._rgb_from_shared(shared, ws, bs, differentiable_surface_points, view, N, train_progress, row0,
+                                            folded=(rnet, rws, rbs))
                 rgb_values = rgb_values.index_put((hit_idx,), rgb)                                           # idr.py:302-304
 
         out = {
@@ -286,13 +293,13 @@ class IDRNetwork(nn.Module):
         self.last_stats = {'R': R, 'N': N, 'E': (x_all.shape[0] - R), 'counters': self.ray_tracer.last_counters}
         return out
 
-    def _rgb_from_shared(self, shared, ws, bs, points, view_dirs, N, train_progress, row0=0):
+    def _rgb_from_shared(self, shared, ws, bs, points, view_dirs, N, train_progress, row0=0, folded=None):
         defer = self.training and points.requires_grad and points.grad_fn is not None
         y2, normals = Fn.sdf_reuse(shared, ws, bs, points, N, defer_dw=defer, row0=row0)                               # idr.py:325-327
         feature_vectors = y2[:, 2:]
         if (train_progress is not None and train_progress < conf.phase[0]) or conf.disable_rgb_grad:         # idr.py:331-334
             points, normals, view_dirs = [a.detach() for a in (points, normals, view_dirs)]
-        return self.rendering_network(points, normals, view_dirs, feature_vectors)
+        return self.rendering_network(points, normals, view_dirs, feature_vectors, folded=folded)
 
     def get_rbg_value(self, points, view_dirs, train_progress):
         """Stand-alone form (idr.py:324-338): evaluates the SDF net at `points` afresh."""
