@@ -162,12 +162,14 @@ int mvsdf_depth_carve(const float* pts, int pts_ld, int M, const float* depths, 
 /* ---- the elementwise terms of IDRLoss.forward + weighted total (loss.py:21-35, 58-61, 167-174, 206-210), one launch ----
  * rgb[R][3], rgb_gt[R][3], rgb_mask[R] (network_object_mask & object_mask); grad_theta[n_eik][3]; eik_out / dist_r / dweight[n_depth]
  * (dist_r, dweight from mvsdf_depth_carve); surf[n_surf] logits with targets (i < *n_pos); feat_pp[n_feat] from mvsdf_feat_corr or NULL.
- * out[6] = {loss, rgb_loss, eikonal_loss, depth_loss, feat_loss, surf_loss}; d_*: unit gradients of each term w.r.t. its input. */
+ * out[6] = {loss, rgb_loss, eikonal_loss, depth_loss, feat_loss, surf_loss}; d_*: unit gradients of each term w.r.t. its input.
+ * inv_counts (device, [3], may be NULL): replaces 1/n_eik, 1/n_depth, 1/n_surf of the three count-normalised means -- with
+ * world_size / (count summed over the data-parallel ranks) the rank-averaged gradient equals the single-process one. */
 int mvsdf_loss_terms(const float* rgb, const float* rgb_gt, const uint8_t* rgb_mask, int R, const float* grad_theta, int n_eik,
                      const float* eik_out, const float* dist_r, const float* dweight, int n_depth, const float* surf, int n_surf,
                      const long long* n_pos, const float* feat_pp, int n_feat, float w_rgb, float w_eik, float w_surf, float w_feat,
-                     float w_depth, int surf_on, int feat_on, float* out, float* d_rgb, float* d_grad, float* d_eik_out, float* d_surf,
-                     void* stream);
+                     float w_depth, int surf_on, int feat_on, const float* inv_counts, float* out, float* d_rgb, float* d_grad,
+                     float* d_eik_out, float* d_surf, void* stream);
 
 /* ---- bookkeeping of one training step of IDRNetwork.forward (idr.py:202-304) between the big kernels ----
  * mvsdf_partition_rays: stable partition of the R rays by surface = net_mask & object_mask (object_mask / true_mask may be NULL = all

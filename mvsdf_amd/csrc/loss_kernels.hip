@@ -242,6 +242,7 @@ struct LossArgs {
     const float* surf; int n_surf; const long long* n_pos;                           // logits[n_surf], targets = (i < *n_pos)
     const float* feat_pp; int n_feat;                                                // per-point feature-loss terms (may be null)
     float w_rgb, w_eik, w_surf, w_feat, w_depth; int surf_on, feat_on;
+    const float* inv_counts;                                                         // optional [3]: 1/count of the eikonal / depth / surf means (data-parallel exact mode)
     float* out;                                                                      // [6]: loss, rgb, eikonal, depth, feat, surf
     float* d_rgb; float* d_grad; float* d_eik_out; float* d_surf;                    // unit gradients (same shapes as the inputs)
 };
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
     const float rgb_loss = block_sum_1024(s, red) * invR;
     // eikonal: mean((||g|| - 1)^2)                                                               loss.py:30-35
     s = 0.f;
-    const float invE = a.n_eik > 0 ? 1.0f / (float)a.n_eik : 0.f;
+    const float invE = a.n_eik > 0 ? (a.inv_counts ? a.inv_counts[0] : 1.0f / (float)a.n_eik) : 0.f;
     for (int i = tid; i < a.n_eik; i += 1024) {
         const float gx = a.grad_theta[3 * i], gy = a.grad_theta[3 * i + 1], gz = a.grad_theta[3 * i + 2];
         const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
     const float eik_loss = block_sum_1024(s, red) * invE;
     // depth: mean(|eikonal_output + dist_r| * weight)                                            loss.py:58-61
     s = 0.f;
-    const float invD = a.n_depth > 0 ? 1.0f / (float)a.n_depth : 0.f;
+    const float invD = a.n_depth > 0 ? (a.inv_counts ? a.inv_counts[1] : 1.0f / (float)a.n_depth) : 0.f;
     for (int i = tid; i < a.n_depth; i += 1024) {
         const float df = a.eik_out[i] + a.dist_r[i], wgt = a.dweight[i];
         s += fabsf(df) * wgt;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
     float surf_loss = 0.f;
     if (a.surf_on) {
         const long long npos = *a.n_pos;
-        const float invS = a.n_surf > 0 ? 1.0f / (float)a.n_surf : 0.f;
+        const float invS = a.n_surf > 0 ? (a.inv_counts ? a.inv_counts[2] : 1.0f / (float)a.n_surf) : 0.f;
         for (int i = tid; i < a.n_surf; i += 1024) {
             const float x = a.surf[i], t = (long long)i < npos ? 1.0f : 0.0f;
             s += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
@@ -328,12 +329,13 @@ extern "C" {
 int mvsdf_loss_terms(const float* rgb, const float* rgb_gt, const uint8_t* rgb_mask, int R, const float* grad_theta, int n_eik,
                      const float* eik_out, const float* dist_r, const float* dweight, int n_depth, const float* surf, int n_surf,
                      const long long* n_pos, const float* feat_pp, int n_feat, float w_rgb, float w_eik, float w_surf, float w_feat,
-                     float w_depth, int surf_on, int feat_on, float* out, float* d_rgb, float* d_grad, float* d_eik_out, float* d_surf,
-                     void* stream) {
+                     float w_depth, int surf_on, int feat_on, const float* inv_counts, float* out, float* d_rgb, float* d_grad, float* d_eik_out,
+                     float* d_surf, void* stream) {
     if (!rgb || !rgb_gt || !rgb_mask || R <= 0 || !out || !d_rgb || (n_eik > 0 && (!grad_theta || !d_grad)) ||
         (n_depth > 0 && (!eik_out || !dist_r || !dweight || !d_eik_out)) || (n_surf > 0 && (!surf || !d_surf || !n_pos)))
         return mv_fail(-1, "mvsdf_loss_terms: bad arguments");
     LossArgs a;
+    a.inv_counts = inv_counts;
     a.rgb = rgb; a.rgb_gt = rgb_gt; a.rgb_mask = rgb_mask; a.R = R; a.grad_theta = grad_theta; a.n_eik = n_eik;
     a.eik_out = eik_out; a.dist_r = dist_r; a.dweight = dweight; a.n_depth = n_depth; a.surf = surf; a.n_surf = n_surf; a.n_pos = n_pos;
     a.feat_pp = feat_pp; a.n_feat = n_feat; a.w_rgb = w_rgb; a.w_eik = w_eik; a.w_surf = w_surf; a.w_feat = w_feat; a.w_depth = w_depth;

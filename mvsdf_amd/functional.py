@@ -262,10 +262,10 @@ class _LossTerms(torch.autograd.Function):
     (d/d loss * weight + d/d term)."""
 
     @staticmethod
-    def forward(ctx, rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r, dweight, n_pos, weights, surf_on, feat_on):
+    def forward(ctx, rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r, dweight, n_pos, weights, surf_on, feat_on, inv_counts=None):
         out, d_rgb, d_grad, d_eo, d_sf = ops.loss_terms(rgb.detach(), rgb_gt, rgb_mask, grad_theta.detach() if grad_theta is not None else None,
                                                         eik_out.detach(), dist_r, dweight, surf.detach() if surf is not None else None, n_pos,
-                                                        feat_pp.detach() if feat_pp is not None else None, weights, surf_on, feat_on)
+                                                        feat_pp.detach() if feat_pp is not None else None, weights, surf_on, feat_on, inv_counts)
         ctx.saved = (d_rgb, d_grad, d_eo, d_sf)
         ctx.weights, ctx.shapes = weights, (eik_out.shape, feat_pp.shape if feat_pp is not None else None)
         ctx.on = (surf_on, feat_on)
@@ -277,15 +277,15 @@ class _LossTerms(torch.autograd.Function):
         use_sf = d_sf is not None and ctx.on[0]
         (g_rgb, g_grad, g_eo, g_sf), c_feat = ops.loss_scale(g, ctx.weights, [d_rgb, d_grad, d_eo, d_sf if use_sf else None])   # one launch
         g_fp = c_feat.expand(ctx.shapes[1]) if (ctx.shapes[1] is not None and ctx.on[1]) else None
-        return g_rgb, g_grad, g_eo.view(ctx.shapes[0]), g_sf, g_fp, None, None, None, None, None, None, None, None
+        return g_rgb, g_grad, g_eo.view(ctx.shapes[0]), g_sf, g_fp, None, None, None, None, None, None, None, None, None
 
 
 def feat_corr_terms(pts, view_start, feat, feat_src, cam, src_cams, size, center):
     return _FeatCorrPP.apply(pts, view_start, feat, feat_src, cam, src_cams, size, center)
 
 
-def loss_terms(rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r, dweight, n_pos, weights, surf_on, feat_on):
-    return _LossTerms.apply(rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r, dweight, n_pos, weights, surf_on, feat_on)
+def loss_terms(rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r, dweight, n_pos, weights, surf_on, feat_on, inv_counts=None):
+    return _LossTerms.apply(rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r, dweight, n_pos, weights, surf_on, feat_on, inv_counts)
 
 
 class StepState:

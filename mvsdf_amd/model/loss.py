@@ -6,6 +6,7 @@ import importlib
 import os
 
 import torch
+import torch.distributed as dist
 from torch import nn
 from torch.nn import functional as F
 
@@ -23,6 +24,8 @@ class IDRLoss(nn.Module):
     def __init__(self):
         super().__init__()
         self.l1_loss = nn.L1Loss(reduction='sum')
+        # with torch.distributed initialised: normalise the count-based means by the counts summed over the ranks (see forward)
+        self.exact_data_parallel = True
 
     def get_rgb_loss(self, rgb_values, rgb_gt, network_object_mask, object_mask):
         mask = network_object_mask & object_mask                                   # loss.py:21-28; a zero-hit batch gives 0 either way
@@ -104,7 +107,16 @@ class IDRLoss(nn.Module):
                                       ground_truth['size'], ground_truth['center'], train_progress)
         weights = (conf.rgb_weight(train_progress), conf.eikonal_weight, conf.surf_weight, conf.feat_weight(train_progress),
                    conf.depth_weight(train_progress))
+        # Data parallel (one process per GPU, rays sharded by view, gradients averaged over ranks): the three count-normalised means
+        # (eikonal over grad_theta rows, depth over eikonal_output entries, surface BCE over its logits; loss.py:34,61,173) divide by
+        # the GLOBAL counts so that the rank-averaged gradient equals the single-process one -- one extra all-reduce of 3 numbers.
+        inv_counts = None
+        if self.exact_data_parallel and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            cnt = torch.tensor([float(model_outputs['grad_theta'].shape[0]), float(model_outputs['eikonal_output'].numel()),
+                                float(model_outputs['surf_indicator_output'].numel())], device=dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            inv_counts = float(dist.get_world_size()) / cnt.clamp(min=1.0)
         out = Fn.loss_terms(model_outputs['rgb_values'], model_outputs['grad_theta'], model_outputs['eikonal_output'],
                             model_outputs['surf_indicator_output'], feat_pp, rgb_gt, hit_mask, dist_r, dweight,
-                            n_pos, weights, bool(phase1), feat_on)
+                            n_pos, weights, bool(phase1), feat_on, inv_counts)
         return {'loss': out[0], 'rgb_loss': out[1], 'eikonal_loss': out[2], 'depth_loss': out[3], 'feat_loss': out[4], 'surf_loss': out[5]}

@@ -308,8 +308,9 @@ def depth_carve(pts, depths, cams, size, center, out_thresh_perc, far_thresh, fa
     return dist_r, weight
 
 
-def loss_terms(rgb, rgb_gt, rgb_mask, grad_theta, eik_out, dist_r, dweight, surf, n_pos, feat_pp, weights, surf_on, feat_on):
-    """-> (out[6] = loss, rgb, eikonal, depth, feat, surf; d_rgb, d_grad, d_eik_out, d_surf).  One launch."""
+def loss_terms(rgb, rgb_gt, rgb_mask, grad_theta, eik_out, dist_r, dweight, surf, n_pos, feat_pp, weights, surf_on, feat_on, inv_counts=None):
+    """-> (out[6] = loss, rgb, eikonal, depth, feat, surf; d_rgb, d_grad, d_eik_out, d_surf).  One launch.
+    inv_counts: optional device float[3] replacing 1/n of the eikonal / depth / surf means (data-parallel exact mode)."""
     rgb, rgb_gt = _f32(rgb), _f32(rgb_gt).reshape(-1, 3)
     dev = rgb.device
     R = rgb.shape[0]
@@ -328,8 +329,8 @@ def loss_terms(rgb, rgb_gt, rgb_mask, grad_theta, eik_out, dist_r, dweight, surf
     check(lib().mvsdf_loss_terms(ptr(rgb), ptr(rgb_gt), ptr(m), R, ptr(gt_), gt_.shape[0] if gt_ is not None else 0, ptr(eo), ptr(_f32(dist_r)),
                                  ptr(_f32(dweight)), eo.numel(), ptr(sf), sf.numel() if sf is not None else 0, ptr(npos), ptr(fp),
                                  fp.numel() if fp is not None else 0, C.c_float(w[0]), C.c_float(w[1]), C.c_float(w[2]), C.c_float(w[3]),
-                                 C.c_float(w[4]), 1 if surf_on else 0, 1 if feat_on else 0, ptr(out), ptr(d_rgb), ptr(d_grad), ptr(d_eo),
-                                 ptr(d_sf), stream_of(rgb)), 'mvsdf_loss_terms')
+                                 C.c_float(w[4]), 1 if surf_on else 0, 1 if feat_on else 0, ptr(_f32(inv_counts)) if inv_counts is not None else None,
+                                 ptr(out), ptr(d_rgb), ptr(d_grad), ptr(d_eo), ptr(d_sf), stream_of(rgb)), 'mvsdf_loss_terms')
     return out, d_rgb, d_grad, d_eo, d_sf
 
 
