@@ -3,9 +3,9 @@ fp32 gradient bucket per step.  The reference is single-G
 
 Rays are independent; the only coupling is the parameter gradient.  Views are sharded across ranks (B views -> B/world each);
 `.grad` of every parameter is a VIEW into one flat buffer, so backward accumulates straight into the bucket and the
-collective needs no packing.  Loss normalisation: gradients are AVERAGED over ranks (mean of per-rank losses), the
-DDP convention; it equals the single-process loss for the per-view / per-ray means and is a mean-of-means for the
-count-normalised terms (eikonal / depth / surface BCE) -- see DESIGN.md."""
+collective needs no packing.  Loss normalisation: gradients are AVERAGED over ranks (mean of per-rank losses), the DDP convention;
+that equals the single-process loss for the per-view / per-ray means, and IDRLoss divides the count-normalised terms (eikonal / depth /
+surface BCE) by the counts summed over the ranks, so the averaged gradient is the single-process one (tests/test_gpu_dp.py)."""
 import torch
 import torch.distributed as dist
 
