@@ -117,8 +117,9 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        local %= max(1, torch.cuda.device_count())             # (a box with fewer GPUs than ranks: dry runs of the launch path only)
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl')
+        dist.init_process_group(os.environ.get('MVSDF_DIST_BACKEND', 'nccl'))      # nccl = RCCL over xGMI; gloo for dry runs on one GPU
     elif a.gpus > 1:
         sys.exit('launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...')
     dev = torch.device('cuda', local)
