@@ -313,6 +313,36 @@ def g_render_bwd(W, n, seed):
     save('render_bwd_w%d' % W, **res)
 
 
+def g_train(W, B, P, V, seed, tp, steps, lr):
+    """A few real optimisation steps of the reference loop (idr_train.py:283-302): zero_grad, forward, loss, backward, all_norm,
+    clip_grad_norm_(grad_cap), Adam.step -- per-step losses, gradient norm, hit count and the parameter norms at the end."""
+    from model import conf as rconf
+    m, sd = build_model(W, seed)
+    inp, gt = synth.make_batch(B, P, V, seed=seed, **SCENE)
+    m.train()
+    mi, gtt = {k: T(v) for k, v in inp.items()}, {k: T(v) for k, v in gt.items()}
+    loss_fn = IDRLoss()
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    losses, gnorms, hits = [], [], []
+    for it in range(steps):
+        torch.manual_seed(seed + 100 + it)
+        opt.zero_grad()
+        with quiet():
+            out = m(mi, tp)
+            lo = loss_fn(out, dict(gtt), tp, B)
+        lo['loss'].backward()
+        all_norm = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None]).norm()
+        if rconf.phase[0] <= tp and rconf.enable_grad_cap:
+            torch.nn.utils.clip_grad_norm_(m.parameters(), rconf.grad_cap(tp))
+        opt.step()
+        losses.append([float(lo[k].reshape(-1)[0]) for k in ('loss', 'rgb_loss', 'eikonal_loss', 'depth_loss', 'feat_loss', 'surf_loss')])
+        gnorms.append(float(all_norm)); hits.append(int((out['network_object_mask'] & out['object_mask']).sum()))
+    pn = {('pnorm_' + k): float(p.detach().double().norm()) for k, p in m.named_parameters()}
+    save('train%d_w%d' % (steps, W), W=W, B=B, P=P, V=V, seed=seed, tp=tp, steps=steps, lr=lr, losses=np.array(losses), gnorms=np.array(gnorms),
+         hits=np.array(hits), scene_size=SCENE['size'], scene_center=np.array(SCENE['center']), feat_hw=np.array(SCENE['feat_hw']),
+         focal_scale=SCENE['focal_scale'], grad_cap=float(rconf.grad_cap(tp)), checksum=synth.state_checksum(sd), **pn)
+
+
 def g_dsurf(seed):
     """Phase-0 depth-surface points (idr.py:234-238): every depth pixel unprojected with the reference's my_utils helpers + the
     in-box tests of idr.py:242 (on-surface points; the jitter is RNG-driven and checked distributionally in the GPU test)."""
@@ -337,9 +367,11 @@ def g_dsurf(seed):
 
 if __name__ == '__main__':
     if len(sys.argv) > 1:                                                       # python make_golden.py g_dsurf 0  (one fixture)
-        globals()[sys.argv[1]](*[int(v) for v in sys.argv[2:]])
+        globals()[sys.argv[1]](*[(float(v) if '.' in v or 'e' in v else int(v)) for v in sys.argv[2:]])
         sys.exit(0)
     g_dsurf(0)
+    g_train_default = lambda: g_train(64, 2, 256, 3, 0, 0.3, 4, 1e-3)
+    g_train_default()
     g_sdf(64, 1000, 0)
     g_sdf(256, 256, 0)
     g_render(64, 300, 0)
