@@ -127,6 +127,12 @@ static LayerArgs base_args(const MvLayer& L, int S, int M) {
     return a;
 }
 
+static bool mv_chain_w8() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MVSDF_CHAIN_W8"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
 static int stride_for(const MvNet& a, const MvNet& b) { return a.S > b.S ? a.S : b.S; }
 
 // layout of the forward context / backward workspace (floats)
@@ -274,8 +280,15 @@ int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float
         f.G0 = ctx + lo.G0; f.y = y; f.ldy = net.L[nl - 1].N; f.w_last_row0 = d->w[nl - 1]; f.nrm = nrm;
         constexpr int MTC = 1, NWC = 8;
         const size_t lds = ((size_t)16 * MTC * S + 2 * ((16 * MTC * lo.d0 + 3) & ~3) + 16 * MTC * 4) * sizeof(float);
-        if (ntw_f == 2) hipLaunchKernelGGL((k_chain_fwd<MTC, 2, NWC>), dim3((M + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, f);
-        else hipLaunchKernelGGL((k_chain_fwd<MTC, 4, NWC>), dim3((M + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, f);
+        // 16 waves per workgroup (one or two column tiles each): these launches are single waves of one-tile workgroups, i.e. chains of
+        // dependent layer phases; twice the waves halve every wave's share of the global loads / stores and of the epilogue between
+        // two GEMMs (measured 148 -> 127 us here, 173 -> 143 us for the backward pass).  MVSDF_CHAIN_W8=1: 8 waves (dev A/B).
+        const bool w8 = mv_chain_w8();
+        const dim3 grid((M + 16 * MTC - 1) / (16 * MTC));
+        if (ntw_f == 2 && !w8) hipLaunchKernelGGL((k_chain_fwd<MTC, 1, 16>), grid, dim3(1024), lds, s, f);
+        else if (ntw_f == 2) hipLaunchKernelGGL((k_chain_fwd<MTC, 2, NWC>), grid, dim3(64 * NWC), lds, s, f);
+        else if (!w8) hipLaunchKernelGGL((k_chain_fwd<MTC, 2, 16>), grid, dim3(1024), lds, s, f);
+        else hipLaunchKernelGGL((k_chain_fwd<MTC, 4, NWC>), grid, dim3(64 * NWC), lds, s, f);
         return mv_check(hipGetLastError(), "mvsdf_sdf_forward");
     }
     hipLaunchKernelGGL(k_pe_global, dim3((M * (3 * net.multires + 1) + 255) / 256), dim3(256), 0, s, x, M, net.multires, H0, lo.ld0);
@@ -365,8 +378,12 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         c.H0B = ws + bl.H0B; c.H0 = H0; c.G0 = G0; c.dn_in = dn; c.VB0w = ws + bl.VB[0]; c.dx = dx;
         constexpr int MTC = 1, NWC = 8;
         const size_t lds = (size_t)16 * MTC * (S + lo.d0) * sizeof(float);
-        if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd<MTC, 2, NWC>), dim3((Mb + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, c);
-        else hipLaunchKernelGGL((k_chain_bwd<MTC, 4, NWC>), dim3((Mb + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC), lds, s, c);
+        const bool w8 = mv_chain_w8();
+        const dim3 grid((Mb + 16 * MTC - 1) / (16 * MTC));
+        if (ntw_b == 2 && !w8) hipLaunchKernelGGL((k_chain_bwd<MTC, 1, 16>), grid, dim3(1024), lds, s, c);
+        else if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd<MTC, 2, NWC>), grid, dim3(64 * NWC), lds, s, c);
+        else if (!w8) hipLaunchKernelGGL((k_chain_bwd<MTC, 2, 16>), grid, dim3(1024), lds, s, c);
+        else hipLaunchKernelGGL((k_chain_bwd<MTC, 4, NWC>), grid, dim3(64 * NWC), lds, s, c);
         MV_TRY(hipGetLastError());
         chains_done = true;
     }
@@ -573,10 +590,13 @@ int mvsdf_render_forward(const MvsdfNetDesc* d, const float* points, const float
         for (int l = 0; l < nl; ++l) c.A[l] = ctx + lo.A[l];
         c.rgb_ctx = ctx + lo.rgb; c.rgb = rgb;
         constexpr int MTC = 1, NWC = 8;
-        if (ntw_r == 2) hipLaunchKernelGGL((k_render_chain_fwd<MTC, 2, NWC>), dim3((N + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC),
-                                           (size_t)16 * MTC * net.S * sizeof(float), s, c);
-        else hipLaunchKernelGGL((k_render_chain_fwd<MTC, 4, NWC>), dim3((N + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC),
-                                (size_t)16 * MTC * net.S * sizeof(float), s, c);
+        const bool w8 = mv_chain_w8();
+        const dim3 grid((N + 16 * MTC - 1) / (16 * MTC));
+        const size_t ldsr = (size_t)16 * MTC * net.S * sizeof(float);
+        if (ntw_r == 2 && !w8) hipLaunchKernelGGL((k_render_chain_fwd<MTC, 1, 16>), grid, dim3(1024), ldsr, s, c);
+        else if (ntw_r == 2) hipLaunchKernelGGL((k_render_chain_fwd<MTC, 2, NWC>), grid, dim3(64 * NWC), ldsr, s, c);
+        else if (!w8) hipLaunchKernelGGL((k_render_chain_fwd<MTC, 2, 16>), grid, dim3(1024), ldsr, s, c);
+        else hipLaunchKernelGGL((k_render_chain_fwd<MTC, 4, NWC>), grid, dim3(64 * NWC), ldsr, s, c);
         return mv_check(hipGetLastError(), "mvsdf_render_forward");
     }
     const size_t tot = (size_t)N * K0;
@@ -619,10 +639,13 @@ int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, 
         c.drgb = drgb; c.rgbc = ctx + lo.rgb; c.din = din;
         for (int l = 0; l < nl; ++l) { c.Ac[l] = ctx + lo.A[l]; c.ZB[l] = ws + bl.ZB[l]; }
         constexpr int MTC = 1, NWC = 8;
-        if (ntw_rb == 2) hipLaunchKernelGGL((k_render_chain_bwd<MTC, 2, NWC>), dim3((N + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC),
-                                            (size_t)16 * MTC * S * sizeof(float), s, c);
-        else hipLaunchKernelGGL((k_render_chain_bwd<MTC, 4, NWC>), dim3((N + 16 * MTC - 1) / (16 * MTC)), dim3(64 * NWC),
-                                (size_t)16 * MTC * S * sizeof(float), s, c);
+        const bool w8 = mv_chain_w8();
+        const dim3 grid((N + 16 * MTC - 1) / (16 * MTC));
+        const size_t ldsr = (size_t)16 * MTC * S * sizeof(float);
+        if (ntw_rb == 2 && !w8) hipLaunchKernelGGL((k_render_chain_bwd<MTC, 1, 16>), grid, dim3(1024), ldsr, s, c);
+        else if (ntw_rb == 2) hipLaunchKernelGGL((k_render_chain_bwd<MTC, 2, NWC>), grid, dim3(64 * NWC), ldsr, s, c);
+        else if (!w8) hipLaunchKernelGGL((k_render_chain_bwd<MTC, 2, 16>), grid, dim3(1024), ldsr, s, c);
+        else hipLaunchKernelGGL((k_render_chain_bwd<MTC, 4, NWC>), grid, dim3(64 * NWC), ldsr, s, c);
         MV_TRY(hipGetLastError());
     } else
     for (int l = nl - 1; l >= 0; --l) {                      // abar_l = zbar_l W_l ; zbar_{l-1} = abar_l . relu'(z_{l-1})
