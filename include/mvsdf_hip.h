@@ -228,9 +228,10 @@ int mvsdf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, 
  * n_pos = #(network_object_mask & object_mask_true) (positives of the surface-indicator BCE, loss.py:167-173). */
 int mvsdf_loss_prep(const uint8_t* net_mask, const uint8_t* obj_mask, const uint8_t* true_mask, int R, int B, uint8_t* hit, int* view_start,
                     long long* n_pos, void* stream);
-/* backward of the weighted total of mvsdf_loss_terms: g[6] = upstream of {loss, rgb, eikonal, depth, feat, surf} (device); every unit
+/* backward of the weighted total of mvsdf_loss_terms: g = HOST array of 6 device pointers to the scalar upstream gradients of {loss, rgb,
+ * eikonal, depth, feat, surf} (NULL = no gradient, the usual case for all but `loss`); every unit
  * gradient tensor is scaled by (g[0] * weight + g[term]) into its output; coef_feat[1] (may be NULL) = g[0] * w_feat + g[4]. */
-int mvsdf_loss_scale(const float* g, float w_rgb, float w_eik, float w_surf, float w_feat, float w_depth, const float* d_rgb, float* g_rgb,
+int mvsdf_loss_scale(const float* const* g, float w_rgb, float w_eik, float w_surf, float w_feat, float w_depth, const float* d_rgb, float* g_rgb,
                      int n_rgb, const float* d_grad, float* g_grad, int n_grad, const float* d_eo, float* g_eo, int n_eo, const float* d_sf,
                      float* g_sf, int n_sf, float* coef_feat, void* stream);
 

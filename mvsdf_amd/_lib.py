@@ -46,7 +46,7 @@ def lib():
             getattr(L, fn).restype = C.c_size_t
         L.mvsdf_adam_ws_floats.restype = C.c_size_t
         L.mvsdf_adam_step.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.mvsdf_loss_scale.argtypes = [C.c_void_p] + [C.c_float] * 5 + [C.c_void_p, C.c_void_p, C.c_int] * 4 + [C.c_void_p, C.c_void_p]
+        L.mvsdf_loss_scale.argtypes = [C.c_void_p] + [C.c_float] * 5 + [C.c_void_p, C.c_void_p, C.c_int] * 4 + [C.c_void_p, C.c_void_p]   # g: host array of 6 pointers
         for name in EXPORTS:
             getattr(L, name)
         _lib = L

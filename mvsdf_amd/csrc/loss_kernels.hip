@@ -419,21 +419,23 @@ __global__ __launch_bounds__(1024) void k_loss_prep(const uint8_t* __restrict__ 
 }
 
 struct LossScaleArgs {
-    const float* g;                       // [6] upstream of {loss, rgb, eikonal, depth, feat, surf}
+    const float* g[6];                    // upstream of {loss, rgb, eikonal, depth, feat, surf}: one scalar each, null = 0
     float w_rgb, w_eik, w_surf, w_feat, w_depth;
     const float* src[4]; float* dst[4]; int n[4];      // unit gradients of rgb / grad_theta / eikonal_output / surf -> scaled copies
     float* coef_feat;                     // [1]: dL/d(sum of the per-point feature terms)
 };
 __global__ void k_loss_scale(LossScaleArgs a) {
-    const float g0 = a.g[0];
-    const float c[4] = {g0 * a.w_rgb + a.g[1], g0 * a.w_eik + a.g[2], g0 * a.w_depth + a.g[3], g0 * a.w_surf + a.g[5]};
+    float g[6];
+    for (int k = 0; k < 6; ++k) g[k] = a.g[k] ? a.g[k][0] : 0.0f;
+    const float g0 = g[0];
+    const float c[4] = {g0 * a.w_rgb + g[1], g0 * a.w_eik + g[2], g0 * a.w_depth + g[3], g0 * a.w_surf + g[5]};
     const int total = a.n[0] + a.n[1] + a.n[2] + a.n[3];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         int k = i, t = 0;
         while (t < 3 && k >= a.n[t]) { k -= a.n[t]; ++t; }
         a.dst[t][k] = a.src[t][k] * c[t];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.coef_feat) a.coef_feat[0] = g0 * a.w_feat + a.g[4];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.coef_feat) a.coef_feat[0] = g0 * a.w_feat + g[4];
 }
 
 extern "C" {
@@ -446,12 +448,13 @@ int mvsdf_loss_prep(const uint8_t* net_mask, const uint8_t* obj_mask, const uint
     return mv_check(hipGetLastError(), "mvsdf_loss_prep");
 }
 
-int mvsdf_loss_scale(const float* g, float w_rgb, float w_eik, float w_surf, float w_feat, float w_depth, const float* d_rgb, float* g_rgb,
+int mvsdf_loss_scale(const float* const* g, float w_rgb, float w_eik, float w_surf, float w_feat, float w_depth, const float* d_rgb, float* g_rgb,
                      int n_rgb, const float* d_grad, float* g_grad, int n_grad, const float* d_eo, float* g_eo, int n_eo, const float* d_sf,
                      float* g_sf, int n_sf, float* coef_feat, void* stream) {
     if (!g || n_rgb < 0 || n_grad < 0 || n_eo < 0 || n_sf < 0) return mv_fail(-1, "mvsdf_loss_scale: bad arguments");
     LossScaleArgs a;
-    a.g = g; a.w_rgb = w_rgb; a.w_eik = w_eik; a.w_surf = w_surf; a.w_feat = w_feat; a.w_depth = w_depth;
+    for (int k = 0; k < 6; ++k) a.g[k] = g[k];
+    a.w_rgb = w_rgb; a.w_eik = w_eik; a.w_surf = w_surf; a.w_feat = w_feat; a.w_depth = w_depth;
     const float* src[4] = {d_rgb, d_grad, d_eo, d_sf};
     float* dst[4] = {g_rgb, g_grad, g_eo, g_sf};
     const int n[4] = {n_rgb, n_grad, n_eo, n_sf};

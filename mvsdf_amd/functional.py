@@ -258,8 +258,8 @@ class _FeatCorrPP(torch.autograd.Function):
 
 class _LossTerms(torch.autograd.Function):
     """rgb L1 + eikonal + depth L1 + surface BCE + feature sum + weighted total in one launch (loss.py:176-219).
-    Returns the 6-vector [loss, rgb, eikonal, depth, feat, surf]; backward = the stored unit gradients times
-    (d/d loss * weight + d/d term)."""
+    Returns the six scalars (loss, rgb, eikonal, depth, feat, surf) as separate 0-d tensors; backward = the stored unit gradients times
+    (d/d loss * weight + d/d term), one launch."""
 
     @staticmethod
     def forward(ctx, rgb, grad_theta, eik_out, surf, feat_pp, rgb_gt, rgb_mask, dist_r, dweight, n_pos, weights, surf_on, feat_on, inv_counts=None):
@@ -269,13 +269,14 @@ class _LossTerms(torch.autograd.Function):
         ctx.saved = (d_rgb, d_grad, d_eo, d_sf)
         ctx.weights, ctx.shapes = weights, (eik_out.shape, feat_pp.shape if feat_pp is not None else None)
         ctx.on = (surf_on, feat_on)
-        return out
+        ctx.set_materialize_grads(False)                         # unused scalars arrive as None, not as zero tensors
+        return tuple(out.unbind(0))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         d_rgb, d_grad, d_eo, d_sf = ctx.saved
         use_sf = d_sf is not None and ctx.on[0]
-        (g_rgb, g_grad, g_eo, g_sf), c_feat = ops.loss_scale(g, ctx.weights, [d_rgb, d_grad, d_eo, d_sf if use_sf else None])   # one launch
+        (g_rgb, g_grad, g_eo, g_sf), c_feat = ops.loss_scale(gs, ctx.weights, [d_rgb, d_grad, d_eo, d_sf if use_sf else None])   # one launch
         g_fp = c_feat.expand(ctx.shapes[1]) if (ctx.shapes[1] is not None and ctx.on[1]) else None
         return g_rgb, g_grad, g_eo.view(ctx.shapes[0]), g_sf, g_fp, None, None, None, None, None, None, None, None, None
 

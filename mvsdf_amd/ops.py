@@ -314,7 +314,8 @@ def loss_terms(rgb, rgb_gt, rgb_mask, grad_theta, eik_out, dist_r, dweight, surf
     rgb, rgb_gt = _f32(rgb), _f32(rgb_gt).reshape(-1, 3)
     dev = rgb.device
     R = rgb.shape[0]
-    m = rgb_mask.to(torch.uint8).contiguous()
+    m = rgb_mask.contiguous()
+    m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
     gt_ = _f32(grad_theta) if grad_theta is not None and grad_theta.shape[0] > 0 else None
     eo = _f32(eik_out).reshape(-1)
     sf = _f32(surf).reshape(-1) if surf is not None else None
@@ -406,16 +407,16 @@ def loss_prep(net_mask, obj_mask, true_mask, B):
     return hit.view(torch.bool), vs, n_pos
 
 
-def loss_scale(g, weights, unit_grads):
-    """unit_grads: [d_rgb, d_grad, d_eo, d_sf] (None allowed) -> (scaled copies in the same order, coef_feat [1]).  weights =
-    (w_rgb, w_eik, w_surf, w_feat, w_depth) as in loss_terms."""
-    g = _f32(g)
+def loss_scale(gs, weights, unit_grads):
+    """gs: the six scalar upstream gradients (tensors or None).  unit_grads: [d_rgb, d_grad, d_eo, d_sf] (None allowed) -> (scaled copies in
+    the same order, coef_feat [1]).  weights = (w_rgb, w_eik, w_surf, w_feat, w_depth) as in loss_terms."""
+    gs = [_f32(g.reshape(1)) if g is not None else None for g in gs]
+    dev = next(g for g in gs if g is not None).device
     outs = [torch.empty_like(t) if t is not None else None for t in unit_grads]
-    coef = torch.empty(1, dtype=torch.float32, device=g.device)
+    coef = torch.empty(1, dtype=torch.float32, device=dev)
     a = []
     for t, o in zip(unit_grads, outs):
-        a += [ptr(t) if t is not None else None, ptr(o) if o is not None else None, t.numel() if t is not None else 0]
+        a += [t.data_ptr() if t is not None else None, o.data_ptr() if o is not None else None, t.numel() if t is not None else 0]
     w = [float(v) for v in weights]
-    check(lib().mvsdf_loss_scale(g.data_ptr(), w[0], w[1], w[2], w[3], w[4], *[x.value if hasattr(x, 'value') else x for x in a],
-                                 coef.data_ptr(), stream_of(g).value), 'mvsdf_loss_scale')
+    check(lib().mvsdf_loss_scale(_ptr_array(gs), w[0], w[1], w[2], w[3], w[4], *a, coef.data_ptr(), stream_of(coef).value), 'mvsdf_loss_scale')
     return outs, coef
