@@ -391,15 +391,14 @@ int mvsdf_depth_carve(const float* pts, int pts_ld, int M, const float* depths, 
 __global__ __launch_bounds__(1024) void k_loss_prep(const uint8_t* __restrict__ net_mask, const uint8_t* __restrict__ obj_mask,
                                                     const uint8_t* __restrict__ true_mask, int R, int B, uint8_t* __restrict__ hit,
                                                     int* __restrict__ view_start, long long* __restrict__ n_pos) {
-    __shared__ int red[2][16];
-    __shared__ int run;
+    // one wave per view (views beyond 16 take turns); the prefix sum over the B counts is done by thread 0
+    __shared__ int cnt[1024];
+    __shared__ int pos[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, P = R / B;
-    if (tid == 0) { run = 0; view_start[0] = 0; }
     int pos_local = 0;
-    __syncthreads();
-    for (int b = 0; b < B; ++b) {
+    for (int b = w; b < B; b += 16) {
         int c = 0;
-        for (int i = tid; i < P; i += 1024) {
+        for (int i = lane; i < P; i += 64) {
             const int r = b * P + i;
             const bool h = net_mask[r] && obj_mask[r];
             hit[r] = h ? 1 : 0;
@@ -407,15 +406,19 @@ __global__ __launch_bounds__(1024) void k_loss_prep(const uint8_t* __restrict__ 
             pos_local += (net_mask[r] && true_mask[r]) ? 1 : 0;
         }
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if (lane == 0) red[0][w] = c;
-        __syncthreads();
-        if (tid == 0) { int s = 0; for (int k = 0; k < 16; ++k) s += red[0][k]; run += s; view_start[b + 1] = run; }
-        __syncthreads();
+        if (lane == 0 && b < 1024) cnt[b] = c;
     }
     for (int o = 32; o > 0; o >>= 1) pos_local += __shfl_xor(pos_local, o);
-    if (lane == 0) red[1][w] = pos_local;
+    if (lane == 0) pos[w] = pos_local;
     __syncthreads();
-    if (tid == 0) { long long s = 0; for (int k = 0; k < 16; ++k) s += red[1][k]; *n_pos = s; }
+    if (tid == 0) {
+        int run = 0;
+        view_start[0] = 0;
+        for (int b = 0; b < B; ++b) { run += cnt[b]; view_start[b + 1] = run; }
+        long long s = 0;
+        for (int k = 0; k < 16; ++k) s += pos[k];
+        *n_pos = s;
+    }
 }
 
 struct LossScaleArgs {
@@ -442,7 +445,7 @@ extern "C" {
 
 int mvsdf_loss_prep(const uint8_t* net_mask, const uint8_t* obj_mask, const uint8_t* true_mask, int R, int B, uint8_t* hit, int* view_start,
                     long long* n_pos, void* stream) {
-    if (!net_mask || !obj_mask || !true_mask || !hit || !view_start || !n_pos || R <= 0 || B <= 0 || R % B)
+    if (!net_mask || !obj_mask || !true_mask || !hit || !view_start || !n_pos || R <= 0 || B <= 0 || B > 1024 || R % B)
         return mv_fail(-1, "mvsdf_loss_prep: bad arguments");
     hipLaunchKernelGGL(k_loss_prep, dim3(1), dim3(1024), 0, (hipStream_t)stream, net_mask, obj_mask, true_mask, R, B, hit, view_start, n_pos);
     return mv_check(hipGetLastError(), "mvsdf_loss_prep");
