@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- traced rays/s for one MVSDF training step (forward + loss + backward + grad-norm/clip + Adam) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5share] [--dtype f32|bf16]
 
-Workload (BASELINE.json configs[1], SURVEY.md section 8d "c2"): 8 views x 256 px = 2048 rays per GPU, 4 source views, 8x256 SDF
-MLP + 4x256 rendering MLP, 10 sphere-tracing iterations, line_step_iters 3, 100 sampler steps, 8 secant steps, train_progress 0.3,
-synthetic random-weight scene (mvsdf_amd.utils.synth), feature maps 32 x 600 x 800, weights frozen (Adam lr = 0, clip 2.0 included).
-Weak scaling: every rank traces its own 2048 rays; one all-reduce on the flat gradient bucket per step.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process (which never touches the GPU) starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a child, relays
+rank 0's JSON line and exits with the child's code.  Launched under torch.distributed.run directly it just runs as one rank.
 
-Prints ONE JSON line (rank 0) incl. `roofline` (the dominant kernel: k_ray_samples, i.e. the tracing MLP on sampler / secant /
-min-sdf rows; HIP events on the launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample of the same workload).
+Workload (BASELINE.json configs[1] = SURVEY.md 8d "c2" at N = 1, configs[3] = "c4" at N = 8): B = 8 views in total, 256 * N pixels per
+view, the views sharded over the N ranks (parallel.shard_views) -> 2048 rays per GPU at every N (weak scaling: 2048 rays at N = 1,
+16384 rays = 8 views x 2048 px, one view per GPU, at N = 8).  The depth maps of all 8 views stay on every rank (the depth term carves each
+sample point against every view, loss.py:39-40); feature maps only of a rank's own views.  4 source views, 8x256 SDF MLP + 4x256 rendering
+MLP, 10 sphere-tracing iterations, line_step_iters 3, 100 sampler steps, 8 secant steps, train_progress 0.3, synthetic random-weight
+scene (mvsdf_amd.utils.synth), feature maps 32 x 600 x 800 stored channels-last (each bilinear tap one 128-byte line), weights frozen
+(Adam lr = 0, clip 2.0 included).  Per step and rank: ONE all-reduce(SUM) of the flat fp32 gradient buffer (RCCL over xGMI), its 1/N folded
+into the Adam launch, plus a 3-float all-reduce of the loss normaliser counts (IDRLoss.exact_data_parallel) that overlaps the forward.
+
+Prints ONE JSON line (rank 0) incl. `roofline` (the tracing-MLP kernels k_ray_samples and k_sphere_trace as peers, HIP events on the
+launch stream; k_feat_corr's gather rate) and `cpu_baseline` (the CPU oracle on a bounded sample of the same workload).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,15 +34,24 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from mvsdf_amd import ops  # noqa: E402
 from mvsdf_amd.model.implicit_differentiable_renderer import IDRNetwork  # noqa: E402
 from mvsdf_amd.model.loss import IDRLoss  # noqa: E402
 from mvsdf_amd.optim import FlatAdam  # noqa: E402
+from mvsdf_amd.parallel import shard_views  # noqa: E402
 from mvsdf_amd.utils import synth  # noqa: E402
 from mvsdf_amd.utils.config import ConfigDict  # noqa: E402
 
-W, B, P, V, TP = 256, 8, 256, 4, 0.3
+W, B, TP = 256, 8, 0.3
+WORKLOADS = {                     # name: (pixels per view and GPU-count unit, source views)
+    'c2': (256, 4),               # BASELINE configs[1]: 2048 rays, 4 source views (the configuration the metric is quoted on)
+    'c3': (1024, 8),              # configs[2]: 8192 rays, 8 source views
+    'c5share': (512, 8),          # configs[4] per-GPU share: 32768 rays / 8 GPUs = 4096 rays, 8 source views (meant for --dtype bf16)
+}
 FEAT_HW = (600, 800)
-PEAK_F32_MFMA = 157.3          # TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
+PEAK = {'f32': 157.3, 'bf16': 2500.0}    # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32 / bf16)
+# the reference itself on CPU (PyTorch + MKL, imported in the build container): it cannot travel to the GPU box
+REFERENCE_CPU_NOTE = 'reference PyTorch-CPU step on the same c2 batch in the build container (8 vCPU Xeon): 2492 rays/s on 8 threads, 0.82 s/step (BASELINE.md)'
 
 
 def flops_per_row(W):
@@ -44,35 +62,41 @@ def flops_per_row(W):
     return f_t, f_s, f_r
 
 
-def make_inputs(dev, seed):
-    inp, gt = synth.make_batch(B, P, V, seed=seed, feat_hw=FEAT_HW, with_features=False)
-    g = torch.Generator(device=dev).manual_seed(1234 + seed)
-    base = torch.randn(1, 1, 32, 1, 1, generator=g, device=dev)
-    f = torch.empty(B, 1 + V, 32, *FEAT_HW, device=dev)
-    for b in range(B):                                         # per view: keeps every op below 2^31 elements at the larger configs
-        noise = torch.randn(1 + V, 32, FEAT_HW[0] + 4, FEAT_HW[1] + 4, generator=g, device=dev)
-        f[b] = torch.nn.functional.avg_pool2d(noise, 5, stride=1) * 2.4 + base[0]
-    del noise
+def make_inputs(dev, rank, world, P, V):
+    """This rank's share of the global batch (B views x P px, seed 0 on every rank): its views' rays / GT / feature maps, all depth maps."""
+    inp, gt = synth.make_batch(B, P, V, seed=0, feat_hw=FEAT_HW, with_features=False)
     to = lambda d: {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in d.items()}
-    inp, gt = to(inp), to(gt)
-    gt['feat'] = f[:, 0].contiguous()
-    gt['feat_src'] = f[:, 1:].contiguous()
+    inp, gt = shard_views(to(inp), rank, world), shard_views(to(gt), rank, world)
+    per = B // world
+    H, Wd = FEAT_HW
+    # channels-last storage [view, 1+V, H, W, C]: the features are constants of the dataset (scene_dataset.py:139-149 caches them once),
+    # laid out so that each of the 4 bilinear taps of k_feat_corr is one 128-byte line instead of 32 scattered dwords
+    store = torch.empty(per, 1 + V, H, Wd, 32, device=dev)
+    base = torch.randn(1, 32, 1, 1, generator=torch.Generator(device=dev).manual_seed(1234), device=dev)
+    for i in range(per):
+        g = torch.Generator(device=dev).manual_seed(5000 + rank * per + i)          # per global view: independent of the sharding
+        noise = torch.randn(1 + V, 32, H + 4, Wd + 4, generator=g, device=dev)
+        store[i].copy_((torch.nn.functional.avg_pool2d(noise, 5, stride=1) * 2.4 + base).permute(0, 2, 3, 1))
+    del noise
+    gt['feat'] = store[:, 0].permute(0, 3, 1, 2)                                  # [b, C, H, W] view with stride(C) = 1
+    gt['feat_src'] = store[:, 1:].permute(0, 1, 4, 2, 3)                          # [b, V, C, H, W]
     return inp, gt
 
 
-def cpu_baseline(rays_per_view=None, views=None):
+def cpu_baseline(V, rays_per_view=None, views=None):
     """The CPU oracle (oracle/: C tracer with OpenMP + numpy float64 differentiable half) on a bounded sample of the workload
     (sized for roughly 10-30 s of CPU work: the whole 2048-ray batch on a many-core host, a quarter of it otherwise)."""
     from oracle import oracle as O
     from oracle import oracle_np as ON
     if rays_per_view is None:
         many = O.num_threads() >= 32
-        views, rays_per_view = (B, P) if many else (2, 256)
+        views, rays_per_view = (B, 256) if many else (2, 256)
     sd = synth.make_state_dict(W, 0)
     onet, nnet, rnet = O.Net(sd), ON.sdf_net(sd), ON.render_net(sd)
     inp, gt = synth.make_batch(views, rays_per_view, V, seed=0, feat_hw=(150, 200))
     tr = synth.model_conf(W)['ray_tracer']
     R = views * rays_per_view
+
     def one_step():
         rs = np.random.RandomState(0)
         t0 = time.time()
@@ -101,7 +125,37 @@ def cpu_baseline(rays_per_view=None, views=None):
     rows = runs[0][1]
     return {'value': R / dt, 'unit': 'rays/s', 'cores': O.num_threads(), 'kind': 'port',
             'sample': '%d views x %d rays of the same scene (W=%d, V=%d): C oracle tracer (OpenMP, %d rows) + numpy float64 value/normal fwd+bwd, '
-                      'rendering fwd+bwd, feature loss fwd (its gradient omitted); median of 3 steps after 1 warm-up, %.1f s per step' % (views, rays_per_view, W, V, int(rows.sum()), dt)}
+                      'rendering fwd+bwd, feature loss fwd (its gradient omitted); median of 3 steps after 1 warm-up, %.1f s per step.  For scale: %s'
+                      % (views, rays_per_view, W, V, int(rows.sum()), dt, REFERENCE_CPU_NOTE)}
+
+
+def self_launch(a):
+    """--gpus N > 1 outside a launcher: start the N ranks as fresh child processes (this process has made no GPU call) and relay."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % a.gpus, '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes of this same command committed under profiles/ (tools/pmc_to_json.py writes the
+    file: separate --pmc FETCH_SIZE / WRITE_SIZE runs, 2 x FETCH_SIZE KB + WRITE_SIZE KB per the guide's gfx950 correction).  None when
+    there is no summary for this workload -- the counters cannot be read from inside the process."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if d.get('workload') != workload:
+        return None
+    k = d.get('kernels', {}).get(kernel)
+    return None if k is None else k.get('hbm_bytes_per_launch')
 
 
 def main():
@@ -109,43 +163,66 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)          # ~3 ms per step: the default run still takes seconds
     ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     a = ap.parse_args()
+
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(a))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('MVSDF_DIST_BACKEND', 'nccl')       # nccl = RCCL over xGMI; gloo for dry runs of the launch path on one GPU
+    if os.environ.get('MVSDF_BENCH_DRYRUN') == '1':              # launch-path check on a box without GPUs (tests/test_bench_launch.py):
+        dist.init_process_group('gloo')                          # rendezvous + one collective + rank 0's line, no device work
+        t_ = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t_)
+        if rank == 0:
+            print(json.dumps({'dry_run': True, 'n_gpus': world, 'sum_of_ranks_plus_1': float(t_), 'views_per_rank': B // world,
+                              'px_per_view': WORKLOADS[a.workload][0] * world}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        local %= max(1, torch.cuda.device_count())             # (a box with fewer GPUs than ranks: dry runs of the launch path only)
-        torch.cuda.set_device(local)
-        dist.init_process_group(os.environ.get('MVSDF_DIST_BACKEND', 'nccl'))      # nccl = RCCL over xGMI; gloo for dry runs on one GPU
-    elif a.gpus > 1:
-        sys.exit('launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...')
+        local %= max(1, torch.cuda.device_count())             # (a box with fewer GPUs than ranks: dry runs only)
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+    if world > 1:
+        if B % world:
+            sys.exit('--gpus must divide the %d views of the batch' % B)
+        dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
 
-    model = IDRNetwork(ConfigDict(synth.model_conf(W)))
+    P_unit, V = WORKLOADS[a.workload]
+    P = P_unit * world                                           # pixels per view: 2048 (c2) rays per GPU at every world size
+    per = B // world
+    R = per * P                                                  # rays of this rank
+    conf = synth.model_conf(W)
+    model = IDRNetwork(ConfigDict(conf))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(W, 0).items()})
     model = model.to(dev).train()
+    if a.dtype == 'bf16':
+        model.set_trace_dtype('bf16')                            # bf16 weights + bf16 MFMA in the tracing MLP (BASELINE configs[4])
     loss_fn = IDRLoss()
     # frozen weights (lr = 0): a step on random GT collapses the scene.  Parameters, gradients and Adam moments
     # live in flat buffers: one memset, one all-reduce, two launches for grad-norm + clip + Adam.
     opt = FlatAdam(model.parameters(), lr=0.0)
-    inp, gt = make_inputs(dev, seed=rank)
+    inp, gt = make_inputs(dev, rank, world, P, V)
     events = []
     model.ray_tracer.events = events
 
     def step():
         opt.zero_grad()
         out = model(inp, TP)
-        lo = loss_fn(out, dict(gt), TP, B)
-        lo['loss'].backward()
-        opt.all_reduce_mean()
+        lo = loss_fn(out, dict(gt), TP, per)
+        opt.backward(lo['loss'])                                 # loss.backward() with the direct gradient sink (one launch for all dv/dg/db)
+        opt.all_reduce_mean()                                    # ONE all-reduce(SUM) of the flat gradient buffer; / world inside Adam
         opt.step(grad_cap=2.0)                                   # grad-norm + clip + Adam (idr_train.py:289-302, conf.grad_cap)
-        return lo
+        return out, lo
 
-    torch.manual_seed(rank)
+    torch.manual_seed(rank)                                      # ranks draw different eikonal points / min-sdf steps
     for _ in range(a.warmup):
         step()
     events.clear()
@@ -154,7 +231,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        lo = step()
+        out, lo = step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -165,8 +242,8 @@ def main():
         dt = float(tt.item())
 
     if rank == 0:
-        R = B * P
         f_t, f_s, f_r = flops_per_row(W)
+        peak = PEAK[a.dtype]
         st = model.last_stats
         cnt = st['counters'].cpu().numpy()
         # tracer rows actually evaluated: counters[8] = ray-sampler rows up to each ray's first sign change (the reference also
@@ -178,31 +255,54 @@ def main():
         rows_samples = int(cnt[8] + cnt[2] + cnt[3])
         n_launch = 3                    # k_ray_samples per step: sampler rows (first window), sampler rows (open rays), secant || min-sdf rows
         ach = rows_samples * f_t / (ms_samples * 1e-3) / 1e12
+        ach_sphere = int(cnt[0]) * f_t / (ms_sphere * 1e-3) / 1e12
+        # k_feat_corr, the one HBM-shaped kernel: 4 taps x 32 channels x 4 B = 512 B per (point, view), timed with HIP events on
+        # the launch stream over 20 launches on the last step's surface points
+        pts = out['diff_surf_pts'].detach()
+        _, view_start, _ = ops.loss_prep(out['network_object_mask'], out['object_mask'], out['object_mask_true'], per)
+        fargs = (pts, view_start, gt['feat'], gt['feat_src'], gt['cam'], gt['src_cams'], gt['size'][:1], gt['center'][:1])
+        ops.feat_corr(*fargs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.feat_corr(*fargs)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_feat = e0.elapsed_time(e1) / 20
+        feat_bytes = 512 * pts.shape[0] * (1 + V)
+        total_R = world * R
         res = {
-            'metric': 'traced rays/sec (fwd+bwd, 10 sphere iters, 4 src views)', 'value': world * R * a.steps / dt, 'unit': 'rays/s',
+            'metric': 'traced rays/sec (fwd+bwd, 10 sphere iters, %d src views)' % V, 'value': total_R * a.steps / dt, 'unit': 'rays/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'DTU-scan24-shaped synthetic scene, %d rays/GPU (%d views x %d px), %d src views, 8x%d SDF MLP, full fwd+loss+bwd+clip+Adam(lr=0)'
-                                   % (R, B, P, V, W), 'rays_per_gpu': R, 'src_views': V, 'sdf_width': W, 'train_progress': TP,
-                       'feature_maps': '32x%dx%d' % FEAT_HW, 'parallelism': 'ray-sharded dp%d, one all-reduce on a flat grad bucket' % world},
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': '%s: DTU-scan24-shaped synthetic scene, %d views x %d px = %d rays in total, %d rays/GPU (%d view(s) per GPU), %d src views, 8x%d SDF MLP, '
+                                   'full fwd+loss+bwd+clip+Adam(lr=0)' % (a.workload if world == 1 else a.workload + ' x%d (c4 shape at 8 GPUs)' % world,
+                                                                          B, P, total_R, R, per, V, W),
+                       'rays_per_gpu': R, 'rays_total': total_R, 'views_total': B, 'src_views': V, 'sdf_width': W, 'train_progress': TP,
+                       'feature_maps': '32x%dx%d channels-last' % FEAT_HW,
+                       'parallelism': 'views sharded over %d rank(s), depth maps replicated; one all-reduce(SUM) on the flat grad buffer (+ 3 loss counts)' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'k_ray_samples (fused 9-layer tracing MLP on the sampler / secant / min-sdf rows)', 'achieved': ach,
-                         'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA,
-                         # HBM bytes per launch from PMC passes of this command (profiles/r01_pmc_summary.csv), mean of the three launches:
-                         # 2 x FETCH_SIZE (gfx950 correction for wide coalesced reads; FETCH_SIZE in KB = 1024 B) + WRITE_SIZE.  Not
-                         # measurable from inside the process.  ~8.6x the 1.84 MB weight set: each of the 8 XCD L2s pulls its own copy.
-                         'traffic': (2 * 7678.5 + 100.8) * 1024 if (W, B, P) == (256, 8, 256) else None,
+                         'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                         'traffic': pmc_traffic(a.workload if world == 1 else None, 'k_ray_samples'),
                          'rows_per_launch': rows_samples / n_launch, 'flop_per_row': f_t, 'avg_launch_ms': ms_samples / n_launch,
                          'launches_per_step': n_launch,
-                         'k_sphere_trace': {'rows_per_launch': int(cnt[0]), 'avg_launch_ms': ms_sphere,
-                                            'achieved': int(cnt[0]) * f_t / (ms_sphere * 1e-3) / 1e12},
+                         # the two tracing-MLP kernels side by side (they take about the same time at this size)
+                         'kernels': {
+                             'k_ray_samples': {'rows_per_step': rows_samples, 'ms_per_step': ms_samples, 'achieved': ach, 'frac': ach / peak},
+                             'k_sphere_trace': {'rows_per_step': int(cnt[0]), 'ms_per_step': ms_sphere, 'achieved': ach_sphere, 'frac': ach_sphere / peak,
+                                                'traffic': pmc_traffic(a.workload if world == 1 else None, 'k_sphere_trace')},
+                             'k_feat_corr': {'bound': 'hbm', 'points': int(pts.shape[0]), 'views_per_point': 1 + V, 'bytes': feat_bytes, 'ms': ms_feat,
+                                             'achieved_GBps': feat_bytes / (ms_feat * 1e-3) / 1e9, 'peak_GBps': 8000.0,
+                                             'traffic': pmc_traffic(a.workload if world == 1 else None, 'k_feat_corr')}},
                          'step': {'T_trace_rows': T, 'T_reference_rows': T_ref, 'R': R, 'E': E, 'N_hit': N, 'flops_step': flops_step,
-                                  'achieved': flops_step / (dt / a.steps) / 1e12, 'frac': flops_step / (dt / a.steps) / 1e12 / PEAK_F32_MFMA}},
+                                  'achieved': flops_step / (dt / a.steps) / 1e12, 'frac': flops_step / (dt / a.steps) / 1e12 / peak}},
             'loss': float(lo['loss'].detach()),
         }
         if not a.no_cpu_baseline and world == 1:
-            res['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(res))
+            res['cpu_baseline'] = cpu_baseline(V)
+        print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

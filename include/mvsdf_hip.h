@@ -116,6 +116,35 @@ int mvsdf_trace_stage(int stage, const MvsdfNetDesc* net, const MvsdfTraceParams
                       float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
                       size_t workspace_bytes, int mt, int mt_samples, void* stream);
 
+/* ---- RayTracing.forward for an OPAQUE `sdf` callable (ray_tracing.py:27-32, called with a lambda at idr.py:194) ----
+ * The per-ray state machine of mvsdf_trace split at its evaluation points, so that a host-side callable can be run between the launches:
+ *   init   : sphere intersection + first requests.  state: mvsdf_tracegen_state_bytes(R) bytes; req[R][2] (uint8: start / end side wants a
+ *            value), pts[R][2][3] (the requested points, dense); zeroes counters[16].
+ *   step   : consumes vals[R][2] (the callable's values at the requested entries, anything elsewhere), advances every ray by one round
+ *            (ray_tracing.py:139-194) and emits the next requests.  The caller loops until no entry of req is set.
+ *   finish : masks / dists / points of the sphere-tracing stage, sampler and min-sdf work lists IN RAY ORDER (counters[MVSDF_CNT_N_SAMPLER],
+ *            [MVSDF_CNT_N_MINSDF]); workspace as for mvsdf_trace.
+ *   rows   : the n_steps sample points of each listed ray (kind 0: ray_sampler with `zs` = intervals, ray_tracing.py:206-213; kind 1:
+ *            minimal_sdf_points with `zs` = the uniform draws, 287-297) -> out_pts[n_list * n_steps][3].
+ *   reduce : the per-ray decisions on the callable's values sv[n_list][n_steps] (kind 0: ray_tracing.py:221-256, fills the secant list sorted
+ *            by ray, marks[R] is scratch; kind 1: 303-307).
+ *   secant : op 0 emits the n_sec points of one secant round -> pts_out[n_sec][3]; op 1 consumes vals[n_sec]; op 2 writes the final result. */
+size_t mvsdf_tracegen_state_bytes(int R);
+int mvsdf_tracegen_init(const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs, const uint8_t* object_mask, int B, int P,
+                        void* state, uint8_t* req, float* pts, unsigned long long* counters, void* stream);
+int mvsdf_tracegen_step(const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs, int B, int P, void* state, const float* vals,
+                        uint8_t* req, float* pts, unsigned long long* counters, void* stream);
+int mvsdf_tracegen_finish(const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs, int B, int P, int training, const void* state,
+                          float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int mvsdf_tracegen_rows(const MvsdfTraceParams* tp, int kind, const float* cam_loc, const float* ray_dirs, int B, int P, const float* zs, int n_list,
+                        void* workspace, float* out_pts, void* stream);
+int mvsdf_tracegen_reduce(const MvsdfTraceParams* tp, int kind, const float* cam_loc, const float* ray_dirs, int B, int P, int training,
+                          const float* intervals, const float* minsdf_steps, const float* sv, float* points, uint8_t* mask, float* dists,
+                          unsigned long long* counters, void* workspace, uint8_t* marks, void* stream);
+int mvsdf_tracegen_secant(const MvsdfTraceParams* tp, int op, const float* cam_loc, const float* ray_dirs, int B, int P, int n_sec, const float* vals,
+                          float* pts_out, float* points, float* dists, unsigned long long* counters, void* workspace, void* stream);
+
 /* ---- differentiable SDF network: value + normal and their first/second-order backward ----
  * Replaces ImplicitNetwork.forward / .gradient (idr.py:77-107) and autograd's (double) backward through them.
  * net: packs of W_l; netT: packs of W_l^T (K and N swapped per layer).  x[M][3].  The first Mg rows also get the normal
@@ -222,6 +251,10 @@ int mvsdf_dsurf_points(const float* depths, const float* kinv, const float* einv
 size_t mvsdf_adam_ws_floats(void);
 int mvsdf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step, float max_norm,
                     float* norm_out, float* ws, void* stream);
+/* Same with every gradient multiplied by grad_scale first (norm and clip see the scaled gradient): grad_scale = 1 / world size turns the
+ * SUM of a data-parallel all-reduce into the rank average inside the optimiser launch -- no separate division pass over the bucket. */
+int mvsdf_adam_step_scaled(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
+                           float max_norm, float grad_scale, float* norm_out, float* ws, void* stream);
 
 /* masks -> what IDRLoss.forward needs from them, one launch: hit[R] = network_object_mask & object_mask (loss.py:21,206), view_start[B+1]
  * = prefix sums of the per-view hit counts (rows of diff_surf_pts per view, loss.py:119-127; R = B * P rays, view-major),

@@ -199,37 +199,6 @@ __global__ __launch_bounds__(64 * NW) void k_sdf_col0(MvNet net, const float* __
     if (tid < ROWS && row0 + tid < n) y[row0 + tid] = out[tid];
 }
 
-// two-group variant: 32*MTg rows per 512-thread workgroup
-template <int MTg, int NTW>
-__global__ __launch_bounds__(512) void k_sdf_col0_2g(MvNet net, const float* __restrict__ x, int n, float* __restrict__ y) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int ROWS = 32 * MTg;
-    const int tid = threadIdx.x, d0 = 3 + 6 * net.multires;
-    float* act = smem;
-    float* pe = act + ROWS * net.S;
-    float* pts = pe + ((ROWS * d0 + 3) & ~3);
-    float* out = pts + ROWS * 4;
-    const int row0 = blockIdx.x * ROWS;
-    for (int i = tid; i < ROWS * 3; i += 512) {
-        const int row = row0 + i / 3;
-        pts[i] = row < n ? x[3 * (size_t)row0 + i] : 0.0f;
-    }
-    __syncthreads();
-    const int nvalid = min(ROWS, n - row0);
-    mv_sdf_eval_col0_2g<MTg, NTW>(net, act, pe, pts, out, (nvalid + 15) >> 4, tid);
-    if (tid < ROWS && row0 + tid < n) y[row0 + tid] = out[tid];
-}
-
-template <int MTg, int NTW>
-static int launch_col0_2g(const MvNet& net, const float* x, int n, float* y, hipStream_t s) {
-    const int rows = 32 * MTg, d0 = 3 + 6 * net.multires;
-    const size_t lds = ((size_t)rows * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows) * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)k_sdf_col0_2g<MTg, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return mv_check(e, "mvsdf_sdf_col0: LDS attribute");
-    hipLaunchKernelGGL((k_sdf_col0_2g<MTg, NTW>), dim3((n + rows - 1) / rows), dim3(512), lds, s, net, x, n, y);
-    return mv_check(hipGetLastError(), "mvsdf_sdf_col0 (2g)");
-}
-
 __global__ void k_det_math(int op, const float* __restrict__ x, int n, float* __restrict__ y0, float* __restrict__ y1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -358,10 +327,6 @@ int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, in
     if (rc) return rc;
     if (!x || !y || n <= 0) return mv_fail(-1, "mvsdf_sdf_col0: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (mt == 5 || mt == 6) {                                   // phase-staggered two-group evaluation
-        if (mv_wide(net)) return mt == 5 ? launch_col0_2g<1, 8>(net, x, n, y, s) : mv_fail(-1, "mvsdf_sdf_col0: mt=6 needs width <= 256");
-        return mt == 5 ? launch_col0_2g<1, 4>(net, x, n, y, s) : launch_col0_2g<2, 4>(net, x, n, y, s);
-    }
     const char* e = getenv("MVSDF_NW");
     const int nw_env = e ? atoi(e) : 0;
     int maxnt = 0;

@@ -23,6 +23,7 @@ struct AdamArgs {
     float* p; float* g; float* m; float* v; size_t n;
     float lr, beta1, beta2, eps, bc1, bc2_sqrt;      // bias corrections 1 - beta1^t, sqrt(1 - beta2^t) (host doubles, rounded once)
     float max_norm;                                  // <= 0: no clipping
+    float grad_scale;                                // applied to every gradient first (1 / world size after a SUM all-reduce)
     const float* part; int nparts;
     float* norm_out;                                 // [2]: total norm, clip coefficient
 };
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(256) void k_adam_flat(AdamArgs a) {
         for (int i = threadIdx.x; i < a.nparts; i += 64) s += a.part[i];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (threadIdx.x == 0) {
-            const float total = sqrtf(s);
+            const float total = sqrtf(s) * a.grad_scale;
             float coef = 1.0f;
             if (a.max_norm > 0.0f) coef = fminf(a.max_norm / (total + 1e-6f), 1.0f);      // torch.nn.utils.clip_grad_norm_
             coef_s = coef;
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void k_adam_flat(AdamArgs a) {
     const float coef = coef_s;
     const float step_size = a.lr / a.bc1;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-        const float g = a.g[i] * coef;
+        const float g = a.g[i] * a.grad_scale * coef;
         const float m = a.m[i] + (g - a.m[i]) * (1.0f - a.beta1);                          // exp_avg.lerp_(grad, 1 - beta1)
         const float v = a.v[i] * a.beta2 + (1.0f - a.beta2) * g * g;                       // mul_(beta2).addcmul_(g, g, 1 - beta2)
         const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
@@ -58,9 +59,9 @@ extern "C" {
 
 size_t mvsdf_adam_ws_floats(void) { return OPT_BLOCKS_MAX; }
 
-int mvsdf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step, float max_norm,
-                    float* norm_out, float* ws, void* stream) {
-    if (!p || !g || !m || !v || !ws || n == 0 || step < 1) return mv_fail(-1, "mvsdf_adam_step: bad arguments");
+int mvsdf_adam_step_scaled(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step, float max_norm,
+                           float grad_scale, float* norm_out, float* ws, void* stream) {
+    if (!p || !g || !m || !v || !ws || n == 0 || step < 1 || !(grad_scale > 0.0f)) return mv_fail(-1, "mvsdf_adam_step: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     int blocks = (int)((n + 2047) / 2048);
     if (blocks > OPT_BLOCKS_MAX) blocks = OPT_BLOCKS_MAX;
@@ -71,9 +72,14 @@ int mvsdf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, 
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    a.max_norm = max_norm; a.part = ws; a.nparts = blocks; a.norm_out = norm_out;
+    a.max_norm = max_norm; a.grad_scale = grad_scale; a.part = ws; a.nparts = blocks; a.norm_out = norm_out;
     hipLaunchKernelGGL(k_adam_flat, dim3(blocks), dim3(256), 0, s, a);
     return mv_check(hipGetLastError(), "mvsdf_adam_step");
+}
+
+int mvsdf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step, float max_norm,
+                    float* norm_out, float* ws, void* stream) {
+    return mvsdf_adam_step_scaled(p, g, m, v, n, lr, beta1, beta2, eps, step, max_norm, 1.0f, norm_out, ws, stream);
 }
 
 }  // extern "C"

@@ -217,87 +217,3 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
     __syncthreads();
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Phase-staggered two-group evaluation (8 waves = 512 threads).  Group 0 (waves 0-3) owns rows [0, 16*MTg), group 1
-// (waves 4-7) rows [16*MTg, 32*MTg).  Every phase one group runs the GEMM of a layer (MFMA pipe) while the other runs
-// the softplus epilogue of ITS previous GEMM (VALU pipe): each SIMD hosts one wave of each group, so matrix and vector
-// work of different rows overlap and the MFMA pipe stays busy.  Phases are separated by ordinary workgroup barriers:
-//     phase p : group 0 -> (p even ? GEMM(p/2) : EPI((p-1)/2)),   group 1 -> the same one phase later.
-// Same arithmetic, same order as mv_sdf_eval_col0 (bit-exact).  LDS: act[2][16*MTg][S], pe[2][16*MTg][d0],
-// pts[32*MTg][3], out[32*MTg].  ntiles (1..2*MTg) row tiles are valid; group g is active iff it owns a valid tile.
-template <int MTg, int NTW>
-__device__ void mv_sdf_eval_col0_2g(const MvNet& net, float* act, float* pe, const float* pts, float* out, int ntiles, int tid) {
-    constexpr int NTH = 256;                                    // threads per group
-    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = w >> 2, wl = w & 3, gt = tid & 255;
-    const int r = lane & 15, q = lane >> 4;
-    const int S = net.S, rows = MTg * 16, d0 = 3 + 6 * net.multires, nl = net.n_layers;
-    const bool active = (g == 0) || (ntiles > MTg);
-    float* actg = act + g * rows * S;
-    float* peg = pe + g * rows * d0;
-    const float* ptsg = pts + g * rows * 3;
-    float* outg = out + g * rows;
-    if (active) mv_pe_rows<NTH>(ptsg, peg, actg, S, rows, net.multires, gt);
-    __syncthreads();
-    f32x4 acc[MTg][NTW];
-    int ct0 = 0, ntw = 0;
-    for (int ph = 0; ph <= 2 * nl; ++ph) {
-        const int my = ph - g;
-        if (active && my >= 0 && my < 2 * nl) {
-            const int l = my >> 1;
-            const MvLayer& L = net.L[l];
-            const bool last = (l == nl - 1);
-            if ((my & 1) == 0) {                                 // ---- GEMM(l)
-                const int NT = last ? 1 : L.NT;
-                const int per = (NT + 3) >> 2;
-                ct0 = wl * per;
-                ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
-                mv_zero_acc<MTg, NTW>(acc);
-                if (ntw > 0) mv_gemm_dispatch<MTg, NTW>(L, actg, S, ct0, ntw, acc, lane);
-            } else if (last) {                                   // ---- EPI(last): column 0 + bias
-                if (wl == 0 && r == 0) {
-                    const float b0 = L.bias[0];
-#pragma unroll
-                    for (int a = 0; a < MTg; ++a)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) outg[a * 16 + 4 * q + i] = acc[a][0][i] + b0;
-                }
-            } else {                                             // ---- EPI(l): softplus, in place (this group's rows only)
-                const bool to_skip = (l + 1 == net.skip_layer);
-                const int N = L.N;
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) {
-                    if (t < ntw) {
-                        const int col = (ct0 + t) * 16 + r;
-                        if (col < N) {
-                            const float bv = L.bias[col];
-                            const int pos = (ct0 + t) * 16 + ((r & 3) << 2) + (r >> 2);
-#pragma unroll
-                            for (int a = 0; a < MTg; ++a)
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    float h = mv_act(acc[a][t][i] + bv);
-                                    if (to_skip) h = dm_div_sqrt2(h);
-                                    actg[(a * 16 + 4 * q + i) * S + pos] = h;
-                                }
-                        }
-                    }
-                }
-                const int Kn = net.L[l + 1].K, Kpn = net.L[l + 1].KB * 16;
-                if (to_skip) {
-                    for (int idx = gt; idx < rows * d0; idx += NTH) {
-                        const int row = idx / d0, j = idx - row * d0;
-                        actg[row * S + mv_perm(N + j)] = dm_div_sqrt2(peg[row * d0 + j]);
-                    }
-                }
-                if (Kpn > Kn) {
-                    const int pad = Kpn - Kn;
-                    for (int idx = gt; idx < rows * pad; idx += NTH) {
-                        const int row = idx / pad, j = idx - row * pad;
-                        actg[row * S + mv_perm(Kn + j)] = 0.0f;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-}

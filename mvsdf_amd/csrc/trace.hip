@@ -1,4 +1,5 @@
-// trace.hip -- RayTracing.forward (reference code/model/ray_tracing.py:27-98) as two persistent-style kernels:
+// trace.hip -- RayTracing.forward (reference code/model/ray_tracing.py:27-98) as 7 launches of three kernels (k_sphere_trace, then
+// k_ray_samples / k_reduce_items three times each: sampler first window, sampler rest, secant || min-sdf):
 //
 //   k_sphere_trace : one workgroup owns NR = 8*MT rays = 16*MT "half-rays" (start/end side).  Per-ray state
 //                    lives in wave 0's registers; every round each ray requests 0/1/2 SDF evaluations, the
@@ -563,6 +564,245 @@ hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp
 }
 
 // =============================================================================================================
+// Generic tracer for an OPAQUE `sdf` callable (ray_tracing.py:27-32; the reference calls it as a lambda, idr.py:194).  The per-ray state
+// machine is the one of k_sphere_trace, split at its evaluation points: `k_gen_init` / `k_gen_step` EMIT the points each ray wants
+// evaluated (dense [R][2][3] + request flags), the host runs the Python callable on the requested rows, `k_gen_step` CONSUMES the values
+// and emits the next requests.  `k_gen_finish` is the tail of k_sphere_trace (masks, work lists); sampler / min-sdf rows are emitted by
+// `k_gen_rows`, reduced by k_reduce_items, the secant by `k_gen_secant`.  Slow (one host round trip per evaluation) but the decisions stay in
+// HIP, bit-identical to the fused path -- this is what pins the state machine to the reference's analytic-SDF goldens on the GPU.
+struct GenRay {                      // 16 dwords per ray
+    float acc_s, acc_e, next_s, next_e, curr_s, curr_e, t0, t1, ts, te;
+    int iters, k, phase, flags, pad0, pad1;      // flags: 1 unf_s, 2 unf_e, 4 req_s, 8 req_e, 16 isect, 32 om
+};
+
+__device__ __forceinline__ void mv_gen_emit(const GenRay& g, const float* c, const float* d, uint8_t* req, float* pts) {
+    const bool rs = g.flags & 4, re = g.flags & 8;
+    req[0] = rs ? 1 : 0; req[1] = re ? 1 : 0;
+    pts[0] = c[0] + g.ts * d[0]; pts[1] = c[1] + g.ts * d[1]; pts[2] = c[2] + g.ts * d[2];
+    pts[3] = c[0] + g.te * d[0]; pts[4] = c[1] + g.te * d[1]; pts[5] = c[2] + g.te * d[2];
+}
+
+__global__ void k_gen_init(MvTraceParams tp, const float* __restrict__ cam_loc, const float* __restrict__ dirs, const uint8_t* __restrict__ om,
+                           int R, int P, GenRay* __restrict__ state, uint8_t* __restrict__ req, float* __restrict__ pts) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= R) return;
+    float c[3], d[3];
+    for (int i = 0; i < 3; ++i) { c[i] = cam_loc[3 * (gid / P) + i]; d[i] = dirs[3 * (size_t)gid + i]; }
+    GenRay g;
+    const bool isect = mv_sphere_isect(c, d, tp.r, g.t0, g.t1);
+    g.acc_s = isect ? g.t0 : 0.f; g.acc_e = isect ? g.t1 : 0.f;
+    g.next_s = g.next_e = g.curr_s = g.curr_e = 0.f;
+    g.ts = g.acc_s; g.te = g.acc_e;
+    g.iters = 0; g.k = 0; g.phase = isect ? 0 : 3;
+    g.flags = (isect ? (1 | 2 | 4 | 8 | 16) : 0) | (om[gid] ? 32 : 0);
+    g.pad0 = g.pad1 = 0;
+    state[gid] = g;
+    mv_gen_emit(g, c, d, req + 2 * (size_t)gid, pts + 6 * (size_t)gid);
+}
+
+// consume vals[R][2] (the callable's outputs scattered back to the dense layout), advance every ray by one round, emit the next requests
+__global__ void k_gen_step(MvTraceParams tp, const float* __restrict__ cam_loc, const float* __restrict__ dirs, int R, int P,
+                           GenRay* __restrict__ state, const float* __restrict__ vals, uint8_t* __restrict__ req, float* __restrict__ pts,
+                           unsigned long long* __restrict__ counters) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    int nreq = 0;
+    if (gid < R) {
+        GenRay g = state[gid];
+        if (g.phase != 3) {
+            bool unf_s = g.flags & 1, unf_e = g.flags & 2;
+            const bool req_s = g.flags & 4, req_e = g.flags & 8;
+            nreq = (req_s ? 1 : 0) + (req_e ? 1 : 0);
+            const float vs = req_s ? mv_clamp(vals[2 * (size_t)gid], -tp.dist_clip, tp.dist_clip) : 0.f;
+            const float ve = req_e ? mv_clamp(vals[2 * (size_t)gid + 1], -tp.dist_clip, tp.dist_clip) : 0.f;
+            bool nreq_s = false, nreq_e = false, end_iter = false;
+            if (g.phase == 0) { g.next_s = vs; g.next_e = ve; }
+            else if (g.phase == 1) { g.next_s = vs; g.next_e = ve; g.k = 0; }
+            else { if (req_s) g.next_s = vs; if (req_e) g.next_e = ve; g.k++; }
+            if (g.phase != 0) {
+                const bool np_s = g.next_s < 0.f, np_e = g.next_e < 0.f;
+                if (g.k < tp.line_step_iters && (np_s || np_e)) {                     // ray_tracing.py:173-191
+                    const float coef = (1.0f - tp.line_search_step) / (float)(1 << g.k);
+                    nreq_s = np_s; nreq_e = np_e;
+                    if (np_s) { g.acc_s -= coef * g.curr_s; g.ts = g.acc_s; }
+                    if (np_e) { g.acc_e += coef * g.curr_e; g.te = g.acc_e; }
+                    g.phase = 2;
+                } else {
+                    end_iter = true;
+                    unf_s = unf_s && (g.acc_s < g.acc_e);                             // ray_tracing.py:193-194
+                    unf_e = unf_e && (g.acc_s < g.acc_e);
+                }
+            }
+            if (g.phase == 0 || end_iter) {                                           // top of the while loop, ray_tracing.py:139-171
+                g.curr_s = unf_s ? g.next_s : 0.f;
+                g.curr_e = unf_e ? g.next_e : 0.f;
+                if (g.curr_s <= tp.thr) g.curr_s = 0.f;
+                if (g.curr_e <= tp.thr) g.curr_e = 0.f;
+                unf_s = unf_s && (g.curr_s > tp.thr);
+                unf_e = unf_e && (g.curr_e > tp.thr);
+                if ((!unf_s && !unf_e) || g.iters == tp.st_iters) {
+                    g.phase = 3; nreq_s = false; nreq_e = false;
+                } else {
+                    g.iters++;
+                    g.acc_s = g.acc_s + g.curr_s;
+                    g.acc_e = g.acc_e - g.curr_e;
+                    nreq_s = unf_s; nreq_e = unf_e; g.ts = g.acc_s; g.te = g.acc_e;
+                    g.phase = 1;
+                }
+            }
+            g.flags = (g.flags & (16 | 32)) | (unf_s ? 1 : 0) | (unf_e ? 2 : 0) | (nreq_s ? 4 : 0) | (nreq_e ? 8 : 0);
+            state[gid] = g;
+            float c[3], d[3];
+            for (int i = 0; i < 3; ++i) { c[i] = cam_loc[3 * (gid / P) + i]; d[i] = dirs[3 * (size_t)gid + i]; }
+            mv_gen_emit(g, c, d, req + 2 * (size_t)gid, pts + 6 * (size_t)gid);
+        } else {
+            req[2 * (size_t)gid] = 0; req[2 * (size_t)gid + 1] = 0;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) nreq += __shfl_xor(nreq, o);
+    if ((threadIdx.x & 63) == 0 && nreq) atomicAdd(&counters[MV_CNT_ROWS_SPHERE], (unsigned long long)nreq);
+}
+
+// tail of k_sphere_trace: ray_tracing.py:41-44, 73-94
+__global__ void k_gen_finish(MvTraceParams tp, const float* __restrict__ cam_loc, const float* __restrict__ dirs, int R, int P, int training,
+                             const GenRay* __restrict__ state, float* __restrict__ o_points, uint8_t* __restrict__ o_mask,
+                             float* __restrict__ o_dists, float* __restrict__ w_zmin, float* __restrict__ w_zmax, int* __restrict__ w_list,
+                             int* __restrict__ w_list_min, unsigned long long* __restrict__ counters) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= R) return;
+    const GenRay g = state[gid];
+    float c[3], d[3];
+    for (int i = 0; i < 3; ++i) { c[i] = cam_loc[3 * (gid / P) + i]; d[i] = dirs[3 * (size_t)gid + i]; }
+    const bool om = g.flags & 32, isect = g.flags & 16;
+    const bool net_mask = g.acc_s < g.acc_e;
+    const bool sampler = g.flags & 1;
+    float dist = g.acc_s, zmin = g.acc_s, zmax = g.acc_e;
+    bool listed = false;
+    int kind = 0;
+    if (sampler) { listed = true; kind = MV_ITEM_SAMPLER | (om ? MV_ITEM_OM : 0); }
+    else if (training) {
+        const bool in_mask = !net_mask && om, out_mask = !om;
+        if (in_mask || out_mask) {
+            if (!isect) {
+                const float dot = (d[0] * c[0] + d[1] * c[1]) + d[2] * c[2];
+                dist = -dot;
+            } else {
+                listed = true; kind = MV_ITEM_MINSDF;
+                zmin = (net_mask && out_mask) ? g.acc_s : g.t0;
+                zmax = g.t1;
+            }
+        }
+    }
+    o_mask[gid] = net_mask ? 1 : 0;
+    o_dists[gid] = dist;
+    o_points[3 * (size_t)gid + 0] = c[0] + dist * d[0];
+    o_points[3 * (size_t)gid + 1] = c[1] + dist * d[1];
+    o_points[3 * (size_t)gid + 2] = c[2] + dist * d[2];
+    w_zmin[gid] = zmin; w_zmax[gid] = zmax;
+    (void)listed; (void)kind; (void)w_list; (void)w_list_min; (void)counters;
+    // the work lists are filled in RAY ORDER by k_gen_lists (one thread): the opaque callable may depend on the order of its rows
+    // (the reference evaluates them in ray order, ray_tracing.py:215-219), so no atomics here
+    w_list[gid] = listed ? (gid | (kind << 28)) : -1;                              // scratch: per-ray entry, compacted below
+}
+
+// stable compaction of the per-ray entries into the sampler / min-sdf lists (single workgroup, ballot scan over chunks of 1024 rays)
+__global__ __launch_bounds__(1024) void k_gen_lists(int R, int* __restrict__ w_list, int* __restrict__ w_list_min, int* __restrict__ scratch,
+                                                    unsigned long long* __restrict__ counters) {
+    __shared__ int wsum[2][16];
+    __shared__ int base[2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < 2) base[tid] = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < R; r0 += 1024) {
+        const int gid = r0 + tid;
+        const int e = gid < R ? scratch[gid] : -1;
+        const bool smp = e >= 0 && ((e >> 28) & MV_ITEM_SAMPLER), mn = e >= 0 && ((e >> 28) & MV_ITEM_MINSDF);
+        const unsigned long long bs = __ballot(smp), bm = __ballot(mn), lt = (1ull << lane) - 1ull;
+        if (lane == 0) { wsum[0][w] = __popcll(bs); wsum[1][w] = __popcll(bm); }
+        __syncthreads();
+        int os = base[0], omn = base[1];
+        for (int j = 0; j < w; ++j) { os += wsum[0][j]; omn += wsum[1][j]; }
+        if (smp) w_list[os + __popcll(bs & lt)] = e;
+        if (mn) w_list_min[omn + __popcll(bm & lt)] = e;
+        __syncthreads();
+        if (tid == 0) { for (int j = 0; j < 16; ++j) { base[0] += wsum[0][j]; base[1] += wsum[1][j]; } }
+        __syncthreads();
+    }
+    if (tid == 0) { counters[MV_CNT_N_SAMPLER] = (unsigned long long)base[0]; counters[MV_CNT_N_MINSDF] = (unsigned long long)base[1]; }
+}
+
+// sample points of a work list: row q = item * n_steps + i  (ray_tracing.py:206-213 sampler, 287-297 min-sdf)
+__global__ void k_gen_rows(int n_list, int n_steps, const int* __restrict__ list, const float* __restrict__ cam_loc, const float* __restrict__ dirs,
+                           int P, const float* __restrict__ zs /* intervals or steps */, int is_sampler, const float* __restrict__ w_zmin,
+                           const float* __restrict__ w_zmax, float* __restrict__ out) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long long)n_list * n_steps) return;
+    const int it = (int)(q / n_steps), i = (int)(q - (long long)it * n_steps);
+    const int gid = list[it] & 0x0fffffff;
+    const float* cc = cam_loc + 3 * (gid / P);
+    const float* d = dirs + 3 * (size_t)gid;
+    const float zmin = w_zmin[gid], zmax = w_zmax[gid];
+    const float z = is_sampler ? (zmin + zs[i] * (zmax - zmin)) : (zs[i] * (zmax - zmin) + zmin);
+    out[3 * q + 0] = cc[0] + z * d[0]; out[3 * q + 1] = cc[1] + z * d[1]; out[3 * q + 2] = cc[2] + z * d[2];
+}
+
+// secant (ray_tracing.py:260-278), one thread per listed ray.  op 0: emit z_pred points; op 1: consume sdf_mid, update the bracket;
+// op 2: write the final z_pred to dists / points.  z_pred is a pure function of the bracket, recomputed where needed.
+__global__ void k_gen_secant(int op, int n_sec, int R, int P, const int* __restrict__ sec_list, float* __restrict__ sec_state,
+                             const float* __restrict__ cam_loc, const float* __restrict__ dirs, const float* __restrict__ vals,
+                             float* __restrict__ pts_out, float* __restrict__ o_points, float* __restrict__ o_dists) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sec) return;
+    const int gid = sec_list[i];
+    float z_low = sec_state[gid], z_high = sec_state[(size_t)R + gid], sdf_low = sec_state[2 * (size_t)R + gid], sdf_high = sec_state[3 * (size_t)R + gid];
+    float z_pred = -sdf_low * (z_high - z_low) / (sdf_high - sdf_low) + z_low;
+    const float* cc = cam_loc + 3 * (gid / P);
+    const float* d = dirs + 3 * (size_t)gid;
+    if (op == 1) {
+        const float sm = vals[i];
+        if (sm > 0.f) { sec_state[gid] = z_pred; sec_state[2 * (size_t)R + gid] = sm; }
+        if (sm < 0.f) { sec_state[(size_t)R + gid] = z_pred; sec_state[3 * (size_t)R + gid] = sm; }
+        return;
+    }
+    float* o = op == 0 ? pts_out + 3 * (size_t)i : o_points + 3 * (size_t)gid;
+    o[0] = cc[0] + z_pred * d[0]; o[1] = cc[1] + z_pred * d[1]; o[2] = cc[2] + z_pred * d[2];
+    if (op == 2) o_dists[gid] = z_pred;
+}
+
+// sort the secant list by ray id (k_reduce_items appends with atomics; the callable sees its rows in ray order like the reference's masks)
+__global__ __launch_bounds__(1024) void k_gen_sort_list(int* __restrict__ list, const unsigned long long* __restrict__ counters, int cnt_index,
+                                                        uint8_t* __restrict__ marks, int R) {
+    // marks[R] must be zero on entry; single workgroup: mark, then stable compaction
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int n = (int)counters[cnt_index], tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < n; i += 1024) marks[list[i]] = 1;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < R; r0 += 1024) {
+        const int gid = r0 + tid;
+        const bool m = gid < R && marks[gid];
+        const unsigned long long b = __ballot(m), lt = (1ull << lane) - 1ull;
+        if (lane == 0) wsum[w] = __popcll(b);
+        __syncthreads();
+        int o = base;
+        for (int j = 0; j < w; ++j) o += wsum[j];
+        if (m) list[o + __popcll(b & lt)] = gid;
+        __syncthreads();
+        if (tid == 0) for (int j = 0; j < 16; ++j) base += wsum[j];
+        __syncthreads();
+    }
+}
+
+struct GenWs { float* w_zmin; float* w_zmax; float* sec_state; int* w_list; int* w_list_min; int* sec_list; float* sv; int* list_rest; int* src_rest; };
+static GenWs mv_gen_ws(void* ws, int R, int n) {
+    GenWs g;
+    g.w_zmin = (float*)ws; g.w_zmax = g.w_zmin + R; g.sec_state = g.w_zmax + R;
+    g.w_list = (int*)(g.sec_state + 4 * (size_t)R); g.w_list_min = g.w_list + R; g.sec_list = g.w_list_min + R;
+    g.sv = (float*)(g.sec_list + R); g.list_rest = (int*)(g.sv + (size_t)R * n); g.src_rest = g.list_rest + R;
+    return g;
+}
+
+// =============================================================================================================
 #include "capi_util.h"
 extern "C" {
 
@@ -614,6 +854,114 @@ int mvsdf_trace_stage(int stage, const MvsdfNetDesc* desc, const MvsdfTraceParam
     static const int bits[5] = {0, 1, 6, 2, 4};
     return trace_impl(bits[stage], desc, tp, cam_loc, ray_dirs, object_mask, B, P, training, intervals, minsdf_steps, points, mask, dists, counters,
                       workspace, workspace_bytes, mt, rpw, stream);
+}
+
+
+/* ---- generic tracer for an opaque SDF callable (see the kernel comments above) ---- */
+size_t mvsdf_tracegen_state_bytes(int R) { return (size_t)(R > 0 ? R : 0) * sizeof(GenRay); }
+
+static int tracegen_check(const MvsdfTraceParams* tp, int B, int P) {
+    if (!tp || B <= 0 || P <= 0 || (long long)B * P >= (1 << 28)) return mv_fail(-1, "mvsdf_tracegen: bad sizes");
+    if (tp->n_steps < 2 || tp->n_steps > 1024 || tp->line_step_iters < 0 || tp->line_step_iters > 30) return mv_fail(-1, "mvsdf_tracegen: tracer parameters out of range");
+    return 0;
+}
+
+int mvsdf_tracegen_init(const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs, const uint8_t* object_mask, int B, int P,
+                        void* state, uint8_t* req, float* pts, unsigned long long* counters, void* stream) {
+    int rc = tracegen_check(tp, B, P);
+    if (rc) return rc;
+    if (!cam_loc || !ray_dirs || !object_mask || !state || !req || !pts || !counters) return mv_fail(-1, "mvsdf_tracegen_init: null argument");
+    const int R = B * P;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(counters, 0, 16 * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return mv_check(e, "mvsdf_tracegen_init: memset");
+    hipLaunchKernelGGL(k_gen_init, dim3((R + 255) / 256), dim3(256), 0, s, *tp, cam_loc, ray_dirs, object_mask, R, P, (GenRay*)state, req, pts);
+    return mv_check(hipGetLastError(), "mvsdf_tracegen_init");
+}
+
+int mvsdf_tracegen_step(const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs, int B, int P, void* state, const float* vals,
+                        uint8_t* req, float* pts, unsigned long long* counters, void* stream) {
+    int rc = tracegen_check(tp, B, P);
+    if (rc) return rc;
+    if (!cam_loc || !ray_dirs || !state || !vals || !req || !pts || !counters) return mv_fail(-1, "mvsdf_tracegen_step: null argument");
+    const int R = B * P;
+    hipLaunchKernelGGL(k_gen_step, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, *tp, cam_loc, ray_dirs, R, P, (GenRay*)state, vals, req, pts, counters);
+    return mv_check(hipGetLastError(), "mvsdf_tracegen_step");
+}
+
+int mvsdf_tracegen_finish(const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs, int B, int P, int training, const void* state,
+                          float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+    int rc = tracegen_check(tp, B, P);
+    if (rc) return rc;
+    const int R = B * P;
+    if (!cam_loc || !ray_dirs || !state || !points || !mask || !dists || !counters || !workspace) return mv_fail(-1, "mvsdf_tracegen_finish: null argument");
+    if (workspace_bytes < mvsdf_trace_workspace_bytes_n(R, tp->n_steps)) return mv_fail(-1, "mvsdf_tracegen_finish: workspace too small");
+    GenWs w = mv_gen_ws(workspace, R, tp->n_steps);
+    hipStream_t s = (hipStream_t)stream;
+    int* scratch = w.sec_list;                                  // per-ray entries before the stable compaction (sec_list is filled later)
+    hipLaunchKernelGGL(k_gen_finish, dim3((R + 255) / 256), dim3(256), 0, s, *tp, cam_loc, ray_dirs, R, P, training, (const GenRay*)state, points, mask,
+                       dists, w.w_zmin, w.w_zmax, scratch, w.w_list_min, counters);
+    hipLaunchKernelGGL(k_gen_lists, dim3(1), dim3(1024), 0, s, R, w.w_list, w.w_list_min, scratch, counters);
+    return mv_check(hipGetLastError(), "mvsdf_tracegen_finish");
+}
+
+/* kind 0: ray-sampler rows (intervals), 1: min-sdf rows (steps) of the n_list listed rays -> out_pts[n_list * n_steps][3] */
+int mvsdf_tracegen_rows(const MvsdfTraceParams* tp, int kind, const float* cam_loc, const float* ray_dirs, int B, int P, const float* zs, int n_list,
+                        void* workspace, float* out_pts, void* stream) {
+    int rc = tracegen_check(tp, B, P);
+    if (rc) return rc;
+    if (!cam_loc || !ray_dirs || !zs || !workspace || !out_pts || n_list <= 0 || n_list > B * P || kind < 0 || kind > 1)
+        return mv_fail(-1, "mvsdf_tracegen_rows: bad arguments");
+    GenWs w = mv_gen_ws(workspace, B * P, tp->n_steps);
+    const long long total = (long long)n_list * tp->n_steps;
+    hipLaunchKernelGGL(k_gen_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_list, tp->n_steps,
+                       kind == 0 ? w.w_list : w.w_list_min, cam_loc, ray_dirs, P, zs, kind == 0 ? 1 : 0, w.w_zmin, w.w_zmax, out_pts);
+    return mv_check(hipGetLastError(), "mvsdf_tracegen_rows");
+}
+
+/* per-ray reduction of the callable's values sv[n_list][n_steps] (kind 0: first sign change / P_out argmin / secant hand-off,
+ * ray_tracing.py:221-256; kind 1: min-sdf argmin, 303-307).  After kind 0 the secant list is sorted by ray and `mask` is final. */
+int mvsdf_tracegen_reduce(const MvsdfTraceParams* tp, int kind, const float* cam_loc, const float* ray_dirs, int B, int P, int training,
+                          const float* intervals, const float* minsdf_steps, const float* sv, float* points, uint8_t* mask, float* dists,
+                          unsigned long long* counters, void* workspace, uint8_t* marks, void* stream) {
+    int rc = tracegen_check(tp, B, P);
+    if (rc) return rc;
+    const int R = B * P;
+    if (!cam_loc || !ray_dirs || !intervals || !sv || !points || !mask || !dists || !counters || !workspace || kind < 0 || kind > 1 || (kind == 0 && !marks))
+        return mv_fail(-1, "mvsdf_tracegen_reduce: bad arguments");
+    GenWs w = mv_gen_ws(workspace, R, tp->n_steps);
+    SampleCtx c;
+    c.cam_loc = cam_loc; c.dirs = ray_dirs; c.R = R; c.P = P; c.training = training; c.RPW = 0; c.intervals = intervals;
+    c.steps = minsdf_steps ? minsdf_steps : intervals;
+    c.o_points = points; c.o_mask = mask; c.o_dists = dists; c.w_zmin = w.w_zmin; c.w_zmax = w.w_zmax; c.sec_state = w.sec_state;
+    c.sec_list = w.sec_list; c.sv = (float*)sv; c.counters = counters; c.list_rest = w.list_rest; c.src_rest = w.src_rest; c.n_first = tp->n_steps;
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == 0) {
+        hipLaunchKernelGGL(k_reduce_items, dim3(R), dim3(64), 0, s, *tp, c, w.w_list, (const int*)nullptr, (int)MV_CNT_N_SAMPLER, 0);
+        hipError_t e = hipMemsetAsync(marks, 0, (size_t)R, s);
+        if (e != hipSuccess) return mv_check(e, "mvsdf_tracegen_reduce: memset");
+        hipLaunchKernelGGL(k_gen_sort_list, dim3(1), dim3(1024), 0, s, w.sec_list, counters, (int)MV_CNT_N_SECANT, marks, R);
+    } else {
+        hipLaunchKernelGGL(k_reduce_items, dim3(R), dim3(64), 0, s, *tp, c, w.w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
+    }
+    return mv_check(hipGetLastError(), "mvsdf_tracegen_reduce");
+}
+
+/* op 0: emit the n_sec secant points -> pts_out[n_sec][3]; op 1: consume vals[n_sec]; op 2: write the final dists / points */
+int mvsdf_tracegen_secant(const MvsdfTraceParams* tp, int op, const float* cam_loc, const float* ray_dirs, int B, int P, int n_sec, const float* vals,
+                          float* pts_out, float* points, float* dists, unsigned long long* counters, void* workspace, void* stream) {
+    int rc = tracegen_check(tp, B, P);
+    if (rc) return rc;
+    const int R = B * P;
+    if (!cam_loc || !ray_dirs || !workspace || n_sec <= 0 || n_sec > R || op < 0 || op > 2 || (op == 0 && !pts_out) || (op == 1 && !vals) ||
+        (op == 2 && (!points || !dists)))
+        return mv_fail(-1, "mvsdf_tracegen_secant: bad arguments");
+    GenWs w = mv_gen_ws(workspace, R, tp->n_steps);
+    hipLaunchKernelGGL(k_gen_secant, dim3((n_sec + 255) / 256), dim3(256), 0, (hipStream_t)stream, op, n_sec, R, P, w.sec_list, w.sec_state, cam_loc,
+                       ray_dirs, vals, pts_out, points, dists);
+    (void)counters;
+    return mv_check(hipGetLastError(), "mvsdf_tracegen_secant");
 }
 
 }  // extern "C"

@@ -6,6 +6,23 @@ import torch
 from . import ops
 
 
+class grad_sink:
+    """Context manager that lets _FoldNet.backward ADD the parameter gradients straight into the persistent flat `.grad` buffers (views
+    set up by optim.FlatAdam / parallel.FlatGradBucket) instead of returning them to autograd -- one launch instead of ~3 AccumulateGrad
+    launches per layer.  Opt-in because it bypasses autograd's bookkeeping: under it `torch.autograd.grad(loss, params)`,
+    `backward(inputs=...)` and parameter hooks would see no gradients.  FlatAdam.backward(loss) / FlatGradBucket.backward(loss) wrap
+    `loss.backward()` in it; a plain `loss.backward()` takes the ordinary autograd route (same numbers)."""
+    depth = 0
+
+    def __enter__(self):
+        grad_sink.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        grad_sink.depth -= 1
+        return False
+
+
 class _Fold(torch.autograd.Function):
     """weight_norm (idr.py:70-71): (weight_v, weight_g) -> folded W; MFMA packs ride along on `holder`."""
 
@@ -25,9 +42,10 @@ class _Fold(torch.autograd.Function):
 
 class _FoldNet(torch.autograd.Function):
     """weight_norm of a whole network in one C call (one fold launch + one pack launch): (*weight_v, *weight_g, *bias) -> (*W, *bias).
-    Biases pass through so that the backward sees every gradient of the network: when the parameters carry the `_mv_grad_sink`
-    mark (set by parallel.FlatGradBucket: their .grad buffers are persistent views of one flat buffer) the single backward launch
-    ADDS dv, dg and db straight into those buffers and returns no gradients -- the work of ~3 AccumulateGrad launches per layer."""
+    Biases pass through so that the backward sees every gradient of the network: inside a `grad_sink()` context, when the parameters
+    carry the `_mv_grad_sink` mark (set by optim.FlatAdam / parallel.FlatGradBucket: their .grad buffers are persistent views of one flat
+    buffer) the single backward launch ADDS dv, dg and db straight into those buffers and returns no gradients -- the work of ~3
+    AccumulateGrad launches per layer."""
 
     @staticmethod
     def forward(ctx, holders, *vgb):
@@ -47,7 +65,7 @@ class _FoldNet(torch.autograd.Function):
         dWs = [d.contiguous() if d is not None else torch.zeros_like(v) for d, v in zip(grads[:n], vs)]
         dbs = [d.contiguous() if d is not None else torch.zeros_like(b) for d, b in zip(grads[n:], bs)]
         vd, gd = [t.detach() for t in vs], [t.detach() for t in gs]
-        direct = all(getattr(p, '_mv_grad_sink', False) and p.grad is not None and p.grad.is_contiguous() and p.requires_grad for p in vgb)
+        direct = grad_sink.depth > 0 and all(getattr(p, '_mv_grad_sink', False) and p.grad is not None and p.grad.is_contiguous() and p.requires_grad for p in vgb)
         if direct:
             ops.fold_backward_net(vd, gd, dWs, dbs, sinks=([p.grad for p in vs], [p.grad for p in gs], [p.grad for p in bs]))
             return (None,) * (1 + 3 * n)

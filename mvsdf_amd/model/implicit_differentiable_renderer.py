@@ -3,7 +3,8 @@ and state_dict layout (reference code/model/implicit_differentiable_renderer.py:
 
 What differs from the reference internally (results are the same, see tests/):
   * weight_norm is folded once per forward by a HIP kernel (the reference refolds in each of ~57 network calls);
-  * the whole RayTracing.forward is two kernel launches (csrc/trace.hip);
+  * the whole RayTracing.forward is 7 kernel launches without a host synchronisation (csrc/trace.hip: k_sphere_trace, 3 x k_ray_samples,
+    3 x k_reduce_items);
   * the five autograd MLP passes of idr.py:202,256,275,325,326 over overlapping point sets are ONE fused
     value + normal evaluation on rows ordered [hit rays | sample points | non-hit rays]; the re-evaluation at the
     differentiable surface points (idr.py:325-326) re-uses it, and both backward passes run the hand-written

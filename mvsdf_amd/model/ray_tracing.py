@@ -1,5 +1,12 @@
-"""RayTracing with the reference's constructor and forward signature (reference code/model/ray_tracing.py:7-98),
-executed by the HIP tracer (csrc/trace.hip) in one C call: no per-iteration launches, no host syncs."""
+"""RayTracing with the reference's constructor and forward signature (reference code/model/ray_tracing.py:7-98), executed by the HIP tracer
+(csrc/trace.hip).
+
+Two routes, same per-ray state machine:
+  * `sdf` carries the folded network (`ImplicitNetwork.native_sdf()`, what IDRNetwork passes): the fused path -- 7 launches per call
+    (k_sphere_trace, 3 x k_ray_samples, 3 x k_reduce_items), MLP evaluated inside the kernels, no host synchronisation;
+  * `sdf` is any other callable [M,3] -> [M] (the reference's signature, ray_tracing.py:27-32): the generic path -- the kernels emit the
+    points to evaluate, the callable runs on the host side of the API between launches (one round trip per evaluation), the kernels
+    consume its values.  Slow by construction, bit-identical decisions."""
 import os
 
 import torch
@@ -53,9 +60,6 @@ class RayTracing(nn.Module):
         mask_ready: optional callable(network_object_mask) run once the mask is final, before the secant / min-sdf launch is enqueued
         (IDRNetwork uses it to fetch the hit count while that launch runs)."""
         net = getattr(sdf, 'native_net', None)
-        if net is None:
-            raise TypeError('the native tracer needs the SDF weights: pass ImplicitNetwork.native_sdf() (a callable carrying the '
-                            'folded MFMA-packed network) instead of an opaque Python callable')
         dev = ray_directions.device
         key = (self.n_steps, str(dev))
         if self._intervals is None or self._intervals[0] != key:               # constant per (n_steps, device): uploaded once
@@ -65,6 +69,14 @@ class RayTracing(nn.Module):
             minsdf_steps = self._draw((self.n_steps,), 0.0, 1.0, dev)           # CPU generator, pinned staging, async copy
         elif minsdf_steps is not None:
             minsdf_steps = minsdf_steps.to(dev, non_blocking=True)
+        if net is None:                                                       # opaque callable: emit / evaluate / consume rounds
+            with torch.no_grad():
+                pts, mask, dists, counters = ops.trace_generic(sdf, cam_loc, ray_directions, object_mask, self._params(), self.training,
+                                                               intervals, minsdf_steps)
+            self.last_counters = counters
+            if mask_ready is not None:
+                mask_ready(mask)
+            return pts, mask, dists
         R = ray_directions.shape[0] * ray_directions.shape[1]
         # rays per sphere-tracing workgroup = 8 * mt: one workgroup per CU (256 of them) while the batch allows it -- the kernel is a chain
         # of dependent evaluations, so fewer, fuller workgroups beat two contending ones per CU (4096 rays: 4.17 -> 3.97 ms per step with

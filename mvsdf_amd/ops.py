@@ -420,3 +420,76 @@ def loss_scale(gs, weights, unit_grads):
     w = [float(v) for v in weights]
     check(lib().mvsdf_loss_scale(_ptr_array(gs), w[0], w[1], w[2], w[3], w[4], *a, coef.data_ptr(), stream_of(coef).value), 'mvsdf_loss_scale')
     return outs, coef
+
+
+# ---- RayTracing.forward with an opaque Python `sdf` callable (csrc/trace.hip, k_gen_*)
+def trace_generic(sdf, cam_loc, ray_dirs, object_mask, params, training, intervals, minsdf_steps=None, chunk=100000):
+    """-> (points[R,3], mask[R] bool, dists[R], counters[16]).  Every decision of the tracer runs in HIP kernels; this loop only carries
+    the requested points to the callable and its values back (one host round trip per evaluation: the price of an opaque `sdf`).
+    Rows reach the callable in ray order, start side before end side, in chunks of at most `chunk` rows (ray_tracing.py:217,300)."""
+    cam_loc, ray_dirs = _f32(cam_loc), _f32(ray_dirs)
+    B, P = ray_dirs.shape[:2]
+    R, dev = B * P, ray_dirs.device
+    om = object_mask.reshape(-1).contiguous()
+    om = om.view(torch.uint8) if om.dtype == torch.bool else om.to(torch.uint8)
+    tp = TraceParams(*params)
+    n = tp.n_steps
+    L, st = lib(), stream_of(ray_dirs)
+    state = torch.empty(L.mvsdf_tracegen_state_bytes(R), dtype=torch.uint8, device=dev)
+    req = torch.empty(R, 2, dtype=torch.uint8, device=dev)
+    rpts = torch.empty(R, 2, 3, dtype=torch.float32, device=dev)
+    vals = torch.zeros(R, 2, dtype=torch.float32, device=dev)
+    counters = torch.empty(16, dtype=torch.int64, device=dev)
+    pts = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    mask = torch.empty(R, dtype=torch.uint8, device=dev)
+    dists = torch.empty(R, dtype=torch.float32, device=dev)
+    wsb = L.mvsdf_trace_workspace_bytes_n(R, n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    iv = _f32(intervals)
+    steps = _f32(minsdf_steps) if minsdf_steps is not None else None
+    geo = (ptr(cam_loc), ptr(ray_dirs))
+
+    def call(x):                                                  # the callable on [m,3] rows, chunked like the reference
+        out = [sdf(c).reshape(-1).to(torch.float32) for c in torch.split(x, chunk, dim=0)]
+        return (out[0] if len(out) == 1 else torch.cat(out)).contiguous()
+
+    check(L.mvsdf_tracegen_init(C.byref(tp), *geo, ptr(om), B, P, ptr(state), ptr(req), ptr(rpts), ptr(counters), st), 'mvsdf_tracegen_init')
+    flat_req, flat_pts, flat_vals = req.view(-1), rpts.view(-1, 3), vals.view(-1)
+    while True:
+        # rows in the reference's order: all requesting start sides (ray order), then all requesting end sides
+        idx_s = torch.nonzero(req[:, 0]).flatten()                # host sync: the callable needs a concrete shape anyway
+        idx_e = torch.nonzero(req[:, 1]).flatten()
+        if idx_s.numel() + idx_e.numel() == 0:
+            break
+        idx = torch.cat([idx_s * 2, idx_e * 2 + 1])
+        flat_vals[idx] = call(flat_pts[idx])
+        check(L.mvsdf_tracegen_step(C.byref(tp), *geo, B, P, ptr(state), ptr(vals), ptr(req), ptr(rpts), ptr(counters), st), 'mvsdf_tracegen_step')
+    check(L.mvsdf_tracegen_finish(C.byref(tp), *geo, B, P, 1 if training else 0, ptr(state), ptr(pts), ptr(mask), ptr(dists), ptr(counters),
+                                  ptr(ws), C.c_size_t(wsb), st), 'mvsdf_tracegen_finish')
+    cnt = counters.tolist()
+    n_s, n_m = cnt[5], cnt[6]                                     # MVSDF_CNT_N_SAMPLER, MVSDF_CNT_N_MINSDF
+    marks = torch.empty(R, dtype=torch.uint8, device=dev)
+    if n_s > 0:                                                   # ray_sampler, ray_tracing.py:198-239
+        rows = torch.empty(n_s * n, 3, dtype=torch.float32, device=dev)
+        check(L.mvsdf_tracegen_rows(C.byref(tp), 0, *geo, B, P, ptr(iv), n_s, ptr(ws), ptr(rows), st), 'mvsdf_tracegen_rows')
+        sv = call(rows)
+        check(L.mvsdf_tracegen_reduce(C.byref(tp), 0, *geo, B, P, 1 if training else 0, ptr(iv), ptr(steps), ptr(sv), ptr(pts), ptr(mask),
+                                      ptr(dists), ptr(counters), ptr(ws), ptr(marks), st), 'mvsdf_tracegen_reduce')
+        n_sec = int(counters[4])                                  # MVSDF_CNT_N_SECANT
+        if n_sec > 0:                                             # secant, ray_tracing.py:241-256
+            sp = torch.empty(n_sec, 3, dtype=torch.float32, device=dev)
+            sec = lambda op, v=None: check(L.mvsdf_tracegen_secant(C.byref(tp), op, *geo, B, P, n_sec, ptr(v), ptr(sp), ptr(pts), ptr(dists),
+                                                                   ptr(counters), ptr(ws), st), 'mvsdf_tracegen_secant')
+            for _ in range(tp.n_secant):
+                sec(0)
+                sec(1, call(sp))
+            sec(2)
+            counters[2] += n_sec * tp.n_secant                    # MVSDF_CNT_ROWS_SECANT
+    if training and n_m > 0:                                      # minimal_sdf_points, ray_tracing.py:280-308
+        assert steps is not None, 'training needs minsdf_steps'
+        rows = torch.empty(n_m * n, 3, dtype=torch.float32, device=dev)
+        check(L.mvsdf_tracegen_rows(C.byref(tp), 1, *geo, B, P, ptr(steps), n_m, ptr(ws), ptr(rows), st), 'mvsdf_tracegen_rows')
+        sv = call(rows)
+        check(L.mvsdf_tracegen_reduce(C.byref(tp), 1, *geo, B, P, 1, ptr(iv), ptr(steps), ptr(sv), ptr(pts), ptr(mask), ptr(dists), ptr(counters),
+                                      ptr(ws), None, st), 'mvsdf_tracegen_reduce')
+    return pts, mask.view(torch.bool), dists, counters

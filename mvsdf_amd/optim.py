@@ -13,7 +13,7 @@ import ctypes as C
 import torch
 
 from ._lib import lib, check
-from .parallel import all_reduce_mean_
+from .parallel import all_reduce_sum_
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -32,6 +32,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._ws = torch.empty(lib().mvsdf_adam_ws_floats(), dtype=torch.float32, device=p0.device)
         self.norm_and_coef = torch.zeros(2, dtype=torch.float32, device=p0.device)     # {||grad||, clip coefficient} of the last step
         self._t = 0
+        self._grad_scale = 1.0                                                         # 1 / world between all_reduce_mean() and step()
         self._slices = []
         off = 0
         for p in ps:
@@ -61,20 +62,48 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat_g.zero_()
         self._attach_grads()
 
+    def backward(self, loss):
+        """loss.backward() with the direct gradient sink on (functional.grad_sink): the weight_norm-fold backward adds dv / dg / db of
+        both networks into the flat gradient buffer in ONE launch instead of handing ~40 tensors to autograd's AccumulateGrad."""
+        from .functional import grad_sink
+        with grad_sink():
+            loss.backward()
+
+    def _sync_grads(self):
+        """Every p.grad must still be its view of flat_g when the flat kernels read it.  `model.zero_grad()` (set_to_none=True by default)
+        or `p.grad = None` detach them: autograd then allocates fresh .grad tensors.  Copy such strays in and re-attach.  A parameter
+        WITHOUT a gradient counts as a zero gradient, i.e. it still moves by its momentum -- what the reference's pinned torch 1.7.1
+        does (its zero_grad() zero-fills, idr_train.py:283), whereas torch >= 2.0's Adam would skip a None gradient."""
+        base = self.flat_g.data_ptr()
+        for p, (off, n) in zip(self.param_groups[0]['params'], self._slices):
+            if p.grad is None:
+                self.flat_g[off:off + n].zero_()
+            elif p.grad.data_ptr() != base + 4 * off:
+                self.flat_g[off:off + n].copy_(p.grad.detach().reshape(-1))
+            else:
+                continue
+            p.grad = self.flat_g[off:off + n].view(p.shape)
+
     def all_reduce_mean(self):
-        """The step's one collective (RCCL over xGMI): gradients averaged over ranks.  No-op without a process group."""
-        all_reduce_mean_(self.flat_g)
+        """The step's one gradient collective (RCCL over xGMI): SUM all-reduce of the flat gradient buffer; the 1 / world that makes it
+        the rank average is applied inside step()'s Adam launch (no separate pass over the buffer).  No-op without a process group.
+        Until step() runs, flat_g holds the SUM."""
+        self._sync_grads()
+        self._grad_scale = all_reduce_sum_(self.flat_g)
 
     @torch.no_grad()
     def step(self, closure=None, grad_cap=None):
         """grad-norm + optional clip_grad_norm_(grad_cap) + Adam in two launches.  `norm_and_coef` holds the norm afterwards."""
         assert closure is None
         g = self.param_groups[0]
+        self._sync_grads()
         self._t += 1
-        check(lib().mvsdf_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
-                                    self.flat_p.numel(), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
-                                    self._t, float(grad_cap) if grad_cap else 0.0, self.norm_and_coef.data_ptr(), self._ws.data_ptr(),
-                                    C.c_void_p(torch.cuda.current_stream(self.flat_p.device).cuda_stream)), 'mvsdf_adam_step')
+        check(lib().mvsdf_adam_step_scaled(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                                           self.flat_p.numel(), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+                                           self._t, float(grad_cap) if grad_cap else 0.0, float(self._grad_scale),
+                                           self.norm_and_coef.data_ptr(), self._ws.data_ptr(),
+                                           C.c_void_p(torch.cuda.current_stream(self.flat_p.device).cuda_stream)), 'mvsdf_adam_step_scaled')
+        self._grad_scale = 1.0
 
     def grad_norm(self):
         return self.norm_and_coef[0]

@@ -10,12 +10,25 @@ import torch
 import torch.distributed as dist
 
 
-def all_reduce_mean_(flat):
-    """The step's one collective: SUM all-reduce of a flat gradient buffer + division by the world size (RCCL over xGMI with the
-    `nccl` backend; gloo in the CPU tests).  No-op without an initialised process group.  Shared by FlatGradBucket and optim.FlatAdam."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def all_reduce_sum_(flat):
+    """The step's one gradient collective: SUM all-reduce of a flat gradient buffer (RCCL over xGMI with the `nccl` backend; gloo in the
+    CPU tests).  No-op without an initialised process group.  -> the factor that turns the sum into the rank average (1 / world): the
+    caller folds it into its next pass over the buffer (optim.FlatAdam: inside the Adam launch) instead of a separate division."""
+    w = world_size()
+    if w > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(dist.get_world_size())
+    return 1.0 / w
+
+
+def all_reduce_mean_(flat):
+    """SUM all-reduce + division by the world size (for callers without a later pass to fold the factor into)."""
+    scale = all_reduce_sum_(flat)
+    if scale != 1.0:
+        flat.mul_(scale)
     return flat
 
 
@@ -41,8 +54,30 @@ class FlatGradBucket:
                 p.grad = self.flat[off:off + n].view_as(p)
             off += n
 
+    def backward(self, loss):
+        """loss.backward() with the direct gradient sink on (functional.grad_sink): gradients are added into the bucket by one launch."""
+        from .functional import grad_sink
+        with grad_sink():
+            loss.backward()
+
+    def sync_grads(self):
+        """Make the bucket hold every parameter's gradient again after something detached `.grad` from it (model.zero_grad(), whose
+        default set_to_none=True makes autograd allocate fresh tensors; `p.grad = None`): copy the stray gradient in (zeros for a
+        parameter without one) and re-attach the view."""
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+                p.grad = self.flat[off:off + n].view_as(p)
+            elif p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+                p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
     def all_reduce_mean(self):
         """One collective for all gradients; no-op without an initialised process group."""
+        self.sync_grads()
         all_reduce_mean_(self.flat)
 
     def grad_norm(self):

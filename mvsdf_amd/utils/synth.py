@@ -198,3 +198,34 @@ def make_batch(B, P, V, seed=0, img_wh=(800, 600), focal_scale=2.2, radius=2.5, 
         gt['feat'] = np.ascontiguousarray(f[:, 0])
         gt['feat_src'] = np.ascontiguousarray(f[:, 1:])
     return inp, gt
+
+
+def make_depth_maps(depth_cams, size, center, seed=0, radius=0.6, hole_frac=0.15, bump=0.04, view_bias=0.03):
+    """Non-trivial MVS depth maps [B,1,1,h,w] for the depth term / phase-0 sampling fixtures: camera-z depth of a bumpy sphere of
+    normalised radius `radius` seen by each depth camera (`depth_cams` [B,1,2,4,4], intrinsics at depth-map resolution, pixel centres
+    at +0.5 like my_utils.get_pixel_grids), 0 where the ray misses it, plus random holes (0), one depth step per view and a per-view
+    scale error so that the views disagree about inside / outside near the surface (exercises carving_t2's voting)."""
+    rs = np.random.RandomState(seed + 4000)
+    cams = np.asarray(depth_cams, np.float64)[:, 0]
+    B = cams.shape[0]
+    h, w = int(round(2 * cams[0, 1, 1, 2])), int(round(2 * cams[0, 1, 0, 2]))
+    xs, ys = np.meshgrid(np.arange(w) + 0.5, np.arange(h) + 0.5)
+    out = np.zeros((B, 1, 1, h, w), np.float32)
+    rw = radius * size / 2.0
+    for b in range(B):
+        E, K = cams[b, 0], cams[b, 1, :3, :3]
+        Rm, t = E[:3, :3], E[:3, 3]
+        o = -Rm.T @ t - np.asarray(center, np.float64)                      # camera centre relative to the sphere centre (world)
+        d = np.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], np.ones_like(xs)], -1) @ Rm   # world dirs with camera z = 1
+        a = (d * d).sum(-1)
+        bq = 2 * (d @ o)
+        c = (o * o).sum() - rw * rw
+        disc = bq * bq - 4 * a * c
+        hit = disc > 0
+        tz = np.where(hit, (-bq - np.sqrt(np.where(hit, disc, 0.0))) / (2 * a), 0.0)
+        tz = tz * (1.0 + bump * np.sin(xs * 0.7 + b) * np.cos(ys * 0.5 - b)) * (1.0 + view_bias * (rs.uniform() - 0.5) * 2)
+        y0, x0 = rs.randint(0, h // 2), rs.randint(0, w // 2)
+        tz[y0:y0 + h // 4, x0:x0 + w // 4] += 0.12 * size / 2.0              # a depth step
+        tz[rs.uniform(size=tz.shape) < hole_frac] = 0.0                       # holes
+        out[b, 0, 0] = np.where(hit, tz, 0.0)
+    return out

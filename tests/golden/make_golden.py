@@ -209,7 +209,7 @@ def g_sample_network(seed):
 SCENE = dict(size=2.6, center=(0.1, -0.2, 0.3), feat_hw=(60, 80), focal_scale=1.4)
 
 
-def g_idr(W, B, P, V, seed, tp):
+def g_idr(W, B, P, V, seed, tp, name=None):
     m, sd = build_model(W, seed)
     inp, gt = synth.make_batch(B, P, V, seed=seed, **SCENE)
     m.train()
@@ -241,17 +241,18 @@ def g_idr(W, B, P, V, seed, tp):
         res['gidx_' + k] = idx
         res['gval_' + k] = g.reshape(-1)[idx]
     # the eikonal points drawn inside forward (torch CPU generator), for implementations that take them as input
-    save('idr_w%d_tp%s' % (W, str(tp).replace('.', '')), W=W, B=B, P=P, V=V, seed=seed, tp=tp,
+    save(name or 'idr_w%d_tp%s' % (W, str(tp).replace('.', '')), W=W, B=B, P=P, V=V, seed=seed, tp=tp,
          scene_size=SCENE['size'], scene_center=np.array(SCENE['center']), feat_hw=np.array(SCENE['feat_hw']),
          focal_scale=SCENE['focal_scale'], checksum=synth.state_checksum(sd), **res)
 
 
-def g_feat(seed):
-    """get_feat_loss_corr alone on fixed points + d loss / d points."""
-    B, P, V = 2, 300, 3
+def g_feat(seed, B=2, P=300, V=3, name='feat_corr'):
+    """get_feat_loss_corr alone on fixed points + d loss / d points (V = 3 / 4 / 8 source views)."""
     inp, gt = synth.make_batch(B, P, V, seed=seed, **SCENE)
     rs = np.random.RandomState(seed + 9)
     hits = rs.uniform(size=(B * P,)) < 0.7
+    if B > 2:
+        hits[P:2 * P] = False                                   # one view without any hit (loss.py:117-118 path)
     n = int(hits.sum())
     d = rs.normal(size=(n, 3))
     pts = (0.6 * d / np.linalg.norm(d, axis=1, keepdims=True) + 0.03 * rs.normal(size=(n, 3))).astype(np.float32)
@@ -261,9 +262,77 @@ def g_feat(seed):
         loss = IDRLoss().get_feat_loss_corr(p, None, gtt['feat'], gtt['cam'], gtt['feat_src'], gtt['src_cams'],
                                             gtt['size'][:1], gtt['center'][:1], T(hits), T(np.ones_like(hits)))
     loss.backward()
-    save('feat_corr', seed=seed, B=B, P=P, V=V, hits=hits, points=pts, loss=loss.item(), dpoints=p.grad.numpy(),
+    save(name, seed=seed, B=B, P=P, V=V, hits=hits, points=pts, loss=loss.item(), dpoints=p.grad.numpy(),
          scene_size=SCENE['size'], scene_center=np.array(SCENE['center']), feat_hw=np.array(SCENE['feat_hw']),
          focal_scale=SCENE['focal_scale'])
+
+
+def g_carve(seed):
+    """carving_t2 (my_utils.py:269-331) + get_depth_loss (loss.py:37-63) on bumpy depth maps with holes, a depth step and per-view scale
+    errors: points inside / outside the surface, near it (views disagree: out_thresh_perc voting) and outside every frustum."""
+    from utils.my_utils import carving_t2
+    B, hw, M = 5, (48, 64), 4000
+    inp, _ = synth.make_batch(B, 8, 1, seed=seed, size=SCENE['size'], center=SCENE['center'], feat_hw=hw, focal_scale=1.4, with_features=False)
+    depths = synth.make_depth_maps(inp['depth_cams'], SCENE['size'], SCENE['center'], seed=seed)
+    rs = np.random.RandomState(seed + 41)
+    pts = rs.uniform(-1.3, 1.3, size=(M, 3))
+    d = rs.normal(size=(M // 2, 3))
+    pts[: M // 2] = d / np.linalg.norm(d, axis=1, keepdims=True) * (0.6 + 0.05 * rs.normal(size=(M // 2, 1)))    # half of them around the surface
+    pts[-200:] *= 4.0                                                                                             # far outside every frustum
+    pts = pts.astype(np.float32)
+    eik_out = (0.3 * rs.normal(size=(1, M))).astype(np.float32)
+    size, center = T(inp['size'])[:1], T(inp['center'])[:1]
+    hom = torch.cat([T(pts), torch.ones(M, 1)], -1).view(1, M, 4, 1)
+    world = hom.clone()
+    world[:, :, :3, 0] = world[:, :, :3, 0] / 2 * size.view(1, 1, 1) + center.view(1, 1, 3)
+    dp, cp = T(depths).permute(1, 0, 2, 3, 4), T(inp['depth_cams']).permute(1, 0, 2, 3, 4)
+    dist, occ, in_range = carving_t2(world, dp, cp, out_thresh_perc=1 / 8)
+    res = dict(seed=seed, depths=depths, depth_cams=inp['depth_cams'], size=inp['size'], center=inp['center'], points=pts, eik_out=eik_out,
+               dist=dist.numpy()[0], occ=occ.numpy()[0], in_range=in_range.numpy()[0])
+    for tag, (fa, na) in dict(a=(1.0, 1.0), b=(1.0, 0.1), c=(0.5, 0.01)).items():
+        loss = IDRLoss().get_depth_loss(hom.clone(), T(eik_out), T(depths), T(inp['depth_cams']), size, center, 0.25, fa, 0.1, na, None)
+        res['loss_' + tag] = loss.item()
+        res['att_' + tag] = np.array([fa, na])
+    save('carve', **res)
+
+
+def g_idr_phase0(W, B, P, V, seed, tp):
+    """Phase 0 (tp < 1/6): depth-surface sampling on (idr.py:226-247), every point group in the depth and eikonal terms, rgb gradient
+    through the features only (idr.py:331-334).  The dsurf samples the reference drew (np.random.choice / rand_like) are stored: the
+    build's own sampler uses another RNG, so its test injects these points."""
+    m, sd = build_model(W, seed)
+    inp, gt = synth.make_batch(B, P, V, seed=seed, **SCENE)
+    inp['depths'] = gt['depths'] = synth.make_depth_maps(inp['depth_cams'], SCENE['size'], SCENE['center'], seed=seed, hole_frac=0.05)
+    m.train()
+    torch.manual_seed(seed + 5)
+    np.random.seed(seed + 6)
+    mi = {k: T(v) for k, v in inp.items()}
+    with quiet():
+        out = m(mi, tp)
+    res = {('out_' + k): v.detach().numpy().copy() for k, v in out.items()}     # copies: the loss rescales eikonal_points_hom in place
+    N = int((out['network_object_mask'] & out['object_mask']).sum())
+    R = B * P
+    hom = res['out_eikonal_points_hom'][0, :, :3, 0]
+    res['dsurf_on'] = hom[N + R // 2: N + R].copy()
+    res['dsurf_jitter'] = hom[N + R:].copy()
+    assert res['dsurf_jitter'].shape[0] == R // 2
+    loss_fn = IDRLoss()
+    gtt = {k: T(v) for k, v in gt.items()}
+    with quiet():
+        lo = loss_fn(out, gtt, tp, B)
+    for k, v in lo.items():
+        res['loss_' + k] = (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v, np.float32)).reshape(-1)[0]
+    m.zero_grad()
+    lo['loss'].backward()
+    rs = np.random.RandomState(1)
+    for k, p in m.named_parameters():
+        g = p.grad.detach().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        res['gnorm_' + k] = np.linalg.norm(g.astype(np.float64))
+        idx = rs.randint(0, g.size, size=8)
+        res['gidx_' + k] = idx
+        res['gval_' + k] = g.reshape(-1)[idx]
+    save('idr_w%d_phase0' % W, W=W, B=B, P=P, V=V, seed=seed, tp=tp, scene_size=SCENE['size'], scene_center=np.array(SCENE['center']),
+         feat_hw=np.array(SCENE['feat_hw']), focal_scale=SCENE['focal_scale'], checksum=synth.state_checksum(sd), **res)
 
 
 def g_sdf_bwd(W, n, seed):
@@ -367,7 +436,14 @@ def g_dsurf(seed):
 
 if __name__ == '__main__':
     if len(sys.argv) > 1:                                                       # python make_golden.py g_dsurf 0  (one fixture)
-        globals()[sys.argv[1]](*[(float(v) if '.' in v or 'e' in v else int(v)) for v in sys.argv[2:]])
+        def _arg(v):
+            for conv in (int, float):
+                try:
+                    return conv(v)
+                except ValueError:
+                    pass
+            return v
+        globals()[sys.argv[1]](*[_arg(v) for v in sys.argv[2:]])
         sys.exit(0)
     g_dsurf(0)
     g_train_default = lambda: g_train(64, 2, 256, 3, 0, 0.3, 4, 1e-3)
@@ -386,3 +462,8 @@ if __name__ == '__main__':
     g_idr(64, 2, 256, 3, 0, 0.3)
     g_idr(64, 2, 256, 3, 0, 0.6)
     g_idr(256, 2, 128, 2, 0, 0.3)
+    g_feat(0, 8, 200, 4, 'feat_corr_v4')
+    g_feat(0, 8, 160, 8, 'feat_corr_v8')
+    g_carve(0)
+    g_idr_phase0(64, 3, 128, 2, 0, 0.1)
+    g_idr(256, 8, 256, 4, 0, 0.3, 'idr_c2')

@@ -25,3 +25,15 @@ def trace_params(W=64, **over):
 
 def t(a, dev='cuda'):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def analytic_sdf(x):
+    """The tier-0 SDF of tests/golden/make_golden.py::analytic_sdf (built from +, -, * only: every torch elementwise op is one correctly
+    rounded IEEE operation on CPU and GPU alike, so the GPU evaluation is bit-identical to the one the goldens were made with)."""
+    X, Y, Z = x[:, 0], x[:, 1], x[:, 2]
+    x2, y2, z2 = X * X, Y * Y, Z * Z
+    r2 = x2 + y2 + z2
+    t5 = ((16.0 * x2 - 20.0) * x2 + 5.0) * X
+    t4 = (8.0 * y2 - 8.0) * y2 + 1.0
+    t3 = (4.0 * z2 - 3.0) * Z
+    return 1.4 * (r2 - 0.36) + 0.2 * (t5 * t4 * t3)

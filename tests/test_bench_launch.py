@@ -1,0 +1,45 @@
+"""`python bench.py --gpus N` must be runnable by the driver as is: with N > 1 and no launcher environment the parent process starts the
+N ranks itself (torch.distributed.run on 127.0.0.1), relays rank 0's one JSON line and returns the children's exit code.  On this CPU box
+the ranks run in MVSDF_BENCH_DRYRUN mode (gloo rendezvous + one collective, no device work); tests/test_gpu_dp.py and the gpu-marked
+test below cover the real step."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _run(args, env_extra, timeout=600):
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None), env.pop('RANK', None), env.pop('LOCAL_RANK', None)
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    return p.returncode, lines, p.stderr.decode()[-3000:]
+
+
+def test_self_launch_two_ranks_dry_run():
+    rc, lines, err = _run(['--gpus', '2', '--steps', '2', '--warmup', '1'], {'MVSDF_BENCH_DRYRUN': '1'})
+    assert rc == 0, err
+    assert len(lines) == 1, (lines, err)
+    d = json.loads(lines[0])
+    assert d == {'dry_run': True, 'n_gpus': 2, 'sum_of_ranks_plus_1': 3.0, 'views_per_rank': 4, 'px_per_view': 512}
+
+
+def test_self_launch_propagates_failure():
+    rc, lines, err = _run(['--gpus', '3'], {'MVSDF_BENCH_DRYRUN': '0', 'CUDA_VISIBLE_DEVICES': ''})   # 3 does not divide 8 views / no GPU: children fail
+    assert rc != 0 and not lines
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_gloo_full_step():
+    """The real data-parallel step through the self-launcher: two ranks sharing the one GPU of the test box (gloo transport), B = 8 views x
+    512 px sharded 4 + 4; the line reports n_gpus = 2 and 2 x 2048 rays per step."""
+    rc, lines, err = _run(['--gpus', '2', '--steps', '3', '--warmup', '2', '--no-cpu-baseline'], {'MVSDF_DIST_BACKEND': 'gloo'})
+    assert rc == 0, err
+    d = json.loads(lines[-1])
+    assert d['n_gpus'] == 2 and d['config']['rays_per_gpu'] == 2048 and d['config']['rays_total'] == 4096
+    assert d['value'] > 0 and d['roofline']['frac'] > 0 and d['scaling'] == 'weak'

@@ -55,10 +55,11 @@ def run_step(rank, world):
     opt.zero_grad()
     out = m(inp, TP)
     lo = IDRLoss()(out, gt, TP, B // world)
-    lo['loss'].backward()
-    opt.all_reduce_mean()
+    opt.backward(lo['loss'])                                                      # loss.backward() with the direct gradient sink
+    opt.all_reduce_mean()                                                         # SUM over ranks ...
+    opt.step()                                                                    # ... / world inside the Adam launch (lr = 0: parameters stay)
     torch.cuda.synchronize()
-    return opt.flat_g.detach().cpu().clone(), {k: float(v) for k, v in lo.items()}
+    return opt.flat_g.detach().cpu().clone(), {k: float(v.detach()) for k, v in lo.items()}
 
 
 def test_two_ranks_reproduce_the_single_process_gradient():

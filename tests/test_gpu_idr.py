@@ -26,14 +26,28 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
 
 
-@pytest.mark.parametrize('name', ['idr_w64_tp03', 'idr_w64_tp06', 'idr_w256_tp03'])
+def _dsurf_override(model, g):
+    """Phase 0 draws its depth-surface samples with np.random.choice / rand_like in the reference (idr.py:239,244): feed the model the very
+    points the reference drew (stored in the fixture) instead of the build's own device-side sampler."""
+    on, jit = t(g['dsurf_on']), t(g['dsurf_jitter'])
+    n = on.shape[0]
+    model._dsurf_samples = lambda input, n_dsurf_points, bb: (on, jit, torch.full((2,), n, dtype=torch.int64, device='cuda'))
+
+
+@pytest.mark.parametrize('name', ['idr_w64_tp03', 'idr_w64_tp06', 'idr_w256_tp03', 'idr_c2', 'idr_w64_phase0'])
 def test_forward_loss_backward_vs_reference(name):
+    """idr_c2 = the bench shape (8 views x 256 px, V = 4, 8x256 networks); idr_w64_phase0 = train_progress < 1/6: depth-surface groups
+    in the depth / eikonal terms, rgb gradient through the features only (idr.py:331-334), no feature / surface loss."""
     g = golden(name)
     W, B, P, V, seed, tp = int(g['W']), int(g['B']), int(g['P']), int(g['V']), int(g['seed']), float(g['tp'])
     model, sd = build(W, seed)
     np.testing.assert_allclose(synth.state_checksum(sd), g['checksum'], rtol=0, atol=0)
     inp, gt = synth.make_batch(B, P, V, seed=seed, size=float(g['scene_size']), center=tuple(g['scene_center']),
                                feat_hw=tuple(int(v) for v in g['feat_hw']), focal_scale=float(g['focal_scale']))
+    if 'dsurf_on' in g.files:
+        inp['depths'] = gt['depths'] = synth.make_depth_maps(inp['depth_cams'], float(g['scene_size']), tuple(g['scene_center']), seed=seed,
+                                                             hole_frac=0.05)
+        _dsurf_override(model, g)
     model.train()
     torch.manual_seed(seed + 5)
     out = model({k: t(v) for k, v in inp.items()}, tp)
@@ -46,13 +60,19 @@ def test_forward_loss_backward_vs_reference(name):
     hit = mask
     p, pg = out['points'].detach().cpu().numpy(), g['out_points']
     assert np.abs(p[hit] - pg[hit]).max() < 1e-4 * 3                            # depths 1e-4 rel (|t| <= ~3)
-    assert _rel(out['diff_surf_pts'], g['out_diff_surf_pts']) < 1e-4
-    assert np.abs(out['rgb_values'].detach().cpu().numpy() - g['out_rgb_values']).max() < 2e-4
+    # north_star: intersection depths within 1e-4 rel; every camera sits >= 1.6 from the unit sphere, so 1e-4 * depth >= 1.6e-4 abs
+    dsp_err = np.abs(out['diff_surf_pts'].detach().cpu().numpy() - g['out_diff_surf_pts']).max()
+    print('%s: max |diff_surf_pts - reference| = %.3g' % (name, dsp_err))
+    assert dsp_err < 1.6e-4
+    rgb_err = np.abs(out['rgb_values'].detach().cpu().numpy() - g['out_rgb_values']).max()
+    print('%s: max |rgb - reference| = %.3g' % (name, rgb_err))
+    assert rgb_err < 1e-4                                                         # north_star: rendered RGB within 1e-4 (values in [-1, 1])
     N = int(hit.sum())
     gth, gth_g = out['grad_theta'].detach().cpu().numpy(), g['out_grad_theta']
     assert np.abs(gth - gth_g).max() < 2e-3 * max(1.0, np.abs(gth_g).max())      # surface rows move with the 1e-5 depth noise
     assert np.abs(gth[N:] - gth_g[N:]).max() < 1e-4 * max(1.0, np.abs(gth_g).max())   # eikonal samples: identical points
-    assert np.abs(out['sdf_output'].detach().cpu().numpy()[hit] - g['out_sdf_output'][hit]).max() < 2e-5
+    # |d sdf| = |grad f| * |d depth| with |grad f| ~ 1: the depth tolerance (1e-4 rel of depths <= 3.5, measured <= 1e-4 abs) carries over
+    assert np.abs(out['sdf_output'].detach().cpu().numpy()[hit] - g['out_sdf_output'][hit]).max() < 1e-4
     assert np.abs(out['eikonal_output'].detach().cpu().numpy() - g['out_eikonal_output']).max() < 5e-5
 
     gtt = {k: t(v) for k, v in gt.items()}
@@ -61,7 +81,12 @@ def test_forward_loss_backward_vs_reference(name):
         v, ref = float(lo[k].reshape(-1)[0]), float(g['loss_' + k])
         assert abs(v - ref) <= 2e-4 * max(1.0, abs(ref)), (k, v, ref)
     # the reference rescales eikonal_points_hom to world coordinates IN PLACE inside the loss (loss.py:38,42); the golden holds that
-    assert _rel(out['eikonal_points_hom'], g['out_eikonal_points_hom']) < 1e-4
+    if 'dsurf_on' in g.files:                                                     # this fixture stores the pre-loss (normalised) points
+        hom = out['eikonal_points_hom'].detach().cpu().numpy()[0, :, :3, 0]
+        world = g['out_eikonal_points_hom'][0, :, :3, 0] / 2 * float(g['scene_size']) + g['scene_center']
+        assert np.abs(hom - world).max() < 1e-4 * 3
+    else:
+        assert _rel(out['eikonal_points_hom'], g['out_eikonal_points_hom']) < 1e-4
     model.zero_grad()
     lo['loss'].backward()
     worst = 0.0
@@ -106,12 +131,16 @@ def test_grad_bucket_direct_sink_matches_autograd_accumulation():
                                feat_hw=tuple(int(v) for v in g['feat_hw']), focal_scale=float(g['focal_scale']))
     inp, gt = {k: t(v) for k, v in inp.items()}, {k: t(v) for k, v in gt.items()}
 
-    def run(model, times):
+    def run(model, times, bucket=None):
         for _ in range(times):
             torch.manual_seed(seed + 5)
             np.random.seed(seed + 5)
             out = model(inp, tp)
-            IDRLoss()(out, dict(gt), tp, B)['loss'].backward()
+            loss = IDRLoss()(out, dict(gt), tp, B)['loss']
+            if bucket is not None:
+                bucket.backward(loss)                                 # grad_sink(): dv / dg / db added into the bucket by one launch
+            else:
+                loss.backward()
         return [p.grad.detach().clone() for p in model.parameters()]
 
     plain, _ = build(W, seed)
@@ -120,15 +149,22 @@ def test_grad_bucket_direct_sink_matches_autograd_accumulation():
     sink, _ = build(W, seed)
     sink.train()
     bucket = FlatGradBucket(sink.parameters())
-    got1 = run(sink, 1)
+    got1 = run(sink, 1, bucket)
     for a, b, (k, _) in zip(got1, ref1, plain.named_parameters()):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7 * float(b.abs().max()) + 1e-12), k
     assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in sink.parameters())        # still views of the bucket
-    got2 = run(sink, 1)                                                                         # no zeroing: accumulates
+    got2 = run(sink, 1, bucket)                                                                     # no zeroing: accumulates
     for a, b, (k, _) in zip(got2, ref1, plain.named_parameters()):
         assert torch.allclose(a, 2 * b, rtol=1e-4, atol=1e-6 * float(b.abs().max()) + 1e-12), k
     bucket.zero()
     assert float(bucket.flat.abs().max()) == 0.0
+    # outside the grad_sink() context the same parameters behave like any others: autograd.grad returns the gradients and leaves .grad alone
+    torch.manual_seed(seed + 5)
+    loss = IDRLoss()(sink(inp, tp), dict(gt), tp, B)['loss']
+    grads = torch.autograd.grad(loss, list(sink.parameters()))
+    assert float(bucket.flat.abs().max()) == 0.0
+    for a, b, (k, _) in zip(grads, ref1, plain.named_parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7 * float(b.abs().max()) + 1e-12), k
 
 
 def test_four_training_steps_follow_the_reference_loop():

@@ -67,3 +67,47 @@ def test_flat_adam_checkpoint_layout_round_trip():
     mine2.load_state_dict(ref.state_dict())
     base = o_mine2.flat_p.data_ptr()
     assert all(base <= p.data_ptr() < base + 4 * o_mine2.flat_p.numel() for p in mine2.parameters())
+
+
+def test_detached_grads_are_picked_up_again():
+    """model.zero_grad() (set_to_none=True by default) detaches every .grad from the flat buffer: autograd then allocates fresh tensors.
+    FlatAdam.step() copies them in and re-attaches instead of applying stale values; a parameter left without a gradient is treated as
+    a zero gradient (torch 1.7.1's zero_grad semantics, the reference's pinned version)."""
+    ref, mine = _models()
+    o_ref = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    o_mine = FlatAdam(mine.parameters(), lr=1e-3)
+    x = torch.randn(128, 37, device='cuda')
+    for it in range(4):
+        ref.zero_grad(set_to_none=False)
+        mine.zero_grad()                                            # nn.Module.zero_grad: p.grad = None
+        assert all(p.grad is None for p in mine.parameters())
+        for m in (ref, mine):
+            (m(x) ** 2).mean().backward()
+        if it == 2:                                                 # one parameter without a gradient this step
+            list(mine.parameters())[-1].grad = None
+            list(ref.parameters())[-1].grad.zero_()
+        o_ref.step()
+        o_mine.step()
+        base = o_mine.flat_g.data_ptr()
+        assert all(base <= p.grad.data_ptr() < base + 4 * o_mine.flat_g.numel() for p in mine.parameters())
+        for p, q in zip(ref.parameters(), mine.parameters()):
+            assert torch.allclose(p, q, rtol=0, atol=2e-6), it
+
+
+def test_grad_scale_is_the_division_by_world():
+    """mvsdf_adam_step_scaled(grad_scale = 1/4) == dividing the gradient by 4 first (norm, clip and update)."""
+    ref, mine = _models()
+    o_ref = FlatAdam(ref.parameters(), lr=1e-3)
+    o_mine = FlatAdam(mine.parameters(), lr=1e-3)
+    x = torch.randn(128, 37, device='cuda')
+    for it in range(3):
+        for m, o in ((ref, o_ref), (mine, o_mine)):
+            o.zero_grad()
+            (m(x) ** 2).mean().backward()
+        o_ref.flat_g.div_(4.0)
+        o_mine._grad_scale = 0.25
+        o_ref.step(grad_cap=0.01)
+        o_mine.step(grad_cap=0.01)
+        assert o_mine._grad_scale == 1.0
+        assert torch.equal(o_ref.norm_and_coef, o_mine.norm_and_coef)
+        assert torch.equal(o_ref.flat_p, o_mine.flat_p) and torch.equal(o_ref.flat_g, o_mine.flat_g)

@@ -98,3 +98,34 @@ def test_dsurf_unprojection_vs_reference_golden():
     assert np.abs(pts[valid] - ref[valid]).max() < 2e-5 * max(1.0, np.abs(ref[valid]).max())
     inb = (np.abs(pts) < float(g['bb'])).all(-1) & valid
     assert (inb != g['inbound']).sum() <= 2                                     # only points within fp32 rounding of the box face may differ
+
+
+@pytest.mark.parametrize('name', ['feat_corr_v4', 'feat_corr_v8'])
+def test_feat_corr_more_source_views(name):
+    """V = 4 (the bench configuration) and V = 8 (c3 / c5), B = 8 views of which one has no hit at all."""
+    g = golden(name)
+    B, P, V = int(g['B']), int(g['P']), int(g['V'])
+    _, gt = synth.make_batch(B, P, V, seed=int(g['seed']), size=float(g['scene_size']), center=tuple(g['scene_center']),
+                             feat_hw=tuple(int(v) for v in g['feat_hw']), focal_scale=float(g['focal_scale']))
+    counts = g['hits'].reshape(B, P).sum(1)
+    assert (counts == 0).any()
+    loss = ON.feat_corr_loss(g['points'], counts, gt['feat'], gt['cam'], gt['feat_src'], gt['src_cams'], gt['size'][0], gt['center'][0])
+    assert abs(loss - float(g['loss'])) < 2e-6
+
+
+def test_carving_and_depth_loss_vs_reference_golden():
+    """oracle_np.carving_t2 / depth_loss == the reference's carving_t2 + get_depth_loss (my_utils.py:269-331, loss.py:37-63) on bumpy
+    depth maps with holes: inside / outside voting across views, points no view sees, both attenuation classes."""
+    g = golden('carve')
+    size, center = float(g['size'][0]), g['center'][0]
+    pw = g['points'].astype(np.float64) / 2 * size + center.astype(np.float64)
+    dist, occ, valid = ON.carving_t2(pw, g['depths'][:, 0, 0].astype(np.float64), g['depth_cams'][:, 0].astype(np.float64))
+    assert 0.1 < valid.mean() < 0.95 and 0.2 < occ.mean() < 0.8 and (~valid).sum() > 100          # every branch is populated
+    bad = (valid != g['in_range']) | (occ != g['occ'])
+    assert bad.sum() <= 4, bad.sum()                              # fp32 (reference) vs float64 decisions at pixel / 0.99-depth boundaries
+    ok = ~bad
+    assert np.abs(dist[ok] - g['dist'][ok]).max() < 2e-5 * max(1.0, np.abs(g['dist'][ok & valid]).max())
+    for tag in 'abc':
+        fa, na = g['att_' + tag]
+        loss, dist_r, w = ON.depth_loss(g['points'], g['eik_out'][0], g['depths'], g['depth_cams'], size, center, 0.25, fa, 0.1, na)
+        assert abs(loss - float(g["loss_" + tag])) < 2e-6 * float(g["loss_" + tag]), (tag, loss, float(g["loss_" + tag]))
