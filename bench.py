@@ -190,9 +190,12 @@ def main():
         local %= max(1, torch.cuda.device_count())             # (a box with fewer GPUs than ranks: dry runs only)
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    under_launcher = 'WORLD_SIZE' in os.environ
+    if under_launcher:                                           # also at world size 1: the collectives then run through RCCL all the same
         if B % world:
             sys.exit('--gpus must divide the %d views of the batch' % B)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
 
     P_unit, V = WORKLOADS[a.workload]
@@ -226,17 +229,17 @@ def main():
     for _ in range(a.warmup):
         step()
     events.clear()
-    if world > 1:
+    if under_launcher:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out, lo = step()
-    if world > 1:
+    if under_launcher:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if under_launcher:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -301,7 +304,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(V)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if under_launcher:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -199,6 +199,34 @@ __global__ __launch_bounds__(64 * NW) void k_sdf_col0(MvNet net, const float* __
     if (tid < ROWS && row0 + tid < n) y[row0 + tid] = out[tid];
 }
 
+// latency-regime variant: ONE 16-row tile per 512-thread workgroup, K-split staggered evaluation (tile_engine.h, mv_sdf_eval_col0_ks)
+template <int NTW>
+__global__ __launch_bounds__(512) void k_sdf_col0_ks(MvNet net, const float* __restrict__ x, int n, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, d0 = 3 + 6 * net.multires;
+    float* act0 = smem;
+    float* act1 = act0 + 16 * net.S;
+    float* pe = act1 + 16 * net.S;
+    float* pts = pe + ((16 * d0 + 3) & ~3);
+    float* out = pts + 64;
+    int* flags = (int*)(out + 16);
+    const int row0 = blockIdx.x * 16;
+    if (tid < 48) pts[tid] = (row0 + tid / 3 < n) ? x[3 * (size_t)row0 + tid] : 0.0f;
+    __syncthreads();
+    mv_sdf_eval_col0_ks<NTW>(net, act0, act1, pe, pts, out, flags, tid);
+    if (tid < 16 && row0 + tid < n) y[row0 + tid] = out[tid];
+}
+
+template <int NTW>
+static int launch_col0_ks(const MvNet& net, const float* x, int n, float* y, hipStream_t s) {
+    const int d0 = 3 + 6 * net.multires;
+    const size_t lds = ((size_t)32 * net.S + ((16 * d0 + 3) & ~3) + 64 + 16 + 4 * MV_MAXL) * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)k_sdf_col0_ks<NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return mv_check(e, "mvsdf_sdf_col0: LDS attribute");
+    hipLaunchKernelGGL((k_sdf_col0_ks<NTW>), dim3((n + 15) / 16), dim3(512), lds, s, net, x, n, y);
+    return mv_check(hipGetLastError(), "mvsdf_sdf_col0 (ks)");
+}
+
 __global__ void k_det_math(int op, const float* __restrict__ x, int n, float* __restrict__ y0, float* __restrict__ y1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -327,6 +355,12 @@ int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, in
     if (rc) return rc;
     if (!x || !y || n <= 0) return mv_fail(-1, "mvsdf_sdf_col0: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (mt == 17) {                                             // latency regime: one tile per workgroup, K-split staggered evaluation
+        int mx = 0;
+        for (int l = 0; l < net.n_layers - 1; ++l) mx = net.L[l].NT > mx ? net.L[l].NT : mx;
+        if (mx > 32) return mv_fail(-1, "mvsdf_sdf_col0: network too wide");
+        return mx > 16 ? launch_col0_ks<4>(net, x, n, y, s) : launch_col0_ks<2>(net, x, n, y, s);
+    }
     const char* e = getenv("MVSDF_NW");
     const int nw_env = e ? atoi(e) : 0;
     int maxnt = 0;

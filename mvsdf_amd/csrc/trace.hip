@@ -98,32 +98,60 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(MvNet net, MvTracePara
     float ts = acc_s, te = acc_e;
     unsigned long long nrows_total = 0;
 
-    const float coef0 = (1.0f - tp.line_search_step);          // first back-off of the line search (ray_tracing.py:178)
+    // Speculative line search.  The back-off positions of a side that steps are known before its evaluation (acc -/+ 0.5*curr, then
+    // -/+ 0.25*curr, -/+ 0.125*curr: ray_tracing.py:178-181), so they ride along as extra rows whenever the row tiles that run anyway have
+    // free slots: a ray whose step overshoots then finishes its iteration in ONE dependent evaluation instead of up to 1 + line_step_iters.
+    // Slots go first to sides that needed a back-off in their previous iteration (rays that overshoot tend to keep doing so), shallow
+    // levels before deep ones.  Results are identical; speculative rows count only if the reference would have evaluated them.
+    bool hard_s = false, hard_e = false, bo_s = false, bo_e = false;
+    const float lss1 = 1.0f - tp.line_search_step;
     for (;;) {
-        int row_s = 0, row_e = 0, row_ss = 0, row_se = 0;
-        bool sp_s = false, sp_e = false;
+        int row_s = 0, row_e = 0;
+        int sr_s[3] = {-1, -1, -1}, sr_e[3] = {-1, -1, -1};       // rows of the speculative levels lvl0 + 1 .. lvl0 + 3 of each side
+        int lvl0 = 0;
         if (w == 0) {
             const unsigned long long ms = __ballot(req_s), me = __ballot(req_e);
             const unsigned long long lt = (1ull << lane) - 1ull;
-            const int ns = __popcll(ms), ne = __popcll(me);
+            const int ns = __popcll(ms), ne = __popcll(me), n = ns + ne;
             row_s = __popcll(ms & lt);
             row_e = ns + __popcll(me & lt);
-            // Speculative line search: a side that steps this round also evaluates its FIRST back-off point (known in advance:
-            // acc -/+ 0.5*curr) whenever that fits into the row tiles that run anyway -- one dependent evaluation per iteration
-            // instead of two.  Identical results; unused speculative rows are not counted.
-            const unsigned long long qs = __ballot(req_s && phase == 1), qe = __ballot(req_e && phase == 1);
-            const int nqs = __popcll(qs), nqe = __popcll(qe);
-            const bool spec = tp.line_step_iters > 0 && (nqs + nqe) > 0 && (ns + ne + nqs + nqe) <= ((ns + ne + 15) & ~15);
             if (req_s) { float* p = lds.pts + row_s * 3; p[0] = c[0] + ts * d[0]; p[1] = c[1] + ts * d[1]; p[2] = c[2] + ts * d[2]; }
             if (req_e) { float* p = lds.pts + row_e * 3; p[0] = c[0] + te * d[0]; p[1] = c[1] + te * d[1]; p[2] = c[2] + te * d[2]; }
-            if (spec) {
-                sp_s = req_s && phase == 1; sp_e = req_e && phase == 1;
-                row_ss = ns + ne + __popcll(qs & lt);
-                row_se = ns + ne + nqs + __popcll(qe & lt);
-                if (sp_s) { const float z = acc_s - coef0 * curr_s; float* p = lds.pts + row_ss * 3; p[0] = c[0] + z * d[0]; p[1] = c[1] + z * d[1]; p[2] = c[2] + z * d[2]; }
-                if (sp_e) { const float z = acc_e + coef0 * curr_e; float* p = lds.pts + row_se * 3; p[0] = c[0] + z * d[0]; p[1] = c[1] + z * d[1]; p[2] = c[2] + z * d[2]; }
+            int base = n, left = ((n + 15) & ~15) - n;
+            lvl0 = (phase == 2) ? k + 1 : 0;                      // level of this round's mandatory request (back-offs already applied)
+            const bool can = (phase == 1 || phase == 2);
+            if (left > 0 && tp.line_step_iters > 0) {
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {            // 0: sides that backed off last iteration, 1: the others
+#pragma unroll
+                    for (int dd = 0; dd < 3; ++dd) {
+                        const bool lv_ok = can && (lvl0 + dd + 1 <= tp.line_step_iters);
+                        const bool cs = lv_ok && req_s && (pass == 0 ? hard_s : !hard_s);
+                        const bool ce = lv_ok && req_e && (pass == 0 ? hard_e : !hard_e);
+                        const unsigned long long bs = __ballot(cs), be = __ballot(ce);
+                        int cnt = __popcll(bs), take = cnt < left ? cnt : left;
+                        if (cs && __popcll(bs & lt) < take) sr_s[dd] = base + __popcll(bs & lt);
+                        base += take; left -= take;
+                        cnt = __popcll(be); take = cnt < left ? cnt : left;
+                        if (ce && __popcll(be & lt) < take) sr_e[dd] = base + __popcll(be & lt);
+                        base += take; left -= take;
+                    }
+                }
+                // points of the granted slots: successive subtraction, exactly like `acc -= coef * curr` level by level
+                float z = ts;
+#pragma unroll
+                for (int dd = 0; dd < 3; ++dd) {
+                    z = z - (lss1 / (float)(1 << (lvl0 + dd))) * curr_s;
+                    if (sr_s[dd] >= 0) { float* p = lds.pts + sr_s[dd] * 3; p[0] = c[0] + z * d[0]; p[1] = c[1] + z * d[1]; p[2] = c[2] + z * d[2]; }
+                }
+                z = te;
+#pragma unroll
+                for (int dd = 0; dd < 3; ++dd) {
+                    z = z + (lss1 / (float)(1 << (lvl0 + dd))) * curr_e;
+                    if (sr_e[dd] >= 0) { float* p = lds.pts + sr_e[dd] * 3; p[0] = c[0] + z * d[0]; p[1] = c[1] + z * d[1]; p[2] = c[2] + z * d[2]; }
+                }
             }
-            if (lane == 0) { s_n[0] = ns + ne + (spec ? nqs + nqe : 0); s_n[1] = ns + ne; }
+            if (lane == 0) { s_n[0] = base; s_n[1] = n; }
         }
         __syncthreads();
         const int n = s_n[0];
@@ -131,33 +159,35 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(MvNet net, MvTracePara
         if (tid == 0) nrows_total += (unsigned long long)s_n[1];
         mv_eval_dispatch<MT, NTW, NW>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
         if (w == 0) {
-            bool used_s = false, used_e = false;
+            int used = 0;
             if (phase != 3) {
                 const float vs = req_s ? mv_clamp(lds.sdfv[row_s], -tp.dist_clip, tp.dist_clip) : 0.f;
                 const float ve = req_e ? mv_clamp(lds.sdfv[row_e], -tp.dist_clip, tp.dist_clip) : 0.f;
+                const bool had_s = req_s, had_e = req_e;          // sides whose speculative rows (if any) belong to this round
                 bool end_iter = false;
                 if (phase == 0) { next_s = vs; next_e = ve; }
-                else if (phase == 1) {
-                    next_s = vs; next_e = ve; k = 0;
-                    if ((sp_s || sp_e) && (next_s < 0.f || next_e < 0.f)) {          // line-search iteration 0, answered by the speculative rows
-                        if (next_s < 0.f) { acc_s -= coef0 * curr_s; next_s = mv_clamp(lds.sdfv[row_ss], -tp.dist_clip, tp.dist_clip); used_s = true; }
-                        if (next_e < 0.f) { acc_e += coef0 * curr_e; next_e = mv_clamp(lds.sdfv[row_se], -tp.dist_clip, tp.dist_clip); used_e = true; }
-                        k = 1;
+                else {
+                    if (phase == 1) { next_s = vs; next_e = ve; k = 0; bo_s = false; bo_e = false; }
+                    else { if (req_s) next_s = vs; if (req_e) next_e = ve; k++; }
+                    for (;;) {                                                        // ray_tracing.py:173-191
+                        const bool np_s = next_s < 0.f, np_e = next_e < 0.f;
+                        if (!(k < tp.line_step_iters && (np_s || np_e))) { end_iter = true; break; }
+                        const float coef = lss1 / (float)(1 << k);
+                        if (np_s) { acc_s -= coef * curr_s; ts = acc_s; bo_s = true; }
+                        if (np_e) { acc_e += coef * curr_e; te = acc_e; bo_e = true; }
+                        const int dd = k - lvl0;                                      // level k + 1 = speculative level index dd of this round
+                        const int rs = (np_s && had_s && dd >= 0 && dd < 3) ? (dd == 0 ? sr_s[0] : (dd == 1 ? sr_s[1] : sr_s[2])) : -1;
+                        const int re = (np_e && had_e && dd >= 0 && dd < 3) ? (dd == 0 ? sr_e[0] : (dd == 1 ? sr_e[1] : sr_e[2])) : -1;
+                        if (rs >= 0) { next_s = mv_clamp(lds.sdfv[rs], -tp.dist_clip, tp.dist_clip); used++; }
+                        if (re >= 0) { next_e = mv_clamp(lds.sdfv[re], -tp.dist_clip, tp.dist_clip); used++; }
+                        req_s = np_s && rs < 0; req_e = np_e && re < 0;
+                        if (req_s || req_e) { phase = 2; break; }                     // evaluate the missing side(s) at level k + 1 next round
+                        k++;
                     }
-                }
-                else { if (req_s) next_s = vs; if (req_e) next_e = ve; k++; }
-                if (phase != 0) {
-                    const bool np_s = next_s < 0.f, np_e = next_e < 0.f;
-                    if (k < tp.line_step_iters && (np_s || np_e)) {                   // ray_tracing.py:173-191
-                        const float coef = (1.0f - tp.line_search_step) / (float)(1 << k);
-                        req_s = np_s; req_e = np_e;
-                        if (np_s) { acc_s -= coef * curr_s; ts = acc_s; }
-                        if (np_e) { acc_e += coef * curr_e; te = acc_e; }
-                        phase = 2;
-                    } else {
-                        end_iter = true;
-                        unf_s = unf_s && (acc_s < acc_e);                           // ray_tracing.py:193-194
+                    if (end_iter) {
+                        unf_s = unf_s && (acc_s < acc_e);                             // ray_tracing.py:193-194
                         unf_e = unf_e && (acc_s < acc_e);
+                        hard_s = bo_s; hard_e = bo_e;
                     }
                 }
                 if (phase == 0 || end_iter) {                                         // top of the while loop, ray_tracing.py:139-171
@@ -178,8 +208,8 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(MvNet net, MvTracePara
                     }
                 }
             }
-            const int nused = __popcll(__ballot(used_s)) + __popcll(__ballot(used_e));   // speculative rows the reference would have evaluated
-            if (lane == 0) nrows_total += (unsigned long long)nused;
+            for (int o = 32; o > 0; o >>= 1) used += __shfl_xor(used, o);             // speculative rows the reference would have evaluated
+            if (lane == 0) nrows_total += (unsigned long long)used;
         }
         // (mv_sdf_eval_col0 ended with a barrier; wave 0 rewrites pts/s_n only after its own reads above)
     }

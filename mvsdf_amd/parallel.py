@@ -19,7 +19,7 @@ def all_reduce_sum_(flat):
     CPU tests).  No-op without an initialised process group.  -> the factor that turns the sum into the rank average (1 / world): the
     caller folds it into its next pass over the buffer (optim.FlatAdam: inside the Adam launch) instead of a separate division."""
     w = world_size()
-    if w > 1:
+    if dist.is_available() and dist.is_initialized():              # also at world size 1 (the collective then is RCCL's identity)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return 1.0 / w
 

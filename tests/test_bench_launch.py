@@ -43,3 +43,19 @@ def test_two_ranks_on_one_gpu_gloo_full_step():
     d = json.loads(lines[-1])
     assert d['n_gpus'] == 2 and d['config']['rays_per_gpu'] == 2048 and d['config']['rays_total'] == 4096
     assert d['value'] > 0 and d['roofline']['frac'] > 0 and d['scaling'] == 'weak'
+
+
+@pytest.mark.gpu
+def test_one_rank_under_the_launcher_runs_the_collectives_through_rccl():
+    """torch.distributed.run with ONE rank and the default backend (`nccl` = RCCL on ROCm): the process group is created on the GPU and the
+    step's gradient all-reduce, barrier and the MAX-of-times all-reduce all go through RCCL (identity at world size 1) -- the same code path
+    the 8-GPU run takes, exercised on the one GPU of the test box."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MVSDF_DIST_BACKEND'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1', '--master-port',
+           str(29600 + os.getpid() % 300), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '2', '--no-cpu-baseline']
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['value'] > 0

@@ -23,4 +23,4 @@ for n in [int(v) for v in a.n.split(',')]:
         for _ in range(10): y = ops.sdf_col0(net, x, mt=mt)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
-        print('W=%d n=%d mt=%d: %.3f ms  %.1f TFLOP/s (%.1f%%)  %.1f us per 16-row tile-eval per CU' % (a.W, n, mt, ms, n * Ft / ms / 1e9, n * Ft / ms / 1e9 / 1.573, ms * 1e3 / (n / 16 / 256)), flush=True)
+        print('W=%d n=%d mt=%d: %.3f ms  %.1f TFLOP/s (%.1f%%)  %.1f us per 16-row tile-eval per CU' % (a.W, n, mt, ms, n * Ft / ms / 1e9, n * Ft / ms / 1e9 / 1.573, ms * 1e3 / max(1.0, n / 16 / 256)), flush=True)
