@@ -30,6 +30,9 @@ typedef struct {
     const float* w[MVSDF_MAX_LAYERS];   /* folded weights, row-major [N][K] (only the last layer's row 0 is read: u_L = W_L[0,:]); may be NULL when no normals are needed */
     int skip_layer;                     /* layer whose input is cat([x, PE(x)])/sqrt(2) (idr.py:86-87), -1 if none */
     int multires;                       /* positional-encoding frequencies (embedder.py:38-50) */
+    const void* wp16[MVSDF_MAX_LAYERS]; /* bf16 packs made by mvsdf_pack_bf16_net (BASELINE configs[4]); NULL unless trace_dtype == 1 */
+    int trace_dtype;                    /* arithmetic of the no-grad tracing MLP (mvsdf_trace, mvsdf_sdf_col0): 0 = fp32 weights and fp32-input
+                                         * MFMA (bit-exact against the oracle), 1 = bf16 weights / activations on the bf16 MFMA, fp32 accumulate */
 } MvsdfNetDesc;
 
 /* RayTracing constructor arguments (ray_tracing.py:7-25) + the hard-coded dist_clip (ray_tracing.py:127-131). */
@@ -81,6 +84,13 @@ int mvsdf_fold_backward_net(int n_layers, const float* const* v, const float* co
                             void* stream);
 /* backward of the fold: dW[N][K] -> dv[N][K], dg[N]    */
 int mvsdf_fold_backward(const float* v, const float* g, const float* dW, int N, int K, float* dv, float* dg, void* stream);
+
+/* bf16 packs of an SDF network for trace_dtype = 1: the folded fp32 weights w[l] ([N][K] row-major, device) rounded to bf16 (nearest even)
+ * in the layout of v_mfma_f32_16x16x32_bf16.  Positional-encoding input columns (all of layer 0, the last 3 + 6*multires of the skip
+ * layer) are stored twice: those inputs enter as hi + lo bf16 pairs (csrc/tile_engine_bf16.h).  wp16[l]: mvsdf_packed_bf16_bytes(...) bytes. */
+size_t mvsdf_packed_bf16_bytes(int N, int K, int nsplit);
+int mvsdf_pack_bf16_net(int n_layers, const float* const* w, const int* N, const int* K, int skip_layer, int multires, void* const* wp16,
+                        void* stream);
 
 /* ImplicitNetwork.forward(x)[:, 0] (idr.py:77-94) for n points: the tracing MLP alone. */
 int mvsdf_sdf_col0(const MvsdfNetDesc* net, const float* x, int n, float* y, int mt, void* stream);

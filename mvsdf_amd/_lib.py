@@ -14,7 +14,7 @@ _lib = None
 class NetDesc(C.Structure):
     _fields_ = [('n_layers', C.c_int), ('K', C.c_int * MAX_LAYERS), ('N', C.c_int * MAX_LAYERS),
                 ('wp', C.c_void_p * MAX_LAYERS), ('bias', C.c_void_p * MAX_LAYERS), ('w', C.c_void_p * MAX_LAYERS),
-                ('skip_layer', C.c_int), ('multires', C.c_int)]
+                ('skip_layer', C.c_int), ('multires', C.c_int), ('wp16', C.c_void_p * MAX_LAYERS), ('trace_dtype', C.c_int)]
 
 
 class TraceParams(C.Structure):
@@ -45,6 +45,8 @@ def lib():
         for fn in ('mvsdf_sdf_ctx_floats', 'mvsdf_sdf_bwd_ws_floats', 'mvsdf_render_ctx_floats', 'mvsdf_render_bwd_ws_floats'):
             getattr(L, fn).restype = C.c_size_t
         L.mvsdf_adam_ws_floats.restype = C.c_size_t
+        L.mvsdf_packed_bf16_bytes.restype = C.c_size_t
+        L.mvsdf_packed_bf16_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
         L.mvsdf_tracegen_state_bytes.restype = C.c_size_t
         L.mvsdf_adam_step.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mvsdf_adam_step_scaled.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -57,7 +59,7 @@ def lib():
 
 # every symbol include/mvsdf_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
 EXPORTS = [
-    'mvsdf_version', 'mvsdf_last_error', 'mvsdf_packed_floats', 'mvsdf_fold_pack', 'mvsdf_fold_backward', 'mvsdf_fold_pack_net', 'mvsdf_fold_backward_net',
+    'mvsdf_version', 'mvsdf_last_error', 'mvsdf_packed_floats', 'mvsdf_fold_pack', 'mvsdf_fold_backward', 'mvsdf_fold_pack_net', 'mvsdf_fold_backward_net', 'mvsdf_packed_bf16_bytes', 'mvsdf_pack_bf16_net',
     'mvsdf_sdf_col0', 'mvsdf_camera_rays', 'mvsdf_sphere_intersection', 'mvsdf_trace_workspace_bytes', 'mvsdf_trace_workspace_bytes_n', 'mvsdf_trace', 'mvsdf_trace_stage', 'mvsdf_det_math',
     'mvsdf_tracegen_state_bytes', 'mvsdf_tracegen_init', 'mvsdf_tracegen_step', 'mvsdf_tracegen_finish', 'mvsdf_tracegen_rows', 'mvsdf_tracegen_reduce',
     'mvsdf_tracegen_secant',

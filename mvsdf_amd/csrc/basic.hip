@@ -199,6 +199,51 @@ __global__ __launch_bounds__(64 * NW) void k_sdf_col0(MvNet net, const float* __
     if (tid < ROWS && row0 + tid < n) y[row0 + tid] = out[tid];
 }
 
+// bf16 packs (tile_engine_bf16.h): one thread per packed element
+struct PackBfArgs { const float* w[MV_MAXL]; uint16_t* wp[MV_MAXL]; int N[MV_MAXL], K[MV_MAXL], nsplit[MV_MAXL]; };
+__global__ void k_pack_bf16_net(PackBfArgs a) {
+    const int l = blockIdx.y;
+    const int N = a.N[l], K = a.K[l], ns = a.nsplit[l], KB = mv_bf_kb(K, ns);
+    const size_t total = mv_packed_bf16_elems(N, K, ns);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = idx & 7, lane = (idx >> 3) & 63;
+        const size_t blk = idx >> 9;
+        const int kb = (int)(blk % KB), ct = (int)(blk / KB);
+        const int o = ct * 16 + (lane & 15), kp = kb * 32 + 8 * (lane >> 4) + i;
+        const int col = kp < K ? kp : (kp < K + ns ? kp - ns : -1);          // the lo copy of a split column shares the hi column's weight
+        a.wp[l][idx] = (o < N && col >= 0) ? mv_f2bf(a.w[l][(size_t)o * K + col]) : (uint16_t)0;
+    }
+}
+
+template <int MT, int NTW>
+__global__ __launch_bounds__(512) void k_sdf_col0_bf(MvNetBf net, const float* __restrict__ x, int n, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWS = 16 * MT;
+    const int tid = threadIdx.x, d0 = 3 + 6 * net.multires;
+    float* act = smem;
+    float* pe = act + ROWS * net.S;
+    float* pts = pe + ((ROWS * d0 + 3) & ~3);
+    float* out = pts + ROWS * 4;
+    const int row0 = blockIdx.x * ROWS;
+    for (int i = tid; i < ROWS * 3; i += 512) {
+        const int row = row0 + i / 3;
+        pts[i] = row < n ? x[3 * (size_t)row0 + i] : 0.0f;
+    }
+    __syncthreads();
+    mv_sdf_eval_col0<MT, NTW, 8>(net, act, pe, pts, out, tid);
+    if (tid < ROWS && row0 + tid < n) y[row0 + tid] = out[tid];
+}
+
+template <int MT, int NTW>
+static int launch_col0_bf(const MvNetBf& net, const float* x, int n, float* y, hipStream_t s) {
+    const int rows = 16 * MT, d0 = 3 + 6 * net.multires;
+    const size_t lds = ((size_t)rows * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows) * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)k_sdf_col0_bf<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return mv_check(e, "mvsdf_sdf_col0: LDS attribute");
+    hipLaunchKernelGGL((k_sdf_col0_bf<MT, NTW>), dim3((n + rows - 1) / rows), dim3(512), lds, s, net, x, n, y);
+    return mv_check(hipGetLastError(), "mvsdf_sdf_col0 (bf16)");
+}
+
 // latency-regime variant: ONE 16-row tile per 512-thread workgroup, K-split staggered evaluation (tile_engine.h, mv_sdf_eval_col0_ks)
 template <int NTW>
 __global__ __launch_bounds__(512) void k_sdf_col0_ks(MvNet net, const float* __restrict__ x, int n, float* __restrict__ y) {
@@ -349,12 +394,43 @@ int mvsdf_sphere_intersection(const float* cam_loc, const float* ray_dirs, int B
     return mv_check(hipGetLastError(), "mvsdf_sphere_intersection");
 }
 
+size_t mvsdf_packed_bf16_bytes(int N, int K, int nsplit) { return mv_packed_bf16_elems(N, K, nsplit) * 2; }
+
+int mvsdf_pack_bf16_net(int n_layers, const float* const* w, const int* N, const int* K, int skip_layer, int multires, void* const* wp16,
+                        void* stream) {
+    if (n_layers < 1 || n_layers > MV_MAXL || !w || !N || !K || !wp16) return mv_fail(-1, "mvsdf_pack_bf16_net: bad arguments");
+    PackBfArgs a;
+    size_t maxTot = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!w[l] || !wp16[l] || N[l] <= 0 || K[l] <= 0) return mv_fail(-1, "mvsdf_pack_bf16_net: null layer pointer / bad dims");
+        a.w[l] = w[l]; a.wp[l] = (uint16_t*)wp16[l]; a.N[l] = N[l]; a.K[l] = K[l];
+        a.nsplit[l] = (l == 0 || l == skip_layer) ? 3 + 6 * multires : 0;
+        const size_t t = mv_packed_bf16_elems(N[l], K[l], a.nsplit[l]);
+        if (t > maxTot) maxTot = t;
+    }
+    const int blocks = (int)((maxTot + 255) / 256 < 256 ? (maxTot + 255) / 256 : 256);
+    hipLaunchKernelGGL(k_pack_bf16_net, dim3(blocks, n_layers), dim3(256), 0, (hipStream_t)stream, a);
+    return mv_check(hipGetLastError(), "mvsdf_pack_bf16_net");
+}
+
 int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, int mt, void* stream) {
+    if (!x || !y || n <= 0) return mv_fail(-1, "mvsdf_sdf_col0: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (desc && desc->trace_dtype == 1) {                       // bf16 weights / activations on the bf16 MFMA
+        MvNetBf nb;
+        int rcb = mv_make_net_bf(desc, &nb);
+        if (rcb) return rcb;
+        int mx = 0;
+        for (int l = 0; l < nb.n_layers - 1; ++l) mx = nb.L[l].NT > mx ? nb.L[l].NT : mx;
+        if (mx > 32) return mv_fail(-1, "mvsdf_sdf_col0: network too wide");
+        if (mx > 16) return mt >= 2 ? launch_col0_bf<2, 4>(nb, x, n, y, s) : launch_col0_bf<1, 4>(nb, x, n, y, s);
+        if (mt >= 4) return launch_col0_bf<4, 2>(nb, x, n, y, s);
+        if (mt >= 2) return launch_col0_bf<2, 2>(nb, x, n, y, s);
+        return launch_col0_bf<1, 2>(nb, x, n, y, s);
+    }
     MvNet net;
     int rc = mv_make_net(desc, &net);
     if (rc) return rc;
-    if (!x || !y || n <= 0) return mv_fail(-1, "mvsdf_sdf_col0: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
     if (mt == 17) {                                             // latency regime: one tile per workgroup, K-split staggered evaluation
         int mx = 0;
         for (int l = 0; l < net.n_layers - 1; ++l) mx = net.L[l].NT > mx ? net.L[l].NT : mx;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "mlp_common.h"
+#include "tile_engine_bf16.h"
 #include "../../include/mvsdf_hip.h"
 
 int mv_fail(int code, const char* msg);          // records msg, returns code
@@ -9,6 +10,8 @@ int mv_check(hipError_t e, const char* where);   // 0 on success
 // mode 0: SDF net (PE input + skip chaining checked); 1: plain chain; 2: transposed packs (no chaining check)
 int mv_make_net_mode(const MvsdfNetDesc* d, MvNet* net, int mode);
 static inline int mv_make_net(const MvsdfNetDesc* d, MvNet* net) { return mv_make_net_mode(d, net, 0); }
+int mv_make_net_bf(const MvsdfNetDesc* d, MvNetBf* net);      // SDF net on the bf16 packs (trace_dtype == 1)
+static inline int mv_bf_nsplit(const MvsdfNetDesc* d, int l) { return (l == 0 || l == d->skip_layer) ? 3 + 6 * d->multires : 0; }
 
 // column tiles per wave the fused chain kernels need for this network (8 waves per workgroup): 2 up to width 256, 4 up to 512,
 // 0 = too wide for them (per-layer kernels take over)

@@ -16,7 +16,9 @@
 //
 // No host synchronisation anywhere: list lengths stay on the device, grids are sized for the worst case.
 #include <stdlib.h>
+#include <type_traits>
 #include "tile_engine.h"
+#include "tile_engine_bf16.h"
 #include "trace_params.h"
 
 struct RayCommon {
@@ -42,8 +44,9 @@ __device__ __forceinline__ bool mv_sphere_isect(const float* c, const float* d, 
     return hit;
 }
 
-template <int MT, int NTW, int NW>
-__device__ __forceinline__ void mv_eval_dispatch(const MvNet& net, int ntiles, float* act, float* pe, const float* pts, float* out, int tid) {
+// NET = MvNet (fp32 weights, fp32-input MFMA, bit-exact vs the oracle) or MvNetBf (bf16 weights / activations, bf16 MFMA): overloads of mv_sdf_eval_col0
+template <int MT, int NTW, int NW, class NET>
+__device__ __forceinline__ void mv_eval_dispatch(const NET& net, int ntiles, float* act, float* pe, const float* pts, float* out, int tid) {
     if (MT >= 4 && ntiles == 4) mv_sdf_eval_col0<(MT >= 4 ? 4 : MT), NTW, NW>(net, act, pe, pts, out, tid);
     else if (MT >= 3 && ntiles == 3) mv_sdf_eval_col0<(MT >= 3 ? 3 : MT), NTW, NW>(net, act, pe, pts, out, tid);
     else if (MT >= 2 && ntiles == 2) mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW, NW>(net, act, pe, pts, out, tid);
@@ -65,8 +68,8 @@ __device__ __forceinline__ TraceLds mv_carve(float* base, int rows, int S, int d
     return l;
 }
 
-template <int MT, int NTW, int NW>
-__global__ __launch_bounds__(64 * NW) void k_sphere_trace(MvNet net, MvTraceParams tp, const float* __restrict__ cam_loc,
+template <int MT, int NTW, int NW, class NET>
+__global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams tp, const float* __restrict__ cam_loc,
                                                             const float* __restrict__ dirs, const uint8_t* __restrict__ object_mask,
                                                             int R, int P, int training, float* __restrict__ o_points,
                                                             uint8_t* __restrict__ o_mask, float* __restrict__ o_dists,
@@ -272,8 +275,8 @@ struct RowSeg { const int* list; const int* src; int cnt_index, i0, ni, blocks; 
 // Sample rows of a work list, FLATTENED over rays: global row q = item * ni + j (sample i0 + j).  A workgroup evaluates one chunk
 // of 16*MT consecutive rows (always full tiles, evenly spread over the chip) and stores the SDF values; the per-ray logic runs
 // in k_reduce_items.  Sampler rays: ray_tracing.py:206-219; min-sdf rays: ray_tracing.py:287-301.
-template <int MT, int NTW, int NW>
-__device__ void mv_eval_rows(const MvNet& net, const MvTraceParams& tp, const SampleCtx& c, const RowSeg& sg, int chunk, float* smem) {
+template <int MT, int NTW, int NW, class NET>
+__device__ void mv_eval_rows(const NET& net, const MvTraceParams& tp, const SampleCtx& c, const RowSeg& sg, int chunk, float* smem) {
     constexpr int ROWS = 16 * MT;
     const int tid = threadIdx.x;
     const int n_steps = tp.n_steps, ni = sg.ni;
@@ -410,8 +413,8 @@ __global__ __launch_bounds__(64) void k_reduce_items(MvTraceParams tp, SampleCtx
 
 // secant (ray_tracing.py:260-278) for 16*MT listed rays per workgroup: n_secant dependent rounds, every round one evaluation of
 // all the workgroup's rays (rows are full tiles instead of one or two rows per workgroup).
-template <int MT, int NTW, int NW>
-__device__ void mv_secant_rays(const MvNet& net, const MvTraceParams& tp, const SampleCtx& c, int n_list, int block, float* smem) {
+template <int MT, int NTW, int NW, class NET>
+__device__ void mv_secant_rays(const NET& net, const MvTraceParams& tp, const SampleCtx& c, int n_list, int block, float* smem) {
     constexpr int ROWS = 16 * MT;
     const int tid = threadIdx.x;
     const int r0 = block * ROWS;
@@ -451,28 +454,29 @@ __device__ void mv_secant_rays(const MvNet& net, const MvTraceParams& tp, const 
 
 // The first sec_blocks workgroups run secant chains, the others evaluate sample rows of up to two row segments: the dependent
 // secant chains of a few dozen workgroups overlap with the throughput-shaped sampling.
-template <int MT, int NTW, int NW>
-__global__ __launch_bounds__(64 * NW) void k_ray_samples(MvNet net, MvTraceParams tp, SampleCtx c, RowSeg s0, RowSeg s1, int sec_blocks) {
+template <int MT, int NTW, int NW, class NET>
+__global__ __launch_bounds__(64 * NW) void k_ray_samples(NET net, MvTraceParams tp, SampleCtx c, RowSeg s0, RowSeg s1, int sec_blocks) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int b = blockIdx.x;
     if (b < sec_blocks) {
-        mv_secant_rays<(MT > 1 ? 1 : MT), NTW, NW>(net, tp, c, (int)c.counters[MV_CNT_N_SECANT], b, smem);
+        mv_secant_rays<(MT > 1 ? 1 : MT), NTW, NW, NET>(net, tp, c, (int)c.counters[MV_CNT_N_SECANT], b, smem);
         return;
     }
     b -= sec_blocks;
-    if (b < s0.blocks) mv_eval_rows<MT, NTW, NW>(net, tp, c, s0, b, smem);
-    else if (b - s0.blocks < s1.blocks) mv_eval_rows<MT, NTW, NW>(net, tp, c, s1, b - s0.blocks, smem);
+    if (b < s0.blocks) mv_eval_rows<MT, NTW, NW, NET>(net, tp, c, s0, b, smem);
+    else if (b - s0.blocks < s1.blocks) mv_eval_rows<MT, NTW, NW, NET>(net, tp, c, s1, b - s0.blocks, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-static size_t trace_lds_bytes(const MvNet& net, int MT, int sv_floats, int rpw) {
+template <class NET>
+static size_t trace_lds_bytes(const NET& net, int MT, int sv_floats, int rpw) {
     const int rows = 16 * MT, d0 = 3 + 6 * net.multires;
     size_t f = (size_t)rows * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows + sv_floats;
     return f * 4 + 16 + (size_t)rpw * (8 * 4 + 4) + 16;
 }
 
-template <int MT, int NTW, int NW>
-static hipError_t launch_stage1(const MvNet& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, const uint8_t* om, int B, int P,
+template <int MT, int NTW, int NW, class NET>
+static hipError_t launch_stage1(const NET& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, const uint8_t* om, int B, int P,
                                 int training, float* points, uint8_t* mask, float* dists, float* ws, unsigned long long* counters,
                                 hipStream_t stream) {
     const int R = B * P, NR = 8 * MT;
@@ -483,17 +487,17 @@ static hipError_t launch_stage1(const MvNet& net, const MvTraceParams& tp, const
     const size_t lds1 = trace_lds_bytes(net, MT, 0, 0);
     static size_t set1 = 0;                                     // raise the dynamic-LDS cap once per size (per instantiation)
     if (lds1 > set1) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_sphere_trace<MT, NTW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        hipError_t e = hipFuncSetAttribute((const void*)k_sphere_trace<MT, NTW, NW, NET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e != hipSuccess) return e;
         set1 = lds1;
     }
-    hipLaunchKernelGGL((k_sphere_trace<MT, NTW, NW>), dim3((R + NR - 1) / NR), dim3(64 * NW), lds1, stream, net, tp, cam_loc, dirs, om, R, P,
+    hipLaunchKernelGGL((k_sphere_trace<MT, NTW, NW, NET>), dim3((R + NR - 1) / NR), dim3(64 * NW), lds1, stream, net, tp, cam_loc, dirs, om, R, P,
                        training, points, mask, dists, w_zmin, w_zmax, w_list, w_list_min, counters);
     return hipGetLastError();
 }
 
-template <int MT, int NTW, int NW>
-static hipError_t launch_stage2(const MvNet& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, int B, int P, int training,
+template <int MT, int NTW, int NW, class NET>
+static hipError_t launch_stage2(const NET& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, int B, int P, int training,
                                 const float* intervals, const float* steps, float* points, uint8_t* mask, float* dists, float* ws,
                                 unsigned long long* counters, int parts, hipStream_t stream) {
     // parts bit 0: sampler rows + their reduction (the hit mask is FINAL after it); bit 1: secant + min-sdf rows
@@ -508,7 +512,7 @@ static hipError_t launch_stage2(const MvNet& net, const MvTraceParams& tp, const
     const size_t lds2 = trace_lds_bytes(net, MT, 0, 0);
     static size_t set2 = 0;
     if (lds2 > set2) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_ray_samples<MT, NTW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        hipError_t e = hipFuncSetAttribute((const void*)k_ray_samples<MT, NTW, NW, NET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) return e;
         set2 = lds2;
     }
@@ -527,17 +531,17 @@ static hipError_t launch_stage2(const MvNet& net, const MvTraceParams& tp, const
     if (parts & 1) {
         // sampler rays: first window of nf samples, then the other samples of the rays the window left open
         const RowSeg first = {w_list, nullptr, (int)MV_CNT_N_SAMPLER, 0, nf, blocks_for(nf)};
-        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(first.blocks), dim3(64 * NW), lds2, stream, net, tp, c, first, none, 0);
+        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(first.blocks), dim3(64 * NW), lds2, stream, net, tp, c, first, none, 0);
         hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list, (const int*)nullptr, (int)MV_CNT_N_SAMPLER, 0);
         if (nf < n) {
             const RowSeg rest = {c.list_rest, c.src_rest, (int)MV_CNT_N_SAMPLER_REST, nf, n - nf, blocks_for(n - nf)};
-            hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(rest.blocks), dim3(64 * NW), lds2, stream, net, tp, c, rest, none, 0);
+            hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(rest.blocks), dim3(64 * NW), lds2, stream, net, tp, c, rest, none, 0);
             hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, c.list_rest, c.src_rest, (int)MV_CNT_N_SAMPLER_REST, 1);
         }
     }
     if (parts & 2) {
         const RowSeg minsdf = {w_list_min, nullptr, (int)MV_CNT_N_MINSDF, 0, n, training ? blocks_for(n) : 0};
-        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW>), dim3(sec_blocks + minsdf.blocks), dim3(64 * NW), lds2, stream, net, tp, c, minsdf, none,
+        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(sec_blocks + minsdf.blocks), dim3(64 * NW), lds2, stream, net, tp, c, minsdf, none,
                            sec_blocks);
         if (training) hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
     }
@@ -545,7 +549,8 @@ static hipError_t launch_stage2(const MvNet& net, const MvTraceParams& tp, const
 }
 
 // mt1: row tiles per workgroup of the sphere-tracing kernel (8*mt1 rays); mt2: row tiles per chunk of the sample-row kernels.
-hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp, int mt1, int mt2, const float* cam_loc, const float* dirs,
+template <class NET>
+hipError_t mv_trace_launch(int stages, const NET& net, const MvTraceParams& tp, int mt1, int mt2, const float* cam_loc, const float* dirs,
                            const uint8_t* om, int B, int P, int training, const float* intervals, const float* steps, float* points,
                            uint8_t* mask, float* dists, float* ws, unsigned long long* counters, hipStream_t stream) {
     int maxnt = 0;
@@ -554,7 +559,8 @@ hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp
     // waves per workgroup: 8 (two per SIMD) once there are >= 2 column tiles per wave to share; MVSDF_NW=4 forces 4 (A/B runs)
     static int nw_env = -1;
     if (nw_env < 0) { const char* e = getenv("MVSDF_NW"); nw_env = e ? atoi(e) : 0; }
-    const bool eight = (nw_env == 8) || (nw_env != 4 && maxnt >= 16);
+    constexpr bool is_bf = !std::is_same<NET, MvNet>::value;                    // the bf16 engine is built for 8-wave workgroups only
+    const bool eight = is_bf || (nw_env == 8) || (nw_env != 4 && maxnt >= 16);
     const bool wide = maxnt > 16;
     hipError_t e = hipSuccess;
 #define MV_S1(MT_, NTW_, NW_) e = launch_stage1<MT_, NTW_, NW_>(net, tp, cam_loc, dirs, om, B, P, training, points, mask, dists, ws, counters, stream)
@@ -563,7 +569,7 @@ hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp
         if (eight) {
             if (wide) { if (mt1 >= 2) MV_S1(2, 4, 8); else MV_S1(1, 4, 8); }
             else if (mt1 >= 4) MV_S1(4, 2, 8); else if (mt1 >= 2) MV_S1(2, 2, 8); else MV_S1(1, 2, 8);
-        } else {
+        } else if constexpr (!is_bf) {
             if (wide) { if (mt1 >= 2) MV_S1(2, 8, 4); else MV_S1(1, 8, 4); }
             else if (mt1 >= 4) MV_S1(4, 4, 4); else if (mt1 >= 2) MV_S1(2, 4, 4); else MV_S1(1, 4, 4);
         }
@@ -581,7 +587,7 @@ hipError_t mv_trace_launch(int stages, const MvNet& net, const MvTraceParams& tp
         if (eight) {
             if (wide) { if (mtp >= 2) MV_S2(2, 4, 8); else MV_S2(1, 4, 8); }
             else if (mtp >= 4) MV_S2(4, 2, 8); else if (mtp >= 2) MV_S2(2, 2, 8); else MV_S2(1, 2, 8);
-        } else {
+        } else if constexpr (!is_bf) {
             if (wide) { if (mtp >= 2) MV_S2(2, 8, 4); else MV_S2(1, 8, 4); }
             else if (mtp >= 4) MV_S2(4, 4, 4); else if (mtp >= 2) MV_S2(2, 4, 4); else MV_S2(1, 4, 4);
         }
@@ -844,7 +850,9 @@ static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTracePara
                       float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
                       size_t workspace_bytes, int mt, int rpw, void* stream) {
     MvNet net;
-    int rc = mv_make_net(desc, &net);
+    MvNetBf netb;
+    const bool bf = desc && desc->trace_dtype == 1;
+    int rc = bf ? mv_make_net_bf(desc, &netb) : mv_make_net(desc, &net);
     if (rc) return rc;
     if (!tp || !cam_loc || !ray_dirs || !object_mask || !intervals || !points || !mask || !dists || !counters || !workspace)
         return mv_fail(-1, "mvsdf_trace: null argument");
@@ -859,8 +867,12 @@ static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTracePara
     hipError_t e = hipSuccess;
     if (stages & 1) e = hipMemsetAsync(counters, 0, 16 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return mv_check(e, "mvsdf_trace: memset");
-    e = mv_trace_launch(stages, net, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,
-                        minsdf_steps ? minsdf_steps : intervals, points, mask, dists, (float*)workspace, counters, s);
+    if (bf)
+        e = mv_trace_launch(stages, netb, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,
+                            minsdf_steps ? minsdf_steps : intervals, points, mask, dists, (float*)workspace, counters, s);
+    else
+        e = mv_trace_launch(stages, net, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,
+                            minsdf_steps ? minsdf_steps : intervals, points, mask, dists, (float*)workspace, counters, s);
     return mv_check(e, "mvsdf_trace");
 }
 

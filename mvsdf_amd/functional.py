@@ -82,6 +82,7 @@ def fold_networks(specs):
             L = ops.PackedLayer()
             L.bias = b.detach()
             L.N, L.K = v.shape
+            L.wp16 = None
             layers.append(L)
         vs_all += list(vs); gs_all += list(gs); bs_all += list(bs)
         cuts.append(len(layers))
@@ -101,6 +102,7 @@ def fold_network(vs, gs, bs, skip_layer, multires):
         L = ops.PackedLayer()
         L.bias = b.detach()
         L.N, L.K = v.shape
+        L.wp16 = None
         layers.append(L)
     n = len(vs)
     out = _FoldNet.apply(layers, *vs, *gs, *bs)

@@ -14,7 +14,7 @@ def _f32(t):
 
 
 class PackedLayer:
-    __slots__ = ('w', 'wp', 'wpT', 'bias', 'K', 'N')
+    __slots__ = ('w', 'wp', 'wpT', 'bias', 'K', 'N', 'wp16')
 
 
 class PackedNet:
@@ -22,6 +22,7 @@ class PackedNet:
 
     def __init__(self, layers, skip_layer, multires):
         self.layers, self.skip_layer, self.multires = layers, skip_layer, multires
+        self.trace_dtype = 0                # 1: the tracing MLP runs on the bf16 packs (pack_bf16_net)
 
     def desc(self, transposed=False):
         d = NetDesc()
@@ -32,6 +33,10 @@ class PackedNet:
             d.bias[i] = L.bias.data_ptr()
             d.w[i] = L.w.data_ptr()
         d.skip_layer, d.multires = self.skip_layer, self.multires
+        if not transposed and self.trace_dtype == 1:
+            for i, L in enumerate(self.layers):
+                d.wp16[i] = L.wp16.data_ptr()
+            d.trace_dtype = 1
         return d
 
     def wsizes(self):
@@ -112,8 +117,26 @@ def pack_net(vs, gs, biases, skip_layer, multires, want_t=True):
         L.w, L.wp, L.wpT = fold_pack(v, g, want_t)
         L.bias = _f32(b)
         L.N, L.K = v.shape
+        L.wp16 = None
         layers.append(L)
     return PackedNet(layers, skip_layer, multires)
+
+
+def pack_bf16_net(net):
+    """bf16 MFMA packs of a folded SDF network (BASELINE configs[4], csrc/tile_engine_bf16.h): one launch; switches the network's tracing
+    MLP (ops.trace, ops.sdf_col0) to bf16 weights / activations.  The differentiable passes keep the fp32 weights."""
+    n = len(net.layers)
+    d0 = 3 + 6 * net.multires
+    dev = net.layers[0].w.device
+    for i, L in enumerate(net.layers):
+        ns = d0 if (i == 0 or i == net.skip_layer) else 0
+        L.wp16 = torch.empty(lib().mvsdf_packed_bf16_bytes(L.N, L.K, ns), dtype=torch.uint8, device=dev)
+    N = (C.c_int * n)(*[L.N for L in net.layers])
+    K = (C.c_int * n)(*[L.K for L in net.layers])
+    check(lib().mvsdf_pack_bf16_net(n, _ptr_array([L.w for L in net.layers]), N, K, net.skip_layer, net.multires,
+                                    _ptr_array([L.wp16 for L in net.layers]), stream_of(net.layers[0].w)), 'mvsdf_pack_bf16_net')
+    net.trace_dtype = 1
+    return net
 
 
 def sdf_col0(net, x, mt=2):

@@ -36,17 +36,25 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def bf16_round(a):
+    """fp32 -> nearest-even bf16, returned as fp32."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    u = (u + np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xffff0000)
+    return u.view(np.float32)
+
+
 class Net:
     """Folded SDF network (weights from a reference-layout state dict)."""
 
-    def __init__(self, state, prefix='implicit_network', skip_in=(4,), multires=6):
+    def __init__(self, state, prefix='implicit_network', skip_in=(4,), multires=6, bf16=False):
         self.multires = multires
+        self.bf16 = bf16                                      # bf16 twin (BASELINE configs[4]): weights rounded here, activations in C
         self.W, self.b = [], []
         l = 0
         while '%s.lin%d.weight_v' % (prefix, l) in state:
             v = _f(state['%s.lin%d.weight_v' % (prefix, l)])
             g = _f(state['%s.lin%d.weight_g' % (prefix, l)]).reshape(-1)
-            self.W.append(fold(v, g))
+            self.W.append(bf16_round(fold(v, g)) if bf16 else fold(v, g))
             self.b.append(_f(state['%s.lin%d.bias' % (prefix, l)]))
             l += 1
         self.n_layers = l
@@ -80,7 +88,9 @@ def sdf_forward(net, x, ncols=None):
     x = _f(x)
     ncols = int(net.outs[-1]) if ncols is None else ncols
     y = np.empty((x.shape[0], ncols), np.float32)
+    lib().orc_set_bf16(C.c_int(1 if net.bf16 else 0))
     lib().orc_sdf_forward(*net.args(), _p(x), C.c_int(x.shape[0]), C.c_int(ncols), _p(y))
+    lib().orc_set_bf16(C.c_int(0))
     return y
 
 
@@ -131,11 +141,13 @@ def trace(net, cam_loc, dirs, object_mask, training, minsdf_steps=None, interval
         nargs = (C.c_int(0), _p(z), _p(z), C.c_int(-1), C.c_int(0), None, None)
     else:
         nargs = net.args()
+    lib().orc_set_bf16(C.c_int(1 if (net is not None and getattr(net, 'bf16', False)) else 0))
     lib().orc_trace(C.c_int(1 if analytic else 0), *nargs, _p(cam_loc), _p(dirs), _p(om), C.c_int(B), C.c_int(P),
                     C.c_float(object_bounding_sphere), C.c_float(sdf_threshold), C.c_float(line_search_step),
                     C.c_int(line_step_iters), C.c_int(sphere_tracing_iters), C.c_int(n_steps), C.c_int(n_secant_steps),
                     C.c_float(dist_clip), C.c_int(1 if training else 0), _p(intervals), _p(steps),
                     _p(pts), _p(mask), _p(dists), _p(rows))
+    lib().orc_set_bf16(C.c_int(0))
     return pts, mask.astype(bool), dists, rows
 
 

@@ -60,8 +60,56 @@ void orc_pe(const float *x, int n, int multires, float *out) {
     for (int i = 0; i < n; ++i) pe_row(x + 3 * i, multires, out + (size_t)d * i);
 }
 
+/* ---- bf16 twin of the tracing MLP (BASELINE configs[4]; product: mvsdf_amd/csrc/tile_engine_bf16.h).  Same rounding points: the caller hands
+ * over weights already rounded to bf16; hidden activations are rounded to bf16 (nearest even); every positional-encoding input v enters as
+ * hi = bf16(v) and lo = bf16(v - hi) sharing one weight; fp32 accumulation in the packed k order [columns | lo copies of the split columns],
+ * fp32 bias / softplus.  The hardware sums each MFMA's 32 products with its own internal alignment, so this twin is NOT bit-identical to the
+ * kernel (tests bound the difference). ---- */
+static int g_bf16 = 0;
+void orc_set_bf16(int on) { g_bf16 = on; }
+static float bf16r(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static void sdf_row_bf16(const orc_net *net, const float *x, int ncols, float *y) {
+    float pe[64], a[MAXW], z[MAXW];
+    int d0 = 3 + 6 * net->multires;
+    pe_row(x, net->multires, pe);
+    int na = 0;                               /* plain (single bf16) columns in a[] */
+    for (int l = 0; l < net->n_layers; ++l) {
+        float sp[64];                         /* split columns of this layer (fp32 values fed as hi + lo) */
+        int nsp = 0;
+        if (l == 0) { for (int k = 0; k < d0; ++k) sp[k] = pe[k]; nsp = d0; na = 0; }
+        else if (l == net->skip_layer) { for (int k = 0; k < d0; ++k) sp[k] = dm_div_sqrt2(pe[k]); nsp = d0; }
+        int last = (l == net->n_layers - 1);
+        int no = last ? ncols : net->out[l];
+        const float *W = net->W[l];
+        int in = net->in[l];                  /* = na + nsp */
+        for (int j = 0; j < no; ++j) {
+            const float *w = W + (size_t)j * in;
+            float acc = 0.0f;
+            for (int k = 0; k < na; ++k) acc = fmaf(a[k], w[k], acc);
+            for (int k = 0; k < nsp; ++k) acc = fmaf(bf16r(sp[k]), w[na + k], acc);
+            for (int k = 0; k < nsp; ++k) acc = fmaf(bf16r(sp[k] - bf16r(sp[k])), w[na + k], acc);
+            z[j] = acc + net->b[l][j];
+        }
+        if (last) { memcpy(y, z, sizeof(float) * no); return; }
+        int to_skip = (l + 1 == net->skip_layer);
+        for (int j = 0; j < no; ++j) {
+            float h = dm_softplus100(z[j]);
+            if (to_skip) h = dm_div_sqrt2(h);
+            a[j] = bf16r(h);
+        }
+        na = no;
+    }
+}
+
 /* ---- ImplicitNetwork.forward for one point (idr.py:77-94).  ncols: how many columns of the last layer. ---- */
 static void sdf_row(const orc_net *net, const float *x, int ncols, float *y) {
+    if (g_bf16) { sdf_row_bf16(net, x, ncols, y); return; }
     float pe[64], a[MAXW], z[MAXW];
     int d0 = 3 + 6 * net->multires;
     pe_row(x, net->multires, pe);

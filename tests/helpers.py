@@ -5,7 +5,7 @@ from mvsdf_amd import ops
 from mvsdf_amd.utils import synth
 
 
-def sdf_packed_net(sd, dev='cuda', prefix='implicit_network', skip_layer=4, multires=6):
+def sdf_packed_net(sd, dev='cuda', prefix='implicit_network', skip_layer=4, multires=6, bf16=False):
     vs, gs, bs = [], [], []
     l = 0
     while '%s.lin%d.weight_v' % (prefix, l) in sd:
@@ -13,7 +13,8 @@ def sdf_packed_net(sd, dev='cuda', prefix='implicit_network', skip_layer=4, mult
         gs.append(torch.from_numpy(sd['%s.lin%d.weight_g' % (prefix, l)]).to(dev))
         bs.append(torch.from_numpy(sd['%s.lin%d.bias' % (prefix, l)]).to(dev))
         l += 1
-    return ops.pack_net(vs, gs, bs, skip_layer, multires)
+    net = ops.pack_net(vs, gs, bs, skip_layer, multires)
+    return ops.pack_bf16_net(net) if bf16 else net
 
 
 def trace_params(W=64, **over):
