@@ -72,7 +72,8 @@ size_t mvsdf_packed_floats(int N, int K);
  * v[N][K], g[N] -> w[N][K] (row-major, required), wp (packed W, mvsdf_packed_floats(N, K) floats, may be NULL),
  * wpT (packed W^T for contractions over the OUT dimension, mvsdf_packed_floats(K, N) floats, may be NULL). */
 int mvsdf_fold_pack(const float* v, const float* g, int N, int K, float* w, float* wp, float* wpT, void* stream);
-/* all layers of a network -- or of several networks, up to 24 layers in total -- at once (one fold launch + one pack launch).  The
+/* all layers of a network -- or of several networks, up to 24 layers in total -- at once (one fold launch + one pack launch).  g[l] may be
+ * NULL for a layer without weight norm (weight_norm=False, idr.py:70-71 skipped): w = v, and the backward gives dv = dW, no dg.  The
  * pointer arrays are HOST arrays of n_layers device pointers; wp[l] / wpT[l] may be NULL. */
 int mvsdf_fold_pack_net(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w,
                         float* const* wp, float* const* wpT, void* stream);
@@ -169,7 +170,10 @@ size_t mvsdf_sdf_bwd_ws_floats(const MvsdfNetDesc* net, int Mb);
 int mvsdf_sdf_backward(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, const float* x, int M, int Mg, int row0, int Mb, const float* dy,
                        const float* dn, const float* ctx, float* dW_cat, float* db_cat, float* dx, float* ws, void* stream);
 
-/* ---- rendering network, mode 'idr' (idr.py:145-167): rgb = tanh(MLP(cat[points, PE(view), normals, feat])) ---- */
+/* ---- rendering network (idr.py:145-167): rgb = tanh(MLP(cat[points, PE(view), normals, feat])) ----
+ * multires_view: low 8 bits = positional-encoding frequencies of the view direction (0: the raw direction); bit 8 (0x100) = mode 'no_view_dir'
+ * (input cat[points, normals, feat]); bit 9 (0x200) = mode 'no_normal' (cat[points, PE(view), feat]); neither = mode 'idr'.  The unused input
+ * pointer must still be valid device memory. */
 size_t mvsdf_render_ctx_floats(const MvsdfNetDesc* net, int N);
 size_t mvsdf_render_bwd_ws_floats(const MvsdfNetDesc* net, int N);
 int mvsdf_render_forward(const MvsdfNetDesc* net, const float* points, const float* view, const float* normals, const float* feat,

@@ -59,6 +59,11 @@ __global__ __launch_bounds__(256) void k_fold_net(FoldNetArgs a) {
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= N) return;
     const float* vr = a.v[l] + (size_t)j * K;
+    if (!a.g[l]) {                                              // no weight norm for this layer (weight_norm=False): w = v
+        float* wr0 = a.w[l] + (size_t)j * K;
+        for (int k = lane; k < K; k += 64) wr0[k] = vr[k];
+        return;
+    }
     float ss = 0.0f;
     for (int k0 = 0; k0 < K; k0 += 64) {
         const float mine = (k0 + lane < K) ? vr[k0 + lane] : 0.0f;
@@ -99,6 +104,12 @@ __global__ void k_fold_bwd_net(FoldNetArgs a) {
     if (j >= N) return;
     const float* vr = a.v[l] + (size_t)j * K;
     const float* dr = a.dW[l] + (size_t)j * K;
+    if (!a.g[l]) {                                              // w = v: dv = dW, no dg
+        float* dv0 = a.dv[l] + (size_t)j * K;
+        for (int k = lane; k < K; k += 64) dv0[k] = a.accumulate ? dv0[k] + dr[k] : dr[k];
+        if (lane == 0 && a.db[l]) a.dbias[l][j] = a.accumulate ? a.dbias[l][j] + a.db[l][j] : a.db[l][j];
+        return;
+    }
     float ss = 0.f, dot = 0.f;
     for (int k = lane; k < K; k += 64) { ss = fmaf(vr[k], vr[k], ss); dot = fmaf(dr[k], vr[k], dot); }
     for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o); dot += __shfl_xor(dot, o); }
@@ -343,7 +354,7 @@ int mvsdf_fold_pack_net(int n_layers, const float* const* v, const float* const*
     if (rc) return rc;
     if (!v || !g || !w || !wp || !wpT) return mv_fail(-1, "mvsdf_fold_pack_net: null argument");
     for (int l = 0; l < n_layers; ++l) {
-        if (!v[l] || !g[l] || !w[l]) return mv_fail(-1, "mvsdf_fold_pack_net: null layer pointer");
+        if (!v[l] || !w[l]) return mv_fail(-1, "mvsdf_fold_pack_net: null layer pointer");    // g[l] NULL: layer without weight norm (w = v)
         a.v[l] = v[l]; a.g[l] = g[l]; a.w[l] = w[l]; a.wp[l] = wp[l]; a.wpT[l] = wpT[l];
     }
     hipStream_t s = (hipStream_t)stream;
@@ -363,7 +374,7 @@ int mvsdf_fold_backward_net(int n_layers, const float* const* v, const float* co
     if (!v || !g || !dW || !dv || !dg || ((db == nullptr) != (dbias == nullptr))) return mv_fail(-1, "mvsdf_fold_backward_net: null argument");
     a.accumulate = accumulate;
     for (int l = 0; l < n_layers; ++l) {
-        if (!v[l] || !g[l] || !dW[l] || !dv[l] || !dg[l]) return mv_fail(-1, "mvsdf_fold_backward_net: null layer pointer");
+        if (!v[l] || !dW[l] || !dv[l] || (g[l] && !dg[l])) return mv_fail(-1, "mvsdf_fold_backward_net: null layer pointer");
         a.v[l] = v[l]; a.g[l] = g[l]; a.dW[l] = dW[l]; a.dv[l] = dv[l]; a.dg[l] = dg[l];
         if (db) {
             if ((db[l] == nullptr) != (dbias[l] == nullptr)) return mv_fail(-1, "mvsdf_fold_backward_net: db / dbias must pair up");

@@ -533,25 +533,13 @@ static RenderBwdLayout render_bwd_layout(const MvNet& net, int N) {
     return o;
 }
 
-// A0[row] = cat[points(3), view(3), sin/cos(2^m view) m<mv, normals(3), feat(F)]   (idr.py:146-150, mode 'idr')
+// A0[row] = cat[points(3), view(3), sin/cos(2^m view) m<mv, normals(3), feat(F)]   (idr.py:146-154; view / normal parts per the mode bits of mv)
 __global__ void k_render_input(const float* __restrict__ points, const float* __restrict__ view, const float* __restrict__ normals,
                                const float* __restrict__ feat, int ldfeat, int N, int mv, int K0, float* __restrict__ A0) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)N * K0) return;
-    const int row = (int)(idx / K0), k = (int)(idx - (size_t)row * K0), dv = 3 + 6 * mv;
-    float v;
-    if (k < 3) v = points[(size_t)row * 3 + k];
-    else if (k < 3 + dv) {
-        const int j = k - 3;
-        if (j < 3) v = view[(size_t)row * 3 + j];
-        else {
-            const int jj = j - 3, m = jj / 6, rem = jj - 6 * m, c = rem % 3;
-            float sn, co;
-            dm_sincos(view[(size_t)row * 3 + c] * (float)(1 << m), &sn, &co);
-            v = rem < 3 ? sn : co;
-        }
-    } else if (k < 6 + dv) v = normals[(size_t)row * 3 + (k - 3 - dv)];
-    else v = feat[(size_t)row * ldfeat + (k - 6 - dv)];
+    const int row = (int)(idx / K0), k = (int)(idx - (size_t)row * K0);
+    const float v = mv_render_input_raw(points, view, normals, feat, ldfeat, mv, row, k);
     A0[idx] = v;
 }
 
@@ -575,8 +563,11 @@ int mvsdf_render_forward(const MvsdfNetDesc* d, const float* points, const float
     int rc = mv_make_net_mode(d, &net, 1);
     if (rc) return rc;
     if (!points || !view || !normals || !feat || !rgb || !ctx || N <= 0) return mv_fail(-1, "mvsdf_render_forward: bad arguments");
-    const int nl = net.n_layers, dv = 3 + 6 * multires_view, K0 = net.L[0].K;
-    if (K0 <= 6 + dv) return mv_fail(-1, "mvsdf_render_forward: first layer too narrow for cat[points, PE(view), normals, feat]");
+    const int nl = net.n_layers, K0 = net.L[0].K;
+    if ((multires_view & ~0x3ff) || (multires_view & 0xff) > 16 || (multires_view & 0x300) == 0x300)
+        return mv_fail(-1, "mvsdf_render_forward: bad multires_view / mode bits");
+    if (K0 <= 3 + mv_render_dv(multires_view) + mv_render_dn(multires_view))
+        return mv_fail(-1, "mvsdf_render_forward: first layer too narrow for cat[points, PE(view), normals, feat]");
     hipStream_t s = (hipStream_t)stream;
     const RenderLayout lo = render_layout(net, N);
     static int fuse_r = -1;

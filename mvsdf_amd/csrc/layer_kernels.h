@@ -1012,19 +1012,27 @@ struct RenderChainArgs {
     const float* drgb; const float* Ac[MV_MAXL]; const float* rgbc; float* ZB[MV_MAXL]; float* din;  // backward
 };
 
-__device__ __forceinline__ float mv_render_input(const RenderChainArgs& a, int row, int k) {
-    const int dv = 3 + 6 * a.mv;
-    if (k < 3) return a.points[(size_t)row * 3 + k];
+// `mv` packs the input layout of RenderingNetwork.forward (idr.py:145-154): low 8 bits = multires_view; bit 8 set = mode 'no_view_dir'
+// (cat[points, normals, feat]); bit 9 set = mode 'no_normal' (cat[points, PE(view), feat]); neither = mode 'idr'.
+__host__ __device__ static inline int mv_render_dv(int mv) { return (mv & 0x100) ? 0 : 3 + 6 * (mv & 0xff); }
+__host__ __device__ static inline int mv_render_dn(int mv) { return (mv & 0x200) ? 0 : 3; }
+__device__ __forceinline__ float mv_render_input_raw(const float* points, const float* view, const float* normals, const float* feat, int ldfeat,
+                                                     int mv, int row, int k) {
+    const int dv = mv_render_dv(mv), dn = mv_render_dn(mv);
+    if (k < 3) return points[(size_t)row * 3 + k];
     if (k < 3 + dv) {
         const int j = k - 3;
-        if (j < 3) return a.view[(size_t)row * 3 + j];
+        if (j < 3) return view[(size_t)row * 3 + j];
         const int jj = j - 3, m = jj / 6, rem = jj - 6 * m, c = rem % 3;
         float sn, co;
-        dm_sincos(a.view[(size_t)row * 3 + c] * (float)(1 << m), &sn, &co);
+        dm_sincos(view[(size_t)row * 3 + c] * (float)(1 << m), &sn, &co);
         return rem < 3 ? sn : co;
     }
-    if (k < 6 + dv) return a.normals[(size_t)row * 3 + (k - 3 - dv)];
-    return a.feat[(size_t)row * a.ldfeat + (k - 6 - dv)];
+    if (k < 3 + dv + dn) return normals[(size_t)row * 3 + (k - 3 - dv)];
+    return feat[(size_t)row * ldfeat + (k - 3 - dv - dn)];
+}
+__device__ __forceinline__ float mv_render_input(const RenderChainArgs& a, int row, int k) {
+    return mv_render_input_raw(a.points, a.view, a.normals, a.feat, a.ldfeat, a.mv, row, k);
 }
 
 template <int MT, int NTW, int NW>

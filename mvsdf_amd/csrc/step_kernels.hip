@@ -146,7 +146,7 @@ __global__ void k_step_bwd_stage0(StepBwdArgs a) {
             a.dy[(size_t)row * a.Nout + c] = v;
         } else {
             float v = 0.0f;
-            if (k >= 0 && a.din && a.use_geo) v = a.din[(size_t)k * a.din_ld + a.din_nrm0 + (c - a.Nout)];
+            if (k >= 0 && a.din && a.use_geo && a.din_nrm0 >= 0) v = a.din[(size_t)k * a.din_ld + a.din_nrm0 + (c - a.Nout)];   // din_nrm0 < 0: mode 'no_normal'
             a.dn[(size_t)row * 3 + (c - a.Nout)] = v;
         }
     }

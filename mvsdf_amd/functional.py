@@ -50,7 +50,7 @@ class _FoldNet(torch.autograd.Function):
     @staticmethod
     def forward(ctx, holders, *vgb):
         n = len(vgb) // 3
-        vs, gs = [t.detach() for t in vgb[:n]], [t.detach() for t in vgb[n:2 * n]]
+        vs, gs = [t.detach() for t in vgb[:n]], [t.detach() if t is not None else None for t in vgb[n:2 * n]]   # g None: weight_norm=False, w = v
         ws, wps, wpTs = ops.fold_pack_net(vs, gs)
         for L, w, wp, wpT in zip(holders, ws, wps, wpTs):
             L.w, L.wp, L.wpT = w, wp, wpT
@@ -64,13 +64,14 @@ class _FoldNet(torch.autograd.Function):
         vs, gs, bs = vgb[:n], vgb[n:2 * n], vgb[2 * n:]
         dWs = [d.contiguous() if d is not None else torch.zeros_like(v) for d, v in zip(grads[:n], vs)]
         dbs = [d.contiguous() if d is not None else torch.zeros_like(b) for d, b in zip(grads[n:], bs)]
-        vd, gd = [t.detach() for t in vs], [t.detach() for t in gs]
-        direct = grad_sink.depth > 0 and all(getattr(p, '_mv_grad_sink', False) and p.grad is not None and p.grad.is_contiguous() and p.requires_grad for p in vgb)
+        vd, gd = [t.detach() for t in vs], [t.detach() if t is not None else None for t in gs]
+        direct = grad_sink.depth > 0 and all(getattr(p, '_mv_grad_sink', False) and p.grad is not None and p.grad.is_contiguous() and p.requires_grad
+                                             for p in vgb if p is not None)
         if direct:
-            ops.fold_backward_net(vd, gd, dWs, dbs, sinks=([p.grad for p in vs], [p.grad for p in gs], [p.grad for p in bs]))
+            ops.fold_backward_net(vd, gd, dWs, dbs, sinks=([p.grad for p in vs], [p.grad if p is not None else None for p in gs], [p.grad for p in bs]))
             return (None,) * (1 + 3 * n)
         dvs, dgs = ops.fold_backward_net(vd, gd, dWs)
-        return (None,) + tuple(dvs) + tuple(dg.view_as(g) for dg, g in zip(dgs, gs)) + tuple(dbs)
+        return (None,) + tuple(dvs) + tuple(dg.view_as(g) if g is not None else None for dg, g in zip(dgs, gs)) + tuple(dbs)
 
 
 def fold_networks(specs):
@@ -214,8 +215,16 @@ def sdf_reuse(shared, ws, bs, pts, N, defer_dw=False, row0=0):
     return _SdfReuse.apply(pts, shared, row0, N, defer_dw, *ws, *bs)
 
 
+def render_offsets(vspec):
+    """Column layout of the rendering net's input for a view spec (multires_view | 0x100 if mode 'no_view_dir' | 0x200 if 'no_normal'):
+    -> (first normal column or -1, first feature column)."""
+    dv = 0 if vspec & 0x100 else 3 + 6 * (vspec & 0xff)
+    dn = 0 if vspec & 0x200 else 3
+    return (3 + dv if dn else -1), 3 + dv + dn
+
+
 class _Render(torch.autograd.Function):
-    """RenderingNetwork.forward, mode 'idr' (idr.py:145-167)."""
+    """RenderingNetwork.forward (idr.py:145-167); multires_view carries the mode bits (render_offsets)."""
 
     @staticmethod
     def forward(ctx, points, normals, view, feat, net, multires_view, *wb):
@@ -231,10 +240,10 @@ class _Render(torch.autograd.Function):
     @staticmethod
     def backward(ctx, drgb):
         dWs, dbs, din = ops.render_backward(ctx.net, ctx.N, drgb.contiguous(), ctx.saved)
-        dv = 3 + 6 * ctx.mv
+        nrm0, feat0 = render_offsets(ctx.mv)
         dp = din[:, 0:3] if ctx.needs[0] else None
-        dn = din[:, 3 + dv:6 + dv] if ctx.needs[1] else None
-        df = din[:, 6 + dv:] if ctx.needs[2] else None
+        dn = (din[:, nrm0:nrm0 + 3] if nrm0 >= 0 else torch.zeros_like(din[:, :3])) if ctx.needs[1] else None
+        df = din[:, feat0:] if ctx.needs[2] else None
         return (dp, dn, None, df, None, None) + tuple(dWs) + tuple(dbs)
 
 
@@ -352,10 +361,10 @@ class _IdrStep(torch.autograd.Function):
         dn = torch.empty(Mb, 3, dtype=torch.float32, device=dev)
         dWr = dbr = din = dx = None
         use_geo = not st.detach_geo                                               # idr.py:329-336: features always carry the rgb gradient
-        dv = 3 + 6 * st.multires_view
+        nrm0, feat0 = render_offsets(st.multires_view)
         if N > 0 and d_rgbv is not None:
             dWr, dbr, din = ops.render_backward(rnet, N, d_rgbv[st.perm[:N]], st.rsaved, n_ctx=R)
-        common = (st.n_eik, st.n_ds, N, Nout, st.n_true, din, 6 + dv, 3 + dv, use_geo)
+        common = (st.n_eik, st.n_ds, N, Nout, st.n_true, din, feat0, nrm0, use_geo)
         ops.step_backward_inputs(0, *common, None, None, st.view_sorted, st.n_eval, st.true_rows, None, None, None, st.d_mask, st.e_mask, dy, dn)
         if din is not None:
             # adjoint of the surface points through features (+ normals): input adjoint only, rows [E, E+N)

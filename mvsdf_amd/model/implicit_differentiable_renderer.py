@@ -45,6 +45,19 @@ class _WNLinear(nn.Module):
         return self.weight_v * (self.weight_g / self.weight_v.norm(dim=1, keepdim=True))
 
 
+class _PlainLinear(nn.Module):
+    """weight_norm=False (idr.py:70-71,137-138 skipped): the parameters of a plain nn.Linear, same state_dict keys (weight, bias).  The fold
+    kernels take a NULL g as "w = v"."""
+
+    def __init__(self, weight, bias):
+        super().__init__()
+        self.weight = nn.Parameter(weight)
+        self.bias = nn.Parameter(bias)
+
+    weight_v = property(lambda self: self.weight)
+    weight_g = None
+
+
 def _linear_default_init(in_f, out_f):
     lin = nn.Linear(in_f, out_f)
     return lin.weight.detach().clone(), lin.bias.detach().clone()
@@ -53,12 +66,10 @@ def _linear_default_init(in_f, out_f):
 class ImplicitNetwork(nn.Module):
     def __init__(self, feature_vector_size, d_in, d_out, dims, geometric_init=True, bias=1.0, skip_in=(), weight_norm=True, multires=0):
         super().__init__()
-        if not weight_norm:
-            raise NotImplementedError('the native path implements weight_norm=True (mvsdf_dtu.conf:28)')
-        if d_in != 3 or multires <= 0:
-            raise NotImplementedError('the native SDF kernels assume d_in=3 with positional encoding (mvsdf_dtu.conf:22,29)')
+        if d_in != 3:
+            raise NotImplementedError('the native SDF kernels trace 3-D points (d_in=3, mvsdf_dtu.conf:22)')
         dims = [d_in] + list(dims) + [d_out + 1 + feature_vector_size]
-        self.multires = multires
+        self.multires = multires                                 # 0: the raw point is the input (no positional encoding), idr.py:36-40
         dims[0] = 3 + 6 * multires
         self.num_layers = len(dims)
         self.skip_in = tuple(skip_in)
@@ -72,18 +83,18 @@ class ImplicitNetwork(nn.Module):
                 if l == self.num_layers - 2:
                     nn.init.normal_(w, mean=np.sqrt(np.pi) / np.sqrt(dims[l]), std=0.0001)
                     nn.init.constant_(b, -bias)
-                elif l == 0:
+                elif multires > 0 and l == 0:
                     nn.init.constant_(b, 0.0)
                     nn.init.constant_(w[:, 3:], 0.0)
                     nn.init.normal_(w[:, :3], 0.0, np.sqrt(2) / np.sqrt(out_dim))
-                elif l in self.skip_in:
+                elif multires > 0 and l in self.skip_in:
                     nn.init.constant_(b, 0.0)
                     nn.init.normal_(w, 0.0, np.sqrt(2) / np.sqrt(out_dim))
                     nn.init.constant_(w[:, -(dims[0] - 3):], 0.0)
                 else:
                     nn.init.constant_(b, 0.0)
                     nn.init.normal_(w, 0.0, np.sqrt(2) / np.sqrt(out_dim))
-            setattr(self, 'lin' + str(l), _WNLinear(w, b))
+            setattr(self, 'lin' + str(l), _WNLinear(w, b) if weight_norm else _PlainLinear(w, b))
 
     def _lins(self):
         return [getattr(self, 'lin' + str(l)) for l in range(self.num_layers - 1)]
@@ -118,17 +129,24 @@ class ImplicitNetwork(nn.Module):
 class RenderingNetwork(nn.Module):
     def __init__(self, feature_vector_size, mode, d_in, d_out, dims, weight_norm=True, multires_view=0):
         super().__init__()
-        if mode != 'idr' or not weight_norm:
-            raise NotImplementedError("the native path implements mode='idr', weight_norm=True (mvsdf_dtu.conf:33-37)")
+        if mode not in ('idr', 'no_view_dir', 'no_normal'):
+            raise ValueError("mode must be 'idr', 'no_view_dir' or 'no_normal' (idr.py:149-154)")
+        if multires_view < 0 or multires_view > 16:
+            raise ValueError('multires_view out of range')
         self.mode = mode
         self.multires_view = multires_view
+        # input layout handed to the kernels: PE frequencies | 0x100 (no view direction) | 0x200 (no normal)
+        self.view_spec = multires_view | (0x100 if mode == 'no_view_dir' else 0) | (0x200 if mode == 'no_normal' else 0)
         dims = [d_in + feature_vector_size] + list(dims) + [d_out]
         if multires_view > 0:
             dims[0] += 6 * multires_view
+        expect = 3 + (0 if mode == 'no_view_dir' else 3 + 6 * multires_view) + (0 if mode == 'no_normal' else 3) + feature_vector_size
+        if dims[0] != expect:                                     # the reference would fail inside lin0 with a shape error
+            raise ValueError('d_in=%d does not match the inputs of mode %r (first layer takes %d columns, the inputs have %d)' % (d_in, mode, dims[0], expect))
         self.num_layers = len(dims)
         for l in range(self.num_layers - 1):
             w, b = _linear_default_init(dims[l], dims[l + 1])
-            setattr(self, 'lin' + str(l), _WNLinear(w, b))
+            setattr(self, 'lin' + str(l), _WNLinear(w, b) if weight_norm else _PlainLinear(w, b))
 
     def fold_spec(self):
         lins = [getattr(self, 'lin' + str(l)) for l in range(self.num_layers - 1)]
@@ -139,7 +157,7 @@ class RenderingNetwork(nn.Module):
 
     def forward(self, points, normals, view_dirs, feature_vectors, folded=None):
         net, ws, bs = folded if folded is not None else self.fold()
-        return Fn.render(net, ws, bs, points, normals, view_dirs, feature_vectors, self.multires_view)
+        return Fn.render(net, ws, bs, points, normals, view_dirs, feature_vectors, self.view_spec)
 
 
 class IDRNetwork(nn.Module):
@@ -261,7 +279,7 @@ class IDRNetwork(nn.Module):
             st.d_mask = sum(1 << g for g in range(4) if has[g] and d_flags[g](train_progress))
             st.e_mask = sum(1 << g for g in range(4) if has[g] and e_flags[g](train_progress))
             st.detach_geo = bool(train_progress < conf.phase[0] or conf.disable_rgb_grad)                     # idr.py:331-334
-            st.rnet, st.multires_view = rnet, self.rendering_network.multires_view
+            st.rnet, st.multires_view = rnet, self.rendering_network.view_spec
 
             def wait_counts():
                 self._counts_event.synchronize()                 # output shapes depend on the counts

@@ -71,9 +71,9 @@ def _ptr_array(tensors):
 
 
 def fold_pack_net(vs, gs):
-    """All layers in one C call -> lists (w, wp, wpT)."""
+    """All layers in one C call -> lists (w, wp, wpT).  gs[l] None: no weight norm for that layer (w = v)."""
     vs = [_f32(v) for v in vs]
-    gs = [_f32(g).reshape(-1) for g in gs]
+    gs = [_f32(g).reshape(-1) if g is not None else None for g in gs]
     dev = vs[0].device
     n = len(vs)
     N = (C.c_int * n)(*[v.shape[0] for v in vs])
@@ -88,9 +88,9 @@ def fold_pack_net(vs, gs):
 
 def fold_backward_net(vs, gs, dWs, dbs=None, sinks=None):
     """-> (dvs, dgs).  With `sinks` = (dv_targets, dg_targets, db_targets) the results (and the bias gradients dbs) are ADDED into
-    those tensors instead (the parameters' .grad buffers) and nothing is returned."""
+    those tensors instead (the parameters' .grad buffers) and nothing is returned.  gs[l] None (no weight norm): dv = dW, dg None."""
     vs = [_f32(v) for v in vs]
-    gs = [_f32(g).reshape(-1) for g in gs]
+    gs = [_f32(g).reshape(-1) if g is not None else None for g in gs]
     dWs = [_f32(d) for d in dWs]
     n = len(vs)
     N = (C.c_int * n)(*[v.shape[0] for v in vs])
@@ -98,16 +98,16 @@ def fold_backward_net(vs, gs, dWs, dbs=None, sinks=None):
     if sinks is not None:
         tv, tg, tb = sinks
         for t in list(tv) + list(tg) + list(tb):
-            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+            assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous())
         dbs = [_f32(d) for d in dbs]
         check(lib().mvsdf_fold_backward_net(n, _ptr_array(vs), _ptr_array(gs), _ptr_array(dWs), _ptr_array(dbs), N, K, _ptr_array(tv),
                                             _ptr_array(tg), _ptr_array(tb), 1, stream_of(vs[0])), 'mvsdf_fold_backward_net')
         return None
     dvs = [torch.empty_like(v) for v in vs]
-    dgs = [torch.empty_like(g) for g in gs]
+    dgs = [torch.empty_like(g) if g is not None else None for g in gs]
     check(lib().mvsdf_fold_backward_net(n, _ptr_array(vs), _ptr_array(gs), _ptr_array(dWs), None, N, K, _ptr_array(dvs), _ptr_array(dgs),
                                         None, 0, stream_of(vs[0])), 'mvsdf_fold_backward_net')
-    return dvs, [g.reshape(-1, 1) for g in dgs]
+    return dvs, [g.reshape(-1, 1) if g is not None else None for g in dgs]
 
 
 def pack_net(vs, gs, biases, skip_layer, multires, want_t=True):

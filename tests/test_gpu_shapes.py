@@ -189,3 +189,55 @@ def test_sdf_grid_for_mesh_extraction_matches_pointwise_eval(oracle):
     sel = np.random.RandomState(0).choice(res ** 3, 500, replace=False)
     want = oracle.sdf_forward(oracle.Net(sd), pts.cpu().numpy()[sel], ncols=1)[:, 0]
     assert np.array_equal(z[sel], want)
+
+
+def test_eval_render_loop_and_psnr():
+    """evaluation.evaluate_rendering (eval.py:133-185): a full 30x40 image through split_input chunks == the unchunked forward; PSNR follows
+    eval.py:239-246 (masked MSE); the model's training flag is restored."""
+    from mvsdf_amd import evaluation as ev
+    m = _model(64).train()
+    H, Wd = 30, 40
+    inp, _ = synth.make_batch(1, H * Wd, 0, seed=5, with_features=False, focal_scale=1.4)
+    ys, xs = np.meshgrid(np.arange(H) * 20.0, np.arange(Wd) * 20.0, indexing='ij')
+    inp['uv'] = np.stack([xs.ravel(), ys.ravel()], -1)[None].astype(np.float32)
+    rs = np.random.RandomState(1)
+    inp['object_mask'] = rs.rand(1, H * Wd) < 0.8
+    full = {k: t(v) for k, v in inp.items() if k in ('uv', 'pose', 'intrinsics', 'object_mask')}
+    gt = {'rgb': t(rs.uniform(-1, 1, size=(1, H * Wd, 3)).astype(np.float32))}
+    psnrs, imgs = ev.evaluate_rendering(m, [(full, gt)], (H, Wd), n_pixels=500)
+    assert m.training and len(psnrs) == 1 and imgs[0].shape == (H, Wd, 3)
+    m.eval()
+    with torch.no_grad():
+        ref = m(full)['rgb_values']
+    img_ref = ((ref + 1) / 2).reshape(H, Wd, 3).cpu().numpy()
+    assert np.abs(imgs[0] - img_ref).max() < 1e-5
+    mask = inp['object_mask'].reshape(H, Wd, 1).astype(np.float64)
+    gt_img = ((gt['rgb'] + 1) / 2).reshape(H, Wd, 3).cpu().numpy()
+    mse = (((img_ref - gt_img) * mask) ** 2).sum() / 3 / mask.sum()
+    assert abs(psnrs[0] - 10 * np.log10(1.0 / mse)) < 1e-3
+    assert ev.calculate_psnr(gt_img, gt_img, mask) == float('inf')
+
+
+def test_high_res_mesh_volume_and_vertex_colours():
+    """utils/plots.get_surface_high_res_mesh_simple's device parts (plots.py:150-205): the marching-cubes volume == implicit_network(x)[:, 0]
+    on get_grid_uniform's points in the (y, x, z) layout, vertex colours == (1 - s, s, 0) with s = sigmoid(implicit_network(v)[:, 1])."""
+    from mvsdf_amd.utils import plots
+    m = _model(64).eval()
+    res = 20
+    vol = plots.surface_volume(m, res)
+    pts = plots.get_grid_uniform(res)['grid_points']
+    with torch.no_grad():
+        y = m.implicit_network(pts)
+    want = y[:, 0].cpu().numpy().reshape(res, res, res).transpose([1, 0, 2])
+    assert vol.shape == (res, res, res) and np.abs(vol - want).max() < 2e-6
+    assert vol.min() < 0 < vol.max()                                            # the surface crosses the grid
+    verts = pts[::37].cpu().numpy()
+    col = plots.surface_vertex_colors(m, verts, chunk=100).cpu().numpy()
+    s = torch.sigmoid(y[::37, 1]).cpu().numpy()
+    assert np.abs(col[:, 1] - s).max() < 1e-6 and np.abs(col[:, 0] - (1 - s)).max() < 1e-6 and (col[:, 2] == 0).all()
+    try:
+        import skimage  # noqa: F401
+        import trimesh  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            plots.get_surface_high_res_mesh_simple(m, None, res)

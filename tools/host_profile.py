@@ -5,20 +5,21 @@ sys.path.insert(0, ROOT)
 import bench
 from mvsdf_amd.model.implicit_differentiable_renderer import IDRNetwork
 from mvsdf_amd.model.loss import IDRLoss
-from mvsdf_amd.parallel import FlatGradBucket
+from mvsdf_amd.optim import FlatAdam
 from mvsdf_amd.utils import synth
 from mvsdf_amd.utils.config import ConfigDict
 dev = torch.device('cuda', 0)
 model = IDRNetwork(ConfigDict(synth.model_conf(bench.W)))
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(bench.W, 0).items()})
 model = model.to(dev).train()
-loss_fn = IDRLoss(); bucket = FlatGradBucket(model.parameters()); opt = torch.optim.Adam(model.parameters(), lr=0.0, fused=True)
-inp, gt = bench.make_inputs(dev, 0)
+loss_fn = IDRLoss(); opt = FlatAdam(model.parameters(), lr=0.0)
+P_, V_ = bench.WORKLOADS['c2']
+inp, gt = bench.make_inputs(dev, 0, 1, P_, V_)
 def step():
-    bucket.zero(); out = model(inp, bench.TP); lo = loss_fn(out, dict(gt), bench.TP, bench.B); lo['loss'].backward(); bucket.all_reduce_mean(); bucket.clip_(2.0); opt.step()
+    opt.zero_grad(); out = model(inp, bench.TP); lo = loss_fn(out, dict(gt), bench.TP, bench.B); opt.backward(lo['loss']); opt.all_reduce_mean(); opt.step(grad_cap=2.0)
 for _ in range(5): step()
 torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
 for _ in range(20): step()
 torch.cuda.synchronize(); pr.disable()
-st = pstats.Stats(pr); st.sort_stats('tottime').print_stats(22)
+st = pstats.Stats(pr); st.sort_stats('tottime').print_stats(45)

@@ -14,7 +14,9 @@ model = IDRNetwork(ConfigDict(synth.model_conf(bench.W)))
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(bench.W, 0).items()})
 model = model.to(dev).train()
 loss_fn = IDRLoss(); opt = FlatAdam(model.parameters(), lr=0.0)
-inp, gt = bench.make_inputs(dev, 0)
+P_, V_ = bench.WORKLOADS['c2']
+inp, gt = bench.make_inputs(dev, 0, 1, P_, V_)
+if len(sys.argv) > 1 and sys.argv[1] == 'bf16': model.set_trace_dtype('bf16')
 acc = {}
 def tick(name, t0):
     t = time.perf_counter(); acc[name] = acc.get(name, 0.0) + (t - t0); return t
@@ -29,7 +31,7 @@ def step():
     opt.zero_grad(); t = tick('zero', t)
     out = model(inp, bench.TP); t = tick('forward (incl. item wait)', t)
     lo = loss_fn(out, dict(gt), bench.TP, bench.B); t = tick('loss', t)
-    lo['loss'].backward(); t = tick('backward', t)
+    opt.backward(lo['loss']); t = tick('backward', t)
     opt.all_reduce_mean(); opt.step(grad_cap=2.0); t = tick('allreduce+clip+adam', t)
 for _ in range(10): step()
 torch.cuda.synchronize(); acc.clear()
