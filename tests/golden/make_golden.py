@@ -467,3 +467,4 @@ if __name__ == '__main__':
     g_carve(0)
     g_idr_phase0(64, 3, 128, 2, 0, 0.1)
     g_idr(256, 8, 256, 4, 0, 0.3, 'idr_c2')
+    g_idr(256, 8, 1024, 8, 0, 0.3, 'idr_c3')

@@ -34,9 +34,9 @@ def _dsurf_override(model, g):
     model._dsurf_samples = lambda input, n_dsurf_points, bb: (on, jit, torch.full((2,), n, dtype=torch.int64, device='cuda'))
 
 
-@pytest.mark.parametrize('name', ['idr_w64_tp03', 'idr_w64_tp06', 'idr_w256_tp03', 'idr_c2', 'idr_w64_phase0'])
+@pytest.mark.parametrize('name', ['idr_w64_tp03', 'idr_w64_tp06', 'idr_w256_tp03', 'idr_c2', 'idr_c3', 'idr_w64_phase0'])
 def test_forward_loss_backward_vs_reference(name):
-    """idr_c2 = the bench shape (8 views x 256 px, V = 4, 8x256 networks); idr_w64_phase0 = train_progress < 1/6: depth-surface groups
+    """idr_c2 = the bench shape (8 views x 256 px, V = 4, 8x256 networks); idr_c3 = BASELINE configs[2] (8 views x 1024 px = 8192 rays, V = 8); idr_w64_phase0 = train_progress < 1/6: depth-surface groups
     in the depth / eikonal terms, rgb gradient through the features only (idr.py:331-334), no feature / surface loss."""
     g = golden(name)
     W, B, P, V, seed, tp = int(g['W']), int(g['B']), int(g['P']), int(g['V']), int(g['seed']), float(g['tp'])

@@ -241,3 +241,20 @@ def test_high_res_mesh_volume_and_vertex_colours():
     except ImportError:
         with pytest.raises(ImportError):
             plots.get_surface_high_res_mesh_simple(m, None, res)
+
+
+def test_cpu_rng_consumption_is_fixed_per_training_forward():
+    """Documented deviation: a training forward ALWAYS consumes n_steps uniforms (the min-sdf steps,
+    ray_tracing.py:287) and then R/2 x 3 uniforms (eikonal points, idr.py:218) from torch's CPU generator, in the reference's order.  The
+    reference skips the first draw when no intersecting ray is left without a hit (ray_tracing.py:88) -- knowing that on the host would cost
+    a device sync per step.  Whenever some ray needs min-sdf (every fixture; any scene with background rays) the streams are identical."""
+    m = _model(64).train()
+    inp, _ = synth.make_batch(2, 64, 2, seed=3, feat_hw=(60, 80))
+    inp = {k: t(v) for k, v in inp.items()}
+    torch.manual_seed(11)
+    m(inp, 0.3)
+    after = torch.rand(4)
+    torch.manual_seed(11)
+    torch.empty(100).uniform_(0.0, 1.0)
+    torch.empty(64, 3).uniform_(-1.0, 1.0)
+    assert torch.equal(after, torch.rand(4))
