@@ -170,6 +170,18 @@ size_t mvsdf_sdf_bwd_ws_floats(const MvsdfNetDesc* net, int Mb);
 int mvsdf_sdf_backward(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, const float* x, int M, int Mg, int row0, int Mb, const float* dy,
                        const float* dn, const float* ctx, float* dW_cat, float* db_cat, float* dx, float* ws, void* stream);
 
+/* The training step's SDF backward in two chain launches instead of three sequential ones (functional._IdrStep.backward):
+ *   pair   : pass A = full backward over rows [0, MbA) with (dyA[MbA][Nout], dnA[MbA][3]), per-layer adjoints kept in wsA
+ *            (mvsdf_sdf_bwd_ws_floats(net, MbA)); pass X = input adjoint only over rows [row0X, row0X + MbX) with (dyX, dnX) -> dx[MbX][3]
+ *            (scratch wsX).  Independent, ONE grid.  Returns -3 when the fused chain kernels do not cover the network (use mvsdf_sdf_backward).
+ *   finish : delta pass over rows [row0D, row0D + MbD): extra upstream fbar[MbD] on output column 0 only (SampleNetwork's scalar, known
+ *            after pass X), its first-order adjoints are ADDED to wsA's (linearity); dy must already include fbar in column 0 of those rows.
+ *            Then the weight / bias gradients of every layer -> dW_cat, db_cat. */
+int mvsdf_sdf_backward_pair(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, int M, int Mg, int MbA, const float* dyA, const float* dnA, float* wsA,
+                            int row0X, int MbX, const float* dyX, const float* dnX, float* wsX, float* dx, const float* ctx, void* stream);
+int mvsdf_sdf_backward_finish(const MvsdfNetDesc* net, const MvsdfNetDesc* netT, int M, int Mg, int Mb, const float* dy, const float* ctx, float* ws,
+                              int row0D, int MbD, const float* fbar, float* dW_cat, float* db_cat, void* stream);
+
 /* ---- rendering network (idr.py:145-167): rgb = tanh(MLP(cat[points, PE(view), normals, feat])) ----
  * multires_view: low 8 bits = positional-encoding frequencies of the view direction (0: the raw direction); bit 8 (0x100) = mode 'no_view_dir'
  * (input cat[points, normals, feat]); bit 9 (0x200) = mode 'no_normal' (cat[points, PE(view), feat]); neither = mode 'idr'.  The unused input
@@ -243,6 +255,10 @@ int mvsdf_step_backward_inputs(int stage, int n_eik, int n_ds, int N, int Nout, 
                                int din_nrm0, int use_geo, const float* d_diff, const float* dx, const float* view_sorted, const float* n_eval,
                                const long long* true_rows, const float* d_eo, const float* d_gth, const float* d_si, int d_mask, int e_mask,
                                float* dy, float* dn, void* stream);
+/* stage 2 of mvsdf_step_backward_inputs = stage 1 without SampleNetwork's scalar; this adds it afterwards: fbar[i] = -(xbar_i . v_i) / (n_i . v_i)
+ * (sample_network.py:10-20), xbar = d_diff + din[:, 0:3] (if use_geo) + dx, written to fbar[N] and added to dy[(E + i) * Nout]. */
+int mvsdf_step_backward_fbar(int n_eik, int n_ds, int N, int Nout, const float* din, int din_ld, int use_geo, const float* d_diff, const float* dx,
+                             const float* view_sorted, const float* n_eval, float* dy, float* fbar, void* stream);
 
 /* ---- phase-0 depth-surface sampling of IDRNetwork.forward (idr.py:226-247, my_utils.py:71-95) ----
  * Two uniformly random n-subsets (without replacement) of the depth pixels (depths[N][H][W] > 0) whose unprojected, normalised point

@@ -63,9 +63,9 @@ EXPORTS = [
     'mvsdf_sdf_col0', 'mvsdf_camera_rays', 'mvsdf_sphere_intersection', 'mvsdf_trace_workspace_bytes', 'mvsdf_trace_workspace_bytes_n', 'mvsdf_trace', 'mvsdf_trace_stage', 'mvsdf_det_math',
     'mvsdf_tracegen_state_bytes', 'mvsdf_tracegen_init', 'mvsdf_tracegen_step', 'mvsdf_tracegen_finish', 'mvsdf_tracegen_rows', 'mvsdf_tracegen_reduce',
     'mvsdf_tracegen_secant',
-    'mvsdf_sdf_ctx_floats', 'mvsdf_sdf_forward', 'mvsdf_sdf_bwd_ws_floats', 'mvsdf_sdf_backward',
+    'mvsdf_sdf_ctx_floats', 'mvsdf_sdf_forward', 'mvsdf_sdf_bwd_ws_floats', 'mvsdf_sdf_backward', 'mvsdf_sdf_backward_pair', 'mvsdf_sdf_backward_finish',
     'mvsdf_feat_corr', 'mvsdf_depth_carve', 'mvsdf_loss_terms', 'mvsdf_loss_prep', 'mvsdf_loss_scale', 'mvsdf_adam_ws_floats', 'mvsdf_adam_step', 'mvsdf_adam_step_scaled',
-    'mvsdf_partition_rays', 'mvsdf_step_outputs', 'mvsdf_step_backward_inputs', 'mvsdf_dsurf_select', 'mvsdf_dsurf_points',
+    'mvsdf_partition_rays', 'mvsdf_step_outputs', 'mvsdf_step_backward_inputs', 'mvsdf_step_backward_fbar', 'mvsdf_dsurf_select', 'mvsdf_dsurf_points',
     'mvsdf_render_ctx_floats', 'mvsdf_render_bwd_ws_floats', 'mvsdf_render_forward', 'mvsdf_render_backward',
 ]
 

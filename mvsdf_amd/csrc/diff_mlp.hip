@@ -501,6 +501,114 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
     return mv_check(hipGetLastError(), "mvsdf_sdf_backward");
 }
 
+// ---- the training step's SDF backward as two launches of chain passes instead of three sequential ones (functional._IdrStep.backward) ----
+// fill the arguments of one fused chain pass over rows [row0, row0 + Mb) of a forward context
+static void fill_chain_args(ChainArgs& c, const MvNet& net, const MvNet& netT, int S, const SdfLayout& lo, const SdfBwdLayout& bl, const float* ctx,
+                            int row0, int Mb, const float* dy, const float* dn, float* ws, float* dx, const float* w8) {
+    memset(&c, 0, sizeof(c));
+    const int nl = lo.nl;
+    const size_t r0 = (size_t)row0;
+    c.net = net; c.netT = netT; c.S = S; c.M = Mb; c.row_ld0 = lo.ld0;
+    c.dy = dy; c.ld_dy = net.L[nl - 1].N; c.w_last_row0 = w8;
+    for (int l = 0; l < nl - 1; ++l) {
+        c.Z[l] = ctx + lo.Z[l] + r0 * net.L[l].N; c.ZB[l] = ws + bl.ZB[l];
+        c.ZB2[l] = dn ? ws + bl.ZB2[l] : nullptr; c.ZB2o[l] = ws + bl.ZB2[l];
+        if (l + 1 < nl - 1) c.U[l + 1] = ctx + lo.U[l + 1] + r0 * net.L[l].N;
+        c.VB[l + 1] = ws + bl.VB[l + 1];
+    }
+    c.H0B = ws + bl.H0B; c.H0 = ctx + lo.H0 + r0 * lo.ld0; c.G0 = ctx + lo.G0 + r0 * lo.ld0; c.dn_in = dn; c.VB0w = ws + bl.VB[0]; c.dx = dx;
+}
+
+/* Pass A: full first/second-order backward over rows [0, MbA) with upstream (dyA, dnA); keeps every per-layer adjoint in wsA
+ * (mvsdf_sdf_bwd_ws_floats(net, MbA) floats) for mvsdf_sdf_backward_finish -- no weight gradients yet.
+ * Pass X: input adjoint only over rows [row0X, row0X + MbX) with upstream (dyX, dnX) -> dx[MbX][3]; scratch wsX (mvsdf_sdf_bwd_ws_floats(net, MbX)).
+ * The two passes are independent and run as ONE grid.  Returns -3 if the fused chain kernels do not cover this network (caller falls back to
+ * mvsdf_sdf_backward). */
+int mvsdf_sdf_backward_pair(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M, int Mg, int MbA, const float* dyA, const float* dnA, float* wsA,
+                            int row0X, int MbX, const float* dyX, const float* dnX, float* wsX, float* dx, const float* ctx, void* stream) {
+    MvNet net, netT;
+    int rc = mv_make_net(d, &net);
+    if (rc) return rc;
+    rc = mv_make_net_mode(dT, &netT, 2);
+    if (rc) return rc;
+    if (!dyA || !dnA || !wsA || !dyX || !wsX || !dx || !ctx || MbA <= 0 || MbX <= 0 || MbA > Mg || row0X < 0 || row0X + MbX > Mg || Mg > M)
+        return mv_fail(-1, "mvsdf_sdf_backward_pair: bad arguments");
+    const int ntw_b = mv_chain_ntw(net);
+    if (!ntw_b) return mv_fail(-3, "mvsdf_sdf_backward_pair: network too wide for the fused chain kernels");
+    const float* w8 = d->w[net.n_layers - 1];
+    if (!w8) return mv_fail(-1, "mvsdf_sdf_backward_pair: row-major last-layer weights missing");
+    hipStream_t s = (hipStream_t)stream;
+    const SdfLayout lo = sdf_ctx_layout(net, M, Mg);
+    const int S = stride_for(net, netT);
+    ChainArgs a, b;
+    fill_chain_args(a, net, netT, S, lo, sdf_bwd_layout(net, MbA), ctx, 0, MbA, dyA, dnA, wsA, nullptr, w8);
+    fill_chain_args(b, net, netT, S, lo, sdf_bwd_layout(net, MbX), ctx, row0X, MbX, dyX, dnX, wsX, dx, w8);
+    const size_t lds = (size_t)16 * (S + lo.d0) * sizeof(float);
+    const int na = (MbA + 15) / 16, nb = (MbX + 15) / 16;
+    const bool w8w = mv_chain_w8();
+    const dim3 grid(na + nb);
+    if (ntw_b == 2 && !w8w) hipLaunchKernelGGL((k_chain_bwd2<1, 1, 16>), grid, dim3(1024), lds, s, a, b, na);
+    else if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd2<1, 2, 8>), grid, dim3(512), lds, s, a, b, na);
+    else if (!w8w) hipLaunchKernelGGL((k_chain_bwd2<1, 2, 16>), grid, dim3(1024), lds, s, a, b, na);
+    else hipLaunchKernelGGL((k_chain_bwd2<1, 4, 8>), grid, dim3(512), lds, s, a, b, na);
+    return mv_check(hipGetLastError(), "mvsdf_sdf_backward_pair");
+}
+
+/* Completes pass A of mvsdf_sdf_backward_pair: (1) delta pass over rows [row0D, row0D + MbD) whose extra upstream is ONE scalar per row on
+ * output column 0 (fbar[MbD]: SampleNetwork's term, known only after pass X): by linearity its zbar_l are ADDED to the stored ones (first-order
+ * descending chain only); dy[(row0D + i) * Nout] must already include fbar[i] (it feeds the last layer's weight gradient).  (2) weight / bias
+ * gradients of every layer from the stored adjoints -> dW_cat, db_cat.  MbD = 0 skips (1). */
+int mvsdf_sdf_backward_finish(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M, int Mg, int Mb, const float* dy, const float* ctx, float* ws,
+                              int row0D, int MbD, const float* fbar, float* dW_cat, float* db_cat, void* stream) {
+    MvNet net, netT;
+    int rc = mv_make_net(d, &net);
+    if (rc) return rc;
+    rc = mv_make_net_mode(dT, &netT, 2);
+    if (rc) return rc;
+    if (!dy || !ctx || !ws || !dW_cat || !db_cat || Mb <= 0 || Mb > Mg || Mg > M || MbD < 0 || row0D < 0 || row0D + MbD > Mb || (MbD > 0 && !fbar))
+        return mv_fail(-1, "mvsdf_sdf_backward_finish: bad arguments");
+    const int ntw_b = mv_chain_ntw(net);
+    if (!ntw_b) return mv_fail(-3, "mvsdf_sdf_backward_finish: network too wide for the fused chain kernels");
+    hipStream_t s = (hipStream_t)stream;
+    const SdfLayout lo = sdf_ctx_layout(net, M, Mg);
+    const SdfBwdLayout bl = sdf_bwd_layout(net, Mb);
+    const int nl = lo.nl, S = stride_for(net, netT);
+    if (MbD > 0) {
+        ChainArgs c;
+        memset(&c, 0, sizeof(c));
+        const size_t r0 = (size_t)row0D;
+        c.net = net; c.netT = netT; c.S = S; c.M = MbD; c.row_ld0 = lo.ld0;
+        c.ld_dy = net.L[nl - 1].N; c.dy_col0 = fbar; c.accum = 1;
+        for (int l = 0; l < nl - 1; ++l) { c.Z[l] = ctx + lo.Z[l] + r0 * net.L[l].N; c.ZB[l] = ws + bl.ZB[l] + r0 * net.L[l].N; }
+        const size_t lds = (size_t)16 * (S + lo.d0) * sizeof(float);
+        const bool w8w = mv_chain_w8();
+        const dim3 grid((MbD + 15) / 16);
+        if (ntw_b == 2 && !w8w) hipLaunchKernelGGL((k_chain_bwd<1, 1, 16>), grid, dim3(1024), lds, s, c);
+        else if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd<1, 2, 8>), grid, dim3(512), lds, s, c);
+        else if (!w8w) hipLaunchKernelGGL((k_chain_bwd<1, 2, 16>), grid, dim3(1024), lds, s, c);
+        else hipLaunchKernelGGL((k_chain_bwd<1, 4, 8>), grid, dim3(512), lds, s, c);
+        MV_TRY(hipGetLastError());
+    }
+    WgradNetArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.n_layers = nl; wa.M = Mb; wa.chunk = bl.chunk; wa.nchunks = bl.nchunks;
+    for (int l = 0; l < nl; ++l) {
+        WgradLayer& L = wa.L[l];
+        const bool last = (l == nl - 1);
+        L.No = net.L[l].N; L.Ki = net.L[l].K;
+        L.P1 = last ? dy : ws + bl.ZB[l]; L.ldp1 = L.No;
+        L.Q1 = l == 0 ? ctx + lo.H0 : ctx + lo.A[l]; L.ldq1 = l == 0 ? lo.ld0 : net.L[l].K;
+        if (!last) { L.P2 = ctx + lo.Sg[l]; L.ldp2 = L.No; L.Q2 = ws + bl.VB[l]; L.ldq2 = L.ldq1; }
+    }
+    wa.slab = ws + bl.slabA; wa.bslab = ws + bl.bslab;
+    wa.dW = dW_cat; wa.db = db_cat;
+    const int Ki = net.L[nl - 1].K;                                                // W_last[0, :] += sum_rows ubar_last   (E.1 end)
+    hipLaunchKernelGGL(k_colsum, dim3((Ki + 63) / 64, bl.nchunks), dim3(256), 0, s, ws + bl.VB[nl - 1], Ki, Mb, Ki, bl.chunk, ws + bl.slabB);
+    wa.colslab = ws + bl.slabB; wa.col_n = Ki;
+    MV_TRY(launch_wgrad_net(wa, s));
+    return mv_check(hipGetLastError(), "mvsdf_sdf_backward_finish");
+}
+
 }  // extern "C"
 
 // ================================================================================================ rendering network

@@ -439,6 +439,9 @@ struct ChainArgs {
     const float* dn_in;                        // [M][3] upstream of the normals (null: E.2 only)
     float* VB0w;                               // vbar_0 out [M][row_ld0]
     float* dx;                                 // [M][3] input adjoint (null: not needed)
+    // delta pass (E.2 only, dn_in == NULL): the upstream is one scalar per row on output column 0, and zbar_l is ADDED to the stored one
+    const float* dy_col0;                      // [M] (null: the full dy)
+    int accum;                                 // 1: ZB[l] += zbar_l (H0B may be null: not written)
 };
 
 // E.2 (descending): hb_L = dy W_L;  for l = L-1..0: zb_l = sigma_l . hb_{l+1} + zb2_l (stored), ab_l = zb_l W_l, split at the skip layer.
@@ -463,11 +466,11 @@ __global__ __launch_bounds__(64 * NW) void k_chain_e2(ChainArgs a) {
                 const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
                 v[u] = 0.0f;
                 if (idx < ROWS * Kp && row < a.M && k < K) {
-                    if (l == nl - 1) v[u] = a.dy[(size_t)row * a.ld_dy + k];
+                    if (l == nl - 1) v[u] = a.dy_col0 ? (k == 0 ? a.dy_col0[row] : 0.0f) : a.dy[(size_t)row * a.ld_dy + k];
                     else {
                         float zb = dm_sigmoid100(a.Z[l][(size_t)row * K + k]) * act[rr * S + mv_perm(k)];
                         if (a.ZB2[l]) zb += a.ZB2[l][(size_t)row * K + k];
-                        a.ZB[l][(size_t)row * K + k] = zb;
+                        a.ZB[l][(size_t)row * K + k] = a.accum ? a.ZB[l][(size_t)row * K + k] + zb : zb;   // the GEMM below continues with this pass's zbar
                         v[u] = zb;
                     }
                 }
@@ -610,11 +613,10 @@ __global__ __launch_bounds__(64 * NW) void k_chain_e1(ChainArgs a) {
 // descending E.2 chain and the input adjoint xbar = J_PE^T hbar_0 + second-order PE term (k_pe_input_bwd, App. E.3).  Same arithmetic
 // as those four launches; z_l bar 2 (E.1 -> E.2) goes through global memory of the same workgroup (L2-hot).  dn_in == NULL: E.2 only.
 template <int MT, int NTW, int NW>
-__global__ __launch_bounds__(64 * NW) void k_chain_bwd(ChainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, float* smem) {
     constexpr int ROWS = 16 * MT, NTH = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers, sk = a.net.skip_layer, d0 = 3 + 6 * a.net.multires;
+    const int row0 = blk * ROWS, S = a.S, nl = a.net.n_layers, sk = a.net.skip_layer, d0 = 3 + 6 * a.net.multires;
     float* act = smem;
     float* g0s = smem + ROWS * S;                                // [ROWS][d0]: gbar_0 (E.1), then the PE adjoint (E.2)
     float* pe_adj = g0s;
@@ -724,11 +726,11 @@ __global__ __launch_bounds__(64 * NW) void k_chain_bwd(ChainArgs a) {
                 const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
                 v[u] = 0.0f;
                 if (idx < ROWS * Kp && row < a.M && k < K) {
-                    if (l == nl - 1) v[u] = a.dy[(size_t)row * a.ld_dy + k];
+                    if (l == nl - 1) v[u] = a.dy_col0 ? (k == 0 ? a.dy_col0[row] : 0.0f) : a.dy[(size_t)row * a.ld_dy + k];
                     else {
                         float zb = dm_sigmoid100(a.Z[l][(size_t)row * K + k]) * act[rr * S + mv_perm(k)];
                         if (a.ZB2[l]) zb += a.ZB2[l][(size_t)row * K + k];
-                        a.ZB[l][(size_t)row * K + k] = zb;
+                        a.ZB[l][(size_t)row * K + k] = a.accum ? a.ZB[l][(size_t)row * K + k] + zb : zb;   // the GEMM below continues with this pass's zbar
                         v[u] = zb;
                     }
                 }
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_bwd(ChainArgs a) {
                             } else if (l == 0) {
                                 const float hb0 = pe_adj[rr * d0 + col] + v;
                                 pe_adj[rr * d0 + col] = hb0;                       // kept for the input adjoint below
-                                if (row < a.M) a.H0B[(size_t)row * a.row_ld0 + col] = hb0;
+                                if (row < a.M && a.H0B) a.H0B[(size_t)row * a.row_ld0 + col] = hb0;
                             } else {
                                 act[rr * S + mv_perm(col)] = v;
                             }
@@ -799,6 +801,22 @@ __global__ __launch_bounds__(64 * NW) void k_chain_bwd(ChainArgs a) {
             a.dx[(size_t)row * 3 + c] = v;
         }
     }
+}
+
+template <int MT, int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_chain_bwd(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    mv_chain_bwd_body<MT, NTW, NW>(a, blockIdx.x, smem);
+}
+
+// Two independent passes in one grid (workgroups [0, na) run `a`, the rest run `b`): the full pass over [samples | hit rays] and the
+// input-adjoint-only pass over the hit rays do not depend on each other (see functional._IdrStep.backward) and together fill the chip.
+static_assert(2 * sizeof(ChainArgs) + 16 <= 4096, "kernel arguments of k_chain_bwd2 exceed 4 KiB");
+template <int MT, int NTW, int NW>
+__global__ __launch_bounds__(64 * NW) void k_chain_bwd2(ChainArgs a, ChainArgs b, int na) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < na) mv_chain_bwd_body<MT, NTW, NW>(a, blockIdx.x, smem);
+    else mv_chain_bwd_body<MT, NTW, NW>(b, blockIdx.x - na, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -134,6 +134,8 @@ struct StepBwdArgs {
     const long long* true_rows;
     const float* d_eo; const float* d_gth; const float* d_si;          // upstream of eikonal_output / grad_theta / surf (null: none)
     float* dy; float* dn;                 // [Mb][Nout], [Mb][3]
+    int no_fbar;                          // stage 1 without SampleNetwork's term (added later by k_step_bwd_fbar)
+    float* fbar;                          // k_step_bwd_fbar: [N]
 };
 __global__ void k_step_bwd_stage0(StepBwdArgs a) {
     const size_t total = (size_t)a.Mb * (a.Nout + 3);
@@ -168,7 +170,7 @@ __global__ void k_step_bwd_stage1(StepBwdArgs a) {
                 v[c] = -a.view_sorted[3 * (size_t)k + c];
             }
             for (int c = 0; c < 3; ++c) { num += xb[c] * v[c]; dot += a.n_eval[3 * (size_t)row + c] * v[c]; }
-            float add = -num / dot;
+            float add = a.no_fbar ? 0.0f : -num / dot;
             if (a.d_eo && (a.d_mask & 1)) add += a.d_eo[k];                  // the hit group leads eikonal_output when selected
             a.dy[(size_t)row * a.Nout] += add;
         } else if (i < seg1) {
@@ -183,6 +185,25 @@ __global__ void k_step_bwd_stage1(StepBwdArgs a) {
             a.dy[(size_t)row * a.Nout + 1] += a.d_si[k];
         }
     }
+}
+
+// SampleNetwork's scalar alone (sample_network.py:10-20 backward): fbar_i = -(xbar_i . v_i) / (n_i . v_i), xbar = d_diff + dp + dx; written to
+// fbar[i] and added to dy[E + i][0]
+__global__ void k_step_bwd_fbar(StepBwdArgs a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.N) return;
+    const int row = a.E + k;
+    float dot = 0.f, num = 0.f;
+    for (int c = 0; c < 3; ++c) {
+        float xb = (a.d_diff ? a.d_diff[3 * (size_t)k + c] : 0.f);
+        if (a.din && a.use_geo) xb += a.din[(size_t)k * a.din_ld + c];
+        if (a.dx) xb += a.dx[3 * (size_t)k + c];
+        const float v = -a.view_sorted[3 * (size_t)k + c];
+        num += xb * v; dot += a.n_eval[3 * (size_t)row + c] * v;
+    }
+    const float f = -num / dot;
+    a.fbar[k] = f;
+    a.dy[(size_t)row * a.Nout] += f;
 }
 
 extern "C" {
@@ -219,7 +240,7 @@ int mvsdf_step_backward_inputs(int stage, int n_eik, int n_ds, int N, int Nout, 
                                const long long* true_rows, const float* d_eo, const float* d_gth, const float* d_si, int d_mask, int e_mask,
                                float* dy, float* dn, void* stream) {
     const int E = n_eik + 2 * n_ds;
-    if (n_eik < 0 || n_ds < 0 || N < 0 || E + N <= 0 || !dy || !dn || (stage != 0 && stage != 1) || (stage == 1 && N > 0 && (!view_sorted || !n_eval)) ||
+    if (n_eik < 0 || n_ds < 0 || N < 0 || E + N <= 0 || !dy || !dn || (stage < 0 || stage > 2) || (stage == 1 && N > 0 && (!view_sorted || !n_eval)) ||
         (d_mask & ~15) || (e_mask & ~15))
         return mv_fail(-1, "mvsdf_step_backward_inputs: bad arguments");
     StepBwdArgs a;
@@ -228,6 +249,7 @@ int mvsdf_step_backward_inputs(int stage, int n_eik, int n_ds, int N, int Nout, 
     a.din = din; a.din_ld = din_ld; a.din_feat0 = din_feat0; a.din_nrm0 = din_nrm0; a.use_geo = use_geo;
     a.d_diff = d_diff; a.dx = dx; a.view_sorted = view_sorted; a.n_eval = n_eval; a.true_rows = true_rows;
     a.d_eo = d_eo; a.d_gth = d_gth; a.d_si = d_si; a.dy = dy; a.dn = dn;
+    a.no_fbar = stage == 2;                                                    // stage 2 = stage 1 minus SampleNetwork's term (mvsdf_step_backward_fbar adds it)
     hipStream_t s = (hipStream_t)stream;
     if (stage == 0) {
         const size_t total = (size_t)a.Mb * (Nout + 3);
@@ -238,6 +260,17 @@ int mvsdf_step_backward_inputs(int stage, int n_eik, int n_ds, int N, int Nout, 
         if (total > 0) hipLaunchKernelGGL(k_step_bwd_stage1, dim3((total + 255) / 256), dim3(256), 0, s, a);
     }
     return mv_check(hipGetLastError(), "mvsdf_step_backward_inputs");
+}
+
+int mvsdf_step_backward_fbar(int n_eik, int n_ds, int N, int Nout, const float* din, int din_ld, int use_geo, const float* d_diff, const float* dx,
+                             const float* view_sorted, const float* n_eval, float* dy, float* fbar, void* stream) {
+    if (n_eik < 0 || n_ds < 0 || N <= 0 || !view_sorted || !n_eval || !dy || !fbar) return mv_fail(-1, "mvsdf_step_backward_fbar: bad arguments");
+    StepBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.E = n_eik + 2 * n_ds; a.N = N; a.Nout = Nout; a.din = din; a.din_ld = din_ld; a.use_geo = use_geo; a.d_diff = d_diff; a.dx = dx;
+    a.view_sorted = view_sorted; a.n_eval = n_eval; a.dy = dy; a.fbar = fbar;
+    hipLaunchKernelGGL(k_step_bwd_fbar, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return mv_check(hipGetLastError(), "mvsdf_step_backward_fbar");
 }
 
 }  // extern "C"

@@ -366,12 +366,27 @@ class _IdrStep(torch.autograd.Function):
             dWr, dbr, din = ops.render_backward(rnet, N, d_rgbv[st.perm[:N]], st.rsaved, n_ctx=R)
         common = (st.n_eik, st.n_ds, N, Nout, st.n_true, din, feat0, nrm0, use_geo)
         ops.step_backward_inputs(0, *common, None, None, st.view_sorted, st.n_eval, st.true_rows, None, None, None, st.d_mask, st.e_mask, dy, dn)
-        if din is not None:
-            # adjoint of the surface points through features (+ normals): input adjoint only, rows [E, E+N)
-            _, _, dx = ops.sdf_backward(net, st.x_eval, M, M, N, dy[E:], dn[E:] if use_geo else None, st.saved, True, want_dw=False, row0=E)
-        ops.step_backward_inputs(1, *common, d_diff, dx, st.view_sorted, st.n_eval, st.true_rows, d_eo, d_gth, d_si, st.d_mask, st.e_mask,
-                                 dy, dn)
-        dWs, dbs, _ = ops.sdf_backward(net, st.x_eval, M, M, Mb, dy, dn, st.saved, False)
+        dWs = None
+        if din is not None and N > 0:
+            # The adjoint of the surface points needs ONE input-adjoint pass over the hit rows with the rendering net's upstream alone
+            # (features + normals, rows [E, E+N)); SampleNetwork's scalar fbar = -xbar.v / n.v (App. E.6) then enters output column 0 of
+            # the same rows.  By linearity the full backward is (A) a pass with every upstream EXCEPT fbar, which does not depend on the
+            # input-adjoint pass and shares a launch with it, plus (B) a short first-order delta pass for fbar added to A's stored adjoints.
+            dy_x, dn_x = dy[E:].clone(), (dn[E:].clone() if use_geo else None)
+            ops.step_backward_inputs(2, *common, d_diff, None, st.view_sorted, st.n_eval, st.true_rows, d_eo, d_gth, d_si, st.d_mask, st.e_mask, dy, dn)
+            pair = ops.sdf_backward_pair(net, M, M, Mb, dy, dn, E, N, dy_x, dn_x, st.saved)
+            if pair is not None:
+                wsA, dx = pair
+                fbar = ops.step_backward_fbar(st.n_eik, st.n_ds, N, Nout, din, use_geo, d_diff, dx, st.view_sorted, st.n_eval, dy)
+                dWs, dbs = ops.sdf_backward_finish(net, M, M, Mb, dy, st.saved, wsA, E, N, fbar)
+            else:                                                # network too wide for the fused chains: the sequential route
+                _, _, dx = ops.sdf_backward(net, st.x_eval, M, M, N, dy_x, dn_x, st.saved, True, want_dw=False, row0=E)
+                ops.step_backward_fbar(st.n_eik, st.n_ds, N, Nout, din, use_geo, d_diff, dx, st.view_sorted, st.n_eval, dy)
+        else:
+            ops.step_backward_inputs(1, *common, d_diff, None, st.view_sorted, st.n_eval, st.true_rows, d_eo, d_gth, d_si, st.d_mask, st.e_mask,
+                                     dy, dn)
+        if dWs is None:
+            dWs, dbs, _ = ops.sdf_backward(net, st.x_eval, M, M, Mb, dy, dn, st.saved, False)
         if dWr is None:
             dWr = [torch.zeros_like(L.w) for L in rnet.layers]
             dbr = [torch.zeros_like(L.bias) for L in rnet.layers]

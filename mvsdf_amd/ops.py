@@ -25,6 +25,11 @@ class PackedNet:
         self.trace_dtype = 0                # 1: the tracing MLP runs on the bf16 packs (pack_bf16_net)
 
     def desc(self, transposed=False):
+        """ctypes descriptor (cached: a PackedNet is immutable once its packs exist; pack_bf16_net drops the cache)."""
+        key = ('_dT' if transposed else '_d')
+        c = self.__dict__.get(key)
+        if c is not None:
+            return c
         d = NetDesc()
         d.n_layers = len(self.layers)
         for i, L in enumerate(self.layers):
@@ -37,6 +42,7 @@ class PackedNet:
             for i, L in enumerate(self.layers):
                 d.wp16[i] = L.wp16.data_ptr()
             d.trace_dtype = 1
+        self.__dict__[key] = d
         return d
 
     def wsizes(self):
@@ -136,6 +142,7 @@ def pack_bf16_net(net):
     check(lib().mvsdf_pack_bf16_net(n, _ptr_array([L.w for L in net.layers]), N, K, net.skip_layer, net.multires,
                                     _ptr_array([L.wp16 for L in net.layers]), stream_of(net.layers[0].w)), 'mvsdf_pack_bf16_net')
     net.trace_dtype = 1
+    net.__dict__.pop('_d', None)
     return net
 
 
@@ -267,6 +274,43 @@ def sdf_backward(net, x, M, Mg, Mb, dy, dn, ctx, want_dx, want_dw=True, row0=0):
         return None, None, dx
     dWs, dbs = _split_cat(net, dW, db)
     return dWs, dbs, dx
+
+
+def sdf_backward_pair(net, M, Mg, MbA, dyA, dnA, row0X, MbX, dyX, dnX, ctx):
+    """Pass A (full backward over rows [0, MbA), adjoints kept in the returned workspace) and pass X (input adjoint of rows
+    [row0X, row0X + MbX) for the upstream (dyX, dnX)) as ONE grid.  -> (wsA, dx[MbX,3]) or None when the fused chains do not cover the net."""
+    dev = dyA.device
+    d, dT = net.desc(), net.desc(True)
+    wsA = torch.empty(lib().mvsdf_sdf_bwd_ws_floats(C.byref(d), MbA), dtype=torch.float32, device=dev)
+    wsX = torch.empty(lib().mvsdf_sdf_bwd_ws_floats(C.byref(d), MbX), dtype=torch.float32, device=dev)
+    dx = torch.empty(MbX, 3, dtype=torch.float32, device=dev)
+    rc = lib().mvsdf_sdf_backward_pair(C.byref(d), C.byref(dT), M, Mg, MbA, ptr(_f32(dyA)), ptr(_f32(dnA)), ptr(wsA), row0X, MbX, ptr(_f32(dyX)),
+                                       ptr(_f32(dnX)) if dnX is not None else None, ptr(wsX), ptr(dx), ptr(ctx), stream_of(dyA))
+    if rc == -3:
+        return None
+    check(rc, 'mvsdf_sdf_backward_pair')
+    return wsA, dx
+
+
+def sdf_backward_finish(net, M, Mg, Mb, dy, ctx, wsA, row0D, MbD, fbar):
+    """Delta pass (fbar on output column 0 of rows [row0D, row0D + MbD), added to the stored adjoints) + weight gradients -> (dWs, dbs)."""
+    dev = dy.device
+    d, dT = net.desc(), net.desc(True)
+    ws_n, bs_n = net.wsizes()
+    dW = torch.empty(sum(ws_n), dtype=torch.float32, device=dev)
+    db = torch.empty(sum(bs_n), dtype=torch.float32, device=dev)
+    check(lib().mvsdf_sdf_backward_finish(C.byref(d), C.byref(dT), M, Mg, Mb, ptr(dy), ptr(ctx), ptr(wsA), row0D, MbD, ptr(fbar) if MbD > 0 else None,
+                                          ptr(dW), ptr(db), stream_of(dy)), 'mvsdf_sdf_backward_finish')
+    return _split_cat(net, dW, db)
+
+
+def step_backward_fbar(n_eik, n_ds, N, Nout, din, use_geo, d_diff, dx, view_sorted, n_eval, dy):
+    """SampleNetwork's scalar per hit row (sample_network.py:10-20 backward): -> fbar[N]; also added to dy[(E + i), 0]."""
+    o = lambda t: None if t is None else ptr(_f32(t))
+    fbar = torch.empty(N, dtype=torch.float32, device=dy.device)
+    check(lib().mvsdf_step_backward_fbar(n_eik, n_ds, N, Nout, o(din), din.shape[1] if din is not None else 0, 1 if use_geo else 0, o(d_diff), o(dx),
+                                         ptr(view_sorted), ptr(n_eval), ptr(dy), ptr(fbar), stream_of(dy)), 'mvsdf_step_backward_fbar')
+    return fbar
 
 
 def render_forward(net, points, view, normals, feat, multires_view):
