@@ -230,15 +230,19 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
 // and each group's epilogue (softplus, LDS writes, bias loads, ring fill of the next GEMM) hides under the other group's MFMAs.  No
 // workgroup barriers inside: per-layer LDS counters (gemm done / activations published, per group), activations ping-pong between two
 // buffers.  Same arithmetic in the same order as mv_sdf_eval_col0: bit-identical.
+// The flags live in LDS: the accesses are made through explicit LDS (address space 3) pointers -- a generic pointer would compile to
+// flat loads / flat atomics, which are tracked by vmcnt too: every poll would then wait for the weight prefetches in flight.
+typedef __attribute__((address_space(3))) int mv_lds_int;
 __device__ __forceinline__ void mv_ks_wait(const int* f, int target) {
-    while (__builtin_amdgcn_readfirstlane(*(const volatile int*)f) < target) __builtin_amdgcn_s_sleep(1);
+    const volatile mv_lds_int* p = (const volatile mv_lds_int*)f;
+    while (__builtin_amdgcn_readfirstlane(*p) < target) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");                              // later LDS reads stay behind the wait
 }
 // The LDS operations of one wave are processed in issue order, so the counter update lands after the wave's earlier LDS writes; the
 // asm only keeps the compiler from reordering (and drains this wave's LDS queue, NOT its outstanding global loads).
 __device__ __forceinline__ void mv_ks_signal(int* f, int lane) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_fetch_add((mv_lds_int*)f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // mv_gemm_ring with a wait before the first LDS read of k-block kA (the weight loads of the ring keep flowing across the wait)
