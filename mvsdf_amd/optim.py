@@ -50,6 +50,7 @@ class FlatAdam(torch.optim.Optimizer):
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                 p.grad = self.flat_g[off:off + n].view(p.shape)
             p._mv_grad_sink = True                                                      # functional._FoldNet adds into p.grad directly
+        self._grad_views = [p.grad for p in self.param_groups[0]['params']]            # identity check in _sync_grads
 
     def _attach_state(self):
         for p, (off, n) in zip(self.param_groups[0]['params'], self._slices):
@@ -60,7 +61,8 @@ class FlatAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         """One memset of the flat gradient buffer; gradients stay attached (views) whatever `set_to_none` says."""
         self.flat_g.zero_()
-        self._attach_grads()
+        if not all(p.grad is v for p, v in zip(self.param_groups[0]['params'], self._grad_views)):
+            self._attach_grads()
 
     def backward(self, loss):
         """loss.backward() with the direct gradient sink on (functional.grad_sink): the weight_norm-fold backward adds dv / dg / db of
@@ -74,15 +76,20 @@ class FlatAdam(torch.optim.Optimizer):
         or `p.grad = None` detach them: autograd then allocates fresh .grad tensors.  Copy such strays in and re-attach.  A parameter
         WITHOUT a gradient counts as a zero gradient, i.e. it still moves by its momentum -- what the reference's pinned torch 1.7.1
         does (its zero_grad() zero-fills, idr_train.py:283), whereas torch >= 2.0's Adam would skip a None gradient."""
+        views = self._grad_views
+        if all(p.grad is v for p, v in zip(self.param_groups[0]['params'], views)):     # the common case: nothing was detached
+            return
         base = self.flat_g.data_ptr()
-        for p, (off, n) in zip(self.param_groups[0]['params'], self._slices):
+        for i, (p, (off, n)) in enumerate(zip(self.param_groups[0]['params'], self._slices)):
             if p.grad is None:
                 self.flat_g[off:off + n].zero_()
             elif p.grad.data_ptr() != base + 4 * off:
                 self.flat_g[off:off + n].copy_(p.grad.detach().reshape(-1))
             else:
+                views[i] = p.grad
                 continue
             p.grad = self.flat_g[off:off + n].view(p.shape)
+            views[i] = p.grad
 
     def all_reduce_mean(self):
         """The step's one gradient collective (RCCL over xGMI): SUM all-reduce of the flat gradient buffer; the 1 / world that makes it
