@@ -74,6 +74,61 @@ class _FoldNet(torch.autograd.Function):
         return (None,) + tuple(dvs) + tuple(dg.view_as(g) if g is not None else None for dg, g in zip(dgs, gs)) + tuple(dbs)
 
 
+class _FoldNetFlat(torch.autograd.Function):
+    """_FoldNet for the training step: the folded weights of all networks are ONE tensor [W | b per network] (ops.FoldPlan), so the step's
+    autograd graph has one edge into the fold instead of one per layer tensor, its backward receives one flat gradient (the backward kernels
+    already emit dW_cat / db_cat per network) and all per-layer bookkeeping is pointer arithmetic on cached ctypes arrays."""
+
+    @staticmethod
+    def forward(ctx, plan, holders, *vgb):
+        n = plan.n
+        flat, packs = ops.fold_pack_net_flat(plan, vgb[:n], vgb[n:2 * n], holders)
+        for L in holders:
+            L.wp16 = None
+            L.keep = packs                                       # the layers carry raw pointers into `packs` / `flat`: keep both alive with them
+        ctx.plan, ctx.params = plan, vgb
+        return flat
+
+    @staticmethod
+    def backward(ctx, dflat):
+        plan, vgb = ctx.plan, ctx.params
+        n = plan.n
+        vs, gs, bs = vgb[:n], vgb[n:2 * n], vgb[2 * n:]
+        sink = grad_sink.depth > 0 and all(getattr(p, '_mv_grad_sink', False) and p.requires_grad for p in vgb if p is not None)
+        res = ops.fold_backward_net_flat(plan, vs, gs, bs, dflat.contiguous(), sink)
+        if res is None:
+            return (None,) * (2 + 3 * n)
+        dvs, dgs, dbs = res
+        return (None, None) + tuple(dvs) + tuple(dg.view_as(g) if g is not None else None for dg, g in zip(dgs, gs)) + tuple(dbs)
+
+
+def fold_networks_flat(specs, cache):
+    """fold_networks with the folded parameters of all networks in one flat tensor.  cache: a dict owned by the model (keeps the FoldPlan).
+    -> (flat, plan, [PackedNet per spec])."""
+    shapes, cuts, vs_all, gs_all, bs_all = [], [], [], [], []
+    for vs, gs, bs, _, _ in specs:
+        shapes += [tuple(v.shape) for v in vs]
+        cuts.append(len(shapes))
+        vs_all += list(vs); gs_all += list(gs); bs_all += list(bs)
+    plan = cache.get('plan')
+    if plan is None or plan.shapes != shapes:
+        plan = cache['plan'] = ops.FoldPlan(shapes, cuts)
+    layers = []
+    for v, b in zip(vs_all, bs_all):
+        L = ops.PackedLayer()
+        L.bias = b.detach()
+        L.N, L.K = v.shape
+        layers.append(L)
+    flat = _FoldNetFlat.apply(plan, layers, *vs_all, *gs_all, *bs_all)
+    nets, lo = [], 0
+    for (vs, gs, bs, skip_layer, multires), hi in zip(specs, cuts):
+        nets.append(ops.PackedNet(layers[lo:hi], skip_layer, multires))
+        lo = hi
+    for net in nets:
+        net._keep = flat                                         # raw pointers into `flat` / its packs: keep them alive with the net
+    return flat, plan, nets
+
+
 def fold_networks(specs):
     """Several networks folded by ONE autograd node (one fold launch + one pack launch forward, one launch backward).
     specs: list of (vs, gs, bs, skip_layer, multires) -> list of (PackedNet, [w linked to autograd], [biases linked to autograd])."""
@@ -322,7 +377,7 @@ class StepState:
     """Everything the fused training step needs besides the (folded) parameters."""
     __slots__ = ('net', 'rnet', 'x_eval', 'y_eval', 'n_eval', 'saved', 'R', 'E', 'N', 'n_true', 'n_eik', 'n_ds', 'inv', 'perm', 'true_rows',
                  'view_sorted', 'counts_dev', 'wait_counts', 'd_mask', 'e_mask', 'detach_geo', 'multires_view', 'rsaved', 'sdf_output',
-                 'points_hom')
+                 'points_hom', 'plan')
 
 
 class _IdrStep(torch.autograd.Function):
@@ -362,8 +417,16 @@ class _IdrStep(torch.autograd.Function):
         dWr = dbr = din = dx = None
         use_geo = not st.detach_geo                                               # idr.py:329-336: features always carry the rgb gradient
         nrm0, feat0 = render_offsets(st.multires_view)
+        plan = getattr(st, 'plan', None)                                          # flat mode: ONE gradient tensor [dW | db per network]
+        out_s = out_r = dflat = None
+        if plan is not None:
+            dflat = torch.empty(plan.total, dtype=torch.float32, device=dev)
+            (w0, b0, e0), (w1, b1, e1) = plan.seg
+            out_s, out_r = (dflat[w0:b0], dflat[b0:e0]), (dflat[w1:b1], dflat[b1:e1])
         if N > 0 and d_rgbv is not None:
-            dWr, dbr, din = ops.render_backward(rnet, N, d_rgbv[st.perm[:N]], st.rsaved, n_ctx=R)
+            dWr, dbr, din = ops.render_backward(rnet, N, d_rgbv[st.perm[:N]], st.rsaved, n_ctx=R, out=out_r)
+        elif plan is not None:
+            dflat[w1:e1].zero_()
         common = (st.n_eik, st.n_ds, N, Nout, st.n_true, din, feat0, nrm0, use_geo)
         ops.step_backward_inputs(0, *common, None, None, st.view_sorted, st.n_eval, st.true_rows, None, None, None, st.d_mask, st.e_mask, dy, dn)
         dWs = None
@@ -378,7 +441,8 @@ class _IdrStep(torch.autograd.Function):
             if pair is not None:
                 wsA, dx = pair
                 fbar = ops.step_backward_fbar(st.n_eik, st.n_ds, N, Nout, din, use_geo, d_diff, dx, st.view_sorted, st.n_eval, dy)
-                dWs, dbs = ops.sdf_backward_finish(net, M, M, Mb, dy, st.saved, wsA, E, N, fbar)
+                res = ops.sdf_backward_finish(net, M, M, Mb, dy, st.saved, wsA, E, N, fbar, out=out_s)
+                dWs, dbs = res if res is not None else ((), ())
             else:                                                # network too wide for the fused chains: the sequential route
                 _, _, dx = ops.sdf_backward(net, st.x_eval, M, M, N, dy_x, dn_x, st.saved, True, want_dw=False, row0=E)
                 ops.step_backward_fbar(st.n_eik, st.n_ds, N, Nout, din, use_geo, d_diff, dx, st.view_sorted, st.n_eval, dy)
@@ -386,7 +450,9 @@ class _IdrStep(torch.autograd.Function):
             ops.step_backward_inputs(1, *common, d_diff, None, st.view_sorted, st.n_eval, st.true_rows, d_eo, d_gth, d_si, st.d_mask, st.e_mask,
                                      dy, dn)
         if dWs is None:
-            dWs, dbs, _ = ops.sdf_backward(net, st.x_eval, M, M, Mb, dy, dn, st.saved, False)
+            dWs, dbs, _ = ops.sdf_backward(net, st.x_eval, M, M, Mb, dy, dn, st.saved, False, out=out_s)
+        if plan is not None:
+            return None, dflat
         if dWr is None:
             dWr = [torch.zeros_like(L.w) for L in rnet.layers]
             dbr = [torch.zeros_like(L.bias) for L in rnet.layers]
@@ -395,3 +461,8 @@ class _IdrStep(torch.autograd.Function):
 
 def idr_step(state, ws, bs, rws, rbs):
     return _IdrStep.apply(state, *ws, *bs, *rws, *rbs)
+
+
+def idr_step_flat(state, flat):
+    """The same node with the folded parameters of both networks as one tensor (fold_networks_flat); state.plan must be set."""
+    return _IdrStep.apply(state, flat)

@@ -174,6 +174,7 @@ class IDRNetwork(nn.Module):
         self._counts_host = None                                 # pinned [N hit, N hit & true mask], filled while the tracer still runs
         self._counts_event = None
         self._draw = PinnedUniform()
+        self._fold_cache = {}                                    # ops.FoldPlan of the training step's flat fold
 
     def set_trace_dtype(self, dtype):
         """'f32' (default: fp32 weights, fp32-input MFMA, bit-exact against the oracle) or 'bf16' (BASELINE configs[4]: the ray tracer's SDF
@@ -208,8 +209,15 @@ class IDRNetwork(nn.Module):
         R = batch_size * num_pixels
         dev = ray_dirs.device
 
-        # one weight-norm fold per step, both networks in one launch pair (and one backward launch)
-        (net, ws, bs), (rnet, rws, rbs) = Fn.fold_networks([self.implicit_network.fold_spec(), self.rendering_network.fold_spec()])
+        # one weight-norm fold per step, both networks in one launch pair (and one backward launch).  Training: the folded parameters are ONE
+        # flat tensor (one autograd edge, pointer arithmetic instead of per-layer tensors); eval keeps the per-layer form the stand-alone
+        # Functions take.
+        flat = None
+        if self.training:
+            flat, plan, (net, rnet) = Fn.fold_networks_flat([self.implicit_network.fold_spec(), self.rendering_network.fold_spec()], self._fold_cache)
+            ws = bs = rws = rbs = None
+        else:
+            (net, ws, bs), (rnet, rws, rbs) = Fn.fold_networks([self.implicit_network.fold_spec(), self.rendering_network.fold_spec()])
         if self.trace_dtype == 'bf16':
             ops.pack_bf16_net(net)                                # one more launch per step: bf16 packs for the tracer
         n_dsurf_points, dsurf = 0, None
@@ -287,7 +295,8 @@ class IDRNetwork(nn.Module):
                     raise ValueError("Cannot take a larger sample than population when 'replace=False'")   # np.random.choice, idr.py:244
                 return int(self._counts_host[0]), int(self._counts_host[1])
             st.wait_counts = wait_counts
-            differentiable_surface_points, rgb_values, grad_theta, eikonal_output, surf_indicator_output = Fn.idr_step(st, ws, bs, rws, rbs)
+            st.plan = plan
+            differentiable_surface_points, rgb_values, grad_theta, eikonal_output, surf_indicator_output = Fn.idr_step_flat(st, flat)
             N = st.N
             hit_idx = perm[:N]
             sdf_output, eikonal_points_hom = st.sdf_output, st.points_hom           # no gradient: the loss never differentiates them

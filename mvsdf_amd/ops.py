@@ -14,7 +14,7 @@ def _f32(t):
 
 
 class PackedLayer:
-    __slots__ = ('w', 'wp', 'wpT', 'bias', 'K', 'N', 'wp16')
+    __slots__ = ('w', 'wp', 'wpT', 'bias', 'K', 'N', 'wp16', 'wp_ptr', 'wpT_ptr', 'w_ptr', 'keep')
 
 
 class PackedNet:
@@ -34,9 +34,10 @@ class PackedNet:
         d.n_layers = len(self.layers)
         for i, L in enumerate(self.layers):
             d.K[i], d.N[i] = (L.N, L.K) if transposed else (L.K, L.N)
-            d.wp[i] = (L.wpT if transposed else L.wp).data_ptr()
+            pk = L.wpT if transposed else L.wp
+            d.wp[i] = pk.data_ptr() if pk is not None else (L.wpT_ptr if transposed else L.wp_ptr)      # raw pointers: packs living in one flat buffer
             d.bias[i] = L.bias.data_ptr()
-            d.w[i] = L.w.data_ptr()
+            d.w[i] = L.w.data_ptr() if L.w is not None else L.w_ptr
         d.skip_layer, d.multires = self.skip_layer, self.multires
         if not transposed and self.trace_dtype == 1:
             for i, L in enumerate(self.layers):
@@ -92,6 +93,93 @@ def fold_pack_net(vs, gs):
     return ws, wps, wpTs
 
 
+def _int_ptr_array(ptrs):
+    arr = (C.c_void_p * len(ptrs))()
+    for i, v in enumerate(ptrs):
+        arr[i] = v
+    return arr
+
+
+class FoldPlan:
+    """Everything about folding a fixed set of layers that does not change from step to step: dims, offsets of each layer inside ONE flat
+    buffer [W of net 0 | b of net 0 | W of net 1 | b of net 1 ...] (the order in which the backward kernels emit dW_cat / db_cat per network),
+    offsets of the MFMA packs inside one flat pack buffer, ctypes arrays.  Built once per model (functional.fold_networks_flat)."""
+
+    def __init__(self, shapes, cuts):
+        self.n = len(shapes)
+        self.N = (C.c_int * self.n)(*[s[0] for s in shapes])
+        self.K = (C.c_int * self.n)(*[s[1] for s in shapes])
+        self.shapes = shapes
+        self.woff, self.boff, self.seg = [0] * self.n, [0] * self.n, []
+        off, lo = 0, 0
+        for hi in cuts:                                          # per network: weights, then biases
+            w0 = off
+            for l in range(lo, hi):
+                self.woff[l] = off; off += shapes[l][0] * shapes[l][1]
+            b0 = off
+            for l in range(lo, hi):
+                self.boff[l] = off; off += shapes[l][0]
+            self.seg.append((w0, b0, off))
+            lo = hi
+        self.total = off
+        self.poff, self.pToff = [], []
+        po = 0
+        for (N, K) in shapes:
+            self.poff.append(po); po += lib().mvsdf_packed_floats(N, K)
+            self.pToff.append(po); po += lib().mvsdf_packed_floats(K, N)
+        self.ptotal = po
+        self._param_key, self._param_arrays = None, None
+
+    def param_arrays(self, vs, gs, bs):
+        """ctypes pointer arrays of the parameters and of their .grad buffers (cached while the storages stay put)."""
+        key = (vs[0].data_ptr(), vs[0].grad.data_ptr() if vs[0].grad is not None else 0, bs[-1].data_ptr(),
+               bs[-1].grad.data_ptr() if bs[-1].grad is not None else 0)
+        if self._param_key != key:
+            g_ok = all(p.grad is not None for p in list(vs) + list(bs)) and all(g is None or g.grad is not None for g in gs)
+            self._param_arrays = (_ptr_array([v.detach() for v in vs]), _ptr_array([g.detach() if g is not None else None for g in gs]),
+                                  (_ptr_array([v.grad for v in vs]), _ptr_array([g.grad if g is not None else None for g in gs]),
+                                   _ptr_array([b.grad for b in bs])) if g_ok else None)
+            self._param_key = key
+        return self._param_arrays
+
+
+def fold_pack_net_flat(plan, vs, gs, layers):
+    """fold + pack of all layers into ONE flat buffer of folded weights (+ room for the bias segment) and ONE buffer of packs: two
+    allocations instead of 3 per layer.  Sets L.w_ptr / L.wp_ptr / L.wpT_ptr of `layers`; -> (flat [plan.total], packs)."""
+    dev = vs[0].device
+    flat = torch.empty(plan.total, dtype=torch.float32, device=dev)
+    packs = torch.empty(plan.ptotal, dtype=torch.float32, device=dev)
+    fb, pb = flat.data_ptr(), packs.data_ptr()
+    wps, wpTs, wss = [], [], []
+    for l, L in enumerate(layers):
+        L.w = L.wp = L.wpT = None
+        L.w_ptr, L.wp_ptr, L.wpT_ptr = fb + 4 * plan.woff[l], pb + 4 * plan.poff[l], pb + 4 * plan.pToff[l]
+        wss.append(L.w_ptr); wps.append(L.wp_ptr); wpTs.append(L.wpT_ptr)
+    pv, pg, _ = plan.param_arrays(vs, gs, [L.bias for L in layers])
+    check(lib().mvsdf_fold_pack_net(plan.n, pv, pg, plan.N, plan.K, _int_ptr_array(wss), _int_ptr_array(wps), _int_ptr_array(wpTs),
+                                    stream_of(vs[0])), 'mvsdf_fold_pack_net')
+    return flat, packs
+
+
+def fold_backward_net_flat(plan, vs, gs, bs, dflat, sink):
+    """Backward of fold_pack_net_flat from the flat gradient [dW | db per network].  sink: add dv / dg / db into the parameters' .grad buffers
+    (-> None); otherwise -> (dvs, dgs, dbs)."""
+    base = dflat.data_ptr()
+    dW = _int_ptr_array([base + 4 * o for o in plan.woff])
+    db = _int_ptr_array([base + 4 * o for o in plan.boff])
+    pv, pg, grads = plan.param_arrays(vs, gs, bs)
+    if sink and grads is not None:
+        check(lib().mvsdf_fold_backward_net(plan.n, pv, pg, dW, db, plan.N, plan.K, grads[0], grads[1], grads[2], 1, stream_of(dflat)),
+              'mvsdf_fold_backward_net')
+        return None
+    dvs = [torch.empty_like(v) for v in vs]
+    dgs = [torch.empty_like(g) if g is not None else None for g in gs]
+    check(lib().mvsdf_fold_backward_net(plan.n, pv, pg, dW, None, plan.N, plan.K, _ptr_array(dvs), _ptr_array(dgs), None, 0, stream_of(dflat)),
+          'mvsdf_fold_backward_net')
+    dbs = [dflat[o:o + s[0]] for o, s in zip(plan.boff, plan.shapes)]
+    return dvs, dgs, dbs
+
+
 def fold_backward_net(vs, gs, dWs, dbs=None, sinks=None):
     """-> (dvs, dgs).  With `sinks` = (dv_targets, dg_targets, db_targets) the results (and the bias gradients dbs) are ADDED into
     those tensors instead (the parameters' .grad buffers) and nothing is returned.  gs[l] None (no weight norm): dv = dW, dg None."""
@@ -133,14 +221,14 @@ def pack_bf16_net(net):
     MLP (ops.trace, ops.sdf_col0) to bf16 weights / activations.  The differentiable passes keep the fp32 weights."""
     n = len(net.layers)
     d0 = 3 + 6 * net.multires
-    dev = net.layers[0].w.device
+    dev = net.layers[0].bias.device
     for i, L in enumerate(net.layers):
         ns = d0 if (i == 0 or i == net.skip_layer) else 0
         L.wp16 = torch.empty(lib().mvsdf_packed_bf16_bytes(L.N, L.K, ns), dtype=torch.uint8, device=dev)
     N = (C.c_int * n)(*[L.N for L in net.layers])
     K = (C.c_int * n)(*[L.K for L in net.layers])
-    check(lib().mvsdf_pack_bf16_net(n, _ptr_array([L.w for L in net.layers]), N, K, net.skip_layer, net.multires,
-                                    _ptr_array([L.wp16 for L in net.layers]), stream_of(net.layers[0].w)), 'mvsdf_pack_bf16_net')
+    check(lib().mvsdf_pack_bf16_net(n, _int_ptr_array([L.w.data_ptr() if L.w is not None else L.w_ptr for L in net.layers]), N, K, net.skip_layer, net.multires,
+                                    _ptr_array([L.wp16 for L in net.layers]), stream_of(net.layers[0].bias)), 'mvsdf_pack_bf16_net')
     net.trace_dtype = 1
     net.__dict__.pop('_d', None)
     return net
@@ -255,22 +343,25 @@ def sdf_forward(net, x, Mg):
     return y, n, ctx
 
 
-def sdf_backward(net, x, M, Mg, Mb, dy, dn, ctx, want_dx, want_dw=True, row0=0):
+def sdf_backward(net, x, M, Mg, Mb, dy, dn, ctx, want_dx, want_dw=True, row0=0, out=None):
     """-> (dWs [list per layer], dbs, dx or None) over rows [row0, row0 + Mb) (dWs = dbs = None when want_dw is False).
     x is the full [M,3] point tensor of the forward; dy / dn hold Mb rows."""
     x, dy = _f32(x), _f32(dy)
     dev = x.device
     d, dT = net.desc(), net.desc(True)
     ws_n, bs_n = net.wsizes()
-    dW = torch.empty(sum(ws_n), dtype=torch.float32, device=dev) if want_dw else None
-    db = torch.empty(sum(bs_n), dtype=torch.float32, device=dev) if want_dw else None
+    if out is not None:                                          # (dW_cat, db_cat) slices of a flat gradient: written in place, not split
+        dW, db = out
+    else:
+        dW = torch.empty(sum(ws_n), dtype=torch.float32, device=dev) if want_dw else None
+        db = torch.empty(sum(bs_n), dtype=torch.float32, device=dev) if want_dw else None
     dx = torch.empty(Mb, 3, dtype=torch.float32, device=dev) if want_dx else None
     ws = torch.empty(lib().mvsdf_sdf_bwd_ws_floats(C.byref(d), Mb), dtype=torch.float32, device=dev)
     dn = _f32(dn) if dn is not None else None
     xr = x[row0:] if row0 else x
     check(lib().mvsdf_sdf_backward(C.byref(d), C.byref(dT), ptr(xr), M, Mg, row0, Mb, ptr(dy), ptr(dn), ptr(ctx), ptr(dW), ptr(db), ptr(dx),
                                    ptr(ws), stream_of(x)), 'mvsdf_sdf_backward')
-    if not want_dw:
+    if not want_dw or out is not None:
         return None, None, dx
     dWs, dbs = _split_cat(net, dW, db)
     return dWs, dbs, dx
@@ -292,16 +383,19 @@ def sdf_backward_pair(net, M, Mg, MbA, dyA, dnA, row0X, MbX, dyX, dnX, ctx):
     return wsA, dx
 
 
-def sdf_backward_finish(net, M, Mg, Mb, dy, ctx, wsA, row0D, MbD, fbar):
+def sdf_backward_finish(net, M, Mg, Mb, dy, ctx, wsA, row0D, MbD, fbar, out=None):
     """Delta pass (fbar on output column 0 of rows [row0D, row0D + MbD), added to the stored adjoints) + weight gradients -> (dWs, dbs)."""
     dev = dy.device
     d, dT = net.desc(), net.desc(True)
-    ws_n, bs_n = net.wsizes()
-    dW = torch.empty(sum(ws_n), dtype=torch.float32, device=dev)
-    db = torch.empty(sum(bs_n), dtype=torch.float32, device=dev)
+    if out is not None:
+        dW, db = out
+    else:
+        ws_n, bs_n = net.wsizes()
+        dW = torch.empty(sum(ws_n), dtype=torch.float32, device=dev)
+        db = torch.empty(sum(bs_n), dtype=torch.float32, device=dev)
     check(lib().mvsdf_sdf_backward_finish(C.byref(d), C.byref(dT), M, Mg, Mb, ptr(dy), ptr(ctx), ptr(wsA), row0D, MbD, ptr(fbar) if MbD > 0 else None,
                                           ptr(dW), ptr(db), stream_of(dy)), 'mvsdf_sdf_backward_finish')
-    return _split_cat(net, dW, db)
+    return None if out is not None else _split_cat(net, dW, db)
 
 
 def step_backward_fbar(n_eik, n_ds, N, Nout, din, use_geo, d_diff, dx, view_sorted, n_eval, dy):
@@ -326,18 +420,23 @@ def render_forward(net, points, view, normals, feat, multires_view):
     return rgb, ctx
 
 
-def render_backward(net, N, drgb, ctx, n_ctx=None):
+def render_backward(net, N, drgb, ctx, n_ctx=None, out=None):
     """n_ctx: rows the forward context was made with (default N); the backward covers its first N rows."""
     drgb = _f32(drgb)
     dev = drgb.device
     d, dT = net.desc(), net.desc(True)
-    ws_n, bs_n = net.wsizes()
-    dW = torch.empty(sum(ws_n), dtype=torch.float32, device=dev)
-    db = torch.empty(sum(bs_n), dtype=torch.float32, device=dev)
+    if out is not None:
+        dW, db = out
+    else:
+        ws_n, bs_n = net.wsizes()
+        dW = torch.empty(sum(ws_n), dtype=torch.float32, device=dev)
+        db = torch.empty(sum(bs_n), dtype=torch.float32, device=dev)
     din = torch.empty(N, net.layers[0].K, dtype=torch.float32, device=dev)
     ws = torch.empty(lib().mvsdf_render_bwd_ws_floats(C.byref(d), N), dtype=torch.float32, device=dev)
     check(lib().mvsdf_render_backward(C.byref(d), C.byref(dT), N, N if n_ctx is None else n_ctx, ptr(drgb), ptr(ctx), ptr(dW), ptr(db),
                                       ptr(din), ptr(ws), stream_of(drgb)), 'mvsdf_render_backward')
+    if out is not None:
+        return None, None, din
     dWs, dbs = _split_cat(net, dW, db)
     return dWs, dbs, din
 
