@@ -49,6 +49,7 @@ WORKLOADS = {                     # name: (pixels per view and GPU-count unit, s
     'c5share': (512, 8),          # configs[4] per-GPU share: 32768 rays / 8 GPUs = 4096 rays, 8 source views (meant for --dtype bf16)
 }
 FEAT_HW = (600, 800)
+P, V = WORKLOADS['c2']            # defaults of make_inputs (dev tools under tools/ set bench.B / bench.P / bench.V and call it)
 PEAK = {'f32': 157.3, 'bf16': 2500.0}    # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32 / bf16)
 # the reference itself on CPU (PyTorch + MKL, imported in the build container): it cannot travel to the GPU box
 REFERENCE_CPU_NOTE = 'reference PyTorch-CPU step on the same c2 batch in the build container (8 vCPU Xeon): 2492 rays/s on 8 threads, 0.82 s/step (BASELINE.md)'
@@ -62,8 +63,10 @@ def flops_per_row(W):
     return f_t, f_s, f_r
 
 
-def make_inputs(dev, rank, world, P, V):
+def make_inputs(dev, rank=0, world=1, P=None, V=None):
     """This rank's share of the global batch (B views x P px, seed 0 on every rank): its views' rays / GT / feature maps, all depth maps."""
+    P = globals()['P'] if P is None else P
+    V = globals()['V'] if V is None else V
     inp, gt = synth.make_batch(B, P, V, seed=0, feat_hw=FEAT_HW, with_features=False)
     to = lambda d: {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in d.items()}
     inp, gt = shard_views(to(inp), rank, world), shard_views(to(gt), rank, world)

@@ -120,7 +120,9 @@ int mvsdf_trace(const MvsdfNetDesc* net, const MvsdfTraceParams* tp, const float
                 size_t workspace_bytes, int mt, int mt_samples, void* stream);
 /* the launches of mvsdf_trace separately, same arguments and workspace.  stage 1: sphere tracing (zeroes the counters);
  * stage 2: ray sampler + secant + min-sdf; or stage 3: ray sampler rows only -- `mask` is FINAL after it (ray_tracing.py:61) --
- * followed by stage 4: secant + min-sdf (only points / dists still change, ray_tracing.py:63-96).  Lets a caller bracket each
+ * followed by stage 4: secant + min-sdf (only points / dists still change, ray_tracing.py:63-96); stage 4 may be split further into
+ * stage 5: min-sdf rows + their reduction alone (independent of stage 3: they only need stage 1's work list, and use their own sample-value
+ * buffer, so a caller may run them on another stream concurrently with stage 3) and stage 6: secant alone.  Lets a caller bracket each
  * kernel with events, and fetch the hit count to the host while stage 4 still runs. */
 int mvsdf_trace_stage(int stage, const MvsdfNetDesc* net, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
                       const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,

@@ -500,7 +500,8 @@ template <int MT, int NTW, int NW, class NET>
 static hipError_t launch_stage2(const NET& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, int B, int P, int training,
                                 const float* intervals, const float* steps, float* points, uint8_t* mask, float* dists, float* ws,
                                 unsigned long long* counters, int parts, hipStream_t stream) {
-    // parts bit 0: sampler rows + their reduction (the hit mask is FINAL after it); bit 1: secant + min-sdf rows
+    // parts bit 0: sampler rows + their reduction (the hit mask is FINAL after it); bit 1: secant + min-sdf rows in one launch;
+    // bit 2: min-sdf rows + their reduction alone (own sample-value buffer: may run concurrently with bit 0 on another stream); bit 3: secant alone
     const int R = B * P, ROWS = 16 * MT;
     float* w_zmin = ws;
     float* w_zmax = w_zmin + R;
@@ -545,6 +546,15 @@ static hipError_t launch_stage2(const NET& net, const MvTraceParams& tp, const f
                            sec_blocks);
         if (training) hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
     }
+    if ((parts & 4) && training) {
+        SampleCtx c2 = c;
+        c2.sv = (float*)(c.src_rest + R);                        // second sample-value buffer [R * n_steps]
+        const RowSeg minsdf = {w_list_min, nullptr, (int)MV_CNT_N_MINSDF, 0, n, blocks_for(n)};
+        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(minsdf.blocks), dim3(64 * NW), lds2, stream, net, tp, c2, minsdf, none, 0);
+        hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c2, w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
+    }
+    if (parts & 8)
+        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(sec_blocks), dim3(64 * NW), lds2, stream, net, tp, c, none, none, sec_blocks);
     return hipGetLastError();
 }
 
@@ -564,7 +574,7 @@ hipError_t mv_trace_launch(int stages, const NET& net, const MvTraceParams& tp, 
     const bool wide = maxnt > 16;
     hipError_t e = hipSuccess;
 #define MV_S1(MT_, NTW_, NW_) e = launch_stage1<MT_, NTW_, NW_>(net, tp, cam_loc, dirs, om, B, P, training, points, mask, dists, ws, counters, stream)
-#define MV_S2(MT_, NTW_, NW_) e = launch_stage2<MT_, NTW_, NW_>(net, tp, cam_loc, dirs, B, P, training, intervals, steps, points, mask, dists, ws, counters, (stages >> 1) & 3, stream)
+#define MV_S2(MT_, NTW_, NW_) e = launch_stage2<MT_, NTW_, NW_>(net, tp, cam_loc, dirs, B, P, training, intervals, steps, points, mask, dists, ws, counters, (stages >> 1) & 15, stream)
     if (stages & 1) {
         if (eight) {
             if (wide) { if (mt1 >= 2) MV_S1(2, 4, 8); else MV_S1(1, 4, 8); }
@@ -579,7 +589,7 @@ hipError_t mv_trace_launch(int stages, const NET& net, const MvTraceParams& tp, 
     // CUs (measured 285 -> 241 us at 2048 rays).  MVSDF_MT_FIRST overrides (dev).
     static int mtf_env = -1;
     if (mtf_env < 0) { const char* e2 = getenv("MVSDF_MT_FIRST"); mtf_env = e2 ? atoi(e2) : 0; }
-    for (int part = 1; part <= 2; ++part) {
+    for (int part = 1; part <= 8; part <<= 1) {
         if (!((stages >> 1) & part)) continue;
         const int mtp = part == 1 ? (mtf_env > 0 ? mtf_env : ((long long)B * P <= 4096 ? 1 : mt2)) : mt2;
         const int st_ = stages;
@@ -842,7 +852,7 @@ static GenWs mv_gen_ws(void* ws, int R, int n) {
 #include "capi_util.h"
 extern "C" {
 
-size_t mvsdf_trace_workspace_bytes_n(int R, int n_steps) { return (size_t)(R > 0 ? R : 0) * (44 + 4 * (size_t)(n_steps > 0 ? n_steps : 0)) + 256; }
+size_t mvsdf_trace_workspace_bytes_n(int R, int n_steps) { return (size_t)(R > 0 ? R : 0) * (44 + 8 * (size_t)(n_steps > 0 ? n_steps : 0)) + 256; }
 size_t mvsdf_trace_workspace_bytes(int R) { return mvsdf_trace_workspace_bytes_n(R, 128); }
 
 static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs,
@@ -892,8 +902,8 @@ int mvsdf_trace_stage(int stage, const MvsdfNetDesc* desc, const MvsdfTraceParam
                       const uint8_t* object_mask, int B, int P, int training, const float* intervals, const float* minsdf_steps,
                       float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
                       size_t workspace_bytes, int mt, int rpw, void* stream) {
-    if (stage < 1 || stage > 4) return mv_fail(-1, "mvsdf_trace_stage: stage must be 1..4");
-    static const int bits[5] = {0, 1, 6, 2, 4};
+    if (stage < 1 || stage > 6) return mv_fail(-1, "mvsdf_trace_stage: stage must be 1..6");
+    static const int bits[7] = {0, 1, 6, 2, 4, 8, 16};
     return trace_impl(bits[stage], desc, tp, cam_loc, ray_dirs, object_mask, B, P, training, intervals, minsdf_steps, points, mask, dists, counters,
                       workspace, workspace_bytes, mt, rpw, stream);
 }

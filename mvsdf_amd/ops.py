@@ -261,6 +261,17 @@ def sphere_intersection(cam_loc, ray_dirs, r=1.0):
     return t, m.bool()
 
 
+_MINSDF_SIDE_STREAM = __import__('os').environ.get('MVSDF_MINSDF_STREAM', '0') == '1'
+_side_streams = {}
+
+
+def _minsdf_stream(dev):
+    s = _side_streams.get(dev)
+    if s is None:
+        s = _side_streams[dev] = torch.cuda.Stream(dev)
+    return s
+
+
 def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, minsdf_steps=None, mt=1, mt_samples=4, events=None,
           mask_ready=None):
     """RayTracing.forward on the device -> (points[R,3], mask[R] bool, dists[R], counters[16] int64 device tensor).
@@ -293,12 +304,26 @@ def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, mins
         if ev: ev[0].record()
         check(lib().mvsdf_trace_stage(1, *args), 'mvsdf_trace_stage(1)')
         if ev: ev[1].record()
+        side = _minsdf_stream(dev) if (training and _MINSDF_SIDE_STREAM) else None
+        if side is not None:
+            # the min-sdf rows need only the sphere tracer's work list: they run on a second stream under the (latency-shaped) sampler launches
+            main = torch.cuda.current_stream(dev)
+            e_in, e_out = torch.cuda.Event(), torch.cuda.Event()
+            e_in.record(main)
+            side.wait_event(e_in)
+            sargs = args[:-1] + (C.c_void_p(side.cuda_stream),)
+            check(lib().mvsdf_trace_stage(5, *sargs), 'mvsdf_trace_stage(5)')
+            e_out.record(side)
         check(lib().mvsdf_trace_stage(3, *args), 'mvsdf_trace_stage(3)')
         if ev: ev[2].record()
         mask_b = mask.view(torch.bool)                           # the kernels write 0 / 1 bytes
         mask_ready(mask_b)
         if ev: ev[3].record()
-        check(lib().mvsdf_trace_stage(4, *args), 'mvsdf_trace_stage(4)')
+        if side is not None:
+            check(lib().mvsdf_trace_stage(6, *args), 'mvsdf_trace_stage(6)')
+            torch.cuda.current_stream(dev).wait_event(e_out)
+        else:
+            check(lib().mvsdf_trace_stage(4, *args), 'mvsdf_trace_stage(4)')
         if ev:
             ev[4].record()
             events.append(tuple(ev))
