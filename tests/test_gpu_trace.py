@@ -177,3 +177,34 @@ def test_opaque_sdf_callable_bit_exact_vs_reference_analytic_goldens(mode, om):
     assert np.abs(dists.cpu().numpy() - g['dists']).max() < 1e-5
     assert sum(calls) == int(g['rows'].sum())                     # the callable saw exactly the rows the reference evaluated
     assert max(calls) <= 100000                                   # chunked like ray_tracing.py:217,300
+
+
+def test_trace_stages_5_and_6_equal_stage_4():
+    """mvsdf_trace_stage: stage 4 (secant + min-sdf rows in one launch) == stage 5 (min-sdf rows alone, own sample buffer) + stage 6 (secant
+    alone), in either order -- the split that lets a caller put the min-sdf rows on another stream."""
+    import ctypes as C
+    from mvsdf_amd._lib import TraceParams, check, lib, ptr, stream_of
+    W = 64
+    net = sdf_packed_net(synth.make_state_dict(W, 0))
+    inp, _ = synth.make_batch(3, 500, 0, seed=4, with_features=False, focal_scale=1.4)
+    dirs, cam = ops.camera_rays(t(inp['uv']), t(inp['pose']), t(inp['intrinsics']))
+    R = 1500
+    om = torch.ones(R, dtype=torch.uint8, device='cuda')
+    iv = torch.linspace(0, 1, 100).cuda()
+    steps = t(np.random.RandomState(1).uniform(size=100).astype(np.float32))
+    tp = TraceParams(*trace_params(W))
+    d = net.desc()
+    res = []
+    for order in ((1, 3, 4), (1, 3, 5, 6), (1, 5, 3, 6)):
+        pts = torch.empty(R, 3, device='cuda'); mask = torch.empty(R, dtype=torch.uint8, device='cuda'); dists = torch.empty(R, device='cuda')
+        cnt = torch.empty(16, dtype=torch.int64, device='cuda')
+        wsb = lib().mvsdf_trace_workspace_bytes_n(R, 100)
+        ws = torch.empty(wsb, dtype=torch.uint8, device='cuda')
+        for stage in order:
+            check(lib().mvsdf_trace_stage(stage, C.byref(d), C.byref(tp), ptr(cam), ptr(dirs), ptr(om), 3, 500, 1, ptr(iv), ptr(steps), ptr(pts), ptr(mask),
+                                          ptr(dists), ptr(cnt), ptr(ws), C.c_size_t(wsb), 1, 2, stream_of(dirs)), 'stage %d' % stage)
+        res.append((pts.clone(), mask.clone(), dists.clone(), cnt[:9].clone()))
+    assert int(res[0][3][6]) > 0 and int(res[0][3][4]) > 0          # both the min-sdf list and the secant list are populated
+    for r in res[1:]:
+        for a, b in zip(res[0], r):
+            assert torch.equal(a, b)
