@@ -66,7 +66,7 @@ def test_forward_loss_backward_vs_reference(name):
     assert dsp_err < 1.6e-4
     rgb_err = np.abs(out['rgb_values'].detach().cpu().numpy() - g['out_rgb_values']).max()
     print('%s: max |rgb - reference| = %.3g' % (name, rgb_err))
-    assert rgb_err < 1e-4                                                         # north_star: rendered RGB within 1e-4 (values in [-1, 1])
+    assert rgb_err < 1e-4                                                         # north_star: rendered RGB within 1e-4 (values in [-1, 1]); measured <= 1.4e-6
     N = int(hit.sum())
     gth, gth_g = out['grad_theta'].detach().cpu().numpy(), g['out_grad_theta']
     assert np.abs(gth - gth_g).max() < 2e-3 * max(1.0, np.abs(gth_g).max())      # surface rows move with the 1e-5 depth noise
@@ -98,7 +98,8 @@ def test_forward_loss_backward_vs_reference(name):
         vals = gr.reshape(-1)[g['gidx_' + k]]
         scale = max(np.abs(g['gval_' + k]).max(), ref_norm / np.sqrt(gr.size), 1e-9)
         worst = max(worst, float(np.abs(vals - g['gval_' + k]).max() / scale))
-    assert worst < 2e-2, worst
+    print('%s: worst sampled gradient entry deviation %.3g of the scale' % (name, worst))
+    assert worst < 1e-3, worst                                                    # measured: <= 1.2e-4 (idr_c3), <= 2.1e-5 on the other fixtures
 
 
 def test_eval_mode_and_public_methods():
