@@ -194,11 +194,11 @@ def test_four_training_steps_follow_the_reference_loop():
         got = np.array([float(lo[k].detach().reshape(-1)[0]) for k in keys])
         # later steps inherit the fp32 noise of the earlier updates, and the depth term is discontinuous in the SDF values (far / near
         # attenuation classes, in-range test: loss.py:44-60): a handful of sample points changing class moves it by a few per cent
-        tol = np.full(6, 3e-4 if it == 0 else (3e-3 if it == 1 else 1e-2))
-        if it >= 2:
-            tol[0], tol[3] = 2e-2, 8e-2
+        # measured: steps 0-1 agree to 2e-7; from step 2 on a sample point or two changes its depth-carving class (depth term / total ~1e-2)
+        tol = np.full(6, 1e-5) if it < 2 else np.array([2.5e-2, 1e-3, 1.5e-2, 2.5e-2, 1e-3, 5e-3])
+        print('step %d: |loss terms - reference| / max(1, |ref|) = %s, grad norm rel %.2g' % (it, np.array2string(np.abs(got - g['losses'][it]) / np.maximum(1.0, np.abs(g['losses'][it])), precision=2), abs(float(opt.grad_norm()) - g['gnorms'][it]) / g['gnorms'][it]))
         assert np.all(np.abs(got - g['losses'][it]) <= tol * np.maximum(1.0, np.abs(g['losses'][it]))), (it, got, g['losses'][it])
-        assert abs(float(opt.grad_norm()) - g['gnorms'][it]) <= (5e-3 if it < 2 else 1e-1) * g['gnorms'][it], (it, float(opt.grad_norm()), g['gnorms'][it])
+        assert abs(float(opt.grad_norm()) - g['gnorms'][it]) <= (1e-4 if it < 2 else 5e-2) * g['gnorms'][it], (it, float(opt.grad_norm()), g['gnorms'][it])
         assert abs(int((out['network_object_mask'] & out['object_mask']).sum()) - int(g['hits'][it])) <= (0 if it == 0 else 2)
     # Adam moves every element by ~lr per step whatever the size of its gradient, so elements whose gradient is noise may move the other way:
     # parameter norms agree up to a fraction of the largest possible drift steps * lr * sqrt(numel)
