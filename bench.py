@@ -304,6 +304,23 @@ def main():
                                   'achieved': flops_step / (dt / a.steps) / 1e12, 'frac': flops_step / (dt / a.steps) / 1e12 / peak}},
             'loss': float(lo['loss'].detach()),
         }
+        if world == 1:
+            # secondary number, never `value`: the same step with the opt-in IDRNetwork.lazy_unused_outputs (the min-sdf points of non-hit rays,
+            # which the training loop never reads, are evaluated only when `points` / `sdf_output` are read -- here: never)
+            model.lazy_unused_outputs = True
+            nv = max(10, a.steps // 2)
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(nv):
+                step()
+            torch.cuda.synchronize()
+            dtv = (time.perf_counter() - t0) / nv
+            model.lazy_unused_outputs = False
+            res['variants'] = {'lazy_unused_outputs': {'ms_per_step': dtv * 1e3, 'rays_per_s': R / dtv, 'steps': nv,
+                                                       'rows_not_evaluated_per_step': int(cnt[3]),
+                                                       'note': 'opt-in, default off; loss and gradients identical (tests/test_gpu_lazy.py); not the headline value'}}
         if not a.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(V)
         print(json.dumps(res), flush=True)

@@ -192,7 +192,7 @@ __global__ void k_sphere_intersection(const float* __restrict__ cam_loc, const f
 }
 
 // ---- the tracing MLP alone: y[i] = ImplicitNetwork(x[i])[0] ----
-template <int MT, int NTW, int NW>
+template <int MT, int NTW, int NW, bool XR = false>
 __global__ __launch_bounds__(64 * NW) void k_sdf_col0(MvNet net, const float* __restrict__ x, int n, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64 * NW) void k_sdf_col0(MvNet net, const float* __
         pts[i] = row < n ? x[3 * (size_t)row0 + i] : 0.0f;
     }
     __syncthreads();
-    mv_sdf_eval_col0<MT, NTW, NW>(net, act, pe, pts, out, tid);
+    mv_sdf_eval_col0<MT, NTW, NW, XR>(net, act, pe, pts, out, tid);
     if (tid < ROWS && row0 + tid < n) y[row0 + tid] = out[tid];
 }
 
@@ -328,13 +328,13 @@ __global__ void k_det_math(int op, const float* __restrict__ x, int n, float* __
     if (y1) y1[i] = b;
 }
 
-template <int MT, int NTW, int NW>
+template <int MT, int NTW, int NW, bool XR = false>
 static int launch_col0(const MvNet& net, const float* x, int n, float* y, hipStream_t s) {
     const int rows = 16 * MT, d0 = 3 + 6 * net.multires;
     const size_t lds = ((size_t)rows * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows) * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)k_sdf_col0<MT, NTW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_sdf_col0<MT, NTW, NW, XR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return mv_check(e, "mvsdf_sdf_col0: LDS attribute");
-    hipLaunchKernelGGL((k_sdf_col0<MT, NTW, NW>), dim3((n + rows - 1) / rows), dim3(64 * NW), lds, s, net, x, n, y);
+    hipLaunchKernelGGL((k_sdf_col0<MT, NTW, NW, XR>), dim3((n + rows - 1) / rows), dim3(64 * NW), lds, s, net, x, n, y);
     return mv_check(hipGetLastError(), "mvsdf_sdf_col0");
 }
 
@@ -475,6 +475,7 @@ int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, in
         if (mx > 16 || mk > 16) return mv_fail(-1, "mvsdf_sdf_col0: mt=33 covers hidden widths up to 256");
         return launch_col0_rows<16>(net, x, n, y, s);
     }
+    if (mt == 49) return launch_col0<1, 2, 8, true>(net, x, n, y, s);     // the sphere tracer's engine: weight ring carried across layers
     if (mt == 17) {                                             // latency regime: one tile per workgroup, K-split staggered evaluation
         int mx = 0;
         for (int l = 0; l < net.n_layers - 1; ++l) mx = net.L[l].NT > mx ? net.L[l].NT : mx;

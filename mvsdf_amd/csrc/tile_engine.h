@@ -82,6 +82,66 @@ __device__ __forceinline__ void mv_gemm_ring(const MvLayer& L, const float* __re
     }
 }
 
+// The same ring carried ACROSS layers (mv_sdf_eval_col0): the weights of a layer do not depend on the activations, so the ring stages that
+// fall free while the last PD k-blocks of layer l issue are refilled with k-blocks 0..PD-1 of layer l+1 (`wn`, this wave's tiles there;
+// nullptr = nothing to prefetch).  Their L2 latency then hides under those MFMAs, the barrier and the softplus epilogue instead of opening
+// layer l+1's GEMM.  `primed` (wave-uniform): b already holds this layer's first PD k-blocks.  Same MFMAs in the same order as mv_gemm_ring.
+template <int MTc, int NT, int NTW, int PD>
+__device__ __forceinline__ void mv_gemm_ring_x(const MvLayer& L, const float* __restrict__ act, int S, int ct0, f32x4 (&acc)[MTc][NTW], int lane,
+                                               float4 (&b)[PD][NT], bool primed, const float4* __restrict__ wn, int KBn) {
+    const int KB = L.KB;
+    const float4* __restrict__ wp = L.wp + (size_t)ct0 * KB * 64 + lane;
+    const float* arow = act + (lane & 15) * S + 4 * (lane >> 4);
+    float4 a[PD][MTc];
+    if (!primed) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[d][t] = wp[((size_t)t * KB + d) * 64];
+    }
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+#pragma unroll
+        for (int r = 0; r < MTc; ++r) a[d][r] = *(const float4*)(arow + r * 16 * S + d * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kb0 = 0; kb0 < KB - PD; kb0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a[d][r])[s], ((const float*)&b[d][t])[s], acc[r][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = kb0 + d + PD;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[d][t] = wp[((size_t)t * KB + kn) * 64];
+#pragma unroll
+            for (int r = 0; r < MTc; ++r) a[d][r] = *(const float4*)(arow + r * 16 * S + kn * 16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // last PD k-blocks: the stages they free take the next layer's first k-blocks
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(((const float*)&a[d][r])[s], ((const float*)&b[d][t])[s], acc[r][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wn) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[d][t] = wn[((size_t)t * KBn + d) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int MTc, int NT, int NTW>
 __device__ __forceinline__ void mv_gemm_tiles(const MvLayer& L, const float* __restrict__ act, int S, int ct0,
                                               f32x4 (&acc)[MTc][NTW], int lane) {
@@ -143,13 +203,18 @@ __device__ __forceinline__ void mv_pe_rows(const float* pts, float* pe, float* a
 // ImplicitNetwork.forward(...)[:, 0] (idr.py:77-94) for MTc*16 rows whose points sit in LDS `pts`.
 // Result -> LDS out[row].  All 64*NW threads must call; ends with a barrier.  NW waves share the column tiles
 // (NW = 8 puts two waves on every SIMD: one wave's LDS / L2 latency and epilogue hide behind the other's MFMAs).
-template <int MTc, int NTW, int NW = 4>
+// XR: carry the weight ring across layers (mv_gemm_ring_x).  It keeps 32 more registers live through the softplus epilogue: for the kernels
+// that run one workgroup per CU (the sphere tracer), not for those that need 4 waves per SIMD.
+template <int MTc, int NTW, int NW = 4, bool XR = false>
 __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const float* pts, float* out, int tid) {
     constexpr int NTHREADS = 64 * NW;
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
     const int S = net.S, rows = MTc * 16, d0 = 3 + 6 * net.multires;
     mv_pe_rows<NTHREADS>(pts, pe, act, S, rows, net.multires, tid);
     const int nl = net.n_layers;
+    constexpr bool XRING = XR && (MTc * NTW <= 8);                // the deep ring (PD = 4) and its carry across layers (mv_gemm_ring_x)
+    float4 bring[4][NTW];
+    bool primed = false;
     for (int l = 0; l < nl; ++l) {
         const MvLayer& L = net.L[l];
         const bool last = (l == nl - 1);
@@ -157,6 +222,16 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
         const int per = (NT + NW - 1) / NW;                   // column tiles per wave
         const int ct0 = w * per;
         int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
+        const bool xr = XRING && ntw == NTW && (L.KB & 3) == 0;
+        // this wave's tiles of the next layer, if it runs the carried ring there too
+        const float4* wn = nullptr;
+        int KBn = 0;
+        if (XRING && xr && l + 1 < nl) {
+            const MvLayer& Ln = net.L[l + 1];
+            const int NTn = (l + 2 == nl) ? 1 : Ln.NT, pern = (NTn + NW - 1) / NW, ctn = w * pern;
+            int ntwn = NTn - ctn; ntwn = ntwn < 0 ? 0 : (ntwn > pern ? pern : ntwn);
+            if (ntwn == NTW && (Ln.KB & 3) == 0) { wn = Ln.wp + (size_t)ctn * Ln.KB * 64 + lane; KBn = Ln.KB; }
+        }
         f32x4 acc[MTc][NTW];
         mv_zero_acc<MTc, NTW>(acc);
         float bv_[NTW];                                       // biases of this wave's columns: loaded now, consumed after the GEMM
@@ -166,7 +241,10 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
             bv_[t] = (t < ntw && col < L.N) ? L.bias[col] : 0.0f;
         }
         mv_barrier_lds();                                     // inputs of layer l complete (LDS); the bias loads stay in flight
-        if (ntw > 0 && !(MV_ABLATE & 2)) mv_gemm_dispatch<MTc, NTW>(L, act, S, ct0, ntw, acc, lane);
+        if (XRING && xr) {
+            mv_gemm_ring_x<MTc, NTW, NTW, 4>(L, act, S, ct0, acc, lane, bring, primed, wn, KBn);
+            primed = (wn != nullptr);
+        } else if (ntw > 0 && !(MV_ABLATE & 2)) mv_gemm_dispatch<MTc, NTW>(L, act, S, ct0, ntw, acc, lane);
         mv_barrier_lds();                                     // every wave done reading act (in-place update)
         if (last) {
             if (w == 0 && r == 0) {

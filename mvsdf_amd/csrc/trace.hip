@@ -45,11 +45,12 @@ __device__ __forceinline__ bool mv_sphere_isect(const float* c, const float* d, 
 }
 
 // NET = MvNet (fp32 weights, fp32-input MFMA, bit-exact vs the oracle) or MvNetBf (bf16 weights / activations, bf16 MFMA): overloads of mv_sdf_eval_col0
-template <int MT, int NTW, int NW, class NET>
+template <int MT, int NTW, int NW, class NET, bool XR = false>
 __device__ __forceinline__ void mv_eval_dispatch(const NET& net, int ntiles, float* act, float* pe, const float* pts, float* out, int tid) {
     if (MT >= 4 && ntiles == 4) mv_sdf_eval_col0<(MT >= 4 ? 4 : MT), NTW, NW>(net, act, pe, pts, out, tid);
     else if (MT >= 3 && ntiles == 3) mv_sdf_eval_col0<(MT >= 3 ? 3 : MT), NTW, NW>(net, act, pe, pts, out, tid);
     else if (MT >= 2 && ntiles == 2) mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW, NW>(net, act, pe, pts, out, tid);
+    else if constexpr (XR && std::is_same<NET, MvNet>::value) mv_sdf_eval_col0<1, NTW, NW, true>(net, act, pe, pts, out, tid);   // fp32 engine: weight ring carried across layers
     else mv_sdf_eval_col0<1, NTW, NW>(net, act, pe, pts, out, tid);
 }
 
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams
         const int n = s_n[0];
         if (n == 0) break;
         if (tid == 0) nrows_total += (unsigned long long)s_n[1];
-        mv_eval_dispatch<MT, NTW, NW>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
+        mv_eval_dispatch<MT, NTW, NW, NET, (MT == 1)>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
         if (w == 0) {
             int used = 0;
             if (phase != 3) {

@@ -12,6 +12,7 @@ What differs from the reference internally (results are the same, see tests/):
 """
 import importlib
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -160,6 +161,63 @@ class RenderingNetwork(nn.Module):
         return Fn.render(net, ws, bs, points, normals, view_dirs, feature_vectors, self.view_spec)
 
 
+class LazyOutputs(dict):
+    """The output dict of a training forward with `IDRNetwork.lazy_unused_outputs`: `points` and `sdf_output` of the rays WITHOUT a hit come
+    from minimal_sdf_points (ray_tracing.py:280-308) -- 100 SDF evaluations per such ray, ~44 % of the tracer's rows at the bench shape --
+    and nothing in the training loop reads them (the loss reads neither key, loss.py:176-219; `use_mask` is off in this fork).  They are
+    computed the first time one of the two keys is read, by the same kernels on the same inputs: every value a caller can observe equals the
+    eager one.  Any access path (`[]`, get, items, values, iteration, dict(...), copy) goes through `_materialize` first when it may touch them."""
+    _LAZY = ('points', 'sdf_output')
+
+    def __init__(self, data, materialize):
+        super().__init__(data)
+        self._pending = materialize
+
+    def _materialize(self):
+        if self._pending is not None:
+            self._pending()                  # (an expired one raises and stays in place)
+            self._pending = None
+
+    def _expire(self):
+        """The next forward re-folds the weights into the same packed buffers: the deferred rows can no longer be evaluated at this step's
+        weights.  Reading them after that is an error, not a silently different value."""
+        if self._pending is not None:
+            def stale():
+                raise RuntimeError("lazy_unused_outputs: 'points' / 'sdf_output' of a previous step were first read after the next forward "
+                                   "started; read them before it, or set model.lazy_unused_outputs = False")
+            self._pending = stale
+
+    def __getitem__(self, k):
+        if k in self._LAZY:
+            self._materialize()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        if k in self._LAZY:
+            self._materialize()
+        return super().get(k, default)
+
+    def __iter__(self):                      # also makes dict(self) / {**self} take the generic (keys + __getitem__) route
+        return super().__iter__()
+
+    def items(self):
+        self._materialize()
+        return super().items()
+
+    def values(self):
+        self._materialize()
+        return super().values()
+
+    def copy(self):
+        self._materialize()
+        return dict(super().items())
+
+    def pop(self, k, *a):
+        if k in self._LAZY:
+            self._materialize()
+        return super().pop(k, *a)
+
+
 class IDRNetwork(nn.Module):
     def __init__(self, conf):
         super().__init__()
@@ -175,6 +233,8 @@ class IDRNetwork(nn.Module):
         self._counts_event = None
         self._draw = PinnedUniform()
         self._fold_cache = {}                                    # ops.FoldPlan of the training step's flat fold
+        self._lazy_prev = None
+        self.lazy_unused_outputs = False                         # training: evaluate the min-sdf points of non-hit rays only if `points` / `sdf_output` are read (LazyOutputs)
 
     def set_trace_dtype(self, dtype):
         """'f32' (default: fp32 weights, fp32-input MFMA, bit-exact against the oracle) or 'bf16' (BASELINE configs[4]: the ray tracer's SDF
@@ -209,6 +269,10 @@ class IDRNetwork(nn.Module):
         R = batch_size * num_pixels
         dev = ray_dirs.device
 
+        prev = self._lazy_prev() if self._lazy_prev is not None else None
+        if prev is not None:
+            prev._expire()
+        self._lazy_prev = None
         # one weight-norm fold per step, both networks in one launch pair (and one backward launch).  Training: the folded parameters are ONE
         # flat tensor (one autograd edge, pointer arithmetic instead of per-layer tensors); eval keeps the per-layer form the stand-alone
         # Functions take.
@@ -244,9 +308,11 @@ class IDRNetwork(nn.Module):
                 self._counts_host.copy_(torch.cat([sync['part'][3], dsurf[2]]), non_blocking=True)
             self._counts_event.record()
 
+        deferred = [] if (self.training and self.lazy_unused_outputs) else None
         with torch.no_grad():
             points, network_object_mask, dists = self.ray_tracer(sdf=NativeSDF(net), cam_loc=cam_loc, object_mask=object_mask,
-                                                                 ray_directions=ray_dirs, mask_ready=on_mask if self.training else None)
+                                                                 ray_directions=ray_dirs, mask_ready=on_mask if self.training else None,
+                                                                 defer_minsdf=deferred)
         ray_dirs = ray_dirs.reshape(-1, 3)
 
         if self.training:
@@ -334,6 +400,18 @@ class IDRNetwork(nn.Module):
             out['eikonal_output'] = eikonal_output
             out['surf_indicator_output'] = surf_indicator_output
         self.last_stats = {'R': R, 'N': N, 'E': (x_all.shape[0] - R), 'counters': self.ray_tracer.last_counters}
+        if deferred:
+            finish = deferred[0]
+
+            def materialize(points=points, sdf_output=sdf_output, mask=network_object_mask, net=net):
+                with torch.no_grad():
+                    finish()                                     # min-sdf rows: rewrites points / dists of the listed rays in place
+                    rows = torch.nonzero(~mask).flatten()        # their sdf_output = implicit_network(points)[:, :1] through the same forward kernel
+                    if rows.numel():
+                        y, _, _ = ops.sdf_forward(net, points[rows].contiguous(), 0)
+                        sdf_output[rows] = y[:, :1]
+            out = LazyOutputs(out, materialize)
+            self._lazy_prev = weakref.ref(out)
         return out
 
     def _rgb_from_shared(self, shared, ws, bs, points, view_dirs, N, train_progress, row0=0, folded=None):

@@ -53,12 +53,13 @@ class RayTracing(nn.Module):
         return (self.object_bounding_sphere, self.sdf_threshold, self.line_search_step, self.line_step_iters, iters,
                 self.n_steps, self.n_secant_steps, dist_clip)
 
-    def forward(self, sdf, cam_loc, object_mask, ray_directions, minsdf_steps=None, mask_ready=None):
+    def forward(self, sdf, cam_loc, object_mask, ray_directions, minsdf_steps=None, mask_ready=None, defer_minsdf=None):
         """-> (points[R,3], network_object_mask[R] bool, dists[R]).
         minsdf_steps: the n_steps uniform draws of minimal_sdf_points (ray_tracing.py:287); drawn here from torch's CPU
         generator when not given -- always, whereas the reference draws only if some ray needs them.
         mask_ready: optional callable(network_object_mask) run once the mask is final, before the secant / min-sdf launch is enqueued
-        (IDRNetwork uses it to fetch the hit count while that launch runs)."""
+        (IDRNetwork uses it to fetch the hit count while that launch runs).
+        defer_minsdf: see ops.trace (IDRNetwork.lazy_unused_outputs)."""
         net = getattr(sdf, 'native_net', None)
         dev = ray_directions.device
         key = (self.n_steps, str(dev))
@@ -85,6 +86,6 @@ class RayTracing(nn.Module):
         mt_samples = self.mt_samples or int(os.environ.get('MVSDF_MT_SAMPLES', '2'))
         pts, mask, dists, counters = ops.trace(net, cam_loc, ray_directions, object_mask, self._params(), self.training, intervals,
                                                minsdf_steps, mt=mt, mt_samples=mt_samples, events=self.events,
-                                               mask_ready=mask_ready)
+                                               mask_ready=mask_ready, defer_minsdf=defer_minsdf)
         self.last_counters = counters
         return pts, mask, dists

@@ -273,13 +273,15 @@ def _minsdf_stream(dev):
 
 
 def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, minsdf_steps=None, mt=1, mt_samples=4, events=None,
-          mask_ready=None):
+          mask_ready=None, defer_minsdf=None):
     """RayTracing.forward on the device -> (points[R,3], mask[R] bool, dists[R], counters[16] int64 device tensor).
     mt: row tiles per sphere-tracing workgroup (8*mt rays); mt_samples: row tiles per chunk of the sample-row kernels.
     events: optional list; when given the two kernels are launched by separate C calls and (start, mid, end) torch events
     recorded on the current stream are appended (per-kernel timing for bench.py's roofline).
     mask_ready: optional callable(mask_bool) invoked (on the host) after the launch that finalises the hit mask and BEFORE the secant /
-    min-sdf launch is enqueued: whatever it enqueues (e.g. an async copy of the hit count) completes while that last launch runs."""
+    min-sdf launch is enqueued: whatever it enqueues (e.g. an async copy of the hit count) completes while that last launch runs.
+    defer_minsdf: optional list; when given (with mask_ready, training) the min-sdf rows are NOT evaluated: a callable that evaluates them
+    later (stage 5: it rewrites points / dists of the non-hit rays in place) is appended instead."""
     cam_loc, ray_dirs = _f32(cam_loc), _f32(ray_dirs)
     B, P = ray_dirs.shape[:2]
     R = B * P
@@ -322,6 +324,14 @@ def trace(net, cam_loc, ray_dirs, object_mask, params, training, intervals, mins
         if side is not None:
             check(lib().mvsdf_trace_stage(6, *args), 'mvsdf_trace_stage(6)')
             torch.cuda.current_stream(dev).wait_event(e_out)
+        elif defer_minsdf is not None and training:
+            check(lib().mvsdf_trace_stage(6, *args), 'mvsdf_trace_stage(6)')
+            keep = (net, cam_loc, ray_dirs, om, iv, st, pts, mask, dists, counters, ws, d, tp)      # everything `args` points into
+
+            def finish(keep=keep, args=args):
+                a = args[:-1] + (stream_of(keep[2]),)
+                check(lib().mvsdf_trace_stage(5, *a), 'mvsdf_trace_stage(5)')
+            defer_minsdf.append(finish)
         else:
             check(lib().mvsdf_trace_stage(4, *args), 'mvsdf_trace_stage(4)')
         if ev:
