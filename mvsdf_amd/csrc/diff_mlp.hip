@@ -236,6 +236,17 @@ static hipError_t launch_wgrad_net(WgradNetArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Row tiles per workgroup of the fused chain kernels (the W <= 256, 16-wave instantiations).  A workgroup with two 16-row tiles takes
+// ~1.76x one tile (measured at c3: the phases are bound by the per-row loads / stores of the saved activations, not by the shared weight
+// fragments), so two tiles pay only when they save a round of the 256 CUs: 257..512 tiles (c5's per-GPU share: 248 -> 215 us), not
+// 513..768 (c3).  Four tiles never pay (3.8x).  MVSDF_CHAIN_MT=1|2 overrides (dev A/B).
+static int mv_chain_mt(int tiles16) {
+    static const int env = [] { const char* e = getenv("MVSDF_CHAIN_MT"); return e ? atoi(e) : 0; }();
+    if (env == 1 || env == 2) return env;
+    const int rounds1 = (tiles16 + 255) / 256, rounds2 = (tiles16 + 511) / 512;
+    return 1.76 * rounds2 < rounds1 ? 2 : 1;
+}
+
 #define MV_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mv_check(e_, #expr); } while (0)
 
 extern "C" {
@@ -285,7 +296,14 @@ int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float
         // two GEMMs (measured 148 -> 127 us here, 173 -> 143 us for the backward pass).  MVSDF_CHAIN_W8=1: 8 waves (dev A/B).
         const bool w8 = mv_chain_w8();
         const dim3 grid((M + 16 * MTC - 1) / (16 * MTC));
-        if (ntw_f == 2 && !w8) hipLaunchKernelGGL((k_chain_fwd<MTC, 1, 16>), grid, dim3(1024), lds, s, f);
+        const int mt = (ntw_f == 2 && !w8) ? mv_chain_mt((M + 15) / 16) : 1;
+        if (mt > 1) {
+            const size_t ldsm = ((size_t)16 * mt * S + 2 * ((16 * mt * lo.d0 + 3) & ~3) + 16 * mt * 4) * sizeof(float);
+            const dim3 gridm((M + 16 * mt - 1) / (16 * mt));
+            MV_TRY(hipFuncSetAttribute((const void*)k_chain_fwd<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
+            hipLaunchKernelGGL((k_chain_fwd<2, 1, 16>), gridm, dim3(1024), ldsm, s, f);
+        }
+        else if (ntw_f == 2 && !w8) hipLaunchKernelGGL((k_chain_fwd<MTC, 1, 16>), grid, dim3(1024), lds, s, f);
         else if (ntw_f == 2) hipLaunchKernelGGL((k_chain_fwd<MTC, 2, NWC>), grid, dim3(64 * NWC), lds, s, f);
         else if (!w8) hipLaunchKernelGGL((k_chain_fwd<MTC, 2, 16>), grid, dim3(1024), lds, s, f);
         else hipLaunchKernelGGL((k_chain_fwd<MTC, 4, NWC>), grid, dim3(64 * NWC), lds, s, f);
@@ -543,11 +561,16 @@ int mvsdf_sdf_backward_pair(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M
     ChainArgs a, b;
     fill_chain_args(a, net, netT, S, lo, sdf_bwd_layout(net, MbA), ctx, 0, MbA, dyA, dnA, wsA, nullptr, w8);
     fill_chain_args(b, net, netT, S, lo, sdf_bwd_layout(net, MbX), ctx, row0X, MbX, dyX, dnX, wsX, dx, w8);
-    const size_t lds = (size_t)16 * (S + lo.d0) * sizeof(float);
-    const int na = (MbA + 15) / 16, nb = (MbX + 15) / 16;
     const bool w8w = mv_chain_w8();
+    const int mt = (ntw_b == 2 && !w8w) ? mv_chain_mt((MbA + 15) / 16 + (MbX + 15) / 16) : 1;
+    const size_t lds = (size_t)16 * mt * (S + lo.d0) * sizeof(float);
+    const int na = (MbA + 16 * mt - 1) / (16 * mt), nb = (MbX + 16 * mt - 1) / (16 * mt);
     const dim3 grid(na + nb);
-    if (ntw_b == 2 && !w8w) hipLaunchKernelGGL((k_chain_bwd2<1, 1, 16>), grid, dim3(1024), lds, s, a, b, na);
+    if (mt == 2) {
+        MV_TRY(hipFuncSetAttribute((const void*)k_chain_bwd2<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_chain_bwd2<2, 1, 16>), grid, dim3(1024), lds, s, a, b, na);
+    }
+    else if (ntw_b == 2 && !w8w) hipLaunchKernelGGL((k_chain_bwd2<1, 1, 16>), grid, dim3(1024), lds, s, a, b, na);
     else if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd2<1, 2, 8>), grid, dim3(512), lds, s, a, b, na);
     else if (!w8w) hipLaunchKernelGGL((k_chain_bwd2<1, 2, 16>), grid, dim3(1024), lds, s, a, b, na);
     else hipLaunchKernelGGL((k_chain_bwd2<1, 4, 8>), grid, dim3(512), lds, s, a, b, na);
@@ -580,10 +603,15 @@ int mvsdf_sdf_backward_finish(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int
         c.net = net; c.netT = netT; c.S = S; c.M = MbD; c.row_ld0 = lo.ld0;
         c.ld_dy = net.L[nl - 1].N; c.dy_col0 = fbar; c.accum = 1;
         for (int l = 0; l < nl - 1; ++l) { c.Z[l] = ctx + lo.Z[l] + r0 * net.L[l].N; c.ZB[l] = ws + bl.ZB[l] + r0 * net.L[l].N; }
-        const size_t lds = (size_t)16 * (S + lo.d0) * sizeof(float);
         const bool w8w = mv_chain_w8();
-        const dim3 grid((MbD + 15) / 16);
-        if (ntw_b == 2 && !w8w) hipLaunchKernelGGL((k_chain_bwd<1, 1, 16>), grid, dim3(1024), lds, s, c);
+        const int mt = (ntw_b == 2 && !w8w) ? mv_chain_mt((MbD + 15) / 16) : 1;
+        const size_t lds = (size_t)16 * mt * (S + lo.d0) * sizeof(float);
+        const dim3 grid((MbD + 16 * mt - 1) / (16 * mt));
+        if (mt == 2) {
+            MV_TRY(hipFuncSetAttribute((const void*)k_chain_bwd<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_chain_bwd<2, 1, 16>), grid, dim3(1024), lds, s, c);
+        }
+        else if (ntw_b == 2 && !w8w) hipLaunchKernelGGL((k_chain_bwd<1, 1, 16>), grid, dim3(1024), lds, s, c);
         else if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd<1, 2, 8>), grid, dim3(512), lds, s, c);
         else if (!w8w) hipLaunchKernelGGL((k_chain_bwd<1, 2, 16>), grid, dim3(1024), lds, s, c);
         else hipLaunchKernelGGL((k_chain_bwd<1, 4, 8>), grid, dim3(512), lds, s, c);

@@ -378,11 +378,21 @@ def sdf_forward(net, x, Mg):
     return y, n, ctx
 
 
+def _check_rows(name, net, Mb, dy, dn):
+    """The kernels index dy / dn by row with the network's own output width: a tensor of another shape would be read as garbage, not rejected."""
+    nout = net.layers[-1].N
+    if dy.dim() != 2 or dy.shape[0] < Mb or dy.shape[1] != nout:
+        raise ValueError('%s: dy must be [>= %d, %d], got %s' % (name, Mb, nout, tuple(dy.shape)))
+    if dn is not None and (dn.dim() != 2 or dn.shape[0] < Mb or dn.shape[1] != 3):
+        raise ValueError('%s: dn must be [>= %d, 3], got %s' % (name, Mb, tuple(dn.shape)))
+
+
 def sdf_backward(net, x, M, Mg, Mb, dy, dn, ctx, want_dx, want_dw=True, row0=0, out=None):
     """-> (dWs [list per layer], dbs, dx or None) over rows [row0, row0 + Mb) (dWs = dbs = None when want_dw is False).
     x is the full [M,3] point tensor of the forward; dy / dn hold Mb rows."""
     x, dy = _f32(x), _f32(dy)
     dev = x.device
+    _check_rows('sdf_backward', net, Mb, dy, dn)
     d, dT = net.desc(), net.desc(True)
     ws_n, bs_n = net.wsizes()
     if out is not None:                                          # (dW_cat, db_cat) slices of a flat gradient: written in place, not split
@@ -406,6 +416,8 @@ def sdf_backward_pair(net, M, Mg, MbA, dyA, dnA, row0X, MbX, dyX, dnX, ctx):
     """Pass A (full backward over rows [0, MbA), adjoints kept in the returned workspace) and pass X (input adjoint of rows
     [row0X, row0X + MbX) for the upstream (dyX, dnX)) as ONE grid.  -> (wsA, dx[MbX,3]) or None when the fused chains do not cover the net."""
     dev = dyA.device
+    _check_rows('sdf_backward_pair (A)', net, MbA, dyA, dnA)
+    _check_rows('sdf_backward_pair (X)', net, MbX, dyX, dnX)
     d, dT = net.desc(), net.desc(True)
     wsA = torch.empty(lib().mvsdf_sdf_bwd_ws_floats(C.byref(d), MbA), dtype=torch.float32, device=dev)
     wsX = torch.empty(lib().mvsdf_sdf_bwd_ws_floats(C.byref(d), MbX), dtype=torch.float32, device=dev)
@@ -421,6 +433,7 @@ def sdf_backward_pair(net, M, Mg, MbA, dyA, dnA, row0X, MbX, dyX, dnX, ctx):
 def sdf_backward_finish(net, M, Mg, Mb, dy, ctx, wsA, row0D, MbD, fbar, out=None):
     """Delta pass (fbar on output column 0 of rows [row0D, row0D + MbD), added to the stored adjoints) + weight gradients -> (dWs, dbs)."""
     dev = dy.device
+    _check_rows('sdf_backward_finish', net, Mb, dy, None)
     d, dT = net.desc(), net.desc(True)
     if out is not None:
         dW, db = out

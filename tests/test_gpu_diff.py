@@ -104,3 +104,47 @@ def test_render_forward_backward_vs_golden():
         dvv, dg = ops.fold_backward(v, gg, dW.contiguous())
         assert _rel(dvv, g['d_lin%d.weight_v' % l]) < 5e-4 and _rel(dg, g['d_lin%d.weight_g' % l]) < 5e-4
         assert _rel(db, g['d_lin%d.bias' % l]) < 5e-4
+
+
+def test_two_tile_chain_workgroups_equal_one_tile():
+    """257..512 row tiles per launch run the fused chain kernels with two 16-row tiles per workgroup (diff_mlp.hip, mv_chain_mt): rows are
+    independent, so forward outputs, saved context use and input adjoints must equal, bit for bit, those of launches small enough to use
+    one tile per workgroup; the weight gradients agree to summation order."""
+    sd = synth.make_state_dict(256, 0)
+    net = sdf_packed_net(sd)
+    M = 4500                                                     # 282 tiles -> two per workgroup;  1500 rows (94 tiles) -> one
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(M, 3, generator=gen) * 2 - 1).cuda()
+    dy = torch.randn(M, net.layers[-1].N, generator=gen).cuda() * 0.1
+    dn = torch.randn(M, 3, generator=gen).cuda()
+    y, n, ctx = ops.sdf_forward(net, x, M)
+    dWs, dbs, dx = ops.sdf_backward(net, x, M, M, M, dy, dn, ctx, True)
+    wsA, dxX = ops.sdf_backward_pair(net, M, M, M, dy, dn, 100, 2000, dy[100:2100].contiguous(), dn[100:2100].contiguous(), ctx)
+    fbar = torch.randn(2000, generator=gen).cuda()
+    dy2 = dy.clone(); dy2[100:2100, 0] += fbar
+    dWf, dbf = ops.sdf_backward_finish(net, M, M, M, dy2, ctx, wsA, 100, 2000, fbar)
+    acc_W = [torch.zeros_like(w) for w in dWs]
+    acc_Wf = [torch.zeros_like(w) for w in dWs]
+    for r0 in range(0, M, 1500):
+        xs = x[r0:r0 + 1500].contiguous()
+        ys, ns, cs = ops.sdf_forward(net, xs, 1500)
+        assert torch.equal(ys, y[r0:r0 + 1500]) and torch.equal(ns, n[r0:r0 + 1500])
+        dWp, _, dxp = ops.sdf_backward(net, xs, 1500, 1500, 1500, dy[r0:r0 + 1500].contiguous(), dn[r0:r0 + 1500].contiguous(), cs, True)
+        assert torch.equal(dxp, dx[r0:r0 + 1500])
+        dWq, _, _ = ops.sdf_backward(net, xs, 1500, 1500, 1500, dy2[r0:r0 + 1500].contiguous(), dn[r0:r0 + 1500].contiguous(), cs, False)
+        for l in range(len(dWs)):
+            acc_W[l] += dWp[l]; acc_Wf[l] += dWq[l]
+    assert torch.equal(dxX, dx[100:2100])                        # pass X of the pair = the same input adjoint
+    for l in range(len(dWs)):
+        assert _rel(acc_W[l], dWs[l].cpu().numpy()) < 2e-5, l
+        assert _rel(acc_Wf[l], dWf[l].cpu().numpy()) < 2e-5, l   # pair + delta pass + finish = plain backward with the fbar folded into dy
+
+
+def test_backward_rejects_upstream_of_the_wrong_width():
+    net = sdf_packed_net(synth.make_state_dict(64, 0))
+    x = torch.rand(40, 3).cuda()
+    y, n, ctx = ops.sdf_forward(net, x, 40)
+    with pytest.raises(ValueError, match='dy must be'):
+        ops.sdf_backward(net, x, 40, 40, 40, torch.zeros(40, y.shape[1] - 1).cuda(), None, ctx, True)
+    with pytest.raises(ValueError, match='dn must be'):
+        ops.sdf_backward(net, x, 40, 40, 40, torch.zeros_like(y), torch.zeros(39, 3).cuda(), ctx, True)
