@@ -169,6 +169,7 @@ def main():
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--variants', action='store_true', help='also time the opt-in lazy_unused_outputs step (secondary number; off by default so that a profile of this command holds the headline step only)')
     a = ap.parse_args()
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -304,7 +305,7 @@ def main():
                                   'achieved': flops_step / (dt / a.steps) / 1e12, 'frac': flops_step / (dt / a.steps) / 1e12 / peak}},
             'loss': float(lo['loss'].detach()),
         }
-        if world == 1:
+        if world == 1 and a.variants:
             # secondary number, never `value`: the same step with the opt-in IDRNetwork.lazy_unused_outputs (the min-sdf points of non-hit rays,
             # which the training loop never reads, are evaluated only when `points` / `sdf_output` are read -- here: never)
             model.lazy_unused_outputs = True
