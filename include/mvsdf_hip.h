@@ -28,11 +28,13 @@ typedef struct {
     const float* wp[MVSDF_MAX_LAYERS];  /* packed weights, mvsdf_packed_floats(N, K) floats */
     const float* bias[MVSDF_MAX_LAYERS];
     const float* w[MVSDF_MAX_LAYERS];   /* folded weights, row-major [N][K] (only the last layer's row 0 is read: u_L = W_L[0,:]); may be NULL when no normals are needed */
-    int skip_layer;                     /* layer whose input is cat([x, PE(x)])/sqrt(2) (idr.py:86-87), -1 if none */
+    int skip_layer;                     /* layer whose input is cat([x, PE(x)])/sqrt(2) (idr.py:86-87), -1 if none (see skip_mask for several) */
     int multires;                       /* positional-encoding frequencies (embedder.py:38-50) */
     const void* wp16[MVSDF_MAX_LAYERS]; /* bf16 packs made by mvsdf_pack_bf16_net (BASELINE configs[4]); NULL unless trace_dtype == 1 */
     int trace_dtype;                    /* arithmetic of the no-grad tracing MLP (mvsdf_trace, mvsdf_sdf_col0): 0 = fp32 weights and fp32-input
                                          * MFMA (bit-exact against the oracle), 1 = bf16 weights / activations on the bf16 MFMA, fp32 accumulate */
+    unsigned skip_mask;                 /* several skip connections (skip_in with more than one entry, idr.py:46,86): bit l set = the input of layer l
+                                         * is cat([x, PE(x)])/sqrt(2).  0 = use skip_layer alone.  Layer 0 and the last layer cannot be skip layers. */
 } MvsdfNetDesc;
 
 /* RayTracing constructor arguments (ray_tracing.py:7-25) + the hard-coded dist_clip (ray_tracing.py:127-131). */
@@ -92,6 +94,9 @@ int mvsdf_fold_backward(const float* v, const float* g, const float* dW, int N, 
 size_t mvsdf_packed_bf16_bytes(int N, int K, int nsplit);
 int mvsdf_pack_bf16_net(int n_layers, const float* const* w, const int* N, const int* K, int skip_layer, int multires, void* const* wp16,
                         void* stream);
+/* the same for a network with several skip connections (MvsdfNetDesc.skip_mask) */
+int mvsdf_pack_bf16_net_skips(int n_layers, const float* const* w, const int* N, const int* K, unsigned skip_mask, int multires, void* const* wp16,
+                              void* stream);
 
 /* ImplicitNetwork.forward(x)[:, 0] (idr.py:77-94) for n points: the tracing MLP alone. */
 int mvsdf_sdf_col0(const MvsdfNetDesc* net, const float* x, int n, float* y, int mt, void* stream);

@@ -436,13 +436,18 @@ size_t mvsdf_packed_bf16_bytes(int N, int K, int nsplit) { return mv_packed_bf16
 
 int mvsdf_pack_bf16_net(int n_layers, const float* const* w, const int* N, const int* K, int skip_layer, int multires, void* const* wp16,
                         void* stream) {
+    return mvsdf_pack_bf16_net_skips(n_layers, w, N, K, skip_layer >= 0 ? 1u << skip_layer : 0u, multires, wp16, stream);
+}
+
+int mvsdf_pack_bf16_net_skips(int n_layers, const float* const* w, const int* N, const int* K, unsigned skip_mask, int multires, void* const* wp16,
+                              void* stream) {
     if (n_layers < 1 || n_layers > MV_MAXL || !w || !N || !K || !wp16) return mv_fail(-1, "mvsdf_pack_bf16_net: bad arguments");
     PackBfArgs a;
     size_t maxTot = 0;
     for (int l = 0; l < n_layers; ++l) {
         if (!w[l] || !wp16[l] || N[l] <= 0 || K[l] <= 0) return mv_fail(-1, "mvsdf_pack_bf16_net: null layer pointer / bad dims");
         a.w[l] = w[l]; a.wp[l] = (uint16_t*)wp16[l]; a.N[l] = N[l]; a.K[l] = K[l];
-        a.nsplit[l] = (l == 0 || l == skip_layer) ? 3 + 6 * multires : 0;
+        a.nsplit[l] = (l == 0 || mv_skip_at(skip_mask, l)) ? 3 + 6 * multires : 0;
         const size_t t = mv_packed_bf16_elems(N[l], K[l], a.nsplit[l]);
         if (t > maxTot) maxTot = t;
     }

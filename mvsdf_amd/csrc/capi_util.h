@@ -11,7 +11,9 @@ int mv_check(hipError_t e, const char* where);   // 0 on success
 int mv_make_net_mode(const MvsdfNetDesc* d, MvNet* net, int mode);
 static inline int mv_make_net(const MvsdfNetDesc* d, MvNet* net) { return mv_make_net_mode(d, net, 0); }
 int mv_make_net_bf(const MvsdfNetDesc* d, MvNetBf* net);      // SDF net on the bf16 packs (trace_dtype == 1)
-static inline int mv_bf_nsplit(const MvsdfNetDesc* d, int l) { return (l == 0 || l == d->skip_layer) ? 3 + 6 * d->multires : 0; }
+// skip layers of a descriptor as a bit mask (skip_mask wins; else the single skip_layer)
+static inline unsigned mv_desc_skip_mask(const MvsdfNetDesc* d) { return d->skip_mask ? d->skip_mask : (d->skip_layer >= 0 ? 1u << d->skip_layer : 0u); }
+static inline int mv_bf_nsplit(const MvsdfNetDesc* d, int l) { return (l == 0 || mv_skip_at(mv_desc_skip_mask(d), l)) ? 3 + 6 * d->multires : 0; }
 
 // column tiles per wave the fused chain kernels need for this network (8 waves per workgroup): 2 up to width 256, 4 up to 512,
 // 0 = too wide for them (per-layer kernels take over)

@@ -17,11 +17,13 @@ int mv_make_net_mode(const MvsdfNetDesc* d, MvNet* net, int mode) {
     if (!d || d->n_layers < 1 || d->n_layers > MV_MAXL) return mv_fail(-2, "net descriptor: n_layers out of range");
     memset(net, 0, sizeof(*net));
     int maxk = 0;
+    const unsigned skm = mode == 0 ? mv_desc_skip_mask(d) : 0u;
+    if (skm & 1u || skm >> (d->n_layers - 1)) return mv_fail(-2, "net descriptor: layer 0 and the last layer cannot be skip layers");
     for (int l = 0; l < d->n_layers; ++l) {
         if (!d->wp[l] || !d->bias[l] || d->K[l] <= 0 || d->N[l] <= 0) return mv_fail(-2, "net descriptor: null pointer or bad dims");
         if (mode == 0) {
             if (l > 0) {
-                const int expect = (l == d->skip_layer) ? d->N[l - 1] + 3 + 6 * d->multires : d->N[l - 1];
+                const int expect = mv_skip_at(skm, l) ? d->N[l - 1] + 3 + 6 * d->multires : d->N[l - 1];
                 if (d->K[l] != expect) return mv_fail(-2, "net descriptor: layer dims do not chain");
             } else if (d->K[0] != 3 + 6 * d->multires) {
                 return mv_fail(-2, "net descriptor: first layer K != 3 + 6*multires");
@@ -38,7 +40,7 @@ int mv_make_net_mode(const MvsdfNetDesc* d, MvNet* net, int mode) {
         if (mode == 0 && l < d->n_layers - 1 && L.NT > 32) return mv_fail(-2, "net descriptor: hidden width > 512 not supported");
     }
     net->n_layers = d->n_layers;
-    net->skip_layer = mode == 0 ? d->skip_layer : -1;
+    net->skip_mask = skm;
     net->multires = mode == 0 ? d->multires : 0;
     net->S = ((maxk + 63) & ~63) + 8;
     return 0;
@@ -60,7 +62,7 @@ int mv_make_net_bf(const MvsdfNetDesc* d, MvNetBf* net) {
         L.KB = mv_bf_kb(L.K, L.nsplit); L.NT = mv_ceil16(d->N[l]) / 16;
         if (L.KB * 32 > maxk) maxk = L.KB * 32;
     }
-    net->n_layers = d->n_layers; net->skip_layer = d->skip_layer; net->multires = d->multires;
+    net->n_layers = d->n_layers; net->skip_mask = chk.skip_mask; net->multires = d->multires;
     net->S = (maxk + 8) / 2;                                      // bf16 row = 32*KB + 8 elements = 64*KB + 16 bytes (odd multiple of 16: conflict-free b128 reads)
     return 0;
 }

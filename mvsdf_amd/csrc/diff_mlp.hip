@@ -236,6 +236,14 @@ static hipError_t launch_wgrad_net(WgradNetArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// the skip layer of a network with at most one (-1: none); -2: several (only the fused chain kernels handle those)
+static int mv_single_skip(const MvNet& net) {
+    const unsigned m = net.skip_mask;
+    if (!m) return -1;
+    if (m & (m - 1)) return -2;
+    return __builtin_ctz(m);
+}
+
 // Row tiles per workgroup of the fused chain kernels (the W <= 256, 16-wave instantiations).  A workgroup with two 16-row tiles takes
 // ~1.76x one tile (measured at c3: the phases are bound by the per-row loads / stores of the saved activations, not by the shared weight
 // fragments), so two tiles pay only when they save a round of the 256 CUs: 257..512 tiles (c5's per-GPU share: 248 -> 215 us), not
@@ -315,7 +323,7 @@ int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float
         a.A = l == 0 ? H0 : ctx + lo.A[l]; a.lda = l == 0 ? lo.ld0 : net.L[l].K;
         a.out1 = ctx + lo.Z[l]; a.ld1 = net.L[l].N;
         a.out0 = ctx + lo.A[l + 1]; a.ld0 = net.L[l + 1].K;
-        a.skip_next = (l + 1 == net.skip_layer); a.d0 = lo.d0; a.pe = H0; a.ldpe = lo.ld0;
+        a.skip_next = mv_skip_at(net.skip_mask, l + 1); a.d0 = lo.d0; a.pe = H0; a.ldpe = lo.ld0;
         MV_TRY((launch_layer<PRO_PLAIN, EPI_SOFTPLUS>(a, s)));
     }
     {
@@ -324,6 +332,8 @@ int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float
         MV_TRY((launch_layer<PRO_PLAIN, EPI_BIAS>(a, s)));
     }
     if (Mg > 0) {                                                                 // normal = VJP of output 0 (idr.py:96-107)
+        const int sk1 = mv_single_skip(net);
+        if (sk1 == -2) return mv_fail(-4, "mvsdf_sdf_forward: several skip connections need the fused chain kernels (MVSDF_FUSE unset)");
         const float* w8 = d->w[nl - 1];                                           // row 0 of the last layer = u_{nl-1}
         for (int l = nl - 2; l >= 0; --l) {
             LayerArgs a = base_args(netT.L[l], S, Mg);
@@ -331,13 +341,13 @@ int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float
             const bool top = (l == nl - 2);
             if (top) a.bcast = w8; else { a.U = ctx + lo.U[l + 1]; a.ldu = net.L[l].N; }
             a.out2 = ctx + lo.Sg[l]; a.ld2 = net.L[l].N;                            // keep s_l for the weight gradient
-            if (l == net.skip_layer) {
+            if (l == sk1) {
                 a.csplit = net.L[l].K - lo.d0; a.scale_sqrt2 = 1;
                 a.out0 = ctx + lo.U[l]; a.ld0 = net.L[l - 1].N;
                 a.out1 = ctx + lo.E; a.ld1 = lo.ld0;
             } else if (l == 0) {
                 a.csplit = net.L[0].K;
-                if (net.skip_layer > 0) { a.add = ctx + lo.E; a.ldadd = lo.ld0; }
+                if (sk1 > 0) { a.add = ctx + lo.E; a.ldadd = lo.ld0; }
                 a.out0 = ctx + lo.G0; a.ld0 = lo.ld0;
             } else {
                 a.csplit = net.L[l].K;
@@ -366,7 +376,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
     hipStream_t s = (hipStream_t)stream;
     const SdfLayout lo = sdf_ctx_layout(net, M, Mg);
     const SdfBwdLayout bl = sdf_bwd_layout(net, Mb);
-    const int nl = lo.nl, S = stride_for(net, netT), sk = net.skip_layer;
+    const int nl = lo.nl, S = stride_for(net, netT), sk = mv_single_skip(net);     // per-layer fallback launches below: one skip layer at most
     const size_t r0 = (size_t)row0;
     const float* H0 = ctx + lo.H0 + r0 * lo.ld0;                 // every context tensor is [rows][width]: a row offset is a pointer offset
     const float* w8 = d->w[nl - 1];
@@ -405,6 +415,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         MV_TRY(hipGetLastError());
         chains_done = true;
     }
+    if (!chains_done && sk == -2) return mv_fail(-4, "mvsdf_sdf_backward: several skip connections need the fused chain kernels (MVSDF_FUSE / MVSDF_SPLIT_CHAINS unset)");
     // ---- E.1: adjoint of the normal chain (ascending) ----
     if (dn && !chains_done) {
         hipLaunchKernelGGL(k_pe_normal_bwd, dim3((Mb * (3 * net.multires + 1) + 255) / 256), dim3(256), 0, s, H0, lo.ld0, dn, Mb,

@@ -450,7 +450,8 @@ __global__ __launch_bounds__(64 * NW) void k_chain_e2(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT, NTH = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers, sk = a.net.skip_layer, d0 = 3 + 6 * a.net.multires;
+    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers, d0 = 3 + 6 * a.net.multires;
+    const unsigned skm = a.net.skip_mask;
     float* act = smem;
     float* pe_adj = smem + ROWS * S;                             // [ROWS][d0]: PE adjoint contributed by the skip layer, added at l = 0
     for (int i = tid; i < ROWS * d0; i += NTH) pe_adj[i] = 0.0f;
@@ -502,10 +503,10 @@ __global__ __launch_bounds__(64 * NW) void k_chain_e2(ChainArgs a) {
                         for (int i = 0; i < 4; ++i) {
                             const int rr = m * 16 + 4 * q + i, row = row0 + rr;
                             float v = acc[m][t][i];
-                            if (l == sk) {
+                            if (mv_skip_at(skm, l)) {
                                 v = dm_div_sqrt2(v);
                                 if (col < N - d0) act[rr * S + mv_perm(col)] = v;
-                                else pe_adj[rr * d0 + (col - (N - d0))] = v;
+                                else pe_adj[rr * d0 + (col - (N - d0))] += v;              // several skip layers: their PE adjoints add up (zeroed above)
                             } else if (l == 0) {
                                 if (row < a.M) a.H0B[(size_t)row * a.row_ld0 + col] = pe_adj[rr * d0 + col] + v;
                             } else {
@@ -526,7 +527,8 @@ __global__ __launch_bounds__(64 * NW) void k_chain_e1(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT, NTH = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers, sk = a.net.skip_layer, d0 = 3 + 6 * a.net.multires;
+    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers, d0 = 3 + 6 * a.net.multires;
+    const unsigned skm = a.net.skip_mask;
     float* act = smem;
     float* g0s = smem + ROWS * S;                                // [ROWS][d0]: gbar_0, re-enters at the skip layer
     {
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_e1(ChainArgs a) {
     for (int l = 0; l < nl - 1; ++l) {
         const MvLayer& L = a.net.L[l];
         const int N = L.N;
-        const bool top = (l == nl - 2), to_skip = (l + 1 == sk);
+        const bool top = (l == nl - 2), to_skip = mv_skip_at(skm, l + 1);
         const int NT = L.NT, per = (NT + NW - 1) / NW, ct0 = w * per;
         int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
         f32x4 acc[MT][NTW];
@@ -616,7 +618,8 @@ template <int MT, int NTW, int NW>
 __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, float* smem) {
     constexpr int ROWS = 16 * MT, NTH = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-    const int row0 = blk * ROWS, S = a.S, nl = a.net.n_layers, sk = a.net.skip_layer, d0 = 3 + 6 * a.net.multires;
+    const int row0 = blk * ROWS, S = a.S, nl = a.net.n_layers, d0 = 3 + 6 * a.net.multires;
+    const unsigned skm = a.net.skip_mask;
     float* act = smem;
     float* g0s = smem + ROWS * S;                                // [ROWS][d0]: gbar_0 (E.1), then the PE adjoint (E.2)
     float* pe_adj = g0s;
@@ -644,7 +647,7 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
         for (int l = 0; l < nl - 1; ++l) {
             const MvLayer& L = a.net.L[l];
             const int N = L.N;
-            const bool top = (l == nl - 2), to_skip = (l + 1 == sk);
+            const bool top = (l == nl - 2), to_skip = mv_skip_at(skm, l + 1);
             const int NT = L.NT, per = (NT + NW - 1) / NW, ct0 = w * per;
             int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
             f32x4 acc[MT][NTW];
@@ -762,10 +765,10 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
                         for (int i = 0; i < 4; ++i) {
                             const int rr = m * 16 + 4 * q + i, row = row0 + rr;
                             float v = acc[m][t][i];
-                            if (l == sk) {
+                            if (mv_skip_at(skm, l)) {
                                 v = dm_div_sqrt2(v);
                                 if (col < N - d0) act[rr * S + mv_perm(col)] = v;
-                                else pe_adj[rr * d0 + (col - (N - d0))] = v;
+                                else pe_adj[rr * d0 + (col - (N - d0))] += v;              // several skip layers: their PE adjoints add up (zeroed above)
                             } else if (l == 0) {
                                 const float hb0 = pe_adj[rr * d0 + col] + v;
                                 pe_adj[rr * d0 + col] = hb0;                       // kept for the input adjoint below
@@ -843,7 +846,8 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT, NTH = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers, sk = a.net.skip_layer, d0 = 3 + 6 * a.net.multires;
+    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers, d0 = 3 + 6 * a.net.multires;
+    const unsigned skm = a.net.skip_mask;
     float* act = smem;
     float* pe = act + ROWS * S;                                  // [ROWS][d0] natural order
     float* padj = pe + ((ROWS * d0 + 3) & ~3);                   // [ROWS][d0] PE adjoint of the skip layer, then g_0
@@ -864,7 +868,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
         const MvLayer& L = a.net.L[l];
         const int N = L.N, NT = L.NT, per = (NT + NW - 1) / NW, ct0 = w * per;
         int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
-        const bool to_skip = (l + 1 == sk);
+        const bool to_skip = mv_skip_at(skm, l + 1);
         const int Kn = a.net.L[l + 1].K, Kpn = a.net.L[l + 1].KB * 16;
         f32x4 acc[MT][NTW];
         mv_zero_acc<MT, NTW>(acc);
@@ -984,14 +988,14 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
                         for (int i = 0; i < 4; ++i) {
                             const int rr = m * 16 + 4 * q + i, row = row0 + rr;
                             float v = acc[m][t][i];
-                            if (l == sk) {
+                            if (mv_skip_at(skm, l)) {
                                 v = dm_div_sqrt2(v);
                                 if (col < N - d0) {
                                     act[rr * S + mv_perm(col)] = v;
                                     if (row < a.Mg) a.U[l][(size_t)row * (N - d0) + col] = v;
-                                } else padj[rr * d0 + (col - (N - d0))] = v;
+                                } else padj[rr * d0 + (col - (N - d0))] += v;
                             } else if (l == 0) {
-                                const float g = (sk > 0 ? padj[rr * d0 + col] : 0.0f) + v;
+                                const float g = padj[rr * d0 + col] + v;
                                 padj[rr * d0 + col] = g;
                                 if (row < a.Mg) a.G0[(size_t)row * a.ld0 + col] = g;
                             } else {

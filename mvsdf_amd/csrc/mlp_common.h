@@ -25,11 +25,12 @@ struct MvLayer {
 struct MvNet {
     MvLayer L[MV_MAXL];
     int n_layers;
-    int skip_layer;     // layer whose input is cat([x, PE]) / sqrt(2), or -1
+    unsigned skip_mask; // bit l set: the input of layer l is cat([x, PE]) / sqrt(2)  (idr.py:86-87; the shipped conf: layer 4 only)
     int multires;       // PE frequencies; d_pe = 3 + 6*multires
     int S;              // LDS activation row stride in floats (== 8 mod 64: conflict-free ds_read_b128 A fragments)
 };
 
+__host__ __device__ static inline bool mv_skip_at(unsigned mask, int l) { return l >= 0 && ((mask >> l) & 1u) != 0; }
 __host__ __device__ static inline int mv_ceil16(int x) { return (x + 15) & ~15; }
 // K is padded to a multiple of 32 (an EVEN number of 16-wide k-blocks) so the 2x-unrolled pipelined loop has no tail
 __host__ __device__ static inline int mv_kpad(int x) { return (x + 31) & ~31; }

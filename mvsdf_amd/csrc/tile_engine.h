@@ -255,7 +255,7 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
                     for (int i = 0; i < 4; ++i) out[a * 16 + 4 * q + i] = acc[a][0][i] + b0;
             }
         } else {
-            const bool to_skip = (l + 1 == net.skip_layer);
+            const bool to_skip = mv_skip_at(net.skip_mask, l + 1);
             const int N = L.N;
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
@@ -427,7 +427,7 @@ __device__ void mv_sdf_eval_col0_ks(const MvNet& net, float* act0, float* act1, 
                 for (int i = 0; i < 4; ++i) out[4 * q + i] = acc[0][0][i] + b0;
             }
         } else {
-            const bool to_skip = (l + 1 == net.skip_layer);
+            const bool to_skip = mv_skip_at(net.skip_mask, l + 1);
             const int N = L.N;
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {

@@ -30,7 +30,7 @@ struct MvLayerBf {
 struct MvNetBf {
     MvLayerBf L[MV_MAXL];
     int n_layers;
-    int skip_layer;
+    unsigned skip_mask;
     int multires;
     int S;              // LDS activation row stride in FLOAT units (the bf16 row holds 2*S elements), so LDS carving matches the fp32 engine
 };
@@ -172,7 +172,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBf& net, float* actf, float* pe, con
                     for (int i = 0; i < 4; ++i) out[a * 16 + 4 * q + i] = acc[a][0][i] + b0;
             }
         } else {
-            const bool to_skip = (l + 1 == net.skip_layer);
+            const bool to_skip = mv_skip_at(net.skip_mask, l + 1);
             const int N = L.N;
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {

@@ -44,7 +44,8 @@ __device__ __forceinline__ int mv_rows_pos(int c) { return ((c & 3) << 2) | (c >
 template <int NTL>
 __device__ __forceinline__ void mv_sdf_eval_col0_rows(const MvNet& net, const MvRowsLds& lds, const float* pts, float* out, int tid) {
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-    const int nl = net.n_layers, d0 = 3 + 6 * net.multires, sk = net.skip_layer;
+    const int nl = net.n_layers, d0 = 3 + 6 * net.multires;
+    const unsigned skm = net.skip_mask;
     float* tile = lds.tile + w * 2 * 16 * MV_ROWS_TS;
 
     // ---- the weight stream: global k-block index G runs over (layer, kb); loader cursor (ll, lkb), data of ONE block in flight in registers
@@ -119,7 +120,7 @@ __device__ __forceinline__ void mv_sdf_eval_col0_rows(const MvNet& net, const Mv
         const int KB = L.KB;
         const MvLayer& Lp = net.L[l > 0 ? l - 1 : 0];            // producer of this layer's input
         const int Np = Lp.N, NTp = Lp.NT;
-        const bool from_skip = (l == sk);                        // this layer's input is cat([h, PE]) / sqrt(2)
+        const bool from_skip = mv_skip_at(skm, l);                        // this layer's input is cat([h, PE]) / sqrt(2)
         f32x4 acc[NTL];
 #pragma unroll
         for (int t = 0; t < NTL; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};

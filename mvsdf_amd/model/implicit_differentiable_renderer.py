@@ -74,8 +74,10 @@ class ImplicitNetwork(nn.Module):
         dims[0] = 3 + 6 * multires
         self.num_layers = len(dims)
         self.skip_in = tuple(skip_in)
-        if len(self.skip_in) > 1:
-            raise NotImplementedError('one skip connection is supported (mvsdf_dtu.conf:27)')
+        if self.num_layers - 2 in self.skip_in:
+            raise NotImplementedError('a skip connection into the LAST Linear is not supported by the native kernels (no shipped conf has one)')
+        if len([s for s in self.skip_in if 0 < s < self.num_layers - 2]) > 1 and max(dims[1:-1]) > 512:
+            raise NotImplementedError('several skip connections need the fused chain kernels (hidden width <= 512)')
         self.d_out = d_out
         for l in range(self.num_layers - 1):
             out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
@@ -102,7 +104,8 @@ class ImplicitNetwork(nn.Module):
 
     def fold_spec(self):
         lins = self._lins()
-        return ([m.weight_v for m in lins], [m.weight_g for m in lins], [m.bias for m in lins], self.skip_in[0] if self.skip_in else -1,
+        skips = tuple(sorted(s for s in set(self.skip_in) if 0 < s < self.num_layers - 1))      # idr.py:86: `if l in self.skip_in`
+        return ([m.weight_v for m in lins], [m.weight_g for m in lins], [m.bias for m in lins], skips if len(skips) != 1 else skips[0],
                 self.multires)
 
     def fold(self):

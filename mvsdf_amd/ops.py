@@ -21,7 +21,10 @@ class PackedNet:
     """A weight-norm-folded MLP: row-major W (for autograd bookkeeping), MFMA-packed W and W^T, biases."""
 
     def __init__(self, layers, skip_layer, multires):
-        self.layers, self.skip_layer, self.multires = layers, skip_layer, multires
+        """skip_layer: the layer whose input is cat([x, PE]) / sqrt(2) (-1: none), or a sequence of such layers (skip_in, idr.py:46,86)."""
+        self.skip_layers = tuple(sorted(int(s) for s in skip_layer)) if isinstance(skip_layer, (tuple, list)) else ((int(skip_layer),) if skip_layer >= 0 else ())
+        self.layers, self.multires = layers, multires
+        self.skip_layer = self.skip_layers[0] if self.skip_layers else -1
         self.trace_dtype = 0                # 1: the tracing MLP runs on the bf16 packs (pack_bf16_net)
 
     def desc(self, transposed=False):
@@ -39,6 +42,8 @@ class PackedNet:
             d.bias[i] = L.bias.data_ptr()
             d.w[i] = L.w.data_ptr() if L.w is not None else L.w_ptr
         d.skip_layer, d.multires = self.skip_layer, self.multires
+        if len(self.skip_layers) > 1 and not transposed:
+            d.skip_mask = sum(1 << s for s in self.skip_layers)
         if not transposed and self.trace_dtype == 1:
             for i, L in enumerate(self.layers):
                 d.wp16[i] = L.wp16.data_ptr()
@@ -223,12 +228,13 @@ def pack_bf16_net(net):
     d0 = 3 + 6 * net.multires
     dev = net.layers[0].bias.device
     for i, L in enumerate(net.layers):
-        ns = d0 if (i == 0 or i == net.skip_layer) else 0
+        ns = d0 if (i == 0 or i in net.skip_layers) else 0
         L.wp16 = torch.empty(lib().mvsdf_packed_bf16_bytes(L.N, L.K, ns), dtype=torch.uint8, device=dev)
     N = (C.c_int * n)(*[L.N for L in net.layers])
     K = (C.c_int * n)(*[L.K for L in net.layers])
-    check(lib().mvsdf_pack_bf16_net(n, _int_ptr_array([L.w.data_ptr() if L.w is not None else L.w_ptr for L in net.layers]), N, K, net.skip_layer, net.multires,
-                                    _ptr_array([L.wp16 for L in net.layers]), stream_of(net.layers[0].bias)), 'mvsdf_pack_bf16_net')
+    check(lib().mvsdf_pack_bf16_net_skips(n, _int_ptr_array([L.w.data_ptr() if L.w is not None else L.w_ptr for L in net.layers]), N, K,
+                                          C.c_uint(sum(1 << s for s in net.skip_layers)), net.multires,
+                                          _ptr_array([L.wp16 for L in net.layers]), stream_of(net.layers[0].bias)), 'mvsdf_pack_bf16_net_skips')
     net.trace_dtype = 1
     net.__dict__.pop('_d', None)
     return net

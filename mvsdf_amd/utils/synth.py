@@ -42,12 +42,12 @@ def render_layer_dims(W, n_hidden=4, multires_view=PE_VIEW, feat=FEAT):
     return [(dims[l], dims[l + 1]) for l in range(len(dims) - 1)]
 
 
-def make_state_dict(W, seed=0, noise=0.02, bias=0.6, n_hidden=8, n_hidden_r=4):
+def make_state_dict(W, seed=0, noise=0.02, bias=0.6, n_hidden=8, n_hidden_r=4, skip_in=(4,)):
     """state_dict (numpy float32) in the reference key layout
     implicit_network.lin{l}.{bias,weight_g,weight_v}, rendering_network.lin{l}.*"""
     rs = np.random.RandomState(seed)
     sd = OrderedDict()
-    dims = sdf_layer_dims(W, n_hidden)
+    dims = sdf_layer_dims(W, n_hidden, skip_in=tuple(skip_in))
     d0 = dims[0][0]
     L = len(dims)
     for l, (i, o) in enumerate(dims):
@@ -58,7 +58,7 @@ def make_state_dict(W, seed=0, noise=0.02, bias=0.6, n_hidden=8, n_hidden_r=4):
             w = np.zeros((o, i))
             w[:, :3] = rs.normal(0.0, np.sqrt(2) / np.sqrt(o), size=(o, 3))
             b = np.zeros((o,))
-        elif l == 4:  # l in skip_in
+        elif l in skip_in:
             w = rs.normal(0.0, np.sqrt(2) / np.sqrt(o), size=(o, i))
             w[:, -(d0 - 3):] = 0.0
             b = np.zeros((o,))
@@ -86,12 +86,12 @@ def state_checksum(sd):
                     + [float(np.abs(np.float64(v)).sum()) for v in sd.values()])
 
 
-def model_conf(W, line_step_iters=3, n_hidden=8, n_hidden_r=4):
+def model_conf(W, line_step_iters=3, n_hidden=8, n_hidden_r=4, skip_in=(4,)):
     """Plain-dict model config equal to the 'model' block of mvsdf_dtu.conf:18-58 at width W."""
     return dict(
         feature_vector_size=FEAT,
         implicit_network=dict(d_in=3, d_out=1, dims=[W] * n_hidden, geometric_init=True, bias=0.6,
-                              skip_in=[4], weight_norm=True, multires=PE_SDF),
+                              skip_in=list(skip_in), weight_norm=True, multires=PE_SDF),
         rendering_network=dict(mode='idr', d_in=9, d_out=3, dims=[W] * n_hidden_r, weight_norm=True,
                                multires_view=PE_VIEW),
         ray_tracer=dict(object_bounding_sphere=1.0, sdf_threshold=5.0e-5, line_search_step=0.5,

@@ -58,14 +58,16 @@ class Net:
             self.b.append(_f(state['%s.lin%d.bias' % (prefix, l)]))
             l += 1
         self.n_layers = l
-        self.skip_layer = skip_in[0] if len(skip_in) else -1
+        self.skip_in = tuple(int(v) for v in skip_in)
+        self.skip_layer = self.skip_in[0] if len(self.skip_in) else -1
+        self.skip_mask = sum(1 << v for v in self.skip_in)
         self.ins = np.array([w.shape[1] for w in self.W], dtype=np.int32)
         self.outs = np.array([w.shape[0] for w in self.W], dtype=np.int32)
         self.Wcat = np.concatenate([w.reshape(-1) for w in self.W])
         self.bcat = np.concatenate(self.b)
 
     def args(self):
-        return (C.c_int(self.n_layers), _p(self.ins), _p(self.outs), C.c_int(self.skip_layer), C.c_int(self.multires),
+        return (C.c_int(self.n_layers), _p(self.ins), _p(self.outs), C.c_int(self.skip_mask), C.c_int(self.multires),
                 _p(self.Wcat), _p(self.bcat))
 
 

@@ -25,7 +25,7 @@
 typedef struct {
     int n_layers;            /* number of Linear layers (9 for the SDF net) */
     int in[MAXL], out[MAXL]; /* per layer (idr.py:45-51) */
-    int skip_layer;          /* layer whose INPUT is cat([x, PE])/sqrt(2) (idr.py:86-87), or -1 */
+    int skip_mask;           /* bit l set: the INPUT of layer l is cat([x, PE])/sqrt(2) (idr.py:86-87: `if l in self.skip_in`) */
     int multires;            /* PE frequencies (embedder.py:38-50) */
     const float *W[MAXL];    /* folded weights, row-major [out][in] */
     const float *b[MAXL];
@@ -83,7 +83,7 @@ static void sdf_row_bf16(const orc_net *net, const float *x, int ncols, float *y
         float sp[64];                         /* split columns of this layer (fp32 values fed as hi + lo) */
         int nsp = 0;
         if (l == 0) { for (int k = 0; k < d0; ++k) sp[k] = pe[k]; nsp = d0; na = 0; }
-        else if (l == net->skip_layer) { for (int k = 0; k < d0; ++k) sp[k] = dm_div_sqrt2(pe[k]); nsp = d0; }
+        else if ((net->skip_mask >> l) & 1) { for (int k = 0; k < d0; ++k) sp[k] = dm_div_sqrt2(pe[k]); nsp = d0; }
         int last = (l == net->n_layers - 1);
         int no = last ? ncols : net->out[l];
         const float *W = net->W[l];
@@ -97,7 +97,7 @@ static void sdf_row_bf16(const orc_net *net, const float *x, int ncols, float *y
             z[j] = acc + net->b[l][j];
         }
         if (last) { memcpy(y, z, sizeof(float) * no); return; }
-        int to_skip = (l + 1 == net->skip_layer);
+        int to_skip = (net->skip_mask >> (l + 1)) & 1;
         for (int j = 0; j < no; ++j) {
             float h = dm_softplus100(z[j]);
             if (to_skip) h = dm_div_sqrt2(h);
@@ -116,7 +116,7 @@ static void sdf_row(const orc_net *net, const float *x, int ncols, float *y) {
     int na = d0;
     memcpy(a, pe, sizeof(float) * d0);
     for (int l = 0; l < net->n_layers; ++l) {
-        if (l == net->skip_layer) {                      /* x = cat([x, input], 1) / sqrt(2) */
+        if ((net->skip_mask >> l) & 1) {                      /* x = cat([x, input], 1) / sqrt(2) */
             for (int k = 0; k < d0; ++k) a[na + k] = pe[k];
             na += d0;
             for (int k = 0; k < na; ++k) a[k] = dm_div_sqrt2(a[k]);
@@ -136,9 +136,9 @@ static void sdf_row(const orc_net *net, const float *x, int ncols, float *y) {
     }
 }
 
-static void make_net(orc_net *net, int n_layers, const int *in, const int *out, int skip_layer, int multires,
+static void make_net(orc_net *net, int n_layers, const int *in, const int *out, int skip_mask, int multires,
                      const float *Wcat, const float *bcat) {
-    net->n_layers = n_layers; net->skip_layer = skip_layer; net->multires = multires;
+    net->n_layers = n_layers; net->skip_mask = skip_mask; net->multires = multires;
     size_t wo = 0, bo = 0;
     for (int l = 0; l < n_layers; ++l) {
         net->in[l] = in[l]; net->out[l] = out[l];
@@ -147,9 +147,9 @@ static void make_net(orc_net *net, int n_layers, const int *in, const int *out, 
     }
 }
 
-void orc_sdf_forward(int n_layers, const int *in, const int *out, int skip_layer, int multires,
+void orc_sdf_forward(int n_layers, const int *in, const int *out, int skip_mask, int multires,
                      const float *Wcat, const float *bcat, const float *x, int n, int ncols, float *y) {
-    orc_net net; make_net(&net, n_layers, in, out, skip_layer, multires, Wcat, bcat);
+    orc_net net; make_net(&net, n_layers, in, out, skip_mask, multires, Wcat, bcat);
 #pragma omp parallel for schedule(dynamic, 16)
     for (int i = 0; i < n; ++i) sdf_row(&net, x + 3 * i, ncols, y + (size_t)ncols * i);
 }
@@ -342,14 +342,14 @@ static void trace_ray(const sdf_ctx *sc, const trace_params *tp, const float *c,
 }
 
 /* analytic = 1: tier-0 SDF; else the MLP given by the net arrays.  object_mask: u8[R].  rows: long long[4]. */
-void orc_trace(int analytic, int n_layers, const int *in, const int *out, int skip_layer, int multires,
+void orc_trace(int analytic, int n_layers, const int *in, const int *out, int skip_mask, int multires,
                const float *Wcat, const float *bcat,
                const float *cam_loc, const float *dirs, const uint8_t *object_mask, int B, int P,
                float r, float thr, float line_search_step, int line_step_iters, int st_iters, int n_steps,
                int n_secant, float dist_clip, int training, const float *intervals, const float *minsdf_steps,
                float *points, uint8_t *mask, float *dists, long long *rows) {
     orc_net net;
-    if (!analytic) make_net(&net, n_layers, in, out, skip_layer, multires, Wcat, bcat);
+    if (!analytic) make_net(&net, n_layers, in, out, skip_mask, multires, Wcat, bcat);
     sdf_ctx sc = {&net, analytic};
     trace_params tp = {r, thr, line_search_step, line_step_iters, st_iters, n_steps, n_secant, dist_clip};
     long long r0 = 0, r1 = 0, r2 = 0, r3 = 0;

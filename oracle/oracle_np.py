@@ -42,11 +42,14 @@ class Net:
             self.b.append(np.asarray(state['%s.lin%d.bias' % (prefix, l)], np.float64))
             self.W.append(fold(self.v[-1], self.g[-1]))
             l += 1
-        self.n_layers, self.skip_layer, self.multires = l, skip_layer, multires
+        self.n_layers, self.multires = l, multires
+        # skip_layer: one layer index (-1: none) or a sequence (skip_in, idr.py:46,86)
+        self.skip_layers = tuple(skip_layer) if isinstance(skip_layer, (tuple, list)) else ((skip_layer,) if skip_layer >= 0 else ())
+        self.skip_layer = self.skip_layers[0] if self.skip_layers else -1
 
 
-def sdf_net(state):
-    return Net(state, 'implicit_network', 4, 6)
+def sdf_net(state, skip_in=(4,), multires=6):
+    return Net(state, 'implicit_network', tuple(skip_in), multires)
 
 
 def render_net(state):
@@ -87,7 +90,7 @@ def sdf_forward(net, x, need_normal=True):
     a, A, Z = h0, [], []
     L = net.n_layers
     for l in range(L):
-        if l == net.skip_layer:
+        if l in net.skip_layers:
             a = np.concatenate([a, h0], 1) / SQRT2
         A.append(a)
         z = a @ net.W[l].T + net.b[l]
@@ -105,9 +108,9 @@ def sdf_forward(net, x, need_normal=True):
     for l in range(L - 2, -1, -1):
         s = sigmoid100(Z[l]) * U[l + 1]
         v = s @ net.W[l]
-        if l == net.skip_layer:
+        if l in net.skip_layers:
             U[l] = v[:, :-d0] / SQRT2
-            e = v[:, -d0:] / SQRT2
+            e = e + v[:, -d0:] / SQRT2
         else:
             U[l] = v
     g0 = U[0] + e
@@ -151,7 +154,7 @@ def sdf_backward(net, cache, dy, dn=None, want_dx=True):
         gb0 = _pe_j(h0, dn, net.multires)
         ub = gb0
         for l in range(L - 1):
-            vb = np.concatenate([ub, gb0], 1) / SQRT2 if l == net.skip_layer else ub
+            vb = np.concatenate([ub, gb0], 1) / SQRT2 if l in net.skip_layers else ub
             sb = vb @ net.W[l].T
             sig = sigmoid100(Z[l])
             dW[l] += (sig * U[l + 1]).T @ vb
@@ -167,7 +170,7 @@ def sdf_backward(net, cache, dy, dn=None, want_dx=True):
         dW[l] += zb.T @ A[l]
         db[l] += zb.sum(0)
         ab = zb @ net.W[l]
-        if l == net.skip_layer:
+        if l in net.skip_layers:
             hb = ab[:, :-d0] / SQRT2
             h0b += ab[:, -d0:] / SQRT2
         elif l == 0:

@@ -62,10 +62,10 @@ def quiet():
     return contextlib.redirect_stdout(io.StringIO())
 
 
-def build_model(W, seed, **kw):
+def build_model(W, seed, skip_in=(4,), **kw):
     with quiet():
-        m = IDRNetwork(Conf(synth.model_conf(W, **kw)))
-    sd = synth.make_state_dict(W, seed)
+        m = IDRNetwork(Conf(synth.model_conf(W, skip_in=skip_in, **kw)))
+    sd = synth.make_state_dict(W, seed, skip_in=skip_in)
     m.load_state_dict({k: T(v) for k, v in sd.items()})
     return m, sd
 
@@ -209,8 +209,8 @@ def g_sample_network(seed):
 SCENE = dict(size=2.6, center=(0.1, -0.2, 0.3), feat_hw=(60, 80), focal_scale=1.4)
 
 
-def g_idr(W, B, P, V, seed, tp, name=None):
-    m, sd = build_model(W, seed)
+def g_idr(W, B, P, V, seed, tp, name=None, skip_in=(4,)):
+    m, sd = build_model(W, seed, skip_in=skip_in)
     inp, gt = synth.make_batch(B, P, V, seed=seed, **SCENE)
     m.train()
     torch.manual_seed(seed + 5)
@@ -335,10 +335,10 @@ def g_idr_phase0(W, B, P, V, seed, tp):
          feat_hw=np.array(SCENE['feat_hw']), focal_scale=SCENE['focal_scale'], checksum=synth.state_checksum(sd), **res)
 
 
-def g_sdf_bwd(W, n, seed):
+def g_sdf_bwd(W, n, seed, skip_in=(4,), name=None):
     """Pins the (double) backward: L = sum(out*dy) + sum(grad*dn) through ImplicitNetwork.forward + .gradient
-    (idr.py:77-107) -> d/d{weight_g, weight_v, bias} of every layer and d/dx."""
-    m, sd = build_model(W, seed)
+    (idr.py:77-107) -> d/d{weight_g, weight_v, bias} of every layer and d/dx.  skip_in: several skip connections (idr.py:46,86)."""
+    m, sd = build_model(W, seed, skip_in=skip_in)
     net = m.implicit_network
     net.train()
     rs = np.random.RandomState(seed + 21)
@@ -351,14 +351,15 @@ def g_sdf_bwd(W, n, seed):
     L = (out * T(dy)).sum() + (g * T(dn)).sum()
     params = [p for _, p in net.named_parameters()]
     grads = torch.autograd.grad(L, [xt] + params)
-    res = dict(W=W, seed=seed, x=x, dy=dy, dn=dn, dx=grads[0].numpy(), checksum=synth.state_checksum(sd))
+    res = dict(W=W, seed=seed, x=x, dy=dy, dn=dn, dx=grads[0].numpy(), checksum=synth.state_checksum(sd), skip_in=np.array(skip_in),
+               out=out.detach().numpy(), grad=g.detach().numpy())
     for (k, _), gr in zip(net.named_parameters(), grads[1:]):
         res['d_' + k] = gr.numpy()
     # first-order only variant (dn = 0), dx through the value chain alone
     xt2 = T(x).clone().requires_grad_(True)
     out2 = net(xt2)
     res['dx_value_only'] = torch.autograd.grad((out2 * T(dy)).sum(), [xt2])[0].numpy()
-    save('sdf_bwd_w%d' % W, **res)
+    save(name or 'sdf_bwd_w%d' % W, **res)
 
 
 def g_render_bwd(W, n, seed):
@@ -468,3 +469,5 @@ if __name__ == '__main__':
     g_idr_phase0(64, 3, 128, 2, 0, 0.1)
     g_idr(256, 8, 256, 4, 0, 0.3, 'idr_c2')
     g_idr(256, 8, 1024, 8, 0, 0.3, 'idr_c3')
+    g_sdf_bwd(64, 150, 0, (3, 6), 'sdf_bwd_w64_skips36')                        # several skip connections (idr.py:46,86)
+    g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_skips36', (3, 6))

@@ -13,9 +13,9 @@ from mvsdf_amd.utils.config import ConfigDict
 pytestmark = pytest.mark.gpu
 
 
-def build(W, seed):
-    m = IDRNetwork(ConfigDict(synth.model_conf(W)))
-    sd = synth.make_state_dict(W, seed)
+def build(W, seed, skip_in=(4,)):
+    m = IDRNetwork(ConfigDict(synth.model_conf(W, skip_in=skip_in)))
+    sd = synth.make_state_dict(W, seed, skip_in=skip_in)
     assert list(m.state_dict().keys()) == list(sd.keys())                       # reference checkpoint layout (idr.py:70-73)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return m.cuda(), sd
@@ -34,13 +34,16 @@ def _dsurf_override(model, g):
     model._dsurf_samples = lambda input, n_dsurf_points, bb: (on, jit, torch.full((2,), n, dtype=torch.int64, device='cuda'))
 
 
-@pytest.mark.parametrize('name', ['idr_w64_tp03', 'idr_w64_tp06', 'idr_w256_tp03', 'idr_c2', 'idr_c3', 'idr_w64_phase0'])
+SKIPS = {'idr_w64_skips36': (3, 6)}                          # fixtures of networks with several skip connections (idr.py:46,86)
+
+
+@pytest.mark.parametrize('name', ['idr_w64_tp03', 'idr_w64_tp06', 'idr_w256_tp03', 'idr_c2', 'idr_c3', 'idr_w64_phase0', 'idr_w64_skips36'])
 def test_forward_loss_backward_vs_reference(name):
     """idr_c2 = the bench shape (8 views x 256 px, V = 4, 8x256 networks); idr_c3 = BASELINE configs[2] (8 views x 1024 px = 8192 rays, V = 8); idr_w64_phase0 = train_progress < 1/6: depth-surface groups
     in the depth / eikonal terms, rgb gradient through the features only (idr.py:331-334), no feature / surface loss."""
     g = golden(name)
     W, B, P, V, seed, tp = int(g['W']), int(g['B']), int(g['P']), int(g['V']), int(g['seed']), float(g['tp'])
-    model, sd = build(W, seed)
+    model, sd = build(W, seed, SKIPS.get(name, (4,)))
     np.testing.assert_allclose(synth.state_checksum(sd), g['checksum'], rtol=0, atol=0)
     inp, gt = synth.make_batch(B, P, V, seed=seed, size=float(g['scene_size']), center=tuple(g['scene_center']),
                                feat_hw=tuple(int(v) for v in g['feat_hw']), focal_scale=float(g['focal_scale']))

@@ -148,3 +148,59 @@ def test_idr_step_without_weight_norm_and_without_normals():
             dv, dg = ops.fold_backward(la.weight_v.detach(), la.weight_g.detach(), lb.weight.grad)
             assert torch.allclose(dv, la.weight_v.grad, rtol=1e-5, atol=1e-8) and torch.allclose(dg, la.weight_g.grad, rtol=1e-5, atol=1e-8)
             assert torch.allclose(lb.bias.grad, la.bias.grad, rtol=1e-6, atol=1e-9)
+
+
+def test_several_skip_connections():
+    """skip_in = (3, 6): (1) value / normal / double backward of the HIP chains vs the reference golden, (2) the tracer bit for bit vs the C
+    oracle in fp32 on every engine, (3) the bf16 tracing engine against its oracle twin, (4) a skip into the last Linear is refused."""
+    from conftest import golden
+    from helpers import sdf_packed_net, trace_params
+    from mvsdf_amd import ops
+    from oracle import oracle as O
+    g = golden('sdf_bwd_w64_skips36')
+    skips = tuple(int(v) for v in g['skip_in'])
+    sd = synth.make_state_dict(64, int(g['seed']), skip_in=skips)
+    net = sdf_packed_net(sd, skip_layer=skips)
+    rel = lambda a, b: float(np.abs(a.detach().cpu().numpy() - b).max() / max(np.abs(b).max(), 1e-12))
+    x = t(g['x'])
+    M = x.shape[0]
+    y, n, ctx = ops.sdf_forward(net, x, M)
+    np.testing.assert_allclose(y.cpu().numpy(), g['out'], rtol=1e-4, atol=3e-6)
+    assert rel(n, g['grad']) < 5e-5
+    dWs, dbs, dx = ops.sdf_backward(net, x, M, M, M, t(g['dy']), t(g['dn']), ctx, True)
+    assert rel(dx, g['dx']) < 2e-4
+    for l, (dW, db) in enumerate(zip(dWs, dbs)):
+        v = t(sd['implicit_network.lin%d.weight_v' % l]); gg = t(sd['implicit_network.lin%d.weight_g' % l])
+        dv, dg = ops.fold_backward(v, gg, dW.contiguous())
+        assert rel(dv, g['d_lin%d.weight_v' % l]) < 5e-4, l
+        assert rel(dg, g['d_lin%d.weight_g' % l]) < 5e-4, l
+        assert rel(db, g['d_lin%d.bias' % l]) < 5e-4, l
+    _, _, dx1 = ops.sdf_backward(net, x, M, M, M, t(g['dy']), None, ctx, True)
+    assert rel(dx1, g['dx_value_only']) < 2e-4
+    # (2) tracer vs the C oracle
+    onet = O.Net(sd, skip_in=skips)
+    inp, _ = synth.make_batch(2, 160, 0, seed=1, with_features=False, focal_scale=1.4)
+    dirs, cam = ops.camera_rays(t(inp['uv']), t(inp['pose']), t(inp['intrinsics']))
+    iv = torch.linspace(0, 1, 100)
+    steps = np.random.RandomState(0).uniform(size=100).astype(np.float32)
+    om = torch.ones(320, dtype=torch.bool, device='cuda')
+    p_o, m_o, d_o, rows = O.trace(onet, cam.cpu().numpy(), dirs.cpu().numpy(), np.ones(320, bool), True, steps, iv.numpy(), **synth.model_conf(64)['ray_tracer'])
+    for mt in (1, 2):
+        pts, mask, dists, cnt = ops.trace(net, cam, dirs, om, trace_params(64), True, iv.cuda(), t(steps), mt=mt)
+        assert np.array_equal(mask.cpu().numpy(), m_o) and np.array_equal(dists.cpu().numpy(), d_o) and np.array_equal(pts.cpu().numpy(), p_o), mt
+        assert np.array_equal(cnt.cpu().numpy()[:4], rows)
+    xs = (torch.rand(3000, 3, generator=torch.Generator().manual_seed(1)) * 2 - 1).cuda()
+    want = O.sdf_forward(onet, xs.cpu().numpy(), ncols=1)[:, 0]
+    for mt in (1, 2, 4, 17, 33):                                 # column-split engine (1 / 2 / 4 tiles), K-split, row-owner
+        assert np.array_equal(ops.sdf_col0(net, xs, mt=mt).cpu().numpy(), want), mt
+    # (3) bf16 engine vs its twin
+    ops.pack_bf16_net(net)
+    twin = O.sdf_forward(O.Net(sd, skip_in=skips, bf16=True), xs.cpu().numpy(), ncols=1)[:, 0]
+    got = ops.sdf_col0(net, xs).cpu().numpy()
+    assert np.abs(got - twin).max() < 6e-3 and np.abs(got - twin).mean() < 1e-4
+    assert np.abs(got - want).max() < 2e-2                       # and near the fp32 network
+    # (4)
+    with pytest.raises(NotImplementedError):
+        ImplicitNetwork(256, 3, 1, [64] * 8, skip_in=(4, 8), multires=6)
+    m2 = ImplicitNetwork(256, 3, 1, [64] * 8, skip_in=(3, 6), multires=6)
+    assert m2.lin2.weight_v.shape == (25, 64) and m2.lin5.weight_v.shape == (25, 64) and m2.fold_spec()[3] == (3, 6)

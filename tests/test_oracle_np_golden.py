@@ -129,3 +129,29 @@ def test_carving_and_depth_loss_vs_reference_golden():
         fa, na = g['att_' + tag]
         loss, dist_r, w = ON.depth_loss(g['points'], g['eik_out'][0], g['depths'], g['depth_cams'], size, center, 0.25, fa, 0.1, na)
         assert abs(loss - float(g["loss_" + tag])) < 2e-6 * float(g["loss_" + tag]), (tag, loss, float(g["loss_" + tag]))
+
+
+def test_several_skip_connections_vs_reference_golden():
+    """skip_in = (3, 6) (idr.py:46,86: every listed layer takes cat([x, PE]) / sqrt(2)): value, normal and the double backward of the numpy
+    oracle, and the value of the C oracle, against the reference's outputs."""
+    from oracle import oracle as O
+    g = golden('sdf_bwd_w64_skips36')
+    skips = tuple(int(v) for v in g['skip_in'])
+    sd = synth.make_state_dict(int(g['W']), int(g['seed']), skip_in=skips)
+    np.testing.assert_allclose(synth.state_checksum(sd), g['checksum'], rtol=0, atol=0)
+    assert sd['implicit_network.lin2.weight_v'].shape == (64 - 39, 64) and sd['implicit_network.lin5.weight_v'].shape == (64 - 39, 64)   # out = W - d0 before a skip
+    net = ON.sdf_net(sd, skip_in=skips)
+    y, n, cache = ON.sdf_forward(net, g['x'])
+    np.testing.assert_allclose(y, g['out'], rtol=1e-4, atol=3e-6)
+    assert _rel(n, g['grad']) < 2e-5
+    dW, db, dx = ON.sdf_backward(net, cache, g['dy'], g['dn'])
+    assert _rel(dx, g['dx']) < 1e-4
+    for l in range(net.n_layers):
+        dv, dg = ON.fold_backward(net.v[l], net.g[l], dW[l])
+        assert _rel(dv, g['d_lin%d.weight_v' % l]) < 2e-4, l
+        assert _rel(dg, g['d_lin%d.weight_g' % l]) < 2e-4, l
+        assert _rel(db[l], g['d_lin%d.bias' % l]) < 2e-4, l
+    _, _, dx1 = ON.sdf_backward(net, cache, g['dy'], None)
+    assert _rel(dx1, g['dx_value_only']) < 1e-4
+    yc = O.sdf_forward(O.Net(sd, skip_in=skips), g['x'])
+    np.testing.assert_allclose(yc, g['out'], rtol=1e-4, atol=3e-6)
