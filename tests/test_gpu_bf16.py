@@ -97,3 +97,39 @@ def test_bf16_training_step_runs_and_stays_close_to_fp32():
     assert agree >= 0.98
     for k in ('loss', 'rgb_loss', 'eikonal_loss', 'depth_loss'):
         assert abs(res['bf16'][1][k] - res['f32'][1][k]) <= 0.05 * max(abs(res['f32'][1][k]), 1e-3), k
+
+
+def test_bf16_step_at_the_c5_per_gpu_shape_vs_the_fp32_reference():
+    """BASELINE configs[4] (32768 rays, V = 8, bf16 MLP weights over 8 GPUs) = 4096 rays per GPU: the bf16-tracer step on that share against
+    the fp32 REFERENCE fixture idr_c5share -- the accuracy budget of the mode (outside the 1e-4 claim), measured and asserted:
+    hit masks agree on >= 99.5 % of the rays, hit depths within 2e-3 relative at the 99th percentile, every loss term within 3 %."""
+    from conftest import golden
+    from mvsdf_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from mvsdf_amd.model.loss import IDRLoss
+    from mvsdf_amd.utils.config import ConfigDict
+    g = golden('idr_c5share')
+    W, B, P, V, seed, tp = int(g['W']), int(g['B']), int(g['P']), int(g['V']), int(g['seed']), float(g['tp'])
+    assert (W, B * P, V) == (256, 4096, 8)
+    m = IDRNetwork(ConfigDict(synth.model_conf(W)))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(W, seed).items()})
+    m = m.cuda().train().set_trace_dtype('bf16')
+    inp, gt = synth.make_batch(B, P, V, seed=seed, size=float(g['scene_size']), center=tuple(g['scene_center']),
+                               feat_hw=tuple(int(v) for v in g['feat_hw']), focal_scale=float(g['focal_scale']))
+    torch.manual_seed(seed + 5)
+    out = m({k: t(v) for k, v in inp.items()}, tp)
+    mask, mref = out['network_object_mask'].cpu().numpy(), g['out_network_object_mask']
+    agree = float((mask == mref).mean())
+    both = mask & mref
+    cam = np.repeat(inp['pose'][:, :3, 3], P, axis=0)
+    depth = np.linalg.norm(out['points'].detach().cpu().numpy() - cam, axis=1)
+    dref = np.linalg.norm(g['out_points'] - cam, axis=1)
+    rel = np.abs(depth - dref)[both] / dref[both]
+    lo = IDRLoss()(out, {k: t(v) for k, v in gt.items()}, tp, B)
+    print('c5 share, bf16 tracer vs fp32 reference: masks agree %.4f, depth rel p99 %.3g max %.3g' % (agree, np.percentile(rel, 99), rel.max()))
+    assert agree >= 0.995 and np.percentile(rel, 99) < 2e-3
+    for k in ('loss', 'rgb_loss', 'eikonal_loss', 'depth_loss', 'feat_loss', 'surf_loss'):
+        v, ref = float(lo[k].detach().reshape(-1)[0]), float(g['loss_' + k])
+        print('   %s %.6g (reference %.6g)' % (k, v, ref))
+        assert abs(v - ref) <= 0.03 * max(abs(ref), 1e-3), (k, v, ref)
+    lo['loss'].backward()
+    assert torch.isfinite(torch.cat([p.grad.flatten() for p in m.parameters()])).all()

@@ -14,23 +14,27 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
-W, B, P, V, SEED, TP = 64, 2, 96, 2, 3, 0.3
+SEED, TP = 3, 0.3
+# (W, B, P, V): a small case, and the per-rank shape of BASELINE configs[3] (c4: 8x256 networks, ONE view of 2048 px per rank, 4 source
+# views, depth maps replicated) with the two ranks this box can hold instead of eight
+CFGS = {'small': (64, 2, 96, 2), 'c4': (256, 2, 2048, 4)}
 
 WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))
-from test_gpu_dp import run_step, W, B, P, V, SEED, TP
+from test_gpu_dp import run_step
 rank, world, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + sys.argv[4], rank=rank, world_size=world)
-flat, losses = run_step(rank, world)
+flat, losses = run_step(rank, world, sys.argv[5])
 torch.save({{'flat': flat, 'losses': losses}}, out)
 dist.destroy_process_group()
 '''
 
 
-def run_step(rank, world):
+def run_step(rank, world, cfg='small'):
     """One forward + loss + backward (+ the gradient all-reduce when a process group exists) on this rank's share of the fixed batch."""
+    W, B, P, V = CFGS[cfg]
     from helpers import t
     from mvsdf_amd.model.implicit_differentiable_renderer import IDRNetwork
     from mvsdf_amd.model.loss import IDRLoss
@@ -62,14 +66,15 @@ def run_step(rank, world):
     return opt.flat_g.detach().cpu().clone(), {k: float(v.detach()) for k, v in lo.items()}
 
 
-def test_two_ranks_reproduce_the_single_process_gradient():
-    ref, ref_losses = run_step(0, 1)                                              # whole batch, no process group
+@pytest.mark.parametrize('cfg', ['small', 'c4'])
+def test_two_ranks_reproduce_the_single_process_gradient(cfg):
+    ref, ref_losses = run_step(0, 1, cfg)                                            # whole batch, no process group
     with tempfile.TemporaryDirectory() as td:
         script = os.path.join(td, 'worker.py')
         open(script, 'w').write(WORKER.format(root=ROOT))
         port = str(29500 + os.getpid() % 2000)
         outs = [os.path.join(td, 'r%d.pt' % r) for r in range(2)]
-        procs = [subprocess.Popen([sys.executable, script, str(r), '2', outs[r], port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        procs = [subprocess.Popen([sys.executable, script, str(r), '2', outs[r], port, cfg], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
                  for r in range(2)]
         logs = [p.communicate(timeout=600)[0].decode(errors='replace') for p in procs]
         assert all(p.returncode == 0 for p in procs), '\n'.join(logs)[-3000:]

@@ -37,9 +37,9 @@ def _dsurf_override(model, g):
 SKIPS = {'idr_w64_skips36': (3, 6)}                          # fixtures of networks with several skip connections (idr.py:46,86)
 
 
-@pytest.mark.parametrize('name', ['idr_w64_tp03', 'idr_w64_tp06', 'idr_w256_tp03', 'idr_c2', 'idr_c3', 'idr_w64_phase0', 'idr_w64_skips36'])
+@pytest.mark.parametrize('name', ['idr_w64_tp03', 'idr_w64_tp06', 'idr_w256_tp03', 'idr_c2', 'idr_c3', 'idr_c5share', 'idr_w64_phase0', 'idr_w64_skips36'])
 def test_forward_loss_backward_vs_reference(name):
-    """idr_c2 = the bench shape (8 views x 256 px, V = 4, 8x256 networks); idr_c3 = BASELINE configs[2] (8 views x 1024 px = 8192 rays, V = 8); idr_w64_phase0 = train_progress < 1/6: depth-surface groups
+    """idr_c2 = the bench shape (8 views x 256 px, V = 4, 8x256 networks); idr_c3 = BASELINE configs[2] (8 views x 1024 px = 8192 rays, V = 8); idr_c5share = one GPU's share of BASELINE configs[4] (8 views x 512 px = 4096 rays, V = 8), here in fp32 (its bf16 budget: test_gpu_bf16.py); idr_w64_phase0 = train_progress < 1/6: depth-surface groups
     in the depth / eikonal terms, rgb gradient through the features only (idr.py:331-334), no feature / surface loss."""
     g = golden(name)
     W, B, P, V, seed, tp = int(g['W']), int(g['B']), int(g['P']), int(g['V']), int(g['seed']), float(g['tp'])
