@@ -4,7 +4,6 @@ import ctypes as C
 
 import torch
 
-from . import _lib
 from ._lib import NetDesc, TraceParams, check, lib, ptr, stream_of
 
 
