@@ -195,25 +195,6 @@ static SdfBwdLayout sdf_bwd_layout(const MvNet& net, int Mb) {
     return o;
 }
 
-static hipError_t launch_wgrad(const float* P1, int ldp1, const float* Q1, int ldq1, int M1, const float* P2, int ldp2, const float* Q2,
-                               int ldq2, int M2, int No, int Ki, int chunk, float* slab, float* bslab, int* nchunks_total, hipStream_t s) {
-    WgradArgs a;
-    a.P1 = P1; a.ldp1 = ldp1; a.Q1 = Q1; a.ldq1 = ldq1; a.M1 = M1;
-    a.P2 = P2; a.ldp2 = ldp2; a.Q2 = Q2; a.ldq2 = ldq2; a.M2 = P2 ? M2 : 0;
-    a.No = No; a.Ki = Ki; a.chunk = chunk;
-    a.nchunks1 = (M1 + chunk - 1) / chunk;
-    const int n2 = a.M2 > 0 ? (a.M2 + chunk - 1) / chunk : 0;
-    a.slab = slab; a.bslab = bslab;
-    *nchunks_total = a.nchunks1 + n2;
-    hipLaunchKernelGGL(k_wgrad, dim3((Ki + 63) / 64, (No + 63) / 64, a.nchunks1 + n2), dim3(MV_THREADS), 0, s, a);
-    return hipGetLastError();
-}
-static hipError_t launch_reduce(const float* sa, int nchunks, size_t n, float* out, int accumulate, hipStream_t s) {
-    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, s, sa, (const float*)nullptr, nchunks, n, out, accumulate);
-    return hipGetLastError();
-}
-
 // all layers' weight / bias gradients: one k_wgrad_net launch + one k_reduce_net launch.  a.L[*].{P1,Q1,P2,Q2,ld*,No,Ki} filled by the caller.
 static hipError_t launch_wgrad_net(WgradNetArgs& a, hipStream_t s) {
     int blk = 0;

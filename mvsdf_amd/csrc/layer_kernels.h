@@ -4,8 +4,9 @@
 //                           16*MT rows per workgroup; the prologue functor builds the A tile in LDS from global
 //                           tensors (fusing sigmoid/softplus-derivative products), the epilogue functor consumes the
 //                           MFMA accumulators (bias, softplus, masks, splits at the skip connection) and stores.
-//   k_wgrad<PMODE>        : dW[No, Ki] = sum_rows P[row, No]^T Q[row, Ki]  (+ column sums of P for the bias),
+//   k_wgrad_net / k_reduce_net : dW[No, Ki] = sum_rows P[row, No]^T Q[row, Ki]  (+ column sums of P for the bias) of EVERY layer,
 //                           split over row chunks into slabs, reduced in a fixed order (deterministic).
+//   k_chain_* / k_render_chain_* : whole forward / backward chains of a row tile in one launch (the running tile stays in LDS).
 //
 // Formulas: SURVEY.md Appendix E (value + normal forward, first- and second-order backward), verified there
 // against torch.autograd double backward.  Reference code being replaced: idr.py:77-107 (forward / gradient),
@@ -191,18 +192,9 @@ __global__ __launch_bounds__(MV_THREADS) void k_layer(LayerArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// dW[No][Ki] = P1^T Q1 (+ P2^T Q2): a GEMM whose contraction runs over ROWS.  Split over 128-row chunks (one workgroup per
-// 64x64 output block per chunk; chunks of the second pair follow those of the first), partial blocks go to slabs that
-// k_reduce_slabs sums in a fixed order (deterministic, no atomics).  Tiles are staged through LDS with 16-byte loads.
-struct WgradArgs {
-    const float* P1; int ldp1; const float* Q1; int ldq1; int M1;      // [M1, No], [M1, Ki]
-    const float* P2; int ldp2; const float* Q2; int ldq2; int M2;      // optional second pair (E.1 term), M2 = 0 if absent
-    int No, Ki;
-    int chunk, nchunks1;           // rows per slab; number of chunks of pair 1
-    float* slab;                   // [nchunks1 + nchunks2][No][Ki]
-    float* bslab;                  // [nchunks1][No] column sums of P1 (bias gradient) or null
-};
-
+// Weight gradients dW[No][Ki] = P1^T Q1 (+ P2^T Q2) are GEMMs whose contraction runs over ROWS: split over 128-row chunks, partial 64x64 blocks go
+// to slabs that a second launch sums in a fixed order (deterministic, no atomics); tiles are staged through LDS with 16-byte loads (wg_stage).
+// The kernels are the network-wide k_wgrad_net / k_reduce_net below.
 __device__ __forceinline__ void wg_stage(const float* __restrict__ src, int ld, int row_lo, int row_hi, int c0, int ncols, float* __restrict__ dst,
                                          int LD, int tid) {
     // 64 rows x 64 cols -> LDS; 16-byte global loads when the source allows it
@@ -239,67 +231,6 @@ __device__ __forceinline__ void wg_stage(const float* __restrict__ src, int ld, 
             const int idx = u * MV_THREADS + tid, rr = idx >> 6, c = idx & 63;
             dst[rr * LD + c] = v[u];
         }
-    }
-}
-
-__global__ __launch_bounds__(MV_THREADS) void k_wgrad(WgradArgs a) {
-    constexpr int LD = 80;                                       // 64 + 16: conflict-free fragment reads, 16-byte aligned rows
-    __shared__ __attribute__((aligned(16))) float Pt[64 * LD];
-    __shared__ __attribute__((aligned(16))) float Qt[64 * LD];
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-    const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
-    int ch = blockIdx.z;
-    const bool second = ch >= a.nchunks1;
-    const float* P = second ? a.P2 : a.P1;
-    const float* Q = second ? a.Q2 : a.Q1;
-    const int ldp = second ? a.ldp2 : a.ldp1, ldq = second ? a.ldq2 : a.ldq1, M = second ? a.M2 : a.M1;
-    const int lch = second ? ch - a.nchunks1 : ch;
-    const int rbeg = lch * a.chunk, rend = min(M, rbeg + a.chunk);
-    f32x4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.0f;
-    const bool do_bias = a.bslab && !second && blockIdx.x == 0;
-    for (int rb = rbeg; rb < rend; rb += 64) {
-        __syncthreads();
-        wg_stage(P, ldp, rb, rend, o0, a.No, Pt, LD, tid);
-        wg_stage(Q, ldq, rb, rend, i0, a.Ki, Qt, LD, tid);
-        __syncthreads();
-        if (do_bias && tid < 64) {
-            for (int rr = 0; rr < 64; ++rr) bsum += Pt[rr * LD + tid];
-        }
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const float av = Pt[(4 * s + q) * LD + 16 * w + r];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Qt[(4 * s + q) * LD + 16 * t + r], acc[t], 0, 0, 0);
-        }
-    }
-    float* slab = a.slab + (size_t)ch * a.No * a.Ki;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int i = i0 + 16 * t + r;
-        if (i < a.Ki) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int o = o0 + 16 * w + 4 * q + e;
-                if (o < a.No) slab[(size_t)o * a.Ki + i] = acc[t][e];
-            }
-        }
-    }
-    if (do_bias && tid < 64 && o0 + tid < a.No) a.bslab[(size_t)ch * a.No + o0 + tid] = bsum;
-}
-
-// out[i] = (accumulate ? out[i] : 0) + sum_c slabA[c][i] (+ sum_c slabB[c][i])      -- fixed order, deterministic
-__global__ void k_reduce_slabs(const float* __restrict__ sa, const float* __restrict__ sb, int nchunks, size_t n, float* __restrict__ out,
-                               int accumulate) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float v = accumulate ? out[i] : 0.0f;
-        for (int c = 0; c < nchunks; ++c) v += sa[(size_t)c * n + i];
-        if (sb)
-            for (int c = 0; c < nchunks; ++c) v += sb[(size_t)c * n + i];
-        out[i] = v;
     }
 }
 
@@ -405,7 +336,7 @@ __global__ void k_reduce_net(WgradNetArgs a) {
     }
 }
 
-// part[chunk][c] = sum over the chunk's rows of X[row][c]   (then k_reduce_slabs with accumulate)
+// part[chunk][c] = sum over the chunk's rows of X[row][c]   (summed by k_reduce_net)
 __global__ void k_colsum(const float* __restrict__ X, int ld, int M, int n, int chunk, float* __restrict__ part) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, ch = blockIdx.y;

@@ -182,7 +182,7 @@ __global__ void k_carve(CarveArgs a) {
     for (int j = 0; j < 3; ++j) pw[j] = a.pts[(size_t)a.pts_ld * i + j] / 2.0f * size + a.center[j];       // loss.py:42
     if (a.pts_world) for (int j = 0; j < 3; ++j) a.pts_world[(size_t)a.pts_ld * i + j] = pw[j];
     const float MAXF = 1e30f / (float)a.B;
-    float tot_in = 0.f, tot_valid = 0.f, tot_inside = 0.f, pos_min = INFINITY, neg_max = -INFINITY;
+    float tot_valid = 0.f, tot_inside = 0.f, pos_min = INFINITY, neg_max = -INFINITY;
     for (int v = 0; v < a.B; ++v) {
         const float* E = a.cams + (size_t)v * 32;
         const float* K = E + 16;
@@ -206,7 +206,7 @@ __global__ void k_carve(CarveArgs a) {
         const bool inside = (pdepth > gd * 0.99f) && valid;
         const bool outside = valid != inside;
         const float dist = valid ? (pdepth - gd) : 0.0f;
-        tot_in += in_range; tot_valid += valid; tot_inside += inside;
+        tot_valid += valid; tot_inside += inside;
         pos_min = fminf(pos_min, inside ? dist : MAXF);
         neg_max = fmaxf(neg_max, outside ? dist : -MAXF);
     }
