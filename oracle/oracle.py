@@ -161,6 +161,7 @@ def _unary(name, x, nout=1):
 
 
 def softplus100(x): return _unary('orc_softplus100', x)
+def softplus100_arr(x): return _unary('orc_softplus100_arr', x)      # the branch-free array form the MLP rows use
 def expneg(x): return _unary('orc_expneg', x)
 def log1p01(x): return _unary('orc_log1p01', x)
 def sincos(x): return _unary('orc_sincos', x, 2)

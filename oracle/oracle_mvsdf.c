@@ -29,6 +29,9 @@ typedef struct {
     int multires;            /* PE frequencies (embedder.py:38-50) */
     const float *W[MAXL];    /* folded weights, row-major [out][in] */
     const float *b[MAXL];
+    float *Wt[MAXL];         /* the same weights transposed, [in][ldt] (ldt = out rounded up to 8, zero padded): lets the compiler evaluate
+                              * eight or more OUTPUT columns side by side; every column still runs its own k-ascending fmaf chain */
+    int ldt[MAXL];
 } orc_net;
 
 /* ---- weight norm: w = v * (g / ||v||_row)   (idr.py:70-71; torch._weight_norm, dim=0) ---- */
@@ -107,6 +110,53 @@ static void sdf_row_bf16(const orc_net *net, const float *x, int ncols, float *y
     }
 }
 
+/* dm_softplus100 over an array, written branch-free (selects instead of early returns) so that the compiler can evaluate eight activations
+ * side by side: per element the SAME operations in the same order as det_math.h's dm_expneg / dm_log1p01 / dm_softplus100 (bit-identical;
+ * tests/test_det_math.py compares the two on a dense grid). */
+static void softplus100_arr(const float *z, float *out, int n) {
+    for (int j = 0; j < n; ++j) {
+        const float zz = z[j];
+        const float y = zz * 100.0f;
+        /* dm_expneg(-|y|) */
+        const float ay = -fabsf(y);
+        float x = ay > -86.0f ? ay : -86.0f;                       /* = fmaxf(-|y|, -86) (no NaNs here) */
+        const float magic = 12582912.0f;
+        const float t0 = fmaf(x, 1.4426950216293335f, magic);
+        const float nn = t0 - magic;
+        float r = fmaf(nn, -0.693359375f, x);
+        r = fmaf(nn, 2.12194440e-4f, r);
+        float p = 1.9875691500e-4f;
+        p = fmaf(p, r, 1.3981999507e-3f);
+        p = fmaf(p, r, 8.3334519073e-3f);
+        p = fmaf(p, r, 4.1665795894e-2f);
+        p = fmaf(p, r, 1.6666665459e-1f);
+        p = fmaf(p, r, 5.0000001201e-1f);
+        const float e = fmaf(p, r * r, r) + 1.0f;
+        uint32_t eb, tb;
+        memcpy(&eb, &e, 4); memcpy(&tb, &t0, 4);
+        eb += tb << 23;
+        float t;
+        memcpy(&t, &eb, 4);
+        /* dm_log1p01(t) */
+        const int k = !(t < 0.4142135679721832f);
+        const float f = k ? fmaf(t, 0.5f, -0.5f) : t;
+        float q = 7.1513607744e-02f;
+        q = fmaf(q, f, -1.1573007339e-01f);
+        q = fmaf(q, f, 1.1661760853e-01f);
+        q = fmaf(q, f, -1.2410829558e-01f);
+        q = fmaf(q, f, 1.4249891856e-01f);
+        q = fmaf(q, f, -1.6668487893e-01f);
+        q = fmaf(q, f, 2.0000708849e-01f);
+        q = fmaf(q, f, -2.4999988981e-01f);
+        q = fmaf(q, f, 3.3333331185e-01f);
+        const float f2 = f * f;
+        const float lg = fmaf(f2 * f, q, fmaf(-0.5f, f2, f)) + (k ? 0.6931471805599453f : 0.0f);
+        const float sres = ((y > 0.0f ? y : 0.0f) + lg) * 0.009999999776482582f;   /* fmaxf(y, 0) + log1p(t), then dm_div100 */
+        out[j] = (y > 20.0f) ? zz : sres;
+    }
+}
+void orc_softplus100_arr(const float *x, int n, float *y) { softplus100_arr(x, y, n); }
+
 /* ---- ImplicitNetwork.forward for one point (idr.py:77-94).  ncols: how many columns of the last layer. ---- */
 static void sdf_row(const orc_net *net, const float *x, int ncols, float *y) {
     if (g_bf16) { sdf_row_bf16(net, x, ncols, y); return; }
@@ -125,13 +175,29 @@ static void sdf_row(const orc_net *net, const float *x, int ncols, float *y) {
         int no = last ? ncols : net->out[l];
         const float *W = net->W[l];
         int in = net->in[l];
+        if (net->Wt[l] && no >= 8) {
+            /* column blocks of 32: acc[j] = fmaf(a[k], w[k][j], acc[j]) for k = 0..in-1 -- per column the same chain as the scalar loop below */
+            const float *Wt = net->Wt[l];
+            const int ldt = net->ldt[l];
+            for (int j0 = 0; j0 < no; j0 += 32) {
+                float acc[32];
+                for (int jj = 0; jj < 32; ++jj) acc[jj] = 0.0f;
+                const int nb = (no - j0 < 32) ? ((no - j0 + 7) & ~7) : 32;          /* the padded columns hold zeros */
+                for (int k = 0; k < in; ++k) {
+                    const float av = a[k];
+                    const float *w = Wt + (size_t)k * ldt + j0;
+                    for (int jj = 0; jj < nb; ++jj) acc[jj] = fmaf(av, w[jj], acc[jj]);
+                }
+                for (int jj = 0; jj < 32 && j0 + jj < no; ++jj) z[j0 + jj] = acc[jj] + net->b[l][j0 + jj];
+            }
+        } else
         for (int j = 0; j < no; ++j) {
             float acc = 0.0f;
             for (int k = 0; k < in; ++k) acc = fmaf(a[k], W[(size_t)j * in + k], acc);
             z[j] = acc + net->b[l][j];
         }
         if (last) { memcpy(y, z, sizeof(float) * no); return; }
-        for (int j = 0; j < no; ++j) a[j] = dm_softplus100(z[j]);   /* Softplus(beta=100), idr.py:75,91-92 */
+        softplus100_arr(z, a, no);                                  /* Softplus(beta=100), idr.py:75,91-92 (= dm_softplus100 per element) */
         na = no;
     }
 }
@@ -144,7 +210,16 @@ static void make_net(orc_net *net, int n_layers, const int *in, const int *out, 
         net->in[l] = in[l]; net->out[l] = out[l];
         net->W[l] = Wcat + wo; net->b[l] = bcat + bo;
         wo += (size_t)in[l] * out[l]; bo += out[l];
+        const int ldt = (out[l] + 7) & ~7;
+        net->ldt[l] = ldt;
+        net->Wt[l] = (float *)calloc((size_t)in[l] * ldt, sizeof(float));
+        if (net->Wt[l])
+            for (int j = 0; j < out[l]; ++j)
+                for (int k = 0; k < in[l]; ++k) net->Wt[l][(size_t)k * ldt + j] = net->W[l][(size_t)j * in[l] + k];
     }
+}
+static void free_net(orc_net *net) {
+    for (int l = 0; l < net->n_layers; ++l) { free(net->Wt[l]); net->Wt[l] = NULL; }
 }
 
 void orc_sdf_forward(int n_layers, const int *in, const int *out, int skip_mask, int multires,
@@ -152,6 +227,7 @@ void orc_sdf_forward(int n_layers, const int *in, const int *out, int skip_mask,
     orc_net net; make_net(&net, n_layers, in, out, skip_mask, multires, Wcat, bcat);
 #pragma omp parallel for schedule(dynamic, 16)
     for (int i = 0; i < n; ++i) sdf_row(&net, x + 3 * i, ncols, y + (size_t)ncols * i);
+    free_net(&net);
 }
 
 /* ---- rend_util.get_camera_params + lift (rend_util.py:48-75, 87-100), pose-matrix branch ---- */
@@ -349,6 +425,7 @@ void orc_trace(int analytic, int n_layers, const int *in, const int *out, int sk
                int n_secant, float dist_clip, int training, const float *intervals, const float *minsdf_steps,
                float *points, uint8_t *mask, float *dists, long long *rows) {
     orc_net net;
+    memset(&net, 0, sizeof(net));
     if (!analytic) make_net(&net, n_layers, in, out, skip_mask, multires, Wcat, bcat);
     sdf_ctx sc = {&net, analytic};
     trace_params tp = {r, thr, line_search_step, line_step_iters, st_iters, n_steps, n_secant, dist_clip};
@@ -361,6 +438,7 @@ void orc_trace(int analytic, int n_layers, const int *in, const int *out, int sk
         r0 += rr[0]; r1 += rr[1]; r2 += rr[2]; r3 += rr[3];
     }
     rows[0] = r0; rows[1] = r1; rows[2] = r2; rows[3] = r3;
+    if (!analytic) free_net(&net);
 }
 
 void orc_analytic_sdf(const float *x, int n, float *y) {

@@ -50,3 +50,13 @@ def test_product_header_bitwise_equals_oracle(oracle):
         d0, d1 = run('p_div', v, 2)
         o0, o1 = oracle.div_consts(v)
         assert np.array_equal(d0, o0) and np.array_equal(d1, o1)
+
+
+def test_oracle_array_softplus_equals_the_scalar_function(oracle):
+    """oracle_mvsdf.c evaluates the hidden activations with a branch-free array form of Softplus(100) (eight lanes per instruction on the
+    host CPU); it must be dm_softplus100 bit for bit: a dense grid through the interesting range, random values, the thresholds."""
+    rs = np.random.RandomState(3)
+    x = np.concatenate([np.linspace(-1.5, 1.5, 3000001), rs.normal(size=400000) * 0.3, rs.normal(size=100000) * 5.0,
+                        np.array([0.0, -0.0, 0.2, 0.20000002, 0.19999999, -0.2, -0.86, -0.8600001, -5.0, 5.0, 1e-8, -1e-8, 3e38, -3e38])]).astype(np.float32)
+    a, b = oracle.softplus100(x), oracle.softplus100_arr(x)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
