@@ -19,14 +19,18 @@ def _scene(B, P, W=256, seed=0):
     return sd, net, dirs, cam
 
 
-def test_c2_tracer_bit_exact_vs_oracle(oracle):
-    """2048 rays, 8x256 MLP, training mode: masks, dists, points and the per-stage row counters equal the CPU oracle bit for bit."""
-    sd, net, dirs, cam = _scene(8, 256)
+@pytest.mark.parametrize('B,P,mt,name', [(8, 256, 1, 'c2'), (8, 512, 2, 'c5 share'), (8, 1024, 4, 'c3'), (8, 4096, 4, 'c5 whole batch')])
+def test_full_size_tracer_bit_exact_vs_oracle(oracle, B, P, mt, name):
+    """BASELINE's batches -- c2: 2048 rays, c5's per-GPU share: 4096, c3: 8192, the whole c5 batch: 32768 -- through the 8x256 MLP in training mode with the row-tile
+    settings RayTracing picks at that size: masks, dists, points and the per-stage row counters equal the CPU oracle bit for bit (the
+    oracle's rows are evaluated eight columns at a time on the host: c3's 585 k rows take about a second, c5's 2.3 M a few)."""
+    sd, net, dirs, cam = _scene(B, P)
     onet = oracle.Net(sd)
+    R = B * P
     iv = torch.linspace(0, 1, 100)
     steps = np.random.RandomState(1).uniform(size=100).astype(np.float32)
-    om = np.ones(2048, bool)
-    pts, mask, dists, cnt = ops.trace(net, cam, dirs, t(om), trace_params(256), True, iv.cuda(), t(steps), mt=1, mt_samples=2)
+    om = np.ones(R, bool)
+    pts, mask, dists, cnt = ops.trace(net, cam, dirs, t(om), trace_params(256), True, iv.cuda(), t(steps), mt=mt, mt_samples=2)
     p_o, m_o, d_o, rows = oracle.trace(onet, cam.cpu().numpy(), dirs.cpu().numpy(), om, True, steps, iv.numpy(), **synth.model_conf(256)['ray_tracer'])
     assert np.array_equal(mask.cpu().numpy(), m_o) and np.array_equal(dists.cpu().numpy(), d_o) and np.array_equal(pts.cpu().numpy(), p_o)
     assert np.array_equal(cnt.cpu().numpy()[:4], rows)
