@@ -46,6 +46,12 @@ __host__ __device__ static inline uint16_t mv_f2bf(float f) {     // round to ne
     return (uint16_t)(u >> 16);
 }
 __device__ __forceinline__ float mv_bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+// two fp32 -> two bf16 (low half = a) with the gfx950 conversion instruction; same rounding as mv_f2bf for finite inputs
+typedef float mv_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 mv_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t mv_f2bf_pk(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(mv_f32x2{a, b}, mv_bf16x2));
+}
 __host__ __device__ static inline int mv_bf_kb(int K, int nsplit) { return (K + nsplit + 31) / 32; }
 __host__ __device__ static inline size_t mv_packed_bf16_elems(int N, int K, int nsplit) { return (size_t)mv_ceil16(N) * mv_bf_kb(K, nsplit) * 32; }
 
@@ -133,6 +139,21 @@ __device__ __forceinline__ void mv_gemm_dispatch_bf(const MvLayerBf& L, const ui
 }
 
 // ImplicitNetwork.forward(...)[:, 0] for MTc*16 rows (points in LDS `pts`) with bf16 weights / activations.  Result -> LDS out[row].
+// Softplus(beta=100, threshold=20) for activations that are rounded to bf16 right after (8 mantissa bits): the hardware's v_exp_f32 /
+// v_log_f32 (1 ulp of fp32, deterministic on the device, not reproducible on a CPU) instead of det_math's correctly-rounded polynomial chains
+// -- 13 instead of 27 VALU instructions per activation, and this engine is bound by its epilogue's VALU work, not by the bf16 MFMAs.  The
+// result differs from dm_softplus100 by <= ~3e-7 relative (and by the absolute 1e-7 of log(1 + t) once t < 2^-12, where t itself is
+// returned); after the bf16 rounding the two agree except at rounding boundaries, the same kind of difference as the MFMA's summation
+// order (tests/test_gpu_bf16.py bounds both against the oracle's twin, which keeps dm_softplus100).
+__device__ __forceinline__ float mv_softplus100_bf(float z) {
+    const float y = z * 100.0f;
+    const float t = __builtin_amdgcn_exp2f(-fabsf(y) * 1.4426950408889634f);            // exp(-|y|)
+    const float lg = __builtin_amdgcn_logf(1.0f + t) * 0.6931471805599453f;             // log1p(t) through log2(1 + t)
+    const float l = t < 2.44140625e-4f ? t : lg;
+    const float s = (fmaxf(y, 0.0f) + l) * 0.009999999776482582f;
+    return y > 20.0f ? z : s;
+}
+
 // `actf` is the activation region (rows * net.S floats), used as bf16 [rows][2*S].  All 64*NW threads must call; ends with a barrier.
 template <int MTc, int NTW, int NW = 8>
 __device__ void mv_sdf_eval_col0(const MvNetBf& net, float* actf, float* pe, const float* pts, float* out, int tid) {
@@ -184,10 +205,11 @@ __device__ void mv_sdf_eval_col0(const MvNetBf& net, float* actf, float* pe, con
                         for (int a = 0; a < MTc; ++a)
 #pragma unroll
                             for (int i = 0; i < 4; i += 2) {
-                                dm_f2 h = dm2_softplus100(dm_f2{acc[a][t][i] + bv, acc[a][t][i + 1] + bv});   // Softplus(beta=100), idr.py:91-92
+                                dm_f2 h = dm_f2{mv_softplus100_bf(acc[a][t][i] + bv), mv_softplus100_bf(acc[a][t][i + 1] + bv)};   // Softplus(beta=100), idr.py:91-92
                                 if (to_skip) h = h * dm2_s(0.7071067690849304f);                              // cat([x, input]) / sqrt(2), idr.py:86-87
-                                act[(a * 16 + 4 * q + i) * S16 + col] = mv_f2bf(h.x);
-                                act[(a * 16 + 4 * q + i + 1) * S16 + col] = mv_f2bf(h.y);
+                                const uint32_t hb = mv_f2bf_pk(h.x, h.y);                 // one v_cvt_pk_bf16_f32 (round to nearest even)
+                                act[(a * 16 + 4 * q + i) * S16 + col] = (uint16_t)hb;
+                                act[(a * 16 + 4 * q + i + 1) * S16 + col] = (uint16_t)(hb >> 16);
                             }
                     }
                 }
