@@ -140,18 +140,16 @@ __device__ __forceinline__ void mv_gemm_dispatch_bf(const MvLayerBf& L, const ui
 
 // ImplicitNetwork.forward(...)[:, 0] for MTc*16 rows (points in LDS `pts`) with bf16 weights / activations.  Result -> LDS out[row].
 // Softplus(beta=100, threshold=20) for activations that are rounded to bf16 right after (8 mantissa bits): the hardware's v_exp_f32 /
-// v_log_f32 (1 ulp of fp32, deterministic on the device, not reproducible on a CPU) instead of det_math's correctly-rounded polynomial chains
-// -- 13 instead of 27 VALU instructions per activation, and this engine is bound by its epilogue's VALU work, not by the bf16 MFMAs.  The
-// result differs from dm_softplus100 by <= ~3e-7 relative (and by the absolute 1e-7 of log(1 + t) once t < 2^-12, where t itself is
-// returned); after the bf16 rounding the two agree except at rounding boundaries, the same kind of difference as the MFMA's summation
-// order (tests/test_gpu_bf16.py bounds both against the oracle's twin, which keeps dm_softplus100).
+// v_log_f32 (1 ulp of fp32, deterministic on the device, not reproducible on a CPU) instead of det_math's correctly-rounded polynomial chains,
+// with the scalings folded:  softplus(100 z) / 100 = max(z, 0) + log2(1 + 2^(-|z| * 100 log2 e)) * (ln 2 / 100)
+// -- 5 ordinary + 2 transcendental VALU instructions per activation instead of 27, and this engine is bound by its epilogue's VALU work, not
+// by the bf16 MFMAs.  Above the threshold (100 z > 20) the log term is below half an ulp of z: the sum IS z, no select needed.  Against
+// dm_softplus100 the result differs by a few 1e-7 relative while the log term matters and by < 1e-9 absolute where it does not (1 + t rounds
+// t away once t < 2^-24); after the bf16 rounding the two agree except at rounding boundaries, the same kind of difference as the MFMA's
+// summation order (tests/test_gpu_bf16.py bounds both against the oracle's twin, which keeps dm_softplus100).
 __device__ __forceinline__ float mv_softplus100_bf(float z) {
-    const float y = z * 100.0f;
-    const float t = __builtin_amdgcn_exp2f(-fabsf(y) * 1.4426950408889634f);            // exp(-|y|)
-    const float lg = __builtin_amdgcn_logf(1.0f + t) * 0.6931471805599453f;             // log1p(t) through log2(1 + t)
-    const float l = t < 2.44140625e-4f ? t : lg;
-    const float s = (fmaxf(y, 0.0f) + l) * 0.009999999776482582f;
-    return y > 20.0f ? z : s;
+    const float t = __builtin_amdgcn_exp2f(fabsf(z) * -144.26950408889634f);            // exp(-|100 z|)
+    return fmaf(__builtin_amdgcn_logf(1.0f + t), 0.006931471805599453f, fmaxf(z, 0.0f));
 }
 
 // `actf` is the activation region (rows * net.S floats), used as bf16 [rows][2*S].  All 64*NW threads must call; ends with a barrier.
