@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- traced rays/s for one MVSDF training step (forward + loss + backward + grad-norm/clip + Adam) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5share] [--dtype f32|bf16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5share] [--dtype f32|bf16] [--width 256|512]
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process (which never touches the GPU) starts
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a child, relays
@@ -168,9 +168,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
+    ap.add_argument('--width', type=int, default=256, help='hidden width of both MLPs: 256 = BASELINE.json (8x256), 512 = the reference\'s shipped conf (mvsdf_dtu.conf:24,35)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--variants', action='store_true', help='also time the opt-in lazy_unused_outputs step (secondary number; off by default so that a profile of this command holds the headline step only)')
     a = ap.parse_args()
+    global W
+    W = a.width
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(a))
@@ -225,7 +228,7 @@ def main():
         out = model(inp, TP)
         lo = loss_fn(out, dict(gt), TP, per)
         opt.backward(lo['loss'])                                 # loss.backward() with the direct gradient sink (one launch for all dv/dg/db)
-        opt.all_reduce_mean()                                    # ONE all-reduce(SUM) of the flat gradient buffer; / world inside Adam
+        opt.all_reduce_mean(defer_scale=True)                    # ONE all-reduce(SUM) of the flat gradient buffer; / world inside Adam
         opt.step(grad_cap=2.0)                                   # grad-norm + clip + Adam (idr_train.py:289-302, conf.grad_cap)
         return out, lo
 

@@ -82,7 +82,7 @@ class _FoldNetFlat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, holders, *vgb):
         n = plan.n
-        flat, packs = ops.fold_pack_net_flat(plan, vgb[:n], vgb[n:2 * n], holders)
+        flat, packs = ops.fold_pack_net_flat(plan, vgb[:n], vgb[n:2 * n], vgb[2 * n:], holders)
         for L in holders:
             L.wp16 = None
             L.keep = packs                                       # the layers carry raw pointers into `packs` / `flat`: keep both alive with them

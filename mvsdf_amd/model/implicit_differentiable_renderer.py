@@ -220,6 +220,51 @@ class LazyOutputs(dict):
             self._materialize()
         return super().pop(k, *a)
 
+    # every remaining way to observe or move the values goes through the eager ones
+    def setdefault(self, k, default=None):
+        if k in self._LAZY:
+            self._materialize()
+        return super().setdefault(k, default)
+
+    def popitem(self):
+        self._materialize()
+        return super().popitem()
+
+    def update(self, *a, **k):
+        self._materialize()                  # an update may replace a lazy key: the pending evaluation must not overwrite it afterwards
+        return super().update(*a, **k)
+
+    def __eq__(self, other):
+        self._materialize()
+        return super().__eq__(other)
+
+    __hash__ = None
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __or__(self, other):
+        self._materialize()
+        return dict(super().items()) | other
+
+    def __ror__(self, other):
+        self._materialize()
+        return other | dict(super().items())
+
+    def __ior__(self, other):
+        self._materialize()
+        return super().__ior__(other)
+
+    def __copy__(self):
+        return self.copy()
+
+    def __deepcopy__(self, memo):
+        import copy as _copy
+        return _copy.deepcopy(self.copy(), memo)
+
+    def __reduce__(self):                    # pickle / copy.copy: a plain dict of the eager values
+        return (dict, (self.copy(),))
+
 
 class IDRNetwork(nn.Module):
     def __init__(self, conf):

@@ -135,9 +135,11 @@ class FoldPlan:
         self._param_key, self._param_arrays = None, None
 
     def param_arrays(self, vs, gs, bs):
-        """ctypes pointer arrays of the parameters and of their .grad buffers (cached while the storages stay put)."""
-        key = (vs[0].data_ptr(), vs[0].grad.data_ptr() if vs[0].grad is not None else 0, bs[-1].data_ptr(),
-               bs[-1].grad.data_ptr() if bs[-1].grad is not None else 0)
+        """ctypes pointer arrays of the parameters and of their .grad buffers, cached while EVERY storage (parameter and gradient) stays put:
+        the key covers all of them, so a gradient detached from the flat buffer in the middle of the list rebuilds the arrays."""
+        key = tuple(p.data_ptr() for p in vs) + tuple(p.data_ptr() for p in bs) + tuple(0 if p is None else p.data_ptr() for p in gs) \
+            + tuple(0 if p.grad is None else p.grad.data_ptr() for p in vs) + tuple(0 if p.grad is None else p.grad.data_ptr() for p in bs) \
+            + tuple(0 if (p is None or p.grad is None) else p.grad.data_ptr() for p in gs)
         if self._param_key != key:
             g_ok = all(p.grad is not None for p in list(vs) + list(bs)) and all(g is None or g.grad is not None for g in gs)
             self._param_arrays = (_ptr_array([v.detach() for v in vs]), _ptr_array([g.detach() if g is not None else None for g in gs]),
@@ -147,7 +149,7 @@ class FoldPlan:
         return self._param_arrays
 
 
-def fold_pack_net_flat(plan, vs, gs, layers):
+def fold_pack_net_flat(plan, vs, gs, bs, layers):
     """fold + pack of all layers into ONE flat buffer of folded weights (+ room for the bias segment) and ONE buffer of packs: two
     allocations instead of 3 per layer.  Sets L.w_ptr / L.wp_ptr / L.wpT_ptr of `layers`; -> (flat [plan.total], packs)."""
     dev = vs[0].device
@@ -159,7 +161,7 @@ def fold_pack_net_flat(plan, vs, gs, layers):
         L.w = L.wp = L.wpT = None
         L.w_ptr, L.wp_ptr, L.wpT_ptr = fb + 4 * plan.woff[l], pb + 4 * plan.poff[l], pb + 4 * plan.pToff[l]
         wss.append(L.w_ptr); wps.append(L.wp_ptr); wpTs.append(L.wpT_ptr)
-    pv, pg, _ = plan.param_arrays(vs, gs, [L.bias for L in layers])
+    pv, pg, _ = plan.param_arrays(vs, gs, bs)                      # the Parameters themselves (same key as the backward: one cache entry per step)
     check(lib().mvsdf_fold_pack_net(plan.n, pv, pg, plan.N, plan.K, _int_ptr_array(wss), _int_ptr_array(wps), _int_ptr_array(wpTs),
                                     stream_of(vs[0])), 'mvsdf_fold_pack_net')
     return flat, packs

@@ -17,9 +17,13 @@ from .parallel import all_reduce_sum_
 
 
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
         params = [p for p in params if p.requires_grad]
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError('FlatAdam implements the reference\'s optimiser: Adam(lr) without weight decay / amsgrad (idr_train.py:113)')
+        # weight_decay / amsgrad are carried in the group only so that state_dict() is a COMPLETE torch.optim.Adam group: the reference's
+        # Adam can load a file written here and step (its step() reads both keys)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
         assert len(self.param_groups) == 1, 'FlatAdam keeps one parameter group (the reference has one, idr_train.py:113)'
         ps = self.param_groups[0]['params']
         p0 = ps[0]
@@ -91,12 +95,19 @@ class FlatAdam(torch.optim.Optimizer):
             p.grad = self.flat_g[off:off + n].view(p.shape)
             views[i] = p.grad
 
-    def all_reduce_mean(self):
-        """The step's one gradient collective (RCCL over xGMI): SUM all-reduce of the flat gradient buffer; the 1 / world that makes it
-        the rank average is applied inside step()'s Adam launch (no separate pass over the buffer).  No-op without a process group.
-        Until step() runs, flat_g holds the SUM."""
+    def all_reduce_mean(self, defer_scale=False):
+        """The step's one gradient collective (RCCL over xGMI): SUM all-reduce of the flat gradient buffer, then the rank average.
+        Default: every p.grad holds the MEAN when this returns (one scaling pass over the 3 MB buffer), so a loop ported from the reference
+        may read or clip the gradients between the collective and step() (idr_train.py:289-294).
+        defer_scale=True: the buffer keeps the SUM and the 1 / world is applied inside step()'s Adam launch (no separate pass; what bench.py
+        uses) -- until step() runs, p.grad is world x too large; grad_norm() / step(grad_cap=...) account for it, external code must not
+        read the gradients in between.  No-op without a process group."""
         self._sync_grads()
-        self._grad_scale = all_reduce_sum_(self.flat_g)
+        scale = all_reduce_sum_(self.flat_g)
+        if defer_scale:
+            self._grad_scale = scale
+        elif scale != 1.0:
+            self.flat_g.mul_(scale)
 
     @torch.no_grad()
     def step(self, closure=None, grad_cap=None):
@@ -122,6 +133,9 @@ class FlatAdam(torch.optim.Optimizer):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        for grp in state_dict.get('param_groups', []):
+            if grp.get('weight_decay', 0) != 0 or grp.get('amsgrad', False):
+                raise NotImplementedError('FlatAdam: checkpoint of an Adam with weight decay / amsgrad')
         super().load_state_dict(state_dict)                  # leaves fresh (non-view) state tensors behind: copy them into the flat buffers
         ps = self.param_groups[0]['params']
         steps = set()

@@ -81,10 +81,12 @@ class FlatGradBucket:
         all_reduce_mean_(self.flat)
 
     def grad_norm(self):
+        self.sync_grads()                                       # gradients detached from the bucket (model.zero_grad()) are copied in first
         return self.flat.norm()
 
     def clip_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_ on the bucket (idr_train.py:291-294): one norm, one scale."""
+        self.sync_grads()
         total = self.flat.norm()
         coef = (max_norm / (total + 1e-6)).clamp(max=1.0)
         self.flat.mul_(coef)

@@ -143,9 +143,78 @@ class CountingSDF:
         return self.f(x)
 
 
-def run_tracer(sdf, cam_loc, object_mask, dirs, training, seed, **tr):
+class MarginRecorder:
+    """Per-ray decision margins of one RayTracing.forward call of the reference, so that a mask or depth
+    difference in a parity test can be attributed to a near-tie instead of to a bug.  Wraps the `sdf` callable: every evaluated row
+    x = cam + t * dir is matched to its ray (float64, smallest angle to a ray of any view) and the values the REFERENCE's network
+    returned are reduced per ray to
+      min_abs_sdf : min |sdf|            -- distance of any sign test from flipping (line search ray_tracing.py:175,192, sampler :230,
+                                            secant :266-272);
+      min_thr_gap : min |sdf - threshold| -- distance of any convergence test from flipping (ray_tracing.py:149-157);
+      n_evals     : evaluations of that ray;
+    and wraps `sphere_tracing` to keep acc_gap = acc_end_dis - acc_start_dis at its return, the quantity whose sign is the initial hit
+    mask (ray_tracing.py:41) and the sampler's range (ray_tracing.py:48-49)."""
+
+    def __init__(self, rt, cam_loc, dirs):
+        self.cam = cam_loc.detach().double()                     # [B,3]
+        self.dirs = dirs.detach().double()                       # [B,P,3]
+        self.dirs = self.dirs / self.dirs.norm(dim=-1, keepdim=True)    # unit in float64 (the float32 directions are unit to 6e-8 only)
+        B, P, _ = self.dirs.shape
+        self.R = B * P
+        self.min_abs = np.full(self.R, np.inf)
+        self.min_thr = np.full(self.R, np.inf)
+        self.n_evals = np.zeros(self.R, np.int64)
+        self.acc_gap = None
+        self.thr = float(rt.sdf_threshold)
+        self.worst_match = 0.0
+        inner = rt.sphere_tracing
+
+        def sphere_tracing(*a, **k):
+            res = inner(*a, **k)
+            self.acc_gap = (res[3] - res[2]).detach().numpy().copy()
+            return res
+        rt.sphere_tracing = sphere_tracing
+
+    def wrap(self, sdf):
+        def f(x):
+            y = sdf(x)
+            self.record(x.detach(), y.detach().reshape(-1))
+            return y
+        return f
+
+    def record(self, x, y):
+        B, P, _ = self.dirs.shape
+        for lo in range(0, x.shape[0], 16384):
+            xc = x[lo:lo + 16384].double()
+            best = torch.full((xc.shape[0],), -2.0, dtype=torch.float64)
+            ray = torch.zeros(xc.shape[0], dtype=torch.int64)
+            for b in range(B):
+                v = xc - self.cam[b]
+                u = v / v.norm(dim=1, keepdim=True)
+                c, i = (u @ self.dirs[b].T).max(1)
+                upd = c > best
+                best[upd] = c[upd]
+                ray[upd] = b * P + i[upd]
+            self.worst_match = max(self.worst_match, float((1 - best).max()))
+            yc = y[lo:lo + 16384].double().numpy()
+            r = ray.numpy()
+            np.minimum.at(self.min_abs, r, np.abs(yc))
+            np.minimum.at(self.min_thr, r, np.abs(yc - self.thr))
+            np.add.at(self.n_evals, r, 1)
+
+    def arrays(self):
+        assert self.worst_match < 1e-10, self.worst_match          # 1 - cos of the angle between a row and its ray: every row sits on a ray
+        return dict(margin_min_abs_sdf=self.min_abs.astype(np.float32), margin_min_thr_gap=self.min_thr.astype(np.float32),
+                    margin_n_evals=self.n_evals, margin_acc_gap=self.acc_gap.astype(np.float32))
+
+
+def run_tracer(sdf, cam_loc, object_mask, dirs, training, seed, margins=False, **tr):
     rt = RayTracing(**tr)
     rt.train(training)
+    rec = None
+    if margins:
+        rec = MarginRecorder(rt, cam_loc, dirs)
+        sdf = rec.wrap(sdf)
     torch.manual_seed(seed)
     steps = torch.empty(100).uniform_(0.0, 1.0).numpy()     # what minimal_sdf_points will draw first
     torch.manual_seed(seed)
@@ -156,6 +225,8 @@ def run_tracer(sdf, cam_loc, object_mask, dirs, training, seed, **tr):
         si, mi = rend_util.get_sphere_intersection(cam_loc, dirs, r=tr.get('object_bounding_sphere', 1.0))
     extra = dict(intervals=torch.linspace(0, 1, steps=tr.get('n_steps', 100)).numpy(),
                  sphere_intersections=si.numpy(), mask_intersect=mi.numpy())
+    if rec is not None:
+        extra.update(rec.arrays())
     return pts.numpy(), mask.numpy(), dists.numpy(), steps, np.array(c.rows, dtype=np.int64), extra
 
 
@@ -186,7 +257,7 @@ def g_trace_mlp(W, B, P, seed):
     om = np.ones((B * P,), dtype=bool)
     for training in (False, True):
         pts, mask, dists, steps, rows, extra = run_tracer(lambda x: net(x)[:, 0], cam_loc, T(om), dirs, training,
-                                                   seed + 5, **tr)
+                                                   seed + 5, margins=True, **tr)
         with torch.no_grad():
             sdf_at = net(T(pts))[:, 0].numpy()
         save('trace_mlp_w%d_%s' % (W, 'train' if training else 'eval'), W=W, seed=seed, B=B, P=P,
@@ -215,9 +286,14 @@ def g_idr(W, B, P, V, seed, tp, name=None, skip_in=(4,)):
     m.train()
     torch.manual_seed(seed + 5)
     mi = {k: T(v) for k, v in inp.items()}
+    with torch.no_grad():
+        dirs, cam_loc = rend_util.get_camera_params(mi['uv'], mi['pose'], mi['intrinsics'])
+    rec = MarginRecorder(m.ray_tracer, cam_loc, dirs)             # per-ray decision margins of the tracer call inside forward
+    rt_forward = m.ray_tracer.forward
+    m.ray_tracer.forward = lambda sdf, **k: rt_forward(sdf=rec.wrap(sdf), **k)
     with quiet():
         out = m(mi, tp)
-    res = {}
+    res = dict(rec.arrays())
     for k, v in out.items():
         res['out_' + k] = v.detach().numpy()
     # loss + gradients
@@ -471,3 +547,9 @@ if __name__ == '__main__':
     g_idr(256, 8, 1024, 8, 0, 0.3, 'idr_c3')
     g_sdf_bwd(64, 150, 0, (3, 6), 'sdf_bwd_w64_skips36')                        # several skip connections (idr.py:46,86)
     g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_skips36', (3, 6))
+    g_idr(256, 8, 512, 8, 0, 0.3, 'idr_c5share')                                # one GPU's share of BASELINE configs[4] (4096 rays, V = 8)
+    g_idr(256, 1, 512, 4, 0, 0.3, 'idr_c1')                                     # BASELINE configs[0] at its own shape: B = 1, 512 rays, V = 4
+    # the reference's SHIPPED configuration: 8x512 SDF net, 4x512 rendering net (confs/mvsdf_dtu.conf:24,35), num_src = 2 (scene_dataset.py:104)
+    g_sdf(512, 256, 0)
+    g_trace_mlp(512, 2, 512, 0)
+    g_idr(512, 8, 128, 2, 0, 0.3, 'idr_w512')

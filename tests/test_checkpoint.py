@@ -67,6 +67,15 @@ def test_flat_adam_checkpoint_round_trip_on_device(tmp_path):
     ref_opt = torch.optim.Adam(m2.parameters(), lr=1e-3)                       # the reference's optimizer reads FlatAdam's file
     assert ck.load_checkpoints(str(tmp_path), m2, ref_opt, checkpoint='latest') == 2
     assert float(ref_opt.state_dict()['state'][0]['step']) == 2.0
+    # ... and can STEP from it (its step() reads weight_decay / amsgrad from the loaded group: FlatAdam writes a complete Adam group)
+    assert ref_opt.param_groups[0]['weight_decay'] == 0 and ref_opt.param_groups[0]['amsgrad'] is False
+    before = [p.detach().clone() for p in m2.parameters()]
+    for p in m2.parameters():
+        p.grad = torch.full_like(p, 0.02)
+    ref_opt.step()
+    assert float(ref_opt.state_dict()['state'][0]['step']) == 3.0
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, m2.parameters()))
+    ck.load_checkpoints(str(tmp_path), m2, checkpoint='latest')                # (restore the parameters for the FlatAdam round trip below)
     opt3 = FlatAdam(m2.parameters(), lr=1e-3)
     ck.load_checkpoints(str(tmp_path), m2, opt3)
     assert torch.equal(opt3.flat_m, opt.flat_m) and torch.equal(opt3.flat_p, opt.flat_p) and opt3._t == 2

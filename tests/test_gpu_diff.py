@@ -21,7 +21,7 @@ def render_packed_net(sd):
     return sdf_packed_net(sd, prefix='rendering_network', skip_layer=-1, multires=0)
 
 
-@pytest.mark.parametrize('W', [64, 256])
+@pytest.mark.parametrize('W', [64, 256, 512])
 def test_sdf_value_normal_vs_golden(W):
     g = golden('sdf_w%d' % W)
     net = sdf_packed_net(synth.make_state_dict(W, int(g['seed'])))

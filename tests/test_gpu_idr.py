@@ -37,9 +37,11 @@ def _dsurf_override(model, g):
 SKIPS = {'idr_w64_skips36': (3, 6)}                          # fixtures of networks with several skip connections (idr.py:46,86)
 
 
-@pytest.mark.parametrize('name', ['idr_w64_tp03', 'idr_w64_tp06', 'idr_w256_tp03', 'idr_c2', 'idr_c3', 'idr_c5share', 'idr_w64_phase0', 'idr_w64_skips36'])
+@pytest.mark.parametrize('name', ['idr_w64_tp03', 'idr_w64_tp06', 'idr_w256_tp03', 'idr_c1', 'idr_c2', 'idr_c3', 'idr_c5share', 'idr_w512', 'idr_w64_phase0', 'idr_w64_skips36'])
 def test_forward_loss_backward_vs_reference(name):
-    """idr_c2 = the bench shape (8 views x 256 px, V = 4, 8x256 networks); idr_c3 = BASELINE configs[2] (8 views x 1024 px = 8192 rays, V = 8); idr_c5share = one GPU's share of BASELINE configs[4] (8 views x 512 px = 4096 rays, V = 8), here in fp32 (its bf16 budget: test_gpu_bf16.py); idr_w64_phase0 = train_progress < 1/6: depth-surface groups
+    """idr_c1 = BASELINE configs[0] at its own shape (B = 1 view x 512 rays, V = 4, 8x256 networks); idr_w512 = the reference's SHIPPED
+    configuration (8x512 SDF net, 4x512 rendering net, confs/mvsdf_dtu.conf:24,35; num_src = 2, scene_dataset.py:104) on 8 views x 128 px;
+    idr_c2 = the bench shape (8 views x 256 px, V = 4, 8x256 networks); idr_c3 = BASELINE configs[2] (8 views x 1024 px = 8192 rays, V = 8); idr_c5share = one GPU's share of BASELINE configs[4] (8 views x 512 px = 4096 rays, V = 8), here in fp32 (its bf16 budget: test_gpu_bf16.py); idr_w64_phase0 = train_progress < 1/6: depth-surface groups
     in the depth / eikonal terms, rgb gradient through the features only (idr.py:331-334), no feature / surface loss."""
     g = golden(name)
     W, B, P, V, seed, tp = int(g['W']), int(g['B']), int(g['P']), int(g['V']), int(g['seed']), float(g['tp'])
@@ -67,6 +69,11 @@ def test_forward_loss_backward_vs_reference(name):
     dsp_err = np.abs(out['diff_surf_pts'].detach().cpu().numpy() - g['out_diff_surf_pts']).max()
     print('%s: max |diff_surf_pts - reference| = %.3g' % (name, dsp_err))
     assert dsp_err < 1.6e-4
+    if 'margin_min_abs_sdf' in g.files:                                          # which ray carries the error, and how close to a tie it was
+        from test_oracle_golden import report_margins
+        derr = np.zeros(mask.shape)
+        derr[hit] = np.abs(out['diff_surf_pts'].detach().cpu().numpy() - g['out_diff_surf_pts']).max(1)
+        report_margins(name, g, hit, derr)
     rgb_err = np.abs(out['rgb_values'].detach().cpu().numpy() - g['out_rgb_values']).max()
     print('%s: max |rgb - reference| = %.3g' % (name, rgb_err))
     assert rgb_err < 1e-4                                                         # north_star: rendered RGB within 1e-4 (values in [-1, 1]); measured <= 1.4e-6

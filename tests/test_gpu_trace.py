@@ -34,7 +34,7 @@ def test_det_math_bitwise(oracle):
     assert np.array_equal(q1.cpu().numpy(), (np.float32(1.0) / v).astype(np.float32))
 
 
-@pytest.mark.parametrize('W', [64, 256])
+@pytest.mark.parametrize('W', [64, 256, 512])
 def test_fold_and_mlp_bitwise(oracle, W):
     sd = synth.make_state_dict(W, 0)
     onet = oracle.Net(sd)
@@ -61,7 +61,7 @@ def test_camera_rays_bitwise(oracle):
 
 
 @pytest.mark.parametrize('W,mode,mt,rpw', [(64, 'eval', 2, 2), (64, 'train', 2, 3), (64, 'train', 4, 8), (64, 'train', 1, 1),
-                                          (256, 'eval', 2, 2), (256, 'train', 4, 4)])
+                                          (256, 'eval', 2, 2), (256, 'train', 4, 4), (512, 'eval', 2, 2), (512, 'train', 1, 2)])
 def test_trace_bit_exact_vs_oracle_and_golden(oracle, W, mode, mt, rpw):
     g = golden('trace_mlp_w%d_%s' % (W, mode))
     sd = synth.make_state_dict(W, int(g['seed']))
@@ -83,6 +83,8 @@ def test_trace_bit_exact_vs_oracle_and_golden(oracle, W, mode, mt, rpw):
     hit = g['mask']
     rel = np.abs(dists - g['dists']) / np.abs(g['dists']).clip(1e-6)
     assert rel[hit].max() < 1e-4                          # depths within 1e-4 rel
+    from test_oracle_golden import report_margins
+    report_margins('trace_mlp_w%d_%s' % (W, mode), g, hit, np.abs(dists - g['dists']))
 
 
 def test_trace_object_mask_paths(oracle):

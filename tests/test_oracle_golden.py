@@ -46,7 +46,7 @@ def test_rays_and_sphere(oracle):
     assert (t == g['sphere_intersections']).mean() > 0.995
 
 
-@pytest.mark.parametrize('W', [64, 256])
+@pytest.mark.parametrize('W', [64, 256, 512])               # 512: the reference's shipped width (confs/mvsdf_dtu.conf:24)
 def test_sdf_forward(oracle, W):
     g = golden('sdf_w%d' % W)
     net = _net(oracle, g)
@@ -80,7 +80,7 @@ def test_tracer_tier0_bit_exact(oracle, name):
     assert rows[1] > 0 and rows[2] > 0 and (rows[3] > 0) == ('train' in name)
 
 
-@pytest.mark.parametrize('W,mode', [(64, 'eval'), (64, 'train'), (256, 'eval')])
+@pytest.mark.parametrize('W,mode', [(64, 'eval'), (64, 'train'), (256, 'eval'), (512, 'eval'), (512, 'train')])
 def test_tracer_mlp(oracle, W, mode):
     g = golden('trace_mlp_w%d_%s' % (W, mode))
     net = _net(oracle, g)
@@ -98,3 +98,22 @@ def test_tracer_mlp(oracle, W, mode):
         s_mine = oracle.sdf_forward(net, pts[far], ncols=1)[:, 0]
         assert np.abs(s_mine - g['sdf_at_points'][far]).max() < 2e-4
     assert abs(int(rows.sum()) - int(g['rows'].sum())) <= 8
+    report_margins('oracle trace_mlp_w%d_%s' % (W, mode), g, g['mask'], np.abs(dists - g['dists']))
+
+
+def report_margins(tag, g, hit, depth_err, limit=2e-5):
+    """SURVEY 8(c) item 4: the fixtures carry the reference's per-ray decision margins (make_golden.py::MarginRecorder).  Prints, for the
+    rays whose depth differs from the reference by more than `limit`, the smallest margin -- a large error on a ray with a comfortable
+    margin would be a bug, on a ray within rounding of a decision boundary it is a tie."""
+    if 'margin_min_abs_sdf' not in g.files:
+        return None
+    bad = hit & (depth_err > limit)
+    mg = np.minimum(g['margin_min_abs_sdf'], g['margin_min_thr_gap'])
+    line = '%s: %d hit rays with |depth - reference| > %g' % (tag, int(bad.sum()), limit)
+    if bad.any():
+        i = np.nonzero(bad)[0][np.argmin(mg[bad])]
+        line += '; smallest decision margin among them %.3g (ray %d: min|sdf| %.3g, min|sdf - thr| %.3g, acc_end - acc_start %.3g, %d evaluations, depth error %.3g)' % (
+            mg[i], i, g['margin_min_abs_sdf'][i], g['margin_min_thr_gap'][i], g['margin_acc_gap'][i], int(g['margin_n_evals'][i]), depth_err[i])
+    line += '; smallest margin of any hit ray %.3g' % float(mg[hit].min())
+    print(line)
+    return line

@@ -17,7 +17,7 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
 
 
-@pytest.mark.parametrize('W', [64, 256])
+@pytest.mark.parametrize('W', [64, 256, 512])
 def test_sdf_value_and_normal(W):
     g = golden('sdf_w%d' % W)
     net = ON.sdf_net(_sd(g))
