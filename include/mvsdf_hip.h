@@ -309,6 +309,113 @@ int mvsdf_loss_scale(const float* const* g, float w_rgb, float w_eik, float w_su
  * 4 div100 / div_sqrt2 (y0, y1), 5 sqrt / reciprocal (y0, y1), 6 two-wide softplus100 (y0 = f(x), y1 = f(-x)). */
 int mvsdf_det_math(int op, const float* x, int n, float* y0, float* y1, void* stream);
 
+/* ==== native step driver: one training step as a handful of calls, no host code between the launches ====
+ * Replaces the host side of IDRNetwork.forward in training mode (idr.py:179-322), of IDRLoss.forward (loss.py:176-219) and of
+ * `loss.backward()` through both (idr_train.py:283-287) -- the reference issues ~2 000 framework ops there; the Python mirror of this
+ * library used to issue ~45 ctypes calls plus autograd glue (1.6 ms of host time per step).  Each call below enqueues ALL launches of its
+ * phase on `stream` from C++; launch shapes that depend on the hit count N read it from device memory or are sized for the worst case.
+ *
+ * Memory: the caller owns two blocks.  `fwd` (MvsdfStepLayout.fwd_bytes, one per forward, kept until its backward has run) receives every
+ * output tensor of the forward at the byte offsets of the layout and everything the backward reads (folded weights, packs, saved
+ * activations); `bwd` (bwd_bytes) is scratch of the backward.  Offsets are multiples of 256 bytes.  */
+#define MVSDF_STEP_MAX_LAYERS 24
+
+typedef struct {
+    int B, P;                              /* this batch: B views x P pixels, R = B * P rays (uv[B][P][2], idr.py:183-190) */
+    int n_eik;                             /* eikonal sample points (idr.py:216-217: R / 2) */
+    int n_ds;                              /* depth-surface samples per set (idr.py:226-247), 0 outside phase 0 */
+    int n_sdf, n_render;                   /* Linear layers of ImplicitNetwork / RenderingNetwork */
+    int N[MVSDF_STEP_MAX_LAYERS];          /* out features per Linear: the n_sdf SDF layers, then the n_render rendering layers */
+    int K[MVSDF_STEP_MAX_LAYERS];          /* in features */
+    unsigned skip_mask;                    /* bit l: the input of SDF layer l is cat([x, PE(x)]) / sqrt(2) (idr.py:86-87) */
+    int multires;                          /* PE frequencies of the SDF net */
+    int view_spec;                         /* multires_view | mode bits, as mvsdf_render_forward takes them */
+    int trace_dtype;                       /* 0: fp32 tracing MLP; 1: bf16 packs are made each forward and the tracer uses them */
+    int use_object_mask;                   /* conf.use_mask (idr.py:187): 0 = the ray partition ignores object_mask */
+    MvsdfTraceParams tp;
+    int mt, mt_samples;                    /* tiling of the tracer kernels (see mvsdf_trace) */
+} MvsdfStepDesc;
+
+typedef struct {                           /* raw parameters (device pointers), SDF layers first; g[l] NULL = no weight norm */
+    const float* v[MVSDF_STEP_MAX_LAYERS];
+    const float* g[MVSDF_STEP_MAX_LAYERS];
+    const float* b[MVSDF_STEP_MAX_LAYERS];
+} MvsdfStepParams;
+
+typedef struct {
+    const float* uv; const float* pose; const float* intrinsics;         /* [B][P][2], [B][4][4], [B][4][4] */
+    const uint8_t* object_mask;            /* [R] the mask the tracer sees (all ones when conf.use_mask is off, idr.py:187) */
+    const uint8_t* object_mask_true;       /* [R] input['object_mask'] */
+    const float* intervals;                /* [n_steps] linspace(0, 1) (ray_tracing.py:206) */
+    const float* minsdf_steps;             /* [n_steps] uniform draws of minimal_sdf_points (ray_tracing.py:287) */
+    const float* eik_points;               /* [n_eik][3] uniform draws in the eikonal box (idr.py:216-221) */
+    const float* ds_on; const float* ds_jit;  /* [n_ds][3] each (mvsdf_dsurf_points), NULL when n_ds == 0 */
+    const long long* ds_counts;            /* [2] device: samples found per set (mvsdf_dsurf_select), NULL when n_ds == 0 */
+} MvsdfStepInputs;
+
+typedef struct {
+    size_t fwd_bytes, bwd_bytes;
+    /* byte offsets into `fwd` of the tensors of the reference's output dict (idr.py:306-322); every N-dependent tensor is sized for N = R
+     * and its first rows are valid (see mvsdf_step_outputs) */
+    size_t ray_dirs, cam_loc;              /* [R][3], [B][3] */
+    size_t points, mask, dists, counters;  /* tracer outputs: [R][3] f32, [R] u8, [R] f32, uint64[16] */
+    size_t object_mask_out;                /* [R] u8: all ones (out['object_mask'] when conf.use_mask is off) */
+    size_t rgb_values, sdf_output, diff_pts, eik_out, points_hom, grad_theta, surf;
+    size_t perm;                           /* int64 [R]: sorted row -> ray (hit rays first) */
+    size_t dflat;                          /* offset into `bwd`: the gradient of the folded parameters [dW | db of the SDF net | dW | db of the rendering net] */
+    size_t dflat_floats;
+} MvsdfStepLayout;
+
+/* create / destroy the host-side state of a step (a pinned 4 x int64 staging buffer and HIP events; no device memory) */
+int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void** step);
+void mvsdf_step_destroy(void* step);
+/* IDRNetwork.forward, training mode: fold (+ bf16 packs) -> camera rays -> RayTracing.forward -> ray partition (hit counts start travelling
+ * to the pinned buffer) -> ONE fused value + normal evaluation over [sample points | rays, hit first] -> rendering net -> output gather.
+ * d_mask / e_mask: point groups of the depth / eikonal terms (see mvsdf_step_outputs). */
+int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepInputs* in, int d_mask, int e_mask, void* fwd, void* stream);
+/* blocks until the counts of the last mvsdf_step_forward are on the host: {N hit, N hit & true mask, depth-surface samples found per set x 2}.
+ * The ONE host wait of a training step; the fused evaluation enqueued behind the count copy keeps the GPU busy meanwhile. */
+int mvsdf_step_wait_counts(void* step, long long counts[4]);
+/* backward of mvsdf_step_forward: upstream gradients of diff_surf_pts [N][3], rgb_values [R][3], grad_theta, eikonal_output,
+ * surf_indicator_output (any may be NULL = zero) -> gradient of every raw parameter.  N, n_true: the counts mvsdf_step_wait_counts returned.
+ * use_geo: 0 = points / normals / view directions detached in front of the rendering net (idr.py:331-334).
+ * dv / dg / db: per-layer targets (device pointers; dg[l] NULL where g[l] is); accumulate != 0 ADDS into them (the parameters' .grad). */
+int mvsdf_step_backward(void* step, const MvsdfStepParams* prm, int N, int n_true, int d_mask, int e_mask, int use_geo, const float* d_diff,
+                        const float* d_rgb, const float* d_gth, const float* d_eo, const float* d_si, const void* fwd, void* bwd,
+                        float* const* dv, float* const* dg, float* const* db, int accumulate, void* stream);
+/* per-kernel timing of the tracer for bench.py's roofline: enable != 0 makes every forward record HIP events on the launch stream around
+ * k_sphere_trace, the sampler launches and the secant / min-sdf launch; mvsdf_step_trace_times (after the stream was synchronised) ->
+ * ms[3] = {sphere tracing, sampler rows, secant + min-sdf rows} of the last forward. */
+int mvsdf_step_set_timing(void* step, int enable);
+int mvsdf_step_trace_times(void* step, float ms[3]);
+
+/* ---- IDRLoss.forward / backward (loss.py:176-219) as one call each ---- */
+typedef struct {
+    int R, B;                              /* rays, views of this batch */
+    int N, n_grad, n_depth, n_surf;        /* rows of diff_surf_pts / grad_theta / eikonal_output / surf_indicator_output */
+    const uint8_t* net_mask; const uint8_t* obj_mask; const uint8_t* true_mask;      /* [R] */
+    const float* rgb; const float* rgb_gt;                                           /* [R][3] */
+    const float* grad_theta; const float* eik_out; const float* surf; const float* diff_pts;
+    float* points_hom;                     /* [n_depth][4]: rescaled to world coordinates IN PLACE (loss.py:38,42) */
+    int feat_on, surf_on;                  /* phase switches (loss.py:195-204) */
+    int V, C, H, W;                        /* source views, feature channels, feature map size */
+    const float* feat; long long feat_strides[4]; const float* feat_src; long long src_strides[5];
+    const float* cam; const float* src_cams; const float* size; const float* center;
+    const float* depths; int dB, dh, dw; const float* depth_cams;                    /* [dB][dh][dw], [dB][2][4][4] */
+    float out_thresh_perc, far_thresh, far_att, near_thresh, near_att;
+    float w_rgb, w_eik, w_surf, w_feat, w_depth;
+    const float* inv_counts;               /* see mvsdf_loss_terms */
+} MvsdfLossArgs;
+typedef struct { size_t bytes, out, hit, view_start, n_pos, loss_pp, dpts, dist_r, weight, d_rgb, d_grad, d_eo, d_sf; } MvsdfLossLayout;
+/* layout of the block both calls work in (out: float[6] = loss, rgb, eikonal, depth, feat, surf) */
+int mvsdf_loss_layout(const MvsdfLossArgs* a, MvsdfLossLayout* lo);
+/* mask bookkeeping + feature consistency + depth carving + all terms and their unit gradients: 4 launches */
+int mvsdf_loss_forward(const MvsdfLossArgs* a, void* blk, void* stream);
+/* g: HOST array of 6 device pointers (upstream of the six scalars, NULL = none) -> gradients of rgb_values [R][3], grad_theta [n_grad][3],
+ * eikonal_output [n_depth], surf_indicator_output [n_surf], diff_surf_pts [N][3] (any target may be NULL): one launch */
+int mvsdf_loss_backward(const MvsdfLossArgs* a, const void* blk, const float* const* g, float* g_rgb, float* g_grad, float* g_eo, float* g_sf,
+                        float* g_diff, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

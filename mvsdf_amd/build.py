@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(HERE, 'libmvsdf_hip.so')
-SOURCES = ['capi_util.hip', 'basic.hip', 'trace.hip', 'diff_mlp.hip', 'loss_kernels.hip', 'optim_kernels.hip', 'step_kernels.hip', 'sample_kernels.hip']
+SOURCES = ['capi_util.hip', 'basic.hip', 'trace.hip', 'diff_mlp.hip', 'loss_kernels.hip', 'optim_kernels.hip', 'step_kernels.hip', 'sample_kernels.hip', 'step_driver.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math',
          '-Wno-unused-result', '-Wno-pass-failed']
 

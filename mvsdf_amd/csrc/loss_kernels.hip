@@ -424,18 +424,18 @@ __global__ __launch_bounds__(1024) void k_loss_prep(const uint8_t* __restrict__ 
 struct LossScaleArgs {
     const float* g[6];                    // upstream of {loss, rgb, eikonal, depth, feat, surf}: one scalar each, null = 0
     float w_rgb, w_eik, w_surf, w_feat, w_depth;
-    const float* src[4]; float* dst[4]; int n[4];      // unit gradients of rgb / grad_theta / eikonal_output / surf -> scaled copies
+    const float* src[5]; float* dst[5]; int n[5];      // unit gradients of rgb / grad_theta / eikonal_output / surf / diff_surf_pts (k_feat_corr's dpts) -> scaled copies
     float* coef_feat;                     // [1]: dL/d(sum of the per-point feature terms)
 };
 __global__ void k_loss_scale(LossScaleArgs a) {
     float g[6];
     for (int k = 0; k < 6; ++k) g[k] = a.g[k] ? a.g[k][0] : 0.0f;
     const float g0 = g[0];
-    const float c[4] = {g0 * a.w_rgb + g[1], g0 * a.w_eik + g[2], g0 * a.w_depth + g[3], g0 * a.w_surf + g[5]};
-    const int total = a.n[0] + a.n[1] + a.n[2] + a.n[3];
+    const float c[5] = {g0 * a.w_rgb + g[1], g0 * a.w_eik + g[2], g0 * a.w_depth + g[3], g0 * a.w_surf + g[5], g0 * a.w_feat + g[4]};
+    const int total = a.n[0] + a.n[1] + a.n[2] + a.n[3] + a.n[4];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         int k = i, t = 0;
-        while (t < 3 && k >= a.n[t]) { k -= a.n[t]; ++t; }
+        while (t < 4 && k >= a.n[t]) { k -= a.n[t]; ++t; }
         a.dst[t][k] = a.src[t][k] * c[t];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.coef_feat) a.coef_feat[0] = g0 * a.w_feat + g[4];
@@ -466,10 +466,94 @@ int mvsdf_loss_scale(const float* const* g, float w_rgb, float w_eik, float w_su
         if (n[t] > 0 && (!src[t] || !dst[t])) return mv_fail(-1, "mvsdf_loss_scale: null tensor with a positive count");
         a.src[t] = src[t]; a.dst[t] = dst[t]; a.n[t] = n[t]; total += n[t];
     }
+    a.src[4] = nullptr; a.dst[4] = nullptr; a.n[4] = 0;
     a.coef_feat = coef_feat;
     const int blocks = total > 0 ? (total + 255) / 256 : 1;
     hipLaunchKernelGGL(k_loss_scale, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, (hipStream_t)stream, a);
     return mv_check(hipGetLastError(), "mvsdf_loss_scale");
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// IDRLoss.forward / backward as one C call each (include/mvsdf_hip.h, "native step driver"): the same kernels as above, enqueued from C++.
+static inline size_t mv_al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" {
+
+int mvsdf_loss_layout(const MvsdfLossArgs* a, MvsdfLossLayout* lo) {
+    if (!a || !lo || a->R <= 0 || a->B <= 0 || a->N < 0 || a->n_grad < 0 || a->n_depth < 0 || a->n_surf < 0) return mv_fail(-1, "mvsdf_loss_layout: bad arguments");
+    size_t p = 0;
+    auto take = [&](size_t bytes) { const size_t o = p; p += mv_al256(bytes ? bytes : 4); return o; };
+    lo->out = take(6 * 4);
+    lo->hit = take((size_t)a->R);
+    lo->view_start = take(((size_t)a->B + 1) * 4);
+    lo->n_pos = take(8);
+    lo->loss_pp = take((size_t)a->N * 4);
+    lo->dpts = take((size_t)a->N * 12);
+    lo->dist_r = take((size_t)a->n_depth * 4);
+    lo->weight = take((size_t)a->n_depth * 4);
+    lo->d_rgb = take((size_t)a->R * 12);
+    lo->d_grad = take((size_t)a->n_grad * 12);
+    lo->d_eo = take((size_t)a->n_depth * 4);
+    lo->d_sf = take((size_t)a->n_surf * 4);
+    lo->bytes = p;
+    return 0;
+}
+
+int mvsdf_loss_forward(const MvsdfLossArgs* a, void* blk, void* stream) {
+    MvsdfLossLayout lo;
+    int rc = mvsdf_loss_layout(a, &lo);
+    if (rc) return rc;
+    if (!blk || !a->net_mask || !a->obj_mask || !a->true_mask || !a->rgb || !a->rgb_gt) return mv_fail(-1, "mvsdf_loss_forward: null argument");
+    char* b = (char*)blk;
+    uint8_t* hit = (uint8_t*)(b + lo.hit);
+    int* view_start = (int*)(b + lo.view_start);
+    long long* n_pos = (long long*)(b + lo.n_pos);
+    rc = mvsdf_loss_prep(a->net_mask, a->obj_mask, a->true_mask, a->R, a->B, hit, view_start, n_pos, stream);
+    if (rc) return rc;
+    const bool feat = a->feat_on && a->N > 0;
+    if (feat) {
+        rc = mvsdf_feat_corr(a->diff_pts, a->N, view_start, a->B, a->V, a->C, a->H, a->W, a->feat, a->feat_strides, a->feat_src, a->src_strides, a->cam,
+                             a->src_cams, a->size, a->center, (float*)(b + lo.loss_pp), (float*)(b + lo.dpts), stream);
+        if (rc) return rc;
+    }
+    if (a->n_depth > 0) {
+        rc = mvsdf_depth_carve(a->points_hom, 4, a->n_depth, a->depths, a->dB, a->dh, a->dw, a->depth_cams, a->size, a->center, a->out_thresh_perc,
+                               a->far_thresh, a->far_att, a->near_thresh, a->near_att, (float*)(b + lo.dist_r), (float*)(b + lo.weight), a->points_hom,
+                               stream);
+        if (rc) return rc;
+    }
+    return mvsdf_loss_terms(a->rgb, a->rgb_gt, hit, a->R, a->n_grad > 0 ? a->grad_theta : nullptr, a->n_grad, a->eik_out, (const float*)(b + lo.dist_r),
+                            (const float*)(b + lo.weight), a->n_depth, a->n_surf > 0 ? a->surf : nullptr, a->n_surf, n_pos,
+                            feat ? (const float*)(b + lo.loss_pp) : nullptr, feat ? a->N : 0, a->w_rgb, a->w_eik, a->w_surf, a->w_feat, a->w_depth,
+                            a->surf_on, a->feat_on, a->inv_counts, (float*)(b + lo.out), (float*)(b + lo.d_rgb), (float*)(b + lo.d_grad),
+                            (float*)(b + lo.d_eo), (float*)(b + lo.d_sf), stream);
+}
+
+int mvsdf_loss_backward(const MvsdfLossArgs* a, const void* blk, const float* const* g, float* g_rgb, float* g_grad, float* g_eo, float* g_sf,
+                        float* g_diff, void* stream) {
+    MvsdfLossLayout lo;
+    int rc = mvsdf_loss_layout(a, &lo);
+    if (rc) return rc;
+    if (!blk || !g) return mv_fail(-1, "mvsdf_loss_backward: null argument");
+    const char* b = (const char*)blk;
+    LossScaleArgs s;
+    for (int k = 0; k < 6; ++k) s.g[k] = g[k];
+    s.w_rgb = a->w_rgb; s.w_eik = a->w_eik; s.w_surf = a->w_surf; s.w_feat = a->w_feat; s.w_depth = a->w_depth;
+    const bool feat = a->feat_on && a->N > 0;
+    const float* src[5] = {(const float*)(b + lo.d_rgb), (const float*)(b + lo.d_grad), (const float*)(b + lo.d_eo), (const float*)(b + lo.d_sf),
+                           (const float*)(b + lo.dpts)};
+    float* dst[5] = {g_rgb, g_grad, g_eo, (a->surf_on ? g_sf : nullptr), (feat ? g_diff : nullptr)};
+    const int n[5] = {a->R * 3, a->n_grad * 3, a->n_depth, a->n_surf, a->N * 3};
+    int total = 0;
+    for (int t = 0; t < 5; ++t) {
+        s.src[t] = src[t]; s.dst[t] = dst[t]; s.n[t] = dst[t] ? n[t] : 0; total += s.n[t];
+    }
+    s.coef_feat = nullptr;
+    const int blocks = total > 0 ? (total + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_loss_scale, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, (hipStream_t)stream, s);
+    return mv_check(hipGetLastError(), "mvsdf_loss_backward");
 }
 
 }  // extern "C"

@@ -1,0 +1,392 @@
+// step_driver.hip -- the native step driver: IDRNetwork.forward (training mode, idr.py:179-322) and the backward through it as ONE C call
+// each.  Every launch of a phase is enqueued from here, in the order functional._IdrStep / IDRNetwork.forward used to issue them from Python
+// through ~45 ctypes calls (1.6 ms of host time per step); the kernels are the library's own entry points (mvsdf_hip.h), reached
+// directly instead of through the interpreter.  No allocation, no synchronisation: the caller hands in one `fwd` block per forward (outputs +
+// everything the backward reads) and a `bwd` scratch block; the one host wait of a step is mvsdf_step_wait_counts.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <new>
+#include "capi_util.h"
+
+namespace {
+
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct FwdOffsets {
+    size_t w[MVSDF_STEP_MAX_LAYERS], wp[MVSDF_STEP_MAX_LAYERS], wpT[MVSDF_STEP_MAX_LAYERS], wp16[MVSDF_STEP_MAX_LAYERS];
+    size_t trace_ws, trace_ws_bytes;
+    size_t inv, true_rows, counts, view_sorted;
+    size_t x_eval, y_eval, n_eval, sdf_ctx, rgb_sorted, render_ctx;
+};
+struct BwdOffsets {
+    size_t dy, dn, dy_x, dn_x, din, drgb_sorted, render_ws, wsA, wsX, dx, fbar;
+};
+
+struct Step {
+    MvsdfStepDesc d;
+    MvsdfStepLayout lay;
+    FwdOffsets fo;
+    BwdOffsets bo;
+    int R, E, M, Nout, K0r, nl;                      // rays, sample rows, evaluation rows, SDF output width, rendering-net input width, layers in total
+    size_t woff[MVSDF_STEP_MAX_LAYERS], boff[MVSDF_STEP_MAX_LAYERS];   // float offsets inside dflat: [W | b of the SDF net | W | b of the rendering net]
+    size_t seg[2][3];                                // per network: first weight, first bias, end
+    long long* counts_host;                          // pinned [4]
+    hipEvent_t ev_counts;
+    bool counts_pending;
+    int timing;
+    hipEvent_t ev_t[5];
+    bool timed;
+};
+
+// descriptors of the two networks over the packs inside a forward block
+void make_descs(const Step& st, const MvsdfStepParams* prm, const char* fwd, MvsdfNetDesc* sdf, MvsdfNetDesc* sdfT, MvsdfNetDesc* rnd, MvsdfNetDesc* rndT) {
+    const MvsdfStepDesc& d = st.d;
+    auto fill = [&](MvsdfNetDesc* o, MvsdfNetDesc* oT, int l0, int n, bool is_sdf) {
+        memset(o, 0, sizeof(*o));
+        memset(oT, 0, sizeof(*oT));
+        o->n_layers = oT->n_layers = n;
+        for (int i = 0; i < n; ++i) {
+            const int l = l0 + i;
+            o->K[i] = d.K[l]; o->N[i] = d.N[l];
+            oT->K[i] = d.N[l]; oT->N[i] = d.K[l];
+            o->wp[i] = (const float*)(fwd + st.fo.wp[l]);
+            oT->wp[i] = (const float*)(fwd + st.fo.wpT[l]);
+            o->bias[i] = oT->bias[i] = prm->b[l];
+            o->w[i] = oT->w[i] = (const float*)(fwd + st.fo.w[l]);
+            if (is_sdf && d.trace_dtype == 1) o->wp16[i] = fwd + st.fo.wp16[l];
+        }
+        if (is_sdf) {
+            const unsigned m = d.skip_mask;
+            const int single = (m && !(m & (m - 1))) ? __builtin_ctz(m) : -1;
+            o->skip_layer = oT->skip_layer = m ? (single >= 0 ? single : __builtin_ctz(m)) : -1;
+            o->skip_mask = (m && single < 0) ? m : 0;
+            o->multires = oT->multires = d.multires;
+            o->trace_dtype = d.trace_dtype == 1 ? 1 : 0;
+        } else {
+            o->skip_layer = oT->skip_layer = -1;
+        }
+    };
+    fill(sdf, sdfT, 0, d.n_sdf, true);
+    fill(rnd, rndT, d.n_sdf, d.n_render, false);
+}
+
+// x_eval = [eikonal points | on-surface samples | jittered samples | traced points of the rays, hit rays first] (idr.py:253-257 evaluates these
+// sets in five separate network calls); also fills the all-ones object mask handed back in the output dict (idr.py:187)
+__global__ void k_step_gather_x(const float* __restrict__ eik, int n_eik, const float* __restrict__ ds_on, const float* __restrict__ ds_jit, int n_ds,
+                                const float* __restrict__ points, const long long* __restrict__ perm, int R, float* __restrict__ x_eval,
+                                uint8_t* __restrict__ ones) {
+    const int E = n_eik + 2 * n_ds, total = (E + R) * 3;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int row = i / 3, c = i - 3 * row;
+        float v;
+        if (row < n_eik) v = eik[i];
+        else if (row < n_eik + n_ds) v = ds_on[3 * (size_t)(row - n_eik) + c];
+        else if (row < E) v = ds_jit[3 * (size_t)(row - n_eik - n_ds) + c];
+        else v = points[3 * (size_t)perm[row - E] + c];
+        x_eval[i] = v;
+        if (ones && i < R) ones[i] = 1;
+    }
+}
+
+// drgb_sorted[i] = d_rgb[perm[i]] for the N hit rows (the rendering net ran on the sorted rows; idr.py:302-304 scatters its output)
+__global__ void k_step_gather_drgb(const float* __restrict__ d_rgb, const long long* __restrict__ perm, int N, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * N) return;
+    const int row = i / 3, c = i - 3 * row;
+    out[i] = d_rgb[3 * (size_t)perm[row] + c];
+}
+
+__global__ void k_step_copy_counts(const long long* __restrict__ ds_counts, long long* __restrict__ counts) {
+    if (threadIdx.x < 2) counts[2 + threadIdx.x] = ds_counts ? ds_counts[threadIdx.x] : 0;
+}
+
+#define ST_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+#define ST_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mv_check(e_, #expr); } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void** out) {
+    if (!desc || !layout || !out) return mv_fail(-1, "mvsdf_step_create: null argument");
+    const MvsdfStepDesc& d = *desc;
+    const int nl = d.n_sdf + d.n_render;
+    if (d.B <= 0 || d.P <= 0 || d.n_eik < 0 || d.n_ds < 0 || d.n_sdf < 2 || d.n_render < 1 || d.n_sdf > MVSDF_MAX_LAYERS || d.n_render > MVSDF_MAX_LAYERS ||
+        nl > MVSDF_STEP_MAX_LAYERS || (long long)d.B * d.P > (1ll << 24))
+        return mv_fail(-1, "mvsdf_step_create: bad sizes");
+    Step* st = new (std::nothrow) Step;
+    if (!st) return mv_fail(-1, "mvsdf_step_create: out of host memory");
+    memset(st, 0, sizeof(*st));
+    st->d = d;
+    st->R = d.B * d.P; st->E = d.n_eik + 2 * d.n_ds; st->M = st->R + st->E; st->nl = nl;
+    st->Nout = d.N[d.n_sdf - 1]; st->K0r = d.K[d.n_sdf];
+    const int R = st->R, M = st->M;
+    // probe descriptors (sizes only; the size functions do not dereference the pack pointers but the validity checks want non-null ones)
+    MvsdfNetDesc sdf, sdfT, rnd, rndT;
+    MvsdfStepParams fake;
+    memset(&fake, 0, sizeof(fake));
+    static const float dummy = 0.f;
+    for (int l = 0; l < nl; ++l) fake.b[l] = &dummy;
+    MvsdfStepLayout& L = st->lay;
+    FwdOffsets& fo = st->fo;
+    size_t p = 0;
+    auto take = [&](size_t bytes) { const size_t o = p; p += al256(bytes ? bytes : 4); return o; };
+    L.ray_dirs = take((size_t)R * 12); L.cam_loc = take((size_t)d.B * 12);
+    L.points = take((size_t)R * 12); L.mask = take((size_t)R); L.dists = take((size_t)R * 4); L.counters = take(16 * 8);
+    L.object_mask_out = take((size_t)R);
+    fo.trace_ws_bytes = mvsdf_trace_workspace_bytes_n(R, d.tp.n_steps);
+    fo.trace_ws = take(fo.trace_ws_bytes);
+    for (int l = 0; l < nl; ++l) {
+        fo.w[l] = take((size_t)d.N[l] * d.K[l] * 4);
+        fo.wp[l] = take(mvsdf_packed_floats(d.N[l], d.K[l]) * 4);
+        fo.wpT[l] = take(mvsdf_packed_floats(d.K[l], d.N[l]) * 4);
+        if (l < d.n_sdf && d.trace_dtype == 1) {
+            const int ns = (l == 0 || ((d.skip_mask >> l) & 1u)) ? 3 + 6 * d.multires : 0;
+            fo.wp16[l] = take(mvsdf_packed_bf16_bytes(d.N[l], d.K[l], ns));
+        }
+    }
+    L.perm = take((size_t)R * 8); fo.inv = take((size_t)R * 8); fo.true_rows = take((size_t)R * 8); fo.counts = take(4 * 8);
+    fo.view_sorted = take((size_t)R * 12);
+    fo.x_eval = take((size_t)M * 12); fo.y_eval = take((size_t)M * st->Nout * 4); fo.n_eval = take((size_t)M * 12);
+    // the size functions need structurally valid descriptors: point every pack at the dummy
+    make_descs(*st, &fake, (const char*)nullptr, &sdf, &sdfT, &rnd, &rndT);
+    for (int i = 0; i < d.n_sdf; ++i) { sdf.wp[i] = sdfT.wp[i] = &dummy; sdf.w[i] = &dummy; }
+    for (int i = 0; i < d.n_render; ++i) { rnd.wp[i] = rndT.wp[i] = &dummy; }
+    const size_t ctx_f = mvsdf_sdf_ctx_floats(&sdf, M, M), rctx_f = mvsdf_render_ctx_floats(&rnd, R);
+    if (!ctx_f || !rctx_f) { delete st; return mv_fail(-2, "mvsdf_step_create: network descriptor rejected (layer dims / skip mask)"); }
+    fo.sdf_ctx = take(ctx_f * 4);
+    fo.rgb_sorted = take((size_t)R * 12);
+    fo.render_ctx = take(rctx_f * 4);
+    L.rgb_values = take((size_t)R * 12); L.sdf_output = take((size_t)R * 4); L.diff_pts = take((size_t)R * 12);
+    L.eik_out = take((size_t)M * 4); L.points_hom = take((size_t)M * 16); L.grad_theta = take((size_t)M * 12);
+    L.surf = take((size_t)(R + d.n_eik) * 4);
+    L.fwd_bytes = p;
+    // backward scratch
+    BwdOffsets& bo = st->bo;
+    p = 0;
+    bo.dy = take((size_t)M * st->Nout * 4); bo.dn = take((size_t)M * 12);
+    bo.dy_x = take((size_t)R * st->Nout * 4); bo.dn_x = take((size_t)R * 12);
+    bo.din = take((size_t)R * st->K0r * 4); bo.drgb_sorted = take((size_t)R * 12);
+    bo.render_ws = take(mvsdf_render_bwd_ws_floats(&rnd, R) * 4);
+    bo.wsA = take(mvsdf_sdf_bwd_ws_floats(&sdf, M) * 4);
+    bo.wsX = take(mvsdf_sdf_bwd_ws_floats(&sdf, R) * 4);
+    bo.dx = take((size_t)R * 12); bo.fbar = take((size_t)R * 4);
+    size_t off = 0;
+    int lo = 0;
+    const int cuts[2] = {d.n_sdf, nl};
+    for (int net = 0; net < 2; ++net) {
+        st->seg[net][0] = off;
+        for (int l = lo; l < cuts[net]; ++l) { st->woff[l] = off; off += (size_t)d.N[l] * d.K[l]; }
+        st->seg[net][1] = off;
+        for (int l = lo; l < cuts[net]; ++l) { st->boff[l] = off; off += (size_t)d.N[l]; }
+        st->seg[net][2] = off;
+        lo = cuts[net];
+    }
+    L.dflat_floats = off;
+    L.dflat = take(off * 4);
+    L.bwd_bytes = p;
+    // the pinned count buffer and the event are made by the first forward (creating a step needs no GPU: layouts can be inspected anywhere)
+    *layout = L;
+    *out = st;
+    return 0;
+}
+
+void mvsdf_step_destroy(void* step) {
+    Step* st = (Step*)step;
+    if (!st) return;
+    if (st->timing) for (int i = 0; i < 5; ++i) hipEventDestroy(st->ev_t[i]);
+    if (st->counts_host) { hipEventDestroy(st->ev_counts); hipHostFree(st->counts_host); }
+    delete st;
+}
+
+int mvsdf_step_set_timing(void* step, int enable) {
+    Step* st = (Step*)step;
+    if (!st) return mv_fail(-1, "mvsdf_step_set_timing: null step");
+    if (enable && !st->timing) {
+        for (int i = 0; i < 5; ++i) ST_HIP(hipEventCreate(&st->ev_t[i]));
+        st->timing = 1;
+    } else if (!enable && st->timing) {
+        for (int i = 0; i < 5; ++i) hipEventDestroy(st->ev_t[i]);
+        st->timing = 0;
+    }
+    st->timed = false;
+    return 0;
+}
+
+int mvsdf_step_trace_times(void* step, float ms[3]) {
+    Step* st = (Step*)step;
+    if (!st || !ms || !st->timing || !st->timed) return mv_fail(-1, "mvsdf_step_trace_times: timing is off or no forward has run");
+    float a = 0.f, b = 0.f, c = 0.f;
+    ST_HIP(hipEventElapsedTime(&a, st->ev_t[0], st->ev_t[1]));
+    ST_HIP(hipEventElapsedTime(&b, st->ev_t[1], st->ev_t[2]));
+    ST_HIP(hipEventElapsedTime(&c, st->ev_t[3], st->ev_t[4]));
+    ms[0] = a; ms[1] = b; ms[2] = c;
+    return 0;
+}
+
+int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepInputs* in, int d_mask, int e_mask, void* fwd_, void* stream) {
+    Step* st = (Step*)step;
+    if (!st || !prm || !in || !fwd_) return mv_fail(-1, "mvsdf_step_forward: null argument");
+    const MvsdfStepDesc& d = st->d;
+    if (!in->uv || !in->pose || !in->intrinsics || !in->object_mask || !in->object_mask_true || !in->intervals || !in->minsdf_steps ||
+        (d.n_eik > 0 && !in->eik_points) || (d.n_ds > 0 && (!in->ds_on || !in->ds_jit || !in->ds_counts)))
+        return mv_fail(-1, "mvsdf_step_forward: missing input");
+    hipStream_t s = (hipStream_t)stream;
+    if (!st->counts_host) {                                       // first forward: host-side staging for the hit counts
+        ST_HIP(hipHostMalloc((void**)&st->counts_host, 4 * sizeof(long long), hipHostMallocDefault));
+        if (hipEventCreateWithFlags(&st->ev_counts, hipEventDisableTiming) != hipSuccess) {
+            hipHostFree(st->counts_host); st->counts_host = nullptr;
+            return mv_fail(-1, "mvsdf_step_forward: hipEventCreate failed");
+        }
+    }
+    char* fwd = (char*)fwd_;
+    const MvsdfStepLayout& L = st->lay;
+    const FwdOffsets& fo = st->fo;
+    const int R = st->R, E = st->E, M = st->M, nl = st->nl;
+    // 1. weight-norm fold + MFMA packs of both networks (idr.py:70-71; one fold per step instead of one per network call)
+    float* w[MVSDF_STEP_MAX_LAYERS]; float* wp[MVSDF_STEP_MAX_LAYERS]; float* wpT[MVSDF_STEP_MAX_LAYERS];
+    for (int l = 0; l < nl; ++l) { w[l] = (float*)(fwd + fo.w[l]); wp[l] = (float*)(fwd + fo.wp[l]); wpT[l] = (float*)(fwd + fo.wpT[l]); }
+    ST_TRY(mvsdf_fold_pack_net(nl, prm->v, prm->g, d.N, d.K, w, wp, wpT, stream));
+    if (d.trace_dtype == 1) {
+        void* wp16[MVSDF_MAX_LAYERS];
+        for (int l = 0; l < d.n_sdf; ++l) wp16[l] = fwd + fo.wp16[l];
+        ST_TRY(mvsdf_pack_bf16_net_skips(d.n_sdf, w, d.N, d.K, d.skip_mask, d.multires, wp16, stream));
+    }
+    MvsdfNetDesc sdf, sdfT, rnd, rndT;
+    make_descs(*st, prm, fwd, &sdf, &sdfT, &rnd, &rndT);
+    // 2. rays + RayTracing.forward (idr.py:190-199)
+    float* ray_dirs = (float*)(fwd + L.ray_dirs); float* cam_loc = (float*)(fwd + L.cam_loc);
+    float* points = (float*)(fwd + L.points); uint8_t* mask = (uint8_t*)(fwd + L.mask); float* dists = (float*)(fwd + L.dists);
+    unsigned long long* counters = (unsigned long long*)(fwd + L.counters);
+    ST_TRY(mvsdf_camera_rays(in->uv, in->pose, in->intrinsics, d.B, d.P, ray_dirs, cam_loc, stream));
+    auto stage = [&](int which) {
+        return mvsdf_trace_stage(which, &sdf, &d.tp, cam_loc, ray_dirs, in->object_mask, d.B, d.P, 1, in->intervals, in->minsdf_steps, points, mask, dists,
+                                 counters, fwd + fo.trace_ws, fo.trace_ws_bytes, d.mt, d.mt_samples, stream);
+    };
+    if (st->timing) ST_HIP(hipEventRecord(st->ev_t[0], s));
+    ST_TRY(stage(1));
+    if (st->timing) ST_HIP(hipEventRecord(st->ev_t[1], s));
+    ST_TRY(stage(3));                                             // the hit mask is final here (ray_tracing.py:61)
+    if (st->timing) ST_HIP(hipEventRecord(st->ev_t[2], s));
+    // 3. stable partition (hit rays first) + both counts; they start travelling to the host while the rest of the forward runs
+    long long* perm = (long long*)(fwd + L.perm); long long* inv = (long long*)(fwd + fo.inv); long long* true_rows = (long long*)(fwd + fo.true_rows);
+    long long* counts = (long long*)(fwd + fo.counts); float* view_sorted = (float*)(fwd + fo.view_sorted);
+    ST_TRY(mvsdf_partition_rays(mask, d.use_object_mask ? in->object_mask : nullptr, in->object_mask_true, ray_dirs, R, perm, inv, true_rows, counts,
+                                view_sorted, stream));
+    hipLaunchKernelGGL(k_step_copy_counts, dim3(1), dim3(64), 0, s, d.n_ds > 0 ? in->ds_counts : nullptr, counts);
+    ST_HIP(hipMemcpyAsync(st->counts_host, counts, 4 * sizeof(long long), hipMemcpyDeviceToHost, s));
+    ST_HIP(hipEventRecord(st->ev_counts, s));
+    st->counts_pending = true;
+    if (st->timing) ST_HIP(hipEventRecord(st->ev_t[3], s));
+    ST_TRY(stage(4));                                             // secant + min-sdf rows: only points / dists still move
+    if (st->timing) { ST_HIP(hipEventRecord(st->ev_t[4], s)); st->timed = true; }
+    // 4. ONE fused value + normal evaluation over [samples | rays, hit first], rendering net on every sorted ray, output gather
+    float* x_eval = (float*)(fwd + fo.x_eval); float* y_eval = (float*)(fwd + fo.y_eval); float* n_eval = (float*)(fwd + fo.n_eval);
+    {
+        const int total = M * 3;
+        hipLaunchKernelGGL(k_step_gather_x, dim3((total + 255) / 256), dim3(256), 0, s, in->eik_points, d.n_eik, in->ds_on, in->ds_jit, d.n_ds, points, perm,
+                           R, x_eval, (uint8_t*)(fwd + L.object_mask_out));
+        ST_HIP(hipGetLastError());
+    }
+    ST_TRY(mvsdf_sdf_forward(&sdf, &sdfT, x_eval, M, M, y_eval, n_eval, (float*)(fwd + fo.sdf_ctx), stream));
+    float* rgb_sorted = (float*)(fwd + fo.rgb_sorted);
+    ST_TRY(mvsdf_render_forward(&rnd, x_eval + 3 * (size_t)E, view_sorted, n_eval + 3 * (size_t)E, y_eval + (size_t)E * st->Nout + 2, st->Nout, R,
+                                d.view_spec, rgb_sorted, (float*)(fwd + fo.render_ctx), stream));
+    ST_TRY(mvsdf_step_outputs(R, d.n_eik, d.n_ds, st->Nout, counts, x_eval, y_eval, n_eval, inv, true_rows, rgb_sorted, d_mask, e_mask,
+                              (float*)(fwd + L.rgb_values), (float*)(fwd + L.sdf_output), (float*)(fwd + L.diff_pts), (float*)(fwd + L.eik_out),
+                              (float*)(fwd + L.points_hom), (float*)(fwd + L.grad_theta), (float*)(fwd + L.surf), stream));
+    return 0;
+}
+
+int mvsdf_step_wait_counts(void* step, long long counts[4]) {
+    Step* st = (Step*)step;
+    if (!st || !counts) return mv_fail(-1, "mvsdf_step_wait_counts: null argument");
+    if (!st->counts_pending) return mv_fail(-1, "mvsdf_step_wait_counts: no forward is in flight");
+    ST_HIP(hipEventSynchronize(st->ev_counts));
+    for (int i = 0; i < 4; ++i) counts[i] = st->counts_host[i];
+    st->counts_pending = false;
+    return 0;
+}
+
+int mvsdf_step_backward(void* step, const MvsdfStepParams* prm, int N, int n_true, int d_mask, int e_mask, int use_geo, const float* d_diff,
+                        const float* d_rgb, const float* d_gth, const float* d_eo, const float* d_si, const void* fwd_, void* bwd_,
+                        float* const* dv, float* const* dg, float* const* db, int accumulate, void* stream) {
+    Step* st = (Step*)step;
+    if (!st || !prm || !fwd_ || !bwd_ || !dv || !dg || !db) return mv_fail(-1, "mvsdf_step_backward: null argument");
+    const MvsdfStepDesc& d = st->d;
+    const int R = st->R, E = st->E, M = st->M, nl = st->nl, Nout = st->Nout;
+    if (N < 0 || N > R || n_true < 0 || n_true > N) return mv_fail(-1, "mvsdf_step_backward: bad counts");
+    hipStream_t s = (hipStream_t)stream;
+    const char* fwd = (const char*)fwd_;
+    char* bwd = (char*)bwd_;
+    const MvsdfStepLayout& L = st->lay;
+    const FwdOffsets& fo = st->fo;
+    const BwdOffsets& bo = st->bo;
+    MvsdfNetDesc sdf, sdfT, rnd, rndT;
+    make_descs(*st, prm, fwd, &sdf, &sdfT, &rnd, &rndT);
+    const int Mb = E + N;
+    float* dflat = (float*)(bwd + L.dflat);
+    float* dW_s = dflat + st->seg[0][0]; float* db_s = dflat + st->seg[0][1];
+    float* dW_r = dflat + st->seg[1][0]; float* db_r = dflat + st->seg[1][1];
+    float* dy = (float*)(bwd + bo.dy); float* dn = (float*)(bwd + bo.dn);
+    const float* x_eval = (const float*)(fwd + fo.x_eval); const float* n_eval = (const float*)(fwd + fo.n_eval);
+    const float* view_sorted = (const float*)(fwd + fo.view_sorted); const long long* true_rows = (const long long*)(fwd + fo.true_rows);
+    const float* ctx = (const float*)(fwd + fo.sdf_ctx);
+    const int dv_ = (d.view_spec & 0x100) ? 0 : 3 + 6 * (d.view_spec & 0xff), dnr = (d.view_spec & 0x200) ? 0 : 3;
+    const int nrm0 = dnr ? 3 + dv_ : -1, feat0 = 3 + dv_ + dnr;                          // column layout of the rendering net's input (functional.render_offsets)
+    if (Mb == 0) {                                                                      // nothing was evaluated with a gradient
+        ST_HIP(hipMemsetAsync(dflat, 0, L.dflat_floats * 4, s));
+    } else {
+        const float* din = nullptr;
+        // rendering-net backward over the N hit rows (idr.py:302-304: only they reach rgb_values)
+        if (N > 0 && d_rgb) {
+            float* drgb_sorted = (float*)(bwd + bo.drgb_sorted);
+            hipLaunchKernelGGL(k_step_gather_drgb, dim3((3 * N + 255) / 256), dim3(256), 0, s, d_rgb, (const long long*)(fwd + L.perm), N, drgb_sorted);
+            float* din_w = (float*)(bwd + bo.din);
+            ST_TRY(mvsdf_render_backward(&rnd, &rndT, N, R, drgb_sorted, (const float*)(fwd + fo.render_ctx), dW_r, db_r, din_w, (float*)(bwd + bo.render_ws),
+                                         stream));
+            din = din_w;
+        } else {
+            ST_HIP(hipMemsetAsync(dflat + st->seg[1][0], 0, (st->seg[1][2] - st->seg[1][0]) * 4, s));
+        }
+        // upstream of the fused SDF backward: zero + the rendering net's feature / normal adjoints on the hit rows
+        ST_TRY(mvsdf_step_backward_inputs(0, d.n_eik, d.n_ds, N, Nout, n_true, din, st->K0r, feat0, nrm0, use_geo, nullptr, nullptr, view_sorted, n_eval,
+                                          true_rows, nullptr, nullptr, nullptr, d_mask, e_mask, dy, dn, stream));
+        bool done = false;
+        if (din && N > 0) {
+            // (X) input adjoint of the surface points for the rendering net's upstream alone, (A) the full pass with every upstream except
+            // SampleNetwork's scalar: independent, one grid; then fbar = -xbar.v / n.v and a first-order delta pass
+            float* dy_x = (float*)(bwd + bo.dy_x); float* dn_x = (float*)(bwd + bo.dn_x);
+            ST_HIP(hipMemcpyAsync(dy_x, dy + (size_t)E * Nout, (size_t)N * Nout * 4, hipMemcpyDeviceToDevice, s));
+            if (use_geo) ST_HIP(hipMemcpyAsync(dn_x, dn + 3 * (size_t)E, (size_t)N * 12, hipMemcpyDeviceToDevice, s));
+            ST_TRY(mvsdf_step_backward_inputs(2, d.n_eik, d.n_ds, N, Nout, n_true, din, st->K0r, feat0, nrm0, use_geo, d_diff, nullptr, view_sorted, n_eval,
+                                              true_rows, d_eo, d_gth, d_si, d_mask, e_mask, dy, dn, stream));
+            float* wsA = (float*)(bwd + bo.wsA); float* dx = (float*)(bwd + bo.dx);
+            int rc = mvsdf_sdf_backward_pair(&sdf, &sdfT, M, M, Mb, dy, dn, wsA, E, N, dy_x, use_geo ? dn_x : nullptr, (float*)(bwd + bo.wsX), dx, ctx, stream);
+            if (rc == 0) {
+                float* fbar = (float*)(bwd + bo.fbar);
+                ST_TRY(mvsdf_step_backward_fbar(d.n_eik, d.n_ds, N, Nout, din, st->K0r, use_geo, d_diff, dx, view_sorted, n_eval, dy, fbar, stream));
+                ST_TRY(mvsdf_sdf_backward_finish(&sdf, &sdfT, M, M, Mb, dy, ctx, wsA, E, N, fbar, dW_s, db_s, stream));
+                done = true;
+            } else if (rc == -3) {                                                      // network too wide for the fused chains: the sequential route
+                ST_TRY(mvsdf_sdf_backward(&sdf, &sdfT, x_eval + 3 * (size_t)E, M, M, E, N, dy_x, use_geo ? dn_x : nullptr, ctx, nullptr, nullptr, dx, wsA, stream));
+                float* fbar = (float*)(bwd + bo.fbar);
+                ST_TRY(mvsdf_step_backward_fbar(d.n_eik, d.n_ds, N, Nout, din, st->K0r, use_geo, d_diff, dx, view_sorted, n_eval, dy, fbar, stream));
+            } else {
+                return rc;
+            }
+        } else {
+            ST_TRY(mvsdf_step_backward_inputs(1, d.n_eik, d.n_ds, N, Nout, n_true, din, st->K0r, feat0, nrm0, use_geo, d_diff, nullptr, view_sorted, n_eval,
+                                              true_rows, d_eo, d_gth, d_si, d_mask, e_mask, dy, dn, stream));
+        }
+        if (!done)
+            ST_TRY(mvsdf_sdf_backward(&sdf, &sdfT, x_eval, M, M, 0, Mb, dy, dn, ctx, dW_s, db_s, nullptr, (float*)(bwd + bo.wsA), stream));
+    }
+    // weight-norm fold backward of both networks: dW / db -> dv, dg, db, added into the targets when accumulate
+    const float* dWl[MVSDF_STEP_MAX_LAYERS]; const float* dbl[MVSDF_STEP_MAX_LAYERS];
+    for (int l = 0; l < nl; ++l) { dWl[l] = dflat + st->woff[l]; dbl[l] = dflat + st->boff[l]; }
+    return mvsdf_fold_backward_net(nl, prm->v, prm->g, dWl, dbl, d.N, d.K, dv, dg, db, accumulate ? 1 : 0, stream);
+}
+
+}  // extern "C"

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import native_step as NS
 from ..utils.general import PinnedUniform
 from .. import ops
 from ..utils import rend_util
@@ -283,6 +284,11 @@ class IDRNetwork(nn.Module):
         self._fold_cache = {}                                    # ops.FoldPlan of the training step's flat fold
         self._lazy_prev = None
         self.lazy_unused_outputs = False                         # training: evaluate the min-sdf points of non-hit rays only if `points` / `sdf_output` are read (LazyOutputs)
+        # training forward / backward through the native step driver (csrc/step_driver.hip: one C call each instead of ~45 ctypes calls and
+        # autograd glue).  False: the Python-orchestrated route over the same kernels (kept for A/B tests and the launch-path experiments).
+        self.native_step = os.environ.get('MVSDF_NATIVE_STEP', '1') != '0'
+        self._steps = {}                                         # NativeStep per batch shape / phase configuration
+        self._ones = None                                        # all-ones object mask handed to the tracer when conf.use_mask is off
 
     def set_trace_dtype(self, dtype):
         """'f32' (default: fp32 weights, fp32-input MFMA, bit-exact against the oracle) or 'bf16' (BASELINE configs[4]: the ray tracer's SDF
@@ -310,6 +316,14 @@ class IDRNetwork(nn.Module):
     def forward(self, input, train_progress=None):
         intrinsics, uv, pose = input['intrinsics'], input['uv'], input['pose']
         object_mask_true = input['object_mask'].reshape(-1)
+        prev = self._lazy_prev() if self._lazy_prev is not None else None
+        if prev is not None:
+            prev._expire()
+        self._lazy_prev = None
+        if self.training and self.native_step and not self.lazy_unused_outputs and self.ray_tracer.events is None and not ops._MINSDF_SIDE_STREAM:
+            out = self._forward_native(input, train_progress, object_mask_true)
+            if out is not None:
+                return out
         object_mask = object_mask_true if conf.use_mask else torch.ones_like(object_mask_true)
 
         ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
@@ -317,10 +331,6 @@ class IDRNetwork(nn.Module):
         R = batch_size * num_pixels
         dev = ray_dirs.device
 
-        prev = self._lazy_prev() if self._lazy_prev is not None else None
-        if prev is not None:
-            prev._expire()
-        self._lazy_prev = None
         # one weight-norm fold per step, both networks in one launch pair (and one backward launch).  Training: the folded parameters are ONE
         # flat tensor (one autograd edge, pointer arithmetic instead of per-layer tensors); eval keeps the per-layer form the stand-alone
         # Functions take.
@@ -461,6 +471,144 @@ class IDRNetwork(nn.Module):
             out = LazyOutputs(out, materialize)
             self._lazy_prev = weakref.ref(out)
         return out
+
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _native_step_for(self, B, P, n_ds, dev):
+        """The NativeStep of this batch shape (created on first use: host-side state only)."""
+        inet, rnet, rt = self.implicit_network, self.rendering_network, self.ray_tracer
+        R = B * P
+        mt, mt_samples = rt.tiling(R)
+        tpv = rt._params()
+        key = (B, P, n_ds, str(dev), self.trace_dtype, mt, mt_samples, tpv, bool(conf.use_mask))
+        st = self._steps.get(key)
+        if st is None:
+            vs, gs, bs, skips, multires = inet.fold_spec()
+            rvs, rgs, rbs, _, _ = rnet.fold_spec()
+            if len(vs) + len(rvs) > NS.STEP_MAX_LAYERS or max(v.shape[0] for v in vs[:-1]) > 512:
+                self._steps[key] = False                          # outside what the driver covers: the Python-orchestrated route
+                return None
+            d = NS.StepDesc()
+            d.B, d.P, d.n_eik, d.n_ds = B, P, R // 2, n_ds
+            d.n_sdf, d.n_render = len(vs), len(rvs)
+            for l, v in enumerate(list(vs) + list(rvs)):
+                d.N[l], d.K[l] = v.shape
+            skips = skips if isinstance(skips, (tuple, list)) else ((skips,) if skips >= 0 else ())
+            d.skip_mask = sum(1 << int(sk) for sk in skips)
+            d.multires, d.view_spec = multires, rnet.view_spec
+            d.trace_dtype = 1 if self.trace_dtype == 'bf16' else 0
+            d.use_object_mask = 1 if conf.use_mask else 0
+            d.tp = NS.TraceParams(*tpv)
+            d.mt, d.mt_samples = mt, mt_samples
+            st = self._steps[key] = NS.NativeStep(d, dev)
+        return st or None
+
+    def _forward_native(self, input, train_progress, object_mask_true):
+        """Training forward through the native step driver: ONE C call enqueues fold -> rays -> tracer -> partition -> fused value + normal
+        evaluation -> rendering net -> output gather; the host then waits for the hit counts (copied out right after the partition, i.e. while
+        the last tracer launch and the evaluation still run) and wraps regions of the forward block as the output tensors.
+        Returns None when the configuration is outside what the driver covers."""
+        assert train_progress is not None
+        uv, pose, intrinsics = input['uv'], input['pose'], input['intrinsics']
+        dev = uv.device
+        if not (uv.is_cuda and uv.dtype == torch.float32 and pose.dtype == torch.float32 and intrinsics.dtype == torch.float32 and pose.shape[1:] == (4, 4)):
+            return None
+        B, P = uv.shape[0], uv.shape[1]
+        R = B * P
+        use_ds = any([conf.d_use_dsurf_on(train_progress), conf.d_use_dsurf_jitter(train_progress),
+                      conf.eik_use_dsurf_on(train_progress), conf.eik_use_dsurf_jitter(train_progress)])
+        n_ds = R // 2 if use_ds else 0
+        st = self._native_step_for(B, P, n_ds, dev)
+        if st is None:
+            return None
+        rt = self.ray_tracer
+        vs, gs, bs, params = self._step_params()
+        # random draws in the order of the Python route: depth-surface seed, min-sdf steps, eikonal points (all from torch's CPU generator)
+        dsurf = self._dsurf_samples(input, n_ds, self.object_bounding_sphere) if use_ds else None
+        bb = self.object_bounding_sphere
+        n_eik = R // 2
+        minsdf_steps, eik = self._draw.pair((rt.n_steps,), 0.0, 1.0, (n_eik, 3), -bb, bb, dev)
+        true_u8 = object_mask_true if object_mask_true.dtype == torch.uint8 else (
+            object_mask_true.view(torch.uint8) if object_mask_true.dtype == torch.bool else object_mask_true.to(torch.uint8))
+        if not true_u8.is_contiguous():
+            true_u8 = true_u8.contiguous()
+        if conf.use_mask:
+            om_u8 = true_u8
+        else:
+            if self._ones is None or self._ones.numel() != R or self._ones.device != dev:
+                self._ones = torch.ones(R, dtype=torch.uint8, device=dev)
+            om_u8 = self._ones
+        iv = rt.intervals(dev)
+        i = st.inputs
+        uv_c, pose_c, intr_c = (uv if uv.is_contiguous() else uv.contiguous()), (pose if pose.is_contiguous() else pose.contiguous()), (
+            intrinsics if intrinsics.is_contiguous() else intrinsics.contiguous())
+        keep = (uv_c, pose_c, intr_c, true_u8, om_u8, iv, minsdf_steps, eik, dsurf)
+        i.uv, i.pose, i.intrinsics = uv_c.data_ptr(), pose_c.data_ptr(), intr_c.data_ptr()
+        i.object_mask, i.object_mask_true = om_u8.data_ptr(), true_u8.data_ptr()
+        i.intervals, i.minsdf_steps, i.eik_points = iv.data_ptr(), minsdf_steps.data_ptr(), eik.data_ptr()
+        if dsurf is not None:
+            i.ds_on, i.ds_jit, i.ds_counts = dsurf[0].data_ptr(), dsurf[1].data_ptr(), dsurf[2].data_ptr()
+        else:
+            i.ds_on = i.ds_jit = i.ds_counts = None
+        rec = NS.StepRecord()
+        rec.step, rec.vs, rec.gs, rec.bs, rec.params = st, vs, gs, bs, params
+        rec.prm = st.params(vs, gs, bs)
+        rec.d_mask, rec.e_mask = self._group_masks(train_progress, n_eik, n_ds)
+        rec.use_geo = not bool(train_progress < conf.phase[0] or conf.disable_rgb_grad)                       # idr.py:331-334
+        diff_pts, rgb_values, grad_theta, eik_out, surf = NS.run_step(rec)
+        if dsurf is not None and min(int(rec.counts[2]), int(rec.counts[3])) < n_ds:
+            raise ValueError("Cannot take a larger sample than population when 'replace=False'")          # np.random.choice, idr.py:244
+        L, f, N = st.layout, rec.fwd, rec.N
+        nd, _ = rec.keep
+        rec.keep = keep                                          # the inputs stay alive as long as the step's autograd node does
+        counters = f.b(L.counters, (128,)).view(torch.int64)
+        rt.last_counters = counters
+        out = {
+            'points': f.f(L.points, (R, 3)),
+            'diff_surf_pts': diff_pts,
+            'rgb_values': rgb_values,
+            'sdf_output': f.f(L.sdf_output, (R, 1)),
+            'network_object_mask': f.b(L.mask, (R,)).view(torch.bool),
+            'object_mask': object_mask_true if conf.use_mask else f.b(L.object_mask_out, (R,)).view(torch.bool),
+            'object_mask_true': object_mask_true,
+            'grad_theta': grad_theta,
+            'eikonal_points_hom': f.f(L.points_hom, (1, nd, 4, 1)),
+            'eikonal_output': eik_out,
+            'surf_indicator_output': surf,
+        }
+        self.last_stats = {'R': R, 'N': N, 'E': st.E, 'counters': counters}
+        self._last_step = st
+        return out
+
+    def _step_params(self):
+        """(weight_v list, weight_g list, bias list, all of them as one tuple) of both networks, SDF layers first.  The Parameter OBJECTS of a
+        module are stable (load_state_dict, .to() and optimizers change their .data), so the lists are built once per set of objects."""
+        c = getattr(self, '_param_cache', None)
+        inet, rnet = self.implicit_network, self.rendering_network
+        if c is not None:
+            lins, objs = c[0], c[1]
+            if all(m._parameters.get(n) is o for (m, n), o in zip(lins, objs)):      # nobody re-assigned a Parameter
+                return c[2]
+        vs, gs, bs, _, _ = inet.fold_spec()
+        rvs, rgs, rbs, _, _ = rnet.fold_spec()
+        vs, gs, bs = list(vs) + list(rvs), list(gs) + list(rgs), list(bs) + list(rbs)
+        lins, objs = [], []
+        mods = inet._lins() + [getattr(rnet, 'lin' + str(l)) for l in range(rnet.num_layers - 1)]
+        for m in mods:
+            for n, o in m._parameters.items():
+                lins.append((m, n)); objs.append(o)
+        res = (vs, gs, bs, tuple(vs) + tuple(gs) + tuple(bs))
+        self._param_cache = (lins, objs, res)
+        return res
+
+    def _group_masks(self, train_progress, n_eik, n_ds):
+        """Point groups in the reference's row order [hit | eikonal | on-surface | jittered] (idr.py:253-257): bit g selects group g for the
+        depth term / the eikonal term (idr.py:258-286)."""
+        d_flags = (conf.d_use_rt_surf, conf.d_use_eik, conf.d_use_dsurf_on, conf.d_use_dsurf_jitter)
+        e_flags = (conf.eik_use_rt_surf, conf.eik_use_eik, conf.eik_use_dsurf_on, conf.eik_use_dsurf_jitter)
+        has = (True, n_eik > 0, n_ds > 0, n_ds > 0)
+        return (sum(1 << g for g in range(4) if has[g] and d_flags[g](train_progress)),
+                sum(1 << g for g in range(4) if has[g] and e_flags[g](train_progress)))
 
     def _rgb_from_shared(self, shared, ws, bs, points, view_dirs, N, train_progress, row0=0, folded=None):
         defer = self.training and points.requires_grad and points.grad_fn is not None

@@ -11,6 +11,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from .. import functional as Fn
+from .. import native_step as NS
 from .. import ops
 from . import conf as _default_conf
 
@@ -26,6 +27,8 @@ class IDRLoss(nn.Module):
         self.l1_loss = nn.L1Loss(reduction='sum')
         # with torch.distributed initialised: normalise the count-based means by the counts summed over the ranks (see forward)
         self.exact_data_parallel = True
+        # forward / backward as ONE C call each (mvsdf_loss_forward / mvsdf_loss_backward) instead of four calls + two autograd nodes
+        self.native = os.environ.get('MVSDF_NATIVE_STEP', '1') != '0'
 
     def get_rgb_loss(self, rgb_values, rgb_gt, network_object_mask, object_mask):
         mask = network_object_mask & object_mask                                   # loss.py:21-28; a zero-hit batch gives 0 either way
@@ -91,22 +94,12 @@ class IDRLoss(nn.Module):
         if conf.smooth(train_progress) is not None or conf.use_invalid or not conf.enable_rgb:
             raise NotImplementedError('smooth / use_invalid / enable_rgb=False are off in the reference conf (model/conf.py:17-25)')
 
-        # masks -> hit mask, per-view row ranges of diff_surf_pts, number of BCE positives: one launch (csrc/loss_kernels.hip::k_loss_prep)
-        n_views = ground_truth['feat'].size()[0] if 'feat' in ground_truth else 1
-        hit_mask, view_start, n_pos = ops.loss_prep(network_object_mask, object_mask, model_outputs['object_mask_true'], n_views)
-        phase1 = conf.phase[0] <= train_progress
-        feat_on = bool(phase1 and conf.enable_feat)
-        feat_pp = None
-        pts = model_outputs['diff_surf_pts']
-        if feat_on and pts.shape[0] > 0:
-            if model_outputs.get('uncerts') is not None:
-                raise NotImplementedError('uncerts is always None in the reference (loss.py:197)')
-            feat_pp = Fn.feat_corr_terms(pts, view_start, ground_truth['feat'], ground_truth['feat_src'], ground_truth['cam'],
-                                         ground_truth['src_cams'], ground_truth['size'], ground_truth['center'])
-        dist_r, dweight = self._carve(model_outputs['eikonal_points_hom'], ground_truth['depths'], ground_truth['depth_cams'],
-                                      ground_truth['size'], ground_truth['center'], train_progress)
         weights = (conf.rgb_weight(train_progress), conf.eikonal_weight, conf.surf_weight, conf.feat_weight(train_progress),
                    conf.depth_weight(train_progress))
+        phase1 = conf.phase[0] <= train_progress
+        feat_on = bool(phase1 and conf.enable_feat)
+        if feat_on and model_outputs.get('uncerts') is not None:
+            raise NotImplementedError('uncerts is always None in the reference (loss.py:197)')
         # Data parallel (one process per GPU, rays sharded by view, gradients averaged over ranks): the three count-normalised means
         # (eikonal over grad_theta rows, depth over eikonal_output entries, surface BCE over its logits; loss.py:34,61,173) divide by
         # the GLOBAL counts so that the rank-averaged gradient equals the single-process one -- one extra all-reduce of 3 numbers.
@@ -116,7 +109,80 @@ class IDRLoss(nn.Module):
                                 float(model_outputs['surf_indicator_output'].numel())], device=dev)
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
             inv_counts = float(dist.get_world_size()) / cnt.clamp(min=1.0)
+        if self.native:
+            out = self._forward_native(model_outputs, ground_truth, rgb_gt, train_progress, weights, bool(phase1), feat_on, inv_counts)
+            if out is not None:
+                return {'loss': out[0], 'rgb_loss': out[1], 'eikonal_loss': out[2], 'depth_loss': out[3], 'feat_loss': out[4], 'surf_loss': out[5]}
+        # masks -> hit mask, per-view row ranges of diff_surf_pts, number of BCE positives: one launch (csrc/loss_kernels.hip::k_loss_prep)
+        n_views = ground_truth['feat'].size()[0] if 'feat' in ground_truth else 1
+        hit_mask, view_start, n_pos = ops.loss_prep(network_object_mask, object_mask, model_outputs['object_mask_true'], n_views)
+        feat_pp = None
+        pts = model_outputs['diff_surf_pts']
+        if feat_on and pts.shape[0] > 0:
+            feat_pp = Fn.feat_corr_terms(pts, view_start, ground_truth['feat'], ground_truth['feat_src'], ground_truth['cam'],
+                                         ground_truth['src_cams'], ground_truth['size'], ground_truth['center'])
+        dist_r, dweight = self._carve(model_outputs['eikonal_points_hom'], ground_truth['depths'], ground_truth['depth_cams'],
+                                      ground_truth['size'], ground_truth['center'], train_progress)
         out = Fn.loss_terms(model_outputs['rgb_values'], model_outputs['grad_theta'], model_outputs['eikonal_output'],
                             model_outputs['surf_indicator_output'], feat_pp, rgb_gt, hit_mask, dist_r, dweight,
                             n_pos, weights, bool(phase1), feat_on, inv_counts)
         return {'loss': out[0], 'rgb_loss': out[1], 'eikonal_loss': out[2], 'depth_loss': out[3], 'feat_loss': out[4], 'surf_loss': out[5]}
+
+    def _forward_native(self, mo, gt, rgb_gt, train_progress, weights, surf_on, feat_on, inv_counts):
+        """The whole forward as ONE C call (mvsdf_loss_forward: mask bookkeeping, feature consistency, depth carving with the in-place
+        world rescale of eikonal_points_hom, every term and its unit gradient) behind one autograd node whose backward is one launch.
+        -> the six scalars, or None when an input is not a plain contiguous fp32 / mask tensor on the GPU (the generic route takes over)."""
+        rgb, gth, eo, sf, pts, hom = (mo['rgb_values'], mo['grad_theta'], mo['eikonal_output'], mo['surf_indicator_output'], mo['diff_surf_pts'],
+                                      mo['eikonal_points_hom'])
+        f32 = lambda t: t is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        depths, dcams = gt['depths'], gt['depth_cams']
+        if not (all(f32(t) for t in (rgb, gth, eo, sf, pts, hom, rgb_gt, depths, dcams, gt['size'], gt['center'])) and hom.dim() == 4 and hom.shape[2:] == (4, 1)):
+            return None
+        masks = []
+        for m in (mo['network_object_mask'], mo['object_mask'], mo['object_mask_true']):
+            m = m.reshape(-1)
+            if not (m.is_cuda and m.dtype in (torch.bool, torch.uint8) and m.is_contiguous()):
+                return None
+            masks.append(m)
+        R = masks[0].numel()
+        a = NS.LossArgs()
+        keep = [rgb_gt, depths, dcams, gt['size'], gt['center'], inv_counts] + masks
+        a.R, a.N, a.n_grad, a.n_depth, a.n_surf = R, pts.shape[0], gth.shape[0], eo.numel(), sf.numel()
+        a.net_mask, a.obj_mask, a.true_mask = masks[0].data_ptr(), masks[1].data_ptr(), masks[2].data_ptr()
+        a.rgb, a.rgb_gt = rgb.data_ptr(), rgb_gt.data_ptr()
+        a.grad_theta, a.eik_out, a.surf, a.diff_pts = gth.data_ptr(), eo.data_ptr(), sf.data_ptr(), pts.data_ptr()
+        a.points_hom = hom.data_ptr()                             # rescaled to world coordinates in place: the side effect of loss.py:38,42
+        if hom.numel() != 4 * eo.numel() or rgb.shape[0] != R or rgb_gt.numel() != 3 * R:
+            return None
+        a.feat_on, a.surf_on = int(feat_on), int(surf_on)
+        a.B = 1
+        if feat_on:
+            feat, fsrc = gt['feat'], gt['feat_src']
+            if not (feat.is_cuda and fsrc.is_cuda and feat.dtype == torch.float32 and fsrc.dtype == torch.float32 and feat.shape[1] <= 32
+                    and f32(gt['cam']) and f32(gt['src_cams'])):
+                return None
+            a.B, a.C, a.H, a.W = feat.shape
+            a.V = fsrc.shape[1]
+            a.feat, a.feat_src, a.cam, a.src_cams = feat.data_ptr(), fsrc.data_ptr(), gt['cam'].data_ptr(), gt['src_cams'].data_ptr()
+            for i, v in enumerate(feat.stride()):
+                a.feat_strides[i] = v
+            for i, v in enumerate(fsrc.stride()):
+                a.src_strides[i] = v
+            keep += [feat, fsrc, gt['cam'], gt['src_cams']]
+        elif 'feat' in gt:
+            a.B = gt['feat'].size()[0]                            # (the per-view row ranges are computed either way)
+        if R % a.B:
+            return None
+        a.size, a.center = gt['size'].data_ptr(), gt['center'].data_ptr()
+        dB = depths.shape[0]
+        a.depths, a.dB, a.dh, a.dw, a.depth_cams = depths.data_ptr(), dB, depths.shape[-2], depths.shape[-1], dcams.data_ptr()
+        if depths.numel() != dB * a.dh * a.dw or dcams.numel() != dB * 32:
+            return None
+        a.out_thresh_perc, a.far_thresh, a.near_thresh = conf.out_thresh_perc, conf.far_thresh, conf.near_thresh
+        a.far_att, a.near_att = float(conf.far_att(train_progress)), float(conf.near_att(train_progress))
+        a.w_rgb, a.w_eik, a.w_surf, a.w_feat, a.w_depth = [float(w) for w in weights]
+        if inv_counts is not None:
+            inv_counts = inv_counts.float().contiguous()
+            keep.append(inv_counts)
+            a.inv_counts = inv_counts.data_ptr()
+        return NS.loss_forward(a, keep, rgb, gth, eo, sf, pts)

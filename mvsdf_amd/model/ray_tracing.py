@@ -53,6 +53,22 @@ class RayTracing(nn.Module):
         return (self.object_bounding_sphere, self.sdf_threshold, self.line_search_step, self.line_step_iters, iters,
                 self.n_steps, self.n_secant_steps, dist_clip)
 
+    def intervals(self, dev):
+        """torch.linspace(0, 1, n_steps) on the device (ray_tracing.py:206; CPU values like the reference), uploaded once per (n_steps, device)."""
+        key = (self.n_steps, str(dev))
+        if self._intervals is None or self._intervals[0] != key:
+            self._intervals = (key, torch.linspace(0, 1, steps=self.n_steps).to(dev))
+        return self._intervals[1]
+
+    def tiling(self, R):
+        """(row tiles per sphere-tracing workgroup, row tiles per chunk of the sample-row kernels) for R rays.  Rays per sphere-tracing
+        workgroup = 8 * mt: one workgroup per CU (256 of them) while the batch allows it -- the kernel is a chain of dependent evaluations, so
+        fewer, fuller workgroups beat two contending ones per CU (4096 rays: 4.17 -> 3.97 ms per step with mt = 2); 4 tiles once the chip is
+        over-subscribed anyway (finer compaction of the rays still active; +6 % at 8k-32k rays)."""
+        mt = self.mt or int(os.environ.get('MVSDF_MT', '0')) or (1 if R <= 2048 else (2 if R <= 4096 else 4))
+        mt_samples = self.mt_samples or int(os.environ.get('MVSDF_MT_SAMPLES', '2'))
+        return mt, mt_samples
+
     def forward(self, sdf, cam_loc, object_mask, ray_directions, minsdf_steps=None, mask_ready=None, defer_minsdf=None):
         """-> (points[R,3], network_object_mask[R] bool, dists[R]).
         minsdf_steps: the n_steps uniform draws of minimal_sdf_points (ray_tracing.py:287); drawn here from torch's CPU
@@ -62,10 +78,7 @@ class RayTracing(nn.Module):
         defer_minsdf: see ops.trace (IDRNetwork.lazy_unused_outputs)."""
         net = getattr(sdf, 'native_net', None)
         dev = ray_directions.device
-        key = (self.n_steps, str(dev))
-        if self._intervals is None or self._intervals[0] != key:               # constant per (n_steps, device): uploaded once
-            self._intervals = (key, torch.linspace(0, 1, steps=self.n_steps).to(dev))   # ray_tracing.py:206 (CPU values, like the reference)
-        intervals = self._intervals[1]
+        intervals = self.intervals(dev)
         if self.training and minsdf_steps is None:
             minsdf_steps = self._draw((self.n_steps,), 0.0, 1.0, dev)           # CPU generator, pinned staging, async copy
         elif minsdf_steps is not None:
@@ -79,11 +92,7 @@ class RayTracing(nn.Module):
                 mask_ready(mask)
             return pts, mask, dists
         R = ray_directions.shape[0] * ray_directions.shape[1]
-        # rays per sphere-tracing workgroup = 8 * mt: one workgroup per CU (256 of them) while the batch allows it -- the kernel is a chain
-        # of dependent evaluations, so fewer, fuller workgroups beat two contending ones per CU (4096 rays: 4.17 -> 3.97 ms per step with
-        # mt = 2); 4 tiles once the chip is over-subscribed anyway (finer compaction of the rays still active; +6 % at 8k-32k rays)
-        mt = self.mt or int(os.environ.get('MVSDF_MT', '0')) or (1 if R <= 2048 else (2 if R <= 4096 else 4))
-        mt_samples = self.mt_samples or int(os.environ.get('MVSDF_MT_SAMPLES', '2'))
+        mt, mt_samples = self.tiling(R)
         pts, mask, dists, counters = ops.trace(net, cam_loc, ray_directions, object_mask, self._params(), self.training, intervals,
                                                minsdf_steps, mt=mt, mt_samples=mt_samples, events=self.events,
                                                mask_ready=mask_ready, defer_minsdf=defer_minsdf)

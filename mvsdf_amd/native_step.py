@@ -1,0 +1,360 @@
+"""Python side of the native step driver (csrc/step_driver.hip, include/mvsdf_hip.h "native step driver").
+
+A training step used to be ~45 ctypes calls plus autograd glue issued from Python (1.6 ms of host time).  Here IDRNetwork.forward in training
+mode is ONE C call + the one host wait for the hit counts, `loss.backward()` through it is ONE C call, and IDRLoss.forward / its backward are
+one C call each; the interpreter only wraps the regions of the forward block as tensors and routes them through two autograd nodes.
+
+Memory: one `fwd` block per forward (outputs of the reference's dict + everything the backward reads), allocated from torch's caching
+allocator, so holding on to a step's outputs or running two forwards before a backward behaves like it does with the reference; the backward's
+scratch block is kept per shape."""
+import ctypes as C
+
+import torch
+
+from ._lib import TraceParams, check, lib
+
+STEP_MAX_LAYERS = 24
+
+
+class StepDesc(C.Structure):
+    _fields_ = [('B', C.c_int), ('P', C.c_int), ('n_eik', C.c_int), ('n_ds', C.c_int), ('n_sdf', C.c_int), ('n_render', C.c_int),
+                ('N', C.c_int * STEP_MAX_LAYERS), ('K', C.c_int * STEP_MAX_LAYERS), ('skip_mask', C.c_uint), ('multires', C.c_int),
+                ('view_spec', C.c_int), ('trace_dtype', C.c_int), ('use_object_mask', C.c_int), ('tp', TraceParams), ('mt', C.c_int),
+                ('mt_samples', C.c_int)]
+
+
+class StepParams(C.Structure):
+    _fields_ = [('v', C.c_void_p * STEP_MAX_LAYERS), ('g', C.c_void_p * STEP_MAX_LAYERS), ('b', C.c_void_p * STEP_MAX_LAYERS)]
+
+
+class StepInputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('uv', 'pose', 'intrinsics', 'object_mask', 'object_mask_true', 'intervals', 'minsdf_steps', 'eik_points',
+                                          'ds_on', 'ds_jit', 'ds_counts')]
+
+
+class StepLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ('fwd_bytes', 'bwd_bytes', 'ray_dirs', 'cam_loc', 'points', 'mask', 'dists', 'counters', 'object_mask_out',
+                                          'rgb_values', 'sdf_output', 'diff_pts', 'eik_out', 'points_hom', 'grad_theta', 'surf', 'perm', 'dflat',
+                                          'dflat_floats')]
+
+
+class LossArgs(C.Structure):
+    _fields_ = [('R', C.c_int), ('B', C.c_int), ('N', C.c_int), ('n_grad', C.c_int), ('n_depth', C.c_int), ('n_surf', C.c_int),
+                ('net_mask', C.c_void_p), ('obj_mask', C.c_void_p), ('true_mask', C.c_void_p), ('rgb', C.c_void_p), ('rgb_gt', C.c_void_p),
+                ('grad_theta', C.c_void_p), ('eik_out', C.c_void_p), ('surf', C.c_void_p), ('diff_pts', C.c_void_p), ('points_hom', C.c_void_p),
+                ('feat_on', C.c_int), ('surf_on', C.c_int), ('V', C.c_int), ('C', C.c_int), ('H', C.c_int), ('W', C.c_int),
+                ('feat', C.c_void_p), ('feat_strides', C.c_longlong * 4), ('feat_src', C.c_void_p), ('src_strides', C.c_longlong * 5),
+                ('cam', C.c_void_p), ('src_cams', C.c_void_p), ('size', C.c_void_p), ('center', C.c_void_p),
+                ('depths', C.c_void_p), ('dB', C.c_int), ('dh', C.c_int), ('dw', C.c_int), ('depth_cams', C.c_void_p),
+                ('out_thresh_perc', C.c_float), ('far_thresh', C.c_float), ('far_att', C.c_float), ('near_thresh', C.c_float), ('near_att', C.c_float),
+                ('w_rgb', C.c_float), ('w_eik', C.c_float), ('w_surf', C.c_float), ('w_feat', C.c_float), ('w_depth', C.c_float),
+                ('inv_counts', C.c_void_p)]
+
+
+class LossLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ('bytes', 'out', 'hit', 'view_start', 'n_pos', 'loss_pp', 'dpts', 'dist_r', 'weight', 'd_rgb', 'd_grad',
+                                          'd_eo', 'd_sf')]
+
+
+_bound = False
+
+
+def _bind():
+    global _bound
+    L = lib()
+    if not _bound:
+        L.mvsdf_step_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mvsdf_step_destroy.argtypes = [C.c_void_p]
+        L.mvsdf_step_destroy.restype = None
+        L.mvsdf_step_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.mvsdf_step_wait_counts.argtypes = [C.c_void_p, C.c_void_p]
+        L.mvsdf_step_backward.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 10 + [C.c_int, C.c_void_p]
+        L.mvsdf_step_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.mvsdf_step_trace_times.argtypes = [C.c_void_p, C.c_void_p]
+        L.mvsdf_loss_layout.argtypes = [C.c_void_p, C.c_void_p]
+        L.mvsdf_loss_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mvsdf_loss_backward.argtypes = [C.c_void_p] * 9
+        _bound = True
+    return L
+
+
+def _region(block, off, nbytes, dtype, shape):
+    """A typed view of `nbytes` bytes of a uint8 block at byte offset `off` (offsets are multiples of 256)."""
+    return block[off:off + nbytes].view(dtype).view(shape)
+
+
+def _strides(shape):
+    st, acc = [], 1
+    for n in reversed(shape):
+        st.append(acc)
+        acc *= max(int(n), 1)
+    return tuple(reversed(st))
+
+
+class Block:
+    """A forward block with its float32 alias: regions are cut with ONE as_strided each (the three-op slice / view / view of `_region`
+    costs ~3 us per tensor, a dozen of them per step)."""
+    __slots__ = ('u8', 'f32')
+
+    def __init__(self, nbytes, device):
+        self.u8 = torch.empty((nbytes + 3) // 4 * 4, dtype=torch.uint8, device=device)
+        self.f32 = self.u8.view(torch.float32)
+
+    def f(self, off, shape):
+        return torch.as_strided(self.f32, shape, _strides(shape), off >> 2)
+
+    def b(self, off, shape):
+        return torch.as_strided(self.u8, shape, _strides(shape), off)
+
+    def data_ptr(self):
+        return self.u8.data_ptr()
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class NativeStep:
+    """Host-side state of one step shape (mvsdf_step_create): layout, pinned count buffer, events; plus the cached ctypes views of the
+    parameters and the backward's scratch block."""
+
+    def __init__(self, desc, device):
+        L = _bind()
+        self.desc, self.device = desc, device
+        self.layout = StepLayout()
+        h = C.c_void_p()
+        check(L.mvsdf_step_create(C.byref(desc), C.byref(self.layout), C.byref(h)), 'mvsdf_step_create')
+        self._h = h
+        self.R, self.E = desc.B * desc.P, desc.n_eik + 2 * desc.n_ds
+        self.Nout = desc.N[desc.n_sdf - 1]
+        self.nl = desc.n_sdf + desc.n_render
+        self._bwd = None
+        self._prm_key, self._prm = None, None
+        self._grad_key, self._grad_arrays = None, None
+        self._counts = (C.c_longlong * 4)()
+        self.inputs = StepInputs()
+        self.timing = False
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            try:
+                lib().mvsdf_step_destroy(h)
+            except Exception:
+                pass
+
+    # ---- parameters
+    def params(self, vs, gs, bs):
+        """ctypes struct of the raw parameter pointers, rebuilt only when a storage moved."""
+        key = tuple(p.data_ptr() for p in vs) + tuple(0 if p is None else p.data_ptr() for p in gs) + tuple(p.data_ptr() for p in bs)
+        if key != self._prm_key:
+            for p in list(vs) + [g for g in gs if g is not None] + list(bs):
+                assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous(), 'float32 contiguous parameters on the GPU expected'
+            prm = StepParams()
+            for l, (v, g, b) in enumerate(zip(vs, gs, bs)):
+                prm.v[l], prm.g[l], prm.b[l] = v.data_ptr(), (g.data_ptr() if g is not None else None), b.data_ptr()
+            self._prm_key, self._prm = key, prm
+        return self._prm
+
+    def grad_arrays(self, vs, gs, bs):
+        """Pointer arrays of the parameters' .grad buffers (the gradient sink), or None when one is missing / not a plain fp32 buffer."""
+        ps = list(vs) + [g for g in gs if g is not None] + list(bs)
+        if any(p.grad is None for p in ps):
+            return None
+        key = tuple(p.grad.data_ptr() for p in ps)
+        if key != self._grad_key:
+            if not all(p.grad.is_cuda and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in ps):
+                return None
+            n = STEP_MAX_LAYERS
+            dv, dg, db = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+            for l, (v, g, b) in enumerate(zip(vs, gs, bs)):
+                dv[l], dg[l], db[l] = v.grad.data_ptr(), (g.grad.data_ptr() if g is not None else None), b.grad.data_ptr()
+            self._grad_key, self._grad_arrays = key, (dv, dg, db)
+        return self._grad_arrays
+
+    # ---- calls
+    def forward(self, prm, d_mask, e_mask):
+        fwd = Block(self.layout.fwd_bytes, self.device)
+        check(lib().mvsdf_step_forward(self._h, C.byref(prm), C.byref(self.inputs), d_mask, e_mask, fwd.data_ptr(), _stream(self.device)),
+              'mvsdf_step_forward')
+        return fwd
+
+    def wait_counts(self):
+        check(lib().mvsdf_step_wait_counts(self._h, self._counts), 'mvsdf_step_wait_counts')
+        return tuple(self._counts)
+
+    def bwd_block(self):
+        if self._bwd is None:
+            self._bwd = torch.empty(self.layout.bwd_bytes, dtype=torch.uint8, device=self.device)
+        return self._bwd
+
+    def backward(self, prm, N, n_true, d_mask, e_mask, use_geo, ups, fwd, targets, accumulate):
+        p = [None if t is None else C.c_void_p(t.data_ptr()) for t in ups]
+        dv, dg, db = targets
+        check(lib().mvsdf_step_backward(self._h, C.byref(prm), N, n_true, d_mask, e_mask, 1 if use_geo else 0, p[0], p[1], p[2], p[3], p[4],
+                                        fwd.data_ptr(), self.bwd_block().data_ptr(), dv, dg, db, 1 if accumulate else 0, _stream(self.device)),
+              'mvsdf_step_backward')
+
+    def set_timing(self, on):
+        check(lib().mvsdf_step_set_timing(self._h, 1 if on else 0), 'mvsdf_step_set_timing')
+        self.timing = bool(on)
+
+    def trace_times(self):
+        """-> (sphere tracing, sampler rows, secant + min-sdf rows) in ms of the last forward; the stream must have been synchronised."""
+        ms = (C.c_float * 3)()
+        check(lib().mvsdf_step_trace_times(self._h, ms), 'mvsdf_step_trace_times')
+        return tuple(ms)
+
+
+class StepRecord:
+    """What one forward leaves behind for its backward and for the output dict."""
+    __slots__ = ('step', 'fwd', 'prm', 'params', 'N', 'n_true', 'counts', 'd_mask', 'e_mask', 'use_geo', 'n_layers', 'vs', 'gs', 'bs', 'keep', 'done')
+
+
+class _NativeStepFn(torch.autograd.Function):
+    """IDRNetwork.forward (training) as one autograd node over the raw parameters: forward = mvsdf_step_forward + the one host wait,
+    backward = mvsdf_step_backward (rendering-net backward, SampleNetwork's scalar, the first/second-order SDF backward, weight gradients,
+    weight-norm fold backward).  Inside functional.grad_sink() with FlatAdam-style persistent .grad buffers the gradients are ADDED
+    into those buffers by the last launch and autograd sees None."""
+
+    @staticmethod
+    def forward(ctx, rec, *params):
+        st = rec.step
+        rec.fwd = st.forward(rec.prm, rec.d_mask, rec.e_mask)
+        counts = st.wait_counts()                                 # the one host wait of the training forward
+        rec.counts = counts
+        N, n_true = int(counts[0]), int(counts[1])
+        rec.N, rec.n_true = N, n_true
+        L, d, R, E, f = st.layout, st.desc, st.R, st.E, rec.fwd
+        sizes = (N, d.n_eik, d.n_ds, d.n_ds)
+        nd = sum(c for g, c in enumerate(sizes) if rec.d_mask >> g & 1)
+        ne = sum(c for g, c in enumerate(sizes) if rec.e_mask >> g & 1)
+        diff = f.f(L.diff_pts, (N, 3))
+        rgb = f.f(L.rgb_values, (R, 3))
+        gth = f.f(L.grad_theta, (ne, 3))
+        eo = f.f(L.eik_out, (1, nd))
+        surf = f.f(L.surf, (n_true + d.n_eik,))
+        rec.keep = (nd, ne)
+        ctx.rec = rec
+        return diff, rgb, gth, eo, surf
+
+    @staticmethod
+    def backward(ctx, d_diff, d_rgb, d_gth, d_eo, d_si):
+        from .functional import grad_sink
+        rec = ctx.rec
+        if getattr(rec, 'done', False):
+            raise RuntimeError('the backward of this step already ran through FlatAdam.backward (its buffers are released after one backward, '
+                               'like autograd\'s)')
+        st = rec.step
+        ups = [None if t is None else (t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()) for t in (d_diff, d_rgb, d_gth, d_eo, d_si)]
+        vs, gs, bs = rec.vs, rec.gs, rec.bs
+        n = len(vs)
+        sink = None
+        if grad_sink.depth > 0 and all(getattr(p, '_mv_grad_sink', False) and p.requires_grad for p in rec.params if p is not None):
+            sink = st.grad_arrays(vs, gs, bs)
+        if sink is not None:
+            st.backward(rec.prm, rec.N, rec.n_true, rec.d_mask, rec.e_mask, rec.use_geo, ups, rec.fwd, sink, True)
+            return (None,) * (1 + 3 * n)
+        # ordinary autograd route: fresh gradient tensors for every parameter (one allocation, carved into views)
+        sizes = [v.numel() for v in vs] + [0 if g is None else g.numel() for g in gs] + [b.numel() for b in bs]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=st.device)
+        parts = list(torch.split(flat, sizes))
+        dvs = [t.view_as(v) for t, v in zip(parts[:n], vs)]
+        dgs = [None if g is None else t.view_as(g) for t, g in zip(parts[n:2 * n], gs)]
+        dbs = [t.view_as(b) for t, b in zip(parts[2 * n:], bs)]
+        m = STEP_MAX_LAYERS
+        dv, dg, db = (C.c_void_p * m)(), (C.c_void_p * m)(), (C.c_void_p * m)()
+        for l in range(n):
+            dv[l], dg[l], db[l] = dvs[l].data_ptr(), (dgs[l].data_ptr() if dgs[l] is not None else None), dbs[l].data_ptr()
+        st.backward(rec.prm, rec.N, rec.n_true, rec.d_mask, rec.e_mask, rec.use_geo, ups, rec.fwd, (dv, dg, db), False)
+        return (None,) + tuple(dvs) + tuple(dgs) + tuple(dbs)
+
+
+def run_step(rec):
+    """-> (diff_surf_pts, rgb_values, grad_theta, eikonal_output, surf_indicator_output) linked to autograd; rec.fwd / N / n_true set."""
+    return _NativeStepFn.apply(rec, *rec.params)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+class _NativeLossFn(torch.autograd.Function):
+    """IDRLoss.forward (loss.py:176-219) as one node: forward = mvsdf_loss_forward (mask bookkeeping, feature consistency, depth carving,
+    every term + its unit gradient: 4 launches), backward = mvsdf_loss_backward (one launch)."""
+
+    @staticmethod
+    def forward(ctx, args, keep, rgb, grad_theta, eik_out, surf, diff_pts):
+        L = _bind()
+        lo = LossLayout()
+        check(L.mvsdf_loss_layout(C.byref(args), C.byref(lo)), 'mvsdf_loss_layout')
+        dev = rgb.device
+        blk = torch.empty(lo.bytes, dtype=torch.uint8, device=dev)
+        check(L.mvsdf_loss_forward(C.byref(args), blk.data_ptr(), _stream(dev)), 'mvsdf_loss_forward')
+        ctx.args, ctx.blk, ctx.keep = args, blk, keep
+        ctx.ins = (rgb, grad_theta, eik_out, surf, diff_pts)     # (for direct_backward: which node produced them)
+        ctx.shapes = (rgb.shape, grad_theta.shape if grad_theta is not None else None, eik_out.shape, surf.shape if surf is not None else None,
+                      diff_pts.shape)
+        ctx.set_materialize_grads(False)                         # unused scalars arrive as None, not as zero tensors
+        out = _region(blk, lo.out, 24, torch.float32, (6,))
+        return tuple(out.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        a, dev = ctx.args, ctx.blk.device
+        garr = (C.c_void_p * 6)()
+        keep = []
+        for k, g in enumerate(gs):
+            if g is not None:
+                g = g.reshape(1).float().contiguous()
+                keep.append(g)
+                garr[k] = g.data_ptr()
+        f = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+        feat = bool(a.feat_on) and a.N > 0
+        sizes = [a.R * 3, a.n_grad * 3, a.n_depth, a.n_surf if a.surf_on else 0, a.N * 3 if feat else 0]
+        flat = f(sum(sizes))
+        g_rgb, g_grad, g_eo, g_sf, g_diff = torch.split(flat, sizes)
+        p = lambda t, on=True: C.c_void_p(t.data_ptr()) if (on and t.numel() > 0) else None
+        check(lib().mvsdf_loss_backward(C.byref(a), ctx.blk.data_ptr(), garr, p(g_rgb), p(g_grad), p(g_eo), p(g_sf, bool(a.surf_on)),
+                                        p(g_diff, feat), _stream(dev)), 'mvsdf_loss_backward')
+        sh = ctx.shapes
+        return (None, None, g_rgb.view(sh[0]), g_grad.view(sh[1]) if (sh[1] is not None and a.n_grad > 0) else None, g_eo.view(sh[2]),
+                g_sf.view(sh[3]) if (sh[3] is not None and a.surf_on and a.n_surf > 0) else None, g_diff.view(sh[4]) if feat else None)
+
+
+def loss_forward(args, keep, rgb, grad_theta, eik_out, surf, diff_pts):
+    return _NativeLossFn.apply(args, keep, rgb, grad_theta, eik_out, surf, diff_pts)
+
+
+_one = {}
+
+
+def direct_backward(loss):
+    """`loss.backward()` without the autograd engine, for the graph the native step builds: loss = output k of a _NativeLossFn node whose five
+    inputs are exactly the five outputs of ONE _NativeStepFn node whose parameters all carry a gradient sink (optim.FlatAdam).  The two
+    backward functions are then called in line on the calling thread (the engine's hand-over to its device thread and back costs ~0.2 ms per
+    step, more than both C calls together).  -> True when it ran; False when the graph is anything else (the caller falls back to
+    loss.backward(): same numbers)."""
+    from .functional import grad_sink
+    node = loss.grad_fn
+    if node is None or getattr(node, 'ins', None) is None or not hasattr(node, 'args') or grad_sink.depth <= 0:
+        return False
+    rgb, gth, eo, sf, pts = node.ins
+    snode = rgb.grad_fn
+    rec = getattr(snode, 'rec', None)
+    if rec is None or getattr(rec, 'done', False):
+        return False
+    for k, t in enumerate((pts, rgb, gth, eo, sf)):              # the step node's outputs in its order, nothing else in between
+        if t is None or t.grad_fn is not snode or t.output_nr != k:
+            return False
+    if not all(getattr(p, '_mv_grad_sink', False) and p.requires_grad for p in rec.params if p is not None):
+        return False
+    if rec.step.grad_arrays(rec.vs, rec.gs, rec.bs) is None:
+        return False
+    dev = loss.device
+    one = _one.get(dev)
+    if one is None:
+        one = _one[dev] = torch.ones((), dtype=torch.float32, device=dev)
+    gs = [None] * 6
+    gs[loss.output_nr] = one
+    grads = _NativeLossFn.backward(node, *gs)
+    _NativeStepFn.backward(snode, grads[6], grads[2], grads[3], grads[4], grads[5])
+    rec.done = True
+    return True

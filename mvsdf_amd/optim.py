@@ -72,8 +72,10 @@ class FlatAdam(torch.optim.Optimizer):
         """loss.backward() with the direct gradient sink on (functional.grad_sink): the weight_norm-fold backward adds dv / dg / db of
         both networks into the flat gradient buffer in ONE launch instead of handing ~40 tensors to autograd's AccumulateGrad."""
         from .functional import grad_sink
+        from .native_step import direct_backward
         with grad_sink():
-            loss.backward()
+            if not direct_backward(loss):                        # the native step's own two-node graph: run in line, no engine hand-over
+                loss.backward()
 
     def _sync_grads(self):
         """Every p.grad must still be its view of flat_g when the flat kernels read it.  `model.zero_grad()` (set_to_none=True by default)
@@ -109,19 +111,34 @@ class FlatAdam(torch.optim.Optimizer):
         elif scale != 1.0:
             self.flat_g.mul_(scale)
 
-    @torch.no_grad()
     def step(self, closure=None, grad_cap=None):
-        """grad-norm + optional clip_grad_norm_(grad_cap) + Adam in two launches.  `norm_and_coef` holds the norm afterwards."""
+        """grad-norm + optional clip_grad_norm_(grad_cap) + Adam in two launches.  `norm_and_coef` holds the norm afterwards.
+        torch.optim.Optimizer's step pre / post hooks run if any are registered (the profiler range torch wraps around step() is skipped:
+        it costs more host time than the two launches)."""
         assert closure is None
+        from torch.optim.optimizer import _global_optimizer_post_hooks, _global_optimizer_pre_hooks
+        hooks = bool(self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _global_optimizer_pre_hooks or _global_optimizer_post_hooks)
+        args, kwargs = (self,), {'closure': closure, 'grad_cap': grad_cap}
+        if hooks:
+            for h in list(_global_optimizer_pre_hooks.values()) + list(self._optimizer_step_pre_hooks.values()):
+                r = h(self, args, kwargs)
+                if r is not None:
+                    args, kwargs = r
+                    grad_cap = kwargs.get('grad_cap', grad_cap)
         g = self.param_groups[0]
         self._sync_grads()
         self._t += 1
-        check(lib().mvsdf_adam_step_scaled(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
-                                           self.flat_p.numel(), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+        fp = self.flat_p
+        check(lib().mvsdf_adam_step_scaled(fp.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                                           fp.numel(), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
                                            self._t, float(grad_cap) if grad_cap else 0.0, float(self._grad_scale),
                                            self.norm_and_coef.data_ptr(), self._ws.data_ptr(),
-                                           C.c_void_p(torch.cuda.current_stream(self.flat_p.device).cuda_stream)), 'mvsdf_adam_step_scaled')
+                                           C.c_void_p(torch.cuda.current_stream(fp.device).cuda_stream)), 'mvsdf_adam_step_scaled')
         self._grad_scale = 1.0
+        if hooks:
+            for h in list(self._optimizer_step_post_hooks.values()) + list(_global_optimizer_post_hooks.values()):
+                h(self, args, kwargs)
+    step.hooked = True                                       # torch.optim.Optimizer would otherwise wrap it in its profiler hook
 
     def grad_norm(self):
         return self.norm_and_coef[0]

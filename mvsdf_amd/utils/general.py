@@ -53,3 +53,27 @@ class PinnedUniform:
             slot[1] = torch.cuda.Event()
             slot[1].record()
         return out
+
+    def pair(self, shape_a, lo_a, hi_a, shape_b, lo_b, hi_b, device):
+        """Two consecutive draws (a, then b: the same values as two separate calls) staged in ONE pinned buffer and delivered by ONE async copy."""
+        shape_a, shape_b = tuple(shape_a), tuple(shape_b)
+        na, nb = 1, 1
+        for v in shape_a:
+            na *= v
+        for v in shape_b:
+            nb *= v
+        key = ('pair', shape_a, shape_b, self._k & 1)
+        self._k += 1
+        slot = self._bufs.get(key)
+        if slot is None:
+            slot = self._bufs[key] = [torch.empty(na + nb).pin_memory(), None]
+        buf, ev = slot
+        if ev is not None:
+            ev.synchronize()
+        buf[:na].uniform_(lo_a, hi_a)
+        buf[na:].uniform_(lo_b, hi_b)
+        out = buf.to(device, non_blocking=True)
+        if out.is_cuda:
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+        return out[:na].view(shape_a), out[na:].view(shape_b)

@@ -36,7 +36,7 @@ model = model.to(dev).train().set_trace_dtype(sys.argv[1] if len(sys.argv) > 1 e
 loss_fn = IDRLoss(); opt = FlatAdam(model.parameters(), lr=0.0)
 P_, V_ = bench.WORKLOADS['c2']; inp, gt = bench.make_inputs(dev, 0, 1, P_, V_)
 def step():
-    opt.zero_grad(); out = model(inp, bench.TP); lo = loss_fn(out, dict(gt), bench.TP, bench.B); opt.backward(lo['loss']); opt.all_reduce_mean(); opt.step(grad_cap=2.0)
+    opt.zero_grad(); out = model(inp, bench.TP); lo = loss_fn(out, dict(gt), bench.TP, bench.B); opt.backward(lo['loss']); opt.all_reduce_mean(defer_scale=True); opt.step(grad_cap=2.0)
 for _ in range(10): step()
 torch.cuda.synchronize(); acc.clear(); cnt.clear()
 n = 50; t0 = time.perf_counter()

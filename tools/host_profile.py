@@ -16,7 +16,7 @@ loss_fn = IDRLoss(); opt = FlatAdam(model.parameters(), lr=0.0)
 P_, V_ = bench.WORKLOADS['c2']
 inp, gt = bench.make_inputs(dev, 0, 1, P_, V_)
 def step():
-    opt.zero_grad(); out = model(inp, bench.TP); lo = loss_fn(out, dict(gt), bench.TP, bench.B); opt.backward(lo['loss']); opt.all_reduce_mean(); opt.step(grad_cap=2.0)
+    opt.zero_grad(); out = model(inp, bench.TP); lo = loss_fn(out, dict(gt), bench.TP, bench.B); opt.backward(lo['loss']); opt.all_reduce_mean(defer_scale=True); opt.step(grad_cap=2.0)
 for _ in range(5): step()
 torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()

@@ -26,20 +26,26 @@ def timed_item(self):
 _evs = torch.cuda.Event.synchronize
 def timed_evs(self):
     t0 = time.perf_counter(); r = _evs(self); acc['  (count-event wait)'] = acc.get('  (count-event wait)', 0.0) + time.perf_counter() - t0; return r
+from mvsdf_amd import native_step as NS
+_wc = NS.NativeStep.wait_counts
+def timed_wc(self):
+    t0 = time.perf_counter(); r = _wc(self); acc['  (count-event wait)'] = acc.get('  (count-event wait)', 0.0) + time.perf_counter() - t0; return r
 def step():
     t = time.perf_counter()
     opt.zero_grad(); t = tick('zero', t)
     out = model(inp, bench.TP); t = tick('forward (incl. item wait)', t)
     lo = loss_fn(out, dict(gt), bench.TP, bench.B); t = tick('loss', t)
     opt.backward(lo['loss']); t = tick('backward', t)
-    opt.all_reduce_mean(); opt.step(grad_cap=2.0); t = tick('allreduce+clip+adam', t)
+    opt.all_reduce_mean(defer_scale=True); opt.step(grad_cap=2.0); t = tick('allreduce+clip+adam', t)
 for _ in range(10): step()
 torch.cuda.synchronize(); acc.clear()
 torch.Tensor.item = timed_item
 torch.cuda.Event.synchronize = timed_evs
+NS.NativeStep.wait_counts = timed_wc
 n = 50
 t0 = time.perf_counter()
 for _ in range(n): step()
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 for k, v in acc.items(): print(f'{k:32s} {v / n * 1e3:7.3f} ms')
-print(f'host loop {(t1 - t0) / n * 1e3:.3f} ms/step, final drain {(t2 - t1) * 1e3:.3f} ms')
+wait = sum(v for k, v in acc.items() if k.startswith('  ('))
+print(f'host loop {(t1 - t0) / n * 1e3:.3f} ms/step, of which waiting for the GPU {wait / n * 1e3:.3f} ms -> host work {((t1 - t0) - wait) / n * 1e3:.3f} ms/step; final drain {(t2 - t1) * 1e3:.3f} ms')
