@@ -527,7 +527,12 @@ class IDRNetwork(nn.Module):
         dsurf = self._dsurf_samples(input, n_ds, self.object_bounding_sphere) if use_ds else None
         bb = self.object_bounding_sphere
         n_eik = R // 2
-        minsdf_steps, eik = self._draw.pair((rt.n_steps,), 0.0, 1.0, (n_eik, 3), -bb, bb, dev)
+        if isinstance(self._draw, PinnedUniform) and isinstance(rt._draw, PinnedUniform):
+            minsdf_steps, eik = self._draw.pair((rt.n_steps,), 0.0, 1.0, (n_eik, 3), -bb, bb, dev)       # one staging buffer, one async copy
+        else:                                                    # (someone replaced a draw hook: the two separate draws of the Python route)
+            minsdf_steps = rt._draw((rt.n_steps,), 0.0, 1.0, dev)
+            eik = self._draw((n_eik, 3), -bb, bb, dev)
+            minsdf_steps, eik = minsdf_steps.float().contiguous(), eik.float().contiguous()
         true_u8 = object_mask_true if object_mask_true.dtype == torch.uint8 else (
             object_mask_true.view(torch.uint8) if object_mask_true.dtype == torch.bool else object_mask_true.to(torch.uint8))
         if not true_u8.is_contiguous():
