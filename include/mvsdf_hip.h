@@ -409,7 +409,7 @@ typedef struct {
 typedef struct { size_t bytes, out, hit, view_start, n_pos, loss_pp, dpts, dist_r, weight, d_rgb, d_grad, d_eo, d_sf; } MvsdfLossLayout;
 /* layout of the block both calls work in (out: float[6] = loss, rgb, eikonal, depth, feat, surf) */
 int mvsdf_loss_layout(const MvsdfLossArgs* a, MvsdfLossLayout* lo);
-/* mask bookkeeping + feature consistency + depth carving + all terms and their unit gradients: 4 launches */
+/* mask bookkeeping || depth carving, feature consistency, all terms and their unit gradients: 3 launches */
 int mvsdf_loss_forward(const MvsdfLossArgs* a, void* blk, void* stream);
 /* g: HOST array of 6 device pointers (upstream of the six scalars, NULL = none) -> gradients of rgb_values [R][3], grad_theta [n_grad][3],
  * eikonal_output [n_depth], surf_indicator_output [n_surf], diff_surf_pts [N][3] (any target may be NULL): one launch */

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include "layer_kernels.h"
 #include "capi_util.h"
+#include "step_internal.h"
 
 // ------------------------------------------------------------------------------------------------ small kernels
 // H0[row][0..d0) = PE(x[row]); H0[row][d0..ld) = 0       (embedder.py:10-36)
@@ -195,26 +196,52 @@ static SdfBwdLayout sdf_bwd_layout(const MvNet& net, int Mb) {
     return o;
 }
 
-// all layers' weight / bias gradients: one k_wgrad_net launch + one k_reduce_net launch.  a.L[*].{P1,Q1,P2,Q2,ld*,No,Ki} filled by the caller.
-static hipError_t launch_wgrad_net(WgradNetArgs& a, hipStream_t s) {
-    int blk = 0;
+// ---- weight / bias gradients: k_wgrad_net (+ folded column sums) and k_reduce_net over a list of layers ----
+// wgrad_net_layers: per-layer bookkeeping of one network's layers [l0, l0 + n) inside `a` (No / Ki / operands filled by the caller): M rows in
+// 128-row chunks, slabs carved from `slab` / `bslab`, reduction targets carved from dW_cat / db_cat.
+static void wgrad_net_layers(WgradNetArgs& a, int l0, int n, int M, int nchunks, float* slab, float* bslab, float* dW_cat, float* db_cat) {
     size_t so = 0, bo = 0, wo = 0, b2 = 0;
+    for (int l = l0; l < l0 + n; ++l) {
+        WgradLayer& L = a.L[l];
+        L.M = M; L.nchunks = nchunks; L.ch0 = 0; L.nch = nchunks;
+        L.nbx = (L.Ki + 63) / 64; L.nby = (L.No + 63) / 64;
+        L.slab = slab + so; so += (size_t)nchunks * L.No * L.Ki;
+        L.bslab = bslab + bo; bo += (size_t)nchunks * L.No;
+        L.dW = dW_cat + wo; wo += (size_t)L.No * L.Ki;
+        L.db = db_cat + b2; b2 += L.No;
+    }
+}
+// one k_wgrad_net launch over the chunk ranges [ch0, ch0 + nch) of the layers (+ the column-sum workgroups when a.colX is set)
+static hipError_t wgrad_launch(WgradNetArgs& a, hipStream_t s) {
+    int blk = 0;
     for (int l = 0; l < a.n_layers; ++l) {
         WgradLayer& L = a.L[l];
-        L.nbx = (L.Ki + 63) / 64; L.nby = (L.No + 63) / 64;
-        L.blk0 = blk; blk += L.nbx * L.nby * a.nchunks;
-        L.slab_off = (unsigned)so; so += (size_t)a.nchunks * L.No * L.Ki;
-        L.bslab_off = (unsigned)bo; bo += (size_t)a.nchunks * L.No;
+        L.blk0 = blk; blk += L.nbx * L.nby * L.nch;
+    }
+    if (a.colX) { a.col_blk0 = blk; blk += ((a.col_n + 63) / 64) * a.col_nch; }
+    if (blk > 0) hipLaunchKernelGGL(k_wgrad_net, dim3(blk), dim3(MV_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+static hipError_t wgrad_reduce(WgradNetArgs& a, hipStream_t s) {
+    size_t wo = 0, b2 = 0;
+    for (int l = 0; l < a.n_layers; ++l) {
+        WgradLayer& L = a.L[l];
         L.woff = (unsigned)wo; wo += (size_t)L.No * L.Ki;
         L.boff = (unsigned)b2; b2 += L.No;
     }
-    if (so >= 0xffffffffull) return hipErrorInvalidValue;
+    if (wo + b2 >= 0xffffffffull) return hipErrorInvalidValue;
     a.wtotal = (unsigned)wo; a.btotal = (unsigned)b2;
-    hipLaunchKernelGGL(k_wgrad_net, dim3(blk), dim3(MV_THREADS), 0, s, a);
     const unsigned total = a.wtotal + a.btotal;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(k_reduce_net, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
+}
+static hipError_t launch_wgrad_net(WgradNetArgs& a, hipStream_t s) {
+    hipError_t e = wgrad_launch(a, s);
+    return e != hipSuccess ? e : wgrad_reduce(a, s);
+}
+static void wgrad_colsum(WgradNetArgs& a, const float* X, int ld, int M, int n, int layer, int nchunks, float* colslab) {
+    a.colX = X; a.col_ld = ld; a.col_M = M; a.col_n = n; a.col_layer = layer; a.col_nchunks = nchunks; a.col_ch0 = 0; a.col_nch = nchunks; a.colslab = colslab;
 }
 
 // the skip layer of a network with at most one (-1: none); -2: several (only the fused chain kernels handle those)
@@ -486,7 +513,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
     if (dW_cat) {                                                                  // dW_cat == NULL: input adjoint only
         WgradNetArgs wa;
         memset(&wa, 0, sizeof(wa));
-        wa.n_layers = nl; wa.M = Mb; wa.chunk = bl.chunk; wa.nchunks = bl.nchunks;
+        wa.n_layers = nl; wa.chunk = bl.chunk;
         for (int l = 0; l < nl; ++l) {
             WgradLayer& L = wa.L[l];
             const bool last = (l == nl - 1);
@@ -495,12 +522,10 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
             L.Q1 = Aof(l); L.ldq1 = ldA(l);
             if (dn && !last) { L.P2 = Sof(l); L.ldp2 = L.No; L.Q2 = ws + bl.VB[l]; L.ldq2 = ldA(l); }
         }
-        wa.slab = ws + bl.slabA; wa.bslab = ws + bl.bslab;
-        wa.dW = dW_cat; wa.db = db_cat;
+        wgrad_net_layers(wa, 0, nl, Mb, bl.nchunks, ws + bl.slabA, ws + bl.bslab, dW_cat, db_cat);
         if (dn) {                                                                  // W_last[0, :] += sum_rows ubar_last   (E.1 end)
             const int Ki = net.L[nl - 1].K;
-            hipLaunchKernelGGL(k_colsum, dim3((Ki + 63) / 64, bl.nchunks), dim3(256), 0, s, ws + bl.VB[nl - 1], Ki, Mb, Ki, bl.chunk, ws + bl.slabB);
-            wa.colslab = ws + bl.slabB; wa.col_n = Ki;
+            wgrad_colsum(wa, ws + bl.VB[nl - 1], Ki, Mb, Ki, nl - 1, bl.nchunks, ws + bl.slabB);
         }
         MV_TRY(launch_wgrad_net(wa, s));
     }
@@ -569,6 +594,51 @@ int mvsdf_sdf_backward_pair(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M
     return mv_check(hipGetLastError(), "mvsdf_sdf_backward_pair");
 }
 
+}  // extern "C"
+
+// delta pass of the training step's SDF backward: extra upstream fbar[MbD] on output column 0 of rows [row0D, row0D + MbD); its first-order zbar_l
+// are ADDED to the adjoints pass A stored in `ws` (linearity)
+static int sdf_delta_pass(const MvNet& net, const MvNet& netT, const SdfLayout& lo, const SdfBwdLayout& bl, const float* ctx, float* ws, int row0D,
+                          int MbD, const float* fbar, hipStream_t s) {
+    const int ntw_b = mv_chain_ntw(net);
+    const int nl = lo.nl, S = stride_for(net, netT);
+    ChainArgs c;
+    memset(&c, 0, sizeof(c));
+    const size_t r0 = (size_t)row0D;
+    c.net = net; c.netT = netT; c.S = S; c.M = MbD; c.row_ld0 = lo.ld0;
+    c.ld_dy = net.L[nl - 1].N; c.dy_col0 = fbar; c.accum = 1;
+    for (int l = 0; l < nl - 1; ++l) { c.Z[l] = ctx + lo.Z[l] + r0 * net.L[l].N; c.ZB[l] = ws + bl.ZB[l] + r0 * net.L[l].N; }
+    const bool w8w = mv_chain_w8();
+    const int mt = (ntw_b == 2 && !w8w) ? mv_chain_mt((MbD + 15) / 16) : 1;
+    const size_t lds = (size_t)16 * mt * (S + lo.d0) * sizeof(float);
+    const dim3 grid((MbD + 16 * mt - 1) / (16 * mt));
+    if (mt == 2) {
+        MV_TRY(hipFuncSetAttribute((const void*)k_chain_bwd<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_chain_bwd<2, 1, 16>), grid, dim3(1024), lds, s, c);
+    }
+    else if (ntw_b == 2 && !w8w) hipLaunchKernelGGL((k_chain_bwd<1, 1, 16>), grid, dim3(1024), lds, s, c);
+    else if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd<1, 2, 8>), grid, dim3(512), lds, s, c);
+    else if (!w8w) hipLaunchKernelGGL((k_chain_bwd<1, 2, 16>), grid, dim3(1024), lds, s, c);
+    else hipLaunchKernelGGL((k_chain_bwd<1, 4, 8>), grid, dim3(512), lds, s, c);
+    return mv_check(hipGetLastError(), "sdf_delta_pass");
+}
+
+// operands of the SDF net's weight gradients (layers a.L[l0 ...]) from the adjoints pass A (+ delta) left in `ws`
+static void sdf_wgrad_operands(WgradNetArgs& wa, int l0, const MvNet& net, const SdfLayout& lo, const SdfBwdLayout& bl, const float* dy, const float* ctx,
+                               float* ws) {
+    const int nl = lo.nl;
+    for (int l = 0; l < nl; ++l) {
+        WgradLayer& L = wa.L[l0 + l];
+        const bool last = (l == nl - 1);
+        L.No = net.L[l].N; L.Ki = net.L[l].K;
+        L.P1 = last ? dy : ws + bl.ZB[l]; L.ldp1 = L.No;
+        L.Q1 = l == 0 ? ctx + lo.H0 : ctx + lo.A[l]; L.ldq1 = l == 0 ? lo.ld0 : net.L[l].K;
+        if (!last) { L.P2 = ctx + lo.Sg[l]; L.ldp2 = L.No; L.Q2 = ws + bl.VB[l]; L.ldq2 = L.ldq1; }
+    }
+}
+
+extern "C" {
+
 /* Completes pass A of mvsdf_sdf_backward_pair: (1) delta pass over rows [row0D, row0D + MbD) whose extra upstream is ONE scalar per row on
  * output column 0 (fbar[MbD]: SampleNetwork's term, known only after pass X): by linearity its zbar_l are ADDED to the stored ones (first-order
  * descending chain only); dy[(row0D + i) * Nout] must already include fbar[i] (it feeds the last layer's weight gradient).  (2) weight / bias
@@ -582,49 +652,22 @@ int mvsdf_sdf_backward_finish(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int
     if (rc) return rc;
     if (!dy || !ctx || !ws || !dW_cat || !db_cat || Mb <= 0 || Mb > Mg || Mg > M || MbD < 0 || row0D < 0 || row0D + MbD > Mb || (MbD > 0 && !fbar))
         return mv_fail(-1, "mvsdf_sdf_backward_finish: bad arguments");
-    const int ntw_b = mv_chain_ntw(net);
-    if (!ntw_b) return mv_fail(-3, "mvsdf_sdf_backward_finish: network too wide for the fused chain kernels");
+    if (!mv_chain_ntw(net)) return mv_fail(-3, "mvsdf_sdf_backward_finish: network too wide for the fused chain kernels");
     hipStream_t s = (hipStream_t)stream;
     const SdfLayout lo = sdf_ctx_layout(net, M, Mg);
     const SdfBwdLayout bl = sdf_bwd_layout(net, Mb);
-    const int nl = lo.nl, S = stride_for(net, netT);
+    const int nl = lo.nl;
     if (MbD > 0) {
-        ChainArgs c;
-        memset(&c, 0, sizeof(c));
-        const size_t r0 = (size_t)row0D;
-        c.net = net; c.netT = netT; c.S = S; c.M = MbD; c.row_ld0 = lo.ld0;
-        c.ld_dy = net.L[nl - 1].N; c.dy_col0 = fbar; c.accum = 1;
-        for (int l = 0; l < nl - 1; ++l) { c.Z[l] = ctx + lo.Z[l] + r0 * net.L[l].N; c.ZB[l] = ws + bl.ZB[l] + r0 * net.L[l].N; }
-        const bool w8w = mv_chain_w8();
-        const int mt = (ntw_b == 2 && !w8w) ? mv_chain_mt((MbD + 15) / 16) : 1;
-        const size_t lds = (size_t)16 * mt * (S + lo.d0) * sizeof(float);
-        const dim3 grid((MbD + 16 * mt - 1) / (16 * mt));
-        if (mt == 2) {
-            MV_TRY(hipFuncSetAttribute((const void*)k_chain_bwd<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_chain_bwd<2, 1, 16>), grid, dim3(1024), lds, s, c);
-        }
-        else if (ntw_b == 2 && !w8w) hipLaunchKernelGGL((k_chain_bwd<1, 1, 16>), grid, dim3(1024), lds, s, c);
-        else if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd<1, 2, 8>), grid, dim3(512), lds, s, c);
-        else if (!w8w) hipLaunchKernelGGL((k_chain_bwd<1, 2, 16>), grid, dim3(1024), lds, s, c);
-        else hipLaunchKernelGGL((k_chain_bwd<1, 4, 8>), grid, dim3(512), lds, s, c);
-        MV_TRY(hipGetLastError());
+        rc = sdf_delta_pass(net, netT, lo, bl, ctx, ws, row0D, MbD, fbar, s);
+        if (rc) return rc;
     }
     WgradNetArgs wa;
     memset(&wa, 0, sizeof(wa));
-    wa.n_layers = nl; wa.M = Mb; wa.chunk = bl.chunk; wa.nchunks = bl.nchunks;
-    for (int l = 0; l < nl; ++l) {
-        WgradLayer& L = wa.L[l];
-        const bool last = (l == nl - 1);
-        L.No = net.L[l].N; L.Ki = net.L[l].K;
-        L.P1 = last ? dy : ws + bl.ZB[l]; L.ldp1 = L.No;
-        L.Q1 = l == 0 ? ctx + lo.H0 : ctx + lo.A[l]; L.ldq1 = l == 0 ? lo.ld0 : net.L[l].K;
-        if (!last) { L.P2 = ctx + lo.Sg[l]; L.ldp2 = L.No; L.Q2 = ws + bl.VB[l]; L.ldq2 = L.ldq1; }
-    }
-    wa.slab = ws + bl.slabA; wa.bslab = ws + bl.bslab;
-    wa.dW = dW_cat; wa.db = db_cat;
+    wa.n_layers = nl; wa.chunk = bl.chunk;
+    sdf_wgrad_operands(wa, 0, net, lo, bl, dy, ctx, ws);
+    wgrad_net_layers(wa, 0, nl, Mb, bl.nchunks, ws + bl.slabA, ws + bl.bslab, dW_cat, db_cat);
     const int Ki = net.L[nl - 1].K;                                                // W_last[0, :] += sum_rows ubar_last   (E.1 end)
-    hipLaunchKernelGGL(k_colsum, dim3((Ki + 63) / 64, bl.nchunks), dim3(256), 0, s, ws + bl.VB[nl - 1], Ki, Mb, Ki, bl.chunk, ws + bl.slabB);
-    wa.colslab = ws + bl.slabB; wa.col_n = Ki;
+    wgrad_colsum(wa, ws + bl.VB[nl - 1], Ki, Mb, Ki, nl - 1, bl.nchunks, ws + bl.slabB);
     MV_TRY(launch_wgrad_net(wa, s));
     return mv_check(hipGetLastError(), "mvsdf_sdf_backward_finish");
 }
@@ -732,17 +775,11 @@ int mvsdf_render_forward(const MvsdfNetDesc* d, const float* points, const float
     return mv_check(hipGetLastError(), "mvsdf_render_forward");
 }
 
-/* Backward: drgb[N][3] -> dW_cat, db_cat, din[N][K0] (adjoint of the concatenated input; the caller slices
- * points = [:, 0:3], normals = [:, 3+dv : 6+dv], feat = [:, 6+dv :]). */
-int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, int Nctx, const float* drgb, const float* ctx, float* dW_cat,
-                          float* db_cat, float* din, float* ws, void* stream) {
-    MvNet net, netT;
-    int rc = mv_make_net_mode(d, &net, 1);
-    if (rc) return rc;
-    rc = mv_make_net_mode(dT, &netT, 2);
-    if (rc) return rc;
-    if (!drgb || !ctx || !dW_cat || !db_cat || !din || !ws || N <= 0 || Nctx < N) return mv_fail(-1, "mvsdf_render_backward: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
+}  // extern "C"
+
+// the descending chain of the rendering net's backward: drgb[N][3] -> per-layer adjoints in `ws` + din[N][K0]
+static int render_backward_chain(const MvNet& net, const MvNet& netT, int N, int Nctx, const float* drgb, const float* ctx, float* din, float* ws,
+                                 hipStream_t s, const long long* drgb_rows = nullptr) {
     const int nl = net.n_layers, S = stride_for(net, netT);
     const RenderLayout lo = render_layout(net, Nctx);        // the forward context holds Nctx rows; the backward covers the first N
     const RenderBwdLayout bl = render_bwd_layout(net, N);
@@ -755,7 +792,7 @@ int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, 
         RenderChainArgs c;
         memset(&c, 0, sizeof(c));
         c.net = net; c.netT = netT; c.S = S; c.N = N; c.K0 = net.L[0].K;
-        c.drgb = drgb; c.rgbc = ctx + lo.rgb; c.din = din;
+        c.drgb = drgb; c.rgbc = ctx + lo.rgb; c.din = din; c.drgb_rows = drgb_rows;
         for (int l = 0; l < nl; ++l) { c.Ac[l] = ctx + lo.A[l]; c.ZB[l] = ws + bl.ZB[l]; }
         constexpr int MTC = 1, NWC = 8;
         const bool w8 = mv_chain_w8();
@@ -766,7 +803,8 @@ int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, 
         else if (!w8) hipLaunchKernelGGL((k_render_chain_bwd<MTC, 2, 16>), grid, dim3(1024), ldsr, s, c);
         else hipLaunchKernelGGL((k_render_chain_bwd<MTC, 4, NWC>), grid, dim3(64 * NWC), ldsr, s, c);
         MV_TRY(hipGetLastError());
-    } else
+    } else {
+    if (drgb_rows) return mv_fail(-3, "render_backward_chain: row indirection needs the fused chain kernel");
     for (int l = nl - 1; l >= 0; --l) {                      // abar_l = zbar_l W_l ; zbar_{l-1} = abar_l . relu'(z_{l-1})
         LayerArgs a = base_args(netT.L[l], S, N);
         const bool last = (l == nl - 1);
@@ -781,19 +819,118 @@ int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, 
             if (last) MV_TRY((launch_layer<PRO_TANH_BWD, EPI_SPLIT>(a, s))); else MV_TRY((launch_layer<PRO_PLAIN, EPI_SPLIT>(a, s)));
         }
     }
-    WgradNetArgs wa;
-    memset(&wa, 0, sizeof(wa));
-    wa.n_layers = nl; wa.M = N; wa.chunk = bl.chunk; wa.nchunks = bl.nchunks;
-    for (int l = 0; l < nl; ++l) {
-        WgradLayer& L = wa.L[l];
+    }
+    return 0;
+}
+static void render_wgrad_operands(WgradNetArgs& wa, int l0, const MvNet& net, const RenderLayout& lo, const RenderBwdLayout& bl, const float* ctx, float* ws) {
+    for (int l = 0; l < net.n_layers; ++l) {
+        WgradLayer& L = wa.L[l0 + l];
         L.No = net.L[l].N; L.Ki = net.L[l].K;
         L.P1 = ws + bl.ZB[l]; L.ldp1 = L.No;
         L.Q1 = ctx + lo.A[l]; L.ldq1 = L.Ki;
     }
-    wa.slab = ws + bl.slab; wa.bslab = ws + bl.bslab;
-    wa.dW = dW_cat; wa.db = db_cat;
+}
+
+extern "C" {
+
+/* Backward: drgb[N][3] -> dW_cat, db_cat, din[N][K0] (adjoint of the concatenated input; the caller slices
+ * points = [:, 0:3], normals = [:, 3+dv : 6+dv], feat = [:, 6+dv :]). */
+int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, int Nctx, const float* drgb, const float* ctx, float* dW_cat,
+                          float* db_cat, float* din, float* ws, void* stream) {
+    MvNet net, netT;
+    int rc = mv_make_net_mode(d, &net, 1);
+    if (rc) return rc;
+    rc = mv_make_net_mode(dT, &netT, 2);
+    if (rc) return rc;
+    if (!drgb || !ctx || !dW_cat || !db_cat || !din || !ws || N <= 0 || Nctx < N) return mv_fail(-1, "mvsdf_render_backward: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    rc = render_backward_chain(net, netT, N, Nctx, drgb, ctx, din, ws, s);
+    if (rc) return rc;
+    const RenderLayout lo = render_layout(net, Nctx);
+    const RenderBwdLayout bl = render_bwd_layout(net, N);
+    WgradNetArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.n_layers = net.n_layers; wa.chunk = bl.chunk;
+    render_wgrad_operands(wa, 0, net, lo, bl, ctx, ws);
+    wgrad_net_layers(wa, 0, net.n_layers, N, bl.nchunks, ws + bl.slab, ws + bl.bslab, dW_cat, db_cat);
     MV_TRY(launch_wgrad_net(wa, s));
     return mv_check(hipGetLastError(), "mvsdf_render_backward");
 }
 
 }  // extern "C"
+
+// ================================================================================================ step driver pieces (step_internal.h)
+// The backward of a training step with the weight gradients of BOTH networks in one k_wgrad_net / k_reduce_net pair, split so that the
+// part that does not depend on the delta pass can run beside it on a second stream (step_driver.hip).
+int mv_render_backward_chain(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, int Nctx, const float* drgb, const long long* drgb_rows, const float* ctx,
+                             float* din, float* ws, void* stream) {
+    MvNet net, netT;
+    int rc = mv_make_net_mode(d, &net, 1);
+    if (rc) return rc;
+    rc = mv_make_net_mode(dT, &netT, 2);
+    if (rc) return rc;
+    if (!drgb || !ctx || !din || !ws || N <= 0 || Nctx < N) return mv_fail(-1, "mv_render_backward_chain: bad arguments");
+    rc = render_backward_chain(net, netT, N, Nctx, drgb, ctx, din, ws, (hipStream_t)stream, drgb_rows);
+    return rc ? rc : mv_check(hipGetLastError(), "mv_render_backward_chain");
+}
+
+int mv_sdf_backward_delta(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M, int Mg, int Mb, const float* ctx, float* ws, int row0D, int MbD,
+                          const float* fbar, void* stream) {
+    MvNet net, netT;
+    int rc = mv_make_net(d, &net);
+    if (rc) return rc;
+    rc = mv_make_net_mode(dT, &netT, 2);
+    if (rc) return rc;
+    if (!ctx || !ws || !fbar || Mb <= 0 || Mb > Mg || Mg > M || MbD <= 0 || row0D < 0 || row0D + MbD > Mb) return mv_fail(-1, "mv_sdf_backward_delta: bad arguments");
+    if (!mv_chain_ntw(net)) return mv_fail(-3, "mv_sdf_backward_delta: network too wide for the fused chain kernels");
+    return sdf_delta_pass(net, netT, sdf_ctx_layout(net, M, Mg), sdf_bwd_layout(net, Mb), ctx, ws, row0D, MbD, fbar, (hipStream_t)stream);
+}
+
+/* part 1: the chunks that do not depend on the delta pass -- every chunk of the rendering net (N rows; skipped when N == 0 or rctx is NULL) and
+ *         the SDF net's chunks that end at or below row `row_split` (the sample rows);
+ * part 2: the other SDF chunks + the column sums of ubar_last, then ONE reduction of all slabs of both networks -> dW_s / db_s / dW_r / db_r.
+ * part 3: both at once (no split).  The rendering net's targets are zero-filled by the caller when it has no rows. */
+int mv_step_wgrad(int part, const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int M, int Mg, int Mb, int row_split, const float* dy, const float* ctx,
+                  float* wsA, int N, int Nctx, const float* rctx, float* rws, float* dW_s, float* db_s, float* dW_r, float* db_r, void* stream) {
+    MvNet net, rnet;
+    int rc = mv_make_net(sd, &net);
+    if (rc) return rc;
+    const bool with_r = N > 0 && rctx && rws;
+    if (with_r) { rc = mv_make_net_mode(rd, &rnet, 1); if (rc) return rc; }
+    if (!dy || !ctx || !wsA || !dW_s || !db_s || Mb <= 0 || Mb > Mg || Mg > M || (with_r && (!dW_r || !db_r || Nctx < N)) || part < 1 || part > 3)
+        return mv_fail(-1, "mv_step_wgrad: bad arguments");
+    const SdfLayout lo = sdf_ctx_layout(net, M, Mg);
+    const SdfBwdLayout bl = sdf_bwd_layout(net, Mb);
+    const int nl = lo.nl, nr = with_r ? rnet.n_layers : 0;
+    if (nl + nr > MV_WG_MAXL) return mv_fail(-1, "mv_step_wgrad: too many layers");
+    WgradNetArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.n_layers = nl + nr; wa.chunk = bl.chunk;
+    sdf_wgrad_operands(wa, 0, net, lo, bl, dy, ctx, wsA);
+    wgrad_net_layers(wa, 0, nl, Mb, bl.nchunks, wsA + bl.slabA, wsA + bl.bslab, dW_s, db_s);
+    if (with_r) {
+        const RenderLayout rlo = render_layout(rnet, Nctx);
+        const RenderBwdLayout rbl = render_bwd_layout(rnet, N);
+        if (rbl.chunk != bl.chunk) return mv_fail(-1, "mv_step_wgrad: chunk sizes differ");
+        render_wgrad_operands(wa, nl, rnet, rlo, rbl, rctx, rws);
+        wgrad_net_layers(wa, nl, nr, N, rbl.nchunks, rws + rbl.slab, rws + rbl.bslab, dW_r, db_r);
+    }
+    const int Ki = net.L[nl - 1].K;
+    int c_split = row_split / bl.chunk;                                             // SDF chunks [0, c_split) hold sample rows only
+    if (c_split > bl.nchunks) c_split = bl.nchunks;
+    if (c_split < 0) c_split = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (part == 1) {
+        for (int l = 0; l < nl; ++l) { wa.L[l].ch0 = 0; wa.L[l].nch = c_split; }
+        MV_TRY(wgrad_launch(wa, s));
+    } else {
+        if (part == 2) {
+            for (int l = 0; l < nl; ++l) { wa.L[l].ch0 = c_split; wa.L[l].nch = bl.nchunks - c_split; }
+            for (int l = nl; l < nl + nr; ++l) wa.L[l].nch = 0;
+        }
+        wgrad_colsum(wa, wsA + bl.VB[nl - 1], Ki, Mb, Ki, nl - 1, bl.nchunks, wsA + bl.slabB);
+        MV_TRY(wgrad_launch(wa, s));
+        MV_TRY(wgrad_reduce(wa, s));
+    }
+    return mv_check(hipGetLastError(), "mv_step_wgrad");
+}

@@ -237,35 +237,57 @@ __device__ __forceinline__ void wg_stage(const float* __restrict__ src, int ld, 
 // ---- network-wide variants: the weight gradients of EVERY layer in one launch, then one reduction launch ----
 // Workgroup = (layer, 128-row chunk, 64x64 output block); both pairs of a layer (E.2 term zbar^T a and E.1 term s^T vbar) accumulate
 // in the same registers, so a layer needs one slab per chunk.
+#define MV_WG_MAXL 16                      // layers of one launch: both networks of a training step (9 + 5)
 struct WgradLayer {
     const float* P1; const float* Q1; const float* P2; const float* Q2;   // [M, No], [M, Ki]; P2 null: single pair
     int ldp1, ldq1, ldp2, ldq2;
     int No, Ki, nbx, nby;
-    int blk0;                      // first workgroup of this layer
-    unsigned slab_off, bslab_off;  // floats, into slab / bslab
-    unsigned woff, boff;           // floats, into dW_cat / db_cat
+    int M;                         // rows of this layer's operands
+    int nchunks;                   // 128-row chunks of M = slabs of this layer
+    int ch0, nch;                  // the chunks THIS launch computes (a caller may split a layer's chunks over two launches)
+    int blk0;                      // first workgroup of this layer in this launch
+    float* slab; float* bslab;     // [nchunks][No * Ki], [nchunks][No]
+    float* dW; float* db;          // reduction targets [No * Ki], [No]
+    unsigned woff, boff;           // prefix offsets of this layer in k_reduce_net's flattened index space
 };
 struct WgradNetArgs {
-    int n_layers, M, chunk, nchunks;
-    WgradLayer L[MV_MAXL];
-    float* slab; float* bslab;
-    // reduction
-    const float* colslab; int col_n;           // optional [nchunks][col_n]: added to row 0 of the LAST layer (E.1 end: W_last[0,:] += sum ubar)
-    float* dW; float* db; unsigned wtotal, btotal;
+    int n_layers, chunk;
+    WgradLayer L[MV_WG_MAXL];
+    // optional column sums: colslab[ch][c] = sum over chunk ch's rows of colX[row][c] (extra workgroups of k_wgrad_net from col_blk0 on);
+    // k_reduce_net adds them to row 0 of layer col_layer (E.1 end: W_last[0, :] += sum_rows ubar_last)
+    const float* colX; int col_ld, col_M, col_n, col_layer, col_nchunks, col_ch0, col_nch, col_blk0;
+    float* colslab;
+    unsigned wtotal, btotal;
 };
+
+__device__ __forceinline__ void mv_colsum_block(const WgradNetArgs& a, int local) {
+    __shared__ float red[4][64];
+    const int nbx = (a.col_n + 63) / 64;
+    const int ch = a.col_ch0 + local / nbx, bx = local - (local / nbx) * nbx;
+    const int c = bx * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int rbeg = ch * a.chunk, rend = min(a.col_M, rbeg + a.chunk);
+    float s = 0.0f;
+    if (c < a.col_n)
+        for (int row = rbeg + g; row < rend; row += 4) s += a.colX[(size_t)row * a.col_ld + c];
+    red[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && c < a.col_n) a.colslab[(size_t)ch * a.col_n + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
 
 __global__ __launch_bounds__(MV_THREADS) void k_wgrad_net(WgradNetArgs a) {
     constexpr int LD = 80;
     __shared__ __attribute__((aligned(16))) float Pt[64 * LD];
     __shared__ __attribute__((aligned(16))) float Qt[64 * LD];
+    if (a.colX && (int)blockIdx.x >= a.col_blk0) { mv_colsum_block(a, blockIdx.x - a.col_blk0); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
     int l = 0;
     while (l + 1 < a.n_layers && (int)blockIdx.x >= a.L[l + 1].blk0) ++l;
     const WgradLayer& L = a.L[l];
     const int local = blockIdx.x - L.blk0, nb = L.nbx * L.nby;
-    const int ch = local / nb, rem = local - ch * nb, by = rem / L.nbx, bx = rem - by * L.nbx;
+    const int chl = local / nb, rem = local - chl * nb, by = rem / L.nbx, bx = rem - by * L.nbx;
+    const int ch = L.ch0 + chl;
     const int i0 = bx * 64, o0 = by * 64, No = L.No, Ki = L.Ki;
-    const int rbeg = ch * a.chunk, rend = min(a.M, rbeg + a.chunk);
+    const int rbeg = ch * a.chunk, rend = min(L.M, rbeg + a.chunk);
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(MV_THREADS) void k_wgrad_net(WgradNetArgs a) {
             }
         }
     }
-    float* slab = a.slab + L.slab_off + (size_t)ch * No * Ki;
+    float* slab = L.slab + (size_t)ch * No * Ki;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int i = i0 + 16 * t + r;
@@ -305,10 +327,10 @@ __global__ __launch_bounds__(MV_THREADS) void k_wgrad_net(WgradNetArgs a) {
             }
         }
     }
-    if (do_bias && tid < 64 && o0 + tid < No) a.bslab[L.bslab_off + (size_t)ch * No + o0 + tid] = bsum;
+    if (do_bias && tid < 64 && o0 + tid < No) L.bslab[(size_t)ch * No + o0 + tid] = bsum;
 }
 
-// dW_cat / db_cat = sum over chunks of the slabs, fixed order (deterministic)
+// dW / db of every layer = sum over its chunks of the slabs, fixed order (deterministic)
 __global__ void k_reduce_net(WgradNetArgs a) {
     const unsigned total = a.wtotal + a.btotal;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -321,17 +343,17 @@ __global__ void k_reduce_net(WgradNetArgs a) {
         float v = 0.0f;
         if (isb) {
             const unsigned j = k - L.boff;
-            const float* sp = a.bslab + L.bslab_off + j;
-            for (int c = 0; c < a.nchunks; ++c) v += sp[(size_t)c * L.No];
-            a.db[k] = v;
+            const float* sp = L.bslab + j;
+            for (int c = 0; c < L.nchunks; ++c) v += sp[(size_t)c * L.No];
+            L.db[j] = v;
         } else {
             const unsigned j = k - L.woff;
             const size_t nk = (size_t)L.No * L.Ki;
-            const float* sp = a.slab + L.slab_off + j;
-            for (int c = 0; c < a.nchunks; ++c) v += sp[(size_t)c * nk];
-            if (a.colslab && l == a.n_layers - 1 && j < (unsigned)a.col_n)
-                for (int c = 0; c < a.nchunks; ++c) v += a.colslab[(size_t)c * a.col_n + j];
-            a.dW[k] = v;
+            const float* sp = L.slab + j;
+            for (int c = 0; c < L.nchunks; ++c) v += sp[(size_t)c * nk];
+            if (a.colslab && l == a.col_layer && j < (unsigned)a.col_n)
+                for (int c = 0; c < a.col_nchunks; ++c) v += a.colslab[(size_t)c * a.col_n + j];
+            L.dW[j] = v;
         }
     }
 }
@@ -963,6 +985,7 @@ struct RenderChainArgs {
     const float* points; const float* view; const float* normals; const float* feat; int ldfeat;   // forward inputs
     float* A[MV_MAXL]; float* rgb_ctx; float* rgb;                                                   // forward outputs
     const float* drgb; const float* Ac[MV_MAXL]; const float* rgbc; float* ZB[MV_MAXL]; float* din;  // backward
+    const long long* drgb_rows;                // backward: row r reads drgb[drgb_rows[r]] (null: drgb[r]) -- the step's upstream arrives in ray order, the net ran on sorted rows
 };
 
 // `mv` packs the input layout of RenderingNetwork.forward (idr.py:145-154): low 8 bits = multires_view; bit 8 set = mode 'no_view_dir'
@@ -1069,7 +1092,7 @@ __global__ __launch_bounds__(64 * NW) void k_render_chain_bwd(RenderChainArgs a)
             float v = 0.0f;
             if (row < a.N && k < K) {
                 const float y = a.rgbc[(size_t)row * K + k];
-                v = a.drgb[(size_t)row * K + k] * (1.0f - y * y);
+                v = a.drgb[(size_t)(a.drgb_rows ? a.drgb_rows[row] : row) * K + k] * (1.0f - y * y);
                 a.ZB[nl - 1][(size_t)row * K + k] = v;
             }
             act[rr * S + mv_perm(k)] = v;

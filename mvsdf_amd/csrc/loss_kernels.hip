@@ -11,6 +11,7 @@
 // HBM-shaped: 2 * 4 * C * 4 B = 1 KiB of gathered features per (point, source view).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <string.h>
 #include "capi_util.h"
 
 struct Proj {
@@ -174,27 +175,23 @@ struct CarveArgs {
 };
 
 // carving_t2 (my_utils.py:269-331) + the weighting of get_depth_loss (loss.py:42-60) for one point per thread.
-__global__ void k_carve(CarveArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.M) return;
-    const float size = a.size[0];
-    float pw[3];
-    for (int j = 0; j < 3; ++j) pw[j] = a.pts[(size_t)a.pts_ld * i + j] / 2.0f * size + a.center[j];       // loss.py:42
-    if (a.pts_world) for (int j = 0; j < 3; ++j) a.pts_world[(size_t)a.pts_ld * i + j] = pw[j];
+struct CarveAcc { float tot_valid, tot_inside, pos_min, neg_max; };
+// the views v0, v0 + vstep, ... of one point (carving_t2's per-view part, my_utils.py:280-312)
+__device__ __forceinline__ CarveAcc mv_carve_views(const CarveArgs& a, const float* pw, int v0, int vstep) {
     const float MAXF = 1e30f / (float)a.B;
-    float tot_valid = 0.f, tot_inside = 0.f, pos_min = INFINITY, neg_max = -INFINITY;
-    for (int v = 0; v < a.B; ++v) {
+    CarveAcc r = {0.f, 0.f, INFINITY, -INFINITY};
+    for (int v = v0; v < a.B; v += vstep) {
         const float* E = a.cams + (size_t)v * 32;
         const float* K = E + 16;
         float c[4];
-        for (int r = 0; r < 4; ++r) c[r] = E[4 * r] * pw[0] + E[4 * r + 1] * pw[1] + E[4 * r + 2] * pw[2] + E[4 * r + 3];
+        for (int q = 0; q < 4; ++q) c[q] = E[4 * q] * pw[0] + E[4 * q + 1] * pw[1] + E[4 * q + 2] * pw[2] + E[4 * q + 3];
         const float s1 = c[3] + 1e-9f;
-        for (int r = 0; r < 4; ++r) c[r] = c[r] / s1;
+        for (int q = 0; q < 4; ++q) c[q] = c[q] / s1;
         const float pdepth = c[2];                                                                // my_utils.py:296
         const float s2 = c[3] + 1e-9f;
         const float c3[3] = {c[0] / s2, c[1] / s2, c[2] / s2};
         float im[3];
-        for (int r = 0; r < 3; ++r) im[r] = K[4 * r] * c3[0] + K[4 * r + 1] * c3[1] + K[4 * r + 2] * c3[2];
+        for (int q = 0; q < 3; ++q) im[q] = K[4 * q] * c3[0] + K[4 * q + 1] * c3[1] + K[4 * q + 2] * c3[2];
         const float u = im[0] / (im[2] + 1e-9f), vv = im[1] / (im[2] + 1e-9f);
         const float gx = fminf(fmaxf(u / (float)a.w * 2.0f - 1.0f, -1.1f), 1.1f);
         const float gy = fminf(fmaxf(vv / (float)a.h * 2.0f - 1.0f, -1.1f), 1.1f);
@@ -206,10 +203,22 @@ __global__ void k_carve(CarveArgs a) {
         const bool inside = (pdepth > gd * 0.99f) && valid;
         const bool outside = valid != inside;
         const float dist = valid ? (pdepth - gd) : 0.0f;
-        tot_valid += valid; tot_inside += inside;
-        pos_min = fminf(pos_min, inside ? dist : MAXF);
-        neg_max = fmaxf(neg_max, outside ? dist : -MAXF);
+        r.tot_valid += valid; r.tot_inside += inside;                                             // counts of 0 / 1: exact in any order
+        r.pos_min = fminf(r.pos_min, inside ? dist : MAXF);
+        r.neg_max = fmaxf(r.neg_max, outside ? dist : -MAXF);
     }
+    return r;
+}
+__device__ __forceinline__ void mv_carve_world(const CarveArgs& a, int i, float* pw) {
+    const float size = a.size[0];
+    for (int j = 0; j < 3; ++j) pw[j] = a.pts[(size_t)a.pts_ld * i + j] / 2.0f * size + a.center[j];       // loss.py:42
+}
+// the voting over the views + the weighting of get_depth_loss (my_utils.py:313-331, loss.py:42-60)
+__device__ __forceinline__ void mv_carve_finish(const CarveArgs& a, int i, const float* pw, const CarveAcc& r) {
+    const float size = a.size[0];
+    if (a.pts_world) for (int j = 0; j < 3; ++j) a.pts_world[(size_t)a.pts_ld * i + j] = pw[j];
+    const float MAXF = 1e30f / (float)a.B;
+    const float tot_valid = r.tot_valid, tot_inside = r.tot_inside, pos_min = r.pos_min, neg_max = r.neg_max;
     auto agg = [&](float res, float sign) {                                                       // RunningTopK(k=1).aggregate, my_utils.py:190-201
         const bool validm = fabsf(res) < MAXF * .99f;
         const float num = validm ? 1.f : 0.f;
@@ -228,6 +237,17 @@ __global__ void k_carve(CarveArgs a) {
     const float fw = far ? a.far_att : 1.0f, nw = near ? a.near_att : 1.0f;
     a.dist_r[i] = dr;
     a.weight[i] = fw * nw * (scene_valid ? 1.f : 0.f);
+}
+// carving_t2 (my_utils.py:269-331) + the weighting of get_depth_loss (loss.py:42-60) for one point per thread.
+__device__ __forceinline__ void mv_carve_point(const CarveArgs& a, int i) {
+    float pw[3];
+    mv_carve_world(a, i, pw);
+    const CarveAcc r = mv_carve_views(a, pw, 0, 1);
+    mv_carve_finish(a, i, pw, r);
+}
+__global__ void k_carve(CarveArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.M) mv_carve_point(a, i);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -388,9 +408,9 @@ int mvsdf_depth_carve(const float* pts, int pts_ld, int M, const float* depths, 
 //                 (which rows of diff_surf_pts belong to which view, loss.py:119-127); n_pos = #(network_object_mask & object_mask_true)
 //                 (the positives of the surface-indicator BCE, loss.py:167-173).
 //   k_loss_scale: backward of the weighted total: every stored unit gradient times (dL/dloss * weight + dL/dterm).
-__global__ __launch_bounds__(1024) void k_loss_prep(const uint8_t* __restrict__ net_mask, const uint8_t* __restrict__ obj_mask,
-                                                    const uint8_t* __restrict__ true_mask, int R, int B, uint8_t* __restrict__ hit,
-                                                    int* __restrict__ view_start, long long* __restrict__ n_pos) {
+__device__ __forceinline__ void mv_loss_prep_block(const uint8_t* __restrict__ net_mask, const uint8_t* __restrict__ obj_mask,
+                                                   const uint8_t* __restrict__ true_mask, int R, int B, uint8_t* __restrict__ hit,
+                                                   int* __restrict__ view_start, long long* __restrict__ n_pos) {
     // one wave per view (views beyond 16 take turns); the prefix sum over the B counts is done by thread 0
     __shared__ int cnt[1024];
     __shared__ int pos[16];
@@ -418,6 +438,38 @@ __global__ __launch_bounds__(1024) void k_loss_prep(const uint8_t* __restrict__ 
         long long s = 0;
         for (int k = 0; k < 16; ++k) s += pos[k];
         *n_pos = s;
+    }
+}
+__global__ __launch_bounds__(1024) void k_loss_prep(const uint8_t* __restrict__ net_mask, const uint8_t* __restrict__ obj_mask,
+                                                    const uint8_t* __restrict__ true_mask, int R, int B, uint8_t* __restrict__ hit,
+                                                    int* __restrict__ view_start, long long* __restrict__ n_pos) {
+    mv_loss_prep_block(net_mask, obj_mask, true_mask, R, B, hit, view_start, n_pos);
+}
+// mask bookkeeping (workgroup 0) and depth carving (the other workgroups, 1024 points each) in one launch: independent work of IDRLoss.forward
+struct PrepCarveArgs {
+    const uint8_t* net_mask; const uint8_t* obj_mask; const uint8_t* true_mask; int R, B; uint8_t* hit; int* view_start; long long* n_pos;
+    CarveArgs c;
+};
+// carve workgroups: 64 points each, the 16 waves split the views (wave w takes views w, w + 16, ...): the per-view counts and min / max combine
+// exactly in any order, so the result equals the one-thread-per-point kernel's bit for bit at a sixteenth of its latency
+__global__ __launch_bounds__(1024) void k_loss_prep_carve(PrepCarveArgs a) {
+    if (blockIdx.x == 0) { mv_loss_prep_block(a.net_mask, a.obj_mask, a.true_mask, a.R, a.B, a.hit, a.view_start, a.n_pos); return; }
+    __shared__ float part[16][4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = (blockIdx.x - 1) * 64 + lane;
+    const bool in = i < a.c.M;
+    float pw[3] = {0.f, 0.f, 0.f};
+    CarveAcc r = {0.f, 0.f, INFINITY, -INFINITY};
+    if (in) { mv_carve_world(a.c, i, pw); r = mv_carve_views(a.c, pw, w, 16); }
+    part[w][0][lane] = r.tot_valid; part[w][1][lane] = r.tot_inside; part[w][2][lane] = r.pos_min; part[w][3][lane] = r.neg_max;
+    __syncthreads();
+    if (w == 0 && in) {
+        CarveAcc t = r;
+        for (int k = 1; k < 16; ++k) {
+            t.tot_valid += part[k][0][lane]; t.tot_inside += part[k][1][lane];
+            t.pos_min = fminf(t.pos_min, part[k][2][lane]); t.neg_max = fmaxf(t.neg_max, part[k][3][lane]);
+        }
+        mv_carve_finish(a.c, i, pw, t);
     }
 }
 
@@ -510,18 +562,27 @@ int mvsdf_loss_forward(const MvsdfLossArgs* a, void* blk, void* stream) {
     uint8_t* hit = (uint8_t*)(b + lo.hit);
     int* view_start = (int*)(b + lo.view_start);
     long long* n_pos = (long long*)(b + lo.n_pos);
-    rc = mvsdf_loss_prep(a->net_mask, a->obj_mask, a->true_mask, a->R, a->B, hit, view_start, n_pos, stream);
-    if (rc) return rc;
+    if (a->B > 1024 || a->R % a->B) return mv_fail(-1, "mvsdf_loss_forward: R must be a multiple of B <= 1024");
+    if (a->n_depth > 0 && (!a->points_hom || !a->depths || !a->depth_cams || !a->size || !a->center || a->dB <= 0 || a->dh <= 0 || a->dw <= 0))
+        return mv_fail(-1, "mvsdf_loss_forward: depth term without depth maps / cameras");
+    {
+        PrepCarveArgs pc;
+        memset(&pc, 0, sizeof(pc));
+        pc.net_mask = a->net_mask; pc.obj_mask = a->obj_mask; pc.true_mask = a->true_mask; pc.R = a->R; pc.B = a->B;
+        pc.hit = hit; pc.view_start = view_start; pc.n_pos = n_pos;
+        CarveArgs& c = pc.c;
+        c.pts = a->points_hom; c.M = a->n_depth; c.pts_ld = 4; c.pts_world = a->points_hom;      // rescaled in place (loss.py:38,42)
+        c.depths = a->depths; c.B = a->dB; c.h = a->dh; c.w = a->dw; c.cams = a->depth_cams; c.size = a->size; c.center = a->center;
+        c.out_thresh_perc = a->out_thresh_perc; c.far_thresh = a->far_thresh; c.far_att = a->far_att; c.near_thresh = a->near_thresh; c.near_att = a->near_att;
+        c.dist_r = (float*)(b + lo.dist_r); c.weight = (float*)(b + lo.weight);
+        hipLaunchKernelGGL(k_loss_prep_carve, dim3(1 + (a->n_depth + 63) / 64), dim3(1024), 0, (hipStream_t)stream, pc);
+        rc = mv_check(hipGetLastError(), "mvsdf_loss_forward (prep + carve)");
+        if (rc) return rc;
+    }
     const bool feat = a->feat_on && a->N > 0;
     if (feat) {
         rc = mvsdf_feat_corr(a->diff_pts, a->N, view_start, a->B, a->V, a->C, a->H, a->W, a->feat, a->feat_strides, a->feat_src, a->src_strides, a->cam,
                              a->src_cams, a->size, a->center, (float*)(b + lo.loss_pp), (float*)(b + lo.dpts), stream);
-        if (rc) return rc;
-    }
-    if (a->n_depth > 0) {
-        rc = mvsdf_depth_carve(a->points_hom, 4, a->n_depth, a->depths, a->dB, a->dh, a->dw, a->depth_cams, a->size, a->center, a->out_thresh_perc,
-                               a->far_thresh, a->far_att, a->near_thresh, a->near_att, (float*)(b + lo.dist_r), (float*)(b + lo.weight), a->points_hom,
-                               stream);
         if (rc) return rc;
     }
     return mvsdf_loss_terms(a->rgb, a->rgb_gt, hit, a->R, a->n_grad > 0 ? a->grad_theta : nullptr, a->n_grad, a->eik_out, (const float*)(b + lo.dist_r),

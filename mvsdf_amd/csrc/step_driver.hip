@@ -5,9 +5,11 @@
 // everything the backward reads) and a `bwd` scratch block; the one host wait of a step is mvsdf_step_wait_counts.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include "capi_util.h"
+#include "step_internal.h"
 
 namespace {
 
@@ -16,7 +18,7 @@ inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct FwdOffsets {
     size_t w[MVSDF_STEP_MAX_LAYERS], wp[MVSDF_STEP_MAX_LAYERS], wpT[MVSDF_STEP_MAX_LAYERS], wp16[MVSDF_STEP_MAX_LAYERS];
     size_t trace_ws, trace_ws_bytes;
-    size_t inv, true_rows, counts, view_sorted;
+    size_t inv, true_rows, true_rank, counts, view_sorted;
     size_t x_eval, y_eval, n_eval, sdf_ctx, rgb_sorted, render_ctx;
 };
 struct BwdOffsets {
@@ -37,6 +39,9 @@ struct Step {
     int timing;
     hipEvent_t ev_t[5];
     bool timed;
+    hipStream_t side;                                // second stream of the backward: weight-gradient chunks beside the delta pass
+    hipEvent_t ev_fork, ev_join;
+    int overlap;                                     // MVSDF_STEP_OVERLAP (default 1)
 };
 
 // descriptors of the two networks over the packs inside a forward block
@@ -97,10 +102,6 @@ __global__ void k_step_gather_drgb(const float* __restrict__ d_rgb, const long l
     out[i] = d_rgb[3 * (size_t)perm[row] + c];
 }
 
-__global__ void k_step_copy_counts(const long long* __restrict__ ds_counts, long long* __restrict__ counts) {
-    if (threadIdx.x < 2) counts[2 + threadIdx.x] = ds_counts ? ds_counts[threadIdx.x] : 0;
-}
-
 #define ST_TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 #define ST_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mv_check(e_, #expr); } while (0)
 
@@ -121,6 +122,7 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
     st->d = d;
     st->R = d.B * d.P; st->E = d.n_eik + 2 * d.n_ds; st->M = st->R + st->E; st->nl = nl;
     st->Nout = d.N[d.n_sdf - 1]; st->K0r = d.K[d.n_sdf];
+    { const char* e = getenv("MVSDF_STEP_OVERLAP"); st->overlap = e ? atoi(e) : 1; }
     const int R = st->R, M = st->M;
     // probe descriptors (sizes only; the size functions do not dereference the pack pointers but the validity checks want non-null ones)
     MvsdfNetDesc sdf, sdfT, rnd, rndT;
@@ -146,7 +148,7 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
             fo.wp16[l] = take(mvsdf_packed_bf16_bytes(d.N[l], d.K[l], ns));
         }
     }
-    L.perm = take((size_t)R * 8); fo.inv = take((size_t)R * 8); fo.true_rows = take((size_t)R * 8); fo.counts = take(4 * 8);
+    L.perm = take((size_t)R * 8); fo.inv = take((size_t)R * 8); fo.true_rows = take((size_t)R * 8); fo.true_rank = take((size_t)R * 4); fo.counts = take(4 * 8);
     fo.view_sorted = take((size_t)R * 12);
     fo.x_eval = take((size_t)M * 12); fo.y_eval = take((size_t)M * st->Nout * 4); fo.n_eval = take((size_t)M * 12);
     // the size functions need structurally valid descriptors: point every pack at the dummy
@@ -197,6 +199,7 @@ void mvsdf_step_destroy(void* step) {
     if (!st) return;
     if (st->timing) for (int i = 0; i < 5; ++i) hipEventDestroy(st->ev_t[i]);
     if (st->counts_host) { hipEventDestroy(st->ev_counts); hipHostFree(st->counts_host); }
+    if (st->side) { hipEventDestroy(st->ev_fork); hipEventDestroy(st->ev_join); hipStreamDestroy(st->side); }
     delete st;
 }
 
@@ -247,19 +250,22 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     // 1. weight-norm fold + MFMA packs of both networks (idr.py:70-71; one fold per step instead of one per network call)
     float* w[MVSDF_STEP_MAX_LAYERS]; float* wp[MVSDF_STEP_MAX_LAYERS]; float* wpT[MVSDF_STEP_MAX_LAYERS];
     for (int l = 0; l < nl; ++l) { w[l] = (float*)(fwd + fo.w[l]); wp[l] = (float*)(fwd + fo.wp[l]); wpT[l] = (float*)(fwd + fo.wpT[l]); }
-    ST_TRY(mvsdf_fold_pack_net(nl, prm->v, prm->g, d.N, d.K, w, wp, wpT, stream));
-    if (d.trace_dtype == 1) {
-        void* wp16[MVSDF_MAX_LAYERS];
-        for (int l = 0; l < d.n_sdf; ++l) wp16[l] = fwd + fo.wp16[l];
-        ST_TRY(mvsdf_pack_bf16_net_skips(d.n_sdf, w, d.N, d.K, d.skip_mask, d.multires, wp16, stream));
+    float* ray_dirs = (float*)(fwd + L.ray_dirs); float* cam_loc = (float*)(fwd + L.cam_loc);
+    {
+        void* wp16[MVSDF_STEP_MAX_LAYERS]; int nsplit[MVSDF_STEP_MAX_LAYERS];
+        for (int l = 0; l < nl; ++l) {
+            const bool bf = l < d.n_sdf && d.trace_dtype == 1;
+            wp16[l] = bf ? (void*)(fwd + fo.wp16[l]) : nullptr;
+            nsplit[l] = (bf && (l == 0 || ((d.skip_mask >> l) & 1u))) ? 3 + 6 * d.multires : 0;
+        }
+        // ... and the camera rays (idr.py:190), all in one launch
+        ST_TRY(mv_step_prologue(nl, prm->v, prm->g, d.N, d.K, w, wp, wpT, wp16, nsplit, in->uv, in->pose, in->intrinsics, d.B, d.P, ray_dirs, cam_loc, stream));
     }
     MvsdfNetDesc sdf, sdfT, rnd, rndT;
     make_descs(*st, prm, fwd, &sdf, &sdfT, &rnd, &rndT);
     // 2. rays + RayTracing.forward (idr.py:190-199)
-    float* ray_dirs = (float*)(fwd + L.ray_dirs); float* cam_loc = (float*)(fwd + L.cam_loc);
     float* points = (float*)(fwd + L.points); uint8_t* mask = (uint8_t*)(fwd + L.mask); float* dists = (float*)(fwd + L.dists);
     unsigned long long* counters = (unsigned long long*)(fwd + L.counters);
-    ST_TRY(mvsdf_camera_rays(in->uv, in->pose, in->intrinsics, d.B, d.P, ray_dirs, cam_loc, stream));
     auto stage = [&](int which) {
         return mvsdf_trace_stage(which, &sdf, &d.tp, cam_loc, ray_dirs, in->object_mask, d.B, d.P, 1, in->intervals, in->minsdf_steps, points, mask, dists,
                                  counters, fwd + fo.trace_ws, fo.trace_ws_bytes, d.mt, d.mt_samples, stream);
@@ -272,9 +278,8 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     // 3. stable partition (hit rays first) + both counts; they start travelling to the host while the rest of the forward runs
     long long* perm = (long long*)(fwd + L.perm); long long* inv = (long long*)(fwd + fo.inv); long long* true_rows = (long long*)(fwd + fo.true_rows);
     long long* counts = (long long*)(fwd + fo.counts); float* view_sorted = (float*)(fwd + fo.view_sorted);
-    ST_TRY(mvsdf_partition_rays(mask, d.use_object_mask ? in->object_mask : nullptr, in->object_mask_true, ray_dirs, R, perm, inv, true_rows, counts,
-                                view_sorted, stream));
-    hipLaunchKernelGGL(k_step_copy_counts, dim3(1), dim3(64), 0, s, d.n_ds > 0 ? in->ds_counts : nullptr, counts);
+    ST_TRY(mv_partition_rays_step(mask, d.use_object_mask ? in->object_mask : nullptr, in->object_mask_true, ray_dirs, R, perm, inv, true_rows, counts,
+                                  view_sorted, (int*)(fwd + fo.true_rank), d.n_ds > 0 ? in->ds_counts : nullptr, stream));
     ST_HIP(hipMemcpyAsync(st->counts_host, counts, 4 * sizeof(long long), hipMemcpyDeviceToHost, s));
     ST_HIP(hipEventRecord(st->ev_counts, s));
     st->counts_pending = true;
@@ -339,35 +344,58 @@ int mvsdf_step_backward(void* step, const MvsdfStepParams* prm, int N, int n_tru
         ST_HIP(hipMemsetAsync(dflat, 0, L.dflat_floats * 4, s));
     } else {
         const float* din = nullptr;
-        // rendering-net backward over the N hit rows (idr.py:302-304: only they reach rgb_values)
-        if (N > 0 && d_rgb) {
+        // rendering-net backward over the N hit rows (idr.py:302-304: only they reach rgb_values): the descending chain now, its weight
+        // gradients together with the SDF net's further down
+        const bool with_r = N > 0 && d_rgb;
+        if (with_r) {
+            // (the upstream arrives in ray order; the net ran on the sorted rows: the chain kernel reads row r from d_rgb[perm[r]])
             float* drgb_sorted = (float*)(bwd + bo.drgb_sorted);
-            hipLaunchKernelGGL(k_step_gather_drgb, dim3((3 * N + 255) / 256), dim3(256), 0, s, d_rgb, (const long long*)(fwd + L.perm), N, drgb_sorted);
             float* din_w = (float*)(bwd + bo.din);
-            ST_TRY(mvsdf_render_backward(&rnd, &rndT, N, R, drgb_sorted, (const float*)(fwd + fo.render_ctx), dW_r, db_r, din_w, (float*)(bwd + bo.render_ws),
-                                         stream));
+            int rcb = mv_render_backward_chain(&rnd, &rndT, N, R, d_rgb, (const long long*)(fwd + L.perm), (const float*)(fwd + fo.render_ctx), din_w,
+                                               (float*)(bwd + bo.render_ws), stream);
+            if (rcb == -3) {                                                            // per-layer route: gather first
+                hipLaunchKernelGGL(k_step_gather_drgb, dim3((3 * N + 255) / 256), dim3(256), 0, s, d_rgb, (const long long*)(fwd + L.perm), N, drgb_sorted);
+                rcb = mv_render_backward_chain(&rnd, &rndT, N, R, drgb_sorted, nullptr, (const float*)(fwd + fo.render_ctx), din_w, (float*)(bwd + bo.render_ws), stream);
+            }
+            if (rcb) return rcb;
             din = din_w;
         } else {
             ST_HIP(hipMemsetAsync(dflat + st->seg[1][0], 0, (st->seg[1][2] - st->seg[1][0]) * 4, s));
         }
-        // upstream of the fused SDF backward: zero + the rendering net's feature / normal adjoints on the hit rows
-        ST_TRY(mvsdf_step_backward_inputs(0, d.n_eik, d.n_ds, N, Nout, n_true, din, st->K0r, feat0, nrm0, use_geo, nullptr, nullptr, view_sorted, n_eval,
-                                          true_rows, nullptr, nullptr, nullptr, d_mask, e_mask, dy, dn, stream));
+        const float* rctx = with_r ? (const float*)(fwd + fo.render_ctx) : nullptr;
+        float* rws = with_r ? (float*)(bwd + bo.render_ws) : nullptr;
+        float* wsA = (float*)(bwd + bo.wsA);
         bool done = false;
         if (din && N > 0) {
             // (X) input adjoint of the surface points for the rendering net's upstream alone, (A) the full pass with every upstream except
-            // SampleNetwork's scalar: independent, one grid; then fbar = -xbar.v / n.v and a first-order delta pass
+            // SampleNetwork's scalar: independent, one grid; then fbar = -xbar.v / n.v and a first-order delta pass.
+            // Both upstreams come out of ONE gather pass (the staged route: zero-fill + rendering-net adjoints, two row-block copies, scatter).
             float* dy_x = (float*)(bwd + bo.dy_x); float* dn_x = (float*)(bwd + bo.dn_x);
-            ST_HIP(hipMemcpyAsync(dy_x, dy + (size_t)E * Nout, (size_t)N * Nout * 4, hipMemcpyDeviceToDevice, s));
-            if (use_geo) ST_HIP(hipMemcpyAsync(dn_x, dn + 3 * (size_t)E, (size_t)N * 12, hipMemcpyDeviceToDevice, s));
-            ST_TRY(mvsdf_step_backward_inputs(2, d.n_eik, d.n_ds, N, Nout, n_true, din, st->K0r, feat0, nrm0, use_geo, d_diff, nullptr, view_sorted, n_eval,
-                                              true_rows, d_eo, d_gth, d_si, d_mask, e_mask, dy, dn, stream));
-            float* wsA = (float*)(bwd + bo.wsA); float* dx = (float*)(bwd + bo.dx);
+            ST_TRY(mv_step_backward_assemble(d.n_eik, d.n_ds, N, Nout, n_true, din, st->K0r, feat0, nrm0, use_geo, (const int*)(fwd + fo.true_rank), d_eo,
+                                             d_gth, d_si, d_mask, e_mask, dy, dn, dy_x, dn_x, stream));
+            float* dx = (float*)(bwd + bo.dx);
             int rc = mvsdf_sdf_backward_pair(&sdf, &sdfT, M, M, Mb, dy, dn, wsA, E, N, dy_x, use_geo ? dn_x : nullptr, (float*)(bwd + bo.wsX), dx, ctx, stream);
             if (rc == 0) {
+                // The delta pass covers the N hit rows only (a few dozen workgroups); the weight gradients of the rendering net and of the SDF
+                // net's sample-row chunks do not depend on it: they run beside it on a second stream, the hit-row chunks and the one reduction
+                // of all slabs follow on the main stream.
+                const bool fork = st->overlap != 0;
+                if (fork) {
+                    if (!st->side) {
+                        ST_HIP(hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
+                        ST_HIP(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
+                        ST_HIP(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
+                    }
+                    ST_HIP(hipEventRecord(st->ev_fork, s));
+                    ST_HIP(hipStreamWaitEvent(st->side, st->ev_fork, 0));
+                    ST_TRY(mv_step_wgrad(1, &sdf, &rnd, M, M, Mb, E, dy, ctx, wsA, with_r ? N : 0, R, rctx, rws, dW_s, db_s, dW_r, db_r, (void*)st->side));
+                    ST_HIP(hipEventRecord(st->ev_join, st->side));
+                }
                 float* fbar = (float*)(bwd + bo.fbar);
                 ST_TRY(mvsdf_step_backward_fbar(d.n_eik, d.n_ds, N, Nout, din, st->K0r, use_geo, d_diff, dx, view_sorted, n_eval, dy, fbar, stream));
-                ST_TRY(mvsdf_sdf_backward_finish(&sdf, &sdfT, M, M, Mb, dy, ctx, wsA, E, N, fbar, dW_s, db_s, stream));
+                ST_TRY(mv_sdf_backward_delta(&sdf, &sdfT, M, M, Mb, ctx, wsA, E, N, fbar, stream));
+                if (fork) ST_HIP(hipStreamWaitEvent(s, st->ev_join, 0));
+                ST_TRY(mv_step_wgrad(fork ? 2 : 3, &sdf, &rnd, M, M, Mb, E, dy, ctx, wsA, with_r ? N : 0, R, rctx, rws, dW_s, db_s, dW_r, db_r, stream));
                 done = true;
             } else if (rc == -3) {                                                      // network too wide for the fused chains: the sequential route
                 ST_TRY(mvsdf_sdf_backward(&sdf, &sdfT, x_eval + 3 * (size_t)E, M, M, E, N, dy_x, use_geo ? dn_x : nullptr, ctx, nullptr, nullptr, dx, wsA, stream));
@@ -377,11 +405,22 @@ int mvsdf_step_backward(void* step, const MvsdfStepParams* prm, int N, int n_tru
                 return rc;
             }
         } else {
+            ST_TRY(mvsdf_step_backward_inputs(0, d.n_eik, d.n_ds, N, Nout, n_true, din, st->K0r, feat0, nrm0, use_geo, nullptr, nullptr, view_sorted, n_eval,
+                                              true_rows, nullptr, nullptr, nullptr, d_mask, e_mask, dy, dn, stream));
             ST_TRY(mvsdf_step_backward_inputs(1, d.n_eik, d.n_ds, N, Nout, n_true, din, st->K0r, feat0, nrm0, use_geo, d_diff, nullptr, view_sorted, n_eval,
                                               true_rows, d_eo, d_gth, d_si, d_mask, e_mask, dy, dn, stream));
         }
-        if (!done)
-            ST_TRY(mvsdf_sdf_backward(&sdf, &sdfT, x_eval, M, M, 0, Mb, dy, dn, ctx, dW_s, db_s, nullptr, (float*)(bwd + bo.wsA), stream));
+        if (!done) {
+            // (routes without the split: the SDF net's gradients by the general backward, the rendering net's by its own wgrad pair)
+            ST_TRY(mvsdf_sdf_backward(&sdf, &sdfT, x_eval, M, M, 0, Mb, dy, dn, ctx, dW_s, db_s, nullptr, wsA, stream));
+            if (with_r) {
+                // the rendering net alone: its slabs through the general entry point would redo the chain; reduce them with the shared helper instead
+                // (an SDF-less call of mv_step_wgrad is not defined, so: the classic full call)
+                float* drgb_sorted = (float*)(bwd + bo.drgb_sorted);
+                hipLaunchKernelGGL(k_step_gather_drgb, dim3((3 * N + 255) / 256), dim3(256), 0, s, d_rgb, (const long long*)(fwd + L.perm), N, drgb_sorted);
+                ST_TRY(mvsdf_render_backward(&rnd, &rndT, N, R, drgb_sorted, rctx, dW_r, db_r, (float*)(bwd + bo.din), rws, stream));
+            }
+        }
     }
     // weight-norm fold backward of both networks: dW / db -> dv, dg, db, added into the targets when accumulate
     const float* dWl[MVSDF_STEP_MAX_LAYERS]; const float* dbl[MVSDF_STEP_MAX_LAYERS];

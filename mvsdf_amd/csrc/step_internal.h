@@ -1,0 +1,31 @@
+// step_internal.h -- library-internal entry points shared by step_kernels.hip / diff_mlp.hip and the step driver (step_driver.hip).
+// Not part of the C ABI (include/mvsdf_hip.h): same conventions (device pointers, stream as void*, 0 on success).
+#pragma once
+#include <stdint.h>
+#include "../../include/mvsdf_hip.h"
+
+// k_partition_rays with the step driver's extra outputs: true_rank[pos] (rank of sorted hit row pos among the true-mask hit rows, -1 outside the
+// true mask) and counts[2..3] = extra_counts[0..1] (0 when NULL)
+int mv_partition_rays_step(const uint8_t* net_mask, const uint8_t* object_mask, const uint8_t* true_mask, const float* ray_dirs, int R, long long* perm,
+                           long long* inv, long long* true_rows, long long* counts, float* view_sorted, int* true_rank, const long long* extra_counts,
+                           void* stream);
+// dy / dn (full pass A upstream without SampleNetwork's scalar) and dy_x / dn_x (rendering-net adjoints alone on the hit rows) in one gather pass
+int mv_step_backward_assemble(int n_eik, int n_ds, int N, int Nout, int n_true, const float* din, int din_ld, int din_feat0, int din_nrm0, int use_geo,
+                              const int* true_rank, const float* d_eo, const float* d_gth, const float* d_si, int d_mask, int e_mask, float* dy,
+                              float* dn, float* dy_x, float* dn_x, void* stream);
+
+// pieces of the training step's backward (diff_mlp.hip): the rendering net's descending chain alone, the SDF net's delta pass alone, and the weight
+// gradients of BOTH networks as one k_wgrad_net / k_reduce_net pair (part 1: what does not depend on the delta pass; part 2: the rest + reduction)
+// drgb_rows (may be NULL): sorted row r takes its upstream from drgb[drgb_rows[r]]; -3 when that needs the fused chain kernel and it does not apply
+int mv_render_backward_chain(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, int Nctx, const float* drgb, const long long* drgb_rows, const float* ctx,
+                             float* din, float* ws, void* stream);
+int mv_sdf_backward_delta(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M, int Mg, int Mb, const float* ctx, float* ws, int row0D, int MbD,
+                          const float* fbar, void* stream);
+int mv_step_wgrad(int part, const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int M, int Mg, int Mb, int row_split, const float* dy, const float* ctx,
+                  float* wsA, int N, int Nctx, const float* rctx, float* rws, float* dW_s, float* db_s, float* dW_r, float* db_r, void* stream);
+
+// fold + MFMA packs (+ bf16 packs where wp16[l] is set: nsplit[l] = its PE split width) of every layer + the camera rays in ONE launch
+// (basic.hip::k_step_prologue): the work of mvsdf_fold_pack_net, mvsdf_pack_bf16_net_skips and mvsdf_camera_rays, same results
+int mv_step_prologue(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w, float* const* wp,
+                     float* const* wpT, void* const* wp16, const int* nsplit, const float* uv, const float* pose, const float* intrinsics, int B, int P,
+                     float* ray_dirs, float* cam_loc, void* stream);

@@ -6,6 +6,7 @@
 #include <string.h>
 #include "capi_util.h"
 #include "det_math.h"
+#include "step_internal.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // Stable partition of the rays by "surface" = net_mask & object_mask: perm = [surface rays in ray order | the others in ray order],
@@ -16,7 +17,8 @@ __global__ __launch_bounds__(1024) void k_partition_rays(const uint8_t* __restri
                                                          const uint8_t* __restrict__ true_mask, const float* __restrict__ ray_dirs, int R,
                                                          long long* __restrict__ perm, long long* __restrict__ inv,
                                                          long long* __restrict__ true_rows, long long* __restrict__ counts,
-                                                         float* __restrict__ view_sorted) {
+                                                         float* __restrict__ view_sorted, int* __restrict__ true_rank,
+                                                         const long long* __restrict__ extra_counts) {
     __shared__ int wsum[3][16];
     __shared__ int base[3];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -47,6 +49,7 @@ __global__ __launch_bounds__(1024) void k_partition_rays(const uint8_t* __restri
             perm[pos] = i; inv[i] = pos;
             if (view_sorted) for (int c = 0; c < 3; ++c) view_sorted[3 * (size_t)pos + c] = -ray_dirs[3 * (size_t)i + c];
             if (tr) true_rows[ot + __popcll(bt & below)] = pos;
+            if (true_rank && hit) true_rank[pos] = tr ? ot + __popcll(bt & below) : -1;
         }
         __syncthreads();
         if (tid == 0) {
@@ -57,6 +60,7 @@ __global__ __launch_bounds__(1024) void k_partition_rays(const uint8_t* __restri
         __syncthreads();
     }
     if (tid == 0) { counts[0] = base[0]; counts[1] = base[2]; }
+    if (true_rank && tid < 2) counts[2 + tid] = extra_counts ? extra_counts[tid] : 0;      // (the step driver's 4-entry count record)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -206,6 +210,83 @@ __global__ void k_step_bwd_fbar(StepBwdArgs a) {
     a.dy[(size_t)row * a.Nout] += f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The upstream of the training step's SDF backward in ONE gather pass (the step driver's route): what k_step_bwd_stage0, two row-block
+// copies and k_step_bwd_stage1 (without SampleNetwork's term) produce in four launches --
+//   dy[row][c] = (rendering-net feature adjoint on the hit rows, c >= 2) + d(eikonal_output) on column 0 + d(surf_indicator_output) on column 1
+//   dn[row]    = (rendering-net normal adjoint on the hit rows, when the geometry is attached) + d(grad_theta)
+//   dy_x / dn_x[k] = the rendering-net part alone on hit row k (upstream of the input-adjoint pass X, functional._IdrStep.backward)
+// -- with every cell written exactly once: v0 + add, the same single addition the staged kernels perform (0 + add and v0 + 0 are exact).
+// Index of an evaluation row inside the concatenation of the groups a mask selects (inverse of mv_group_row), -1 when not selected.
+__device__ __forceinline__ int mv_group_index(const StepGroups& g, int row) {
+    if (row >= g.E) return (g.mask & 1) ? row - g.E : -1;
+    int base = (g.mask & 1) ? g.N : 0;
+    if (row < g.n_eik) return (g.mask & 2) ? base + row : -1;
+    base += (g.mask & 2) ? g.n_eik : 0;
+    if (row < g.n_eik + g.n_ds) return (g.mask & 4) ? base + (row - g.n_eik) : -1;
+    base += (g.mask & 4) ? g.n_ds : 0;
+    return (g.mask & 8) ? base + (row - g.n_eik - g.n_ds) : -1;
+}
+struct StepAsmArgs {
+    StepBwdArgs b;
+    const int* true_rank;                 // [>= N] rank of sorted hit row k among the true-mask hit rows, -1 outside
+    float* dy_x; float* dn_x;             // [N][Nout], [N][3]
+};
+__global__ void k_step_bwd_assemble(StepAsmArgs s) {
+    const StepBwdArgs& a = s.b;
+    const StepGroups gd = {a.n_eik, a.n_ds, a.E, a.N, a.d_mask}, ge = {a.n_eik, a.n_ds, a.E, a.N, a.e_mask};
+    const int W = a.Nout + 3;
+    const size_t total = (size_t)a.Mb * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / W), c = (int)(i - (size_t)row * W);
+        const int k = row - a.E;
+        if (c < a.Nout) {
+            float v0 = 0.0f;
+            if (k >= 0 && c >= 2 && a.din) v0 = a.din[(size_t)k * a.din_ld + a.din_feat0 + (c - 2)];
+            if (k >= 0) s.dy_x[(size_t)k * a.Nout + c] = v0;
+            float v = v0;
+            if (c == 0 && a.d_eo) {
+                const int idx = mv_group_index(gd, row);
+                if (idx >= 0) v = v0 + a.d_eo[idx];
+            } else if (c == 1 && a.d_si) {
+                const int idx = k >= 0 ? s.true_rank[k] : (row < a.n_eik ? a.n_true + row : -1);
+                if (idx >= 0) v = v0 + a.d_si[idx];
+            }
+            a.dy[(size_t)row * a.Nout + c] = v;
+        } else {
+            const int cc = c - a.Nout;
+            float v0 = 0.0f;
+            if (k >= 0 && a.din && a.use_geo && a.din_nrm0 >= 0) v0 = a.din[(size_t)k * a.din_ld + a.din_nrm0 + cc];
+            if (k >= 0) s.dn_x[(size_t)k * 3 + cc] = v0;
+            float v = v0;
+            if (a.d_gth) {
+                const int idx = mv_group_index(ge, row);
+                if (idx >= 0) v = v0 + a.d_gth[3 * (size_t)idx + cc];
+            }
+            a.dn[(size_t)row * 3 + cc] = v;
+        }
+    }
+}
+
+int mv_step_backward_assemble(int n_eik, int n_ds, int N, int Nout, int n_true, const float* din, int din_ld, int din_feat0, int din_nrm0, int use_geo,
+                              const int* true_rank, const float* d_eo, const float* d_gth, const float* d_si, int d_mask, int e_mask, float* dy,
+                              float* dn, float* dy_x, float* dn_x, void* stream) {
+    const int E = n_eik + 2 * n_ds;
+    if (n_eik < 0 || n_ds < 0 || N <= 0 || !dy || !dn || !dy_x || !dn_x || !true_rank || (d_mask & ~15) || (e_mask & ~15))
+        return mv_fail(-1, "mv_step_backward_assemble: bad arguments");
+    StepAsmArgs s;
+    memset(&s, 0, sizeof(s));
+    StepBwdArgs& a = s.b;
+    a.E = E; a.N = N; a.Nout = Nout; a.Mb = E + N; a.n_true = n_true; a.n_eik = n_eik; a.n_ds = n_ds; a.d_mask = d_mask; a.e_mask = e_mask;
+    a.din = din; a.din_ld = din_ld; a.din_feat0 = din_feat0; a.din_nrm0 = din_nrm0; a.use_geo = use_geo;
+    a.d_eo = d_eo; a.d_gth = d_gth; a.d_si = d_si; a.dy = dy; a.dn = dn;
+    s.true_rank = true_rank; s.dy_x = dy_x; s.dn_x = dn_x;
+    const size_t total = (size_t)a.Mb * (Nout + 3);
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_step_bwd_assemble, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s);
+    return mv_check(hipGetLastError(), "mv_step_backward_assemble");
+}
+
 extern "C" {
 
 int mvsdf_partition_rays(const uint8_t* net_mask, const uint8_t* object_mask, const uint8_t* true_mask, const float* ray_dirs, int R,
@@ -213,7 +294,7 @@ int mvsdf_partition_rays(const uint8_t* net_mask, const uint8_t* object_mask, co
     if (!net_mask || !perm || !inv || !true_rows || !counts || R <= 0 || (view_sorted && !ray_dirs))
         return mv_fail(-1, "mvsdf_partition_rays: bad arguments");
     hipLaunchKernelGGL(k_partition_rays, dim3(1), dim3(1024), 0, (hipStream_t)stream, net_mask, object_mask, true_mask, ray_dirs, R, perm, inv,
-                       true_rows, counts, view_sorted);
+                       true_rows, counts, view_sorted, (int*)nullptr, (const long long*)nullptr);
     return mv_check(hipGetLastError(), "mvsdf_partition_rays");
 }
 
@@ -274,3 +355,16 @@ int mvsdf_step_backward_fbar(int n_eik, int n_ds, int N, int Nout, const float* 
 }
 
 }  // extern "C"
+
+// the step driver's form (csrc/step_driver.hip): also true_rank[pos] for the sorted hit rows (rank among the true-mask hit rows, -1 outside
+// the true mask: the inverse of true_rows, so that the backward's upstream assembly is one gather pass) and counts[2..3] = extra_counts (the
+// depth-surface sample counts travelling to the host with the hit counts)
+int mv_partition_rays_step(const uint8_t* net_mask, const uint8_t* object_mask, const uint8_t* true_mask, const float* ray_dirs, int R, long long* perm,
+                           long long* inv, long long* true_rows, long long* counts, float* view_sorted, int* true_rank, const long long* extra_counts,
+                           void* stream) {
+    if (!net_mask || !perm || !inv || !true_rows || !counts || !true_rank || R <= 0 || (view_sorted && !ray_dirs))
+        return mv_fail(-1, "mv_partition_rays_step: bad arguments");
+    hipLaunchKernelGGL(k_partition_rays, dim3(1), dim3(1024), 0, (hipStream_t)stream, net_mask, object_mask, true_mask, ray_dirs, R, perm, inv,
+                       true_rows, counts, view_sorted, true_rank, extra_counts);
+    return mv_check(hipGetLastError(), "mv_partition_rays_step");
+}
