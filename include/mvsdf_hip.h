@@ -59,9 +59,15 @@ enum {
     MVSDF_CNT_N_SAMPLER = 5,    /* rays on the sampler work list */
     MVSDF_CNT_N_MINSDF = 6,     /* rays on the min-sdf work list */
     MVSDF_CNT_N_SAMPLER_REST = 7,    /* sampler rays whose first sample window did not settle them (no sign change yet) */
-    MVSDF_CNT_ROWS_SAMPLER_EVAL = 8  /* ray_sampler rows actually evaluated here: the samples AFTER a ray's first sign change cannot
+    MVSDF_CNT_ROWS_SAMPLER_EVAL = 8, /* ray_sampler rows actually evaluated here: the samples AFTER a ray's first sign change cannot
                                       * influence any output (ray_tracing.py:221-256 reads only sdf_val[ind-1], sdf_val[ind]) and are
                                       * skipped.  counters[1] keeps the reference's count (n_rays * n_steps). */
+    /* tail filling of the sphere-tracing kernel (training): the min-sdf rows are a queue that finished sphere-tracing workgroups serve until
+     * the slowest one is done, the min-sdf launch takes the rest */
+    MVSDF_CNT_TAIL_NEXT = 9,    /* next unit of min-sdf rows to hand out */
+    MVSDF_CNT_TAIL_READY = 10,  /* min-sdf list items completely written */
+    MVSDF_CNT_TAIL_WGS = 11,    /* sphere-tracing workgroups whose rays are done */
+    MVSDF_CNT_TAIL_ROWS = 12    /* min-sdf rows evaluated inside the sphere-tracing kernel (a subset of counters[3]) */
 };
 
 int mvsdf_version(void);

@@ -515,9 +515,10 @@ int mvsdf_det_math(int op, const float* x, int n, float* y0, float* y1, void* st
 // ================================================================================================ step prologue (step_internal.h)
 // Everything a training forward needs before the tracer, in ONE launch: the weight-norm fold of every layer of both networks (idr.py:70-71),
 // the MFMA packs of W and W^T, the bf16 packs of the tracing MLP (trace_dtype = 1) and the camera rays (rend_util.py:48-75,87-100) -- the work
-// of k_fold_net, k_pack_net, k_pack_bf16_net and k_camera_rays.  A workgroup owns 16 rows of one layer: its four waves fold four rows each
+// of k_fold_net, k_pack_net, k_pack_bf16_net and k_camera_rays.  A workgroup owns 16 rows of one layer: its sixteen waves fold one row each
 // (the same serialised fmaf chain over k as k_fold_net: bit-identical), the 16 folded rows stay in LDS and the workgroup writes its tile row of the
 // W pack, its k-block column of the W^T pack and its tile row of the bf16 pack from there.  The last workgroups compute the rays.
+// 16 waves per workgroup, one row each: a row's norm is a serial fmaf chain of ~K steps (~10 us), so the rows must all run side by side.
 struct ProloArgs {
     FoldNetArgs f;
     int blk0[MV_FOLD_MAXL + 1];          // first workgroup of each layer; blk0[n_layers] = first ray workgroup
@@ -525,12 +526,12 @@ struct ProloArgs {
     const float* uv; const float* pose; const float* Kin; int B, P; float* dirs; float* cam_loc;
     int ld;                              // LDS row stride (floats) >= max K
 };
-__global__ __launch_bounds__(256) void k_step_prologue(ProloArgs a) {
+__global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tile[];              // [16][ld]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nl = a.f.n_layers;
     if ((int)blockIdx.x >= a.blk0[nl]) {                                       // ---- camera rays
-        const int idx = ((int)blockIdx.x - a.blk0[nl]) * 256 + tid;
+        const int idx = ((int)blockIdx.x - a.blk0[nl]) * 1024 + tid;
         if (idx >= a.B * a.P) return;
         const int b = idx / a.P;
         const float* p = a.pose + 16 * b;
@@ -559,35 +560,37 @@ __global__ __launch_bounds__(256) void k_step_prologue(ProloArgs a) {
     while (l + 1 < nl && (int)blockIdx.x >= a.blk0[l + 1]) ++l;
     const int rg = (int)blockIdx.x - a.blk0[l];                                // 16-row group of layer l (groups beyond the rows: pack padding only)
     const int N = a.f.N[l], K = a.f.K[l], ld = a.ld;
-    // ---- fold: wave wv takes rows 16 rg + 4 wv + q
-    for (int q = 0; q < 4; ++q) {
-        const int jl = 4 * wv + q, j = 16 * rg + jl;
+    // ---- fold: wave wv takes row 16 rg + wv
+    {
+        const int jl = wv, j = 16 * rg + jl;
         float* tr = tile + jl * ld;
-        if (j >= N) { for (int k = lane; k < K; k += 64) tr[k] = 0.0f; continue; }
-        const float* vr = a.f.v[l] + (size_t)j * K;
-        float* wr = a.f.w[l] + (size_t)j * K;
-        if (!a.f.g[l]) {                                                       // weight_norm=False: w = v
-            for (int k = lane; k < K; k += 64) { const float x = vr[k]; wr[k] = x; tr[k] = x; }
-            continue;
-        }
-        float ss = 0.0f;
-        for (int k0 = 0; k0 < K; k0 += 64) {
-            const float mine = (k0 + lane < K) ? vr[k0 + lane] : 0.0f;
-            const int n = min(64, K - k0);
-            for (int i = 0; i < n; ++i) {
-                const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), i));
-                ss = fmaf(x, x, ss);
+        if (j >= N) { for (int k = lane; k < K; k += 64) tr[k] = 0.0f; }
+        else {
+            const float* vr = a.f.v[l] + (size_t)j * K;
+            float* wr = a.f.w[l] + (size_t)j * K;
+            if (!a.f.g[l]) {                                                   // weight_norm=False: w = v
+                for (int k = lane; k < K; k += 64) { const float x = vr[k]; wr[k] = x; tr[k] = x; }
+            } else {
+                float ss = 0.0f;
+                for (int k0 = 0; k0 < K; k0 += 64) {
+                    const float mine = (k0 + lane < K) ? vr[k0 + lane] : 0.0f;
+                    const int n = min(64, K - k0);
+                    for (int i = 0; i < n; ++i) {
+                        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), i));
+                        ss = fmaf(x, x, ss);
+                    }
+                }
+                const float sc = a.f.g[l][j] / sqrtf(ss);
+                for (int k = lane; k < K; k += 64) { const float x = vr[k] * sc; wr[k] = x; tr[k] = x; }
             }
         }
-        const float sc = a.f.g[l][j] / sqrtf(ss);
-        for (int k = lane; k < K; k += 64) { const float x = vr[k] * sc; wr[k] = x; tr[k] = x; }
     }
     __syncthreads();
     // ---- pack of W: tile row ct = rg, every k-block
     const int NT = mv_ceil16(N) / 16, KB = mv_kpad(K) / 16;
     if (a.f.wp[l] && rg < NT) {
         float* dst = a.f.wp[l] + (size_t)rg * KB * 256;
-        for (int idx = tid; idx < KB * 256; idx += 256) {
+        for (int idx = tid; idx < KB * 256; idx += 1024) {
             const int s = idx & 3, ln = (idx >> 2) & 63, kb = idx >> 8;
             const int ol = ln & 15, i = kb * 16 + 4 * s + (ln >> 4);
             dst[idx] = (i < K) ? tile[ol * ld + i] : 0.0f;                      // rows >= N are zero in the tile
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(256) void k_step_prologue(ProloArgs a) {
     // ---- pack of W^T: k-block kb' = rg of every tile row ct' (columns of W)
     if (a.f.wpT[l]) {
         const int NTt = mv_ceil16(K) / 16, KBt = mv_kpad(N) / 16;
-        for (int idx = tid; idx < NTt * 256; idx += 256) {
+        for (int idx = tid; idx < NTt * 256; idx += 1024) {
             const int e = idx & 255, ct = idx >> 8;
             const int s = e & 3, ln = (e >> 2) & 63;
             const int o = ct * 16 + (ln & 15), il = 4 * s + (ln >> 4);
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(256) void k_step_prologue(ProloArgs a) {
     if (a.wp16[l] && rg < NT) {
         const int ns = a.nsplit[l], KB32 = mv_bf_kb(K, ns);
         uint16_t* dst = a.wp16[l] + (size_t)rg * KB32 * 512;
-        for (int idx = tid; idx < KB32 * 512; idx += 256) {
+        for (int idx = tid; idx < KB32 * 512; idx += 1024) {
             const int i = idx & 7, ln = (idx >> 3) & 63, kb = idx >> 9;
             const int ol = ln & 15, kp = kb * 32 + 8 * (ln >> 4) + i;
             const int col = kp < K ? kp : (kp < K + ns ? kp - ns : -1);        // the lo copy of a split column shares the hi column's weight
@@ -637,7 +640,7 @@ int mv_step_prologue(int n_layers, const float* const* v, const float* const* g,
     a.uv = uv; a.pose = pose; a.Kin = intrinsics; a.B = B; a.P = P; a.dirs = ray_dirs; a.cam_loc = cam_loc;
     a.ld = ((maxK + 3) & ~3) + 4;
     const size_t lds = (size_t)16 * a.ld * sizeof(float);
-    blk += (B * P + 255) / 256;
-    hipLaunchKernelGGL(k_step_prologue, dim3(blk), dim3(256), lds, (hipStream_t)stream, a);
+    blk += (B * P + 1023) / 1024;
+    hipLaunchKernelGGL(k_step_prologue, dim3(blk), dim3(1024), lds, (hipStream_t)stream, a);
     return mv_check(hipGetLastError(), "mv_step_prologue");
 }

@@ -69,15 +69,65 @@ __device__ __forceinline__ TraceLds mv_carve(float* base, int rows, int S, int d
     return l;
 }
 
+// Tail filling ("tail filling of k_sphere_trace" below): what a sphere-tracing workgroup needs to evaluate min-sdf rows once its own rays are done
+struct TailCtx {
+    const float* steps;               // the uniform draws of minimal_sdf_points (ray_tracing.py:287)
+    float* sv;                        // min-sdf sample values [n_items][n_steps] (the second sample-value buffer of the workspace)
+    int unit_rows;                    // rows per claimed unit (a multiple of the row tiles of both kernels)
+    int enable, spin;                 // spin: every workgroup of the grid is resident, a helper may wait for more work
+    unsigned* probe;                  // optional [gridDim.x][4]: rounds, units helped, clock ticks tracing, clock ticks helping (dev)
+};
+// results of a workgroup's rays + work-list appends (ray_tracing.py:41-44, 73-94): the statement block k_sphere_trace runs once when its rays are done
+#define MV_SPHERE_FINALIZE \
+    if (tid == 0 && nrows_total) atomicAdd(&counters[MV_CNT_ROWS_SPHERE], nrows_total); \
+    if (valid) { \
+        bool net_mask = acc_s < acc_e; \
+        const bool sampler = unf_s; \
+        float dist = acc_s; \
+        bool listed = false; \
+        float zmin = acc_s, zmax = acc_e; \
+        int kind = 0; \
+        if (sampler) { listed = true; kind = MV_ITEM_SAMPLER | (om ? MV_ITEM_OM : 0); } \
+        else if (training) { \
+            const bool in_mask = !net_mask && om; \
+            const bool out_mask = !om; \
+            if (in_mask || out_mask) { \
+                if (!isect) { \
+                    const float dot = (d[0] * c[0] + d[1] * c[1]) + d[2] * c[2]; \
+                    dist = -dot; \
+                } else { \
+                    listed = true; kind = MV_ITEM_MINSDF; \
+                    zmin = (net_mask && out_mask) ? acc_s : t0; \
+                    zmax = t1; \
+                } \
+            } \
+        } \
+        o_mask[gid] = net_mask ? 1 : 0; \
+        o_dists[gid] = dist; \
+        o_points[3 * (size_t)gid + 0] = c[0] + dist * d[0]; \
+        o_points[3 * (size_t)gid + 1] = c[1] + dist * d[1]; \
+        o_points[3 * (size_t)gid + 2] = c[2] + dist * d[2]; \
+        if (listed) { \
+            const bool smp = kind & MV_ITEM_SAMPLER; \
+            w_zmin[gid] = zmin; \
+            w_zmax[gid] = zmax; \
+            const unsigned long long idx = atomicAdd(&counters[smp ? MV_CNT_N_SAMPLER : MV_CNT_N_MINSDF], 1ull); \
+            (smp ? w_list : w_list_min)[idx] = gid | (kind << 28); \
+            if (!smp) n_pub = 1; \
+        } \
+    }
+
 template <int MT, int NTW, int NW, class NET>
 __global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams tp, const float* __restrict__ cam_loc,
                                                             const float* __restrict__ dirs, const uint8_t* __restrict__ object_mask,
                                                             int R, int P, int training, float* __restrict__ o_points,
                                                             uint8_t* __restrict__ o_mask, float* __restrict__ o_dists,
                                                             float* __restrict__ w_zmin, float* __restrict__ w_zmax, int* __restrict__ w_list,
-                                                            int* __restrict__ w_list_min, unsigned long long* __restrict__ counters) {
+                                                            int* __restrict__ w_list_min, unsigned long long* __restrict__ counters, TailCtx tail) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT, NR = 8 * MT;
+    const long long clk0 = tail.probe ? (long long)wall_clock64() : 0;
+    unsigned n_rounds = 0;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     TraceLds lds = mv_carve(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
     int* s_n = lds.misc;
@@ -109,11 +159,19 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams
     // levels before deep ones.  Results are identical; speculative rows count only if the reference would have evaluated them.
     bool hard_s = false, hard_e = false, bo_s = false, bo_e = false;
     const float lss1 = 1.0f - tp.line_search_step;
+    // helping mode (tail filling): once this workgroup's rays are done it evaluates min-sdf rows through the SAME evaluation call below (one
+    // copy of the fused MLP in the kernel: a second call site costs 11 KB of code and the two copies evict each other from the instruction cache)
+    bool helping = false;
+    int n_pub = 0;                                                // this thread appended a min-sdf item
+    int h_chunk = 0, h_left = 0, h_items = 0, h_nr = 0;
+    long long h_svi = 0;
+    unsigned h_units = 0;
+    long long clk1 = 0;
     for (;;) {
         int row_s = 0, row_e = 0;
         int sr_s[3] = {-1, -1, -1}, sr_e[3] = {-1, -1, -1};       // rows of the speculative levels lvl0 + 1 .. lvl0 + 3 of each side
         int lvl0 = 0;
-        if (w == 0) {
+        if (!helping && w == 0) {
             const unsigned long long ms = __ballot(req_s), me = __ballot(req_e);
             const unsigned long long lt = (1ull << lane) - 1ull;
             const int ns = __popcll(ms), ne = __popcll(me), n = ns + ne;
@@ -157,11 +215,90 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams
             }
             if (lane == 0) { s_n[0] = base; s_n[1] = n; }
         }
-        __syncthreads();
-        const int n = s_n[0];
-        if (n == 0) break;
-        if (tid == 0) nrows_total += (unsigned long long)s_n[1];
+        int n = 0;
+        if (!helping) {
+            __syncthreads();
+            n = s_n[0];
+            if (n == 0) {                                         // every ray of this workgroup is done: write its results (once)
+                MV_SPHERE_FINALIZE
+                if (!tail.enable) break;
+                // publish this workgroup's min-sdf items: ONE release per workgroup after all its appends, no acquire anywhere (an agent-scope
+                // acquire invalidates the whole L2 of the XCD, i.e. the cached weights of every workgroup still tracing there: measured 44 -> 70 us
+                // per round); the readers use cache-bypassing loads instead
+                const int pub = (w == 0) ? __popcll(__ballot(n_pub != 0)) : 0;
+                __syncthreads();
+                if (tid == 0) {
+                    __hip_atomic_fetch_add(&counters[MV_CNT_TAIL_READY], (unsigned long long)pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&counters[MV_CNT_TAIL_WGS], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                clk1 = tail.probe ? (long long)wall_clock64() : 0;
+                helping = true;
+            } else {
+                ++n_rounds;
+                if (tid == 0) nrows_total += (unsigned long long)s_n[1];
+            }
+        }
+        if (helping) {
+            // ---- tail filling: the next chunk of min-sdf rows (a new unit from the queue when the current one is used up)
+            if (h_left == 0) {
+                if (tid == 0) {
+                    long long take = -1;
+                    int n_items = 0;                              // the item count the unit was validated against (>= what it touches)
+                    for (int tries = 0; ; ++tries) {
+                        const bool all_done = __hip_atomic_load(&counters[MV_CNT_TAIL_WGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)gridDim.x;
+                        if (all_done) break;                      // the next launch takes the rest with the whole chip
+                        const unsigned long long u = __hip_atomic_load(&counters[MV_CNT_TAIL_NEXT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long rdy = __hip_atomic_load(&counters[MV_CNT_TAIL_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long res = __hip_atomic_load(&counters[MV_CNT_N_MINSDF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (rdy == res && (long long)u + ROWS <= (long long)res * tp.n_steps) {
+                            unsigned long long expect = u;
+                            if (__hip_atomic_compare_exchange_strong(&counters[MV_CNT_TAIL_NEXT], &expect, u + ROWS, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT)) { take = (long long)u; n_items = (int)res; break; }
+                            continue;                             // another workgroup took it: look again
+                        }
+                        if (!tail.spin || tries >= 2000) break;
+                        __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);        // a few us between looks: a few hundred idle workgroups must not crowd the counters' line
+                    }
+                    s_n[0] = (int)take; s_n[1] = n_items;
+                }
+                __syncthreads();
+                const int take = s_n[0];
+                if (take < 0) break;
+                h_items = s_n[1];
+                h_left = 1;
+                h_chunk = take;                                   // first row of the claimed tile(s)
+                ++h_units;
+            }
+            {   // rows h_chunk .. h_chunk + ROWS - 1 of the queue (as mv_eval_rows builds them for a min-sdf segment: ray_tracing.py:287-297);
+                // list entry and range were written by another workgroup during this kernel: cache-bypassing loads
+                const long long total = (long long)h_items * tp.n_steps, q0 = (long long)h_chunk;
+                h_nr = (int)min((long long)ROWS, total - q0);
+                if (tid < ROWS) {
+                    float* p = lds.pts + tid * 3;
+                    if (tid < h_nr) {
+                        const long long q = q0 + tid;
+                        const int it = (int)(q / tp.n_steps), i = (int)(q - (long long)it * tp.n_steps);
+                        const int g2 = __hip_atomic_load(&w_list_min[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x0fffffff;
+                        const float* cc = cam_loc + 3 * (g2 / P);
+                        const float* dd = dirs + 3 * (size_t)g2;
+                        const float zmin = __hip_atomic_load(&w_zmin[g2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const float zmax = __hip_atomic_load(&w_zmax[g2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const float z = tail.steps[i] * (zmax - zmin) + zmin;          // ray_tracing.py:290
+                        p[0] = cc[0] + z * dd[0]; p[1] = cc[1] + z * dd[1]; p[2] = cc[2] + z * dd[2];
+                        h_svi = (long long)it * tp.n_steps + i;
+                    } else { p[0] = 0.f; p[1] = 0.f; p[2] = 0.f; }
+                }
+                n = h_nr;
+                --h_left;
+            }
+            __syncthreads();
+        }
         mv_eval_dispatch<MT, NTW, NW, NET, (MT == 1)>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
+        if (helping) {
+            if (tid < h_nr) tail.sv[h_svi] = lds.sdfv[tid];
+            __syncthreads();                                      // values read before the next chunk's points overwrite the tile
+            continue;
+        }
         if (w == 0) {
             int used = 0;
             if (phase != 3) {
@@ -218,40 +355,11 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams
         // (mv_sdf_eval_col0 ended with a barrier; wave 0 rewrites pts/s_n only after its own reads above)
     }
 
-    if (tid == 0 && nrows_total) atomicAdd(&counters[MV_CNT_ROWS_SPHERE], nrows_total);
-    if (valid) {
-        bool net_mask = acc_s < acc_e;                                            // ray_tracing.py:41
-        const bool sampler = unf_s;                                               // ray_tracing.py:44
-        float dist = acc_s;
-        bool listed = false;
-        float zmin = acc_s, zmax = acc_e;
-        int kind = 0;
-        if (sampler) { listed = true; kind = MV_ITEM_SAMPLER | (om ? MV_ITEM_OM : 0); }
-        else if (training) {                                                      // ray_tracing.py:73-94
-            const bool in_mask = !net_mask && om;
-            const bool out_mask = !om;
-            if (in_mask || out_mask) {
-                if (!isect) {
-                    const float dot = (d[0] * c[0] + d[1] * c[1]) + d[2] * c[2];  // -bmm(rays, cam), plain order
-                    dist = -dot;
-                } else {
-                    listed = true; kind = MV_ITEM_MINSDF;
-                    zmin = (net_mask && out_mask) ? acc_s : t0;                   // min_dis override, ray_tracing.py:89
-                    zmax = t1;
-                }
-            }
-        }
-        o_mask[gid] = net_mask ? 1 : 0;
-        o_dists[gid] = dist;
-        o_points[3 * (size_t)gid + 0] = c[0] + dist * d[0];
-        o_points[3 * (size_t)gid + 1] = c[1] + dist * d[1];
-        o_points[3 * (size_t)gid + 2] = c[2] + dist * d[2];
-        if (listed) {                                                             // two work lists: sampler rays / min-sdf rays
-            const bool smp = kind & MV_ITEM_SAMPLER;
-            const unsigned long long idx = atomicAdd(&counters[smp ? MV_CNT_N_SAMPLER : MV_CNT_N_MINSDF], 1ull);
-            (smp ? w_list : w_list_min)[idx] = gid | (kind << 28);
-            w_zmin[gid] = zmin;
-            w_zmax[gid] = zmax;
+    if (tail.enable) {
+        if (tid == 0 && h_units) atomicAdd(&counters[MV_CNT_TAIL_ROWS], (unsigned long long)h_units * (unsigned long long)ROWS);
+        if (tail.probe && tid == 0) {
+            unsigned* pr = tail.probe + 4 * blockIdx.x;
+            pr[0] = n_rounds; pr[1] = h_units; pr[2] = (unsigned)(clk1 - clk0); pr[3] = (unsigned)((long long)wall_clock64() - clk1);
         }
     }
 }
@@ -271,19 +379,17 @@ struct SampleCtx {
 };
 
 // one segment of sample rows: the samples [i0, i0 + ni) of every item of a device-side list
-struct RowSeg { const int* list; const int* src; int cnt_index, i0, ni, blocks; };
+struct RowSeg { const int* list; const int* src; int cnt_index, i0, ni, blocks; int unit_rows; };   // unit_rows > 0: the rows are a queue, each workgroup claims its 16*MT rows from counters[MV_CNT_TAIL_NEXT]
 
 // Sample rows of a work list, FLATTENED over rays: global row q = item * ni + j (sample i0 + j).  A workgroup evaluates one chunk
 // of 16*MT consecutive rows (always full tiles, evenly spread over the chip) and stores the SDF values; the per-ray logic runs
 // in k_reduce_items.  Sampler rays: ray_tracing.py:206-219; min-sdf rays: ray_tracing.py:287-301.
 template <int MT, int NTW, int NW, class NET>
-__device__ void mv_eval_rows(const NET& net, const MvTraceParams& tp, const SampleCtx& c, const RowSeg& sg, int chunk, float* smem) {
+__device__ void mv_eval_rows(const NET& net, const MvTraceParams& tp, const SampleCtx& c, const RowSeg& sg, long long q0, float* smem, int n_list) {
     constexpr int ROWS = 16 * MT;
     const int tid = threadIdx.x;
     const int n_steps = tp.n_steps, ni = sg.ni;
-    const int n_list = (int)c.counters[sg.cnt_index];
     const long long total = (long long)n_list * ni;
-    const long long q0 = (long long)chunk * ROWS;
     if (q0 >= total) return;
     const int nr = (int)min((long long)ROWS, total - q0);
     TraceLds lds = mv_carve(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
@@ -453,6 +559,15 @@ __device__ void mv_secant_rays(const NET& net, const MvTraceParams& tp, const Sa
     if (tid == 0) atomicAdd(&c.counters[MV_CNT_ROWS_SECANT], (unsigned long long)n * (unsigned long long)tp.n_secant);
 }
 
+// ---- tail filling of k_sphere_trace ----
+// The min-sdf rows are a queue of units of `unit_rows` consecutive rows of the flattened (list item, sample) space, claimed through
+// counters[MV_CNT_TAIL_NEXT]: first by sphere-tracing workgroups whose rays are done (here), then by the min-sdf workgroups of the last
+// k_ray_samples launch, which take whatever is left.  A unit is handed out only when every list item it touches is completely written:
+// items are appended by atomics on counters[MV_CNT_N_MINSDF] (reserved) and counted again in counters[MV_CNT_TAIL_READY] once entry and
+// range are visible; ready == reserved (read in that order) means no append is in flight, i.e. all `reserved` items are complete.
+// Only FULL units are taken while other workgroups still trace (the list may still grow); helpers stop as soon as the last workgroup is
+// done -- the launch that follows evaluates the rest on the whole chip.  Values are written to the min-sdf sample buffer exactly as that
+// launch would (same engine arithmetic: bit-identical).
 // The first sec_blocks workgroups run secant chains, the others evaluate sample rows of up to two row segments: the dependent
 // secant chains of a few dozen workgroups overlap with the throughput-shaped sampling.
 template <int MT, int NTW, int NW, class NET>
@@ -464,11 +579,41 @@ __global__ __launch_bounds__(64 * NW) void k_ray_samples(NET net, MvTraceParams 
         return;
     }
     b -= sec_blocks;
-    if (b < s0.blocks) mv_eval_rows<MT, NTW, NW, NET>(net, tp, c, s0, b, smem);
-    else if (b - s0.blocks < s1.blocks) mv_eval_rows<MT, NTW, NW, NET>(net, tp, c, s1, b - s0.blocks, smem);
+    // one call site for the row evaluation (a second one doubles the kernel's code: the 32-row fp32 instantiation would no longer fit the
+    // instruction cache): pick segment and chunk range first
+    const bool first = b < s0.blocks;
+    if (!first && b - s0.blocks >= s1.blocks) return;
+    const RowSeg sg = first ? s0 : s1;
+    long long q0 = (long long)(first ? b : b - s0.blocks) * (16 * MT);
+    const int n_list = (int)c.counters[sg.cnt_index];
+    if (sg.unit_rows > 0) {                                      // the row queue k_sphere_trace's finished workgroups already served (tail filling)
+        __shared__ long long s_q0;
+        if (threadIdx.x == 0) s_q0 = (long long)atomicAdd(&c.counters[MV_CNT_TAIL_NEXT], (unsigned long long)(16 * MT));
+        __syncthreads();
+        q0 = s_q0;
+    }
+    mv_eval_rows<MT, NTW, NW, NET>(net, tp, c, sg, q0, smem, n_list);
+}
+// ---------------------------------------------------------------------------------------------------------------
+// tail filling switches: MVSDF_TAIL=1 turns it on (off by default: measured slower); MVSDF_TAIL_PROBE=1 makes mvsdf_trace_tail_probe() return per-workgroup records
+static int mv_tail_mode() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MVSDF_TAIL"); v = e ? atoi(e) : 0; }
+    return v;
+}
+static unsigned* g_tail_probe = nullptr;
+static unsigned* mv_tail_probe() { return g_tail_probe; }
+// dev hook (tools/tail_probe.py): device buffer [workgroups][4] that k_sphere_trace fills with {rounds, units helped, ticks tracing, ticks helping}
+extern "C" void mv_trace_set_tail_probe(unsigned* buf) { g_tail_probe = buf; }
+// the min-sdf rows' own sample-value buffer: the second [R][n_steps] buffer of the workspace (behind the sampler's buffer and the rest lists)
+static float* mv_minsdf_sv(float* ws, int R, int n_steps) {
+    float* sec_state = ws + 2 * (size_t)R;
+    int* w_list = (int*)(sec_state + 4 * (size_t)R);
+    float* sv = (float*)(w_list + 3 * (size_t)R);
+    int* list_rest = (int*)(sv + (size_t)R * n_steps);
+    return (float*)(list_rest + 2 * (size_t)R);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
 template <class NET>
 static size_t trace_lds_bytes(const NET& net, int MT, int sv_floats, int rpw) {
     const int rows = 16 * MT, d0 = 3 + 6 * net.multires;
@@ -478,13 +623,24 @@ static size_t trace_lds_bytes(const NET& net, int MT, int sv_floats, int rpw) {
 
 template <int MT, int NTW, int NW, class NET>
 static hipError_t launch_stage1(const NET& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, const uint8_t* om, int B, int P,
-                                int training, float* points, uint8_t* mask, float* dists, float* ws, unsigned long long* counters,
-                                hipStream_t stream) {
+                                int training, const float* steps, int mt2, float* points, uint8_t* mask, float* dists, float* ws,
+                                unsigned long long* counters, hipStream_t stream) {
     const int R = B * P, NR = 8 * MT;
     float* w_zmin = ws;
     float* w_zmax = w_zmin + R;
     int* w_list = (int*)(w_zmax + 5 * (size_t)R);
     int* w_list_min = w_list + R;
+    TailCtx tail;
+    memset(&tail, 0, sizeof(tail));
+    const int grid1 = (R + NR - 1) / NR;
+    if (training && steps && mv_tail_mode()) {
+        tail.enable = 1;
+        tail.steps = steps;
+        tail.sv = mv_minsdf_sv(ws, R, tp.n_steps);
+        tail.unit_rows = 16 * MT;
+        tail.spin = grid1 <= 256 ? 1 : 0;                       // every workgroup resident (one or more per CU): waiting for work cannot starve a tracer
+        tail.probe = mv_tail_probe();
+    }
     const size_t lds1 = trace_lds_bytes(net, MT, 0, 0);
     static size_t set1 = 0;                                     // raise the dynamic-LDS cap once per size (per instantiation)
     if (lds1 > set1) {
@@ -492,15 +648,15 @@ static hipError_t launch_stage1(const NET& net, const MvTraceParams& tp, const f
         if (e != hipSuccess) return e;
         set1 = lds1;
     }
-    hipLaunchKernelGGL((k_sphere_trace<MT, NTW, NW, NET>), dim3((R + NR - 1) / NR), dim3(64 * NW), lds1, stream, net, tp, cam_loc, dirs, om, R, P,
-                       training, points, mask, dists, w_zmin, w_zmax, w_list, w_list_min, counters);
+    hipLaunchKernelGGL((k_sphere_trace<MT, NTW, NW, NET>), dim3(grid1), dim3(64 * NW), lds1, stream, net, tp, cam_loc, dirs, om, R, P,
+                       training, points, mask, dists, w_zmin, w_zmax, w_list, w_list_min, counters, tail);
     return hipGetLastError();
 }
 
 template <int MT, int NTW, int NW, class NET>
 static hipError_t launch_stage2(const NET& net, const MvTraceParams& tp, const float* cam_loc, const float* dirs, int B, int P, int training,
                                 const float* intervals, const float* steps, float* points, uint8_t* mask, float* dists, float* ws,
-                                unsigned long long* counters, int parts, hipStream_t stream) {
+                                unsigned long long* counters, int parts, int mt1, hipStream_t stream) {
     // parts bit 0: sampler rows + their reduction (the hit mask is FINAL after it); bit 1: secant + min-sdf rows in one launch;
     // bit 2: min-sdf rows + their reduction alone (own sample-value buffer: may run concurrently with bit 0 on another stream); bit 3: secant alone
     const int R = B * P, ROWS = 16 * MT;
@@ -529,28 +685,34 @@ static hipError_t launch_stage2(const NET& net, const MvTraceParams& tp, const f
     // worst-case grids (every ray listed); blocks beyond the device-side counts exit at once
     auto blocks_for = [&](int per_item) { return (int)(((long long)R * per_item + ROWS - 1) / ROWS); };
     const int sec_blocks = (R + 15) / 16, red_blocks = R;                        // one wave per listed ray
-    const RowSeg none = {nullptr, nullptr, 0, 0, 1, 0};
+    const RowSeg none = {nullptr, nullptr, 0, 0, 1, 0, 0};
     if (parts & 1) {
         // sampler rays: first window of nf samples, then the other samples of the rays the window left open
-        const RowSeg first = {w_list, nullptr, (int)MV_CNT_N_SAMPLER, 0, nf, blocks_for(nf)};
+        const RowSeg first = {w_list, nullptr, (int)MV_CNT_N_SAMPLER, 0, nf, blocks_for(nf), 0};
         hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(first.blocks), dim3(64 * NW), lds2, stream, net, tp, c, first, none, 0);
         hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list, (const int*)nullptr, (int)MV_CNT_N_SAMPLER, 0);
         if (nf < n) {
-            const RowSeg rest = {c.list_rest, c.src_rest, (int)MV_CNT_N_SAMPLER_REST, nf, n - nf, blocks_for(n - nf)};
+            const RowSeg rest = {c.list_rest, c.src_rest, (int)MV_CNT_N_SAMPLER_REST, nf, n - nf, blocks_for(n - nf), 0};
             hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(rest.blocks), dim3(64 * NW), lds2, stream, net, tp, c, rest, none, 0);
             hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, c.list_rest, c.src_rest, (int)MV_CNT_N_SAMPLER_REST, 1);
         }
     }
     if (parts & 2) {
-        const RowSeg minsdf = {w_list_min, nullptr, (int)MV_CNT_N_MINSDF, 0, n, training ? blocks_for(n) : 0};
-        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(sec_blocks + minsdf.blocks), dim3(64 * NW), lds2, stream, net, tp, c, minsdf, none,
+        // with tail filling the min-sdf rows are a queue that k_sphere_trace's finished workgroups have already served: own value buffer,
+        // units claimed dynamically (the grid stays worst-case: workgroups without a unit exit at once)
+        const bool tail = training && steps && mv_tail_mode();
+        SampleCtx cm = c;
+        if (tail) cm.sv = mv_minsdf_sv(ws, R, n);
+        const RowSeg minsdf = {w_list_min, nullptr, (int)MV_CNT_N_MINSDF, 0, n, training ? blocks_for(n) + (tail ? 1 : 0) : 0, tail ? 1 : 0};
+        hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(sec_blocks + minsdf.blocks), dim3(64 * NW), lds2, stream, net, tp, cm, minsdf, none,
                            sec_blocks);
-        if (training) hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
+        if (training) hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, cm, w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
     }
     if ((parts & 4) && training) {
         SampleCtx c2 = c;
         c2.sv = (float*)(c.src_rest + R);                        // second sample-value buffer [R * n_steps]
-        const RowSeg minsdf = {w_list_min, nullptr, (int)MV_CNT_N_MINSDF, 0, n, blocks_for(n)};
+        const bool tail = steps && mv_tail_mode();
+        const RowSeg minsdf = {w_list_min, nullptr, (int)MV_CNT_N_MINSDF, 0, n, blocks_for(n) + (tail ? 1 : 0), tail ? 1 : 0};
         hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(minsdf.blocks), dim3(64 * NW), lds2, stream, net, tp, c2, minsdf, none, 0);
         hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c2, w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
     }
@@ -574,8 +736,10 @@ hipError_t mv_trace_launch(int stages, const NET& net, const MvTraceParams& tp, 
     const bool eight = is_bf || (nw_env == 8) || (nw_env != 4 && maxnt >= 16);
     const bool wide = maxnt > 16;
     hipError_t e = hipSuccess;
-#define MV_S1(MT_, NTW_, NW_) e = launch_stage1<MT_, NTW_, NW_>(net, tp, cam_loc, dirs, om, B, P, training, points, mask, dists, ws, counters, stream)
-#define MV_S2(MT_, NTW_, NW_) e = launch_stage2<MT_, NTW_, NW_>(net, tp, cam_loc, dirs, B, P, training, intervals, steps, points, mask, dists, ws, counters, (stages >> 1) & 15, stream)
+    auto eff = [&](int mt) { return wide ? (mt >= 2 ? 2 : 1) : (mt >= 4 ? 4 : (mt >= 2 ? 2 : 1)); };   // the instantiation a requested tile count maps to
+    const int mt1_eff = eff(mt1), mt2_eff = eff(mt2);
+#define MV_S1(MT_, NTW_, NW_) e = launch_stage1<MT_, NTW_, NW_>(net, tp, cam_loc, dirs, om, B, P, training, steps, mt2_eff, points, mask, dists, ws, counters, stream)
+#define MV_S2(MT_, NTW_, NW_) e = launch_stage2<MT_, NTW_, NW_>(net, tp, cam_loc, dirs, B, P, training, intervals, steps, points, mask, dists, ws, counters, (stages >> 1) & 15, mt1_eff, stream)
     if (stages & 1) {
         if (eight) {
             if (wide) { if (mt1 >= 2) MV_S1(2, 4, 8); else MV_S1(1, 4, 8); }
