@@ -51,8 +51,17 @@ WORKLOADS = {                     # name: (pixels per view and GPU-count unit, s
 FEAT_HW = (600, 800)
 P, V = WORKLOADS['c2']            # defaults of make_inputs (dev tools under tools/ set bench.B / bench.P / bench.V and call it)
 PEAK = {'f32': 157.3, 'bf16': 2500.0}    # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32 / bf16)
-# the reference itself on CPU (PyTorch + MKL, imported in the build container): it cannot travel to the GPU box
-REFERENCE_CPU_NOTE = 'reference PyTorch-CPU step on the same c2 batch in the build container (8 vCPU Xeon): 2492 rays/s on 8 threads, 0.82 s/step (BASELINE.md)'
+
+
+def reference_cpu_note():
+    """The reference itself on CPU (PyTorch + MKL): it cannot travel to the GPU box, so it is timed in the build container by
+    tools/time_reference_cpu.py (the golden generator's import shim + the protocol of SURVEY 8d) and carried as data in profiles/reference_cpu.json."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'reference_cpu.json')))
+        per = ', '.join('%s thread(s): %.0f rays/s (%.2f s/step)' % (k, d['rays_per_s'][k], d['seconds_per_step'][k]) for k in sorted(d['rays_per_s'], key=int))
+        return 'the reference PyTorch-CPU step (%s) in the build container (%d cores), tools/time_reference_cpu.py: %s' % (d['workload'], d['container_cores'], per)
+    except (OSError, ValueError, KeyError):
+        return 'no profiles/reference_cpu.json (run tools/time_reference_cpu.py where /root/reference exists)'
 
 
 def flops_per_row(W):
@@ -129,7 +138,7 @@ def cpu_baseline(V, rays_per_view=None, views=None):
     return {'value': R / dt, 'unit': 'rays/s', 'cores': O.num_threads(), 'kind': 'port',
             'sample': '%d views x %d rays of the same scene (W=%d, V=%d): C oracle tracer (OpenMP, %d rows) + numpy float64 value/normal fwd+bwd, '
                       'rendering fwd+bwd, feature loss fwd (its gradient omitted); median of 3 steps after 1 warm-up, %.1f s per step.  For scale: %s'
-                      % (views, rays_per_view, W, V, int(rows.sum()), dt, REFERENCE_CPU_NOTE)}
+                      % (views, rays_per_view, W, V, int(rows.sum()), dt, reference_cpu_note())}
 
 
 def self_launch(a):

@@ -75,6 +75,7 @@ struct TailCtx {
     float* sv;                        // min-sdf sample values [n_items][n_steps] (the second sample-value buffer of the workspace)
     int unit_rows;                    // rows per claimed unit (a multiple of the row tiles of both kernels)
     int enable, spin;                 // spin: every workgroup of the grid is resident, a helper may wait for more work
+    int stop_left;                    // helpers take no new tile once at most this many workgroups still trace
     unsigned* probe;                  // optional [gridDim.x][4]: rounds, units helped, clock ticks tracing, clock ticks helping (dev)
 };
 // results of a workgroup's rays + work-list appends (ray_tracing.py:41-44, 73-94): the statement block k_sphere_trace runs once when its rays are done
@@ -242,22 +243,28 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams
             // ---- tail filling: the next chunk of min-sdf rows (a new unit from the queue when the current one is used up)
             if (h_left == 0) {
                 if (tid == 0) {
+                    // claim by fetch-add (a compare-and-swap loop hands out one tile per memory round trip with ~200 contenders: measured 150 tiles
+                    // in 190 us), then wait until the claimed rows exist: every list item they touch published (ready == reserved, read in that
+                    // order: no append in flight, so all `reserved` items are complete), or the list final (every workgroup done)
                     long long take = -1;
-                    int n_items = 0;                              // the item count the unit was validated against (>= what it touches)
-                    for (int tries = 0; ; ++tries) {
-                        const bool all_done = __hip_atomic_load(&counters[MV_CNT_TAIL_WGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)gridDim.x;
-                        if (all_done) break;                      // the next launch takes the rest with the whole chip
-                        const unsigned long long u = __hip_atomic_load(&counters[MV_CNT_TAIL_NEXT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long rdy = __hip_atomic_load(&counters[MV_CNT_TAIL_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long res = __hip_atomic_load(&counters[MV_CNT_N_MINSDF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (rdy == res && (long long)u + ROWS <= (long long)res * tp.n_steps) {
-                            unsigned long long expect = u;
-                            if (__hip_atomic_compare_exchange_strong(&counters[MV_CNT_TAIL_NEXT], &expect, u + ROWS, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                     __HIP_MEMORY_SCOPE_AGENT)) { take = (long long)u; n_items = (int)res; break; }
-                            continue;                             // another workgroup took it: look again
+                    int n_items = 0;                              // the item count the tile was validated against (>= what it touches)
+                    // no new tile once only a handful of workgroups still trace: a tile started in the kernel's last round outlives it (measured: the
+                    // kernel then ends ~70 us after its slowest tracer)
+                    if (__hip_atomic_load(&counters[MV_CNT_TAIL_WGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (unsigned long long)tail.stop_left < (unsigned long long)gridDim.x) {
+                        const long long u = (long long)__hip_atomic_fetch_add(&counters[MV_CNT_TAIL_NEXT], (unsigned long long)ROWS, __ATOMIC_RELAXED,
+                                                                              __HIP_MEMORY_SCOPE_AGENT);
+                        for (int tries = 0; tries < 100000; ++tries) {
+                            const bool all_done = __hip_atomic_load(&counters[MV_CNT_TAIL_WGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)gridDim.x;
+                            const unsigned long long rdy = __hip_atomic_load(&counters[MV_CNT_TAIL_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned long long res = __hip_atomic_load(&counters[MV_CNT_N_MINSDF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const long long rows = (long long)res * tp.n_steps;
+                            if (rdy == res && (u + ROWS <= rows || (all_done && u < rows))) { take = u; n_items = (int)res; break; }
+                            if (all_done && rdy == res) break;    // the claimed rows lie beyond the end of the (final) list
+                            if (!tail.spin) {                     // not every workgroup is resident: never wait (the rows of an abandoned claim are
+                                break;                            // re-evaluated nowhere: only taken when tail.spin, see launch_stage1)
+                            }
+                            __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
                         }
-                        if (!tail.spin || tries >= 2000) break;
-                        __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);        // a few us between looks: a few hundred idle workgroups must not crowd the counters' line
                     }
                     s_n[0] = (int)take; s_n[1] = n_items;
                 }
@@ -587,6 +594,8 @@ __global__ __launch_bounds__(64 * NW) void k_ray_samples(NET net, MvTraceParams 
     long long q0 = (long long)(first ? b : b - s0.blocks) * (16 * MT);
     const int n_list = (int)c.counters[sg.cnt_index];
     if (sg.unit_rows > 0) {                                      // the row queue k_sphere_trace's finished workgroups already served (tail filling)
+        if (q0 >= (long long)n_list * sg.ni + 16 * MT) return;     // more workgroups than tiles in the whole queue: no claim (one atomic per
+                                                                   // workgroup of the worst-case grid costs ~50 us on one address)
         __shared__ long long s_q0;
         if (threadIdx.x == 0) s_q0 = (long long)atomicAdd(&c.counters[MV_CNT_TAIL_NEXT], (unsigned long long)(16 * MT));
         __syncthreads();
@@ -595,10 +604,10 @@ __global__ __launch_bounds__(64 * NW) void k_ray_samples(NET net, MvTraceParams 
     mv_eval_rows<MT, NTW, NW, NET>(net, tp, c, sg, q0, smem, n_list);
 }
 // ---------------------------------------------------------------------------------------------------------------
-// tail filling switches: MVSDF_TAIL=1 turns it on (off by default: measured slower); MVSDF_TAIL_PROBE=1 makes mvsdf_trace_tail_probe() return per-workgroup records
+// tail filling switches: MVSDF_TAIL=0 turns it off, MVSDF_TAIL=2 also enables it for the bf16 engine (measured slower there: DESIGN.md); MVSDF_TAIL_PROBE=1 makes mvsdf_trace_tail_probe() return per-workgroup records
 static int mv_tail_mode() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("MVSDF_TAIL"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char* e = getenv("MVSDF_TAIL"); v = e ? atoi(e) : 1; }
     return v;
 }
 static unsigned* g_tail_probe = nullptr;
@@ -612,6 +621,15 @@ static float* mv_minsdf_sv(float* ws, int R, int n_steps) {
     float* sv = (float*)(w_list + 3 * (size_t)R);
     int* list_rest = (int*)(sv + (size_t)R * n_steps);
     return (float*)(list_rest + 2 * (size_t)R);
+}
+
+// is the tail filling on for this call?  (mt1: row tiles per sphere-tracing workgroup.)  Only when every sphere-tracing workgroup is resident
+// at once (<= 256 of them): a helper waits for its claimed rows to be published by workgroups that must be running.
+template <class NET>
+static bool mv_tail_on(int training, const float* steps, int R, int mt1) {
+    constexpr bool is_bf = !std::is_same<NET, MvNet>::value;
+    const int grid1 = (R + 8 * mt1 - 1) / (8 * mt1);
+    return training && steps && mv_tail_mode() >= (is_bf ? 2 : 1) && grid1 <= 256;
 }
 
 template <class NET>
@@ -633,13 +651,18 @@ static hipError_t launch_stage1(const NET& net, const MvTraceParams& tp, const f
     TailCtx tail;
     memset(&tail, 0, sizeof(tail));
     const int grid1 = (R + NR - 1) / NR;
-    if (training && steps && mv_tail_mode()) {
+    // fp32 engine only: with the bf16 engine a tile takes half the time, the launch that follows is bound by its secant chains and the helpers
+    // cost the sphere kernel more than they save (measured: c2 +10 us, c5share +20 us per step)
+    if (mv_tail_on<NET>(training, steps, R, MT)) {
         tail.enable = 1;
         tail.steps = steps;
         tail.sv = mv_minsdf_sv(ws, R, tp.n_steps);
         tail.unit_rows = 16 * MT;
         tail.spin = grid1 <= 256 ? 1 : 0;                       // every workgroup resident (one or more per CU): waiting for work cannot starve a tracer
         tail.probe = mv_tail_probe();
+        static int stop_env = -1;
+        if (stop_env < 0) { const char* e = getenv("MVSDF_TAIL_STOP"); stop_env = e ? atoi(e) : -1; }
+        tail.stop_left = stop_env >= 0 ? stop_env : grid1 / 4;      // (swept at c2: 0 / 16 / 32 / 48 / 64 of 256 -> tracer 1575 / 1527 / 1521 / 1507 / 1507 us, off: 1549)
     }
     const size_t lds1 = trace_lds_bytes(net, MT, 0, 0);
     static size_t set1 = 0;                                     // raise the dynamic-LDS cap once per size (per instantiation)
@@ -700,7 +723,7 @@ static hipError_t launch_stage2(const NET& net, const MvTraceParams& tp, const f
     if (parts & 2) {
         // with tail filling the min-sdf rows are a queue that k_sphere_trace's finished workgroups have already served: own value buffer,
         // units claimed dynamically (the grid stays worst-case: workgroups without a unit exit at once)
-        const bool tail = training && steps && mv_tail_mode();
+        const bool tail = mv_tail_on<NET>(training, steps, R, mt1);
         SampleCtx cm = c;
         if (tail) cm.sv = mv_minsdf_sv(ws, R, n);
         const RowSeg minsdf = {w_list_min, nullptr, (int)MV_CNT_N_MINSDF, 0, n, training ? blocks_for(n) + (tail ? 1 : 0) : 0, tail ? 1 : 0};
@@ -711,7 +734,7 @@ static hipError_t launch_stage2(const NET& net, const MvTraceParams& tp, const f
     if ((parts & 4) && training) {
         SampleCtx c2 = c;
         c2.sv = (float*)(c.src_rest + R);                        // second sample-value buffer [R * n_steps]
-        const bool tail = steps && mv_tail_mode();
+        const bool tail = mv_tail_on<NET>(training, steps, R, mt1);
         const RowSeg minsdf = {w_list_min, nullptr, (int)MV_CNT_N_MINSDF, 0, n, blocks_for(n) + (tail ? 1 : 0), tail ? 1 : 0};
         hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(minsdf.blocks), dim3(64 * NW), lds2, stream, net, tp, c2, minsdf, none, 0);
         hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c2, w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
