@@ -32,7 +32,10 @@ typedef struct {
     int multires;                       /* positional-encoding frequencies (embedder.py:38-50) */
     const void* wp16[MVSDF_MAX_LAYERS]; /* bf16 packs made by mvsdf_pack_bf16_net (BASELINE configs[4]); NULL unless trace_dtype == 1 */
     int trace_dtype;                    /* arithmetic of the no-grad tracing MLP (mvsdf_trace, mvsdf_sdf_col0): 0 = fp32 weights and fp32-input
-                                         * MFMA (bit-exact against the oracle), 1 = bf16 weights / activations on the bf16 MFMA, fp32 accumulate */
+                                         * MFMA (bit-exact against the oracle), 1 = bf16 weights / activations on the bf16 MFMA, fp32 accumulate,
+                                         * 2 = bf16-ROUNDED WEIGHTS ONLY: wp16[l] holds an fp32 pack (mvsdf_packed_floats(N, K) floats, made by
+                                         * mvsdf_pack_bf16w_net) of the weights rounded to bf16, activations stay fp32 on the fp32-input MFMA -- bit-exact
+                                         * against the oracle run on the rounded weights; what rounding the activations too (mode 1) costs is then a number */
     unsigned skip_mask;                 /* several skip connections (skip_in with more than one entry, idr.py:46,86): bit l set = the input of layer l
                                          * is cat([x, PE(x)])/sqrt(2).  0 = use skip_layer alone.  Layer 0 and the last layer cannot be skip layers. */
 } MvsdfNetDesc;
@@ -100,6 +103,8 @@ int mvsdf_fold_backward(const float* v, const float* g, const float* dW, int N, 
 size_t mvsdf_packed_bf16_bytes(int N, int K, int nsplit);
 int mvsdf_pack_bf16_net(int n_layers, const float* const* w, const int* N, const int* K, int skip_layer, int multires, void* const* wp16,
                         void* stream);
+/* trace_dtype = 2: fp32 MFMA packs (layout of mvsdf_fold_pack's wp) of the folded weights w[l] rounded to bf16 (nearest even) */
+int mvsdf_pack_bf16w_net(int n_layers, const float* const* w, const int* N, const int* K, float* const* wp_rounded, void* stream);
 /* the same for a network with several skip connections (MvsdfNetDesc.skip_mask) */
 int mvsdf_pack_bf16_net_skips(int n_layers, const float* const* w, const int* N, const int* K, unsigned skip_mask, int multires, void* const* wp16,
                               void* stream);
@@ -336,7 +341,7 @@ typedef struct {
     unsigned skip_mask;                    /* bit l: the input of SDF layer l is cat([x, PE(x)]) / sqrt(2) (idr.py:86-87) */
     int multires;                          /* PE frequencies of the SDF net */
     int view_spec;                         /* multires_view | mode bits, as mvsdf_render_forward takes them */
-    int trace_dtype;                       /* 0: fp32 tracing MLP; 1: bf16 packs are made each forward and the tracer uses them */
+    int trace_dtype;                       /* 0: fp32 tracing MLP; 1: bf16 packs are made each forward and the tracer uses them; 2: fp32 packs of the bf16-rounded weights (MvsdfNetDesc.trace_dtype) */
     int use_object_mask;                   /* conf.use_mask (idr.py:187): 0 = the ray partition ignores object_mask */
     MvsdfTraceParams tp;
     int mt, mt_samples;                    /* tiling of the tracer kernels (see mvsdf_trace) */

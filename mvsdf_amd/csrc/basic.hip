@@ -227,6 +227,21 @@ __global__ void k_pack_bf16_net(PackBfArgs a) {
     }
 }
 
+// trace_dtype = 2: fp32 packs of the bf16-rounded weights (layout of k_pack, non-transposed)
+__global__ void k_pack_round_net(PackBfArgs a) {
+    const int l = blockIdx.y;
+    const int N = a.N[l], K = a.K[l], KB = mv_kpad(K) / 16;
+    float* wp = (float*)a.wp[l];
+    const size_t total = mv_packed_floats(N, K);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int s = idx & 3, lane = (idx >> 2) & 63;
+        const size_t blk = idx >> 8;
+        const int kb = (int)(blk % KB), ct = (int)(blk / KB);
+        const int o = ct * 16 + (lane & 15), i = kb * 16 + 4 * s + (lane >> 4);
+        wp[idx] = (o < N && i < K) ? mv_bf2f(mv_f2bf(a.w[l][(size_t)o * K + i])) : 0.0f;
+    }
+}
+
 template <int MT, int NTW>
 __global__ __launch_bounds__(512) void k_sdf_col0_bf(MvNetBf net, const float* __restrict__ x, int n, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -456,6 +471,22 @@ int mvsdf_pack_bf16_net_skips(int n_layers, const float* const* w, const int* N,
     return mv_check(hipGetLastError(), "mvsdf_pack_bf16_net");
 }
 
+int mvsdf_pack_bf16w_net(int n_layers, const float* const* w, const int* N, const int* K, float* const* wp_rounded, void* stream) {
+    if (n_layers < 1 || n_layers > MV_MAXL || !w || !N || !K || !wp_rounded) return mv_fail(-1, "mvsdf_pack_bf16w_net: bad arguments");
+    PackBfArgs a;
+    memset(&a, 0, sizeof(a));
+    size_t maxTot = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!w[l] || !wp_rounded[l] || N[l] <= 0 || K[l] <= 0) return mv_fail(-1, "mvsdf_pack_bf16w_net: null layer pointer / bad dims");
+        a.w[l] = w[l]; a.wp[l] = (uint16_t*)wp_rounded[l]; a.N[l] = N[l]; a.K[l] = K[l];
+        const size_t t = mv_packed_floats(N[l], K[l]);
+        if (t > maxTot) maxTot = t;
+    }
+    const int blocks = (int)((maxTot + 255) / 256 < 256 ? (maxTot + 255) / 256 : 256);
+    hipLaunchKernelGGL(k_pack_round_net, dim3(blocks, n_layers), dim3(256), 0, (hipStream_t)stream, a);
+    return mv_check(hipGetLastError(), "mvsdf_pack_bf16w_net");
+}
+
 int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, int mt, void* stream) {
     if (!x || !y || n <= 0) return mv_fail(-1, "mvsdf_sdf_col0: bad arguments");
     hipStream_t s = (hipStream_t)stream;
@@ -472,7 +503,7 @@ int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, in
         return launch_col0_bf<1, 2>(nb, x, n, y, s);
     }
     MvNet net;
-    int rc = mv_make_net(desc, &net);
+    int rc = mv_make_net_trace(desc, &net);
     if (rc) return rc;
     if (mt == 33) {                                             // throughput regime: row-owner waves, weights staged in LDS
         int mx = 0, mk = 0;
@@ -523,6 +554,7 @@ struct ProloArgs {
     FoldNetArgs f;
     int blk0[MV_FOLD_MAXL + 1];          // first workgroup of each layer; blk0[n_layers] = first ray workgroup
     uint16_t* wp16[MV_FOLD_MAXL]; int nsplit[MV_FOLD_MAXL];
+    int wp16_fp32;                       // 1: wp16[l] receives the fp32 pack of the bf16-rounded weights (trace_dtype = 2) instead of the bf16 pack
     const float* uv; const float* pose; const float* Kin; int B, P; float* dirs; float* cam_loc;
     int ld;                              // LDS row stride (floats) >= max K
 };
@@ -607,7 +639,14 @@ __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
         }
     }
     // ---- bf16 pack of the tracing MLP: tile row ct = rg
-    if (a.wp16[l] && rg < NT) {
+    if (a.wp16[l] && rg < NT && a.wp16_fp32) {                                 // trace_dtype = 2: the W pack again, values rounded to bf16
+        float* dst = (float*)a.wp16[l] + (size_t)rg * KB * 256;
+        for (int idx = tid; idx < KB * 256; idx += 1024) {
+            const int s = idx & 3, ln = (idx >> 2) & 63, kb = idx >> 8;
+            const int ol = ln & 15, i = kb * 16 + 4 * s + (ln >> 4);
+            dst[idx] = (i < K) ? mv_bf2f(mv_f2bf(tile[ol * ld + i])) : 0.0f;
+        }
+    } else if (a.wp16[l] && rg < NT) {
         const int ns = a.nsplit[l], KB32 = mv_bf_kb(K, ns);
         uint16_t* dst = a.wp16[l] + (size_t)rg * KB32 * 512;
         for (int idx = tid; idx < KB32 * 512; idx += 1024) {
@@ -620,7 +659,7 @@ __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
 }
 
 int mv_step_prologue(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w, float* const* wp,
-                     float* const* wpT, void* const* wp16, const int* nsplit, const float* uv, const float* pose, const float* intrinsics, int B, int P,
+                     float* const* wpT, void* const* wp16, const int* nsplit, int wp16_fp32, const float* uv, const float* pose, const float* intrinsics, int B, int P,
                      float* ray_dirs, float* cam_loc, void* stream) {
     ProloArgs a;
     int maxN; size_t maxTot;
@@ -638,6 +677,7 @@ int mv_step_prologue(int n_layers, const float* const* v, const float* const* g,
     for (int l = n_layers; l < MV_FOLD_MAXL; ++l) { a.wp16[l] = nullptr; a.nsplit[l] = 0; a.blk0[l] = blk; }
     a.blk0[n_layers] = blk;
     a.uv = uv; a.pose = pose; a.Kin = intrinsics; a.B = B; a.P = P; a.dirs = ray_dirs; a.cam_loc = cam_loc;
+    a.wp16_fp32 = wp16_fp32 ? 1 : 0;
     a.ld = ((maxK + 3) & ~3) + 4;
     const size_t lds = (size_t)16 * a.ld * sizeof(float);
     blk += (B * P + 1023) / 1024;

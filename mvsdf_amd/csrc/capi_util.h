@@ -11,6 +11,7 @@ int mv_check(hipError_t e, const char* where);   // 0 on success
 int mv_make_net_mode(const MvsdfNetDesc* d, MvNet* net, int mode);
 static inline int mv_make_net(const MvsdfNetDesc* d, MvNet* net) { return mv_make_net_mode(d, net, 0); }
 int mv_make_net_bf(const MvsdfNetDesc* d, MvNetBf* net);      // SDF net on the bf16 packs (trace_dtype == 1)
+int mv_make_net_trace(const MvsdfNetDesc* d, MvNet* net);     // the fp32-engine tracing net: the fp32 packs, or (trace_dtype == 2) the fp32 packs of the bf16-rounded weights
 // skip layers of a descriptor as a bit mask (skip_mask wins; else the single skip_layer)
 static inline unsigned mv_desc_skip_mask(const MvsdfNetDesc* d) { return d->skip_mask ? d->skip_mask : (d->skip_layer >= 0 ? 1u << d->skip_layer : 0u); }
 static inline int mv_bf_nsplit(const MvsdfNetDesc* d, int l) { return (l == 0 || mv_skip_at(mv_desc_skip_mask(d), l)) ? 3 + 6 * d->multires : 0; }

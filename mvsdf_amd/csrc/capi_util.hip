@@ -46,6 +46,16 @@ int mv_make_net_mode(const MvsdfNetDesc* d, MvNet* net, int mode) {
     return 0;
 }
 
+int mv_make_net_trace(const MvsdfNetDesc* d, MvNet* net) {
+    if (!d || d->trace_dtype != 2) return mv_make_net(d, net);
+    MvsdfNetDesc r = *d;
+    for (int l = 0; l < d->n_layers && l < MVSDF_MAX_LAYERS; ++l) {
+        if (!d->wp16[l]) return mv_fail(-2, "net descriptor: trace_dtype = 2 without the rounded packs (mvsdf_pack_bf16w_net)");
+        r.wp[l] = (const float*)d->wp16[l];
+    }
+    return mv_make_net(&r, net);
+}
+
 int mv_make_net_bf(const MvsdfNetDesc* d, MvNetBf* net) {
     MvNet chk;
     int rc = mv_make_net_mode(d, &chk, 0);                       // same structural checks as the fp32 net

@@ -59,7 +59,7 @@ void make_descs(const Step& st, const MvsdfStepParams* prm, const char* fwd, Mvs
             oT->wp[i] = (const float*)(fwd + st.fo.wpT[l]);
             o->bias[i] = oT->bias[i] = prm->b[l];
             o->w[i] = oT->w[i] = (const float*)(fwd + st.fo.w[l]);
-            if (is_sdf && d.trace_dtype == 1) o->wp16[i] = fwd + st.fo.wp16[l];
+            if (is_sdf && d.trace_dtype != 0) o->wp16[i] = fwd + st.fo.wp16[l];
         }
         if (is_sdf) {
             const unsigned m = d.skip_mask;
@@ -67,7 +67,7 @@ void make_descs(const Step& st, const MvsdfStepParams* prm, const char* fwd, Mvs
             o->skip_layer = oT->skip_layer = m ? (single >= 0 ? single : __builtin_ctz(m)) : -1;
             o->skip_mask = (m && single < 0) ? m : 0;
             o->multires = oT->multires = d.multires;
-            o->trace_dtype = d.trace_dtype == 1 ? 1 : 0;
+            o->trace_dtype = (d.trace_dtype == 1 || d.trace_dtype == 2) ? d.trace_dtype : 0;
         } else {
             o->skip_layer = oT->skip_layer = -1;
         }
@@ -146,6 +146,8 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
         if (l < d.n_sdf && d.trace_dtype == 1) {
             const int ns = (l == 0 || ((d.skip_mask >> l) & 1u)) ? 3 + 6 * d.multires : 0;
             fo.wp16[l] = take(mvsdf_packed_bf16_bytes(d.N[l], d.K[l], ns));
+        } else if (l < d.n_sdf && d.trace_dtype == 2) {
+            fo.wp16[l] = take(mvsdf_packed_floats(d.N[l], d.K[l]) * 4);
         }
     }
     L.perm = take((size_t)R * 8); fo.inv = take((size_t)R * 8); fo.true_rows = take((size_t)R * 8); fo.true_rank = take((size_t)R * 4); fo.counts = take(4 * 8);
@@ -254,12 +256,12 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     {
         void* wp16[MVSDF_STEP_MAX_LAYERS]; int nsplit[MVSDF_STEP_MAX_LAYERS];
         for (int l = 0; l < nl; ++l) {
-            const bool bf = l < d.n_sdf && d.trace_dtype == 1;
+            const bool bf = l < d.n_sdf && d.trace_dtype != 0;
             wp16[l] = bf ? (void*)(fwd + fo.wp16[l]) : nullptr;
-            nsplit[l] = (bf && (l == 0 || ((d.skip_mask >> l) & 1u))) ? 3 + 6 * d.multires : 0;
+            nsplit[l] = (bf && d.trace_dtype == 1 && (l == 0 || ((d.skip_mask >> l) & 1u))) ? 3 + 6 * d.multires : 0;
         }
         // ... and the camera rays (idr.py:190), all in one launch
-        ST_TRY(mv_step_prologue(nl, prm->v, prm->g, d.N, d.K, w, wp, wpT, wp16, nsplit, in->uv, in->pose, in->intrinsics, d.B, d.P, ray_dirs, cam_loc, stream));
+        ST_TRY(mv_step_prologue(nl, prm->v, prm->g, d.N, d.K, w, wp, wpT, wp16, nsplit, d.trace_dtype == 2 ? 1 : 0, in->uv, in->pose, in->intrinsics, d.B, d.P, ray_dirs, cam_loc, stream));
     }
     MvsdfNetDesc sdf, sdfT, rnd, rndT;
     make_descs(*st, prm, fwd, &sdf, &sdfT, &rnd, &rndT);

@@ -27,5 +27,5 @@ int mv_step_wgrad(int part, const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int 
 // fold + MFMA packs (+ bf16 packs where wp16[l] is set: nsplit[l] = its PE split width) of every layer + the camera rays in ONE launch
 // (basic.hip::k_step_prologue): the work of mvsdf_fold_pack_net, mvsdf_pack_bf16_net_skips and mvsdf_camera_rays, same results
 int mv_step_prologue(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w, float* const* wp,
-                     float* const* wpT, void* const* wp16, const int* nsplit, const float* uv, const float* pose, const float* intrinsics, int B, int P,
+                     float* const* wpT, void* const* wp16, const int* nsplit, int wp16_fp32, const float* uv, const float* pose, const float* intrinsics, int B, int P,
                      float* ray_dirs, float* cam_loc, void* stream);

@@ -1050,7 +1050,7 @@ static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTracePara
     MvNet net;
     MvNetBf netb;
     const bool bf = desc && desc->trace_dtype == 1;
-    int rc = bf ? mv_make_net_bf(desc, &netb) : mv_make_net(desc, &net);
+    int rc = bf ? mv_make_net_bf(desc, &netb) : mv_make_net_trace(desc, &net);
     if (rc) return rc;
     if (!tp || !cam_loc || !ray_dirs || !object_mask || !intervals || !points || !mask || !dists || !counters || !workspace)
         return mv_fail(-1, "mvsdf_trace: null argument");

@@ -115,8 +115,9 @@ class ImplicitNetwork(nn.Module):
 
     def native_sdf(self):
         net = self.fold()[0]
-        if getattr(self, 'trace_dtype', 'f32') == 'bf16':
-            ops.pack_bf16_net(net)
+        td = getattr(self, 'trace_dtype', 'f32')
+        if td != 'f32':
+            ops.pack_bf16_net(net, weights_only=(td == 'bf16w'))
         return NativeSDF(net)
 
     def forward(self, input, compute_grad=False):
@@ -293,8 +294,10 @@ class IDRNetwork(nn.Module):
     def set_trace_dtype(self, dtype):
         """'f32' (default: fp32 weights, fp32-input MFMA, bit-exact against the oracle) or 'bf16' (BASELINE configs[4]: the ray tracer's SDF
         evaluations -- ~90 % of the step's FLOPs, all under no_grad -- use bf16-rounded weights and activations on the bf16 MFMA with fp32
-        accumulation; the differentiable passes keep fp32).  Outside the 1e-4 parity claim: see DESIGN.md for the accuracy budget."""
-        assert dtype in ('f32', 'bf16')
+        accumulation; the differentiable passes keep fp32).  Outside the 1e-4 parity claim: see DESIGN.md for the accuracy budget.
+        'bf16w': only the tracing MLP's WEIGHTS are rounded to bf16 (BASELINE configs[4] says "bf16 MLP weights"), activations and arithmetic
+        stay fp32 on the fp32 MFMA: bit-exact against the oracle on the rounded weights; the control that prices the activation rounding."""
+        assert dtype in ('f32', 'bf16', 'bf16w')
         self.trace_dtype = dtype
         self.implicit_network.trace_dtype = dtype
         return self
@@ -340,8 +343,8 @@ class IDRNetwork(nn.Module):
             ws = bs = rws = rbs = None
         else:
             (net, ws, bs), (rnet, rws, rbs) = Fn.fold_networks([self.implicit_network.fold_spec(), self.rendering_network.fold_spec()])
-        if self.trace_dtype == 'bf16':
-            ops.pack_bf16_net(net)                                # one more launch per step: bf16 packs for the tracer
+        if self.trace_dtype != 'f32':
+            ops.pack_bf16_net(net, weights_only=(self.trace_dtype == 'bf16w'))     # one more launch per step: bf16 / rounded packs for the tracer
         n_dsurf_points, dsurf = 0, None
         if self.training:
             assert train_progress is not None
@@ -496,7 +499,7 @@ class IDRNetwork(nn.Module):
             skips = skips if isinstance(skips, (tuple, list)) else ((skips,) if skips >= 0 else ())
             d.skip_mask = sum(1 << int(sk) for sk in skips)
             d.multires, d.view_spec = multires, rnet.view_spec
-            d.trace_dtype = 1 if self.trace_dtype == 'bf16' else 0
+            d.trace_dtype = {'f32': 0, 'bf16': 1, 'bf16w': 2}[self.trace_dtype]
             d.use_object_mask = 1 if conf.use_mask else 0
             d.tp = NS.TraceParams(*tpv)
             d.mt, d.mt_samples = mt, mt_samples

@@ -48,7 +48,9 @@ class Net:
 
     def __init__(self, state, prefix='implicit_network', skip_in=(4,), multires=6, bf16=False):
         self.multires = multires
-        self.bf16 = bf16                                      # bf16 twin (BASELINE configs[4]): weights rounded here, activations in C
+        # bf16 twin (BASELINE configs[4]): weights rounded here, activations in C.  bf16='weights': only the weights are rounded (the twin of
+        # trace_dtype 2: fp32 activations and arithmetic on bf16-rounded weights)
+        self.bf16 = bool(bf16) and bf16 != 'weights'
         self.W, self.b = [], []
         l = 0
         while '%s.lin%d.weight_v' % (prefix, l) in state:

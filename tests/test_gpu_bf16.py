@@ -65,6 +65,11 @@ def test_bf16_tracer_vs_oracle_twin_and_reference_golden(oracle, W, mode):
     rel_r = np.abs(dists - g['dists'])[both] / np.abs(g['dists'][both])
     print('W=%d %s vs fp32 reference: masks agree %.4f, hit depth rel max %.3g 99%% %.3g median %.3g' % (W, mode, agree_r, rel_r.max(), np.percentile(rel_r, 99), np.median(rel_r)))
     assert agree_r >= 0.98 and np.percentile(rel_r, 99) < 5e-3 and np.median(rel_r) < 5e-4
+    # the TAIL, not only percentiles: a regression that doubles the outliers must fail.  Measured: W=256 max 1.6e-3, none beyond 1e-2;
+    # W=64 train max 7.3e-2, 7 of 3419 rays beyond 1e-2 (the narrow net's surface has thin features the 8-bit mantissas miss)
+    n_bad = int((rel_r > 1e-2).sum())
+    print('   tail: max %.3g, rays with depth error > 1e-2: %d of %d' % (rel_r.max(), n_bad, rel_r.size))
+    assert rel_r.max() < (0.15 if W == 64 else 1e-2) and n_bad <= (12 if W == 64 else 0)
     # all chunkings give the same result (rows are independent)
     p2, m2, d2, _ = ops.trace(net, cam, dirs, om, trace_params(W), training, iv.cuda(), t(g['minsdf_steps']), mt=2, mt_samples=4)
     assert np.array_equal(m2.cpu().numpy(), mask) and np.array_equal(d2.cpu().numpy(), dists)
@@ -127,9 +132,89 @@ def test_bf16_step_at_the_c5_per_gpu_shape_vs_the_fp32_reference():
     lo = IDRLoss()(out, {k: t(v) for k, v in gt.items()}, tp, B)
     print('c5 share, bf16 tracer vs fp32 reference: masks agree %.4f, depth rel p99 %.3g max %.3g' % (agree, np.percentile(rel, 99), rel.max()))
     assert agree >= 0.995 and np.percentile(rel, 99) < 2e-3
+    n_bad = int((rel > 1e-2).sum())                               # the tail (measured: max 6e-3, none beyond 1e-2)
+    print('   tail: rays with depth error > 1e-2: %d of %d' % (n_bad, rel.size))
+    assert rel.max() < 1.5e-2 and n_bad <= 1
     for k in ('loss', 'rgb_loss', 'eikonal_loss', 'depth_loss', 'feat_loss', 'surf_loss'):
         v, ref = float(lo[k].detach().reshape(-1)[0]), float(g['loss_' + k])
         print('   %s %.6g (reference %.6g)' % (k, v, ref))
         assert abs(v - ref) <= 0.03 * max(abs(ref), 1e-3), (k, v, ref)
     lo['loss'].backward()
     assert torch.isfinite(torch.cat([p.grad.flatten() for p in m.parameters()])).all()
+
+
+# ---- weights-only bf16 (trace_dtype 2, IDRNetwork.set_trace_dtype('bf16w')): bf16-rounded weights, fp32 activations on the fp32 MFMA.
+# BASELINE configs[4] asks for "bf16 MLP weights"; this mode is exactly that and nothing more, and it is BIT-CHECKABLE: the fp32 engine on
+# rounded weights equals the oracle on rounded weights.  Against it the full bf16 engine's extra error (activation rounding) is a number.
+@pytest.mark.parametrize('W', [64, 256, 512])
+def test_weights_only_bf16_mlp_bit_exact_vs_oracle(oracle, W):
+    sd = synth.make_state_dict(W, 0)
+    net = ops.pack_bf16_net(sdf_packed_net(sd), weights_only=True)
+    rs = np.random.RandomState(3)
+    x = rs.uniform(-1.2, 1.2, size=(4000, 3)).astype(np.float32)
+    ref = oracle.sdf_forward(oracle.Net(sd, bf16='weights'), x, ncols=1)[:, 0]
+    f32 = oracle.sdf_forward(oracle.Net(sd), x, ncols=1)[:, 0]
+    for mt in (1, 2, 4):
+        y = ops.sdf_col0(net, t(x), mt=mt).cpu().numpy()
+        assert np.array_equal(y, ref), 'mt=%d max diff %g' % (mt, np.abs(y - ref).max())
+    print('W=%d weights-only bf16 vs fp32 network: max %.3g mean %.3g' % (W, np.abs(ref - f32).max(), np.abs(ref - f32).mean()))
+    assert not np.array_equal(ref, f32)
+
+
+@pytest.mark.parametrize('W,mode', [(64, 'train'), (256, 'eval'), (256, 'train')])
+def test_weights_only_bf16_tracer_bit_exact_vs_oracle_and_budget(oracle, W, mode):
+    g = golden('trace_mlp_w%d_%s' % (W, mode))
+    sd = synth.make_state_dict(W, int(g['seed']))
+    net = ops.pack_bf16_net(sdf_packed_net(sd), weights_only=True)
+    B, P = int(g['B']), int(g['P'])
+    cam, dirs = t(g['cam_loc']), t(g['ray_dirs']).reshape(B, P, 3)
+    om = torch.ones(B * P, dtype=torch.bool, device='cuda')
+    training = mode == 'train'
+    iv = torch.linspace(0, 1, 100)
+    pts, mask, dists, cnt = ops.trace(net, cam, dirs, om, trace_params(W), training, iv.cuda(), t(g['minsdf_steps']), mt=1, mt_samples=2)
+    p_o, m_o, d_o, rows = oracle.trace(oracle.Net(sd, bf16='weights'), g['cam_loc'], g['ray_dirs'], np.ones(B * P, bool), training, g['minsdf_steps'],
+                                       iv.numpy(), **synth.model_conf(W)['ray_tracer'])
+    mask, dists = mask.cpu().numpy(), dists.cpu().numpy()
+    assert np.array_equal(mask, m_o) and np.array_equal(dists, d_o) and np.array_equal(pts.cpu().numpy(), p_o)     # bit for bit
+    assert np.array_equal(cnt.cpu().numpy()[:4], rows)
+    agree_r = (mask == g['mask']).mean()
+    both = mask & g['mask']
+    rel_r = np.abs(dists - g['dists'])[both] / np.abs(g['dists'][both])
+    print('W=%d %s weights-only bf16 vs fp32 reference: masks agree %.4f, hit depth rel max %.3g 99%% %.3g median %.3g, rays > 1e-2: %d' % (
+        W, mode, agree_r, rel_r.max(), np.percentile(rel_r, 99), np.median(rel_r), int((rel_r > 1e-2).sum())))
+    assert agree_r >= 0.98 and np.percentile(rel_r, 99) < 5e-3
+
+
+def test_what_rounding_the_activations_costs_at_the_c5_share():
+    """idr_c5share (fp32 reference, 4096 rays, V = 8): the step with the weights-only-bf16 tracer and with the full bf16 engine side by side --
+    mask agreement, depth error percentiles / maximum, loss deviation.  The difference between the two columns is the price of rounding
+    the activations (and of the hardware exp / log softplus) on top of what BASELINE's "bf16 MLP weights" asks for."""
+    from mvsdf_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from mvsdf_amd.model.loss import IDRLoss
+    from mvsdf_amd.utils.config import ConfigDict
+    g = golden('idr_c5share')
+    W, B, P, V, seed, tp = int(g['W']), int(g['B']), int(g['P']), int(g['V']), int(g['seed']), float(g['tp'])
+    inp, gt = synth.make_batch(B, P, V, seed=seed, size=float(g['scene_size']), center=tuple(g['scene_center']),
+                               feat_hw=tuple(int(v) for v in g['feat_hw']), focal_scale=float(g['focal_scale']))
+    cam = np.repeat(inp['pose'][:, :3, 3], P, axis=0)
+    dref = np.linalg.norm(g['out_points'] - cam, axis=1)
+    mref = g['out_network_object_mask']
+    res = {}
+    for dt in ('f32', 'bf16w', 'bf16'):
+        m = IDRNetwork(ConfigDict(synth.model_conf(W)))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(W, seed).items()})
+        m = m.cuda().train().set_trace_dtype(dt)
+        torch.manual_seed(seed + 5)
+        out = m({k: t(v) for k, v in inp.items()}, tp)
+        mask = out['network_object_mask'].cpu().numpy()
+        both = mask & mref
+        depth = np.linalg.norm(out['points'].detach().cpu().numpy() - cam, axis=1)
+        rel = np.abs(depth - dref)[both] / dref[both]
+        lo = IDRLoss()(out, {k: t(v) for k, v in gt.items()}, tp, B)
+        dl = max(abs(float(lo[k].detach().reshape(-1)[0]) - float(g['loss_' + k])) / max(abs(float(g['loss_' + k])), 1e-3)
+                 for k in ('loss', 'rgb_loss', 'eikonal_loss', 'depth_loss', 'feat_loss', 'surf_loss'))
+        res[dt] = (float((mask == mref).mean()), float(np.median(rel)), float(np.percentile(rel, 99)), float(rel.max()), int((rel > 1e-2).sum()), dl)
+        print('c5 share, tracer %-5s vs fp32 reference: masks agree %.4f, depth rel median %.3g p99 %.3g max %.3g, rays > 1e-2: %d, worst loss term off by %.3g' % ((dt,) + res[dt]))
+    assert res['f32'][0] == 1.0 and res['f32'][3] < 1e-4
+    assert res['bf16w'][0] >= 0.995 and res['bf16w'][2] < 2e-3
+    assert res['bf16w'][2] <= res['bf16'][2] * 1.5 + 1e-4          # the weights-only mode is not (much) worse than the full bf16 engine anywhere
