@@ -230,12 +230,20 @@ def main():
     opt = FlatAdam(model.parameters(), lr=0.0)
     inp, gt = make_inputs(dev, rank, world, P, V)
 
+    grad_events = None                                           # set to a list during the extra steps: (start, end) events around the gradient all-reduce
+
     def step():
         opt.zero_grad()
         out = model(inp, TP)
         lo = loss_fn(out, dict(gt), TP, per)
         opt.backward(lo['loss'])                                 # loss.backward() with the direct gradient sink (one launch for all dv/dg/db)
+        if grad_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         opt.all_reduce_mean(defer_scale=True)                    # ONE all-reduce(SUM) of the flat gradient buffer; / world inside Adam
+        if grad_events is not None:
+            ev[1].record()
+            grad_events.append(ev)
         opt.step(grad_cap=2.0)                                   # grad-norm + clip + Adam (idr_train.py:289-302, conf.grad_cap)
         return out, lo
 
@@ -264,6 +272,9 @@ def main():
     nt = 20
     st_native = getattr(model, '_last_step', None) if model.native_step else None
     tms = []
+    if under_launcher:                                           # ... and of the two collectives (HIP events on the compute stream around each call)
+        grad_events = []
+        loss_fn.collective_events = []
     if st_native is not None:
         st_native.set_timing(True)
         for _ in range(nt):
@@ -282,6 +293,14 @@ def main():
         model.ray_tracer.events = None
         ms_sphere = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
         ms_samples = float(np.mean([e[1].elapsed_time(e[2]) + e[3].elapsed_time(e[4]) if len(e) == 5 else e[1].elapsed_time(e[2]) for e in events]))
+    collective_ms = None
+    if under_launcher:
+        torch.cuda.synchronize()
+        ms = lambda evs: float(np.mean([a_.elapsed_time(b_) for a_, b_ in evs])) if evs else None
+        collective_ms = {'backend': backend, 'world': world, 'grad_all_reduce': ms(grad_events), 'grad_bytes': int(opt.flat_g.numel() * 4),
+                         'loss_counts_all_reduce': ms(loss_fn.collective_events),
+                         'note': 'mean over %d steps outside the timed region; events on the compute stream around each call (the time the stream is held, incl. waiting for the slowest rank)' % nt}
+        grad_events, loss_fn.collective_events = None, None
     if rank == 0:
         f_t, f_s, f_r = flops_per_row(W)
         peak = PEAK[a.dtype]
@@ -337,6 +356,8 @@ def main():
                                   'achieved': flops_step / (dt / a.steps) / 1e12, 'frac': flops_step / (dt / a.steps) / 1e12 / peak}},
             'loss': float(lo['loss'].detach()),
         }
+        if collective_ms is not None:
+            res['collective_ms'] = collective_ms
         if world == 1 and a.variants:
             # secondary number, never `value`: the same step with the opt-in IDRNetwork.lazy_unused_outputs (the min-sdf points of non-hit rays,
             # which the training loop never reads, are evaluated only when `points` / `sdf_output` are read -- here: never)

@@ -29,6 +29,7 @@ class IDRLoss(nn.Module):
         self.exact_data_parallel = True
         # forward / backward as ONE C call each (mvsdf_loss_forward / mvsdf_loss_backward) instead of four calls + two autograd nodes
         self.native = os.environ.get('MVSDF_NATIVE_STEP', '1') != '0'
+        self.collective_events = None                            # set to a list: (start, end) CUDA events around the 3-count all-reduce are appended (bench.py)
 
     def get_rgb_loss(self, rgb_values, rgb_gt, network_object_mask, object_mask):
         mask = network_object_mask & object_mask                                   # loss.py:21-28; a zero-hit batch gives 0 either way
@@ -107,7 +108,14 @@ class IDRLoss(nn.Module):
         if self.exact_data_parallel and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             cnt = torch.tensor([float(model_outputs['grad_theta'].shape[0]), float(model_outputs['eikonal_output'].numel()),
                                 float(model_outputs['surf_indicator_output'].numel())], device=dev)
+            ev = None
+            if self.collective_events is not None and cnt.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            if ev is not None:
+                ev[1].record()
+                self.collective_events.append(ev)
             inv_counts = float(dist.get_world_size()) / cnt.clamp(min=1.0)
         if self.native:
             out = self._forward_native(model_outputs, ground_truth, rgb_gt, train_progress, weights, bool(phase1), feat_on, inv_counts)

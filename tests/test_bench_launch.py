@@ -46,6 +46,30 @@ def test_two_ranks_on_one_gpu_gloo_full_step():
 
 
 @pytest.mark.gpu
+def test_eight_ranks_on_one_gpu_gloo_c4_shape_and_collective_timings():
+    """`bench.py --gpus 8` exactly as the driver calls it, with the eight ranks sharing the one GPU of the test box (gloo transport): the real
+    c4 shape (8 views x 2048 px = 16384 rays, one view per rank); the line reports n_gpus = 8 and per-collective timings."""
+    rc, lines, err = _run(['--gpus', '8', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], {'MVSDF_DIST_BACKEND': 'gloo', 'OMP_NUM_THREADS': '2'}, timeout=1200)
+    assert rc == 0, err
+    d = json.loads(lines[-1])
+    assert d['n_gpus'] == 8 and d['config']['rays_per_gpu'] == 2048 and d['config']['rays_total'] == 16384 and d['scaling'] == 'weak'
+    c = d['collective_ms']
+    assert c['world'] == 8 and c['backend'] == 'gloo' and c['grad_all_reduce'] > 0 and c['loss_counts_all_reduce'] > 0 and c['grad_bytes'] > 3e6
+    print('8 ranks on one GPU (gloo): %.1f ms per step, gradient all-reduce %.2f ms, loss-count all-reduce %.2f ms' % (d['ms_per_step'], c['grad_all_reduce'], c['loss_counts_all_reduce']))
+
+
+@pytest.mark.gpu
+def test_eight_ranks_on_one_gpu_c5_share_bf16_smoke():
+    """BASELINE configs[4] as the 8-rank run it is: --workload c5share --dtype bf16 --gpus 8 (32768 rays in total, bf16 tracing MLP)."""
+    rc, lines, err = _run(['--gpus', '8', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--workload', 'c5share', '--dtype', 'bf16'],
+                          {'MVSDF_DIST_BACKEND': 'gloo', 'OMP_NUM_THREADS': '2'}, timeout=1200)
+    assert rc == 0, err
+    d = json.loads(lines[-1])
+    assert d['n_gpus'] == 8 and d['config']['rays_total'] == 32768 and d['dtype'] == 'bf16' and d['value'] > 0
+    assert d['collective_ms']['grad_all_reduce'] > 0
+
+
+@pytest.mark.gpu
 def test_one_rank_under_the_launcher_runs_the_collectives_through_rccl():
     """torch.distributed.run with ONE rank and the default backend (`nccl` = RCCL on ROCm): the process group is created on the GPU and the
     step's gradient all-reduce, barrier and the MAX-of-times all-reduce all go through RCCL (identity at world size 1) -- the same code path
@@ -59,3 +83,4 @@ def test_one_rank_under_the_launcher_runs_the_collectives_through_rccl():
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
     assert d['n_gpus'] == 1 and d['value'] > 0
+    assert d['collective_ms']['backend'] == 'nccl' and d['collective_ms']['grad_all_reduce'] > 0     # (world 1: no count all-reduce)
