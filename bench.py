@@ -310,10 +310,13 @@ def main():
         # evaluates the samples behind it, counters[1], which no output reads)
         T, T_ref, N, E = int(cnt[0] + cnt[8] + cnt[2] + cnt[3]), int(cnt[:4].sum()), st['N'], R // 2
         flops_step = T * f_t + ((R + E) + 2 * (N + E)) * f_s + 3 * (N + E) * f_t + 3 * N * f_r
-        rows_samples = int(cnt[8] + cnt[2] + cnt[3])
+        rows_tail = int(cnt[12])                 # min-sdf rows evaluated by finished workgroups INSIDE k_sphere_trace (tail filling): that kernel's work
+        rows_samples = int(cnt[8] + cnt[2] + cnt[3]) - rows_tail
+        rows_sphere = int(cnt[0]) + rows_tail
         n_launch = 3                    # k_ray_samples per step: sampler rows (first window), sampler rows (open rays), secant || min-sdf rows
         ach = rows_samples * f_t / (ms_samples * 1e-3) / 1e12
-        ach_sphere = int(cnt[0]) * f_t / (ms_sphere * 1e-3) / 1e12
+        ach_sphere = rows_sphere * f_t / (ms_sphere * 1e-3) / 1e12
+        ach_both = (rows_samples + rows_sphere) * f_t / ((ms_samples + ms_sphere) * 1e-3) / 1e12
         # k_feat_corr, the one HBM-shaped kernel: 4 taps x 32 channels x 4 B = 512 B per (point, view), timed with HIP events on
         # the launch stream over 20 launches on the last step's surface points
         pts = out['diff_surf_pts'].detach()
@@ -347,7 +350,9 @@ def main():
                          # the two tracing-MLP kernels side by side (they take about the same time at this size)
                          'kernels': {
                              'k_ray_samples': {'rows_per_step': rows_samples, 'ms_per_step': ms_samples, 'achieved': ach, 'frac': ach / peak},
-                             'k_sphere_trace': {'rows_per_step': int(cnt[0]), 'ms_per_step': ms_sphere, 'achieved': ach_sphere, 'frac': ach_sphere / peak,
+                             'tracing (k_ray_samples + k_sphere_trace)': {'rows_per_step': rows_samples + rows_sphere, 'ms_per_step': ms_samples + ms_sphere,
+                                                                          'achieved': ach_both, 'frac': ach_both / peak},
+                             'k_sphere_trace': {'rows_per_step': rows_sphere, 'rows_min_sdf_tail': rows_tail, 'ms_per_step': ms_sphere, 'achieved': ach_sphere, 'frac': ach_sphere / peak,
                                                 'traffic': pmc_traffic(a.workload if world == 1 else None, 'k_sphere_trace')},
                              'k_feat_corr': {'bound': 'hbm', 'points': int(pts.shape[0]), 'views_per_point': 1 + V, 'bytes': feat_bytes, 'ms': ms_feat,
                                              'achieved_GBps': feat_bytes / (ms_feat * 1e-3) / 1e9, 'peak_GBps': 8000.0,
