@@ -184,7 +184,7 @@ static SdfBwdLayout sdf_bwd_layout(const MvNet& net, int Mb) {
     o.HB[0] = p; p += (size_t)Mb * maxw;
     o.HB[1] = p; p += (size_t)Mb * maxw;
     o.H0B = p; p += (size_t)Mb * ld0;
-    o.chunk = 128;
+    o.chunk = MV_WG_CHUNK;
     o.nchunks = (Mb + o.chunk - 1) / o.chunk;
     if (o.nchunks < 1) o.nchunks = 1;
     o.maxnk = 0;
@@ -697,7 +697,7 @@ static RenderBwdLayout render_bwd_layout(const MvNet& net, int N) {
         maxnk = nk > maxnk ? nk : maxnk;
         maxw = net.L[l].N > maxw ? net.L[l].N : maxw;
     }
-    o.chunk = 128; o.nchunks = (N + 127) / 128; if (o.nchunks < 1) o.nchunks = 1;
+    o.chunk = MV_WG_CHUNK; o.nchunks = (N + MV_WG_CHUNK - 1) / MV_WG_CHUNK; if (o.nchunks < 1) o.nchunks = 1;
     o.slab = p; p += wgrad_net_slab_floats(net, o.nchunks);
     o.bslab = p; p += wgrad_net_bslab_floats(net, o.nchunks);
     o.total = p;

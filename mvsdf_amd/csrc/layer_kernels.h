@@ -238,6 +238,11 @@ __device__ __forceinline__ void wg_stage(const float* __restrict__ src, int ld, 
 // Workgroup = (layer, 128-row chunk, 64x64 output block); both pairs of a layer (E.2 term zbar^T a and E.1 term s^T vbar) accumulate
 // in the same registers, so a layer needs one slab per chunk.
 #define MV_WG_MAXL 16                      // layers of one launch: both networks of a training step (9 + 5)
+// rows per weight-gradient chunk (one slab per chunk and layer).  128 -> 256: k_wgrad_net unchanged, k_reduce_net reads half the slabs (c2 20 -> 13 us,
+// c5share 41 -> 23 us).  Measured and NOT kept for k_wgrad_net itself (it runs at 0.32-0.37 matrix-pipe busy): register-prefetching the next operand tiles
+// under the MFMA loop (63.6 vs 61.6 us at c2) and 128 x 128 output tiles with 8 waves, i.e. half the L2 traffic per flop (62.7 vs 61.5 us at c2, 120 vs 110
+// at the c5 share) -- neither exposed load latency nor L2 bandwidth is its bound.
+#define MV_WG_CHUNK 256
 struct WgradLayer {
     const float* P1; const float* Q1; const float* P2; const float* Q2;   // [M, No], [M, Ki]; P2 null: single pair
     int ldp1, ldq1, ldp2, ldq2;

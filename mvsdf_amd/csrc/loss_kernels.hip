@@ -267,15 +267,14 @@ struct LossArgs {
     float* d_rgb; float* d_grad; float* d_eik_out; float* d_surf;                    // unit gradients (same shapes as the inputs)
 };
 
+// sum over the 1024 threads of the workgroup, the same value in every thread; fixed order (butterfly inside a wave, then the 16 wave sums in
+// index order): deterministic.  Two barriers instead of the eleven of an LDS tree -- the kernel is five of these in a row.
 __device__ float block_sum_1024(float v, float* red) {
-    const int tid = threadIdx.x;
-    red[tid] = v;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
-    const float r = red[0];
+    float r = 0.0f;
+    for (int k = 0; k < 16; ++k) r += red[k];
     __syncthreads();
     return r;
 }
