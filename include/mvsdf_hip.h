@@ -417,7 +417,12 @@ typedef struct {
     float w_rgb, w_eik, w_surf, w_feat, w_depth;
     const float* inv_counts;               /* see mvsdf_loss_terms */
 } MvsdfLossArgs;
-typedef struct { size_t bytes, out, hit, view_start, n_pos, loss_pp, dpts, dist_r, weight, d_rgb, d_grad, d_eo, d_sf; } MvsdfLossLayout;
+typedef struct {
+    size_t bytes, out, hit, view_start, n_pos, loss_pp, dpts, dist_r, weight, d_rgb, d_grad, d_eo, d_sf;
+    /* gradients of the TOTAL loss w.r.t. rgb_values / grad_theta / eikonal_output / surf_indicator_output / diff_surf_pts (unit gradient x term weight:
+     * exactly what mvsdf_loss_backward returns for an upstream of 1 on `loss` alone), written by mvsdf_loss_forward */
+    size_t s_rgb, s_grad, s_eo, s_sf, s_diff;
+} MvsdfLossLayout;
 /* layout of the block both calls work in (out: float[6] = loss, rgb, eikonal, depth, feat, surf) */
 int mvsdf_loss_layout(const MvsdfLossArgs* a, MvsdfLossLayout* lo);
 /* mask bookkeeping || depth carving, feature consistency, all terms and their unit gradients: 3 launches */

@@ -280,10 +280,21 @@ size_t mvsdf_sdf_bwd_ws_floats(const MvsdfNetDesc* d, int Mb) {
 
 int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float* x, int M, int Mg, float* y, float* nrm, float* ctx,
                       void* stream) {
+    return mv_sdf_forward_gather(d, dT, x, nullptr, M, Mg, y, nrm, ctx, stream);
+}
+
+}  // extern "C"
+
+/* mvsdf_sdf_forward whose rows are gathered inside the fused chain kernel (g != NULL: the rows [eikonal | on-surface | jittered | pts[perm]], also
+ * written to g->x_out) -- the training step's x_eval without a gather launch.  -> 1 when g was given but the per-layer route had to run: nothing was
+ * launched, the caller gathers itself and calls again with x. */
+int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float* x, const void* gather, int M, int Mg, float* y, float* nrm,
+                          float* ctx, void* stream) {
+    const FwdGather* g = (const FwdGather*)gather;
     MvNet net, netT;
     int rc = mv_make_net(d, &net);
     if (rc) return rc;
-    if (!x || !y || !ctx || M <= 0 || Mg < 0 || Mg > M) return mv_fail(-1, "mvsdf_sdf_forward: bad arguments");
+    if ((!x && !g) || !y || !ctx || M <= 0 || Mg < 0 || Mg > M) return mv_fail(-1, "mvsdf_sdf_forward: bad arguments");
     if (Mg > 0) {
         rc = mv_make_net_mode(dT, &netT, 2);
         if (rc) return rc;
@@ -305,6 +316,7 @@ int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float
         for (int l = 0; l < nl - 1; ++l) { f.Z[l] = ctx + lo.Z[l]; f.Sg[l] = ctx + lo.Sg[l]; }
         for (int l = 1; l < nl - 1; ++l) f.U[l] = ctx + lo.U[l];
         f.G0 = ctx + lo.G0; f.y = y; f.ldy = net.L[nl - 1].N; f.w_last_row0 = d->w[nl - 1]; f.nrm = nrm;
+        if (g) f.g = *g;
         constexpr int MTC = 1, NWC = 8;
         const size_t lds = ((size_t)16 * MTC * S + 2 * ((16 * MTC * lo.d0 + 3) & ~3) + 16 * MTC * 4) * sizeof(float);
         // 16 waves per workgroup (one or two column tiles each): these launches are single waves of one-tile workgroups, i.e. chains of
@@ -325,6 +337,7 @@ int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float
         else hipLaunchKernelGGL((k_chain_fwd<MTC, 4, NWC>), grid, dim3(64 * NWC), lds, s, f);
         return mv_check(hipGetLastError(), "mvsdf_sdf_forward");
     }
+    if (g) return 1;                                             // per-layer route: rows must be materialised by the caller
     hipLaunchKernelGGL(k_pe_global, dim3((M * (3 * net.multires + 1) + 255) / 256), dim3(256), 0, s, x, M, net.multires, H0, lo.ld0);
     for (int l = 0; l < nl - 1; ++l) {                                            // hidden layers (idr.py:82-92)
         LayerArgs a = base_args(net.L[l], S, M);
@@ -368,6 +381,8 @@ int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float
     }
     return mv_check(hipGetLastError(), "mvsdf_sdf_forward");
 }
+
+extern "C" {
 
 /* Backward over rows [row0, row0 + Mb) of a forward context made with (M, Mg).  dy[Mb][Nout] (required), dn[Mb][3] or NULL
  * (rows must lie inside [0, Mg) when dn is given).  Outputs: dW_cat / db_cat (all layers concatenated, row-major [N][K]; both NULL

@@ -13,6 +13,7 @@
 // idr.py:145-167 (rendering net) and autograd's backward of both.
 #pragma once
 #include "tile_engine.h"
+#include "step_internal.h"
 
 enum {
     PRO_PLAIN = 0,      // A[row][k]
@@ -797,6 +798,7 @@ struct FwdArgs {
     float* y; int ldy;                         // [M][Nout]
     const float* w_last_row0;                  // W_L[0, :]
     float* nrm;                                // [Mg][3]
+    FwdGather g;                               // g.pts != null: x is gathered (x is ignored)
 };
 
 template <int MT, int NTW, int NW>
@@ -811,8 +813,20 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
     float* padj = pe + ((ROWS * d0 + 3) & ~3);                   // [ROWS][d0] PE adjoint of the skip layer, then g_0
     float* pts = padj + ((ROWS * d0 + 3) & ~3);                  // [ROWS][3]
     for (int i = tid; i < ROWS * 3; i += NTH) {
-        const int row = row0 + i / 3;
-        pts[i] = row < a.M ? a.x[3 * (size_t)row0 + i] : 0.0f;
+        const int row = row0 + i / 3, c = i - 3 * (i / 3);
+        float v = 0.0f;
+        if (row < a.M) {
+            if (!a.g.pts) v = a.x[3 * (size_t)row0 + i];
+            else {
+                const int E = a.g.n_eik + 2 * a.g.n_ds;
+                if (row < a.g.n_eik) v = a.g.eik[3 * (size_t)row + c];
+                else if (row < a.g.n_eik + a.g.n_ds) v = a.g.on[3 * (size_t)(row - a.g.n_eik) + c];
+                else if (row < E) v = a.g.jit[3 * (size_t)(row - a.g.n_eik - a.g.n_ds) + c];
+                else v = a.g.pts[3 * (size_t)a.g.perm[row - E] + c];
+                a.g.x_out[3 * (size_t)row + c] = v;
+            }
+        }
+        pts[i] = v;
     }
     __syncthreads();
     mv_pe_rows<NTH>(pts, pe, act, S, ROWS, a.net.multires, tid);

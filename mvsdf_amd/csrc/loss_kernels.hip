@@ -265,6 +265,9 @@ struct LossArgs {
     const float* inv_counts;                                                         // optional [3]: 1/count of the eikonal / depth / surf means (data-parallel exact mode)
     float* out;                                                                      // [6]: loss, rgb, eikonal, depth, feat, surf
     float* d_rgb; float* d_grad; float* d_eik_out; float* d_surf;                    // unit gradients (same shapes as the inputs)
+    // optional: the gradients of the TOTAL loss (unit gradient x the term's weight: what k_loss_scale produces for an upstream of exactly 1 on `loss`
+    // alone -- 1 * w + 0 is w, so the values are bit-identical) and of the feature term's points; lets `loss.backward()` skip that launch
+    float* s_rgb; float* s_grad; float* s_eik_out; float* s_surf; const float* dpts; float* s_diff; int n_dpts;
 };
 
 // sum over the 1024 threads of the workgroup, the same value in every thread; fixed order (butterfly inside a wave, then the 16 wave sums in
@@ -289,7 +292,9 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
         const bool m = a.rgb_mask[i / 3] != 0;
         const float df = a.rgb[i] - a.rgb_gt[i];
         if (m) s += fabsf(df);
-        a.d_rgb[i] = m ? (df > 0.f ? invR : (df < 0.f ? -invR : 0.f)) : 0.f;
+        const float dr = m ? (df > 0.f ? invR : (df < 0.f ? -invR : 0.f)) : 0.f;
+        a.d_rgb[i] = dr;
+        if (a.s_rgb) a.s_rgb[i] = dr * a.w_rgb;
     }
     const float rgb_loss = block_sum_1024(s, red) * invR;
     // eikonal: mean((||g|| - 1)^2)                                                               loss.py:30-35
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
         s += e * e;
         const float k = nrm > 0.f ? 2.0f * e / nrm * invE : 0.f;
         a.d_grad[3 * i] = k * gx; a.d_grad[3 * i + 1] = k * gy; a.d_grad[3 * i + 2] = k * gz;
+        if (a.s_grad) { a.s_grad[3 * i] = (k * gx) * a.w_eik; a.s_grad[3 * i + 1] = (k * gy) * a.w_eik; a.s_grad[3 * i + 2] = (k * gz) * a.w_eik; }
     }
     const float eik_loss = block_sum_1024(s, red) * invE;
     // depth: mean(|eikonal_output + dist_r| * weight)                                            loss.py:58-61
@@ -310,7 +316,9 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
     for (int i = tid; i < a.n_depth; i += 1024) {
         const float df = a.eik_out[i] + a.dist_r[i], wgt = a.dweight[i];
         s += fabsf(df) * wgt;
-        a.d_eik_out[i] = (df > 0.f ? wgt : (df < 0.f ? -wgt : 0.f)) * invD;
+        const float de = (df > 0.f ? wgt : (df < 0.f ? -wgt : 0.f)) * invD;
+        a.d_eik_out[i] = de;
+        if (a.s_eik_out) a.s_eik_out[i] = de * a.w_depth;
     }
     const float depth_loss = block_sum_1024(s, red) * invD;
     // surface indicator: BCEWithLogits(mean) against [1]*n_pos + [0]*rest                        loss.py:167-174
@@ -322,11 +330,13 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
         for (int i = tid; i < a.n_surf; i += 1024) {
             const float x = a.surf[i], t = (long long)i < npos ? 1.0f : 0.0f;
             s += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
-            a.d_surf[i] = (1.0f / (1.0f + expf(-x)) - t) * invS;
+            const float ds = (1.0f / (1.0f + expf(-x)) - t) * invS;
+            a.d_surf[i] = ds;
+            if (a.s_surf) a.s_surf[i] = ds * a.w_surf;
         }
         surf_loss = block_sum_1024(s, red) * invS;
     } else {
-        for (int i = tid; i < a.n_surf; i += 1024) a.d_surf[i] = 0.f;
+        for (int i = tid; i < a.n_surf; i += 1024) { a.d_surf[i] = 0.f; if (a.s_surf) a.s_surf[i] = 0.f; }
     }
     // feature consistency: sum of the per-point terms of k_feat_corr
     s = 0.f;
@@ -335,6 +345,7 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
         for (int i = tid; i < a.n_feat; i += 1024) s += a.feat_pp[i];
         feat_loss = block_sum_1024(s, red);
     }
+    if (a.s_diff && a.dpts) for (int i = tid; i < a.n_dpts; i += 1024) a.s_diff[i] = a.dpts[i] * a.w_feat;
     if (tid == 0) {
         a.out[1] = rgb_loss; a.out[2] = eik_loss; a.out[3] = depth_loss; a.out[4] = feat_loss; a.out[5] = surf_loss;
         a.out[0] = rgb_loss * a.w_rgb + eik_loss * a.w_eik + surf_loss * a.w_surf + feat_loss * a.w_feat + depth_loss * a.w_depth;   // loss.py:206-210
@@ -354,6 +365,7 @@ int mvsdf_loss_terms(const float* rgb, const float* rgb_gt, const uint8_t* rgb_m
         (n_depth > 0 && (!eik_out || !dist_r || !dweight || !d_eik_out)) || (n_surf > 0 && (!surf || !d_surf || !n_pos)))
         return mv_fail(-1, "mvsdf_loss_terms: bad arguments");
     LossArgs a;
+    memset(&a, 0, sizeof(a));
     a.inv_counts = inv_counts;
     a.rgb = rgb; a.rgb_gt = rgb_gt; a.rgb_mask = rgb_mask; a.R = R; a.grad_theta = grad_theta; a.n_eik = n_eik;
     a.eik_out = eik_out; a.dist_r = dist_r; a.dweight = dweight; a.n_depth = n_depth; a.surf = surf; a.n_surf = n_surf; a.n_pos = n_pos;
@@ -548,6 +560,11 @@ int mvsdf_loss_layout(const MvsdfLossArgs* a, MvsdfLossLayout* lo) {
     lo->d_grad = take((size_t)a->n_grad * 12);
     lo->d_eo = take((size_t)a->n_depth * 4);
     lo->d_sf = take((size_t)a->n_surf * 4);
+    lo->s_rgb = take((size_t)a->R * 12);
+    lo->s_grad = take((size_t)a->n_grad * 12);
+    lo->s_eo = take((size_t)a->n_depth * 4);
+    lo->s_sf = take((size_t)a->n_surf * 4);
+    lo->s_diff = take((size_t)a->N * 12);
     lo->bytes = p;
     return 0;
 }
@@ -584,11 +601,26 @@ int mvsdf_loss_forward(const MvsdfLossArgs* a, void* blk, void* stream) {
                              a->src_cams, a->size, a->center, (float*)(b + lo.loss_pp), (float*)(b + lo.dpts), stream);
         if (rc) return rc;
     }
-    return mvsdf_loss_terms(a->rgb, a->rgb_gt, hit, a->R, a->n_grad > 0 ? a->grad_theta : nullptr, a->n_grad, a->eik_out, (const float*)(b + lo.dist_r),
-                            (const float*)(b + lo.weight), a->n_depth, a->n_surf > 0 ? a->surf : nullptr, a->n_surf, n_pos,
-                            feat ? (const float*)(b + lo.loss_pp) : nullptr, feat ? a->N : 0, a->w_rgb, a->w_eik, a->w_surf, a->w_feat, a->w_depth,
-                            a->surf_on, a->feat_on, a->inv_counts, (float*)(b + lo.out), (float*)(b + lo.d_rgb), (float*)(b + lo.d_grad),
-                            (float*)(b + lo.d_eo), (float*)(b + lo.d_sf), stream);
+    {
+        if (a->R <= 0 || (a->n_grad > 0 && !a->grad_theta) || (a->n_depth > 0 && !a->eik_out) || (a->n_surf > 0 && !a->surf))
+            return mv_fail(-1, "mvsdf_loss_forward: null term input");
+        LossArgs k;
+        memset(&k, 0, sizeof(k));
+        k.rgb = a->rgb; k.rgb_gt = a->rgb_gt; k.rgb_mask = hit; k.R = a->R;
+        k.grad_theta = a->n_grad > 0 ? a->grad_theta : nullptr; k.n_eik = a->n_grad;
+        k.eik_out = a->eik_out; k.dist_r = (const float*)(b + lo.dist_r); k.dweight = (const float*)(b + lo.weight); k.n_depth = a->n_depth;
+        k.surf = a->n_surf > 0 ? a->surf : nullptr; k.n_surf = a->n_surf; k.n_pos = n_pos;
+        k.feat_pp = feat ? (const float*)(b + lo.loss_pp) : nullptr; k.n_feat = feat ? a->N : 0;
+        k.w_rgb = a->w_rgb; k.w_eik = a->w_eik; k.w_surf = a->w_surf; k.w_feat = a->w_feat; k.w_depth = a->w_depth;
+        k.surf_on = a->surf_on; k.feat_on = a->feat_on; k.inv_counts = a->inv_counts;
+        k.out = (float*)(b + lo.out); k.d_rgb = (float*)(b + lo.d_rgb); k.d_grad = (float*)(b + lo.d_grad); k.d_eik_out = (float*)(b + lo.d_eo);
+        k.d_surf = (float*)(b + lo.d_sf);
+        // + the gradients of the total loss itself (weights folded in): `loss.backward()` with the plain upstream 1 then needs no launch of its own
+        k.s_rgb = (float*)(b + lo.s_rgb); k.s_grad = (float*)(b + lo.s_grad); k.s_eik_out = (float*)(b + lo.s_eo); k.s_surf = (float*)(b + lo.s_sf);
+        k.dpts = feat ? (const float*)(b + lo.dpts) : nullptr; k.s_diff = feat ? (float*)(b + lo.s_diff) : nullptr; k.n_dpts = feat ? a->N * 3 : 0;
+        hipLaunchKernelGGL(k_loss_terms, dim3(1), dim3(1024), 0, (hipStream_t)stream, k);
+        return mv_check(hipGetLastError(), "mvsdf_loss_forward (terms)");
+    }
 }
 
 int mvsdf_loss_backward(const MvsdfLossArgs* a, const void* blk, const float* const* g, float* g_rgb, float* g_grad, float* g_eo, float* g_sf,

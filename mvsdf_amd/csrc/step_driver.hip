@@ -261,7 +261,8 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
             nsplit[l] = (bf && d.trace_dtype == 1 && (l == 0 || ((d.skip_mask >> l) & 1u))) ? 3 + 6 * d.multires : 0;
         }
         // ... and the camera rays (idr.py:190), all in one launch
-        ST_TRY(mv_step_prologue(nl, prm->v, prm->g, d.N, d.K, w, wp, wpT, wp16, nsplit, d.trace_dtype == 2 ? 1 : 0, in->uv, in->pose, in->intrinsics, d.B, d.P, ray_dirs, cam_loc, stream));
+        ST_TRY(mv_step_prologue(nl, prm->v, prm->g, d.N, d.K, w, wp, wpT, wp16, nsplit, d.trace_dtype == 2 ? 1 : 0, in->uv, in->pose, in->intrinsics, d.B, d.P, ray_dirs, cam_loc,
+                                (uint8_t*)(fwd + L.object_mask_out), stream));
     }
     MvsdfNetDesc sdf, sdfT, rnd, rndT;
     make_descs(*st, prm, fwd, &sdf, &sdfT, &rnd, &rndT);
@@ -291,12 +292,19 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     // 4. ONE fused value + normal evaluation over [samples | rays, hit first], rendering net on every sorted ray, output gather
     float* x_eval = (float*)(fwd + fo.x_eval); float* y_eval = (float*)(fwd + fo.y_eval); float* n_eval = (float*)(fwd + fo.n_eval);
     {
-        const int total = M * 3;
-        hipLaunchKernelGGL(k_step_gather_x, dim3((total + 255) / 256), dim3(256), 0, s, in->eik_points, d.n_eik, in->ds_on, in->ds_jit, d.n_ds, points, perm,
-                           R, x_eval, (uint8_t*)(fwd + L.object_mask_out));
-        ST_HIP(hipGetLastError());
+        // the evaluation rows [samples | traced points of the rays, hit first] are gathered inside the chain kernel (which also leaves them in x_eval)
+        FwdGather g;
+        g.eik = in->eik_points; g.on = in->ds_on; g.jit = in->ds_jit; g.pts = points; g.perm = perm; g.n_eik = d.n_eik; g.n_ds = d.n_ds; g.x_out = x_eval;
+        int rcf = mv_sdf_forward_gather(&sdf, &sdfT, nullptr, &g, M, M, y_eval, n_eval, (float*)(fwd + fo.sdf_ctx), stream);
+        if (rcf == 1) {                                           // per-layer route: materialise the rows first
+            const int total = M * 3;
+            hipLaunchKernelGGL(k_step_gather_x, dim3((total + 255) / 256), dim3(256), 0, s, in->eik_points, d.n_eik, in->ds_on, in->ds_jit, d.n_ds, points, perm,
+                               R, x_eval, (uint8_t*)nullptr);
+            ST_HIP(hipGetLastError());
+            rcf = mvsdf_sdf_forward(&sdf, &sdfT, x_eval, M, M, y_eval, n_eval, (float*)(fwd + fo.sdf_ctx), stream);
+        }
+        if (rcf) return rcf;
     }
-    ST_TRY(mvsdf_sdf_forward(&sdf, &sdfT, x_eval, M, M, y_eval, n_eval, (float*)(fwd + fo.sdf_ctx), stream));
     float* rgb_sorted = (float*)(fwd + fo.rgb_sorted);
     ST_TRY(mvsdf_render_forward(&rnd, x_eval + 3 * (size_t)E, view_sorted, n_eval + 3 * (size_t)E, y_eval + (size_t)E * st->Nout + 2, st->Nout, R,
                                 d.view_spec, rgb_sorted, (float*)(fwd + fo.render_ctx), stream));

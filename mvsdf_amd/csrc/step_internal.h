@@ -4,6 +4,10 @@
 #include <stdint.h>
 #include "../../include/mvsdf_hip.h"
 
+// optional row source of k_chain_fwd: the training step's evaluation rows [eikonal samples | on-surface samples | jittered samples | traced points of the
+// rays in sorted order] gathered on the fly (and written to x_out for the later consumers) instead of by a separate launch
+struct FwdGather { const float* eik; const float* on; const float* jit; const float* pts; const long long* perm; int n_eik, n_ds; float* x_out; };
+
 // k_partition_rays with the step driver's extra outputs: true_rank[pos] (rank of sorted hit row pos among the true-mask hit rows, -1 outside the
 // true mask) and counts[2..3] = extra_counts[0..1] (0 when NULL)
 int mv_partition_rays_step(const uint8_t* net_mask, const uint8_t* object_mask, const uint8_t* true_mask, const float* ray_dirs, int R, long long* perm,
@@ -13,6 +17,11 @@ int mv_partition_rays_step(const uint8_t* net_mask, const uint8_t* object_mask, 
 int mv_step_backward_assemble(int n_eik, int n_ds, int N, int Nout, int n_true, const float* din, int din_ld, int din_feat0, int din_nrm0, int use_geo,
                               const int* true_rank, const float* d_eo, const float* d_gth, const float* d_si, int d_mask, int e_mask, float* dy,
                               float* dn, float* dy_x, float* dn_x, void* stream);
+
+// mvsdf_sdf_forward with the step's evaluation rows gathered inside the fused chain kernel; `gather` = const FwdGather* (layer_kernels.h) or NULL;
+// -> 1 when the per-layer route would run (nothing launched: gather yourself and call with x)
+int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float* x, const void* gather, int M, int Mg, float* y, float* nrm,
+                          float* ctx, void* stream);
 
 // pieces of the training step's backward (diff_mlp.hip): the rendering net's descending chain alone, the SDF net's delta pass alone, and the weight
 // gradients of BOTH networks as one k_wgrad_net / k_reduce_net pair (part 1: what does not depend on the delta pass; part 2: the rest + reduction)
@@ -28,4 +37,4 @@ int mv_step_wgrad(int part, const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int 
 // (basic.hip::k_step_prologue): the work of mvsdf_fold_pack_net, mvsdf_pack_bf16_net_skips and mvsdf_camera_rays, same results
 int mv_step_prologue(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w, float* const* wp,
                      float* const* wpT, void* const* wp16, const int* nsplit, int wp16_fp32, const float* uv, const float* pose, const float* intrinsics, int B, int P,
-                     float* ray_dirs, float* cam_loc, void* stream);
+                     float* ray_dirs, float* cam_loc, uint8_t* ones, void* stream);

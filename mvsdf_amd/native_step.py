@@ -53,7 +53,7 @@ class LossArgs(C.Structure):
 
 class LossLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ('bytes', 'out', 'hit', 'view_start', 'n_pos', 'loss_pp', 'dpts', 'dist_r', 'weight', 'd_rgb', 'd_grad',
-                                          'd_eo', 'd_sf')]
+                                          'd_eo', 'd_sf', 's_rgb', 's_grad', 's_eo', 's_sf', 's_diff')]
 
 
 _bound = False
@@ -288,7 +288,7 @@ class _NativeLossFn(torch.autograd.Function):
         dev = rgb.device
         blk = torch.empty(lo.bytes, dtype=torch.uint8, device=dev)
         check(L.mvsdf_loss_forward(C.byref(args), blk.data_ptr(), _stream(dev)), 'mvsdf_loss_forward')
-        ctx.args, ctx.blk, ctx.keep = args, blk, keep
+        ctx.args, ctx.blk, ctx.keep, ctx.lo = args, blk, keep, lo
         ctx.ins = (rgb, grad_theta, eik_out, surf, diff_pts)     # (for direct_backward: which node produced them)
         ctx.shapes = (rgb.shape, grad_theta.shape if grad_theta is not None else None, eik_out.shape, surf.shape if surf is not None else None,
                       diff_pts.shape)
@@ -352,9 +352,22 @@ def direct_backward(loss):
     one = _one.get(dev)
     if one is None:
         one = _one[dev] = torch.ones((), dtype=torch.float32, device=dev)
-    gs = [None] * 6
-    gs[loss.output_nr] = one
-    grads = _NativeLossFn.backward(node, *gs)
-    _NativeStepFn.backward(snode, grads[6], grads[2], grads[3], grads[4], grads[5])
+    if loss.output_nr == 0:
+        # d(total loss): mvsdf_loss_forward already left the weighted gradients in its block (bit-identical to the backward launch for an upstream of 1)
+        a, lo, blk = node.args, node.lo, node.blk
+        f32 = blk.view(torch.float32)
+        cut = lambda off, n, shape: torch.as_strided(f32, shape, _strides(shape), off >> 2) if n > 0 else None
+        feat = bool(a.feat_on) and a.N > 0
+        g_rgb = cut(lo.s_rgb, a.R, (a.R, 3))
+        g_grad = cut(lo.s_grad, a.n_grad, (a.n_grad, 3))
+        g_eo = cut(lo.s_eo, a.n_depth, (a.n_depth,))
+        g_sf = cut(lo.s_sf, a.n_surf, (a.n_surf,)) if a.surf_on else None
+        g_diff = cut(lo.s_diff, a.N, (a.N, 3)) if feat else None
+        _NativeStepFn.backward(snode, g_diff, g_rgb, g_grad, g_eo, g_sf)
+    else:
+        gs = [None] * 6
+        gs[loss.output_nr] = one
+        grads = _NativeLossFn.backward(node, *gs)
+        _NativeStepFn.backward(snode, grads[6], grads[2], grads[3], grads[4], grads[5])
     rec.done = True
     return True
