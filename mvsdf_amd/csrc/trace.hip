@@ -74,7 +74,7 @@ struct TailCtx {
     const float* steps;               // the uniform draws of minimal_sdf_points (ray_tracing.py:287)
     float* sv;                        // min-sdf sample values [n_items][n_steps] (the second sample-value buffer of the workspace)
     int unit_rows;                    // rows per claimed unit (a multiple of the row tiles of both kernels)
-    int enable, spin;                 // spin: every workgroup of the grid is resident, a helper may wait for more work
+    int enable, spin;                 // spin: a helper without a tile looks again a few times (every ~15 us, up to ~1 ms) before it exits
     int stop_left;                    // helpers take no new tile once at most this many workgroups still trace
     unsigned* probe;                  // optional [gridDim.x][4]: rounds, units helped, clock ticks tracing, clock ticks helping (dev)
 };
@@ -243,28 +243,29 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams
             // ---- tail filling: the next chunk of min-sdf rows (a new unit from the queue when the current one is used up)
             if (h_left == 0) {
                 if (tid == 0) {
-                    // claim by fetch-add (a compare-and-swap loop hands out one tile per memory round trip with ~200 contenders: measured 150 tiles
-                    // in 190 us), then wait until the claimed rows exist: every list item they touch published (ready == reserved, read in that
-                    // order: no append in flight, so all `reserved` items are complete), or the list final (every workgroup done)
+                    // A tile is claimed by fetch-add (a compare-and-swap loop hands out one tile per memory round trip with ~200 contenders: measured
+                    // 150 tiles in 190 us) -- but only when it is CERTAIN to lie inside the rows that already exist: every list item published
+                    // (ready == reserved, read in that order: no append in flight, so all `reserved` items are complete) and a margin of one tile per
+                    // workgroup of the grid beyond the queue head (between this look and the fetch-add every other workgroup can claim at most one
+                    // tile).  So a claim never has to wait for rows to appear and is never abandoned -- nothing here can deadlock or lose rows, also when
+                    // other processes share the GPU; the margin (<= 256 tiles of a few thousand) is simply left to the launch that follows.
                     long long take = -1;
                     int n_items = 0;                              // the item count the tile was validated against (>= what it touches)
-                    // no new tile once only a handful of workgroups still trace: a tile started in the kernel's last round outlives it (measured: the
-                    // kernel then ends ~70 us after its slowest tracer)
-                    if (__hip_atomic_load(&counters[MV_CNT_TAIL_WGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (unsigned long long)tail.stop_left < (unsigned long long)gridDim.x) {
-                        const long long u = (long long)__hip_atomic_fetch_add(&counters[MV_CNT_TAIL_NEXT], (unsigned long long)ROWS, __ATOMIC_RELAXED,
-                                                                              __HIP_MEMORY_SCOPE_AGENT);
-                        for (int tries = 0; tries < 100000; ++tries) {
-                            const bool all_done = __hip_atomic_load(&counters[MV_CNT_TAIL_WGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)gridDim.x;
-                            const unsigned long long rdy = __hip_atomic_load(&counters[MV_CNT_TAIL_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const unsigned long long res = __hip_atomic_load(&counters[MV_CNT_N_MINSDF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const long long rows = (long long)res * tp.n_steps;
-                            if (rdy == res && (u + ROWS <= rows || (all_done && u < rows))) { take = u; n_items = (int)res; break; }
-                            if (all_done && rdy == res) break;    // the claimed rows lie beyond the end of the (final) list
-                            if (!tail.spin) {                     // not every workgroup is resident: never wait (the rows of an abandoned claim are
-                                break;                            // re-evaluated nowhere: only taken when tail.spin, see launch_stage1)
-                            }
-                            __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+                    for (int tries = 0; tries < 64; ++tries) {
+                        // no new tile once only a handful of workgroups still trace: a tile started in the kernel's last round outlives it (measured: the
+                        // kernel then ends ~70 us after its slowest tracer)
+                        if (__hip_atomic_load(&counters[MV_CNT_TAIL_WGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (unsigned long long)tail.stop_left >= (unsigned long long)gridDim.x) break;
+                        const long long head = (long long)__hip_atomic_load(&counters[MV_CNT_TAIL_NEXT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long rdy = __hip_atomic_load(&counters[MV_CNT_TAIL_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long res = __hip_atomic_load(&counters[MV_CNT_N_MINSDF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const long long rows = (long long)res * tp.n_steps;
+                        if (rdy == res && head + ((long long)gridDim.x + 1) * ROWS <= rows) {
+                            take = (long long)__hip_atomic_fetch_add(&counters[MV_CNT_TAIL_NEXT], (unsigned long long)ROWS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            n_items = (int)res;
+                            break;
                         }
+                        if (!tail.spin) break;
+                        __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);   // ~15 us
                     }
                     s_n[0] = (int)take; s_n[1] = n_items;
                 }
@@ -623,8 +624,8 @@ static float* mv_minsdf_sv(float* ws, int R, int n_steps) {
     return (float*)(list_rest + 2 * (size_t)R);
 }
 
-// is the tail filling on for this call?  (mt1: row tiles per sphere-tracing workgroup.)  Only when every sphere-tracing workgroup is resident
-// at once (<= 256 of them): a helper waits for its claimed rows to be published by workgroups that must be running.
+// is the tail filling on for this call?  (mt1: row tiles per sphere-tracing workgroup.)  Only for grids of <= 256 workgroups (one per CU): with more,
+// a finished workgroup's slot is wanted by a tracing workgroup that has not started yet -- helping would delay it.
 template <class NET>
 static bool mv_tail_on(int training, const float* steps, int R, int mt1) {
     constexpr bool is_bf = !std::is_same<NET, MvNet>::value;
@@ -658,7 +659,7 @@ static hipError_t launch_stage1(const NET& net, const MvTraceParams& tp, const f
         tail.steps = steps;
         tail.sv = mv_minsdf_sv(ws, R, tp.n_steps);
         tail.unit_rows = 16 * MT;
-        tail.spin = grid1 <= 256 ? 1 : 0;                       // every workgroup resident (one or more per CU): waiting for work cannot starve a tracer
+        tail.spin = 1;
         tail.probe = mv_tail_probe();
         static int stop_env = -1;
         if (stop_env < 0) { const char* e = getenv("MVSDF_TAIL_STOP"); stop_env = e ? atoi(e) : -1; }
