@@ -613,8 +613,44 @@ int mvsdf_sdf_backward_pair(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M
 
 // delta pass of the training step's SDF backward: extra upstream fbar[MbD] on output column 0 of rows [row0D, row0D + MbD); its first-order zbar_l
 // are ADDED to the adjoints pass A stored in `ws` (linearity)
+// The delta pass without a chain.  Its upstream is ONE scalar per row on output column 0, so by linearity every adjoint it produces is that scalar
+// times the adjoint for the upstream e_0 -- and zbar_l for e_0 is exactly s_l = sigma'_l . u_{l+1}, the tensor the forward's normal chain already
+// computed and saved for the weight gradients (k_chain_fwd: Sg[l]).  Hence zbar_l += fbar . s_l: one elementwise launch (~10 us) instead of a
+// 9-phase dependent chain of GEMMs over the hit rows (92 us at c2, 100-136 us at the c5 share, on the critical path of the backward).
+struct DeltaArgs {
+    int nl1, rows;                           // layers 0 .. L-2; hit rows
+    int N[MV_MAXL];
+    const float* Sg[MV_MAXL]; float* ZB[MV_MAXL];     // already offset to the first hit row
+    const float* fbar;
+};
+__global__ __launch_bounds__(256) void k_delta_apply(DeltaArgs a) {
+    const int row = blockIdx.x, l = blockIdx.y, N = a.N[l];
+    const float f = a.fbar[row];
+    const float* sg = a.Sg[l] + (size_t)row * N;
+    float* zb = a.ZB[l] + (size_t)row * N;
+    for (int c = threadIdx.x; c < N; c += 256) zb[c] = zb[c] + f * sg[c];
+}
+static int mv_delta_chain() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MVSDF_DELTA_CHAIN"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 static int sdf_delta_pass(const MvNet& net, const MvNet& netT, const SdfLayout& lo, const SdfBwdLayout& bl, const float* ctx, float* ws, int row0D,
                           int MbD, const float* fbar, hipStream_t s) {
+    if (!mv_delta_chain()) {
+        DeltaArgs d;
+        memset(&d, 0, sizeof(d));
+        d.nl1 = lo.nl - 1; d.rows = MbD; d.fbar = fbar;
+        for (int l = 0; l < lo.nl - 1; ++l) {
+            d.N[l] = net.L[l].N;
+            d.Sg[l] = ctx + lo.Sg[l] + (size_t)row0D * net.L[l].N;
+            d.ZB[l] = ws + bl.ZB[l] + (size_t)row0D * net.L[l].N;
+        }
+        hipLaunchKernelGGL(k_delta_apply, dim3(MbD, lo.nl - 1), dim3(256), 0, s, d);
+        return mv_check(hipGetLastError(), "sdf_delta_pass");
+    }
+    // MVSDF_DELTA_CHAIN=1: the first-order chain (the form this replaced; kept as the cross-check of tests/test_gpu_diff.py)
     const int ntw_b = mv_chain_ntw(net);
     const int nl = lo.nl, S = stride_for(net, netT);
     ChainArgs c;
@@ -875,8 +911,7 @@ int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, 
 }  // extern "C"
 
 // ================================================================================================ step driver pieces (step_internal.h)
-// The backward of a training step with the weight gradients of BOTH networks in one k_wgrad_net / k_reduce_net pair, split so that the
-// part that does not depend on the delta pass can run beside it on a second stream (step_driver.hip).
+// The backward of a training step in pieces: rendering-net chain, delta, and the weight gradients of BOTH networks in one k_wgrad_net / k_reduce_net pair.
 int mv_render_backward_chain(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, int Nctx, const float* drgb, const long long* drgb_rows, const float* ctx,
                              float* din, float* ws, void* stream) {
     MvNet net, netT;
@@ -901,18 +936,17 @@ int mv_sdf_backward_delta(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M, 
     return sdf_delta_pass(net, netT, sdf_ctx_layout(net, M, Mg), sdf_bwd_layout(net, Mb), ctx, ws, row0D, MbD, fbar, (hipStream_t)stream);
 }
 
-/* part 1: the chunks that do not depend on the delta pass -- every chunk of the rendering net (N rows; skipped when N == 0 or rctx is NULL) and
- *         the SDF net's chunks that end at or below row `row_split` (the sample rows);
- * part 2: the other SDF chunks + the column sums of ubar_last, then ONE reduction of all slabs of both networks -> dW_s / db_s / dW_r / db_r.
- * part 3: both at once (no split).  The rendering net's targets are zero-filled by the caller when it has no rows. */
-int mv_step_wgrad(int part, const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int M, int Mg, int Mb, int row_split, const float* dy, const float* ctx,
-                  float* wsA, int N, int Nctx, const float* rctx, float* rws, float* dW_s, float* db_s, float* dW_r, float* db_r, void* stream) {
+/* Weight / bias gradients of BOTH networks of a training step: one k_wgrad_net launch over every layer and chunk (+ the column sums of ubar_last) and
+ * ONE reduction of all slabs -> dW_s / db_s / dW_r / db_r.  The rendering net takes part when N > 0 and rctx / rws are given; otherwise the caller
+ * zero-fills its targets. */
+int mv_step_wgrad(const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int M, int Mg, int Mb, const float* dy, const float* ctx, float* wsA, int N, int Nctx,
+                  const float* rctx, float* rws, float* dW_s, float* db_s, float* dW_r, float* db_r, void* stream) {
     MvNet net, rnet;
     int rc = mv_make_net(sd, &net);
     if (rc) return rc;
     const bool with_r = N > 0 && rctx && rws;
     if (with_r) { rc = mv_make_net_mode(rd, &rnet, 1); if (rc) return rc; }
-    if (!dy || !ctx || !wsA || !dW_s || !db_s || Mb <= 0 || Mb > Mg || Mg > M || (with_r && (!dW_r || !db_r || Nctx < N)) || part < 1 || part > 3)
+    if (!dy || !ctx || !wsA || !dW_s || !db_s || Mb <= 0 || Mb > Mg || Mg > M || (with_r && (!dW_r || !db_r || Nctx < N)))
         return mv_fail(-1, "mv_step_wgrad: bad arguments");
     const SdfLayout lo = sdf_ctx_layout(net, M, Mg);
     const SdfBwdLayout bl = sdf_bwd_layout(net, Mb);
@@ -931,21 +965,7 @@ int mv_step_wgrad(int part, const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int 
         wgrad_net_layers(wa, nl, nr, N, rbl.nchunks, rws + rbl.slab, rws + rbl.bslab, dW_r, db_r);
     }
     const int Ki = net.L[nl - 1].K;
-    int c_split = row_split / bl.chunk;                                             // SDF chunks [0, c_split) hold sample rows only
-    if (c_split > bl.nchunks) c_split = bl.nchunks;
-    if (c_split < 0) c_split = 0;
-    hipStream_t s = (hipStream_t)stream;
-    if (part == 1) {
-        for (int l = 0; l < nl; ++l) { wa.L[l].ch0 = 0; wa.L[l].nch = c_split; }
-        MV_TRY(wgrad_launch(wa, s));
-    } else {
-        if (part == 2) {
-            for (int l = 0; l < nl; ++l) { wa.L[l].ch0 = c_split; wa.L[l].nch = bl.nchunks - c_split; }
-            for (int l = nl; l < nl + nr; ++l) wa.L[l].nch = 0;
-        }
-        wgrad_colsum(wa, wsA + bl.VB[nl - 1], Ki, Mb, Ki, nl - 1, bl.nchunks, wsA + bl.slabB);
-        MV_TRY(wgrad_launch(wa, s));
-        MV_TRY(wgrad_reduce(wa, s));
-    }
+    wgrad_colsum(wa, wsA + bl.VB[nl - 1], Ki, Mb, Ki, nl - 1, bl.nchunks, wsA + bl.slabB);
+    MV_TRY(launch_wgrad_net(wa, (hipStream_t)stream));
     return mv_check(hipGetLastError(), "mv_step_wgrad");
 }

@@ -39,9 +39,6 @@ struct Step {
     int timing;
     hipEvent_t ev_t[5];
     bool timed;
-    hipStream_t side;                                // second stream of the backward: weight-gradient chunks beside the delta pass
-    hipEvent_t ev_fork, ev_join;
-    int overlap;                                     // MVSDF_STEP_OVERLAP (default 1)
 };
 
 // descriptors of the two networks over the packs inside a forward block
@@ -122,7 +119,6 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
     st->d = d;
     st->R = d.B * d.P; st->E = d.n_eik + 2 * d.n_ds; st->M = st->R + st->E; st->nl = nl;
     st->Nout = d.N[d.n_sdf - 1]; st->K0r = d.K[d.n_sdf];
-    { const char* e = getenv("MVSDF_STEP_OVERLAP"); st->overlap = e ? atoi(e) : 1; }
     const int R = st->R, M = st->M;
     // probe descriptors (sizes only; the size functions do not dereference the pack pointers but the validity checks want non-null ones)
     MvsdfNetDesc sdf, sdfT, rnd, rndT;
@@ -201,7 +197,6 @@ void mvsdf_step_destroy(void* step) {
     if (!st) return;
     if (st->timing) for (int i = 0; i < 5; ++i) hipEventDestroy(st->ev_t[i]);
     if (st->counts_host) { hipEventDestroy(st->ev_counts); hipHostFree(st->counts_host); }
-    if (st->side) { hipEventDestroy(st->ev_fork); hipEventDestroy(st->ev_join); hipStreamDestroy(st->side); }
     delete st;
 }
 
@@ -386,26 +381,13 @@ int mvsdf_step_backward(void* step, const MvsdfStepParams* prm, int N, int n_tru
             float* dx = (float*)(bwd + bo.dx);
             int rc = mvsdf_sdf_backward_pair(&sdf, &sdfT, M, M, Mb, dy, dn, wsA, E, N, dy_x, use_geo ? dn_x : nullptr, (float*)(bwd + bo.wsX), dx, ctx, stream);
             if (rc == 0) {
-                // The delta pass covers the N hit rows only (a few dozen workgroups); the weight gradients of the rendering net and of the SDF
-                // net's sample-row chunks do not depend on it: they run beside it on a second stream, the hit-row chunks and the one reduction
-                // of all slabs follow on the main stream.
-                const bool fork = st->overlap != 0;
-                if (fork) {
-                    if (!st->side) {
-                        ST_HIP(hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking));
-                        ST_HIP(hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
-                        ST_HIP(hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming));
-                    }
-                    ST_HIP(hipEventRecord(st->ev_fork, s));
-                    ST_HIP(hipStreamWaitEvent(st->side, st->ev_fork, 0));
-                    ST_TRY(mv_step_wgrad(1, &sdf, &rnd, M, M, Mb, E, dy, ctx, wsA, with_r ? N : 0, R, rctx, rws, dW_s, db_s, dW_r, db_r, (void*)st->side));
-                    ST_HIP(hipEventRecord(st->ev_join, st->side));
-                }
+                // SampleNetwork's scalar (f = -xbar.v / n.v, App. E.6), its adjoints as fbar x s_l (one elementwise launch: the forward saved s_l), then the
+                // weight gradients of BOTH networks in one k_wgrad_net / k_reduce_net pair.  (Round 3 ran the chunks that do not depend on fbar on a
+                // second stream beside a 9-phase delta chain; with the delta reduced to ~10 us the split measured no gain and is gone.)
                 float* fbar = (float*)(bwd + bo.fbar);
                 ST_TRY(mvsdf_step_backward_fbar(d.n_eik, d.n_ds, N, Nout, din, st->K0r, use_geo, d_diff, dx, view_sorted, n_eval, dy, fbar, stream));
                 ST_TRY(mv_sdf_backward_delta(&sdf, &sdfT, M, M, Mb, ctx, wsA, E, N, fbar, stream));
-                if (fork) ST_HIP(hipStreamWaitEvent(s, st->ev_join, 0));
-                ST_TRY(mv_step_wgrad(fork ? 2 : 3, &sdf, &rnd, M, M, Mb, E, dy, ctx, wsA, with_r ? N : 0, R, rctx, rws, dW_s, db_s, dW_r, db_r, stream));
+                ST_TRY(mv_step_wgrad(&sdf, &rnd, M, M, Mb, dy, ctx, wsA, with_r ? N : 0, R, rctx, rws, dW_s, db_s, dW_r, db_r, stream));
                 done = true;
             } else if (rc == -3) {                                                      // network too wide for the fused chains: the sequential route
                 ST_TRY(mvsdf_sdf_backward(&sdf, &sdfT, x_eval + 3 * (size_t)E, M, M, E, N, dy_x, use_geo ? dn_x : nullptr, ctx, nullptr, nullptr, dx, wsA, stream));

@@ -24,14 +24,14 @@ int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const f
                           float* ctx, void* stream);
 
 // pieces of the training step's backward (diff_mlp.hip): the rendering net's descending chain alone, the SDF net's delta pass alone, and the weight
-// gradients of BOTH networks as one k_wgrad_net / k_reduce_net pair (part 1: what does not depend on the delta pass; part 2: the rest + reduction)
+// gradients of BOTH networks as one k_wgrad_net / k_reduce_net pair
 // drgb_rows (may be NULL): sorted row r takes its upstream from drgb[drgb_rows[r]]; -3 when that needs the fused chain kernel and it does not apply
 int mv_render_backward_chain(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, int Nctx, const float* drgb, const long long* drgb_rows, const float* ctx,
                              float* din, float* ws, void* stream);
 int mv_sdf_backward_delta(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M, int Mg, int Mb, const float* ctx, float* ws, int row0D, int MbD,
                           const float* fbar, void* stream);
-int mv_step_wgrad(int part, const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int M, int Mg, int Mb, int row_split, const float* dy, const float* ctx,
-                  float* wsA, int N, int Nctx, const float* rctx, float* rws, float* dW_s, float* db_s, float* dW_r, float* db_r, void* stream);
+int mv_step_wgrad(const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int M, int Mg, int Mb, const float* dy, const float* ctx, float* wsA, int N, int Nctx,
+                  const float* rctx, float* rws, float* dW_s, float* db_s, float* dW_r, float* db_r, void* stream);
 
 // fold + MFMA packs (+ bf16 packs where wp16[l] is set: nsplit[l] = its PE split width) of every layer + the camera rays in ONE launch
 // (basic.hip::k_step_prologue): the work of mvsdf_fold_pack_net, mvsdf_pack_bf16_net_skips and mvsdf_camera_rays, same results

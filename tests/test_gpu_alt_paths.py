@@ -1,6 +1,7 @@
 """The library keeps alternative launch paths behind environment switches (tools/README.md): per-layer kernels instead of the fused chain
 kernels (MVSDF_FUSE=0), the backward pass as separate E.1 / E.2 chain launches (MVSDF_SPLIT_CHAINS=1), 8-wave chain workgroups
-(MVSDF_CHAIN_W8=1), two row tiles per chain workgroup everywhere (MVSDF_CHAIN_MT=2).  Each is an independent implementation of the same
+(MVSDF_CHAIN_W8=1), two row tiles per chain workgroup everywhere (MVSDF_CHAIN_MT=2), the delta pass as a chain of GEMMs instead of the
+scaling of the saved s_l (MVSDF_DELTA_CHAIN=1), the Python-orchestrated step (MVSDF_NATIVE_STEP=0), the tracer without tail filling (MVSDF_TAIL=0).  Each is an independent implementation of the same
 passes: the reference-fixture tests of the differentiable kernels and one end-to-end fixture must pass on every one of them.  The switches
 are read once per process, so each configuration runs in a child pytest."""
 import os
@@ -17,7 +18,8 @@ TARGETS = ['tests/test_gpu_diff.py', 'tests/test_gpu_idr.py::test_forward_loss_b
            'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w256_tp03]']
 
 
-@pytest.mark.parametrize('env', [{'MVSDF_FUSE': '0'}, {'MVSDF_SPLIT_CHAINS': '1'}, {'MVSDF_CHAIN_W8': '1'}, {'MVSDF_CHAIN_MT': '2'}],
+@pytest.mark.parametrize('env', [{'MVSDF_FUSE': '0'}, {'MVSDF_SPLIT_CHAINS': '1'}, {'MVSDF_CHAIN_W8': '1'}, {'MVSDF_CHAIN_MT': '2'}, {'MVSDF_DELTA_CHAIN': '1'},
+                                 {'MVSDF_NATIVE_STEP': '0'}, {'MVSDF_TAIL': '0'}],
                          ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()))
 def test_reference_fixtures_pass_on_the_alternative_paths(env):
     e = dict(os.environ)
@@ -27,3 +29,30 @@ def test_reference_fixtures_pass_on_the_alternative_paths(env):
     tail = p.stdout.decode(errors='replace')[-2500:]
     assert p.returncode == 0, tail
     assert ' passed' in tail and 'failed' not in tail, tail
+
+
+def test_delta_by_scaling_equals_the_delta_chain():
+    """SampleNetwork's scalar enters the SDF backward as one extra upstream per hit row on output column 0.  The library adds its adjoints as
+    fbar x s_l (s_l = the forward's saved first-order sensitivities); MVSDF_DELTA_CHAIN=1 runs the 9-phase chain of GEMMs it replaced.  Same
+    mathematics, different rounding: the parameter gradients of a whole step agree to ~1e-6 of their largest entry."""
+    import tempfile
+    import torch
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
+from test_gpu_native_step import _run
+outs, losses, g, _, _ = _run(True, W=256, B=4, P=256, V=3, tp=0.3, sink=True)
+torch.save(g.cpu(), sys.argv[1])
+''' % (ROOT, ROOT)
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for chain in ('0', '1'):
+            out = os.path.join(td, 'g%s.pt' % chain)
+            e = dict(os.environ, MVSDF_DELTA_CHAIN=chain)
+            p = subprocess.run([sys.executable, '-c', code, out], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+            assert p.returncode == 0, p.stdout.decode(errors='replace')[-2000:]
+            res.append(torch.load(out))
+    a, b = res
+    dev = float((a - b).abs().max() / b.abs().max())
+    print('delta by scaling vs delta chain: max |dgrad| = %.3g of the largest gradient entry' % dev)
+    assert 0 < dev < 2e-5 or dev == 0.0
