@@ -242,7 +242,7 @@ __global__ void k_pack_round_net(PackBfArgs a) {
     }
 }
 
-template <int MT, int NTW>
+template <int MT, int NTW, bool CARRY>
 __global__ __launch_bounds__(512) void k_sdf_col0_bf(MvNetBf net, const float* __restrict__ x, int n, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512) void k_sdf_col0_bf(MvNetBf net, const float* _
         pts[i] = row < n ? x[3 * (size_t)row0 + i] : 0.0f;
     }
     __syncthreads();
-    mv_sdf_eval_col0<MT, NTW, 8>(net, act, pe, pts, out, tid);
+    mv_sdf_eval_col0<MT, NTW, 8, CARRY>(net, act, pe, pts, out, tid);
     if (tid < ROWS && row0 + tid < n) y[row0 + tid] = out[tid];
 }
 
@@ -265,9 +265,15 @@ template <int MT, int NTW>
 static int launch_col0_bf(const MvNetBf& net, const float* x, int n, float* y, hipStream_t s) {
     const int rows = 16 * MT, d0 = 3 + 6 * net.multires;
     const size_t lds = ((size_t)rows * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows) * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)k_sdf_col0_bf<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // MVSDF_BF_CARRY=1 (dev / tests): the weight-fetch scheme of k_sphere_trace (tile_engine_bf16.h, CARRIED) instead of the row-sample kernels' (ROLLING);
+    // same arithmetic, bit-identical results (tests/test_gpu_bf16.py)
+    static int carry = -1;
+    if (carry < 0) { const char* ev = getenv("MVSDF_BF_CARRY"); carry = ev ? atoi(ev) : 0; }
+    hipError_t e = carry ? hipFuncSetAttribute((const void*)k_sdf_col0_bf<MT, NTW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                         : hipFuncSetAttribute((const void*)k_sdf_col0_bf<MT, NTW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return mv_check(e, "mvsdf_sdf_col0: LDS attribute");
-    hipLaunchKernelGGL((k_sdf_col0_bf<MT, NTW>), dim3((n + rows - 1) / rows), dim3(512), lds, s, net, x, n, y);
+    if (carry) hipLaunchKernelGGL((k_sdf_col0_bf<MT, NTW, true>), dim3((n + rows - 1) / rows), dim3(512), lds, s, net, x, n, y);
+    else hipLaunchKernelGGL((k_sdf_col0_bf<MT, NTW, false>), dim3((n + rows - 1) / rows), dim3(512), lds, s, net, x, n, y);
     return mv_check(hipGetLastError(), "mvsdf_sdf_col0 (bf16)");
 }
 

@@ -45,13 +45,22 @@ __device__ __forceinline__ bool mv_sphere_isect(const float* c, const float* d, 
 }
 
 // NET = MvNet (fp32 weights, fp32-input MFMA, bit-exact vs the oracle) or MvNetBf (bf16 weights / activations, bf16 MFMA): overloads of mv_sdf_eval_col0
+// XR: the weight fetch of the next layer runs under this layer's work (fp32 engine: ring carried across layers, one row tile only; bf16 engine:
+// the CARRIED scheme of tile_engine_bf16.h) -- for k_sphere_trace, whose evaluations wait for each other; costs registers
 template <int MT, int NTW, int NW, class NET, bool XR = false>
 __device__ __forceinline__ void mv_eval_dispatch(const NET& net, int ntiles, float* act, float* pe, const float* pts, float* out, int tid) {
-    if (MT >= 4 && ntiles == 4) mv_sdf_eval_col0<(MT >= 4 ? 4 : MT), NTW, NW>(net, act, pe, pts, out, tid);
-    else if (MT >= 3 && ntiles == 3) mv_sdf_eval_col0<(MT >= 3 ? 3 : MT), NTW, NW>(net, act, pe, pts, out, tid);
-    else if (MT >= 2 && ntiles == 2) mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW, NW>(net, act, pe, pts, out, tid);
-    else if constexpr (XR && std::is_same<NET, MvNet>::value) mv_sdf_eval_col0<1, NTW, NW, true>(net, act, pe, pts, out, tid);   // fp32 engine: weight ring carried across layers
-    else mv_sdf_eval_col0<1, NTW, NW>(net, act, pe, pts, out, tid);
+    if constexpr (std::is_same<NET, MvNet>::value) {
+        if (MT >= 4 && ntiles == 4) mv_sdf_eval_col0<(MT >= 4 ? 4 : MT), NTW, NW>(net, act, pe, pts, out, tid);
+        else if (MT >= 3 && ntiles == 3) mv_sdf_eval_col0<(MT >= 3 ? 3 : MT), NTW, NW>(net, act, pe, pts, out, tid);
+        else if (MT >= 2 && ntiles == 2) mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW, NW>(net, act, pe, pts, out, tid);
+        else if constexpr (XR) mv_sdf_eval_col0<1, NTW, NW, true>(net, act, pe, pts, out, tid);
+        else mv_sdf_eval_col0<1, NTW, NW>(net, act, pe, pts, out, tid);
+    } else {
+        if (MT >= 4 && ntiles == 4) mv_sdf_eval_col0<(MT >= 4 ? 4 : MT), NTW, NW, XR>(net, act, pe, pts, out, tid);
+        else if (MT >= 3 && ntiles == 3) mv_sdf_eval_col0<(MT >= 3 ? 3 : MT), NTW, NW, XR>(net, act, pe, pts, out, tid);
+        else if (MT >= 2 && ntiles == 2) mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW, NW, XR>(net, act, pe, pts, out, tid);
+        else mv_sdf_eval_col0<1, NTW, NW, XR>(net, act, pe, pts, out, tid);
+    }
 }
 
 // LDS carve shared by both kernels
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams
             }
             __syncthreads();
         }
-        mv_eval_dispatch<MT, NTW, NW, NET, (MT == 1)>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
+        mv_eval_dispatch<MT, NTW, NW, NET, (MT == 1 || !std::is_same<NET, MvNet>::value)>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
         if (helping) {
             if (tid < h_nr) tail.sv[h_svi] = lds.sdfv[tid];
             __syncthreads();                                      // values read before the next chunk's points overwrite the tile

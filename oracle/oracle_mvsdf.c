@@ -63,11 +63,13 @@ void orc_pe(const float *x, int n, int multires, float *out) {
     for (int i = 0; i < n; ++i) pe_row(x + 3 * i, multires, out + (size_t)d * i);
 }
 
-/* ---- bf16 twin of the tracing MLP (BASELINE configs[4]; product: mvsdf_amd/csrc/tile_engine_bf16.h).  Same rounding points: the caller hands
- * over weights already rounded to bf16; hidden activations are rounded to bf16 (nearest even); every positional-encoding input v enters as
- * hi = bf16(v) and lo = bf16(v - hi) sharing one weight; fp32 accumulation in the packed k order [columns | lo copies of the split columns],
- * fp32 bias / softplus.  The hardware sums each MFMA's 32 products with its own internal alignment, so this twin is NOT bit-identical to the
- * kernel (tests bound the difference). ---- */
+/* ---- bf16 twin of the tracing MLP (BASELINE configs[4]; product: mvsdf_amd/csrc/tile_engine_bf16.h).  Same rounding points and the same
+ * formulas: the caller hands over weights already rounded to bf16; hidden activations are rounded to bf16 (nearest even); every
+ * positional-encoding input v enters as hi = bf16(v) and lo = bf16(v - hi) sharing one weight; fp32 accumulation STARTING FROM THE BIAS in the
+ * packed k order [columns | lo copies of the split columns]; fp32 softplus in the engine's form
+ *     softplus(100 z) / 100 = max(z, 0) + t * Q(t),  t = exp(-100 |z|),  Q = the engine's degree-5 fit of ln(1 + t) / (100 t)  (8.5e-6 relative).
+ * The hardware sums each MFMA's 32 products with its own internal alignment and has its own 1-ulp exp2, so this twin is NOT bit-identical to
+ * the kernel (tests bound the difference). ---- */
 static int g_bf16 = 0;
 void orc_set_bf16(int on) { g_bf16 = on; }
 static float bf16r(float f) {
@@ -93,16 +95,23 @@ static void sdf_row_bf16(const orc_net *net, const float *x, int ncols, float *y
         int in = net->in[l];                  /* = na + nsp */
         for (int j = 0; j < no; ++j) {
             const float *w = W + (size_t)j * in;
-            float acc = 0.0f;
+            float acc = net->b[l][j];
             for (int k = 0; k < na; ++k) acc = fmaf(a[k], w[k], acc);
             for (int k = 0; k < nsp; ++k) acc = fmaf(bf16r(sp[k]), w[na + k], acc);
             for (int k = 0; k < nsp; ++k) acc = fmaf(bf16r(sp[k] - bf16r(sp[k])), w[na + k], acc);
-            z[j] = acc + net->b[l][j];
+            z[j] = acc;
         }
         if (last) { memcpy(y, z, sizeof(float) * no); return; }
         int to_skip = (net->skip_mask >> (l + 1)) & 1;
         for (int j = 0; j < no; ++j) {
-            float h = dm_softplus100(z[j]);
+            const float t = dm_expneg(-fabsf(z[j]) * 100.0f);
+            float u = -2.3869141936302185e-4f;
+            u = fmaf(u, t, 1.0122226178646088e-3f);
+            u = fmaf(u, t, -2.1004866063594818e-3f);
+            u = fmaf(u, t, 3.252066671848297e-3f);
+            u = fmaf(u, t, -4.993613660335541e-3f);
+            u = fmaf(u, t, 9.999915957450867e-3f);
+            float h = fmaf(t, u, z[j] > 0.0f ? z[j] : 0.0f);
             if (to_skip) h = dm_div_sqrt2(h);
             a[j] = bf16r(h);
         }
