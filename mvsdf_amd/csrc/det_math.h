@@ -97,6 +97,18 @@ DM_FN float dm_softplus100(float z) {
     return dm_div100(s);
 }
 
+/* dm_softplus100(z) and dm_sigmoid100(z) together: they share t = exp(-|100 z|) -- per element the same operations in the same order as the two
+ * functions (bit-identical).  The differentiable passes save sigma once in the forward instead of recomputing it three times from z. */
+DM_FN void dm_softplus_sigmoid100(float z, float *h, float *sg) {
+    float y = z * 100.0f;
+    if (y > 20.0f) { *h = z; *sg = 1.0f; return; }
+    float t = dm_expneg(-fabsf(y));
+    *h = dm_div100(fmaxf(y, 0.0f) + dm_log1p01(t));
+    *sg = (y >= 0.0f ? 1.0f : t) / (1.0f + t);
+}
+/* d/dz sigmoid(100 z) from sigma: where 100 z > 20 sigma is exactly 1 and the product exactly 0 */
+DM_FN float dm_sigmoid_prime100(float sg) { return 100.0f * sg * (1.0f - sg); }
+
 /* sin(a), cos(a) for |a| < ~1e4 (positional encoding arguments are < 64) */
 DM_FN void dm_sincos(float a, float *s, float *c) {
     float j = dm_rint(a * 0.6366197466850281f);

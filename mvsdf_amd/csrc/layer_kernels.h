@@ -17,13 +17,14 @@
 
 enum {
     PRO_PLAIN = 0,      // A[row][k]
-    PRO_SIG_MUL,        // sigmoid100(Z[row][k]) * U[row][k]            (s_l = sigma_l . u_{l+1})
-    PRO_SIG_BCAST,      // sigmoid100(Z[row][k]) * bcast[k]             (l = 7: u_8 = W_8[0, :])
-    PRO_ZBAR,           // zb = sigmoid100(Z)*U + (row < Mg ? A[row][k] : 0); also stored to out2     (E.2)
+    PRO_SIG_MUL,        // Z[row][k] * U[row][k], Z = the saved sigma_l = sigmoid100(z_l)   (s_l = sigma_l . u_{l+1})
+    PRO_SIG_BCAST,      // Z[row][k] * bcast[k]                         (l = 7: u_8 = W_8[0, :])
+    PRO_ZBAR,           // zb = Z*U + (row < Mg ? A[row][k] : 0); also stored to out2     (E.2)
     PRO_TANH_BWD        // dz = A[row][k] * (1 - U[row][k]^2); also stored to out2
 };
 enum {
-    EPI_SOFTPLUS = 0,   // z = acc + b -> out1 (Z);  h = softplus100(z) (/sqrt2 if skip_next) -> out0 (+ PE tail if skip_next)
+    EPI_SOFTPLUS = 0,   // z = acc + b;  sigmoid100(z) -> out1 ("Z": the backward and the normal chain need sigma, never z itself);
+                        // h = softplus100(z) (/sqrt2 if skip_next) -> out0 (+ PE tail if skip_next)
     EPI_BIAS,           // out0 = acc + b
     EPI_SPLIT,          // col < csplit: out0[row][col] = f(acc) ; else out1[row][col - csplit] = f(acc); f = /sqrt2 if scale; + add[row][col] if add
     EPI_SBAR,           // sbar = acc: out0 = sigma*sbar (/sqrt2 if skip_next), out1 = u*sbar*sigma'            (E.1)
@@ -51,21 +52,17 @@ struct LayerArgs {
     const float* pe; int ldpe; // PE rows for the skip tail
 };
 
-__device__ __forceinline__ float mv_sigmoid_prime100(float z, float sig) {      // d/dz sigmoid(100 z) (0 past the threshold)
-    return (z * 100.0f > 20.0f) ? 0.0f : 100.0f * sig * (1.0f - sig);
-}
-
 template <int PRO>
 __device__ __forceinline__ float mv_prologue(const LayerArgs& a, int row, int k) {
     if (PRO == PRO_PLAIN) return a.A[(size_t)row * a.lda + k];
     if (PRO == PRO_SIG_MUL || PRO == PRO_SIG_BCAST) {
         const float u = PRO == PRO_SIG_MUL ? a.U[(size_t)row * a.ldu + k] : a.bcast[k];
-        const float sv = dm_sigmoid100(a.Z[(size_t)row * a.ldz + k]) * u;
+        const float sv = a.Z[(size_t)row * a.ldz + k] * u;
         if (a.out2) a.out2[(size_t)row * a.ld2 + k] = sv;                       // s_l, kept for the weight gradient (E.1)
         return sv;
     }
     if (PRO == PRO_ZBAR) {
-        float zb = dm_sigmoid100(a.Z[(size_t)row * a.ldz + k]) * a.U[(size_t)row * a.ldu + k];
+        float zb = a.Z[(size_t)row * a.ldz + k] * a.U[(size_t)row * a.ldu + k];
         if (row < a.Mg && a.A) zb += a.A[(size_t)row * a.lda + k];
         a.out2[(size_t)row * a.ld2 + k] = zb;
         return zb;
@@ -95,8 +92,9 @@ template <int EPI>
 __device__ __forceinline__ void mv_epilogue(const LayerArgs& a, int row, int col, float acc, const EpiIn& in) {
     if (EPI == EPI_SOFTPLUS) {
         const float z = acc + a.L.bias[col];
-        a.out1[(size_t)row * a.ld1 + col] = z;
-        float h = dm_softplus100(z);
+        float h, sg;
+        dm_softplus_sigmoid100(z, &h, &sg);
+        a.out1[(size_t)row * a.ld1 + col] = sg;
         if (a.skip_next) h = dm_div_sqrt2(h);
         a.out0[(size_t)row * a.ld0 + col] = h;
     } else if (EPI == EPI_BIAS) {
@@ -108,13 +106,12 @@ __device__ __forceinline__ void mv_epilogue(const LayerArgs& a, int row, int col
         if (col < a.csplit) a.out0[(size_t)row * a.ld0 + col] = v;
         else a.out1[(size_t)row * a.ld1 + (col - a.csplit)] = v;
     } else if (EPI == EPI_SBAR) {
-        const float z = in.z;
-        const float sig = dm_sigmoid100(z);
+        const float sig = in.z;                                                 // the saved sigma
         const float u = in.u;
         float ub = sig * acc;
         if (a.skip_next) ub = dm_div_sqrt2(ub);
         a.out0[(size_t)row * a.ld0 + col] = ub;
-        a.out1[(size_t)row * a.ld1 + col] = u * acc * mv_sigmoid_prime100(z, sig);
+        a.out1[(size_t)row * a.ld1 + col] = u * acc * dm_sigmoid_prime100(sig);
     } else if (EPI == EPI_RELU) {
         a.out0[(size_t)row * a.ld0 + col] = fmaxf(acc + a.L.bias[col], 0.0f);
     } else if (EPI == EPI_TANH) {
@@ -428,7 +425,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_e2(ChainArgs a) {
                 if (idx < ROWS * Kp && row < a.M && k < K) {
                     if (l == nl - 1) v[u] = a.dy_col0 ? (k == 0 ? a.dy_col0[row] : 0.0f) : a.dy[(size_t)row * a.ld_dy + k];
                     else {
-                        float zb = dm_sigmoid100(a.Z[l][(size_t)row * K + k]) * act[rr * S + mv_perm(k)];
+                        float zb = a.Z[l][(size_t)row * K + k] * act[rr * S + mv_perm(k)];
                         if (a.ZB2[l]) zb += a.ZB2[l][(size_t)row * K + k];
                         a.ZB[l][(size_t)row * K + k] = a.accum ? a.ZB[l][(size_t)row * K + k] + zb : zb;   // the GEMM below continues with this pass's zbar
                         v[u] = zb;
@@ -539,13 +536,13 @@ __global__ __launch_bounds__(64 * NW) void k_chain_e1(ChainArgs a) {
                         for (int i = 0; i < 4; ++i) {
                             const int rr = m * 16 + 4 * q + i, row = row0 + rr;
                             const float sb = acc[m][t][i];
-                            const float sig = dm_sigmoid100(zz[t][m][i]);
+                            const float sig = zz[t][m][i];                           // the saved sigma
                             float ub = sig * sb;
                             if (to_skip) ub = dm_div_sqrt2(ub);
                             act[rr * S + mv_perm(col)] = ub;
                             if (row < a.M) {
                                 a.VB[l + 1][(size_t)row * ldn + col] = ub;
-                                a.ZB2o[l][(size_t)row * N + col] = uu[t][m][i] * sb * mv_sigmoid_prime100(zz[t][m][i], sig);
+                                a.ZB2o[l][(size_t)row * N + col] = uu[t][m][i] * sb * dm_sigmoid_prime100(sig);
                             }
                         }
                 }
@@ -643,13 +640,13 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
                             for (int i = 0; i < 4; ++i) {
                                 const int rr = m * 16 + 4 * q + i, row = row0 + rr;
                                 const float sb = acc[m][t][i];
-                                const float sig = dm_sigmoid100(zz[t][m][i]);
+                                const float sig = zz[t][m][i];                           // the saved sigma
                                 float ub = sig * sb;
                                 if (to_skip) ub = dm_div_sqrt2(ub);
                                 act[rr * S + mv_perm(col)] = ub;
                                 if (row < a.M) {
                                     a.VB[l + 1][(size_t)row * ldn + col] = ub;
-                                    a.ZB2o[l][(size_t)row * N + col] = uu[t][m][i] * sb * mv_sigmoid_prime100(zz[t][m][i], sig);
+                                    a.ZB2o[l][(size_t)row * N + col] = uu[t][m][i] * sb * dm_sigmoid_prime100(sig);
                                 }
                             }
                     }
@@ -690,7 +687,7 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
                 if (idx < ROWS * Kp && row < a.M && k < K) {
                     if (l == nl - 1) v[u] = a.dy_col0 ? (k == 0 ? a.dy_col0[row] : 0.0f) : a.dy[(size_t)row * a.ld_dy + k];
                     else {
-                        float zb = dm_sigmoid100(a.Z[l][(size_t)row * K + k]) * act[rr * S + mv_perm(k)];
+                        float zb = a.Z[l][(size_t)row * K + k] * act[rr * S + mv_perm(k)];
                         if (a.ZB2[l]) zb += a.ZB2[l][(size_t)row * K + k];
                         a.ZB[l][(size_t)row * K + k] = a.accum ? a.ZB[l][(size_t)row * K + k] + zb : zb;   // the GEMM below continues with this pass's zbar
                         v[u] = zb;
@@ -783,7 +780,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_bwd2(ChainArgs a, ChainArgs b
 
 // ---------------------------------------------------------------------------------------------------------------
 // Forward value + normal of the SDF network for 16*MT rows per workgroup in ONE launch (replaces 1 + 9 + 8 + 1 launches):
-//   value  (ascending, idr.py:77-94):  PE -> [Linear, Softplus(100)] x (L-1) -> Linear; stores H0, A_l, Z_l, y;
+//   value  (ascending, idr.py:77-94):  PE -> [Linear, Softplus(100)] x (L-1) -> Linear; stores H0, A_l, sigma_l = sigmoid(100 z_l), y;
 //   normal (descending, idr.py:96-107 = VJP of output 0): u_L = W_L[0,:]; s_l = sigma(100 z_l) . u_{l+1}; u_l = s_l W_l (split and
 //           /sqrt2 at the skip layer); g_0 = u_0 (+ PE part of the skip layer); n = J_PE^T g_0; stores Sg_l, U_l, G0, n.
 // The running activation / adjoint tile never leaves LDS.  Same arithmetic as the per-layer kernels it replaces.
@@ -792,7 +789,7 @@ struct FwdArgs {
     int S, M, Mg, ld0;
     const float* x;                            // [M][3]
     float* H0;                                 // [M][ld0]
-    float* A[MV_MAXL]; float* Z[MV_MAXL];      // A_l [M][K_l] (l >= 1), Z_l [M][N_l]
+    float* A[MV_MAXL]; float* Z[MV_MAXL];      // A_l [M][K_l] (l >= 1), Z_l [M][N_l] = sigma_l = sigmoid100(z_l) (what every later pass needs of z_l)
     float* U[MV_MAXL]; float* Sg[MV_MAXL];     // u_l [Mg][N_{l-1}] (1 <= l <= L-2), s_l [Mg][N_l]
     float* G0;                                 // [Mg][ld0]
     float* y; int ldy;                         // [M][Nout]
@@ -859,11 +856,12 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
                         for (int i = 0; i < 4; ++i) {
                             const int rr = m * 16 + 4 * q + i, row = row0 + rr;
                             const float z = acc[m][t][i] + bv;
-                            float h = dm_softplus100(z);
+                            float h, sg;
+                            dm_softplus_sigmoid100(z, &h, &sg);
                             if (to_skip) h = dm_div_sqrt2(h);
                             act[rr * S + mv_perm(col)] = h;
                             if (row < a.M) {
-                                a.Z[l][(size_t)row * N + col] = z;
+                                a.Z[l][(size_t)row * N + col] = sg;
                                 a.A[l + 1][(size_t)row * Kn + col] = h;
                             }
                         }
@@ -931,7 +929,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
                 v[u] = 0.0f;
                 if (idx < ROWS * Kp && row < a.Mg && k < K) {
                     const float uu = top ? a.w_last_row0[k] : act[rr * S + mv_perm(k)];
-                    v[u] = dm_sigmoid100(a.Z[l][(size_t)row * K + k]) * uu;
+                    v[u] = a.Z[l][(size_t)row * K + k] * uu;
                     a.Sg[l][(size_t)row * K + k] = v[u];
                 }
             }

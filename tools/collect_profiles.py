@@ -1,0 +1,19 @@
+"""gpurun_out/r03 (written on the GPU box by tools/run_profiles.sh) -> the tracked artefacts under profiles/ (bench lines, rocprofv3 kernel stats,
+PMC summaries, pmc_traffic.json).  usage: python tools/collect_profiles.py [round tag, default r03]"""
+import glob, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+src, dst = os.path.join(ROOT, 'gpurun_out', tag), os.path.join(ROOT, 'profiles')
+for f in sorted(glob.glob(src + '/bench_line*.json')):
+    lines = [l for l in open(f).read().splitlines() if l.startswith('{')]
+    assert lines, f
+    open(os.path.join(dst, '%s_%s' % (tag, os.path.basename(f))), 'w').write(lines[-1] + '\n')
+for d in sorted(glob.glob(src + '/stats_*')):
+    f = glob.glob(d + '/**/*kernel_stats.csv', recursive=True)
+    assert len(f) == 1, d
+    shutil.copy(f[0], os.path.join(dst, '%s_%s_kernel_stats.csv' % (tag, os.path.basename(d)[len('stats_'):])))
+for d in sorted(glob.glob(src + '/pmc_*')):
+    w = os.path.basename(d)[len('pmc_'):]
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_to_csv.py'), d, os.path.join(dst, '%s_pmc_summary_%s.csv' % (tag, w))])
+subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_to_json.py'), os.path.join(src, 'pmc_c2_f32'), 'c2', os.path.join(dst, 'pmc_traffic.json'),
+                       'c2 round 3: separate --pmc FETCH_SIZE / WRITE_SIZE passes of python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline (tools/run_profiles.sh)'])
