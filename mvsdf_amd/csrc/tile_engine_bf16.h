@@ -232,7 +232,7 @@ __device__ __forceinline__ void mv_gemm_rolling_dispatch_bf(int KB, const uint16
 //     ln(1 + t) / 100 = t * Q(t),  Q = a degree-5 fit of ln(1 + t) / (100 t) on [0, 1] with relative error 8.5e-6 = 2^-17 -- 1/230 of the half
 //     ulp of the bf16 rounding that follows (degree 4, 5.7e-5, flips that rounding for ~2 % of the activations: the mean distance to the
 //     oracle's twin went from 5e-5 to 2e-4) -- evaluated for two activations per instruction (v_pk_fma_f32).
-// 18 ordinary (12 of them two-wide) + 4 transcendental VALU instructions per four activations instead of 27 per activation (det_math): this
+// 24 ordinary (14 of them two-wide) + 4 transcendental VALU instructions per four activations instead of 27 per activation (det_math): this
 // engine is bound by issue and waits, not by the bf16 MFMAs (PMC: DESIGN.md).  Above the threshold (100 z > 20) t * Q(t) is below half an ulp
 // of z: the sum IS z, no select needed.  After the bf16 rounding the result agrees with dm_softplus100's except at rounding boundaries, the
 // same kind of difference as the MFMA's summation order (tests/test_gpu_bf16.py bounds both against the oracle's twin, which keeps
