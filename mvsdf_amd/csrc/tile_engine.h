@@ -17,6 +17,13 @@
 
 #define MV_THREADS 256
 
+// phase stamps of tools/micro/f32_engine_rounds.hip (dev probe); nothing in the product build
+#ifndef MV_PH
+#define MV_PH_DECL
+#define MV_PH(p)
+#define MV_PH_END
+#endif
+
 // dev-only ablation switches (never set in the shipped build): 1 = softplus -> identity, 2 = skip the GEMM
 #ifndef MV_ABLATE
 #define MV_ABLATE 0
@@ -210,7 +217,9 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
     constexpr int NTHREADS = 64 * NW;
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
     const int S = net.S, rows = MTc * 16, d0 = 3 + 6 * net.multires;
+    MV_PH_DECL
     mv_pe_rows<NTHREADS>(pts, pe, act, S, rows, net.multires, tid);
+    MV_PH(0)
     const int nl = net.n_layers;
     constexpr bool XRING = XR && (MTc * NTW <= 8);                // the deep ring (PD = 4) and its carry across layers (mv_gemm_ring_x)
     float4 bring[4][NTW];
@@ -240,12 +249,16 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
             const int col = (ct0 + t) * 16 + r;
             bv_[t] = (t < ntw && col < L.N) ? L.bias[col] : 0.0f;
         }
+        MV_PH(7)
         mv_barrier_lds();                                     // inputs of layer l complete (LDS); the bias loads stay in flight
+        MV_PH(1)
         if (XRING && xr) {
             mv_gemm_ring_x<MTc, NTW, NTW, 4>(L, act, S, ct0, acc, lane, bring, primed, wn, KBn);
             primed = (wn != nullptr);
         } else if (ntw > 0 && !(MV_ABLATE & 2)) mv_gemm_dispatch<MTc, NTW>(L, act, S, ct0, ntw, acc, lane);
+        MV_PH(6)
         mv_barrier_lds();                                     // every wave done reading act (in-place update)
+        MV_PH(3)
         if (last) {
             if (w == 0 && r == 0) {
                 const float b0 = bv_[0];
@@ -291,8 +304,11 @@ __device__ void mv_sdf_eval_col0(const MvNet& net, float* act, float* pe, const 
                 }
             }
         }
+        MV_PH(4)
     }
     __syncthreads();
+    MV_PH(5)
+    MV_PH_END
 }
 
 
