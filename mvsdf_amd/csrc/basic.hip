@@ -563,6 +563,7 @@ struct ProloArgs {
     int wp16_fp32;                       // 1: wp16[l] receives the fp32 pack of the bf16-rounded weights (trace_dtype = 2) instead of the bf16 pack
     const float* uv; const float* pose; const float* Kin; int B, P; float* dirs; float* cam_loc;
     uint8_t* ones;                       // optional [B * P]: filled with 1 (the all-ones object mask of the output dict, idr.py:187)
+    unsigned long long* counters;        // optional [16]: zeroed (the tracer's device counters: saves its memset node)
     int ld;                              // LDS row stride (floats) >= max K
 };
 __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
@@ -571,6 +572,7 @@ __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
     const int nl = a.f.n_layers;
     if ((int)blockIdx.x >= a.blk0[nl]) {                                       // ---- camera rays
         const int idx = ((int)blockIdx.x - a.blk0[nl]) * 1024 + tid;
+        if (a.counters && idx < 16) a.counters[idx] = 0ull;
         if (idx >= a.B * a.P) return;
         if (a.ones) a.ones[idx] = 1;
         const int b = idx / a.P;
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
 
 int mv_step_prologue(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w, float* const* wp,
                      float* const* wpT, void* const* wp16, const int* nsplit, int wp16_fp32, const float* uv, const float* pose, const float* intrinsics, int B, int P,
-                     float* ray_dirs, float* cam_loc, uint8_t* ones, void* stream) {
+                     float* ray_dirs, float* cam_loc, uint8_t* ones, unsigned long long* counters, void* stream) {
     ProloArgs a;
     int maxN; size_t maxTot;
     int rc = fill_fold_args(a.f, n_layers, N, K, &maxN, &maxTot);
@@ -686,7 +688,7 @@ int mv_step_prologue(int n_layers, const float* const* v, const float* const* g,
     a.blk0[n_layers] = blk;
     a.uv = uv; a.pose = pose; a.Kin = intrinsics; a.B = B; a.P = P; a.dirs = ray_dirs; a.cam_loc = cam_loc;
     a.wp16_fp32 = wp16_fp32 ? 1 : 0;
-    a.ones = ones;
+    a.ones = ones; a.counters = counters;
     a.ld = ((maxK + 3) & ~3) + 4;
     const size_t lds = (size_t)16 * a.ld * sizeof(float);
     blk += (B * P + 1023) / 1024;

@@ -622,10 +622,28 @@ struct DeltaArgs {
     int N[MV_MAXL];
     const float* Sg[MV_MAXL]; float* ZB[MV_MAXL];     // already offset to the first hit row
     const float* fbar;
+    // FB (the step driver): fbar is computed here instead of by k_step_bwd_fbar (same operations in the same order, sample_network.py:10-20
+    // backward: fbar_i = -(xbar_i . v_i) / (n_i . v_i), xbar = d_diff + dp + dx); the blocks of layer 0 write fbar_out[i] and add it to dy[i][0]
+    const float* d_diff; const float* din; const float* dx; const float* view_sorted; const float* n_hit;   // n_hit: normals of the hit rows
+    int din_ld, use_geo, Nout;
+    float* dy_hit; float* fbar_out;          // dy already offset to the first hit row
 };
+template <bool FB>
 __global__ __launch_bounds__(256) void k_delta_apply(DeltaArgs a) {
     const int row = blockIdx.x, l = blockIdx.y, N = a.N[l];
-    const float f = a.fbar[row];
+    float f;
+    if (FB) {
+        float dot = 0.f, num = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            float xb = (a.d_diff ? a.d_diff[3 * (size_t)row + c] : 0.f);
+            if (a.din && a.use_geo) xb += a.din[(size_t)row * a.din_ld + c];
+            if (a.dx) xb += a.dx[3 * (size_t)row + c];
+            const float v = -a.view_sorted[3 * (size_t)row + c];
+            num += xb * v; dot += a.n_hit[3 * (size_t)row + c] * v;
+        }
+        f = -num / dot;
+        if (l == 0 && threadIdx.x == 0) { a.fbar_out[row] = f; a.dy_hit[(size_t)row * a.Nout] += f; }
+    } else f = a.fbar[row];
     const float* sg = a.Sg[l] + (size_t)row * N;
     float* zb = a.ZB[l] + (size_t)row * N;
     for (int c = threadIdx.x; c < N; c += 256) zb[c] = zb[c] + f * sg[c];
@@ -635,6 +653,7 @@ static int mv_delta_chain() {
     if (v < 0) { const char* e = getenv("MVSDF_DELTA_CHAIN"); v = e ? atoi(e) : 0; }
     return v;
 }
+int mv_delta_is_chain() { return mv_delta_chain(); }
 
 static int sdf_delta_pass(const MvNet& net, const MvNet& netT, const SdfLayout& lo, const SdfBwdLayout& bl, const float* ctx, float* ws, int row0D,
                           int MbD, const float* fbar, hipStream_t s) {
@@ -647,7 +666,7 @@ static int sdf_delta_pass(const MvNet& net, const MvNet& netT, const SdfLayout& 
             d.Sg[l] = ctx + lo.Sg[l] + (size_t)row0D * net.L[l].N;
             d.ZB[l] = ws + bl.ZB[l] + (size_t)row0D * net.L[l].N;
         }
-        hipLaunchKernelGGL(k_delta_apply, dim3(MbD, lo.nl - 1), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k_delta_apply<false>, dim3(MbD, lo.nl - 1), dim3(256), 0, s, d);
         return mv_check(hipGetLastError(), "sdf_delta_pass");
     }
     // MVSDF_DELTA_CHAIN=1: the first-order chain (the form this replaced; kept as the cross-check of tests/test_gpu_diff.py)
@@ -934,6 +953,32 @@ int mv_sdf_backward_delta(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M, 
     if (!ctx || !ws || !fbar || Mb <= 0 || Mb > Mg || Mg > M || MbD <= 0 || row0D < 0 || row0D + MbD > Mb) return mv_fail(-1, "mv_sdf_backward_delta: bad arguments");
     if (!mv_chain_ntw(net)) return mv_fail(-3, "mv_sdf_backward_delta: network too wide for the fused chain kernels");
     return sdf_delta_pass(net, netT, sdf_ctx_layout(net, M, Mg), sdf_bwd_layout(net, Mb), ctx, ws, row0D, MbD, fbar, (hipStream_t)stream);
+}
+
+// mvsdf_step_backward_fbar + mv_sdf_backward_delta in one launch (the step driver's route; identical results): the hit rows are rows
+// [row0D, row0D + MbD) of the evaluation, dy / n_eval are the evaluation's [M][Nout] / [M][3]
+int mv_sdf_backward_delta_fbar(const MvsdfNetDesc* d, int M, int Mg, int Mb, const float* ctx, float* ws, int row0D, int MbD, int Nout, const float* din,
+                               int din_ld, int use_geo, const float* d_diff, const float* dx, const float* view_sorted, const float* n_eval, float* dy,
+                               float* fbar, void* stream) {
+    MvNet net;
+    int rc = mv_make_net(d, &net);
+    if (rc) return rc;
+    if (!ctx || !ws || !fbar || !view_sorted || !n_eval || !dy || Mb <= 0 || Mb > Mg || Mg > M || MbD <= 0 || row0D < 0 || row0D + MbD > Mb)
+        return mv_fail(-1, "mv_sdf_backward_delta_fbar: bad arguments");
+    const SdfLayout lo = sdf_ctx_layout(net, M, Mg);
+    const SdfBwdLayout bl = sdf_bwd_layout(net, Mb);
+    DeltaArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nl1 = lo.nl - 1; a.rows = MbD;
+    for (int l = 0; l < lo.nl - 1; ++l) {
+        a.N[l] = net.L[l].N;
+        a.Sg[l] = ctx + lo.Sg[l] + (size_t)row0D * net.L[l].N;
+        a.ZB[l] = ws + bl.ZB[l] + (size_t)row0D * net.L[l].N;
+    }
+    a.d_diff = d_diff; a.din = din; a.dx = dx; a.view_sorted = view_sorted; a.n_hit = n_eval + 3 * (size_t)row0D;
+    a.din_ld = din_ld; a.use_geo = use_geo; a.Nout = Nout; a.dy_hit = dy + (size_t)row0D * Nout; a.fbar_out = fbar;
+    hipLaunchKernelGGL(k_delta_apply<true>, dim3(MbD, lo.nl - 1), dim3(256), 0, (hipStream_t)stream, a);
+    return mv_check(hipGetLastError(), "mv_sdf_backward_delta_fbar");
 }
 
 /* Weight / bias gradients of BOTH networks of a training step: one k_wgrad_net launch over every layer and chunk (+ the column sums of ubar_last) and

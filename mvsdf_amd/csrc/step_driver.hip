@@ -257,7 +257,7 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
         }
         // ... and the camera rays (idr.py:190), all in one launch
         ST_TRY(mv_step_prologue(nl, prm->v, prm->g, d.N, d.K, w, wp, wpT, wp16, nsplit, d.trace_dtype == 2 ? 1 : 0, in->uv, in->pose, in->intrinsics, d.B, d.P, ray_dirs, cam_loc,
-                                (uint8_t*)(fwd + L.object_mask_out), stream));
+                                (uint8_t*)(fwd + L.object_mask_out), (unsigned long long*)(fwd + L.counters), stream));
     }
     MvsdfNetDesc sdf, sdfT, rnd, rndT;
     make_descs(*st, prm, fwd, &sdf, &sdfT, &rnd, &rndT);
@@ -269,7 +269,8 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
                                  counters, fwd + fo.trace_ws, fo.trace_ws_bytes, d.mt, d.mt_samples, stream);
     };
     if (st->timing) ST_HIP(hipEventRecord(st->ev_t[0], s));
-    ST_TRY(stage(1));
+    ST_TRY(mv_trace_stage1_prezeroed(&sdf, &d.tp, cam_loc, ray_dirs, in->object_mask, d.B, d.P, 1, in->intervals, in->minsdf_steps, points, mask, dists,
+                                     counters, fwd + fo.trace_ws, fo.trace_ws_bytes, d.mt, d.mt_samples, stream));   // counters zeroed by the prologue
     if (st->timing) ST_HIP(hipEventRecord(st->ev_t[1], s));
     ST_TRY(stage(3));                                             // the hit mask is final here (ray_tracing.py:61)
     if (st->timing) ST_HIP(hipEventRecord(st->ev_t[2], s));
@@ -385,8 +386,12 @@ int mvsdf_step_backward(void* step, const MvsdfStepParams* prm, int N, int n_tru
                 // weight gradients of BOTH networks in one k_wgrad_net / k_reduce_net pair.  (Round 3 ran the chunks that do not depend on fbar on a
                 // second stream beside a 9-phase delta chain; with the delta reduced to ~10 us the split measured no gain and is gone.)
                 float* fbar = (float*)(bwd + bo.fbar);
-                ST_TRY(mvsdf_step_backward_fbar(d.n_eik, d.n_ds, N, Nout, din, st->K0r, use_geo, d_diff, dx, view_sorted, n_eval, dy, fbar, stream));
-                ST_TRY(mv_sdf_backward_delta(&sdf, &sdfT, M, M, Mb, ctx, wsA, E, N, fbar, stream));
+                if (mv_delta_is_chain()) {                                              // MVSDF_DELTA_CHAIN=1: the cross-check route
+                    ST_TRY(mvsdf_step_backward_fbar(d.n_eik, d.n_ds, N, Nout, din, st->K0r, use_geo, d_diff, dx, view_sorted, n_eval, dy, fbar, stream));
+                    ST_TRY(mv_sdf_backward_delta(&sdf, &sdfT, M, M, Mb, ctx, wsA, E, N, fbar, stream));
+                } else {
+                    ST_TRY(mv_sdf_backward_delta_fbar(&sdf, M, M, Mb, ctx, wsA, E, N, Nout, din, st->K0r, use_geo, d_diff, dx, view_sorted, n_eval, dy, fbar, stream));
+                }
                 ST_TRY(mv_step_wgrad(&sdf, &rnd, M, M, Mb, dy, ctx, wsA, with_r ? N : 0, R, rctx, rws, dW_s, db_s, dW_r, db_r, stream));
                 done = true;
             } else if (rc == -3) {                                                      // network too wide for the fused chains: the sequential route

@@ -28,6 +28,10 @@ int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const f
 // drgb_rows (may be NULL): sorted row r takes its upstream from drgb[drgb_rows[r]]; -3 when that needs the fused chain kernel and it does not apply
 int mv_render_backward_chain(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, int Nctx, const float* drgb, const long long* drgb_rows, const float* ctx,
                              float* din, float* ws, void* stream);
+int mv_delta_is_chain();                                       // MVSDF_DELTA_CHAIN=1
+int mv_sdf_backward_delta_fbar(const MvsdfNetDesc* d, int M, int Mg, int Mb, const float* ctx, float* ws, int row0D, int MbD, int Nout, const float* din,
+                               int din_ld, int use_geo, const float* d_diff, const float* dx, const float* view_sorted, const float* n_eval, float* dy,
+                               float* fbar, void* stream);
 int mv_sdf_backward_delta(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M, int Mg, int Mb, const float* ctx, float* ws, int row0D, int MbD,
                           const float* fbar, void* stream);
 int mv_step_wgrad(const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int M, int Mg, int Mb, const float* dy, const float* ctx, float* wsA, int N, int Nctx,
@@ -37,4 +41,8 @@ int mv_step_wgrad(const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int M, int Mg,
 // (basic.hip::k_step_prologue): the work of mvsdf_fold_pack_net, mvsdf_pack_bf16_net_skips and mvsdf_camera_rays, same results
 int mv_step_prologue(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w, float* const* wp,
                      float* const* wpT, void* const* wp16, const int* nsplit, int wp16_fp32, const float* uv, const float* pose, const float* intrinsics, int B, int P,
-                     float* ray_dirs, float* cam_loc, uint8_t* ones, void* stream);
+                     float* ray_dirs, float* cam_loc, uint8_t* ones, unsigned long long* counters, void* stream);
+// stage 1 of mvsdf_trace_stage for a caller whose previous launch (mv_step_prologue) zeroed the counters
+extern "C" int mv_trace_stage1_prezeroed(const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs, const uint8_t* object_mask,
+                              int B, int P, int training, const float* intervals, const float* minsdf_steps, float* points, uint8_t* mask, float* dists,
+                              unsigned long long* counters, void* workspace, size_t workspace_bytes, int mt, int rpw, void* stream);

@@ -1073,7 +1073,7 @@ static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTracePara
     if (rpw < 1) rpw = 1;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-    if (stages & 1) e = hipMemsetAsync(counters, 0, 16 * sizeof(unsigned long long), s);
+    if ((stages & 1) && !(stages & 0x100)) e = hipMemsetAsync(counters, 0, 16 * sizeof(unsigned long long), s);   // 0x100: the caller's previous launch zeroed them
     if (e != hipSuccess) return mv_check(e, "mvsdf_trace: memset");
     if (bf)
         e = mv_trace_launch(stages, netb, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,
@@ -1106,6 +1106,13 @@ int mvsdf_trace_stage(int stage, const MvsdfNetDesc* desc, const MvsdfTraceParam
                       workspace, workspace_bytes, mt, rpw, stream);
 }
 
+// the step driver's form of stage 1: the counters were zeroed by k_step_prologue (one fill node less per step)
+int mv_trace_stage1_prezeroed(const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs, const uint8_t* object_mask,
+                              int B, int P, int training, const float* intervals, const float* minsdf_steps, float* points, uint8_t* mask, float* dists,
+                              unsigned long long* counters, void* workspace, size_t workspace_bytes, int mt, int rpw, void* stream) {
+    return trace_impl(1 | 0x100, desc, tp, cam_loc, ray_dirs, object_mask, B, P, training, intervals, minsdf_steps, points, mask, dists, counters,
+                      workspace, workspace_bytes, mt, rpw, stream);
+}
 
 /* ---- generic tracer for an opaque SDF callable (see the kernel comments above) ---- */
 size_t mvsdf_tracegen_state_bytes(int R) { return (size_t)(R > 0 ? R : 0) * sizeof(GenRay); }

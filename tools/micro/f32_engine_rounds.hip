@@ -94,5 +94,6 @@ int main(int argc, char** argv) {
     run(k_rounds<1, 2, 8, true>, 1, "MT=1 8 waves, carried ring", 512);
     run(k_rounds<2, 2, 8, false>, 2, "MT=2 8 waves", 512);
     run(k_rounds<1, 4, 4, false>, 1, "MT=1 4 waves", 256);
+    run(k_rounds<1, 1, 16, false>, 1, "MT=1 16 waves", 1024);
     return 0;
 }
