@@ -158,7 +158,8 @@ def self_launch(a):
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the PMC passes of this same command committed under profiles/ (tools/pmc_to_json.py writes the
     file: separate --pmc FETCH_SIZE / WRITE_SIZE runs, 2 x FETCH_SIZE KB + WRITE_SIZE KB per the guide's gfx950 correction).  None when
-    there is no summary for this workload -- the counters cannot be read from inside the process."""
+    there is no summary for this workload (the committed passes are of the default command: c2, fp32, 8 x 256) -- the counters cannot be read
+    from inside the process."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         d = json.load(open(path))
@@ -344,7 +345,7 @@ def main():
                        'parallelism': 'views sharded over %d rank(s), depth maps replicated; one all-reduce(SUM) on the flat grad buffer (+ 3 loss counts)' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'k_ray_samples (fused 9-layer tracing MLP on the sampler / secant / min-sdf rows)', 'achieved': ach,
                          'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                         'traffic': pmc_traffic(a.workload if world == 1 else None, 'k_ray_samples'),
+                         'traffic': pmc_traffic(a.workload if (world == 1 and a.dtype == 'f32' and a.width == 256) else None, 'k_ray_samples'),
                          'rows_per_launch': rows_samples / n_launch, 'flop_per_row': f_t, 'avg_launch_ms': ms_samples / n_launch,
                          'launches_per_step': n_launch,
                          # the two tracing-MLP kernels side by side (they take about the same time at this size)
@@ -353,10 +354,10 @@ def main():
                              'tracing (k_ray_samples + k_sphere_trace)': {'rows_per_step': rows_samples + rows_sphere, 'ms_per_step': ms_samples + ms_sphere,
                                                                           'achieved': ach_both, 'frac': ach_both / peak},
                              'k_sphere_trace': {'rows_per_step': rows_sphere, 'rows_min_sdf_tail': rows_tail, 'ms_per_step': ms_sphere, 'achieved': ach_sphere, 'frac': ach_sphere / peak,
-                                                'traffic': pmc_traffic(a.workload if world == 1 else None, 'k_sphere_trace')},
+                                                'traffic': pmc_traffic(a.workload if (world == 1 and a.dtype == 'f32' and a.width == 256) else None, 'k_sphere_trace')},
                              'k_feat_corr': {'bound': 'hbm', 'points': int(pts.shape[0]), 'views_per_point': 1 + V, 'bytes': feat_bytes, 'ms': ms_feat,
                                              'achieved_GBps': feat_bytes / (ms_feat * 1e-3) / 1e9, 'peak_GBps': 8000.0,
-                                             'traffic': pmc_traffic(a.workload if world == 1 else None, 'k_feat_corr')}},
+                                             'traffic': pmc_traffic(a.workload if (world == 1 and a.dtype == 'f32' and a.width == 256) else None, 'k_feat_corr')}},
                          'step': {'T_trace_rows': T, 'T_reference_rows': T_ref, 'R': R, 'E': E, 'N_hit': N, 'flops_step': flops_step,
                                   'achieved': flops_step / (dt / a.steps) / 1e12, 'frac': flops_step / (dt / a.steps) / 1e12 / peak}},
             'loss': float(lo['loss'].detach()),

@@ -4,6 +4,8 @@ import glob, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 src, dst = os.path.join(ROOT, 'gpurun_out', tag), os.path.join(ROOT, 'profiles')
+# gpurun MERGES into gpurun_out/: delete gpurun_out/<tag> before the run, or files of earlier runs mix in
+assert len(glob.glob(src + '/bench_line*.json')) >= 7 and len(glob.glob(src + '/stats_*')) == 4 and len(glob.glob(src + '/pmc_*')) == 3, 'incomplete ' + src
 for f in sorted(glob.glob(src + '/bench_line*.json')):
     lines = [l for l in open(f).read().splitlines() if l.startswith('{')]
     assert lines, f
