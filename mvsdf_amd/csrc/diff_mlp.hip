@@ -1014,3 +1014,13 @@ int mv_step_wgrad(const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int M, int Mg,
     MV_TRY(launch_wgrad_net(wa, (hipStream_t)stream));
     return mv_check(hipGetLastError(), "mv_step_wgrad");
 }
+
+#ifdef MV_CHAIN_PROBE
+// dev probe (tools/chain_probe.py): per-wave clock ticks (100 MHz) between the marks of workgroup 0 of k_chain_fwd, summed over the launches since the last reset
+extern "C" int mv_chain_probe_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_ph), sizeof(unsigned long long) * 256) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[256]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_chain_ph), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+

@@ -778,6 +778,19 @@ __global__ __launch_bounds__(64 * NW) void k_chain_bwd2(ChainArgs a, ChainArgs b
     else mv_chain_bwd_body<MT, NTW, NW>(b, blockIdx.x - na, smem);
 }
 
+// dev probe (side build with -DMV_CHAIN_PROBE, tools/chain_probe.py): wave w of workgroup 0 accumulates the 100 MHz clock between the marks of
+// k_chain_fwd / mv_chain_bwd_body into g_chain_ph[w][mark]; nothing in the product build
+#ifdef MV_CHAIN_PROBE
+__device__ unsigned long long g_chain_ph[16][16];
+#define CH_PH_DECL unsigned long long chp_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long cht_ = wall_clock64();
+#define CH_PH(i) { const unsigned long long t_ = wall_clock64(); chp_[i] += t_ - cht_; cht_ = t_; }
+#define CH_PH_END if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_chain_ph[threadIdx.x >> 6][i_], chp_[i_]); }
+#else
+#define CH_PH_DECL
+#define CH_PH(i)
+#define CH_PH_END
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------
 // Forward value + normal of the SDF network for 16*MT rows per workgroup in ONE launch (replaces 1 + 9 + 8 + 1 launches):
 //   value  (ascending, idr.py:77-94):  PE -> [Linear, Softplus(100)] x (L-1) -> Linear; stores H0, A_l, sigma_l = sigmoid(100 z_l), y;
@@ -809,6 +822,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
     float* pe = act + ROWS * S;                                  // [ROWS][d0] natural order
     float* padj = pe + ((ROWS * d0 + 3) & ~3);                   // [ROWS][d0] PE adjoint of the skip layer, then g_0
     float* pts = padj + ((ROWS * d0 + 3) & ~3);                  // [ROWS][3]
+    CH_PH_DECL
     for (int i = tid; i < ROWS * 3; i += NTH) {
         const int row = row0 + i / 3, c = i - 3 * (i / 3);
         float v = 0.0f;
@@ -832,6 +846,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
         const int rr = idx / a.ld0, k = idx - rr * a.ld0, row = row0 + rr;
         if (row < a.M) a.H0[(size_t)row * a.ld0 + k] = k < d0 ? pe[rr * d0 + k] : 0.0f;
     }
+    CH_PH(0)
     // ---- value chain
     for (int l = 0; l < nl - 1; ++l) {
         const MvLayer& L = a.net.L[l];
@@ -842,8 +857,11 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
         f32x4 acc[MT][NTW];
         mv_zero_acc<MT, NTW>(acc);
         __syncthreads();
+        CH_PH(1)
         if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
+        CH_PH(2)
         __syncthreads();
+        CH_PH(3)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             if (t < ntw) {
@@ -882,6 +900,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
                 act[rr * S + mv_perm(Kn + j)] = 0.0f;
             }
         }
+        CH_PH(4)
     }
     {   // last layer: every output column, groups of NTW column tiles per wave
         const MvLayer& L = a.net.L[nl - 1];
@@ -912,15 +931,36 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
             }
         }
     }
+    CH_PH(5)
     if (row0 >= a.Mg) return;                                    // workgroup-uniform: no normals for these rows
     // ---- normal chain (rows >= Mg inside the tile carry zeros)
     for (int i = tid; i < ROWS * d0; i += NTH) padj[i] = 0.0f;
+    // sigma_l of this thread's elements of a layer's prologue, requested one layer ahead (before the GEMM of the layer above): the prologue is a
+    // load, a multiply and two stores per element, and with the load issued on the spot it was 2 us of exposed L2 latency per layer (probe: 16-18
+    // of the kernel's 124 us at c2).  Covers the first ZPF passes of a prologue (all of it up to 32 rows x 256 columns).  No branch around the
+    // loads and no branch that rewrites zpre (the compiler would copy registers with loads in flight, i.e. wait for them): clamped addresses.
+    constexpr int ZPF = 2;
+    float zpre[ZPF][4];
+    auto z_prefetch = [&](int lq) {
+        const int Kq = a.netT.L[lq].K, Kpq = a.netT.L[lq].KB * 16;
+#pragma unroll
+        for (int it = 0; it < ZPF; ++it)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = it * NTH * 4 + u * NTH + tid;
+                const int rr = idx / Kpq, k = idx - rr * Kpq, row = row0 + rr;
+                const bool ok = idx < ROWS * Kpq && row < a.Mg && k < Kq;
+                zpre[it][u] = a.Z[lq][ok ? (size_t)row * Kq + k : 0];
+            }
+    };
+    z_prefetch(nl - 2);
     for (int l = nl - 2; l >= 0; --l) {
         const MvLayer& L = a.netT.L[l];                          // contraction over out_l (K), produces in_l columns (N)
         const int K = L.K, Kp = L.KB * 16, N = L.N;
         const bool top = (l == nl - 2);
         __syncthreads();                                         // Z_l of this tile written (value chain) / previous epilogue done
-        for (int base = 0; base < ROWS * Kp; base += NTH * 4) {
+        CH_PH(6)
+        auto prologue_pass = [&](int base, const float* zp) {
             float v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -929,7 +969,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
                 v[u] = 0.0f;
                 if (idx < ROWS * Kp && row < a.Mg && k < K) {
                     const float uu = top ? a.w_last_row0[k] : act[rr * S + mv_perm(k)];
-                    v[u] = a.Z[l][(size_t)row * K + k] * uu;
+                    v[u] = (zp ? zp[u] : a.Z[l][(size_t)row * K + k]) * uu;
                     a.Sg[l][(size_t)row * K + k] = v[u];
                 }
             }
@@ -939,14 +979,23 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
                 const int rr = idx / Kp, k = idx - rr * Kp;
                 if (idx < ROWS * Kp) act[rr * S + mv_perm(k)] = v[u];
             }
-        }
+        };
+#pragma unroll
+        for (int it = 0; it < ZPF; ++it)
+            if (it * NTH * 4 < ROWS * Kp) prologue_pass(it * NTH * 4, zpre[it]);
+        for (int base = ZPF * NTH * 4; base < ROWS * Kp; base += NTH * 4) prologue_pass(base, nullptr);
+        CH_PH(7)
         __syncthreads();
+        CH_PH(8)
+        z_prefetch(l > 0 ? l - 1 : 0);                           // (l == 0: loaded, unused)
         const int NT = L.NT, per = (NT + NW - 1) / NW, ct0 = w * per;
         int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
         f32x4 acc[MT][NTW];
         mv_zero_acc<MT, NTW>(acc);
         if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
+        CH_PH(9)
         __syncthreads();
+        CH_PH(10)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             if (t < ntw) {
@@ -976,6 +1025,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
                 }
             }
         }
+        CH_PH(11)
     }
     __syncthreads();
     for (int idx = tid; idx < ROWS * 3; idx += NTH) {            // n = J_PE^T g_0
@@ -990,6 +1040,8 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
         }
         a.nrm[(size_t)row * 3 + c] = v;
     }
+    CH_PH(12)
+    CH_PH_END
 }
 
 // ---------------------------------------------------------------------------------------------------------------
