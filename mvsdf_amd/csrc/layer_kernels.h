@@ -232,6 +232,22 @@ __device__ __forceinline__ void wg_stage(const float* __restrict__ src, int ld, 
     }
 }
 
+// dev probe (side build with -DMV_CHAIN_PROBE, tools/chain_probe.py): wave w of workgroup 0 accumulates the 100 MHz clock between the marks of
+// k_chain_fwd (tools/chain_probe.py) or of one 256 x 256 workgroup of k_wgrad_net (tools/chain_probe.py wgrad) into g_chain_ph[w][mark]; nothing in
+// the product build
+#ifdef MV_CHAIN_PROBE
+__device__ unsigned long long g_chain_ph[16][16];
+#define CH_PH_DECL unsigned long long chp_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long cht_ = wall_clock64();
+#define CH_PH(i) { const unsigned long long t_ = wall_clock64(); chp_[i] += t_ - cht_; cht_ = t_; }
+#define CH_PH_END if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_chain_ph[threadIdx.x >> 6][i_], chp_[i_]); }
+#define WG_PH_END(blk) if ((int)blockIdx.x == (blk) && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_chain_ph[8 + (threadIdx.x >> 6)][i_], chp_[i_]); }
+#else
+#define CH_PH_DECL
+#define CH_PH(i)
+#define CH_PH_END
+#define WG_PH_END(blk)
+#endif
+
 // ---- network-wide variants: the weight gradients of EVERY layer in one launch, then one reduction launch ----
 // Workgroup = (layer, 128-row chunk, 64x64 output block); both pairs of a layer (E.2 term zbar^T a and E.1 term s^T vbar) accumulate
 // in the same registers, so a layer needs one slab per chunk.
@@ -296,17 +312,43 @@ __global__ __launch_bounds__(MV_THREADS) void k_wgrad_net(WgradNetArgs a) {
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
     const bool do_bias = bx == 0;
+    CH_PH_DECL
     const int npairs = L.P2 ? 2 : 1;
-    for (int pair = 0; pair < npairs; ++pair) {
-        const float* P = pair ? L.P2 : L.P1;
-        const float* Q = pair ? L.Q2 : L.Q1;
-        const int ldp = pair ? L.ldp2 : L.ldp1, ldq = pair ? L.ldq2 : L.ldq1;
-        for (int rb = rbeg; rb < rend; rb += 64) {
-            __syncthreads();
-            wg_stage(P, ldp, rb, rend, o0, No, Pt, LD, tid);
-            wg_stage(Q, ldq, rb, rend, i0, Ki, Qt, LD, tid);
-            __syncthreads();
-            if (do_bias && pair == 0 && tid < 64) {
+    // Fast path (full 64-column tiles, 16-byte aligned rows: every 256-wide layer): the operand tiles of stage s + 1 are requested into
+    // registers BEFORE the MFMA loop of stage s and written to LDS after it -- the probe (tools/chain_probe.py) showed a workgroup spending half
+    // of its life waiting for the tiles it had just asked for.  The loads are unconditional (rows clamped, masked when stored): a load inside a
+    // branch cannot stay in flight across the loop (the compiler waits for it at the merge) -- why the same idea measured nothing in round 3's
+    // first attempt.
+    const int nrb = (rend - rbeg + 63) / 64, nst = npairs * nrb;
+    const bool fast = ((L.ldp1 & 3) == 0) && ((L.ldq1 & 3) == 0) && ((((size_t)L.P1) & 15) == 0) && ((((size_t)L.Q1) & 15) == 0) && o0 + 64 <= No && i0 + 64 <= Ki &&
+                      (!L.P2 || (((L.ldp2 & 3) == 0) && ((L.ldq2 & 3) == 0) && ((((size_t)L.P2) & 15) == 0) && ((((size_t)L.Q2) & 15) == 0))) && nst > 0;
+    if (fast) {
+        float4 pv[4], qv[4];
+        auto issue = [&](int st) {
+            const int pair = st >= nrb ? 1 : 0, rb = rbeg + (st - pair * nrb) * 64;
+            const float* P = pair ? L.P2 : L.P1;
+            const float* Q = pair ? L.Q2 : L.Q1;
+            const int ldp = pair ? L.ldp2 : L.ldp1, ldq = pair ? L.ldq2 : L.ldq1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = u * MV_THREADS + tid, rr = idx >> 4, c4 = (idx & 15) * 4;
+                const int row = min(rb + rr, rend - 1);
+                pv[u] = *(const float4*)(P + (size_t)row * ldp + o0 + c4);
+                qv[u] = *(const float4*)(Q + (size_t)row * ldq + i0 + c4);
+            }
+        };
+        auto store = [&](int st) {
+            const int pair = st >= nrb ? 1 : 0, rb = rbeg + (st - pair * nrb) * 64;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = u * MV_THREADS + tid, rr = idx >> 4, c4 = (idx & 15) * 4;
+                const bool in = rb + rr < rend;
+                *(float4*)(Pt + rr * LD + c4) = in ? pv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                *(float4*)(Qt + rr * LD + c4) = in ? qv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto compute = [&](int st) {
+            if (do_bias && st < nrb && tid < 64) {
                 for (int rr = 0; rr < 64; ++rr) bsum += Pt[rr * LD + tid];
             }
 #pragma unroll 4
@@ -316,8 +358,47 @@ __global__ __launch_bounds__(MV_THREADS) void k_wgrad_net(WgradNetArgs a) {
                 for (int t = 0; t < 4; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Qt[(4 * s + q) * LD + 16 * t + r], acc[t], 0, 0, 0);
             }
+        };
+        issue(0);
+        for (int st = 0; st + 1 < nst; ++st) {
+            __syncthreads();
+            store(st);
+            __syncthreads();
+            issue(st + 1);
+            compute(st);
+        }
+        __syncthreads();
+        store(nst - 1);
+        __syncthreads();
+        compute(nst - 1);
+    } else
+    for (int pair = 0; pair < npairs; ++pair) {
+        const float* P = pair ? L.P2 : L.P1;
+        const float* Q = pair ? L.Q2 : L.Q1;
+        const int ldp = pair ? L.ldp2 : L.ldp1, ldq = pair ? L.ldq2 : L.ldq1;
+        for (int rb = rbeg; rb < rend; rb += 64) {
+            CH_PH(0)
+            __syncthreads();
+            CH_PH(1)
+            wg_stage(P, ldp, rb, rend, o0, No, Pt, LD, tid);
+            wg_stage(Q, ldq, rb, rend, i0, Ki, Qt, LD, tid);
+            CH_PH(2)
+            __syncthreads();
+            CH_PH(3)
+            if (do_bias && pair == 0 && tid < 64) {
+                for (int rr = 0; rr < 64; ++rr) bsum += Pt[rr * LD + tid];
+            }
+            CH_PH(4)
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+                const float av = Pt[(4 * s + q) * LD + 16 * w + r];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Qt[(4 * s + q) * LD + 16 * t + r], acc[t], 0, 0, 0);
+            }
         }
     }
+    CH_PH(5)
     float* slab = L.slab + (size_t)ch * No * Ki;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -331,6 +412,8 @@ __global__ __launch_bounds__(MV_THREADS) void k_wgrad_net(WgradNetArgs a) {
         }
     }
     if (do_bias && tid < 64 && o0 + tid < No) L.bslab[(size_t)ch * No + o0 + tid] = bsum;
+    CH_PH(6)
+    WG_PH_END(a.L[1].blk0 + 1)                                   // a bx = 1 block (no bias sum) of the first chunk of layer 1 (256 x 256)
 }
 
 // dW / db of every layer = sum over its chunks of the slabs, fixed order (deterministic)
@@ -777,19 +860,6 @@ __global__ __launch_bounds__(64 * NW) void k_chain_bwd2(ChainArgs a, ChainArgs b
     if ((int)blockIdx.x < na) mv_chain_bwd_body<MT, NTW, NW>(a, blockIdx.x, smem);
     else mv_chain_bwd_body<MT, NTW, NW>(b, blockIdx.x - na, smem);
 }
-
-// dev probe (side build with -DMV_CHAIN_PROBE, tools/chain_probe.py): wave w of workgroup 0 accumulates the 100 MHz clock between the marks of
-// k_chain_fwd / mv_chain_bwd_body into g_chain_ph[w][mark]; nothing in the product build
-#ifdef MV_CHAIN_PROBE
-__device__ unsigned long long g_chain_ph[16][16];
-#define CH_PH_DECL unsigned long long chp_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long cht_ = wall_clock64();
-#define CH_PH(i) { const unsigned long long t_ = wall_clock64(); chp_[i] += t_ - cht_; cht_ = t_; }
-#define CH_PH_END if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_chain_ph[threadIdx.x >> 6][i_], chp_[i_]); }
-#else
-#define CH_PH_DECL
-#define CH_PH(i)
-#define CH_PH_END
-#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Forward value + normal of the SDF network for 16*MT rows per workgroup in ONE launch (replaces 1 + 9 + 8 + 1 launches):

@@ -14,7 +14,7 @@ from mvsdf_amd.model.loss import IDRLoss
 from mvsdf_amd.optim import FlatAdam
 from mvsdf_amd.utils import synth
 from mvsdf_amd.utils.config import ConfigDict
-wl = sys.argv[1] if len(sys.argv) > 1 else 'c2'
+wl = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] != 'wgrad' else 'c2'
 dev = torch.device('cuda', 0)
 model = IDRNetwork(ConfigDict(synth.model_conf(bench.W)))
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(bench.W, 0).items()})
@@ -41,3 +41,10 @@ print('%-34s' % 'phase' + ''.join('  w%-4d' % w for w in (0, 1, 4, 5, 8, 12, 15)
 for i, nm in enumerate(names):
     print('%-34s' % nm + ''.join(' %6.2f' % a[w, i] for w in (0, 1, 4, 5, 8, 12, 15)) + '   %6.2f' % a[:, i].max())
 print('%-34s' % 'sum' + ''.join(' %6.2f' % a[w, :13].sum() for w in (0, 1, 4, 5, 8, 12, 15)))
+wn = ['MFMA loop (+ loop back)', 'wait: tiles free', 'stage P, Q (global -> LDS)', 'wait: tiles staged', 'bias sum', 'last MFMA loop', 'slab store']
+print('k_wgrad_net, one 64 x 64 block of a 256 x 256 layer (256 rows, two operand pairs = 8 stages), us per launch')
+print('%-34s' % 'phase' + ''.join('  w%-4d' % w for w in range(4)))
+for i, nm in enumerate(wn):
+    print('%-34s' % nm + ''.join(' %6.2f' % a[8 + w, i] for w in range(4)))
+print('%-34s' % 'sum' + ''.join(' %6.2f' % a[8 + w, :7].sum() for w in range(4)))
+
