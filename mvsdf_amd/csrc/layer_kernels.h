@@ -299,10 +299,14 @@ __global__ __launch_bounds__(MV_THREADS) void k_wgrad_net(WgradNetArgs a) {
     __shared__ __attribute__((aligned(16))) float Qt[64 * LD];
     if (a.colX && (int)blockIdx.x >= a.col_blk0) { mv_colsum_block(a, blockIdx.x - a.col_blk0); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+    // (XCD-aware block orders were measured and not kept: the 16 blocks of one (layer, chunk) share their operand tiles and the dispatcher places
+    // block b on XCD b % 8, so in launch order every tile is fetched by several L2s.  A contiguous range of the logical order per XCD: 94 -> 112 us
+    // (the layers differ in cost, the XCDs get unequal shares); runs of 16 consecutive blocks per XCD, round-robin: 89-95 us, i.e. nothing.)
+    const int bid = blockIdx.x;
     int l = 0;
-    while (l + 1 < a.n_layers && (int)blockIdx.x >= a.L[l + 1].blk0) ++l;
+    while (l + 1 < a.n_layers && bid >= a.L[l + 1].blk0) ++l;
     const WgradLayer& L = a.L[l];
-    const int local = blockIdx.x - L.blk0, nb = L.nbx * L.nby;
+    const int local = bid - L.blk0, nb = L.nbx * L.nby;
     const int chl = local / nb, rem = local - chl * nb, by = rem / L.nbx, bx = rem - by * L.nbx;
     const int ch = L.ch0 + chl;
     const int i0 = bx * 64, o0 = by * 64, No = L.No, Ki = L.Ki;
