@@ -279,8 +279,10 @@ struct WgradNetArgs {
     unsigned wtotal, btotal;
 };
 
-__device__ __forceinline__ void mv_colsum_block(const WgradNetArgs& a, int local) {
-    __shared__ float red[4][64];
+// `scratch`: 256 floats of LDS (the caller's operand tile: a static array of its own here would push k_wgrad_net from 40 960 to 41 984 bytes of LDS, i.e.
+// from FOUR to THREE workgroups per CU)
+__device__ __forceinline__ void mv_colsum_block(const WgradNetArgs& a, int local, float* scratch) {
+    float (*red)[64] = (float (*)[64])scratch;
     const int nbx = (a.col_n + 63) / 64;
     const int ch = a.col_ch0 + local / nbx, bx = local - (local / nbx) * nbx;
     const int c = bx * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(MV_THREADS) void k_wgrad_net(WgradNetArgs a) {
     constexpr int LD = 80;
     __shared__ __attribute__((aligned(16))) float Pt[64 * LD];
     __shared__ __attribute__((aligned(16))) float Qt[64 * LD];
-    if (a.colX && (int)blockIdx.x >= a.col_blk0) { mv_colsum_block(a, blockIdx.x - a.col_blk0); return; }
+    if (a.colX && (int)blockIdx.x >= a.col_blk0) { mv_colsum_block(a, blockIdx.x - a.col_blk0, Pt); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
     // (XCD-aware block orders were measured and not kept: the 16 blocks of one (layer, chunk) share their operand tiles and the dispatcher places
     // block b on XCD b % 8, so in launch order every tile is fetched by several L2s.  A contiguous range of the logical order per XCD: 94 -> 112 us
@@ -355,12 +357,25 @@ __global__ __launch_bounds__(MV_THREADS) void k_wgrad_net(WgradNetArgs a) {
             if (do_bias && st < nrb && tid < 64) {
                 for (int rr = 0; rr < 64; ++rr) bsum += Pt[rr * LD + tid];
             }
-#pragma unroll 4
-            for (int s = 0; s < 16; ++s) {
-                const float av = Pt[(4 * s + q) * LD + 16 * w + r];
+            // operands of k-step s + 1 are read from LDS while the four MFMAs of k-step s issue (the plain loop reads, waits ~100 cycles, issues two
+            // MFMAs, reads again: each wave kept the matrix pipe busy 40 % of its own time)
+            float av[2], bq[2][4];
+            const float* pa = Pt + q * LD + 16 * w + r;
+            const float* pb = Qt + q * LD + r;
+            av[0] = pa[0];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Qt[(4 * s + q) * LD + 16 * t + r], acc[t], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) bq[0][t] = pb[16 * t];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (s + 1 < 16) {
+                    av[(s + 1) & 1] = pa[4 * (s + 1) * LD];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) bq[(s + 1) & 1][t] = pb[4 * (s + 1) * LD + 16 * t];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1], bq[s & 1][t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         issue(0);
