@@ -56,8 +56,9 @@ __device__ __forceinline__ void mv_eval_dispatch(const NET& net, int ntiles, flo
         else if constexpr (XR) mv_sdf_eval_col0<1, NTW, NW, true>(net, act, pe, pts, out, tid);
         else mv_sdf_eval_col0<1, NTW, NW>(net, act, pe, pts, out, tid);
     } else {
-        if (MT >= 4 && ntiles == 4) mv_sdf_eval_col0<(MT >= 4 ? 4 : MT), NTW, NW, XR>(net, act, pe, pts, out, tid);
-        else if (MT >= 3 && ntiles == 3) mv_sdf_eval_col0<(MT >= 3 ? 3 : MT), NTW, NW, XR>(net, act, pe, pts, out, tid);
+        // (three or four row tiles: the carried scheme's 64 weight registers on top of 32-48 accumulators / activation registers spill)
+        if (MT >= 4 && ntiles == 4) mv_sdf_eval_col0<(MT >= 4 ? 4 : MT), NTW, NW, false>(net, act, pe, pts, out, tid);
+        else if (MT >= 3 && ntiles == 3) mv_sdf_eval_col0<(MT >= 3 ? 3 : MT), NTW, NW, false>(net, act, pe, pts, out, tid);
         else if (MT >= 2 && ntiles == 2) mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW, NW, XR>(net, act, pe, pts, out, tid);
         else mv_sdf_eval_col0<1, NTW, NW, XR>(net, act, pe, pts, out, tid);
     }
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams
             }
             __syncthreads();
         }
-        mv_eval_dispatch<MT, NTW, NW, NET, (MT == 1 || !std::is_same<NET, MvNet>::value)>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
+        mv_eval_dispatch<MT, NTW, NW, NET, (MT == 1 || (MT <= 2 && !std::is_same<NET, MvNet>::value))>(net, (n + 15) >> 4, lds.act, lds.pe, lds.pts, lds.sdfv, tid);
         if (helping) {
             if (tid < h_nr) tail.sv[h_svi] = lds.sdfv[tid];
             __syncthreads();                                      // values read before the next chunk's points overwrite the tile
