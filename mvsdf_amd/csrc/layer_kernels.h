@@ -775,11 +775,30 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
         __syncthreads();                                         // zbar2 of this tile written (global) before E.2 reads it
     }
     for (int i = tid; i < ROWS * d0; i += NTH) pe_adj[i] = 0.0f;
+    // sigma_l and zbar2_l of this thread's elements of a layer's prologue, requested one layer ahead (before the GEMM of the layer above), like
+    // k_chain_fwd's normal chain: unconditional loads (clamped), the first ZPF passes of a prologue
+    constexpr int ZPF = 2;
+    float zpre[ZPF][4], z2pre[ZPF][4];
+    auto z_prefetch = [&](int lq) {
+        const int Kq = a.netT.L[lq].K, Kpq = a.netT.L[lq].KB * 16;
+        const float* z2 = a.ZB2[lq] ? a.ZB2[lq] : a.Z[lq];      // (no second-order term in this pass: any valid address, the value is not used)
+#pragma unroll
+        for (int it = 0; it < ZPF; ++it)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = it * NTH * 4 + u * NTH + tid;
+                const int rr = idx / Kpq, k = idx - rr * Kpq, row = row0 + rr;
+                const bool ok = idx < ROWS * Kpq && row < a.M && k < Kq;
+                const size_t off = ok ? (size_t)row * Kq + k : 0;
+                zpre[it][u] = a.Z[lq][off];
+                z2pre[it][u] = z2[off];
+            }
+    };
     for (int l = nl - 1; l >= 0; --l) {
         const MvLayer& L = a.netT.L[l];                          // contraction over out_l (K), produces in_l columns (N)
         const int K = L.K, Kp = L.KB * 16, N = L.N;
         // ---- prologue: build the A tile (zbar_l, or dy for the last layer) in LDS
-        for (int base = 0; base < ROWS * Kp; base += NTH * 4) {
+        auto prologue_pass = [&](int base, const float* zp, const float* z2p) {
             float v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -789,8 +808,8 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
                 if (idx < ROWS * Kp && row < a.M && k < K) {
                     if (l == nl - 1) v[u] = a.dy_col0 ? (k == 0 ? a.dy_col0[row] : 0.0f) : a.dy[(size_t)row * a.ld_dy + k];
                     else {
-                        float zb = a.Z[l][(size_t)row * K + k] * act[rr * S + mv_perm(k)];
-                        if (a.ZB2[l]) zb += a.ZB2[l][(size_t)row * K + k];
+                        float zb = (zp ? zp[u] : a.Z[l][(size_t)row * K + k]) * act[rr * S + mv_perm(k)];
+                        if (a.ZB2[l]) zb += z2p ? z2p[u] : a.ZB2[l][(size_t)row * K + k];
                         a.ZB[l][(size_t)row * K + k] = a.accum ? a.ZB[l][(size_t)row * K + k] + zb : zb;   // the GEMM below continues with this pass's zbar
                         v[u] = zb;
                     }
@@ -802,8 +821,17 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
                 const int rr = idx / Kp, k = idx - rr * Kp;
                 if (idx < ROWS * Kp) act[rr * S + mv_perm(k)] = v[u];
             }
+        };
+        if (l == nl - 1) {
+            for (int base = 0; base < ROWS * Kp; base += NTH * 4) prologue_pass(base, nullptr, nullptr);
+        } else {
+#pragma unroll
+            for (int it = 0; it < ZPF; ++it)
+                if (it * NTH * 4 < ROWS * Kp) prologue_pass(it * NTH * 4, zpre[it], z2pre[it]);
+            for (int base = ZPF * NTH * 4; base < ROWS * Kp; base += NTH * 4) prologue_pass(base, nullptr, nullptr);
         }
         __syncthreads();
+        z_prefetch(l > 0 ? l - 1 : 0);                           // (l == 0: loaded, unused)
         // ---- GEMM
         const int NT = L.NT, per = (NT + NW - 1) / NW, ct0 = w * per;
         int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
