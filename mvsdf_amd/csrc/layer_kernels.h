@@ -973,6 +973,9 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
         const int Kn = a.net.L[l + 1].K, Kpn = a.net.L[l + 1].KB * 16;
         f32x4 acc[MT][NTW];
         mv_zero_acc<MT, NTW>(acc);
+        float bv_[NTW];                                          // biases of this wave's columns: requested now, consumed after the GEMM (clamped: no branch)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) { const int col = (ct0 + t) * 16 + r; bv_[t] = L.bias[col < N ? col : N - 1]; }
         __syncthreads();
         CH_PH(1)
         if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
             if (t < ntw) {
                 const int col = (ct0 + t) * 16 + r;
                 if (col < N) {
-                    const float bv = L.bias[col];
+                    const float bv = bv_[t];
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1029,13 +1032,16 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
             ntw = ntw < 0 ? 0 : (ntw > NTW ? NTW : ntw);
             f32x4 acc[MT][NTW];
             mv_zero_acc<MT, NTW>(acc);
+            float bv_[NTW];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) { const int col = (ct0 + t) * 16 + r; bv_[t] = L.bias[(col >= 0 && col < N) ? col : N - 1]; }
             if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 if (t < ntw) {
                     const int col = (ct0 + t) * 16 + r;
                     if (col < N) {
-                        const float bv = L.bias[col];
+                        const float bv = bv_[t];
 #pragma unroll
                         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1224,6 +1230,9 @@ __global__ __launch_bounds__(64 * NW) void k_render_chain_fwd(RenderChainArgs a)
             ntw = ntw < 0 ? 0 : (ntw > NTW ? NTW : ntw);
             f32x4 acc[MT][NTW];
             mv_zero_acc<MT, NTW>(acc);
+            float bv_[NTW];                                      // requested before the GEMM, consumed after it
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) { const int col = (ct0 + t) * 16 + r; bv_[t] = L.bias[(col >= 0 && col < N) ? col : N - 1]; }
             if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
             if (per > NTW || !last) __syncthreads();             // every wave done reading act before the in-place update
 #pragma unroll
@@ -1231,7 +1240,7 @@ __global__ __launch_bounds__(64 * NW) void k_render_chain_fwd(RenderChainArgs a)
                 if (t < ntw) {
                     const int col = (ct0 + t) * 16 + r;
                     if (col < N) {
-                        const float bv = L.bias[col];
+                        const float bv = bv_[t];
 #pragma unroll
                         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1296,6 +1305,23 @@ __global__ __launch_bounds__(64 * NW) void k_render_chain_bwd(RenderChainArgs a)
             ntw = ntw < 0 ? 0 : (ntw > NTW ? NTW : ntw);
             f32x4 acc[MT][NTW];
             mv_zero_acc<MT, NTW>(acc);
+            // the ReLU masks of this wave's outputs (post-activation values): requested before the GEMM, consumed after it (clamped: no branch)
+            float am[NTW][MT][4];
+            {
+                const float* Acl = l > 0 ? a.Ac[l] : a.rgbc;     // (l == 0: any valid address, the values are not used)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const int col = (ct0 + t) * 16 + r;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = row0 + m * 16 + 4 * q + i;
+                            const bool ok = l > 0 && t < ntw && col >= 0 && col < N && row < a.N;
+                            am[t][m][i] = Acl[ok ? (size_t)row * N + col : 0];
+                        }
+                }
+            }
             if (ntw > 0) mv_gemm_dispatch<MT, NTW>(L, act, S, ct0, ntw, acc, lane);
             if (l > 0) __syncthreads();                          // (l > 0 has a single group: per <= NTW, checked by the launcher)
 #pragma unroll
@@ -1312,7 +1338,7 @@ __global__ __launch_bounds__(64 * NW) void k_render_chain_bwd(RenderChainArgs a)
                                 if (l > 0) {
                                     float zb = 0.0f;
                                     if (row < a.N) {
-                                        zb = a.Ac[l][(size_t)row * N + col] > 0.0f ? ab : 0.0f;      // relu mask: stored post-activation > 0
+                                        zb = am[t][m][i] > 0.0f ? ab : 0.0f;                          // relu mask: stored post-activation > 0
                                         a.ZB[l - 1][(size_t)row * N + col] = zb;
                                     }
                                     act[rr * S + mv_perm(col)] = zb;
