@@ -268,6 +268,8 @@ struct LossArgs {
     // optional: the gradients of the TOTAL loss (unit gradient x the term's weight: what k_loss_scale produces for an upstream of exactly 1 on `loss`
     // alone -- 1 * w + 0 is w, so the values are bit-identical) and of the feature term's points; lets `loss.backward()` skip that launch
     float* s_rgb; float* s_grad; float* s_eik_out; float* s_surf; const float* dpts; float* s_diff; int n_dpts;
+    // launch over MV_LOSS_SLICES workgroups (mvsdf_loss_forward): partial[MV_LOSS_SLICES][8] and a ticket counter zeroed before the launch; both null: one workgroup
+    float* partial; unsigned* ticket;
 };
 
 // sum over the 1024 threads of the workgroup, the same value in every thread; fixed order (butterfly inside a wave, then the 16 wave sums in
@@ -282,71 +284,105 @@ __device__ float block_sum_1024(float v, float* red) {
     return r;
 }
 
+// The five sums are defined over a FIXED partition of the index space into MV_LOSS_SLICES interleaved slices (slice s owns i = s * 1024 + tid + k *
+// MV_LOSS_SLICES * the term's wave count * 64): per slice the sum over the term's waves, then the slice sums in index order.  One workgroup walks all slices
+// (mvsdf_loss_terms), or MV_LOSS_SLICES workgroups take one each and the last one to finish adds them up (mvsdf_loss_forward: 15-25 us of one CU
+// chasing loads -> a few us) -- the same bits either way.
+#define MV_LOSS_SLICES 16
 __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
     __shared__ float red[1024];
-    const int tid = threadIdx.x;
-    // rgb: L1Loss(reduction='sum')(rgb[mask], gt[mask]) / R                                      loss.py:21-28
-    float s = 0.f;
+    __shared__ float s_part[MV_LOSS_SLICES][5];
+    __shared__ unsigned s_last;
+    const int tid = threadIdx.x, G = gridDim.x, STR = MV_LOSS_SLICES * 1024;
     const float invR = 1.0f / (float)a.R;
-    for (int i = tid; i < a.R * 3; i += 1024) {
-        const bool m = a.rgb_mask[i / 3] != 0;
-        const float df = a.rgb[i] - a.rgb_gt[i];
-        if (m) s += fabsf(df);
-        const float dr = m ? (df > 0.f ? invR : (df < 0.f ? -invR : 0.f)) : 0.f;
-        a.d_rgb[i] = dr;
-        if (a.s_rgb) a.s_rgb[i] = dr * a.w_rgb;
-    }
-    const float rgb_loss = block_sum_1024(s, red) * invR;
-    // eikonal: mean((||g|| - 1)^2)                                                               loss.py:30-35
-    s = 0.f;
     const float invE = a.n_eik > 0 ? (a.inv_counts ? a.inv_counts[0] : 1.0f / (float)a.n_eik) : 0.f;
-    for (int i = tid; i < a.n_eik; i += 1024) {
-        const float gx = a.grad_theta[3 * i], gy = a.grad_theta[3 * i + 1], gz = a.grad_theta[3 * i + 2];
-        const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
-        const float e = nrm - 1.0f;
-        s += e * e;
-        const float k = nrm > 0.f ? 2.0f * e / nrm * invE : 0.f;
-        a.d_grad[3 * i] = k * gx; a.d_grad[3 * i + 1] = k * gy; a.d_grad[3 * i + 2] = k * gz;
-        if (a.s_grad) { a.s_grad[3 * i] = (k * gx) * a.w_eik; a.s_grad[3 * i + 1] = (k * gy) * a.w_eik; a.s_grad[3 * i + 2] = (k * gz) * a.w_eik; }
-    }
-    const float eik_loss = block_sum_1024(s, red) * invE;
-    // depth: mean(|eikonal_output + dist_r| * weight)                                            loss.py:58-61
-    s = 0.f;
     const float invD = a.n_depth > 0 ? (a.inv_counts ? a.inv_counts[1] : 1.0f / (float)a.n_depth) : 0.f;
-    for (int i = tid; i < a.n_depth; i += 1024) {
-        const float df = a.eik_out[i] + a.dist_r[i], wgt = a.dweight[i];
-        s += fabsf(df) * wgt;
-        const float de = (df > 0.f ? wgt : (df < 0.f ? -wgt : 0.f)) * invD;
-        a.d_eik_out[i] = de;
-        if (a.s_eik_out) a.s_eik_out[i] = de * a.w_depth;
-    }
-    const float depth_loss = block_sum_1024(s, red) * invD;
-    // surface indicator: BCEWithLogits(mean) against [1]*n_pos + [0]*rest                        loss.py:167-174
-    s = 0.f;
-    float surf_loss = 0.f;
-    if (a.surf_on) {
-        const long long npos = *a.n_pos;
-        const float invS = a.n_surf > 0 ? (a.inv_counts ? a.inv_counts[2] : 1.0f / (float)a.n_surf) : 0.f;
-        for (int i = tid; i < a.n_surf; i += 1024) {
-            const float x = a.surf[i], t = (long long)i < npos ? 1.0f : 0.0f;
-            s += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
-            const float ds = (1.0f / (1.0f + expf(-x)) - t) * invS;
-            a.d_surf[i] = ds;
-            if (a.s_surf) a.s_surf[i] = ds * a.w_surf;
+    const float invS = a.n_surf > 0 ? (a.inv_counts ? a.inv_counts[2] : 1.0f / (float)a.n_surf) : 0.f;
+    const long long npos = a.surf_on ? *a.n_pos : 0;
+    // the five terms run side by side on disjoint groups of the 16 waves (rgb 6, eikonal 4, depth 3, surface 2, feature 1): their loads are
+    // in flight together instead of one term after the other behind a workgroup sum each (5 x ~3 us of load latency)
+    const int w = tid >> 6, lane = tid & 63;
+    for (int slice = blockIdx.x; slice < MV_LOSS_SLICES; slice += G) {
+        float s = 0.f;                                            // this thread's partial of ITS term
+        if (w < 6) {
+            // rgb: L1Loss(reduction='sum')(rgb[mask], gt[mask]) / R                                  loss.py:21-28
+            for (int i = slice * 384 + w * 64 + lane; i < a.R * 3; i += MV_LOSS_SLICES * 384) {
+                const bool m = a.rgb_mask[i / 3] != 0;
+                const float df = a.rgb[i] - a.rgb_gt[i];
+                if (m) s += fabsf(df);
+                const float dr = m ? (df > 0.f ? invR : (df < 0.f ? -invR : 0.f)) : 0.f;
+                a.d_rgb[i] = dr;
+                if (a.s_rgb) a.s_rgb[i] = dr * a.w_rgb;
+            }
+        } else if (w < 10) {
+            // eikonal: mean((||g|| - 1)^2)                                                           loss.py:30-35
+            for (int i = slice * 256 + (w - 6) * 64 + lane; i < a.n_eik; i += MV_LOSS_SLICES * 256) {
+                const float gx = a.grad_theta[3 * i], gy = a.grad_theta[3 * i + 1], gz = a.grad_theta[3 * i + 2];
+                const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+                const float e = nrm - 1.0f;
+                s += e * e;
+                const float k = nrm > 0.f ? 2.0f * e / nrm * invE : 0.f;
+                a.d_grad[3 * i] = k * gx; a.d_grad[3 * i + 1] = k * gy; a.d_grad[3 * i + 2] = k * gz;
+                if (a.s_grad) { a.s_grad[3 * i] = (k * gx) * a.w_eik; a.s_grad[3 * i + 1] = (k * gy) * a.w_eik; a.s_grad[3 * i + 2] = (k * gz) * a.w_eik; }
+            }
+        } else if (w < 13) {
+            // depth: mean(|eikonal_output + dist_r| * weight)                                        loss.py:58-61
+            for (int i = slice * 192 + (w - 10) * 64 + lane; i < a.n_depth; i += MV_LOSS_SLICES * 192) {
+                const float df = a.eik_out[i] + a.dist_r[i], wgt = a.dweight[i];
+                s += fabsf(df) * wgt;
+                const float de = (df > 0.f ? wgt : (df < 0.f ? -wgt : 0.f)) * invD;
+                a.d_eik_out[i] = de;
+                if (a.s_eik_out) a.s_eik_out[i] = de * a.w_depth;
+            }
+        } else if (w < 15) {
+            // surface indicator: BCEWithLogits(mean) against [1]*n_pos + [0]*rest                    loss.py:167-174
+            for (int i = slice * 128 + (w - 13) * 64 + lane; i < a.n_surf; i += MV_LOSS_SLICES * 128) {
+                if (a.surf_on) {
+                    const float x = a.surf[i], t = (long long)i < npos ? 1.0f : 0.0f;
+                    s += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+                    const float ds = (1.0f / (1.0f + expf(-x)) - t) * invS;
+                    a.d_surf[i] = ds;
+                    if (a.s_surf) a.s_surf[i] = ds * a.w_surf;
+                } else { a.d_surf[i] = 0.f; if (a.s_surf) a.s_surf[i] = 0.f; }
+            }
+        } else {
+            // feature consistency: sum of the per-point terms of k_feat_corr
+            if (a.feat_on && a.feat_pp) for (int i = slice * 64 + lane; i < a.n_feat; i += MV_LOSS_SLICES * 64) s += a.feat_pp[i];
         }
-        surf_loss = block_sum_1024(s, red) * invS;
-    } else {
-        for (int i = tid; i < a.n_surf; i += 1024) { a.d_surf[i] = 0.f; if (a.s_surf) a.s_surf[i] = 0.f; }
+        if (a.s_diff && a.dpts) for (int i = slice * 1024 + tid; i < a.n_dpts; i += STR) a.s_diff[i] = a.dpts[i] * a.w_feat;
+        // the five sums of this slice: butterfly inside every wave, then the waves of each term in index order
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) red[w] = s;
+        __syncthreads();
+        if (tid == 0) {
+            const float p_rgb = ((((red[0] + red[1]) + red[2]) + red[3]) + red[4]) + red[5], p_eik = ((red[6] + red[7]) + red[8]) + red[9];
+            const float p_depth = (red[10] + red[11]) + red[12], p_surf = red[13] + red[14], p_feat = red[15];
+            if (G > 1) {                                          // device-coherent stores: no release fence (= a write-back of this XCD's whole L2) needed
+                float* pp = a.partial + 8 * slice;
+                const float pv[5] = {p_rgb, p_eik, p_depth, p_surf, p_feat};
+                for (int t = 0; t < 5; ++t) __hip_atomic_store(pp + t, pv[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else { s_part[slice][0] = p_rgb; s_part[slice][1] = p_eik; s_part[slice][2] = p_depth; s_part[slice][3] = p_surf; s_part[slice][4] = p_feat; }
+        }
+        __syncthreads();
     }
-    // feature consistency: sum of the per-point terms of k_feat_corr
-    s = 0.f;
-    float feat_loss = 0.f;
-    if (a.feat_on && a.feat_pp) {
-        for (int i = tid; i < a.n_feat; i += 1024) s += a.feat_pp[i];
-        feat_loss = block_sum_1024(s, red);
+    if (G > 1) {                                                  // the last workgroup to arrive adds the slices up
+        if (tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's slice sums have reached the coherence point before its ticket
+            s_last = (__hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)G - 1u) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        if (tid == 0) {                                           // cache-bypassing loads of everybody's slice sums
+            for (int sl = 0; sl < MV_LOSS_SLICES; ++sl)
+                for (int t = 0; t < 5; ++t) s_part[sl][t] = __hip_atomic_load(a.partial + 8 * sl + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    if (a.s_diff && a.dpts) for (int i = tid; i < a.n_dpts; i += 1024) a.s_diff[i] = a.dpts[i] * a.w_feat;
     if (tid == 0) {
+        float t5[5];
+        for (int t = 0; t < 5; ++t) { float r = 0.f; for (int sl = 0; sl < MV_LOSS_SLICES; ++sl) r += s_part[sl][t]; t5[t] = r; }
+        const float rgb_loss = t5[0] * invR, eik_loss = t5[1] * invE, depth_loss = t5[2] * invD, surf_loss = a.surf_on ? t5[3] * invS : 0.f;
+        const float feat_loss = (a.feat_on && a.feat_pp) ? t5[4] : 0.f;
         a.out[1] = rgb_loss; a.out[2] = eik_loss; a.out[3] = depth_loss; a.out[4] = feat_loss; a.out[5] = surf_loss;
         a.out[0] = rgb_loss * a.w_rgb + eik_loss * a.w_eik + surf_loss * a.w_surf + feat_loss * a.w_feat + depth_loss * a.w_depth;   // loss.py:206-210
     }
@@ -459,12 +495,17 @@ __global__ __launch_bounds__(1024) void k_loss_prep(const uint8_t* __restrict__ 
 // mask bookkeeping (workgroup 0) and depth carving (the other workgroups, 1024 points each) in one launch: independent work of IDRLoss.forward
 struct PrepCarveArgs {
     const uint8_t* net_mask; const uint8_t* obj_mask; const uint8_t* true_mask; int R, B; uint8_t* hit; int* view_start; long long* n_pos;
+    unsigned* ticket;                     // zeroed here for k_loss_terms' last-workgroup-done count
     CarveArgs c;
 };
 // carve workgroups: 64 points each, the 16 waves split the views (wave w takes views w, w + 16, ...): the per-view counts and min / max combine
 // exactly in any order, so the result equals the one-thread-per-point kernel's bit for bit at a sixteenth of its latency
 __global__ __launch_bounds__(1024) void k_loss_prep_carve(PrepCarveArgs a) {
-    if (blockIdx.x == 0) { mv_loss_prep_block(a.net_mask, a.obj_mask, a.true_mask, a.R, a.B, a.hit, a.view_start, a.n_pos); return; }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0 && a.ticket) *a.ticket = 0u;
+        mv_loss_prep_block(a.net_mask, a.obj_mask, a.true_mask, a.R, a.B, a.hit, a.view_start, a.n_pos);
+        return;
+    }
     __shared__ float part[16][4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = (blockIdx.x - 1) * 64 + lane;
@@ -565,9 +606,12 @@ int mvsdf_loss_layout(const MvsdfLossArgs* a, MvsdfLossLayout* lo) {
     lo->s_eo = take((size_t)a->n_depth * 4);
     lo->s_sf = take((size_t)a->n_surf * 4);
     lo->s_diff = take((size_t)a->N * 12);
+    take(MV_LOSS_SLICES * 8 * 4 + 16);                            // scratch of k_loss_terms (slice sums + ticket): loss_scratch() below
     lo->bytes = p;
     return 0;
 }
+// the scratch region behind s_diff (not part of the public layout)
+static size_t loss_scratch(const MvsdfLossArgs* a, const MvsdfLossLayout& lo) { return lo.s_diff + mv_al256((size_t)a->N * 12 ? (size_t)a->N * 12 : 4); }
 
 int mvsdf_loss_forward(const MvsdfLossArgs* a, void* blk, void* stream) {
     MvsdfLossLayout lo;
@@ -586,6 +630,7 @@ int mvsdf_loss_forward(const MvsdfLossArgs* a, void* blk, void* stream) {
         memset(&pc, 0, sizeof(pc));
         pc.net_mask = a->net_mask; pc.obj_mask = a->obj_mask; pc.true_mask = a->true_mask; pc.R = a->R; pc.B = a->B;
         pc.hit = hit; pc.view_start = view_start; pc.n_pos = n_pos;
+        pc.ticket = (unsigned*)(b + loss_scratch(a, lo) + MV_LOSS_SLICES * 8 * 4);
         CarveArgs& c = pc.c;
         c.pts = a->points_hom; c.M = a->n_depth; c.pts_ld = 4; c.pts_world = a->points_hom;      // rescaled in place (loss.py:38,42)
         c.depths = a->depths; c.B = a->dB; c.h = a->dh; c.w = a->dw; c.cams = a->depth_cams; c.size = a->size; c.center = a->center;
@@ -618,7 +663,8 @@ int mvsdf_loss_forward(const MvsdfLossArgs* a, void* blk, void* stream) {
         // + the gradients of the total loss itself (weights folded in): `loss.backward()` with the plain upstream 1 then needs no launch of its own
         k.s_rgb = (float*)(b + lo.s_rgb); k.s_grad = (float*)(b + lo.s_grad); k.s_eik_out = (float*)(b + lo.s_eo); k.s_surf = (float*)(b + lo.s_sf);
         k.dpts = feat ? (const float*)(b + lo.dpts) : nullptr; k.s_diff = feat ? (float*)(b + lo.s_diff) : nullptr; k.n_dpts = feat ? a->N * 3 : 0;
-        hipLaunchKernelGGL(k_loss_terms, dim3(1), dim3(1024), 0, (hipStream_t)stream, k);
+        k.partial = (float*)(b + loss_scratch(a, lo)); k.ticket = (unsigned*)(b + loss_scratch(a, lo) + MV_LOSS_SLICES * 8 * 4);
+        hipLaunchKernelGGL(k_loss_terms, dim3(MV_LOSS_SLICES), dim3(1024), 0, (hipStream_t)stream, k);
         return mv_check(hipGetLastError(), "mvsdf_loss_forward (terms)");
     }
 }
