@@ -59,8 +59,9 @@ __device__ __forceinline__ void mv_eval_dispatch(const NET& net, int ntiles, flo
         // (three or four row tiles: the carried scheme's 64 weight registers on top of 32-48 accumulators / activation registers spill)
         if (MT >= 4 && ntiles == 4) mv_sdf_eval_col0<(MT >= 4 ? 4 : MT), NTW, NW, false>(net, act, pe, pts, out, tid);
         else if (MT >= 3 && ntiles == 3) mv_sdf_eval_col0<(MT >= 3 ? 3 : MT), NTW, NW, false>(net, act, pe, pts, out, tid);
-        else if (MT >= 2 && ntiles == 2) mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW, NW, XR>(net, act, pe, pts, out, tid);
-        else mv_sdf_eval_col0<1, NTW, NW, XR>(net, act, pe, pts, out, tid);
+        // (four column tiles per wave = 512-wide nets: the carried scheme would hold 4 of their 16 k-blocks and fetch the rest on the spot)
+        else if (MT >= 2 && ntiles == 2) mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW, NW, (XR && NTW < 4)>(net, act, pe, pts, out, tid);
+        else mv_sdf_eval_col0<1, NTW, NW, (XR && NTW < 4)>(net, act, pe, pts, out, tid);
     }
 }
 
