@@ -33,7 +33,8 @@ struct Step {
     int R, E, M, Nout, K0r, nl;                      // rays, sample rows, evaluation rows, SDF output width, rendering-net input width, layers in total
     size_t woff[MVSDF_STEP_MAX_LAYERS], boff[MVSDF_STEP_MAX_LAYERS];   // float offsets inside dflat: [W | b of the SDF net | W | b of the rendering net]
     size_t seg[2][3];                                // per network: first weight, first bias, end
-    long long* counts_host;                          // pinned [4]
+    long long* counts_host;                          // pinned, host-mapped [4]
+    long long* counts_host_dev;                      // its device address (nullptr: not mapped, the counts travel by a copy)
     hipEvent_t ev_counts;
     bool counts_pending;
     int timing;
@@ -234,7 +235,9 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
         return mv_fail(-1, "mvsdf_step_forward: missing input");
     hipStream_t s = (hipStream_t)stream;
     if (!st->counts_host) {                                       // first forward: host-side staging for the hit counts
-        ST_HIP(hipHostMalloc((void**)&st->counts_host, 4 * sizeof(long long), hipHostMallocDefault));
+        ST_HIP(hipHostMalloc((void**)&st->counts_host, 4 * sizeof(long long), hipHostMallocMapped));
+        // the partition kernel writes the counts straight into this buffer (no D2H copy node between two kernels)
+        if (hipHostGetDevicePointer((void**)&st->counts_host_dev, st->counts_host, 0) != hipSuccess) { (void)hipGetLastError(); st->counts_host_dev = nullptr; }
         if (hipEventCreateWithFlags(&st->ev_counts, hipEventDisableTiming) != hipSuccess) {
             hipHostFree(st->counts_host); st->counts_host = nullptr;
             return mv_fail(-1, "mvsdf_step_forward: hipEventCreate failed");
@@ -278,8 +281,8 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     long long* perm = (long long*)(fwd + L.perm); long long* inv = (long long*)(fwd + fo.inv); long long* true_rows = (long long*)(fwd + fo.true_rows);
     long long* counts = (long long*)(fwd + fo.counts); float* view_sorted = (float*)(fwd + fo.view_sorted);
     ST_TRY(mv_partition_rays_step(mask, d.use_object_mask ? in->object_mask : nullptr, in->object_mask_true, ray_dirs, R, perm, inv, true_rows, counts,
-                                  view_sorted, (int*)(fwd + fo.true_rank), d.n_ds > 0 ? in->ds_counts : nullptr, stream));
-    ST_HIP(hipMemcpyAsync(st->counts_host, counts, 4 * sizeof(long long), hipMemcpyDeviceToHost, s));
+                                  view_sorted, (int*)(fwd + fo.true_rank), d.n_ds > 0 ? in->ds_counts : nullptr, st->counts_host_dev, stream));
+    if (!st->counts_host_dev) ST_HIP(hipMemcpyAsync(st->counts_host, counts, 4 * sizeof(long long), hipMemcpyDeviceToHost, s));   // (pinned memory not mapped)
     ST_HIP(hipEventRecord(st->ev_counts, s));
     st->counts_pending = true;
     if (st->timing) ST_HIP(hipEventRecord(st->ev_t[3], s));
