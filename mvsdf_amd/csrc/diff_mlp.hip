@@ -630,9 +630,8 @@ struct DeltaArgs {
 };
 template <bool FB>
 __global__ __launch_bounds__(256) void k_delta_apply(DeltaArgs a) {
-    const int row = blockIdx.x, l = blockIdx.y, N = a.N[l];
-    float f;
-    if (FB) {
+    const int row = blockIdx.x;
+    if (FB) {                                                     // one workgroup per row, all layers: fbar once, then 8 independent streams per thread
         float dot = 0.f, num = 0.f;
         for (int c = 0; c < 3; ++c) {
             float xb = (a.d_diff ? a.d_diff[3 * (size_t)row + c] : 0.f);
@@ -641,9 +640,18 @@ __global__ __launch_bounds__(256) void k_delta_apply(DeltaArgs a) {
             const float v = -a.view_sorted[3 * (size_t)row + c];
             num += xb * v; dot += a.n_hit[3 * (size_t)row + c] * v;
         }
-        f = -num / dot;
-        if (l == 0 && threadIdx.x == 0) { a.fbar_out[row] = f; a.dy_hit[(size_t)row * a.Nout] += f; }
-    } else f = a.fbar[row];
+        const float f = -num / dot;
+        if (threadIdx.x == 0) { a.fbar_out[row] = f; a.dy_hit[(size_t)row * a.Nout] += f; }
+        for (int l = 0; l < a.nl1; ++l) {
+            const int N = a.N[l];
+            const float* sg = a.Sg[l] + (size_t)row * N;
+            float* zb = a.ZB[l] + (size_t)row * N;
+            for (int c = threadIdx.x; c < N; c += 256) zb[c] = zb[c] + f * sg[c];
+        }
+        return;
+    }
+    const int l = blockIdx.y, N = a.N[l];
+    const float f = a.fbar[row];
     const float* sg = a.Sg[l] + (size_t)row * N;
     float* zb = a.ZB[l] + (size_t)row * N;
     for (int c = threadIdx.x; c < N; c += 256) zb[c] = zb[c] + f * sg[c];
@@ -977,7 +985,7 @@ int mv_sdf_backward_delta_fbar(const MvsdfNetDesc* d, int M, int Mg, int Mb, con
     }
     a.d_diff = d_diff; a.din = din; a.dx = dx; a.view_sorted = view_sorted; a.n_hit = n_eval + 3 * (size_t)row0D;
     a.din_ld = din_ld; a.use_geo = use_geo; a.Nout = Nout; a.dy_hit = dy + (size_t)row0D * Nout; a.fbar_out = fbar;
-    hipLaunchKernelGGL(k_delta_apply<true>, dim3(MbD, lo.nl - 1), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_delta_apply<true>, dim3(MbD), dim3(256), 0, (hipStream_t)stream, a);
     return mv_check(hipGetLastError(), "mv_sdf_backward_delta_fbar");
 }
 
