@@ -255,7 +255,8 @@ __device__ unsigned long long g_chain_ph[16][16];
 // rows per weight-gradient chunk (one slab per chunk and layer).  128 -> 256: k_wgrad_net unchanged, k_reduce_net reads half the slabs (c2 20 -> 13 us,
 // c5share 41 -> 23 us).  Measured and NOT kept for k_wgrad_net itself (it runs at 0.32-0.37 matrix-pipe busy): register-prefetching the next operand tiles
 // under the MFMA loop (63.6 vs 61.6 us at c2) and 128 x 128 output tiles with 8 waves, i.e. half the L2 traffic per flop (62.7 vs 61.5 us at c2, 120 vs 110
-// at the c5 share) -- neither exposed load latency nor L2 bandwidth is its bound.
+// at the c5 share) -- neither exposed load latency nor L2 bandwidth is its bound.  512 rows: k_reduce_net 13.6 -> 10.3 / 24 -> 14 us, k_wgrad_net
+// 94 -> 91 us at c2 (825 workgroups: one round of the 1024 slots) but 154 -> 166 us at the c5 share and 311 -> 323 us at c3: not taken.
 #define MV_WG_CHUNK 256
 struct WgradLayer {
     const float* P1; const float* Q1; const float* P2; const float* Q2;   // [M, No], [M, Ki]; P2 null: single pair
