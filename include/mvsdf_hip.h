@@ -76,6 +76,10 @@ enum {
 };
 
 int mvsdf_version(void);
+/* sizeof() of the structs of this header as the library was compiled, in the order MvsdfNetDesc, MvsdfTraceParams, MvsdfStepDesc, MvsdfStepParams,
+ * MvsdfStepInputs, MvsdfStepLayout, MvsdfLossArgs, MvsdfLossLayout -> out[8]; a binding checks its own struct definitions against it
+ * (tests/test_abi.py does for the ctypes binding).  Returns 8. */
+int mvsdf_abi_struct_sizes(size_t* out);
 const char* mvsdf_last_error(void);
 
 /* number of floats of the packed form of an [N][K] Linear (both dims rounded up to 16) */

@@ -429,3 +429,11 @@ int mvsdf_step_backward(void* step, const MvsdfStepParams* prm, int N, int n_tru
 }
 
 }  // extern "C"
+
+extern "C" int mvsdf_abi_struct_sizes(size_t* out) {
+    if (!out) return mv_fail(-1, "mvsdf_abi_struct_sizes: null argument");
+    out[0] = sizeof(MvsdfNetDesc); out[1] = sizeof(MvsdfTraceParams); out[2] = sizeof(MvsdfStepDesc); out[3] = sizeof(MvsdfStepParams);
+    out[4] = sizeof(MvsdfStepInputs); out[5] = sizeof(MvsdfStepLayout); out[6] = sizeof(MvsdfLossArgs); out[7] = sizeof(MvsdfLossLayout);
+    return 8;
+}
+

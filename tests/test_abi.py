@@ -31,3 +31,16 @@ def test_product_does_not_import_oracle():
                 if re.search(r'^\s*(from|import)\s+oracle\b|#include\s+"[^"]*oracle', txt, flags=re.M):
                     bad.append(fn)
     assert not bad, bad
+
+
+def test_ctypes_structs_have_the_sizes_the_library_was_compiled_with():
+    """The ctypes mirrors of the header's structs (mvsdf_amd/_lib.py, native_step.py) against sizeof() inside the library: a field added on one
+    side only shows up here instead of as silently shifted arguments."""
+    from mvsdf_amd import _lib, native_step as ns
+    out = (ctypes.c_size_t * 8)()
+    _lib.lib().mvsdf_abi_struct_sizes.argtypes = [ctypes.POINTER(ctypes.c_size_t)]
+    assert _lib.lib().mvsdf_abi_struct_sizes(out) == 8
+    mirrors = [_lib.NetDesc, _lib.TraceParams, ns.StepDesc, ns.StepParams, ns.StepInputs, ns.StepLayout, ns.LossArgs, ns.LossLayout]
+    for cls, size in zip(mirrors, list(out)):
+        assert ctypes.sizeof(cls) == size, (cls.__name__, ctypes.sizeof(cls), size)
+
