@@ -28,8 +28,28 @@ struct AdamArgs {
     float* norm_out;                                 // [2]: total norm, clip coefficient
 };
 
+__device__ __forceinline__ void mv_adam_one(const AdamArgs& a, float coef, float step_size, float gi, float mi, float vi, float pi, float& g, float& m,
+                                            float& v, float& p) {
+    g = gi * a.grad_scale * coef;
+    m = mi + (g - mi) * (1.0f - a.beta1);                                                  // exp_avg.lerp_(grad, 1 - beta1)
+    v = vi * a.beta2 + (1.0f - a.beta2) * g * g;                                           // mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = pi - step_size * (m / denom);
+}
+
 __global__ __launch_bounds__(256) void k_adam_flat(AdamArgs a) {
     __shared__ float coef_s;
+    // this thread's first four elements are requested BEFORE the norm is re-derived (their loads do not depend on it): the kernel was a chain of
+    // two load round trips (partials, then the parameters); 16-byte accesses when the four buffers allow it
+    const size_t n4 = a.n >> 2;
+    const bool vec = ((((size_t)a.p | (size_t)a.g | (size_t)a.m | (size_t)a.v) & 15) == 0);
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x, stride4 = (size_t)gridDim.x * 256;
+    float4 g4 = {0.f, 0.f, 0.f, 0.f}, m4 = g4, v4 = g4, p4 = g4;
+    const bool have = vec && i4 < n4;
+    {
+        const size_t j = have ? i4 : 0;                          // clamped: no branch around the loads
+        if (vec) { g4 = ((const float4*)a.g)[j]; m4 = ((const float4*)a.m)[j]; v4 = ((const float4*)a.v)[j]; p4 = ((const float4*)a.p)[j]; }
+    }
     if (threadIdx.x < 64) {                          // every block re-derives the norm from the partials, same order everywhere
         float s = 0.0f;
         for (int i = threadIdx.x; i < a.nparts; i += 64) s += a.part[i];
@@ -45,13 +65,21 @@ __global__ __launch_bounds__(256) void k_adam_flat(AdamArgs a) {
     __syncthreads();
     const float coef = coef_s;
     const float step_size = a.lr / a.bc1;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-        const float g = a.g[i] * a.grad_scale * coef;
-        const float m = a.m[i] + (g - a.m[i]) * (1.0f - a.beta1);                          // exp_avg.lerp_(grad, 1 - beta1)
-        const float v = a.v[i] * a.beta2 + (1.0f - a.beta2) * g * g;                       // mul_(beta2).addcmul_(g, g, 1 - beta2)
-        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-        a.m[i] = m; a.v[i] = v; a.g[i] = g;
-        a.p[i] = a.p[i] - step_size * (m / denom);
+    if (vec) {
+        for (size_t i = i4; i < n4; i += stride4) {
+            if (i != i4) { g4 = ((const float4*)a.g)[i]; m4 = ((const float4*)a.m)[i]; v4 = ((const float4*)a.v)[i]; p4 = ((const float4*)a.p)[i]; }
+            float4 go, mo, vo, po;
+            mv_adam_one(a, coef, step_size, g4.x, m4.x, v4.x, p4.x, go.x, mo.x, vo.x, po.x);
+            mv_adam_one(a, coef, step_size, g4.y, m4.y, v4.y, p4.y, go.y, mo.y, vo.y, po.y);
+            mv_adam_one(a, coef, step_size, g4.z, m4.z, v4.z, p4.z, go.z, mo.z, vo.z, po.z);
+            mv_adam_one(a, coef, step_size, g4.w, m4.w, v4.w, p4.w, go.w, mo.w, vo.w, po.w);
+            ((float4*)a.m)[i] = mo; ((float4*)a.v)[i] = vo; ((float4*)a.g)[i] = go; ((float4*)a.p)[i] = po;
+        }
+    }
+    for (size_t i = (vec ? (n4 << 2) : 0) + (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {   // tail / unaligned buffers
+        float g, m, v, p;
+        mv_adam_one(a, coef, step_size, a.g[i], a.m[i], a.v[i], a.p[i], g, m, v, p);
+        a.m[i] = m; a.v[i] = v; a.g[i] = g; a.p[i] = p;
     }
 }
 
