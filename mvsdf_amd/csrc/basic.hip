@@ -612,6 +612,25 @@ __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
             float* wr = a.f.w[l] + (size_t)j * K;
             if (!a.f.g[l]) {                                                   // weight_norm=False: w = v
                 for (int k = lane; k < K; k += 64) { const float x = vr[k]; wr[k] = x; tr[k] = x; }
+            } else if (K <= 64 * 9) {
+                // the whole row is requested before the k-ordered chain starts (chunk by chunk inside the chain, every chunk's load round trip sat
+                // between two pieces of it: 4 x ~2 us of the launch's 20 at K = 256) and is reused for the scaling pass
+                float mine[9];
+                const float gj = a.f.g[l][j];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) { const int k = 64 * c + lane; const float x = vr[k < K ? k : K - 1]; mine[c] = k < K ? x : 0.0f; }
+                float ss = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    const int n = min(64, K - 64 * c);
+                    for (int i = 0; i < n; ++i) {
+                        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine[c]), i));
+                        ss = fmaf(x, x, ss);
+                    }
+                }
+                const float sc = gj / sqrtf(ss);
+#pragma unroll
+                for (int c = 0; c < 9; ++c) { const int k = 64 * c + lane; if (k < K) { const float x = mine[c] * sc; wr[k] = x; tr[k] = x; } }
             } else {
                 float ss = 0.0f;
                 for (int k0 = 0; k0 < K; k0 += 64) {
