@@ -111,13 +111,39 @@ __global__ void k_fold_bwd_net(FoldNetArgs a) {
         if (lane == 0 && a.db[l]) a.dbias[l][j] = a.accumulate ? a.dbias[l][j] + a.db[l][j] : a.db[l][j];
         return;
     }
+    float* dvr = a.dv[l] + (size_t)j * K;
+    const bool acc = a.accumulate != 0;
+    if (K <= 64 * 9) {                                          // the row's three operands once, all requested up front (clamped addresses), kept in registers
+        float vv[9], dd[9], old[9];
+        const float gj = a.g[l][j];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const int k = 64 * c + lane, kc = k < K ? k : K - 1;
+            const float x = vr[kc], y = dr[kc], z = acc ? dvr[kc] : 0.0f;
+            vv[c] = k < K ? x : 0.0f; dd[c] = k < K ? y : 0.0f; old[c] = z;
+        }
+        float ss = 0.f, dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) if (64 * c < K) { ss = fmaf(vv[c], vv[c], ss); dot = fmaf(dd[c], vv[c], dot); }
+        for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o); dot += __shfl_xor(dot, o); }
+        const float inv = 1.0f / sqrtf(ss);
+        const float dgj = dot * inv, s = gj * inv;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const int k = 64 * c + lane;
+            if (k < K) { const float t = s * (dd[c] - dgj * vv[c] * inv); dvr[k] = acc ? old[c] + t : t; }
+        }
+        if (lane == 0) {
+            a.dg[l][j] = acc ? a.dg[l][j] + dgj : dgj;
+            if (a.db[l]) a.dbias[l][j] = acc ? a.dbias[l][j] + a.db[l][j] : a.db[l][j];
+        }
+        return;
+    }
     float ss = 0.f, dot = 0.f;
     for (int k = lane; k < K; k += 64) { ss = fmaf(vr[k], vr[k], ss); dot = fmaf(dr[k], vr[k], dot); }
     for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o); dot += __shfl_xor(dot, o); }
     const float inv = 1.0f / sqrtf(ss);
     const float dgj = dot * inv, s = a.g[l][j] * inv;
-    float* dvr = a.dv[l] + (size_t)j * K;
-    const bool acc = a.accumulate != 0;
     for (int k = lane; k < K; k += 64) {
         const float t = s * (dr[k] - dgj * vr[k] * inv);
         dvr[k] = acc ? dvr[k] + t : t;
