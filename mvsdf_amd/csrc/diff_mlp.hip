@@ -262,6 +262,14 @@ static int mv_chain_mt(int tiles16) {
     const int rounds1 = (tiles16 + 255) / 256, rounds2 = (tiles16 + 511) / 512;
     return 1.76 * rounds2 < rounds1 ? 2 : 1;
 }
+/* Does the fused forward chain over the rows [E, M) alone need fewer / shorter rounds of workgroups than over [0, M)?  (the same model as
+ * mv_chain_mt: a round of two-tile workgroups costs 1.76 rounds of one-tile workgroups)  The step asks before it moves the E sample rows beside the tracer. */
+int mv_chain_split_pays(const MvsdfNetDesc* d, int E, int M) {
+    MvNet net;
+    if (E < 16 || E >= M || mv_make_net(d, &net) || mv_chain_ntw(net) != 2 || mv_chain_w8()) return 0;
+    auto cost = [](int tiles16) { const int r1 = (tiles16 + 255) / 256, r2 = (tiles16 + 511) / 512; return 1.76 * r2 < r1 ? 1.76 * r2 : 1.0 * r1; };
+    return cost((M - E + 15) / 16) < cost((M + 15) / 16) ? 1 : 0;
+}
 
 #define MV_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mv_check(e_, #expr); } while (0)
 
@@ -280,21 +288,26 @@ size_t mvsdf_sdf_bwd_ws_floats(const MvsdfNetDesc* d, int Mb) {
 
 int mvsdf_sdf_forward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float* x, int M, int Mg, float* y, float* nrm, float* ctx,
                       void* stream) {
-    return mv_sdf_forward_gather(d, dT, x, nullptr, M, Mg, y, nrm, ctx, stream);
+    return mv_sdf_forward_gather(d, dT, x, nullptr, M, Mg, 0, M, y, nrm, ctx, stream);
 }
 
 }  // extern "C"
 
 /* mvsdf_sdf_forward whose rows are gathered inside the fused chain kernel (g != NULL: the rows [eikonal | on-surface | jittered | pts[perm]], also
  * written to g->x_out) -- the training step's x_eval without a gather launch.  -> 1 when g was given but the per-layer route had to run: nothing was
- * launched, the caller gathers itself and calls again with x. */
-int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float* x, const void* gather, int M, int Mg, float* y, float* nrm,
-                          float* ctx, void* stream) {
+ * launched, the caller gathers itself and calls again with x.
+ * [r_begin, r_end) is the row range THIS launch evaluates (buffers and M / Mg always describe all the rows): the step evaluates its sample rows, which
+ * do not depend on the tracer, beside the tracer and the rows of the rays after it.  Rows are independent, so the split changes no bit; only the
+ * fused chain accepts a proper sub-range (-> 1 otherwise, nothing launched). */
+int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float* x, const void* gather, int M, int Mg, int r_begin, int r_end,
+                          float* y, float* nrm, float* ctx, void* stream) {
     const FwdGather* g = (const FwdGather*)gather;
     MvNet net, netT;
     int rc = mv_make_net(d, &net);
     if (rc) return rc;
-    if ((!x && !g) || !y || !ctx || M <= 0 || Mg < 0 || Mg > M) return mv_fail(-1, "mvsdf_sdf_forward: bad arguments");
+    if ((!x && !g) || !y || !ctx || M <= 0 || Mg < 0 || Mg > M || r_begin < 0 || r_end > M || r_begin >= r_end)
+        return mv_fail(-1, "mvsdf_sdf_forward: bad arguments");
+    const bool sub = r_begin > 0 || r_end < M;
     if (Mg > 0) {
         rc = mv_make_net_mode(dT, &netT, 2);
         if (rc) return rc;
@@ -311,7 +324,8 @@ int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const f
         FwdArgs f;
         memset(&f, 0, sizeof(f));
         f.net = net; if (Mg > 0) f.netT = netT;
-        f.S = S; f.M = M; f.Mg = Mg; f.ld0 = lo.ld0; f.x = x; f.H0 = H0;
+        const int Mr = r_end - r_begin;
+        f.S = S; f.M = r_end; f.Mg = Mg < r_end ? Mg : r_end; f.row_base = r_begin; f.ld0 = lo.ld0; f.x = x; f.H0 = H0;
         for (int l = 1; l < nl; ++l) f.A[l] = ctx + lo.A[l];
         for (int l = 0; l < nl - 1; ++l) { f.Z[l] = ctx + lo.Z[l]; f.Sg[l] = ctx + lo.Sg[l]; }
         for (int l = 1; l < nl - 1; ++l) f.U[l] = ctx + lo.U[l];
@@ -323,11 +337,11 @@ int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const f
         // dependent layer phases; twice the waves halve every wave's share of the global loads / stores and of the epilogue between
         // two GEMMs (measured 148 -> 127 us here, 173 -> 143 us for the backward pass).  MVSDF_CHAIN_W8=1: 8 waves (dev A/B).
         const bool w8 = mv_chain_w8();
-        const dim3 grid((M + 16 * MTC - 1) / (16 * MTC));
-        const int mt = (ntw_f == 2 && !w8) ? mv_chain_mt((M + 15) / 16) : 1;
+        const dim3 grid((Mr + 16 * MTC - 1) / (16 * MTC));
+        const int mt = (ntw_f == 2 && !w8) ? mv_chain_mt((Mr + 15) / 16) : 1;
         if (mt > 1) {
             const size_t ldsm = ((size_t)16 * mt * S + 2 * ((16 * mt * lo.d0 + 3) & ~3) + 16 * mt * 4) * sizeof(float);
-            const dim3 gridm((M + 16 * mt - 1) / (16 * mt));
+            const dim3 gridm((Mr + 16 * mt - 1) / (16 * mt));
             MV_TRY(hipFuncSetAttribute((const void*)k_chain_fwd<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
             hipLaunchKernelGGL((k_chain_fwd<2, 1, 16>), gridm, dim3(1024), ldsm, s, f);
         }
@@ -337,7 +351,7 @@ int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const f
         else hipLaunchKernelGGL((k_chain_fwd<MTC, 4, NWC>), grid, dim3(64 * NWC), lds, s, f);
         return mv_check(hipGetLastError(), "mvsdf_sdf_forward");
     }
-    if (g) return 1;                                             // per-layer route: rows must be materialised by the caller
+    if (g || sub) return 1;                                      // per-layer route: rows must be materialised by the caller, all of them at once
     hipLaunchKernelGGL(k_pe_global, dim3((M * (3 * net.multires + 1) + 255) / 256), dim3(256), 0, s, x, M, net.multires, H0, lo.ld0);
     for (int l = 0; l < nl - 1; ++l) {                                            // hidden layers (idr.py:82-92)
         LayerArgs a = base_args(net.L[l], S, M);

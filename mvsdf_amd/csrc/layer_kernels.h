@@ -917,7 +917,8 @@ __global__ __launch_bounds__(64 * NW) void k_chain_bwd2(ChainArgs a, ChainArgs b
 // The running activation / adjoint tile never leaves LDS.  Same arithmetic as the per-layer kernels it replaces.
 struct FwdArgs {
     MvNet net, netT;
-    int S, M, Mg, ld0;
+    int S, M, Mg, ld0;                         // M / Mg: END of the rows this launch evaluates / gives normals to ...
+    int row_base;                              // ... which start at row_base (workgroup b owns the rows row_base + 16 MT b ..)
     const float* x;                            // [M][3]
     float* H0;                                 // [M][ld0]
     float* A[MV_MAXL]; float* Z[MV_MAXL];      // A_l [M][K_l] (l >= 1), Z_l [M][N_l] = sigma_l = sigmoid100(z_l) (what every later pass needs of z_l)
@@ -934,7 +935,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT, NTH = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers, d0 = 3 + 6 * a.net.multires;
+    const int row0 = a.row_base + blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers, d0 = 3 + 6 * a.net.multires;
     const unsigned skm = a.net.skip_mask;
     float* act = smem;
     float* pe = act + ROWS * S;                                  // [ROWS][d0] natural order

@@ -40,6 +40,9 @@ struct Step {
     int timing;
     hipEvent_t ev_t[5];
     bool timed;
+    hipStream_t side;                                // the sample rows of the fused evaluation run here, beside the tracer (created on first use)
+    hipEvent_t ev_fork, ev_join;
+    int split_rows;                                  // -1 undecided, 0 one launch over all rows, 1 samples beside the tracer + rays after it
 };
 
 // descriptors of the two networks over the packs inside a forward block
@@ -120,6 +123,7 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
     st->d = d;
     st->R = d.B * d.P; st->E = d.n_eik + 2 * d.n_ds; st->M = st->R + st->E; st->nl = nl;
     st->Nout = d.N[d.n_sdf - 1]; st->K0r = d.K[d.n_sdf];
+    st->split_rows = -1;
     const int R = st->R, M = st->M;
     // probe descriptors (sizes only; the size functions do not dereference the pack pointers but the validity checks want non-null ones)
     MvsdfNetDesc sdf, sdfT, rnd, rndT;
@@ -198,6 +202,7 @@ void mvsdf_step_destroy(void* step) {
     if (!st) return;
     if (st->timing) for (int i = 0; i < 5; ++i) hipEventDestroy(st->ev_t[i]);
     if (st->counts_host) { hipEventDestroy(st->ev_counts); hipHostFree(st->counts_host); }
+    if (st->side) { hipStreamSynchronize(st->side); hipEventDestroy(st->ev_fork); hipEventDestroy(st->ev_join); hipStreamDestroy(st->side); }
     delete st;
 }
 
@@ -264,6 +269,32 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     }
     MvsdfNetDesc sdf, sdfT, rnd, rndT;
     make_descs(*st, prm, fwd, &sdf, &sdfT, &rnd, &rndT);
+    float* x_eval = (float*)(fwd + fo.x_eval); float* y_eval = (float*)(fwd + fo.y_eval); float* n_eval = (float*)(fwd + fo.n_eval);
+    FwdGather g;                                                  // the evaluation rows [samples | traced points of the rays, hit first]
+    g.eik = in->eik_points; g.on = in->ds_on; g.jit = in->ds_jit; g.pts = (float*)(fwd + L.points); g.perm = (long long*)(fwd + L.perm);
+    g.n_eik = d.n_eik; g.n_ds = d.n_ds; g.x_out = x_eval;
+    // 1b. the E sample rows of the fused value + normal evaluation (idr.py:240-275) depend on the folded weights only: where the rows of the rays
+    // alone make a shorter launch (mv_chain_split_pays), the samples run NOW on a side stream, on the CUs the sphere tracer's latency chains
+    // leave idle, and join before the rays' launch.  Rows are independent: no bit changes.  MVSDF_SPLIT_ROWS=0 / 1 forces one launch / the split.
+    if (st->split_rows < 0) {
+        const char* e = getenv("MVSDF_SPLIT_ROWS");
+        st->split_rows = (e && *e) ? (atoi(e) != 0 && E >= 1) : mv_chain_split_pays(&sdf, E, M);
+        if (st->split_rows) {
+            if (hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st->side = nullptr; st->split_rows = 0; }
+            else if (hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming) != hipSuccess)
+                return mv_fail(-1, "mvsdf_step_forward: hipEventCreate failed");
+        }
+    }
+    bool split = st->split_rows == 1;
+    if (split) {
+        ST_HIP(hipEventRecord(st->ev_fork, s));
+        ST_HIP(hipStreamWaitEvent(st->side, st->ev_fork, 0));
+        const int rcs = mv_sdf_forward_gather(&sdf, &sdfT, nullptr, &g, M, M, 0, E, y_eval, n_eval, (float*)(fwd + fo.sdf_ctx), st->side);
+        if (rcs == 1) split = false;                              // per-layer route: nothing was launched, one pass over all rows below
+        else if (rcs) return rcs;
+        else ST_HIP(hipEventRecord(st->ev_join, st->side));
+    }
     // 2. rays + RayTracing.forward (idr.py:190-199)
     float* points = (float*)(fwd + L.points); uint8_t* mask = (uint8_t*)(fwd + L.mask); float* dists = (float*)(fwd + L.dists);
     unsigned long long* counters = (unsigned long long*)(fwd + L.counters);
@@ -289,12 +320,10 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     ST_TRY(stage(4));                                             // secant + min-sdf rows: only points / dists still move
     if (st->timing) { ST_HIP(hipEventRecord(st->ev_t[4], s)); st->timed = true; }
     // 4. ONE fused value + normal evaluation over [samples | rays, hit first], rendering net on every sorted ray, output gather
-    float* x_eval = (float*)(fwd + fo.x_eval); float* y_eval = (float*)(fwd + fo.y_eval); float* n_eval = (float*)(fwd + fo.n_eval);
     {
-        // the evaluation rows [samples | traced points of the rays, hit first] are gathered inside the chain kernel (which also leaves them in x_eval)
-        FwdGather g;
-        g.eik = in->eik_points; g.on = in->ds_on; g.jit = in->ds_jit; g.pts = points; g.perm = perm; g.n_eik = d.n_eik; g.n_ds = d.n_ds; g.x_out = x_eval;
-        int rcf = mv_sdf_forward_gather(&sdf, &sdfT, nullptr, &g, M, M, y_eval, n_eval, (float*)(fwd + fo.sdf_ctx), stream);
+        // (the rows are gathered inside the chain kernel, which also leaves them in x_eval)
+        if (split) ST_HIP(hipStreamWaitEvent(s, st->ev_join, 0));
+        int rcf = mv_sdf_forward_gather(&sdf, &sdfT, nullptr, &g, M, M, split ? E : 0, M, y_eval, n_eval, (float*)(fwd + fo.sdf_ctx), stream);
         if (rcf == 1) {                                           // per-layer route: materialise the rows first
             const int total = M * 3;
             hipLaunchKernelGGL(k_step_gather_x, dim3((total + 255) / 256), dim3(256), 0, s, in->eik_points, d.n_eik, in->ds_on, in->ds_jit, d.n_ds, points, perm,

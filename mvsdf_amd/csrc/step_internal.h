@@ -20,8 +20,11 @@ int mv_step_backward_assemble(int n_eik, int n_ds, int N, int Nout, int n_true, 
 
 // mvsdf_sdf_forward with the step's evaluation rows gathered inside the fused chain kernel; `gather` = const FwdGather* (layer_kernels.h) or NULL;
 // -> 1 when the per-layer route would run (nothing launched: gather yourself and call with x)
-int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float* x, const void* gather, int M, int Mg, float* y, float* nrm,
-                          float* ctx, void* stream);
+// [r_begin, r_end): the rows this launch evaluates (a proper sub-range only through the fused chain; -> 1 otherwise)
+int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const float* x, const void* gather, int M, int Mg, int r_begin, int r_end,
+                          float* y, float* nrm, float* ctx, void* stream);
+// 1 when the fused chain over the rows [E, M) alone is a shorter launch than over [0, M) (diff_mlp.hip)
+int mv_chain_split_pays(const MvsdfNetDesc* d, int E, int M);
 
 // pieces of the training step's backward (diff_mlp.hip): the rendering net's descending chain alone, the SDF net's delta pass alone, and the weight
 // gradients of BOTH networks as one k_wgrad_net / k_reduce_net pair

@@ -1,7 +1,8 @@
 """The library keeps alternative launch paths behind environment switches (tools/README.md): per-layer kernels instead of the fused chain
 kernels (MVSDF_FUSE=0), the backward pass as separate E.1 / E.2 chain launches (MVSDF_SPLIT_CHAINS=1), 8-wave chain workgroups
 (MVSDF_CHAIN_W8=1), two row tiles per chain workgroup everywhere (MVSDF_CHAIN_MT=2), the delta pass as a chain of GEMMs instead of the
-scaling of the saved s_l (MVSDF_DELTA_CHAIN=1), the Python-orchestrated step (MVSDF_NATIVE_STEP=0), the tracer without tail filling (MVSDF_TAIL=0).  Each is an independent implementation of the same
+scaling of the saved s_l (MVSDF_DELTA_CHAIN=1), the Python-orchestrated step (MVSDF_NATIVE_STEP=0), the tracer without tail filling (MVSDF_TAIL=0), the step's sample rows evaluated on a side
+stream beside the tracer at every size (MVSDF_SPLIT_ROWS=1; by default only where the rays' rows alone make a shorter launch).  Each is an independent implementation of the same
 passes: the reference-fixture tests of the differentiable kernels and one end-to-end fixture must pass on every one of them.  The switches
 are read once per process, so each configuration runs in a child pytest."""
 import os
@@ -19,7 +20,7 @@ TARGETS = ['tests/test_gpu_diff.py', 'tests/test_gpu_idr.py::test_forward_loss_b
 
 
 @pytest.mark.parametrize('env', [{'MVSDF_FUSE': '0'}, {'MVSDF_SPLIT_CHAINS': '1'}, {'MVSDF_CHAIN_W8': '1'}, {'MVSDF_CHAIN_MT': '2'}, {'MVSDF_DELTA_CHAIN': '1'},
-                                 {'MVSDF_NATIVE_STEP': '0'}, {'MVSDF_TAIL': '0'}],
+                                 {'MVSDF_NATIVE_STEP': '0'}, {'MVSDF_TAIL': '0'}, {'MVSDF_SPLIT_ROWS': '1'}],
                          ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()))
 def test_reference_fixtures_pass_on_the_alternative_paths(env):
     e = dict(os.environ)
@@ -56,3 +57,36 @@ torch.save(g.cpu(), sys.argv[1])
     dev = float((a - b).abs().max() / b.abs().max())
     print('delta by scaling vs delta chain: max |dgrad| = %.3g of the largest gradient entry' % dev)
     assert 0 < dev < 2e-5 or dev == 0.0
+
+
+def test_sample_rows_beside_the_tracer_change_no_bit():
+    """The step may evaluate its E sample rows (eikonal / depth samples: idr.py:240-275) on a side stream while the tracer runs, and only the rays'
+    rows after it (step_driver.hip, 1b).  Rows of the fused chain are independent of their tile: outputs, losses and gradients are identical bits."""
+    import tempfile
+    import torch
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
+from test_gpu_native_step import _run
+res = []
+for rep in range(2):                                   # the second step reuses the side stream / events
+    outs, losses, g, _, _ = _run(True, W=256, B=4, P=256, V=3, tp=0.3, sink=True)
+    res.append({'g': g.cpu(), 'losses': {k: v.detach().cpu() for k, v in losses.items()},
+                'outs': {k: v.detach().cpu() for k, v in outs.items() if torch.is_tensor(v)}})
+torch.save(res, sys.argv[1])
+''' % (ROOT, ROOT)
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for split in ('0', '1'):
+            out = os.path.join(td, 'r%s.pt' % split)
+            e = dict(os.environ, MVSDF_SPLIT_ROWS=split)
+            p = subprocess.run([sys.executable, '-c', code, out], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+            assert p.returncode == 0, p.stdout.decode(errors='replace')[-2000:]
+            res.append(torch.load(out))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a['g'], b['g'])
+        for k in a['losses']:
+            assert torch.equal(a['losses'][k], b['losses'][k]), k
+        assert a['outs'].keys() == b['outs'].keys() and len(a['outs']) >= 8
+        for k in a['outs']:
+            assert torch.equal(a['outs'][k], b['outs'][k]), k
