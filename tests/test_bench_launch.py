@@ -84,3 +84,21 @@ def test_one_rank_under_the_launcher_runs_the_collectives_through_rccl():
     d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
     assert d['n_gpus'] == 1 and d['value'] > 0
     assert d['collective_ms']['backend'] == 'nccl' and d['collective_ms']['grad_all_reduce'] > 0     # (world 1: no count all-reduce)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('args,ms_max,frac_min,combined_min', [
+    ([], 2.65, 0.40, 0.33),                                            # measured 2.02 ms, 0.48, 0.40 (profiles/r03_bench_line.json)
+    (['--workload', 'c5share', '--dtype', 'bf16'], 2.2, None, None),   # measured 1.64 ms
+], ids=['c2_f32', 'c5share_bf16'])
+def test_regression_gate_of_the_headline_numbers(args, ms_max, frac_min, combined_min):
+    """Not a benchmark: a gate 30 % above the committed numbers (boxes differ by ~2 %), so that a change which silently loses a fusion, the
+    native step driver or an engine path fails the suite instead of surfacing as a slower bench line a round later."""
+    rc, lines, err = _run(args + ['--steps', '40', '--warmup', '15', '--no-cpu-baseline'], {})
+    assert rc == 0, err
+    d = json.loads(lines[-1])
+    print('%s: %.3f ms/step, roofline %s' % (' '.join(args) or 'c2', d['ms_per_step'], d['roofline'].get('frac')))
+    assert d['ms_per_step'] < ms_max, d['ms_per_step']
+    if frac_min is not None:
+        assert d['roofline']['frac'] >= frac_min, d['roofline']
+        assert d['roofline']['kernels']['tracing (k_ray_samples + k_sphere_trace)']['frac'] >= combined_min, d['roofline']['kernels']
