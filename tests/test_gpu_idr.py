@@ -88,7 +88,7 @@ def test_forward_loss_backward_vs_reference(name):
     gtt = {k: t(v) for k, v in gt.items()}
     lo = IDRLoss()(out, gtt, tp, B)
     for k in ('loss', 'rgb_loss', 'eikonal_loss', 'depth_loss', 'feat_loss', 'surf_loss'):
-        v, ref = float(lo[k].reshape(-1)[0]), float(g['loss_' + k])
+        v, ref = float(lo[k].detach().reshape(-1)[0]), float(g['loss_' + k])
         assert abs(v - ref) <= 2e-4 * max(1.0, abs(ref)), (k, v, ref)
     # the reference rescales eikonal_points_hom to world coordinates IN PLACE inside the loss (loss.py:38,42); the golden holds that
     if 'dsurf_on' in g.files:                                                     # this fixture stores the pre-loss (normalised) points
