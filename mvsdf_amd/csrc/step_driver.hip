@@ -280,21 +280,17 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
         const char* e = getenv("MVSDF_SPLIT_ROWS");
         st->split_rows = (e && *e) ? (atoi(e) != 0 && E >= 1) : mv_chain_split_pays(&sdf, E, M);
         if (st->split_rows) {
-            if (hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st->side = nullptr; st->split_rows = 0; }
+            // lowest priority: the samples fill what the tracer leaves idle, they must not take CUs from its latency chains
+            int prio_least = 0, prio_greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_least = 0; }
+            if (hipStreamCreateWithPriority(&st->side, hipStreamNonBlocking, prio_least) != hipSuccess) { (void)hipGetLastError(); st->side = nullptr; st->split_rows = 0; }
             else if (hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming) != hipSuccess ||
                      hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming) != hipSuccess)
                 return mv_fail(-1, "mvsdf_step_forward: hipEventCreate failed");
         }
     }
     bool split = st->split_rows == 1;
-    if (split) {
-        ST_HIP(hipEventRecord(st->ev_fork, s));
-        ST_HIP(hipStreamWaitEvent(st->side, st->ev_fork, 0));
-        const int rcs = mv_sdf_forward_gather(&sdf, &sdfT, nullptr, &g, M, M, 0, E, y_eval, n_eval, (float*)(fwd + fo.sdf_ctx), st->side);
-        if (rcs == 1) split = false;                              // per-layer route: nothing was launched, one pass over all rows below
-        else if (rcs) return rcs;
-        else ST_HIP(hipEventRecord(st->ev_join, st->side));
-    }
+    if (split) ST_HIP(hipEventRecord(st->ev_fork, s));             // (the folded weights are ready here)
     // 2. rays + RayTracing.forward (idr.py:190-199)
     float* points = (float*)(fwd + L.points); uint8_t* mask = (uint8_t*)(fwd + L.mask); float* dists = (float*)(fwd + L.dists);
     unsigned long long* counters = (unsigned long long*)(fwd + L.counters);
@@ -306,6 +302,13 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     ST_TRY(mv_trace_stage1_prezeroed(&sdf, &d.tp, cam_loc, ray_dirs, in->object_mask, d.B, d.P, 1, in->intervals, in->minsdf_steps, points, mask, dists,
                                      counters, fwd + fo.trace_ws, fo.trace_ws_bytes, d.mt, d.mt_samples, stream));   // counters zeroed by the prologue
     if (st->timing) ST_HIP(hipEventRecord(st->ev_t[1], s));
+    if (split) {                                                  // enqueued AFTER the sphere tracer: its workgroups take the CUs first
+        ST_HIP(hipStreamWaitEvent(st->side, st->ev_fork, 0));
+        const int rcs = mv_sdf_forward_gather(&sdf, &sdfT, nullptr, &g, M, M, 0, E, y_eval, n_eval, (float*)(fwd + fo.sdf_ctx), st->side);
+        if (rcs == 1) split = false;                              // per-layer route: nothing was launched, one pass over all rows below
+        else if (rcs) return rcs;
+        else ST_HIP(hipEventRecord(st->ev_join, st->side));
+    }
     ST_TRY(stage(3));                                             // the hit mask is final here (ray_tracing.py:61)
     if (st->timing) ST_HIP(hipEventRecord(st->ev_t[2], s));
     // 3. stable partition (hit rays first) + both counts; they start travelling to the host while the rest of the forward runs
