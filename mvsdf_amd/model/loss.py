@@ -21,6 +21,9 @@ if os.environ.get('IDR_USE_ENV', '0') == '1' and os.environ.get('IDR_CONF', '') 
     conf = importlib.import_module(os.environ.get('IDR_CONF'))
 
 
+_COUNT_STREAMS = {}                                              # per device: the stream of the data-parallel count all-reduce (IDRLoss.forward)
+
+
 class IDRLoss(nn.Module):
     def __init__(self):
         super().__init__()
@@ -30,6 +33,13 @@ class IDRLoss(nn.Module):
         # forward / backward as ONE C call each (mvsdf_loss_forward / mvsdf_loss_backward) instead of four calls + two autograd nodes
         self.native = os.environ.get('MVSDF_NATIVE_STEP', '1') != '0'
         self.collective_events = None                            # set to a list: (start, end) CUDA events around the 3-count all-reduce are appended (bench.py)
+
+    @staticmethod
+    def _count_stream(dev):
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        if key not in _COUNT_STREAMS:
+            _COUNT_STREAMS[key] = torch.cuda.Stream(device=dev)
+        return _COUNT_STREAMS[key]
 
     def get_rgb_loss(self, rgb_values, rgb_gt, network_object_mask, object_mask):
         mask = network_object_mask & object_mask                                   # loss.py:21-28; a zero-hit batch gives 0 either way
@@ -106,17 +116,34 @@ class IDRLoss(nn.Module):
         # the GLOBAL counts so that the rank-averaged gradient equals the single-process one -- one extra all-reduce of 3 numbers.
         inv_counts = None
         if self.exact_data_parallel and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            cnt = torch.tensor([float(model_outputs['grad_theta'].shape[0]), float(model_outputs['eikonal_output'].numel()),
-                                float(model_outputs['surf_indicator_output'].numel())], device=dev)
-            ev = None
-            if self.collective_events is not None and cnt.is_cuda:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-            if ev is not None:
-                ev[1].record()
-                self.collective_events.append(ev)
-            inv_counts = float(dist.get_world_size()) / cnt.clamp(min=1.0)
+            cnt_host = [float(model_outputs['grad_theta'].shape[0]), float(model_outputs['eikonal_output'].numel()),
+                        float(model_outputs['surf_indicator_output'].numel())]
+            world = float(dist.get_world_size())
+            if dev.type == 'cuda':
+                # The counts are host numbers (shapes) while the GPU still has the end of the forward queued (the host ran ahead after the
+                # step's one wait): the collective goes on a side stream, i.e. beside that work instead of behind it, and the loss kernels
+                # wait for it by an event.  (The collective library orders itself against the CURRENT stream only.)
+                main = torch.cuda.current_stream(dev)
+                side = self._count_stream(dev)
+                with torch.cuda.stream(side):
+                    cnt = torch.tensor(cnt_host, device=dev)
+                    ev = None
+                    if self.collective_events is not None:
+                        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                        ev[0].record(side)
+                    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+                    if ev is not None:
+                        ev[1].record(side)
+                        self.collective_events.append(ev)
+                    inv_counts = world / cnt.clamp(min=1.0)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                main.wait_event(done)
+                inv_counts.record_stream(main)                     # allocated on the side stream, read by the loss kernels on `main`
+            else:
+                cnt = torch.tensor(cnt_host, device=dev)
+                dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+                inv_counts = world / cnt.clamp(min=1.0)
         if self.native:
             out = self._forward_native(model_outputs, ground_truth, rgb_gt, train_progress, weights, bool(phase1), feat_on, inv_counts)
             if out is not None:
