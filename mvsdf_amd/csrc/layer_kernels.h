@@ -456,7 +456,14 @@ __global__ void k_reduce_net(WgradNetArgs a) {
             const unsigned j = k - L.woff;
             const size_t nk = (size_t)L.No * L.Ki;
             const float* sp = L.slab + j;
-            for (int c = 0; c < L.nchunks; ++c) v += sp[(size_t)c * nk];
+            const int nch = L.nchunks;
+            for (int c = 0; c < nch; c += 8) {                    // eight slabs requested at once (clamped), added in slab order
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = sp[(size_t)(c + u < nch ? c + u : nch - 1) * nk];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (c + u < nch) v += t[u];
+            }
             if (a.colslab && l == a.col_layer && j < (unsigned)a.col_n)
                 for (int c = 0; c < a.col_nchunks; ++c) v += a.colslab[(size_t)c * a.col_n + j];
             L.dW[j] = v;
