@@ -645,13 +645,24 @@ __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
                 const float gj = a.f.g[l][j];
 #pragma unroll
                 for (int c = 0; c < 9; ++c) { const int k = 64 * c + lane; const float x = vr[k < K ? k : K - 1]; mine[c] = k < K ? x : 0.0f; }
+                // the k-ascending fmaf chain of orc_fold, bit for bit.  Full 64-blocks are unrolled with constant lane numbers: the v_readlane of the
+                // elements ahead are independent of the chain and get issued early, so a step costs the fma's latency and not the
+                // readlane -> SGPR -> VALU round trip of a rolled loop (which made this chain ~10 us of the launch's 18)
                 float ss = 0.0f;
 #pragma unroll
                 for (int c = 0; c < 9; ++c) {
-                    const int n = min(64, K - 64 * c);
-                    for (int i = 0; i < n; ++i) {
-                        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine[c]), i));
-                        ss = fmaf(x, x, ss);
+                    if (64 * (c + 1) <= K) {
+#pragma unroll
+                        for (int i = 0; i < 64; ++i) {
+                            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine[c]), i));
+                            ss = fmaf(x, x, ss);
+                        }
+                    } else if (64 * c < K) {
+                        const int n = K - 64 * c;
+                        for (int i = 0; i < n; ++i) {
+                            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine[c]), i));
+                            ss = fmaf(x, x, ss);
+                        }
                     }
                 }
                 const float sc = gj / sqrtf(ss);
