@@ -10,6 +10,7 @@
 #include <new>
 #include "capi_util.h"
 #include "step_internal.h"
+#include <sched.h>
 
 namespace {
 
@@ -33,10 +34,12 @@ struct Step {
     int R, E, M, Nout, K0r, nl;                      // rays, sample rows, evaluation rows, SDF output width, rendering-net input width, layers in total
     size_t woff[MVSDF_STEP_MAX_LAYERS], boff[MVSDF_STEP_MAX_LAYERS];   // float offsets inside dflat: [W | b of the SDF net | W | b of the rendering net]
     size_t seg[2][3];                                // per network: first weight, first bias, end
-    long long* counts_host;                          // pinned, host-mapped [4]
-    long long* counts_host_dev;                      // its device address (nullptr: not mapped, the counts travel by a copy)
+    long long* counts_host;                          // pinned, host-mapped [5]: the 4 counts + the sequence number of the forward that wrote them
+    long long* counts_host_dev;                      // its device address (nullptr: not mapped, the counts travel by a copy + ev_counts)
     hipEvent_t ev_counts;
     bool counts_pending;
+    long long counts_seq;                            // forwards so far: the number the host waits for in counts_host[4]
+    hipStream_t counts_stream;                       // the stream of the forward in flight (queried if the number does not arrive)
     int timing;
     hipEvent_t ev_t[5];
     bool timed;
@@ -240,7 +243,8 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
         return mv_fail(-1, "mvsdf_step_forward: missing input");
     hipStream_t s = (hipStream_t)stream;
     if (!st->counts_host) {                                       // first forward: host-side staging for the hit counts
-        ST_HIP(hipHostMalloc((void**)&st->counts_host, 4 * sizeof(long long), hipHostMallocMapped));
+        ST_HIP(hipHostMalloc((void**)&st->counts_host, 5 * sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
+        st->counts_host[4] = 0;
         // the partition kernel writes the counts straight into this buffer (no D2H copy node between two kernels)
         if (hipHostGetDevicePointer((void**)&st->counts_host_dev, st->counts_host, 0) != hipSuccess) { (void)hipGetLastError(); st->counts_host_dev = nullptr; }
         if (hipEventCreateWithFlags(&st->ev_counts, hipEventDisableTiming) != hipSuccess) {
@@ -315,10 +319,12 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     long long* perm = (long long*)(fwd + L.perm); long long* inv = (long long*)(fwd + fo.inv); long long* true_rows = (long long*)(fwd + fo.true_rows);
     long long* counts = (long long*)(fwd + fo.counts); float* view_sorted = (float*)(fwd + fo.view_sorted);
     ST_TRY(mv_partition_rays_step(mask, d.use_object_mask ? in->object_mask : nullptr, in->object_mask_true, ray_dirs, R, perm, inv, true_rows, counts,
-                                  view_sorted, (int*)(fwd + fo.true_rank), d.n_ds > 0 ? in->ds_counts : nullptr, st->counts_host_dev, stream));
-    if (!st->counts_host_dev) ST_HIP(hipMemcpyAsync(st->counts_host, counts, 4 * sizeof(long long), hipMemcpyDeviceToHost, s));   // (pinned memory not mapped)
-    ST_HIP(hipEventRecord(st->ev_counts, s));
-    st->counts_pending = true;
+                                  view_sorted, (int*)(fwd + fo.true_rank), d.n_ds > 0 ? in->ds_counts : nullptr, st->counts_host_dev, ++st->counts_seq, stream));
+    if (!st->counts_host_dev) {                                   // (pinned memory not mapped: a copy and an event)
+        ST_HIP(hipMemcpyAsync(st->counts_host, counts, 4 * sizeof(long long), hipMemcpyDeviceToHost, s));
+        ST_HIP(hipEventRecord(st->ev_counts, s));
+    }
+    st->counts_pending = true; st->counts_stream = s;
     if (st->timing) ST_HIP(hipEventRecord(st->ev_t[3], s));
     ST_TRY(stage(4));                                             // secant + min-sdf rows: only points / dists still move
     if (st->timing) { ST_HIP(hipEventRecord(st->ev_t[4], s)); st->timed = true; }
@@ -349,7 +355,29 @@ int mvsdf_step_wait_counts(void* step, long long counts[4]) {
     Step* st = (Step*)step;
     if (!st || !counts) return mv_fail(-1, "mvsdf_step_wait_counts: null argument");
     if (!st->counts_pending) return mv_fail(-1, "mvsdf_step_wait_counts: no forward is in flight");
-    ST_HIP(hipEventSynchronize(st->ev_counts));
+    if (!st->counts_host_dev) {
+        ST_HIP(hipEventSynchronize(st->ev_counts));
+    } else {
+        // the partition kernel stores this forward's sequence number behind the counts (release, system scope): poll it.  Should it never arrive
+        // (the stream drained or failed without the kernel having run), the stream's status ends the wait.
+        const long long want = st->counts_seq;
+        for (unsigned long long it = 1; __atomic_load_n(&st->counts_host[4], __ATOMIC_ACQUIRE) != want; ++it) {
+            if ((it & 0x3ff) == 0) {
+                sched_yield();
+                if ((it & 0xfffff) == 0) {
+                    const hipError_t q = hipStreamQuery(st->counts_stream);
+                    if (q == hipSuccess) {
+                        if (__atomic_load_n(&st->counts_host[4], __ATOMIC_ACQUIRE) == want) break;
+                        st->counts_pending = false;
+                        return mv_fail(-1, "mvsdf_step_wait_counts: the forward finished without delivering its counts");
+                    }
+                    if (q != hipErrorNotReady) { st->counts_pending = false; return mv_check(q, "mvsdf_step_wait_counts (hipStreamQuery)"); }
+                }
+            } else {
+                __builtin_ia32_pause();
+            }
+        }
+    }
     for (int i = 0; i < 4; ++i) counts[i] = st->counts_host[i];
     st->counts_pending = false;
     return 0;

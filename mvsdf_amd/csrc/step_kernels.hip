@@ -18,7 +18,8 @@ __global__ __launch_bounds__(1024) void k_partition_rays(const uint8_t* __restri
                                                          long long* __restrict__ perm, long long* __restrict__ inv,
                                                          long long* __restrict__ true_rows, long long* __restrict__ counts,
                                                          float* __restrict__ view_sorted, int* __restrict__ true_rank,
-                                                         const long long* __restrict__ extra_counts, long long* __restrict__ counts_host) {
+                                                         const long long* __restrict__ extra_counts, long long* __restrict__ counts_host,
+                                                         long long counts_seq) {
     __shared__ int wsum[3][16];
     __shared__ int base[3];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -62,10 +63,12 @@ __global__ __launch_bounds__(1024) void k_partition_rays(const uint8_t* __restri
     if (tid == 0) { counts[0] = base[0]; counts[1] = base[2]; }
     if (true_rank && tid < 2) counts[2 + tid] = extra_counts ? extra_counts[tid] : 0;      // (the step driver's 4-entry count record)
     // the same record straight into host-mapped pinned memory (the step driver: no copy node -- a D2H copy between two kernels costs its 4 us plus a
-    // ~10 us bubble before the next kernel starts); visible to the host once the event recorded behind this kernel has completed
-    if (counts_host) {
-        if (tid == 0) { counts_host[0] = base[0]; counts_host[1] = base[2]; }
-        if (tid < 2) counts_host[2 + tid] = extra_counts ? extra_counts[tid] : 0;
+    // ~10 us bubble before the next kernel starts -- and no event either: an event record behind this kernel is a ~6 us bubble of its own).  The host
+    // polls entry 4: the forward's sequence number, stored with system-scope release AFTER the four counts.
+    if (counts_host && tid == 0) {
+        counts_host[0] = base[0]; counts_host[1] = base[2];
+        counts_host[2] = extra_counts ? extra_counts[0] : 0; counts_host[3] = extra_counts ? extra_counts[1] : 0;
+        __hip_atomic_store(&counts_host[4], counts_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -300,7 +303,7 @@ int mvsdf_partition_rays(const uint8_t* net_mask, const uint8_t* object_mask, co
     if (!net_mask || !perm || !inv || !true_rows || !counts || R <= 0 || (view_sorted && !ray_dirs))
         return mv_fail(-1, "mvsdf_partition_rays: bad arguments");
     hipLaunchKernelGGL(k_partition_rays, dim3(1), dim3(1024), 0, (hipStream_t)stream, net_mask, object_mask, true_mask, ray_dirs, R, perm, inv,
-                       true_rows, counts, view_sorted, (int*)nullptr, (const long long*)nullptr, (long long*)nullptr);
+                       true_rows, counts, view_sorted, (int*)nullptr, (const long long*)nullptr, (long long*)nullptr, 0ll);
     return mv_check(hipGetLastError(), "mvsdf_partition_rays");
 }
 
@@ -367,10 +370,10 @@ int mvsdf_step_backward_fbar(int n_eik, int n_ds, int N, int Nout, const float* 
 // depth-surface sample counts travelling to the host with the hit counts)
 int mv_partition_rays_step(const uint8_t* net_mask, const uint8_t* object_mask, const uint8_t* true_mask, const float* ray_dirs, int R, long long* perm,
                            long long* inv, long long* true_rows, long long* counts, float* view_sorted, int* true_rank, const long long* extra_counts,
-                           long long* counts_host, void* stream) {
+                           long long* counts_host, long long counts_seq, void* stream) {
     if (!net_mask || !perm || !inv || !true_rows || !counts || !true_rank || R <= 0 || (view_sorted && !ray_dirs))
         return mv_fail(-1, "mv_partition_rays_step: bad arguments");
     hipLaunchKernelGGL(k_partition_rays, dim3(1), dim3(1024), 0, (hipStream_t)stream, net_mask, object_mask, true_mask, ray_dirs, R, perm, inv,
-                       true_rows, counts, view_sorted, true_rank, extra_counts, counts_host);
+                       true_rows, counts, view_sorted, true_rank, extra_counts, counts_host, counts_seq);
     return mv_check(hipGetLastError(), "mv_partition_rays_step");
 }
