@@ -368,6 +368,11 @@ typedef struct {
     const float* eik_points;               /* [n_eik][3] uniform draws in the eikonal box (idr.py:216-221) */
     const float* ds_on; const float* ds_jit;  /* [n_ds][3] each (mvsdf_dsurf_points), NULL when n_ds == 0 */
     const long long* ds_counts;            /* [2] device: samples found per set (mvsdf_dsurf_select), NULL when n_ds == 0 */
+    const float* host_stage;               /* optional: PINNED host memory (hipHostMalloc / a torch pinned tensor) holding [minsdf_steps | eik_points]
+                                            * = tp.n_steps + 3 n_eik floats.  When given, minsdf_steps / eik_points are uninitialised device buffers and
+                                            * the forward's first kernel fills them from here (no copy node, and no copy-to-kernel bubble, in front of
+                                            * the step); the host may rewrite the memory once mvsdf_step_wait_counts has returned.  NULL: the two
+                                            * device buffers already hold the draws. */
 } MvsdfStepInputs;
 
 typedef struct {

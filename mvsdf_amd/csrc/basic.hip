@@ -590,6 +590,7 @@ struct ProloArgs {
     const float* uv; const float* pose; const float* Kin; int B, P; float* dirs; float* cam_loc;
     uint8_t* ones;                       // optional [B * P]: filled with 1 (the all-ones object mask of the output dict, idr.py:187)
     unsigned long long* counters;        // optional [16]: zeroed (the tracer's device counters: saves its memset node)
+    const float* stage_src; float* stage_a; float* stage_b; int stage_na, stage_nb;   // optional: pinned host memory [na | nb] -> two device buffers
     int ld;                              // LDS row stride (floats) >= max K
 };
 __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
@@ -599,6 +600,13 @@ __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
     if ((int)blockIdx.x >= a.blk0[nl]) {                                       // ---- camera rays
         const int idx = ((int)blockIdx.x - a.blk0[nl]) * 1024 + tid;
         if (a.counters && idx < 16) a.counters[idx] = 0ull;
+        if (a.stage_src) {                                                      // the step's CPU-generator draws, read straight from pinned host memory
+            const int nthr = ((int)gridDim.x - a.blk0[nl]) * 1024, ntot = a.stage_na + a.stage_nb;
+            for (int i = idx; i < ntot; i += nthr) {
+                const float x = a.stage_src[i];
+                if (i < a.stage_na) a.stage_a[i] = x; else a.stage_b[i - a.stage_na] = x;
+            }
+        }
         if (idx >= a.B * a.P) return;
         if (a.ones) a.ones[idx] = 1;
         const int b = idx / a.P;
@@ -726,7 +734,8 @@ __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
 
 int mv_step_prologue(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w, float* const* wp,
                      float* const* wpT, void* const* wp16, const int* nsplit, int wp16_fp32, const float* uv, const float* pose, const float* intrinsics, int B, int P,
-                     float* ray_dirs, float* cam_loc, uint8_t* ones, unsigned long long* counters, void* stream) {
+                     float* ray_dirs, float* cam_loc, uint8_t* ones, unsigned long long* counters, const float* stage_src, float* stage_a, int stage_na,
+                     float* stage_b, int stage_nb, void* stream) {
     ProloArgs a;
     int maxN; size_t maxTot;
     int rc = fill_fold_args(a.f, n_layers, N, K, &maxN, &maxTot);
@@ -745,6 +754,8 @@ int mv_step_prologue(int n_layers, const float* const* v, const float* const* g,
     a.uv = uv; a.pose = pose; a.Kin = intrinsics; a.B = B; a.P = P; a.dirs = ray_dirs; a.cam_loc = cam_loc;
     a.wp16_fp32 = wp16_fp32 ? 1 : 0;
     a.ones = ones; a.counters = counters;
+    a.stage_src = stage_src; a.stage_a = stage_a; a.stage_b = stage_b; a.stage_na = stage_src ? stage_na : 0; a.stage_nb = stage_src ? stage_nb : 0;
+    if (stage_src && (!stage_a || !stage_b || stage_na < 0 || stage_nb < 0)) return mv_fail(-1, "mv_step_prologue: staged inputs without targets");
     a.ld = ((maxK + 3) & ~3) + 4;
     const size_t lds = (size_t)16 * a.ld * sizeof(float);
     blk += (B * P + 1023) / 1024;

@@ -268,8 +268,17 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
             nsplit[l] = (bf && d.trace_dtype == 1 && (l == 0 || ((d.skip_mask >> l) & 1u))) ? 3 + 6 * d.multires : 0;
         }
         // ... and the camera rays (idr.py:190), all in one launch
+        // the CPU-generator draws (min-sdf steps, eikonal points) may arrive in pinned host memory: the prologue reads them from there
+        const float* stage_dev = nullptr;
+        if (in->host_stage) {
+            if (hipHostGetDevicePointer((void**)&stage_dev, (void*)in->host_stage, 0) != hipSuccess || !stage_dev) {
+                (void)hipGetLastError();
+                return mv_fail(-1, "mvsdf_step_forward: host_stage is not device-visible pinned memory");
+            }
+        }
         ST_TRY(mv_step_prologue(nl, prm->v, prm->g, d.N, d.K, w, wp, wpT, wp16, nsplit, d.trace_dtype == 2 ? 1 : 0, in->uv, in->pose, in->intrinsics, d.B, d.P, ray_dirs, cam_loc,
-                                (uint8_t*)(fwd + L.object_mask_out), (unsigned long long*)(fwd + L.counters), stream));
+                                (uint8_t*)(fwd + L.object_mask_out), (unsigned long long*)(fwd + L.counters), stage_dev, (float*)in->minsdf_steps, d.tp.n_steps,
+                                (float*)in->eik_points, 3 * d.n_eik, stream));
     }
     MvsdfNetDesc sdf, sdfT, rnd, rndT;
     make_descs(*st, prm, fwd, &sdf, &sdfT, &rnd, &rndT);

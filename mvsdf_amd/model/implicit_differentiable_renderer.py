@@ -531,11 +531,17 @@ class IDRNetwork(nn.Module):
         bb = self.object_bounding_sphere
         n_eik = R // 2
         if isinstance(self._draw, PinnedUniform) and isinstance(rt._draw, PinnedUniform):
-            minsdf_steps, eik = self._draw.pair((rt.n_steps,), 0.0, 1.0, (n_eik, 3), -bb, bb, dev)       # one staging buffer, one async copy
+            # one pinned staging buffer, NO copy: the step's first kernel reads it (MvsdfStepInputs.host_stage)
+            # (MVSDF_HOST_STAGE=0: one async copy in front of the step instead -- dev A/B)
+            if os.environ.get('MVSDF_HOST_STAGE', '1') != '0':
+                minsdf_steps, eik, stage = self._draw.pair((rt.n_steps,), 0.0, 1.0, (n_eik, 3), -bb, bb, dev, defer=True)
+            else:
+                (minsdf_steps, eik), stage = self._draw.pair((rt.n_steps,), 0.0, 1.0, (n_eik, 3), -bb, bb, dev), None
         else:                                                    # (someone replaced a draw hook: the two separate draws of the Python route)
             minsdf_steps = rt._draw((rt.n_steps,), 0.0, 1.0, dev)
             eik = self._draw((n_eik, 3), -bb, bb, dev)
             minsdf_steps, eik = minsdf_steps.float().contiguous(), eik.float().contiguous()
+            stage = None
         true_u8 = object_mask_true if object_mask_true.dtype == torch.uint8 else (
             object_mask_true.view(torch.uint8) if object_mask_true.dtype == torch.bool else object_mask_true.to(torch.uint8))
         if not true_u8.is_contiguous():
@@ -554,6 +560,7 @@ class IDRNetwork(nn.Module):
         i.uv, i.pose, i.intrinsics = uv_c.data_ptr(), pose_c.data_ptr(), intr_c.data_ptr()
         i.object_mask, i.object_mask_true = om_u8.data_ptr(), true_u8.data_ptr()
         i.intervals, i.minsdf_steps, i.eik_points = iv.data_ptr(), minsdf_steps.data_ptr(), eik.data_ptr()
+        i.host_stage = stage.data_ptr() if stage is not None else None
         if dsurf is not None:
             i.ds_on, i.ds_jit, i.ds_counts = dsurf[0].data_ptr(), dsurf[1].data_ptr(), dsurf[2].data_ptr()
         else:

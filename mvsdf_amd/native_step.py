@@ -29,7 +29,7 @@ class StepParams(C.Structure):
 
 class StepInputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('uv', 'pose', 'intrinsics', 'object_mask', 'object_mask_true', 'intervals', 'minsdf_steps', 'eik_points',
-                                          'ds_on', 'ds_jit', 'ds_counts')]
+                                          'ds_on', 'ds_jit', 'ds_counts', 'host_stage')]
 
 
 class StepLayout(C.Structure):

@@ -54,8 +54,11 @@ class PinnedUniform:
             slot[1].record()
         return out
 
-    def pair(self, shape_a, lo_a, hi_a, shape_b, lo_b, hi_b, device):
-        """Two consecutive draws (a, then b: the same values as two separate calls) staged in ONE pinned buffer and delivered by ONE async copy."""
+    def pair(self, shape_a, lo_a, hi_a, shape_b, lo_b, hi_b, device, defer=False):
+        """Two consecutive draws (a, then b: the same values as two separate calls) staged in ONE pinned buffer and delivered by ONE async copy.
+        defer=True: no copy at all -- returns (a, b, staging) with a / b UNINITIALISED device tensors (views of one buffer) and the pinned staging
+        tensor; the consumer fills a / b from it on the device (the native step's first kernel reads the pinned memory directly) and must have
+        done so before the next-but-one draw (two staging buffers alternate; the native step's host wait per forward guarantees it)."""
         shape_a, shape_b = tuple(shape_a), tuple(shape_b)
         na, nb = 1, 1
         for v in shape_a:
@@ -72,8 +75,14 @@ class PinnedUniform:
             ev.synchronize()
         buf[:na].uniform_(lo_a, hi_a)
         buf[na:].uniform_(lo_b, hi_b)
+        if defer and torch.device(device).type == 'cuda':
+            slot[1] = None
+            out = torch.empty(na + nb, dtype=buf.dtype, device=device)
+            return out[:na].view(shape_a), out[na:].view(shape_b), buf
         out = buf.to(device, non_blocking=True)
         if out.is_cuda:
             slot[1] = torch.cuda.Event()
             slot[1].record()
+        if defer:
+            return out[:na].view(shape_a), out[na:].view(shape_b), None
         return out[:na].view(shape_a), out[na:].view(shape_b)
