@@ -462,79 +462,111 @@ __device__ __forceinline__ int mv_first_argmin(const float* __restrict__ sv, int
     return bi == 0x7fffffff ? 0 : bi;                           // nothing below +inf: the serial scan keeps index 0
 }
 
-__global__ __launch_bounds__(64) void k_reduce_items(MvTraceParams tp, SampleCtx c, const int* __restrict__ list, const int* __restrict__ src,
-                                                     int cnt_index, int mode) {
+// Sixteen waves (= sixteen listed rays) per workgroup: the appends to the rest / secant lists are ONE atomic per list and workgroup, the waves take
+// consecutive slots behind it (a wave per workgroup and an atomic per ray serialised ~1000 same-address atomics at the c5 share: 21 us of a launch
+// that otherwise takes 5).  The order of a list's entries was arrival order before and is arbitrary still: every consumer works per ray.
+#define MV_RED_WAVES 16
+__global__ __launch_bounds__(64 * MV_RED_WAVES) void k_reduce_items(MvTraceParams tp, SampleCtx c, const int* __restrict__ list, const int* __restrict__ src,
+                                                                  int cnt_index, int mode) {
+    __shared__ int s_cat[MV_RED_WAVES];
+    __shared__ unsigned long long s_base[2];
     const int n_list = (int)c.counters[cnt_index];
-    const int it = blockIdx.x, lane = threadIdx.x;
-    if (it >= n_list) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int it = blockIdx.x * MV_RED_WAVES + w;
+    if (blockIdx.x * MV_RED_WAVES >= n_list) return;               // workgroup-uniform
+    const bool active = it < n_list, lead = lane == 0;
     const int n_steps = tp.n_steps;
-    const int e = list[it];
-    const int gid = e & 0x0fffffff, kind = e >> 28;
-    const bool om = kind & MV_ITEM_OM;
-    const float* cc = c.cam_loc + 3 * (gid / c.P);
-    const float* d = c.dirs + 3 * (size_t)gid;
-    const float zmin = c.w_zmin[gid], zmax = c.w_zmax[gid];
-    const int row = src ? src[it] : it;
-    const float* sv = c.sv + (size_t)row * n_steps;
-    const bool lead = lane == 0;
-    float dist;
-    if (mode == 0 && c.n_first < n_steps) {
-        if (it == 0 && lead) {
-            atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER], (unsigned long long)n_list * (unsigned long long)n_steps);
-            atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER_EVAL], (unsigned long long)n_list * (unsigned long long)c.n_first);
-        }
-        const int ind = mv_first_where(sv, c.n_first, lane, 0);
-        if (!lead) return;
-        if (!(om && ind >= 1)) {                                                   // open: needs the other samples (ind == 0 wraps to the last one)
-            const unsigned long long k = atomicAdd(&c.counters[MV_CNT_N_SAMPLER_REST], 1ull);
-            c.list_rest[k] = e; c.src_rest[k] = it;
-            return;
-        }
-        dist = zmin + c.intervals[ind] * (zmax - zmin);
-        c.o_mask[gid] = 1;
-        const unsigned long long k = atomicAdd(&c.counters[MV_CNT_N_SECANT], 1ull);
-        c.sec_list[k] = gid;
-        c.sec_state[gid] = zmin + c.intervals[ind - 1] * (zmax - zmin);
-        c.sec_state[(size_t)c.R + gid] = dist;
-        c.sec_state[2 * (size_t)c.R + gid] = sv[ind - 1];
-        c.sec_state[3 * (size_t)c.R + gid] = sv[ind];
-    } else if (mode <= 1) {
-        if (it == 0 && lead) {
-            if (mode == 0) {
+    int cat = 0;                                                  // 1: append (e, it) to the rest list; 2: append gid to the secant list
+    int e = 0, gid = 0;
+    bool have_dist = false;
+    float dist = 0.f;
+    const float* cc = nullptr; const float* d = nullptr;
+    if (active) {
+        e = list[it];
+        gid = e & 0x0fffffff;
+        const int kind = e >> 28;
+        const bool om = kind & MV_ITEM_OM;
+        cc = c.cam_loc + 3 * (gid / c.P);
+        d = c.dirs + 3 * (size_t)gid;
+        const float zmin = c.w_zmin[gid], zmax = c.w_zmax[gid];
+        const int row = src ? src[it] : it;
+        const float* sv = c.sv + (size_t)row * n_steps;
+        if (mode == 0 && c.n_first < n_steps) {
+            if (it == 0 && lead) {
                 atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER], (unsigned long long)n_list * (unsigned long long)n_steps);
-                atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER_EVAL], (unsigned long long)n_list * (unsigned long long)n_steps);
-            } else
-                atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER_EVAL], (unsigned long long)n_list * (unsigned long long)(n_steps - c.n_first));
+                atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER_EVAL], (unsigned long long)n_list * (unsigned long long)c.n_first);
+            }
+            const int ind = mv_first_where(sv, c.n_first, lane, 0);
+            if (!(om && ind >= 1)) {                                                   // open: needs the other samples (ind == 0 wraps to the last one)
+                cat = 1;
+            } else if (lead) {
+                dist = zmin + c.intervals[ind] * (zmax - zmin);
+                have_dist = true;
+                c.o_mask[gid] = 1;
+                cat = 2;
+                c.sec_state[gid] = zmin + c.intervals[ind - 1] * (zmax - zmin);
+                c.sec_state[(size_t)c.R + gid] = dist;
+                c.sec_state[2 * (size_t)c.R + gid] = sv[ind - 1];
+                c.sec_state[3 * (size_t)c.R + gid] = sv[ind];
+            }
+        } else if (mode <= 1) {
+            if (it == 0 && lead) {
+                if (mode == 0) {
+                    atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER], (unsigned long long)n_list * (unsigned long long)n_steps);
+                    atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER_EVAL], (unsigned long long)n_list * (unsigned long long)n_steps);
+                } else
+                    atomicAdd(&c.counters[MV_CNT_ROWS_SAMPLER_EVAL], (unsigned long long)n_list * (unsigned long long)(n_steps - c.n_first));
+            }
+            // argmin(sign(sdf) * [n..1]) (ray_tracing.py:221-222), first minimum: the first negative sample, else the first exact zero, else the last
+            int ind = mv_first_where(sv, n_steps, lane, 0);
+            if (ind < 0) ind = mv_first_where(sv, n_steps, lane, 1);
+            if (ind < 0) ind = n_steps - 1;
+            const bool net_surf = sv[ind] < 0.f;
+            const int i2 = (om && net_surf) ? 0 : mv_first_argmin(sv, n_steps, lane);   // P_out: argmin sdf, ray_tracing.py:229-235
+            if (lead) {
+                dist = zmin + c.intervals[(om && net_surf) ? ind : i2] * (zmax - zmin);
+                have_dist = true;
+                c.o_mask[gid] = net_surf ? 1 : 0;                                      // ray_tracing.py:237-239, 61
+                const bool do_secant = c.training ? (net_surf && om) : net_surf;       // ray_tracing.py:242
+                if (do_secant) {
+                    int lo = ind - 1; if (lo < 0) lo += n_steps;                      // negative index wraps
+                    cat = 2;
+                    c.sec_state[gid] = zmin + c.intervals[lo] * (zmax - zmin);
+                    c.sec_state[(size_t)c.R + gid] = zmin + c.intervals[ind] * (zmax - zmin);
+                    c.sec_state[2 * (size_t)c.R + gid] = sv[lo];
+                    c.sec_state[3 * (size_t)c.R + gid] = sv[ind];
+                }
+            }
+        } else {
+            if (it == 0 && lead) atomicAdd(&c.counters[MV_CNT_ROWS_MINSDF], (unsigned long long)n_list * (unsigned long long)n_steps);
+            const int bi = mv_first_argmin(sv, n_steps, lane);                         // min over the shared random steps
+            if (lead) { dist = c.steps[bi] * (zmax - zmin) + zmin; have_dist = true; }
         }
-        // argmin(sign(sdf) * [n..1]) (ray_tracing.py:221-222), first minimum: the first negative sample, else the first exact zero, else the last
-        int ind = mv_first_where(sv, n_steps, lane, 0);
-        if (ind < 0) ind = mv_first_where(sv, n_steps, lane, 1);
-        if (ind < 0) ind = n_steps - 1;
-        const bool net_surf = sv[ind] < 0.f;
-        const int i2 = (om && net_surf) ? 0 : mv_first_argmin(sv, n_steps, lane);   // P_out: argmin sdf, ray_tracing.py:229-235
-        if (!lead) return;
-        dist = zmin + c.intervals[(om && net_surf) ? ind : i2] * (zmax - zmin);
-        c.o_mask[gid] = net_surf ? 1 : 0;                                          // ray_tracing.py:237-239, 61
-        const bool do_secant = c.training ? (net_surf && om) : net_surf;           // ray_tracing.py:242
-        if (do_secant) {
-            int lo = ind - 1; if (lo < 0) lo += n_steps;                          // negative index wraps
-            const unsigned long long k = atomicAdd(&c.counters[MV_CNT_N_SECANT], 1ull);
-            c.sec_list[k] = gid;
-            c.sec_state[gid] = zmin + c.intervals[lo] * (zmax - zmin);
-            c.sec_state[(size_t)c.R + gid] = zmin + c.intervals[ind] * (zmax - zmin);
-            c.sec_state[2 * (size_t)c.R + gid] = sv[lo];
-            c.sec_state[3 * (size_t)c.R + gid] = sv[ind];
+        if (lead && have_dist) {
+            c.o_dists[gid] = dist;                                                     // secant rays are overwritten by the secant stage
+            c.o_points[3 * (size_t)gid + 0] = cc[0] + dist * d[0];
+            c.o_points[3 * (size_t)gid + 1] = cc[1] + dist * d[1];
+            c.o_points[3 * (size_t)gid + 2] = cc[2] + dist * d[2];
         }
-    } else {
-        if (it == 0 && lead) atomicAdd(&c.counters[MV_CNT_ROWS_MINSDF], (unsigned long long)n_list * (unsigned long long)n_steps);
-        const int bi = mv_first_argmin(sv, n_steps, lane);                         // min over the shared random steps
-        if (!lead) return;
-        dist = c.steps[bi] * (zmax - zmin) + zmin;
     }
-    c.o_dists[gid] = dist;                                                         // secant rays are overwritten by the secant stage
-    c.o_points[3 * (size_t)gid + 0] = cc[0] + dist * d[0];
-    c.o_points[3 * (size_t)gid + 1] = cc[1] + dist * d[1];
-    c.o_points[3 * (size_t)gid + 2] = cc[2] + dist * d[2];
+    if (mode == 2) return;                                        // no lists behind the min-sdf rays
+    // ---- the appends: one atomic per list and workgroup
+    if (lead) s_cat[w] = cat;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned n1 = 0, n2 = 0;
+        for (int k = 0; k < MV_RED_WAVES; ++k) { n1 += s_cat[k] == 1; n2 += s_cat[k] == 2; }
+        if (n1) s_base[0] = atomicAdd(&c.counters[MV_CNT_N_SAMPLER_REST], (unsigned long long)n1);
+        if (n2) s_base[1] = atomicAdd(&c.counters[MV_CNT_N_SECANT], (unsigned long long)n2);
+    }
+    __syncthreads();
+    if (lead && cat) {
+        unsigned rank = 0;
+        for (int k = 0; k < w; ++k) rank += s_cat[k] == cat;
+        const unsigned long long k = s_base[cat - 1] + rank;
+        if (cat == 1) { c.list_rest[k] = e; c.src_rest[k] = it; }
+        else c.sec_list[k] = gid;
+    }
 }
 
 // secant (ray_tracing.py:260-278) for 16*MT listed rays per workgroup: n_secant dependent rounds, every round one evaluation of
@@ -719,17 +751,17 @@ static hipError_t launch_stage2(const NET& net, const MvTraceParams& tp, const f
     c.list_rest = (int*)(sv + (size_t)R * n); c.src_rest = c.list_rest + R; c.n_first = nf;
     // worst-case grids (every ray listed); blocks beyond the device-side counts exit at once
     auto blocks_for = [&](int per_item) { return (int)(((long long)R * per_item + ROWS - 1) / ROWS); };
-    const int sec_blocks = (R + 15) / 16, red_blocks = R;                        // one wave per listed ray
+    const int sec_blocks = (R + 15) / 16, red_blocks = (R + MV_RED_WAVES - 1) / MV_RED_WAVES;   // one wave per listed ray, 16 per workgroup
     const RowSeg none = {nullptr, nullptr, 0, 0, 1, 0, 0};
     if (parts & 1) {
         // sampler rays: first window of nf samples, then the other samples of the rays the window left open
         const RowSeg first = {w_list, nullptr, (int)MV_CNT_N_SAMPLER, 0, nf, blocks_for(nf), 0};
         hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(first.blocks), dim3(64 * NW), lds2, stream, net, tp, c, first, none, 0);
-        hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, w_list, (const int*)nullptr, (int)MV_CNT_N_SAMPLER, 0);
+        hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64 * MV_RED_WAVES), 0, stream, tp, c, w_list, (const int*)nullptr, (int)MV_CNT_N_SAMPLER, 0);
         if (nf < n) {
             const RowSeg rest = {c.list_rest, c.src_rest, (int)MV_CNT_N_SAMPLER_REST, nf, n - nf, blocks_for(n - nf), 0};
             hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(rest.blocks), dim3(64 * NW), lds2, stream, net, tp, c, rest, none, 0);
-            hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c, c.list_rest, c.src_rest, (int)MV_CNT_N_SAMPLER_REST, 1);
+            hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64 * MV_RED_WAVES), 0, stream, tp, c, c.list_rest, c.src_rest, (int)MV_CNT_N_SAMPLER_REST, 1);
         }
     }
     if (parts & 2) {
@@ -741,7 +773,7 @@ static hipError_t launch_stage2(const NET& net, const MvTraceParams& tp, const f
         const RowSeg minsdf = {w_list_min, nullptr, (int)MV_CNT_N_MINSDF, 0, n, training ? blocks_for(n) + (tail ? 1 : 0) : 0, tail ? 1 : 0};
         hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(sec_blocks + minsdf.blocks), dim3(64 * NW), lds2, stream, net, tp, cm, minsdf, none,
                            sec_blocks);
-        if (training) hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, cm, w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
+        if (training) hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64 * MV_RED_WAVES), 0, stream, tp, cm, w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
     }
     if ((parts & 4) && training) {
         SampleCtx c2 = c;
@@ -749,7 +781,7 @@ static hipError_t launch_stage2(const NET& net, const MvTraceParams& tp, const f
         const bool tail = mv_tail_on<NET>(training, steps, R, mt1);
         const RowSeg minsdf = {w_list_min, nullptr, (int)MV_CNT_N_MINSDF, 0, n, blocks_for(n) + (tail ? 1 : 0), tail ? 1 : 0};
         hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(minsdf.blocks), dim3(64 * NW), lds2, stream, net, tp, c2, minsdf, none, 0);
-        hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64), 0, stream, tp, c2, w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
+        hipLaunchKernelGGL(k_reduce_items, dim3(red_blocks), dim3(64 * MV_RED_WAVES), 0, stream, tp, c2, w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
     }
     if (parts & 8)
         hipLaunchKernelGGL((k_ray_samples<MT, NTW, NW, NET>), dim3(sec_blocks), dim3(64 * NW), lds2, stream, net, tp, c, none, none, sec_blocks);
@@ -1197,12 +1229,12 @@ int mvsdf_tracegen_reduce(const MvsdfTraceParams* tp, int kind, const float* cam
     c.sec_list = w.sec_list; c.sv = (float*)sv; c.counters = counters; c.list_rest = w.list_rest; c.src_rest = w.src_rest; c.n_first = tp->n_steps;
     hipStream_t s = (hipStream_t)stream;
     if (kind == 0) {
-        hipLaunchKernelGGL(k_reduce_items, dim3(R), dim3(64), 0, s, *tp, c, w.w_list, (const int*)nullptr, (int)MV_CNT_N_SAMPLER, 0);
+        hipLaunchKernelGGL(k_reduce_items, dim3((R + MV_RED_WAVES - 1) / MV_RED_WAVES), dim3(64 * MV_RED_WAVES), 0, s, *tp, c, w.w_list, (const int*)nullptr, (int)MV_CNT_N_SAMPLER, 0);
         hipError_t e = hipMemsetAsync(marks, 0, (size_t)R, s);
         if (e != hipSuccess) return mv_check(e, "mvsdf_tracegen_reduce: memset");
         hipLaunchKernelGGL(k_gen_sort_list, dim3(1), dim3(1024), 0, s, w.sec_list, counters, (int)MV_CNT_N_SECANT, marks, R);
     } else {
-        hipLaunchKernelGGL(k_reduce_items, dim3(R), dim3(64), 0, s, *tp, c, w.w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
+        hipLaunchKernelGGL(k_reduce_items, dim3((R + MV_RED_WAVES - 1) / MV_RED_WAVES), dim3(64 * MV_RED_WAVES), 0, s, *tp, c, w.w_list_min, (const int*)nullptr, (int)MV_CNT_N_MINSDF, 2);
     }
     return mv_check(hipGetLastError(), "mvsdf_tracegen_reduce");
 }
