@@ -71,8 +71,8 @@ import sys, torch
 sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
 from test_gpu_native_step import _run
 res = []
-for rep in range(2):                                   # the second step reuses the side stream / events
-    outs, losses, g, _, _ = _run(True, W=256, B=4, P=256, V=3, tp=0.3, sink=True)
+for P in (256, 250):                                   # 250: E = 500 sample rows, not a multiple of the 16-row tile -- the rays' launch starts mid-tile
+    outs, losses, g, _, _ = _run(True, W=256, B=4, P=P, V=3, tp=0.3, sink=True)
     res.append({'g': g.cpu(), 'losses': {k: v.detach().cpu() for k, v in losses.items()},
                 'outs': {k: v.detach().cpu() for k, v in outs.items() if torch.is_tensor(v)}})
 torch.save(res, sys.argv[1])
