@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- traced rays/s for one MVSDF training step (forward + loss + backward + grad-norm/clip + Adam) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5share] [--dtype f32|bf16] [--width 256|512]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5share] [--dtype f32|bf16|bf16w|bf16x2|bf16x3] [--width 256|512]
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process (which never touches the GPU) starts
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a child, relays
@@ -50,7 +50,9 @@ WORKLOADS = {                     # name: (pixels per view and GPU-count unit, s
 }
 FEAT_HW = (600, 800)
 P, V = WORKLOADS['c2']            # defaults of make_inputs (dev tools under tools/ set bench.B / bench.P / bench.V and call it)
-PEAK = {'f32': 157.3, 'bf16': 2500.0}    # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32 / bf16)
+PEAK = {'f32': 157.3, 'bf16w': 157.3, 'bf16': 2500.0, 'bf16x2': 2500.0, 'bf16x3': 2500.0}    # dense MFMA TFLOP/s of the tracing MLP's matrix instruction,
+# /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32 / v_mfma_f32_16x16x32_bf16); bf16x2 / bf16x3 issue 2 / 3 bf16 matrix instructions per
+# ALGORITHMIC multiply-add (activations as bf16 terms): `achieved` counts the algorithmic FLOPs once
 
 
 def reference_cpu_note():
@@ -177,7 +179,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)          # ~3 ms per step: the default run still takes seconds
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
+    ap.add_argument('--dtype', default='f32', choices=sorted(PEAK), help="arithmetic of the no-grad tracing MLP (IDRNetwork.set_trace_dtype); the differentiable half is always fp32")
     ap.add_argument('--width', type=int, default=256, help='hidden width of both MLPs: 256 = BASELINE.json (8x256), 512 = the reference\'s shipped conf (mvsdf_dtu.conf:24,35)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--variants', action='store_true', help='also time the opt-in lazy_unused_outputs step (secondary number; off by default so that a profile of this command holds the headline step only)')
@@ -223,8 +225,7 @@ def main():
     model = IDRNetwork(ConfigDict(conf))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(W, 0).items()})
     model = model.to(dev).train()
-    if a.dtype == 'bf16':
-        model.set_trace_dtype('bf16')                            # bf16 weights + bf16 MFMA in the tracing MLP (BASELINE configs[4])
+    model.set_trace_dtype(a.dtype)                               # bf16*: bf16 weights in the tracing MLP (BASELINE configs[4])
     loss_fn = IDRLoss()
     # frozen weights (lr = 0): a step on random GT collapses the scene.  Parameters, gradients and Adam moments
     # live in flat buffers: one memset, one all-reduce, two launches for grad-norm + clip + Adam.

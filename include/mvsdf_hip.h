@@ -32,12 +32,17 @@ typedef struct {
     const float* w[MVSDF_MAX_LAYERS];   /* folded weights, row-major [N][K] (only the last layer's row 0 is read: u_L = W_L[0,:]); may be NULL when no normals are needed */
     int skip_layer;                     /* layer whose input is cat([x, PE(x)])/sqrt(2) (idr.py:86-87), -1 if none (see skip_mask for several) */
     int multires;                       /* positional-encoding frequencies (embedder.py:38-50) */
-    const void* wp16[MVSDF_MAX_LAYERS]; /* bf16 packs made by mvsdf_pack_bf16_net (BASELINE configs[4]); NULL unless trace_dtype == 1 */
+    const void* wp16[MVSDF_MAX_LAYERS]; /* trace_dtype 1: bf16 packs made by mvsdf_pack_bf16_net (BASELINE configs[4]); 2: fp32 packs of the rounded weights
+                                         * (mvsdf_pack_bf16w_net); 3 / 4: bf16 packs made by mvsdf_pack_bf16s_net; NULL for trace_dtype 0 */
     int trace_dtype;                    /* arithmetic of the no-grad tracing MLP (mvsdf_trace, mvsdf_sdf_col0): 0 = fp32 weights and fp32-input
                                          * MFMA (bit-exact against the oracle), 1 = bf16 weights / activations on the bf16 MFMA, fp32 accumulate,
                                          * 2 = bf16-ROUNDED WEIGHTS ONLY: wp16[l] holds an fp32 pack (mvsdf_packed_floats(N, K) floats, made by
                                          * mvsdf_pack_bf16w_net) of the weights rounded to bf16, activations stay fp32 on the fp32-input MFMA -- bit-exact
-                                         * against the oracle run on the rounded weights; what rounding the activations too (mode 1) costs is then a number */
+                                         * against the oracle run on the rounded weights; what rounding the activations too (mode 1) costs is then a number,
+                                         * 3 / 4 = bf16 weights on the bf16 MFMA with every activation carried as 2 / 3 bf16 TERMS (a = t0 + t1 [+ t2], 16 / all 24
+                                         * mantissa bits; csrc/tile_engine_bf16s.h): the arithmetic of mode 2 (idr.py:77-94 on bf16-rounded weights) up to the order
+                                         * of the fp32 additions inside the matrix core -- the fast mode that is parity-checked against that oracle (hit masks
+                                         * equal except at recorded ties, depths 1e-4).  bias[] is read like in mode 1 */
     unsigned skip_mask;                 /* several skip connections (skip_in with more than one entry, idr.py:46,86): bit l set = the input of layer l
                                          * is cat([x, PE(x)])/sqrt(2).  0 = use skip_layer alone.  Layer 0 and the last layer cannot be skip layers. */
 } MvsdfNetDesc;
@@ -111,9 +116,12 @@ int mvsdf_pack_bf16_net(int n_layers, const float* const* w, const int* N, const
                         void* stream);
 /* trace_dtype = 2: fp32 MFMA packs (layout of mvsdf_fold_pack's wp) of the folded weights w[l] rounded to bf16 (nearest even) */
 int mvsdf_pack_bf16w_net(int n_layers, const float* const* w, const int* N, const int* K, float* const* wp_rounded, void* stream);
-/* the same for a network with several skip connections (MvsdfNetDesc.skip_mask) */
+/* mvsdf_pack_bf16_net for a network with several skip connections (MvsdfNetDesc.skip_mask) */
 int mvsdf_pack_bf16_net_skips(int n_layers, const float* const* w, const int* N, const int* K, unsigned skip_mask, int multires, void* const* wp16,
                               void* stream);
+/* trace_dtype = 3 / 4: bf16 packs in the layout of mode 1 WITHOUT duplicated columns (the positional-encoding inputs are split into bf16 terms like
+ * every other activation); wp16[l]: mvsdf_packed_bf16_bytes(N, K, 0) bytes.  idr.py:77-94 on bf16-rounded weights. */
+int mvsdf_pack_bf16s_net(int n_layers, const float* const* w, const int* N, const int* K, void* const* wp16, void* stream);
 
 /* ImplicitNetwork.forward(x)[:, 0] (idr.py:77-94) for n points: the tracing MLP alone. */
 int mvsdf_sdf_col0(const MvsdfNetDesc* net, const float* x, int n, float* y, int mt, void* stream);
@@ -347,7 +355,7 @@ typedef struct {
     unsigned skip_mask;                    /* bit l: the input of SDF layer l is cat([x, PE(x)]) / sqrt(2) (idr.py:86-87) */
     int multires;                          /* PE frequencies of the SDF net */
     int view_spec;                         /* multires_view | mode bits, as mvsdf_render_forward takes them */
-    int trace_dtype;                       /* 0: fp32 tracing MLP; 1: bf16 packs are made each forward and the tracer uses them; 2: fp32 packs of the bf16-rounded weights (MvsdfNetDesc.trace_dtype) */
+    int trace_dtype;                       /* 0: fp32 tracing MLP; 1: bf16 packs are made each forward and the tracer uses them; 2: fp32 packs of the bf16-rounded weights; 3 / 4: bf16 packs without duplicated columns, activations as 2 / 3 bf16 terms (MvsdfNetDesc.trace_dtype) */
     int use_object_mask;                   /* conf.use_mask (idr.py:187): 0 = the ray partition ignores object_mask */
     MvsdfTraceParams tp;
     int mt, mt_samples;                    /* tiling of the tracer kernels (see mvsdf_trace) */

@@ -268,8 +268,8 @@ __global__ void k_pack_round_net(PackBfArgs a) {
     }
 }
 
-template <int MT, int NTW, bool CARRY>
-__global__ __launch_bounds__(512) void k_sdf_col0_bf(MvNetBf net, const float* __restrict__ x, int n, float* __restrict__ y) {
+template <int MT, int NTW, bool CARRY, class NET>
+__global__ __launch_bounds__(512) void k_sdf_col0_bf(NET net, const float* __restrict__ x, int n, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT;
     const int tid = threadIdx.x, d0 = 3 + 6 * net.multires;
@@ -287,20 +287,32 @@ __global__ __launch_bounds__(512) void k_sdf_col0_bf(MvNetBf net, const float* _
     if (tid < ROWS && row0 + tid < n) y[row0 + tid] = out[tid];
 }
 
-template <int MT, int NTW>
-static int launch_col0_bf(const MvNetBf& net, const float* x, int n, float* y, hipStream_t s) {
+// NET = MvNetBf (bf16 weights + activations) or MvNetBs<NS> (bf16 weights, activations as NS bf16 terms: tile_engine_bf16s.h)
+template <int MT, int NTW, class NET>
+static int launch_col0_bf(const NET& net, const float* x, int n, float* y, hipStream_t s) {
     const int rows = 16 * MT, d0 = 3 + 6 * net.multires;
     const size_t lds = ((size_t)rows * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows) * 4;
     // MVSDF_BF_CARRY=1 (dev / tests): the weight-fetch scheme of k_sphere_trace (tile_engine_bf16.h, CARRIED) instead of the row-sample kernels' (ROLLING);
     // same arithmetic, bit-identical results (tests/test_gpu_bf16.py)
     static int carry = -1;
     if (carry < 0) { const char* ev = getenv("MVSDF_BF_CARRY"); carry = ev ? atoi(ev) : 0; }
-    hipError_t e = carry ? hipFuncSetAttribute((const void*)k_sdf_col0_bf<MT, NTW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                         : hipFuncSetAttribute((const void*)k_sdf_col0_bf<MT, NTW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = carry ? hipFuncSetAttribute((const void*)k_sdf_col0_bf<MT, NTW, true, NET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                         : hipFuncSetAttribute((const void*)k_sdf_col0_bf<MT, NTW, false, NET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return mv_check(e, "mvsdf_sdf_col0: LDS attribute");
-    if (carry) hipLaunchKernelGGL((k_sdf_col0_bf<MT, NTW, true>), dim3((n + rows - 1) / rows), dim3(512), lds, s, net, x, n, y);
-    else hipLaunchKernelGGL((k_sdf_col0_bf<MT, NTW, false>), dim3((n + rows - 1) / rows), dim3(512), lds, s, net, x, n, y);
+    if (carry) hipLaunchKernelGGL((k_sdf_col0_bf<MT, NTW, true, NET>), dim3((n + rows - 1) / rows), dim3(512), lds, s, net, x, n, y);
+    else hipLaunchKernelGGL((k_sdf_col0_bf<MT, NTW, false, NET>), dim3((n + rows - 1) / rows), dim3(512), lds, s, net, x, n, y);
     return mv_check(hipGetLastError(), "mvsdf_sdf_col0 (bf16)");
+}
+
+template <class NET>
+static int dispatch_col0_bf(const NET& nb, const float* x, int n, float* y, int mt, hipStream_t s) {
+    int mx = 0;
+    for (int l = 0; l < nb.n_layers - 1; ++l) mx = nb.L[l].NT > mx ? nb.L[l].NT : mx;
+    if (mx > 32) return mv_fail(-1, "mvsdf_sdf_col0: network too wide");
+    if (mx > 16) return mt >= 2 ? launch_col0_bf<2, 4>(nb, x, n, y, s) : launch_col0_bf<1, 4>(nb, x, n, y, s);
+    if (mt >= 4) return launch_col0_bf<4, 2>(nb, x, n, y, s);
+    if (mt >= 2) return launch_col0_bf<2, 2>(nb, x, n, y, s);
+    return launch_col0_bf<1, 2>(nb, x, n, y, s);
 }
 
 // throughput variant: every wave owns 16 rows for the whole network, weights staged in an LDS ring shared by the workgroup (tile_engine_rows.h)
@@ -503,6 +515,24 @@ int mvsdf_pack_bf16_net_skips(int n_layers, const float* const* w, const int* N,
     return mv_check(hipGetLastError(), "mvsdf_pack_bf16_net");
 }
 
+/* trace_dtype = 3 / 4: the bf16 packs without duplicated columns (every activation, the positional encoding included, is split into bf16
+ * terms in LDS: tile_engine_bf16s.h) */
+int mvsdf_pack_bf16s_net(int n_layers, const float* const* w, const int* N, const int* K, void* const* wp16, void* stream) {
+    if (n_layers < 1 || n_layers > MV_MAXL || !w || !N || !K || !wp16) return mv_fail(-1, "mvsdf_pack_bf16s_net: bad arguments");
+    PackBfArgs a;
+    memset(&a, 0, sizeof(a));
+    size_t maxTot = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!w[l] || !wp16[l] || N[l] <= 0 || K[l] <= 0) return mv_fail(-1, "mvsdf_pack_bf16s_net: null layer pointer / bad dims");
+        a.w[l] = w[l]; a.wp[l] = (uint16_t*)wp16[l]; a.N[l] = N[l]; a.K[l] = K[l]; a.nsplit[l] = 0;
+        const size_t t = mv_packed_bf16_elems(N[l], K[l], 0);
+        if (t > maxTot) maxTot = t;
+    }
+    const int blocks = (int)((maxTot + 255) / 256 < 256 ? (maxTot + 255) / 256 : 256);
+    hipLaunchKernelGGL(k_pack_bf16_net, dim3(blocks, n_layers), dim3(256), 0, (hipStream_t)stream, a);
+    return mv_check(hipGetLastError(), "mvsdf_pack_bf16s_net");
+}
+
 int mvsdf_pack_bf16w_net(int n_layers, const float* const* w, const int* N, const int* K, float* const* wp_rounded, void* stream) {
     if (n_layers < 1 || n_layers > MV_MAXL || !w || !N || !K || !wp_rounded) return mv_fail(-1, "mvsdf_pack_bf16w_net: bad arguments");
     PackBfArgs a;
@@ -526,13 +556,14 @@ int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, in
         MvNetBf nb;
         int rcb = mv_make_net_bf(desc, &nb);
         if (rcb) return rcb;
-        int mx = 0;
-        for (int l = 0; l < nb.n_layers - 1; ++l) mx = nb.L[l].NT > mx ? nb.L[l].NT : mx;
-        if (mx > 32) return mv_fail(-1, "mvsdf_sdf_col0: network too wide");
-        if (mx > 16) return mt >= 2 ? launch_col0_bf<2, 4>(nb, x, n, y, s) : launch_col0_bf<1, 4>(nb, x, n, y, s);
-        if (mt >= 4) return launch_col0_bf<4, 2>(nb, x, n, y, s);
-        if (mt >= 2) return launch_col0_bf<2, 2>(nb, x, n, y, s);
-        return launch_col0_bf<1, 2>(nb, x, n, y, s);
+        return dispatch_col0_bf(nb, x, n, y, mt, s);
+    }
+    if (desc && (desc->trace_dtype == 3 || desc->trace_dtype == 4)) {   // bf16 weights x activations carried as 2 / 3 bf16 terms
+        MvNetBs<2> n2;
+        MvNetBs<3> n3;
+        int rcb = desc->trace_dtype == 3 ? mv_make_net_bs(desc, &n2, 2) : mv_make_net_bs(desc, &n3, 3);
+        if (rcb) return rcb;
+        return desc->trace_dtype == 3 ? dispatch_col0_bf(n2, x, n, y, mt, s) : dispatch_col0_bf(n3, x, n, y, mt, s);
     }
     MvNet net;
     int rc = mv_make_net_trace(desc, &net);

@@ -77,4 +77,26 @@ int mv_make_net_bf(const MvsdfNetDesc* d, MvNetBf* net) {
     return 0;
 }
 
+int mv_make_net_bs(const MvsdfNetDesc* d, MvNetBf* net, int ns) {
+    MvNet chk;
+    int rc = mv_make_net_mode(d, &chk, 0);
+    if (rc) return rc;
+    if (ns < 2 || ns > 3) return mv_fail(-2, "net descriptor: 2 or 3 activation terms");
+    memset(net, 0, sizeof(*net));
+    int maxk = 0;
+    for (int l = 0; l < d->n_layers; ++l) {
+        if (!d->wp16[l]) return mv_fail(-2, "net descriptor: trace_dtype = 3 / 4 without bf16 packs (mvsdf_pack_bf16s_net)");
+        MvLayerBf& L = net->L[l];
+        L.wp = (const uint4*)d->wp16[l];
+        L.bias = d->bias[l];
+        L.K = d->K[l]; L.N = d->N[l];
+        L.nsplit = 0;
+        L.KB = mv_bf_kb(L.K, 0); L.NT = mv_ceil16(d->N[l]) / 16;
+        if (L.KB * 32 > maxk) maxk = L.KB * 32;
+    }
+    net->n_layers = d->n_layers; net->skip_mask = chk.skip_mask; net->multires = d->multires;
+    net->S = ns * ((maxk + 8) / 2);                               // ns term tiles of bf16 rows of 32*KB + 8 elements (64*KB + 16 bytes: conflict-free b128 reads)
+    return 0;
+}
+
 extern "C" const char* mvsdf_last_error(void) { return g_err; }

@@ -71,7 +71,7 @@ void make_descs(const Step& st, const MvsdfStepParams* prm, const char* fwd, Mvs
             o->skip_layer = oT->skip_layer = m ? (single >= 0 ? single : __builtin_ctz(m)) : -1;
             o->skip_mask = (m && single < 0) ? m : 0;
             o->multires = oT->multires = d.multires;
-            o->trace_dtype = (d.trace_dtype == 1 || d.trace_dtype == 2) ? d.trace_dtype : 0;
+            o->trace_dtype = (d.trace_dtype >= 1 && d.trace_dtype <= 4) ? d.trace_dtype : 0;
         } else {
             o->skip_layer = oT->skip_layer = -1;
         }
@@ -152,6 +152,8 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
             fo.wp16[l] = take(mvsdf_packed_bf16_bytes(d.N[l], d.K[l], ns));
         } else if (l < d.n_sdf && d.trace_dtype == 2) {
             fo.wp16[l] = take(mvsdf_packed_floats(d.N[l], d.K[l]) * 4);
+        } else if (l < d.n_sdf && (d.trace_dtype == 3 || d.trace_dtype == 4)) {
+            fo.wp16[l] = take(mvsdf_packed_bf16_bytes(d.N[l], d.K[l], 0));      // no duplicated columns: the activations are split into bf16 terms in LDS
         }
     }
     L.perm = take((size_t)R * 8); fo.inv = take((size_t)R * 8); fo.true_rows = take((size_t)R * 8); fo.true_rank = take((size_t)R * 4); fo.counts = take(4 * 8);

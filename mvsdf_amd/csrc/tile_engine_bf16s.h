@@ -1,0 +1,360 @@
+// tile_engine_bf16s.h -- the tracing MLP with bf16 WEIGHTS and fp32-ACCURATE activations on gfx950's bf16 matrix cores
+// (BASELINE configs[4], "bf16 MLP weights": the mode that is both fast and parity-checked against the reference arithmetic on
+// bf16-rounded weights, idr.py:77-94 inside ray_tracing.py:27-98).
+//
+// tile_engine_bf16.h rounds the hidden activations to bf16 too (8 mantissa bits: masks 99.95 %, depth p99 1.5e-3 at the c5 share).  Here an
+// fp32 activation a is carried as NS bf16 TERMS
+//       t0 = bf16(a),  t1 = bf16(a - t0),  [t2 = bf16(a - t0 - t1)]          (every subtraction is exact in fp32)
+// i.e. 16 (NS = 2) or all 24 (NS = 3: a == t0 + t1 + t2 exactly) mantissa bits, and a Linear is NS matrix instructions per k-block that SHARE
+// one weight fragment:   z = bias + sum_k W16[n][k] * (t0[k] + t1[k] + t2[k]),   v_mfma_f32_16x16x32_bf16, fp32 accumulators.
+// A bf16 x bf16 product is exact in fp32, so with NS = 3 the only difference to the fp32 engine on the rounded weights (trace_dtype 2, bit-exact
+// vs oracle.Net(sd, bf16='weights')) is the ORDER of the fp32 additions inside the matrix core and the softplus below: accumulation noise of a
+// few 1e-8 on |z| ~ 1, no 8-bit rounding anywhere.  The L2 weight stream -- what bounds the bf16 engine -- does not grow: only the LDS activation
+// reads and the (16x cheaper than fp32) matrix instructions are multiplied by NS.
+//   * weights: bf16 packs of tile_engine_bf16.h WITHOUT duplicated columns (nsplit = 0: the positional-encoding columns are split like
+//     every other activation, into the term tiles);
+//   * LDS: NS term tiles [rows][S16] bf16 behind each other (term stride rows * S16), row stride 64*KB + 16 bytes (conflict-free b128 reads);
+//   * softplus: max(z, 0) + t Q(t), t = 2^(-100 log2(e) |z|) by v_exp_f32, Q = degree-8 fit of ln(1 + t) / (100 t) on [0, 1] (1.3e-7 relative
+//     in fp32 Horner form = the rounding floor; two activations per v_pk_fma_f32): ~1 ulp of the activation, the accuracy class of det_math's;
+//   * everything else (bias as the accumulator's start value, transposed accumulators, the two weight-fetch schemes) as in tile_engine_bf16.h.
+#pragma once
+#include "tile_engine_bf16.h"
+
+template <int NS>
+struct MvNetBs : MvNetBf {};        // S = NS * (32 * KBmax + 8) / 2 floats per row (all term tiles); L[l].nsplit == 0
+
+__host__ __device__ constexpr int mv_bs_pa(int NS) { return NS == 1 ? 4 : 2; }          // activation k-blocks in flight (LDS)
+
+// Softplus(beta=100, threshold=20) to fp32 accuracy: z > 0.2 gives t Q(t) < 2.1e-11 < ulp(z) / 2, the sum IS z (the reference's threshold branch)
+__device__ __forceinline__ dm_f2 mv_softplus100_acc2(dm_f2 z) {
+    const dm_f2 t = dm_f2{__builtin_amdgcn_exp2f(fabsf(z.x) * -144.26950408889634f), __builtin_amdgcn_exp2f(fabsf(z.y) * -144.26950408889634f)};
+    dm_f2 u = dm2_s(5.232587500358932e-05f);
+    u = dm2_fma(u, t, dm2_s(-0.000295048113912344f));
+    u = dm2_fma(u, t, dm2_s(0.0007822525803931057f));
+    u = dm2_fma(u, t, dm2_s(-0.0013663186691701412f));
+    u = dm2_fma(u, t, dm2_s(0.0019105979008600116f));
+    u = dm2_fma(u, t, dm2_s(-0.002484297612681985f));
+    u = dm2_fma(u, t, dm2_s(0.003331909654662013f));
+    u = dm2_fma(u, t, dm2_s(-0.0049999491311609745f));
+    u = dm2_fma(u, t, dm2_s(0.009999999776482582f));
+    return dm2_fma(t, u, dm_f2{__builtin_amdgcn_fmed3f(z.x, 0.0f, 3.0e38f), __builtin_amdgcn_fmed3f(z.y, 0.0f, 3.0e38f)});
+}
+
+__device__ __forceinline__ dm_f2 mv_bf_unpack2(uint32_t p) { return dm_f2{__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)}; }
+
+// two activations -> NS packed pairs of bf16 terms
+template <int NS>
+__device__ __forceinline__ void mv_split_pk(dm_f2 h, uint32_t (&p)[NS]) {
+    p[0] = mv_f2bf_pk(h.x, h.y);
+#pragma unroll
+    for (int s = 1; s < NS; ++s) {
+        h = h - mv_bf_unpack2(p[s - 1]);
+        p[s] = mv_f2bf_pk(h.x, h.y);
+    }
+}
+template <int NS>
+__device__ __forceinline__ void mv_split_1(float v, uint16_t (&p)[NS]) {
+    p[0] = mv_f2bf(v);
+#pragma unroll
+    for (int s = 1; s < NS; ++s) {
+        v = v - mv_bf2f(p[s - 1]);
+        p[s] = mv_f2bf(v);
+    }
+}
+
+// positional encoding -> pe[rows][d0] (fp32, kept for the skip connection) and the layer-0 input rows of the NS term tiles (zero padded to kpad)
+template <int NTHREADS, int NS>
+__device__ __forceinline__ void mv_pe_rows_bs(const float* pts, float* pe, uint16_t* act, int S16, int TS, int rows, int multires, int kpad, int tid) {
+    const int d0 = 3 + 6 * multires, T = 3 * multires + 1;
+    for (int task = tid; task < rows * T; task += NTHREADS) {
+        const int row = task / T, j = task - row * T;
+        const float* x = pts + row * 3;
+        float* pr = pe + row * d0;
+        uint16_t* ar = act + row * S16;
+        auto put = [&](int col, float v) {
+            pr[col] = v;
+            uint16_t p[NS];
+            mv_split_1<NS>(v, p);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) ar[s * TS + col] = p[s];
+        };
+        if (j < 3 * multires) {
+            const int m = j / 3, c = j - 3 * m;
+            float s, co;
+            dm_sincos(x[c] * (float)(1 << m), &s, &co);
+            put(3 + 6 * m + c, s);
+            put(3 + 6 * m + 3 + c, co);
+        } else {
+            for (int c = 0; c < 3; ++c) put(c, x[c]);
+            for (int c = d0; c < kpad; ++c) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) ar[s * TS + c] = 0;
+            }
+        }
+    }
+}
+
+// CARRIED weight fetch (k_sphere_trace), see tile_engine_bf16.h::mv_gemm_carried_bf: the same ring, NS matrix instructions per weight fragment
+template <int MTc, int NTW, int PD, int PDR, int NS>
+__device__ __forceinline__ void mv_gemm_carried_bs(int KB, const uint16_t* __restrict__ act, int S16, int TS, const uint4* const (&wcur)[NTW], int ntw,
+                                                   f32x4 (&acc)[MTc][NTW], int lane, uint4 (&b)[PD][NTW], const uint4* const (&wnext)[NTW], int kbnext) {
+    constexpr int PA = mv_bs_pa(NS);
+    static_assert(PD % PA == 0, "weight register depth must be a multiple of the activation ring depth");
+    const uint16_t* arow = act + (lane & 15) * S16 + 8 * (lane >> 4);
+    uint4 a[PA][MTc][NS];
+#pragma unroll
+    for (int d = 0; d < PA; ++d) {
+        const int kb = d < KB ? d : KB - 1;
+#pragma unroll
+        for (int r = 0; r < MTc; ++r)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) a[d][r][s] = *(const uint4*)(arow + s * TS + r * 16 * S16 + kb * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < PD; ++kb) {
+        if (kb < KB) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+                    if (t < ntw) {
+#pragma unroll
+                        for (int r = 0; r < MTc; ++r)
+                            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mv_bf8, b[kb][t]), __builtin_bit_cast(mv_bf8, a[kb % PA][r][s]), acc[r][t], 0, 0, 0);
+                    }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb < PDR) {
+            const int kn = kb < kbnext ? kb : kbnext - 1;                                    // clamped: no branch around a load
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) b[kb][t] = wnext[t][kn * 64];
+        }
+        {
+            const int ka = kb + PA < KB ? kb + PA : KB - 1;
+#pragma unroll
+            for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) a[kb % PA][r][s] = *(const uint4*)(arow + s * TS + r * 16 * S16 + ka * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int kb = PD; kb < KB; ++kb) {
+        uint4 bx[NTW], ax[MTc][NS];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) bx[t] = wcur[t][kb * 64];
+#pragma unroll
+        for (int r = 0; r < MTc; ++r)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) ax[r][s] = *(const uint4*)(arow + s * TS + r * 16 * S16 + kb * 32);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+                if (t < ntw) {
+#pragma unroll
+                    for (int r = 0; r < MTc; ++r)
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mv_bf8, bx[t]), __builtin_bit_cast(mv_bf8, ax[r][s]), acc[r][t], 0, 0, 0);
+                }
+    }
+}
+
+// ROLLING weight fetch (the row-sample kernels), see tile_engine_bf16.h::mv_gemm_rolling_bf
+template <int MTc, int NT, int NTW, int PD, int NS>
+__device__ __forceinline__ void mv_gemm_rolling_bs(int KB, const uint16_t* __restrict__ act, int S16, int TS, const uint4* __restrict__ wp, f32x4 (&acc)[MTc][NTW], int lane) {
+    constexpr int PA = mv_bs_pa(NS);
+    static_assert(PD % PA == 0, "weight ring depth must be a multiple of the activation ring depth");
+    const uint16_t* arow = act + (lane & 15) * S16 + 8 * (lane >> 4);
+    uint4 b[PD][NT], a[PA][MTc][NS];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+        const int kb = d < KB ? d : KB - 1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[d][t] = wp[((size_t)t * KB + kb) * 64];
+        if (d < PA) {
+#pragma unroll
+            for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) a[d][r][s] = *(const uint4*)(arow + s * TS + r * 16 * S16 + kb * 32);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kb0 = 0; kb0 < KB; kb0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            if (kb0 + d < KB) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mv_bf8, b[d][t]), __builtin_bit_cast(mv_bf8, a[d % PA][r][s]), acc[r][t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = (kb0 + d + PD < KB) ? kb0 + d + PD : KB - 1;
+            const int ka = (kb0 + d + PA < KB) ? kb0 + d + PA : KB - 1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[d][t] = wp[((size_t)t * KB + kn) * 64];
+#pragma unroll
+            for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) a[d % PA][r][s] = *(const uint4*)(arow + s * TS + r * 16 * S16 + ka * 32);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int MTc, int NTW, int NS>
+__device__ __forceinline__ void mv_gemm_rolling_dispatch_bs(int KB, const uint16_t* act, int S16, int TS, const uint4* wp, int ntw, f32x4 (&acc)[MTc][NTW], int lane) {
+    if (ntw == NTW) { mv_gemm_rolling_bs<MTc, NTW, NTW, 4, NS>(KB, act, S16, TS, wp, acc, lane); return; }
+    if (NTW >= 4 && ntw == 3) { mv_gemm_rolling_bs<MTc, (NTW >= 4 ? 3 : 1), NTW, 4, NS>(KB, act, S16, TS, wp, acc, lane); return; }
+    if (NTW >= 2 && ntw == 2) { mv_gemm_rolling_bs<MTc, (NTW >= 2 ? 2 : 1), NTW, 4, NS>(KB, act, S16, TS, wp, acc, lane); return; }
+    if (ntw == 1) { mv_gemm_rolling_bs<MTc, 1, NTW, 4, NS>(KB, act, S16, TS, wp, acc, lane); return; }
+    for (int t0 = 0; t0 < ntw; ++t0) {                              // 5..NTW-1 tiles (wide nets only): one by one
+        f32x4 tmp[MTc][NTW];
+#pragma unroll
+        for (int r = 0; r < MTc; ++r) tmp[r][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mv_gemm_rolling_bs<MTc, 1, NTW, 4, NS>(KB, act, S16, TS, wp + (size_t)t0 * KB * 64, tmp, lane);
+#pragma unroll
+        for (int r = 0; r < MTc; ++r)
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) if (u == t0) acc[r][u] += tmp[r][0];
+    }
+}
+
+// ImplicitNetwork.forward(...)[:, 0] for MTc*16 rows (points in LDS `pts`), bf16 weights x NS-term activations.  Result -> LDS out[row].
+// `actf` is the activation region (rows * net.S floats) = NS term tiles of bf16 [rows][S16].  All 64*NW threads must call; ends with a barrier.
+template <int MTc, int NTW, int NW = 8, bool CARRY = false, int NS = 2>
+__device__ void mv_sdf_eval_col0(const MvNetBs<NS>& net, float* actf, float* pe, const float* pts, float* out, int tid) {
+    constexpr int NTHREADS = 64 * NW, PD = mv_bf_pd(NTW, CARRY), PDR = mv_bf_pdr(NTW, CARRY);
+    uint16_t* act = (uint16_t*)actf;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+    const int S16 = 2 * net.S / NS, rows = MTc * 16, d0 = 3 + 6 * net.multires, TS = rows * S16;
+    const int nl = net.n_layers;
+    uint4 b[CARRY ? PD : 1][NTW];                                   // CARRIED: weights of the current / coming layer's first k-blocks
+    f32x4 bias4[NTW];                                               // the coming layer's biases
+    const uint4* wcur[NTW];                                         // the current layer's column tiles of this wave (+ lane)
+    const uint4* wnext[NTW];                                        // the coming layer's, its k-block count
+    int kbnext = 1;
+    auto prep_bias = [&](int l) {
+        const MvLayerBf& Ln = net.L[l];
+        const int NTn = (l == nl - 1) ? 1 : Ln.NT, c0 = w * ((NTn + NW - 1) / NW);
+        kbnext = Ln.KB;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int tile = c0 + t < NTn ? c0 + t : NTn - 1;                                // tiles past the layer's last: clamped (loaded, unused)
+            wnext[t] = Ln.wp + (size_t)tile * kbnext * 64 + lane;
+            bias4[t] = *(const f32x4*)(Ln.bias + tile * 16 + 4 * q);
+        }
+    };
+    auto prep_chunk = [&](int from, int g, int G) {
+        if constexpr (CARRY) {
+            const int CH = (PD - from) * NTW / G;
+#pragma unroll
+            for (int j = 0; j < (PD - from) * NTW; ++j) {
+                if (j / CH == g || (g == G - 1 && j / CH >= G)) {
+                    const int idx = from * NTW + j, d = idx / NTW, t = idx % NTW;
+                    const int kb = d < kbnext ? d : kbnext - 1;                              // clamped: no branch around a load
+                    b[d][t] = wnext[t][kb * 64];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    prep_bias(0);
+    prep_chunk(0, 0, 1);
+    mv_pe_rows_bs<NTHREADS, NS>(pts, pe, act, S16, TS, rows, net.multires, net.L[0].KB * 32, tid);
+    for (int l = 0; l < nl - 1; ++l) {
+        const MvLayerBf& L = net.L[l];
+        const int NT = L.NT, KB = kbnext;
+        const int per = (NT + NW - 1) / NW;
+        const int ct0 = w * per;
+        int ntw = NT - ct0; ntw = ntw < 0 ? 0 : (ntw > per ? per : ntw);
+        f32x4 acc[MTc][NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            wcur[t] = wnext[t];
+#pragma unroll
+            for (int a = 0; a < MTc; ++a) acc[a][t] = bias4[t];
+        }
+        prep_bias(l + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // inputs of layer l complete (LDS)
+        if constexpr (CARRY) mv_gemm_carried_bs<MTc, NTW, PD, PDR, NS>(KB, act, S16, TS, wcur, ntw, acc, lane, b, wnext, kbnext);
+        else if (ntw > 0) mv_gemm_rolling_dispatch_bs<MTc, NTW, NS>(KB, act, S16, TS, wcur[0], ntw, acc, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every wave done reading act (in-place update)
+        {
+            const float sc = mv_skip_at(net.skip_mask, l + 1) ? 0.7071067690849304f : 1.0f;   // cat([x, input]) / sqrt(2), idr.py:86-87 (x 1 is exact)
+            const int N = L.N;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int col0 = (ct0 + t) * 16 + 4 * q;
+#pragma unroll
+                for (int a = 0; a < MTc; ++a) {
+                    if (t < ntw) {
+                        const dm_f2 h0 = mv_softplus100_acc2(dm_f2{acc[a][t][0], acc[a][t][1]}) * dm2_s(sc);      // Softplus(beta=100), idr.py:91-92
+                        const dm_f2 h1 = mv_softplus100_acc2(dm_f2{acc[a][t][2], acc[a][t][3]}) * dm2_s(sc);
+                        uint32_t p0[NS], p1[NS];
+                        mv_split_pk<NS>(h0, p0);
+                        mv_split_pk<NS>(h1, p1);
+                        uint16_t* dst = act + (a * 16 + r) * S16 + col0;
+                        if ((ct0 + t) * 16 + 16 <= N) {                                                           // (wave-uniform)
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) *(uint2*)(dst + s * TS) = uint2{p0[s], p1[s]};
+                        } else {                                                                                  // the layer's last, partial tile
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) {
+                                if (col0 < N) dst[s * TS] = (uint16_t)p0[s];
+                                if (col0 + 1 < N) dst[s * TS + 1] = (uint16_t)(p0[s] >> 16);
+                                if (col0 + 2 < N) dst[s * TS + 2] = (uint16_t)p1[s];
+                                if (col0 + 3 < N) dst[s * TS + 3] = (uint16_t)(p1[s] >> 16);
+                            }
+                        }
+                    }
+                    if constexpr (CARRY) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        prep_chunk(PDR, t * MTc + a, MTc * NTW);                                                  // outside the branch: nothing conditional writes `b`
+                    }
+                }
+            }
+            const MvLayerBf& Ln = net.L[l + 1];
+            const int Kb = Ln.K, Kp = Ln.KB * 32;
+            if (sc != 1.0f) {                                                     // PE part of the skip input
+                for (int idx = tid; idx < rows * d0; idx += NTHREADS) {
+                    const int row = idx / d0, j = idx - row * d0;
+                    uint16_t p[NS];
+                    mv_split_1<NS>(dm_div_sqrt2(pe[row * d0 + j]), p);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) act[s * TS + row * S16 + N + j] = p[s];
+                }
+            }
+            if (Kp > Kb) {
+                const int pad = Kp - Kb;
+                for (int idx = tid; idx < rows * pad; idx += NTHREADS) {
+                    const int row = idx / pad, j = idx - row * pad;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) act[s * TS + row * S16 + Kb + j] = 0;
+                }
+            }
+        }
+    }
+    {   // last layer: column 0 only (wave 0)
+        f32x4 acc[MTc][NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            wcur[t] = wnext[t];
+#pragma unroll
+            for (int a = 0; a < MTc; ++a) acc[a][t] = bias4[t];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (w == 0) {
+            if constexpr (CARRY) mv_gemm_carried_bs<MTc, NTW, PD, 0, NS>(kbnext, act, S16, TS, wcur, 1, acc, lane, b, wcur, 1);
+            else mv_gemm_rolling_bs<MTc, 1, NTW, 4, NS>(kbnext, act, S16, TS, wcur[0], acc, lane);
+            if (q == 0) {
+#pragma unroll
+                for (int a = 0; a < MTc; ++a) out[a * 16 + r] = acc[a][0][0];
+            }
+        }
+    }
+    __syncthreads();
+}

@@ -19,6 +19,7 @@
 #include <type_traits>
 #include "tile_engine.h"
 #include "tile_engine_bf16.h"
+#include "tile_engine_bf16s.h"
 #include "trace_params.h"
 
 struct RayCommon {
@@ -44,7 +45,8 @@ __device__ __forceinline__ bool mv_sphere_isect(const float* c, const float* d, 
     return hit;
 }
 
-// NET = MvNet (fp32 weights, fp32-input MFMA, bit-exact vs the oracle) or MvNetBf (bf16 weights / activations, bf16 MFMA): overloads of mv_sdf_eval_col0
+// NET = MvNet (fp32 weights, fp32-input MFMA, bit-exact vs the oracle), MvNetBf (bf16 weights / activations, bf16 MFMA) or MvNetBs<NS> (bf16 weights,
+// activations as NS bf16 terms, bf16 MFMA: tile_engine_bf16s.h): overloads of mv_sdf_eval_col0
 // XR: the weight fetch of the next layer runs under this layer's work (fp32 engine: ring carried across layers, one row tile only; bf16 engine:
 // the CARRIED scheme of tile_engine_bf16.h) -- for k_sphere_trace, whose evaluations wait for each other; costs registers
 template <int MT, int NTW, int NW, class NET, bool XR = false>
@@ -1093,8 +1095,11 @@ static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTracePara
                       size_t workspace_bytes, int mt, int rpw, void* stream) {
     MvNet net;
     MvNetBf netb;
-    const bool bf = desc && desc->trace_dtype == 1;
-    int rc = bf ? mv_make_net_bf(desc, &netb) : mv_make_net_trace(desc, &net);
+    MvNetBs<2> net2;
+    MvNetBs<3> net3;
+    const int td = desc ? desc->trace_dtype : 0;
+    const bool bf = td == 1;
+    int rc = bf ? mv_make_net_bf(desc, &netb) : (td == 3 ? mv_make_net_bs(desc, &net2, 2) : (td == 4 ? mv_make_net_bs(desc, &net3, 3) : mv_make_net_trace(desc, &net)));
     if (rc) return rc;
     if (!tp || !cam_loc || !ray_dirs || !object_mask || !intervals || !points || !mask || !dists || !counters || !workspace)
         return mv_fail(-1, "mvsdf_trace: null argument");
@@ -1111,6 +1116,12 @@ static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTracePara
     if (e != hipSuccess) return mv_check(e, "mvsdf_trace: memset");
     if (bf)
         e = mv_trace_launch(stages, netb, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,
+                            minsdf_steps ? minsdf_steps : intervals, points, mask, dists, (float*)workspace, counters, s);
+    else if (td == 3)
+        e = mv_trace_launch(stages, net2, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,
+                            minsdf_steps ? minsdf_steps : intervals, points, mask, dists, (float*)workspace, counters, s);
+    else if (td == 4)
+        e = mv_trace_launch(stages, net3, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,
                             minsdf_steps ? minsdf_steps : intervals, points, mask, dists, (float*)workspace, counters, s);
     else
         e = mv_trace_launch(stages, net, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,

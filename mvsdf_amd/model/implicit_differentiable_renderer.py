@@ -116,8 +116,7 @@ class ImplicitNetwork(nn.Module):
     def native_sdf(self):
         net = self.fold()[0]
         td = getattr(self, 'trace_dtype', 'f32')
-        if td != 'f32':
-            ops.pack_bf16_net(net, weights_only=(td == 'bf16w'))
+        ops.pack_trace_net(net, td)
         return NativeSDF(net)
 
     def forward(self, input, compute_grad=False):
@@ -296,8 +295,11 @@ class IDRNetwork(nn.Module):
         evaluations -- ~90 % of the step's FLOPs, all under no_grad -- use bf16-rounded weights and activations on the bf16 MFMA with fp32
         accumulation; the differentiable passes keep fp32).  Outside the 1e-4 parity claim: see DESIGN.md for the accuracy budget.
         'bf16w': only the tracing MLP's WEIGHTS are rounded to bf16 (BASELINE configs[4] says "bf16 MLP weights"), activations and arithmetic
-        stay fp32 on the fp32 MFMA: bit-exact against the oracle on the rounded weights; the control that prices the activation rounding."""
-        assert dtype in ('f32', 'bf16', 'bf16w')
+        stay fp32 on the fp32 MFMA: bit-exact against the oracle on the rounded weights; the control that prices the activation rounding.
+        'bf16x2' / 'bf16x3': bf16 weights on the bf16 MFMA, every activation carried as 2 / 3 bf16 terms (16 / all 24 mantissa bits,
+        csrc/tile_engine_bf16s.h): the arithmetic of 'bf16w' up to the order of the fp32 additions inside the matrix core -- the configs[4] mode
+        that is fast AND parity-checked (hit masks equal to the oracle's on the rounded weights except at recorded ties, depths 1e-4)."""
+        assert dtype in ops.TRACE_DTYPES
         self.trace_dtype = dtype
         self.implicit_network.trace_dtype = dtype
         return self
@@ -343,8 +345,7 @@ class IDRNetwork(nn.Module):
             ws = bs = rws = rbs = None
         else:
             (net, ws, bs), (rnet, rws, rbs) = Fn.fold_networks([self.implicit_network.fold_spec(), self.rendering_network.fold_spec()])
-        if self.trace_dtype != 'f32':
-            ops.pack_bf16_net(net, weights_only=(self.trace_dtype == 'bf16w'))     # one more launch per step: bf16 / rounded packs for the tracer
+        ops.pack_trace_net(net, self.trace_dtype)                                  # one more launch per step: bf16 / rounded packs for the tracer
         n_dsurf_points, dsurf = 0, None
         if self.training:
             assert train_progress is not None
@@ -499,7 +500,7 @@ class IDRNetwork(nn.Module):
             skips = skips if isinstance(skips, (tuple, list)) else ((skips,) if skips >= 0 else ())
             d.skip_mask = sum(1 << int(sk) for sk in skips)
             d.multires, d.view_spec = multires, rnet.view_spec
-            d.trace_dtype = {'f32': 0, 'bf16': 1, 'bf16w': 2}[self.trace_dtype]
+            d.trace_dtype = ops.TRACE_DTYPES[self.trace_dtype]
             d.use_object_mask = 1 if conf.use_mask else 0
             d.tp = NS.TraceParams(*tpv)
             d.mt, d.mt_samples = mt, mt_samples

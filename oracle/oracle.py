@@ -128,8 +128,10 @@ def linspace01(n):
 
 def trace(net, cam_loc, dirs, object_mask, training, minsdf_steps=None, intervals=None, analytic=False,
           object_bounding_sphere=1.0, sdf_threshold=5.0e-5, line_search_step=0.5, line_step_iters=1,
-          sphere_tracing_iters=10, n_steps=100, n_secant_steps=8, dist_clip=0.5):
-    """RayTracing.forward (ray_tracing.py:27-98) -> points[R,3], mask[R] bool, dists[R], rows[4]."""
+          sphere_tracing_iters=10, n_steps=100, n_secant_steps=8, dist_clip=0.5, margins=False):
+    """RayTracing.forward (ray_tracing.py:27-98) -> points[R,3], mask[R] bool, dists[R], rows[4]
+    (+ margins[R,2] with margins=True: per ray min |sdf| and min |sdf - threshold| over every evaluation the ray made -- how far its
+    sign / convergence decisions were from flipping, the quantities make_golden.py::MarginRecorder takes from the reference)."""
     cam_loc, dirs = _f(cam_loc), _f(dirs)
     B, P = dirs.shape[:2]
     R = B * P
@@ -146,12 +148,15 @@ def trace(net, cam_loc, dirs, object_mask, training, minsdf_steps=None, interval
     else:
         nargs = net.args()
     lib().orc_set_bf16(C.c_int(1 if (net is not None and getattr(net, 'bf16', False)) else 0))
-    lib().orc_trace(C.c_int(1 if analytic else 0), *nargs, _p(cam_loc), _p(dirs), _p(om), C.c_int(B), C.c_int(P),
-                    C.c_float(object_bounding_sphere), C.c_float(sdf_threshold), C.c_float(line_search_step),
-                    C.c_int(line_step_iters), C.c_int(sphere_tracing_iters), C.c_int(n_steps), C.c_int(n_secant_steps),
-                    C.c_float(dist_clip), C.c_int(1 if training else 0), _p(intervals), _p(steps),
-                    _p(pts), _p(mask), _p(dists), _p(rows))
+    mg = np.empty((R, 2), np.float32) if margins else None
+    lib().orc_trace_m(C.c_int(1 if analytic else 0), *nargs, _p(cam_loc), _p(dirs), _p(om), C.c_int(B), C.c_int(P),
+                      C.c_float(object_bounding_sphere), C.c_float(sdf_threshold), C.c_float(line_search_step),
+                      C.c_int(line_step_iters), C.c_int(sphere_tracing_iters), C.c_int(n_steps), C.c_int(n_secant_steps),
+                      C.c_float(dist_clip), C.c_int(1 if training else 0), _p(intervals), _p(steps),
+                      _p(pts), _p(mask), _p(dists), _p(rows), _p(mg) if margins else None)
     lib().orc_set_bf16(C.c_int(0))
+    if margins:
+        return pts, mask.astype(bool), dists, rows, mg
     return pts, mask.astype(bool), dists, rows
 
 

@@ -307,6 +307,17 @@ static float eval_sdf(const sdf_ctx *c, const float *p) {
     sdf_row(c->net, p, 1, &y);
     return y;
 }
+/* eval_sdf + the ray's decision margins (what tests/golden/make_golden.py::MarginRecorder records from the reference's own values): mg[0] = min |sdf| over
+ * every evaluation of the ray (distance of any sign test from flipping), mg[1] = min |sdf - threshold| (convergence tests).  mg may be NULL. */
+static float eval_sdf_m(const sdf_ctx *c, const float *p, float thr, float *mg) {
+    float v = eval_sdf(c, p);
+    if (mg) {
+        float a = fabsf(v), t = fabsf(v - thr);
+        if (a < mg[0]) mg[0] = a;
+        if (t < mg[1]) mg[1] = t;
+    }
+    return v;
+}
 static float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 static void point_at(const float *c, const float *d, float t, float *p) {   /* cam_loc + t * dir (mul, then add) */
     p[0] = c[0] + t * d[0]; p[1] = c[1] + t * d[1]; p[2] = c[2] + t * d[2];
@@ -321,7 +332,7 @@ typedef struct {
  * rows[0..3] += sdf evaluations in sphere tracing / sampler / secant / min-sdf. ---- */
 static void trace_ray(const sdf_ctx *sc, const trace_params *tp, const float *c, const float *d, int object_mask,
                       int training, const float *intervals, const float *minsdf_steps,
-                      float *out_pt, uint8_t *out_mask, float *out_dist, long long *rows) {
+                      float *out_pt, uint8_t *out_mask, float *out_dist, long long *rows, float *mg) {
     float t0, t1, p[3];
     int isect = sphere_isect(c, d, tp->r, &t0, &t1);
     /* sphere_tracing (ray_tracing.py:101-196) */
@@ -329,8 +340,8 @@ static void trace_ray(const sdf_ctx *sc, const trace_params *tp, const float *c,
     float acc_s = isect ? t0 : 0.0f, acc_e = isect ? t1 : 0.0f;
     float min_dis = acc_s, max_dis = acc_e;
     float next_s = 0.0f, next_e = 0.0f;
-    if (unf_s) { point_at(c, d, t0, p); next_s = clampf(eval_sdf(sc, p), -tp->dist_clip, tp->dist_clip); rows[0]++; }
-    if (unf_e) { point_at(c, d, t1, p); next_e = clampf(eval_sdf(sc, p), -tp->dist_clip, tp->dist_clip); rows[0]++; }
+    if (unf_s) { point_at(c, d, t0, p); next_s = clampf(eval_sdf_m(sc, p, tp->thr, mg), -tp->dist_clip, tp->dist_clip); rows[0]++; }
+    if (unf_e) { point_at(c, d, t1, p); next_e = clampf(eval_sdf_m(sc, p, tp->thr, mg), -tp->dist_clip, tp->dist_clip); rows[0]++; }
     for (int iters = 0;; ) {
         float curr_s = unf_s ? next_s : 0.0f, curr_e = unf_e ? next_e : 0.0f;
         if (curr_s <= tp->thr) curr_s = 0.0f;
@@ -342,15 +353,15 @@ static void trace_ray(const sdf_ctx *sc, const trace_params *tp, const float *c,
         acc_s = acc_s + curr_s;
         acc_e = acc_e - curr_e;
         next_s = 0.0f; next_e = 0.0f;
-        if (unf_s) { point_at(c, d, acc_s, p); next_s = clampf(eval_sdf(sc, p), -tp->dist_clip, tp->dist_clip); rows[0]++; }
-        if (unf_e) { point_at(c, d, acc_e, p); next_e = clampf(eval_sdf(sc, p), -tp->dist_clip, tp->dist_clip); rows[0]++; }
+        if (unf_s) { point_at(c, d, acc_s, p); next_s = clampf(eval_sdf_m(sc, p, tp->thr, mg), -tp->dist_clip, tp->dist_clip); rows[0]++; }
+        if (unf_e) { point_at(c, d, acc_e, p); next_e = clampf(eval_sdf_m(sc, p, tp->thr, mg), -tp->dist_clip, tp->dist_clip); rows[0]++; }
         int np_s = next_s < 0.0f, np_e = next_e < 0.0f;
         for (int k = 0; k < tp->line_step_iters && (np_s || np_e); ++k) {
             float coef = (1.0f - tp->line_search_step) / (float)(1 << k);
             if (np_s) { acc_s -= coef * curr_s; point_at(c, d, acc_s, p);
-                        next_s = clampf(eval_sdf(sc, p), -tp->dist_clip, tp->dist_clip); rows[0]++; }
+                        next_s = clampf(eval_sdf_m(sc, p, tp->thr, mg), -tp->dist_clip, tp->dist_clip); rows[0]++; }
             if (np_e) { acc_e += coef * curr_e; point_at(c, d, acc_e, p);
-                        next_e = clampf(eval_sdf(sc, p), -tp->dist_clip, tp->dist_clip); rows[0]++; }
+                        next_e = clampf(eval_sdf_m(sc, p, tp->thr, mg), -tp->dist_clip, tp->dist_clip); rows[0]++; }
             np_s = next_s < 0.0f; np_e = next_e < 0.0f;
         }
         unf_s = unf_s && (acc_s < acc_e);
@@ -367,7 +378,7 @@ static void trace_ray(const sdf_ctx *sc, const trace_params *tp, const float *c,
         for (int i = 0; i < n; ++i) {
             zi[i] = smin + intervals[i] * (smax - smin);
             point_at(c, d, zi[i], p);
-            sv[i] = eval_sdf(sc, p); rows[1]++;
+            sv[i] = eval_sdf_m(sc, p, tp->thr, mg); rows[1]++;
         }
         int ind = 0; float best = INFINITY;              /* argmin(sign(sdf) * [n..1]), first minimum */
         for (int i = 0; i < n; ++i) {
@@ -391,7 +402,7 @@ static void trace_ray(const sdf_ctx *sc, const trace_params *tp, const float *c,
             float z_pred = -sdf_low * (z_high - z_low) / (sdf_high - sdf_low) + z_low;
             for (int i = 0; i < tp->n_secant; ++i) {
                 point_at(c, d, z_pred, p);
-                float sm = eval_sdf(sc, p); rows[2]++;
+                float sm = eval_sdf_m(sc, p, tp->thr, mg); rows[2]++;
                 if (sm > 0.0f) { z_low = z_pred; sdf_low = sm; }
                 if (sm < 0.0f) { z_high = z_pred; sdf_high = sm; }
                 z_pred = -sdf_low * (z_high - z_low) / (sdf_high - sdf_low) + z_low;
@@ -414,7 +425,7 @@ static void trace_ray(const sdf_ctx *sc, const trace_params *tp, const float *c,
             for (int i = 0; i < n; ++i) {
                 float z = minsdf_steps[i] * (max_dis - min_dis) + min_dis;
                 point_at(c, d, z, p);
-                float v = eval_sdf(sc, p); rows[3]++;
+                float v = eval_sdf_m(sc, p, tp->thr, mg); rows[3]++;
                 if (v < bv) { bv = v; bi = i; bz = z; }
             }
             (void)bi;
@@ -427,12 +438,12 @@ static void trace_ray(const sdf_ctx *sc, const trace_params *tp, const float *c,
 }
 
 /* analytic = 1: tier-0 SDF; else the MLP given by the net arrays.  object_mask: u8[R].  rows: long long[4]. */
-void orc_trace(int analytic, int n_layers, const int *in, const int *out, int skip_mask, int multires,
-               const float *Wcat, const float *bcat,
-               const float *cam_loc, const float *dirs, const uint8_t *object_mask, int B, int P,
-               float r, float thr, float line_search_step, int line_step_iters, int st_iters, int n_steps,
-               int n_secant, float dist_clip, int training, const float *intervals, const float *minsdf_steps,
-               float *points, uint8_t *mask, float *dists, long long *rows) {
+void orc_trace_m(int analytic, int n_layers, const int *in, const int *out, int skip_mask, int multires,
+                 const float *Wcat, const float *bcat,
+                 const float *cam_loc, const float *dirs, const uint8_t *object_mask, int B, int P,
+                 float r, float thr, float line_search_step, int line_step_iters, int st_iters, int n_steps,
+                 int n_secant, float dist_clip, int training, const float *intervals, const float *minsdf_steps,
+                 float *points, uint8_t *mask, float *dists, long long *rows, float *margins /* [R][2] or NULL */) {
     orc_net net;
     memset(&net, 0, sizeof(net));
     if (!analytic) make_net(&net, n_layers, in, out, skip_mask, multires, Wcat, bcat);
@@ -442,12 +453,24 @@ void orc_trace(int analytic, int n_layers, const int *in, const int *out, int sk
 #pragma omp parallel for schedule(dynamic, 8) reduction(+ : r0, r1, r2, r3)
     for (int q = 0; q < B * P; ++q) {
         long long rr[4] = {0, 0, 0, 0};
+        float *mg = margins ? margins + 2 * (size_t)q : NULL;
+        if (mg) { mg[0] = INFINITY; mg[1] = INFINITY; }
         trace_ray(&sc, &tp, cam_loc + 3 * (q / P), dirs + 3 * (size_t)q, object_mask[q], training, intervals,
-                  minsdf_steps, points + 3 * (size_t)q, mask + q, dists + q, rr);
+                  minsdf_steps, points + 3 * (size_t)q, mask + q, dists + q, rr, mg);
         r0 += rr[0]; r1 += rr[1]; r2 += rr[2]; r3 += rr[3];
     }
     rows[0] = r0; rows[1] = r1; rows[2] = r2; rows[3] = r3;
     if (!analytic) free_net(&net);
+}
+
+void orc_trace(int analytic, int n_layers, const int *in, const int *out, int skip_mask, int multires,
+               const float *Wcat, const float *bcat,
+               const float *cam_loc, const float *dirs, const uint8_t *object_mask, int B, int P,
+               float r, float thr, float line_search_step, int line_step_iters, int st_iters, int n_steps,
+               int n_secant, float dist_clip, int training, const float *intervals, const float *minsdf_steps,
+               float *points, uint8_t *mask, float *dists, long long *rows) {
+    orc_trace_m(analytic, n_layers, in, out, skip_mask, multires, Wcat, bcat, cam_loc, dirs, object_mask, B, P, r, thr, line_search_step,
+                line_step_iters, st_iters, n_steps, n_secant, dist_clip, training, intervals, minsdf_steps, points, mask, dists, rows, NULL);
 }
 
 void orc_analytic_sdf(const float *x, int n, float *y) {

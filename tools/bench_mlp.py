@@ -11,8 +11,11 @@ ap.add_argument('--W', type=int, default=256)
 ap.add_argument('--n', default='4096,16384,65536,262144')
 ap.add_argument('--mt', default='1,2,4')
 ap.add_argument('--bf16', action='store_true')
+ap.add_argument('--dtype', default='', help='f32 | bf16 | bf16w | bf16x2 | bf16x3 (overrides --bf16)')
 a = ap.parse_args()
-net = sdf_packed_net(synth.make_state_dict(a.W, 0), bf16=a.bf16)
+net = sdf_packed_net(synth.make_state_dict(a.W, 0), bf16=a.bf16 and not a.dtype)
+if a.dtype:
+    ops.pack_trace_net(net, a.dtype)
 Ft = 2 * sum(i * o for i, o in synth.sdf_layer_dims(a.W)[:-1]) + 2 * synth.sdf_layer_dims(a.W)[-1][0]
 for n in [int(v) for v in a.n.split(',')]:
     x = (torch.rand(n, 3, device='cuda') * 2 - 1)
