@@ -23,7 +23,13 @@
 template <int NS>
 struct MvNetBs : MvNetBf {};        // S = NS * (32 * KBmax + 8) / 2 floats per row (all term tiles); L[l].nsplit == 0
 
-__host__ __device__ constexpr int mv_bs_pa(int NS) { return NS == 1 ? 4 : 2; }          // activation k-blocks in flight (LDS)
+__host__ __device__ constexpr int mv_bs_pa(int NS) { return NS == 1 ? 4 : 2; }          // activation k-blocks in flight (LDS), CARRIED
+#ifndef MV_BS_PAR3
+#define MV_BS_PAR3 1
+#endif
+__host__ __device__ constexpr int mv_bs_par(int NS) { return NS >= 3 ? MV_BS_PAR3 : mv_bs_pa(NS); }   // ... ROLLING: three terms x two row tiles x two k-blocks of
+                                                                                        // A fragments are 48 registers -- with one k-block in flight the 32-row sample kernel
+                                                                                        // stays under 128 VGPRs (two workgroups per CU)
 
 // Softplus(beta=100, threshold=20) to fp32 accuracy: z > 0.2 gives t Q(t) < 2.1e-11 < ulp(z) / 2, the sum IS z (the reference's threshold branch)
 __device__ __forceinline__ dm_f2 mv_softplus100_acc2(dm_f2 z) {
@@ -162,7 +168,7 @@ __device__ __forceinline__ void mv_gemm_carried_bs(int KB, const uint16_t* __res
 // ROLLING weight fetch (the row-sample kernels), see tile_engine_bf16.h::mv_gemm_rolling_bf
 template <int MTc, int NT, int NTW, int PD, int NS>
 __device__ __forceinline__ void mv_gemm_rolling_bs(int KB, const uint16_t* __restrict__ act, int S16, int TS, const uint4* __restrict__ wp, f32x4 (&acc)[MTc][NTW], int lane) {
-    constexpr int PA = mv_bs_pa(NS);
+    constexpr int PA = mv_bs_par(NS);
     static_assert(PD % PA == 0, "weight ring depth must be a multiple of the activation ring depth");
     const uint16_t* arow = act + (lane & 15) * S16 + 8 * (lane >> 4);
     uint4 b[PD][NT], a[PA][MTc][NS];
