@@ -14,8 +14,8 @@
 //   * weights: bf16 packs of tile_engine_bf16.h WITHOUT duplicated columns (nsplit = 0: the positional-encoding columns are split like
 //     every other activation, into the term tiles);
 //   * LDS: NS term tiles [rows][S16] bf16 behind each other (term stride rows * S16), row stride 64*KB + 16 bytes (conflict-free b128 reads);
-//   * softplus: max(z, 0) + t Q(t), t = 2^(-100 log2(e) |z|) by v_exp_f32, Q = degree-8 fit of ln(1 + t) / (100 t) on [0, 1] (1.3e-7 relative
-//     in fp32 Horner form = the rounding floor; two activations per v_pk_fma_f32): ~1 ulp of the activation, the accuracy class of det_math's;
+//   * softplus: max(z, 0) + (ln 2 / 100) log2(1 + 2^(-100 log2(e) |z|)) by v_exp_f32 / v_log_f32: absolute error <= 8e-9, the accuracy class of
+//     det_math's at a quarter of its instructions (mv_softplus100_acc1 below);
 //   * everything else (bias as the accumulator's start value, transposed accumulators, the two weight-fetch schemes) as in tile_engine_bf16.h.
 #pragma once
 #include "tile_engine_bf16.h"
@@ -31,20 +31,19 @@ __host__ __device__ constexpr int mv_bs_par(int NS) { return NS >= 3 ? MV_BS_PAR
                                                                                         // A fragments are 48 registers -- with one k-block in flight the 32-row sample kernel
                                                                                         // stays under 128 VGPRs (two workgroups per CU)
 
-// Softplus(beta=100, threshold=20) to fp32 accuracy: z > 0.2 gives t Q(t) < 2.1e-11 < ulp(z) / 2, the sum IS z (the reference's threshold branch)
-__device__ __forceinline__ dm_f2 mv_softplus100_acc2(dm_f2 z) {
-    const dm_f2 t = dm_f2{__builtin_amdgcn_exp2f(fabsf(z.x) * -144.26950408889634f), __builtin_amdgcn_exp2f(fabsf(z.y) * -144.26950408889634f)};
-    dm_f2 u = dm2_s(5.232587500358932e-05f);
-    u = dm2_fma(u, t, dm2_s(-0.000295048113912344f));
-    u = dm2_fma(u, t, dm2_s(0.0007822525803931057f));
-    u = dm2_fma(u, t, dm2_s(-0.0013663186691701412f));
-    u = dm2_fma(u, t, dm2_s(0.0019105979008600116f));
-    u = dm2_fma(u, t, dm2_s(-0.002484297612681985f));
-    u = dm2_fma(u, t, dm2_s(0.003331909654662013f));
-    u = dm2_fma(u, t, dm2_s(-0.0049999491311609745f));
-    u = dm2_fma(u, t, dm2_s(0.009999999776482582f));
-    return dm2_fma(t, u, dm_f2{__builtin_amdgcn_fmed3f(z.x, 0.0f, 3.0e38f), __builtin_amdgcn_fmed3f(z.y, 0.0f, 3.0e38f)});
+// Softplus(beta=100, threshold=20) to fp32 accuracy in six instructions per activation:
+//     softplus(100 z) / 100 = max(z, 0) + (ln 2 / 100) log2(1 + t),   t = 2^(-100 log2(e) |z|)      (v_exp_f32, v_log_f32: 1 ulp each)
+// Absolute error <= 8e-9 on results up to 0.3 (= the final rounding; the degree-8 polynomial form of log(1 + t) / t measured the same 7.5e-9 and costs
+// 13 instructions).  For t below 6e-8 the sum 1 + t rounds to 1 and the result is max(z, 0) exactly: an absolute error below 6e-10, i.e. nothing against
+// the fp32 rounding of the next layer's sums -- and 100 z > 20 gives t < 2.1e-9: the reference's threshold branch (result = z) falls out by itself.
+// The engines of this family are VALU-issue-bound (PMC: ~20 VALU instructions per activation and matrix instruction, matrix pipe busy 0.17-0.24), so the
+// activation's instruction count IS their speed.
+__device__ __forceinline__ float mv_softplus100_acc1(float z) {
+    const float t = __builtin_amdgcn_exp2f(fabsf(z) * -144.26950408889634f);
+    const float lg = __builtin_amdgcn_logf(1.0f + t);
+    return fmaf(lg, 0.0069314718246459961f, __builtin_amdgcn_fmed3f(z, 0.0f, 3.0e38f));
 }
+__device__ __forceinline__ dm_f2 mv_softplus100_acc2(dm_f2 z) { return dm_f2{mv_softplus100_acc1(z.x), mv_softplus100_acc1(z.y)}; }
 
 __device__ __forceinline__ dm_f2 mv_bf_unpack2(uint32_t p) { return dm_f2{__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)}; }
 

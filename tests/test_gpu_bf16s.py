@@ -100,7 +100,7 @@ def _compare_with_oracle(tag, oracle, sd, W, cam, dirs, om, training, steps, ter
     print('   rays beyond 1e-4: %d%s' % (bad.size, ''.join(' [ray %d rel %.3g margin %.3g]' % (i, rel[i], margin[i]) for i in bad[:8])))
     assert all(margin[i] < TIE for i in bad), [(int(i), float(rel[i]), float(margin[i])) for i in bad]
     # the row counters (evaluations per stage) move only with such ties
-    assert np.abs(cnt[:4].astype(np.int64) - rows).max() <= 200 * (diff.size + bad.size) + 400
+    assert np.abs(cnt[:4].astype(np.int64) - rows).max() <= 200 * (diff.size + bad.size) + max(400, rows.max() // 100)     # (a sampler ray more or less = 100 rows)
     return mask, dists, diff.size
 
 
