@@ -3,7 +3,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include "tile_engine.h"
-#include "tile_engine_rows.h"
 #include "trace_params.h"
 #include "capi_util.h"
 #include "det_math_pk.h"
@@ -315,60 +314,6 @@ static int dispatch_col0_bf(const NET& nb, const float* x, int n, float* y, int 
     return launch_col0_bf<1, 2>(nb, x, n, y, s);
 }
 
-// throughput variant: every wave owns 16 rows for the whole network, weights staged in an LDS ring shared by the workgroup (tile_engine_rows.h)
-template <int NTL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sdf_col0_rows(MvNet net, const float* __restrict__ x, int n, float* __restrict__ y) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x;
-    MvRowsLds lds = mv_rows_carve<NTL>(smem);
-    float* pts = smem + mv_rows_lds_floats<NTL>();
-    float* out = pts + 64 * 3;
-    const int row0 = blockIdx.x * 64;
-    if (tid < 192) pts[tid] = (row0 + tid / 3 < n) ? x[3 * (size_t)row0 + tid] : 0.0f;
-    if (tid < 2 * MV_ROWS_RING) lds.full[tid] = 0;
-    for (int i = tid; i < MV_ROWS_RING * NTL * 64; i += 256) lds.ring[i] = float4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-    mv_sdf_eval_col0_rows<NTL>(net, lds, pts, out, tid);
-    if (tid < 64 && row0 + tid < n) y[row0 + tid] = out[tid];
-}
-
-template <int NTL>
-static int launch_col0_rows(const MvNet& net, const float* x, int n, float* y, hipStream_t s) {
-    const size_t lds = (mv_rows_lds_floats<NTL>() + 64 * 4) * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)k_sdf_col0_rows<NTL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return mv_check(e, "mvsdf_sdf_col0: LDS attribute");
-    hipLaunchKernelGGL((k_sdf_col0_rows<NTL>), dim3((n + 63) / 64), dim3(256), lds, s, net, x, n, y);
-    return mv_check(hipGetLastError(), "mvsdf_sdf_col0 (rows)");
-}
-
-// latency-regime variant: ONE 16-row tile per 512-thread workgroup, K-split staggered evaluation (tile_engine.h, mv_sdf_eval_col0_ks)
-template <int NTW>
-__global__ __launch_bounds__(512) void k_sdf_col0_ks(MvNet net, const float* __restrict__ x, int n, float* __restrict__ y) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, d0 = 3 + 6 * net.multires;
-    float* act0 = smem;
-    float* act1 = act0 + 16 * net.S;
-    float* pe = act1 + 16 * net.S;
-    float* pts = pe + ((16 * d0 + 3) & ~3);
-    float* out = pts + 64;
-    int* flags = (int*)(out + 16);
-    const int row0 = blockIdx.x * 16;
-    if (tid < 48) pts[tid] = (row0 + tid / 3 < n) ? x[3 * (size_t)row0 + tid] : 0.0f;
-    __syncthreads();
-    mv_sdf_eval_col0_ks<NTW>(net, act0, act1, pe, pts, out, flags, tid);
-    if (tid < 16 && row0 + tid < n) y[row0 + tid] = out[tid];
-}
-
-template <int NTW>
-static int launch_col0_ks(const MvNet& net, const float* x, int n, float* y, hipStream_t s) {
-    const int d0 = 3 + 6 * net.multires;
-    const size_t lds = ((size_t)32 * net.S + ((16 * d0 + 3) & ~3) + 64 + 16 + 4 * MV_MAXL) * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)k_sdf_col0_ks<NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return mv_check(e, "mvsdf_sdf_col0: LDS attribute");
-    hipLaunchKernelGGL((k_sdf_col0_ks<NTW>), dim3((n + 15) / 16), dim3(512), lds, s, net, x, n, y);
-    return mv_check(hipGetLastError(), "mvsdf_sdf_col0 (ks)");
-}
-
 __global__ void k_det_math(int op, const float* __restrict__ x, int n, float* __restrict__ y0, float* __restrict__ y1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -568,19 +513,7 @@ int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, in
     MvNet net;
     int rc = mv_make_net_trace(desc, &net);
     if (rc) return rc;
-    if (mt == 33) {                                             // throughput regime: row-owner waves, weights staged in LDS
-        int mx = 0, mk = 0;
-        for (int l = 0; l < net.n_layers; ++l) { if (l < net.n_layers - 1) mx = net.L[l].NT > mx ? net.L[l].NT : mx; mk = net.L[l].KB > mk ? net.L[l].KB : mk; }
-        if (mx > 16 || mk > 16) return mv_fail(-1, "mvsdf_sdf_col0: mt=33 covers hidden widths up to 256");
-        return launch_col0_rows<16>(net, x, n, y, s);
-    }
     if (mt == 49) return launch_col0<1, 2, 8, true>(net, x, n, y, s);     // the sphere tracer's engine: weight ring carried across layers
-    if (mt == 17) {                                             // latency regime: one tile per workgroup, K-split staggered evaluation
-        int mx = 0;
-        for (int l = 0; l < net.n_layers - 1; ++l) mx = net.L[l].NT > mx ? net.L[l].NT : mx;
-        if (mx > 32) return mv_fail(-1, "mvsdf_sdf_col0: network too wide");
-        return mx > 16 ? launch_col0_ks<4>(net, x, n, y, s) : launch_col0_ks<2>(net, x, n, y, s);
-    }
     const char* e = getenv("MVSDF_NW");
     const int nw_env = e ? atoi(e) : 0;
     int maxnt = 0;

@@ -44,8 +44,8 @@ def test_fold_and_mlp_bitwise(oracle, W):
     rs = np.random.RandomState(3)
     x = rs.uniform(-1.2, 1.2, size=(1000, 3)).astype(np.float32)
     ref = oracle.sdf_forward(onet, x, ncols=1)[:, 0]
-    # 17: K-split staggered single-tile evaluation; 33: row-owner waves + LDS weight ring (the two experimental engines cover widths <= 256)
-    for mt in ((1, 2, 4, 17, 33) if W <= 256 else (1, 2, 4)):
+    # 1 / 2 / 4 row tiles per workgroup; 49: the sphere tracer's form (weight ring carried across layers)
+    for mt in (1, 2, 4, 49):
         y = ops.sdf_col0(net, t(x), mt=mt).cpu().numpy()
         assert np.array_equal(y, ref), 'mt=%d max diff %g' % (mt, np.abs(y - ref).max())
     g = golden('sdf_w%d' % W)
