@@ -55,15 +55,18 @@ PEAK = {'f32': 157.3, 'bf16w': 157.3, 'bf16': 2500.0, 'bf16x2': 2500.0, 'bf16x3'
 # ALGORITHMIC multiply-add (activations as bf16 terms): `achieved` counts the algorithmic FLOPs once
 
 
-def reference_cpu_note():
+def reference_cpu():
     """The reference itself on CPU (PyTorch + MKL): it cannot travel to the GPU box, so it is timed in the build container by
-    tools/time_reference_cpu.py (the golden generator's import shim + the protocol of SURVEY 8d) and carried as data in profiles/reference_cpu.json."""
+    tools/time_reference_cpu.py (the golden generator's import shim + the protocol of SURVEY 8d) and carried as data in profiles/reference_cpu.json.
+    -> structured record for cpu_baseline.reference (None when the file is missing)."""
     try:
         d = json.load(open(os.path.join(ROOT, 'profiles', 'reference_cpu.json')))
-        per = ', '.join('%s thread(s): %.0f rays/s (%.2f s/step)' % (k, d['rays_per_s'][k], d['seconds_per_step'][k]) for k in sorted(d['rays_per_s'], key=int))
-        return 'the reference PyTorch-CPU step (%s) in the build container (%d cores), tools/time_reference_cpu.py: %s' % (d['workload'], d['container_cores'], per)
+        threads = sorted(d['rays_per_s'], key=int)
+        return {'what': d['what'], 'workload': d['workload'], 'protocol': d['protocol'], 'host': 'build container, %d cores (%s)' % (d['container_cores'], d['host']),
+                'rays_per_s_1t': d['rays_per_s'].get('1'), 'rays_per_s_all': d['rays_per_s'][threads[-1]], 'threads': int(threads[-1]),
+                'seconds_per_step_all': d['seconds_per_step'][threads[-1]], 'source': 'profiles/reference_cpu.json (tools/time_reference_cpu.py)'}
     except (OSError, ValueError, KeyError):
-        return 'no profiles/reference_cpu.json (run tools/time_reference_cpu.py where /root/reference exists)'
+        return None
 
 
 def flops_per_row(W):
@@ -139,8 +142,10 @@ def cpu_baseline(V, rays_per_view=None, views=None):
     rows = runs[0][1]
     return {'value': R / dt, 'unit': 'rays/s', 'cores': O.num_threads(), 'kind': 'port',
             'sample': '%d views x %d rays of the same scene (W=%d, V=%d): C oracle tracer (OpenMP, %d rows) + numpy float64 value/normal fwd+bwd, '
-                      'rendering fwd+bwd, feature loss fwd (its gradient omitted); median of 3 steps after 1 warm-up, %.1f s per step.  For scale: %s'
-                      % (views, rays_per_view, W, V, int(rows.sum()), dt, reference_cpu_note())}
+                      'rendering fwd+bwd, feature loss fwd (its gradient omitted); median of 3 steps after 1 warm-up, %.1f s per step'
+                      % (views, rays_per_view, W, V, int(rows.sum()), dt),
+            # the reference itself (PyTorch CPU, whole step incl. loss backward and Adam) -- measured where /root/reference exists, carried as data
+            'reference': reference_cpu()}
 
 
 def self_launch(a):
@@ -157,20 +162,46 @@ def self_launch(a):
     return subprocess.call(cmd, env=env)
 
 
-def pmc_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the PMC passes of this same command committed under profiles/ (tools/pmc_to_json.py writes the
-    file: separate --pmc FETCH_SIZE / WRITE_SIZE runs, 2 x FETCH_SIZE KB + WRITE_SIZE KB per the guide's gfx950 correction).  None when
-    there is no summary for this workload (the committed passes are of the default command: c2, fp32, 8 x 256) -- the counters cannot be read
-    from inside the process."""
-    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    try:
-        d = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    if d.get('workload') != workload:
-        return None
-    k = d.get('kernels', {}).get(kernel)
+_PMC = None
+
+
+def pmc_entry(workload, dtype, width):
+    """The PMC record of this exact command (workload, tracing dtype, width) from profiles/pmc_traffic.json, or None.  tools/pmc_to_json.py writes the
+    file from separate --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 5 --warmup 2 --no-cpu-baseline [...]` (2 x FETCH_SIZE KB + WRITE_SIZE KB
+    per the guide's gfx950 correction); the counters cannot be read from inside the process."""
+    global _PMC
+    if _PMC is None:
+        try:
+            _PMC = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+        except (OSError, ValueError):
+            _PMC = {}
+    return _PMC.get('entries', {}).get('%s|%s|%d' % (workload, dtype, width))
+
+
+def pmc_traffic(entry, kernel):
+    """HBM bytes per launch of `kernel` (mean over its launches, all template instances)."""
+    k = None if entry is None else entry.get('kernels', {}).get(kernel)
     return None if k is None else k.get('hbm_bytes_per_launch')
+
+
+def pmc_step_bytes(entry):
+    """HBM bytes of one whole step: sum over the step's own kernels of bytes per launch x launches per step."""
+    if entry is None:
+        return None
+    return sum(k['hbm_bytes_per_launch'] * k['launches_per_step'] for k in entry.get('kernels', {}).values())
+
+
+def pin_rank_cpus(local, local_world):
+    """Before any GPU call: give this rank its own slice of the host cores.  Every rank busy-polls a host-mapped sequence number once per step
+    (mvsdf_step_wait_counts) -- unpinned, the 8 polling threads of a node wander over each other's cores."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cpus) // max(1, local_world))
+        mine = cpus[local * per:(local + 1) * per] or cpus
+        os.sched_setaffinity(0, mine)
+        return len(mine)
+    except (AttributeError, OSError):
+        return None
 
 
 def main():
@@ -204,9 +235,16 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+    cpus_pinned = pin_rank_cpus(local, local_world) if world > 1 else None      # (before the first GPU call)
+    n_dev = torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        local %= max(1, torch.cuda.device_count())             # (a box with fewer GPUs than ranks: dry runs only)
+        if backend == 'nccl' and n_dev < local_world:
+            # RCCL needs one device per rank; sharing a device would only fail later, inside the first collective, with an opaque message
+            sys.exit('bench.py --gpus %d: this node shows %d GPU(s) and the backend is nccl (RCCL): one device per rank is required '
+                     '(MVSDF_DIST_BACKEND=gloo shares devices: launch-path tests only)' % (world, n_dev))
+        local %= max(1, n_dev)                                   # (gloo dry runs on a box with fewer GPUs than ranks)
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     under_launcher = 'WORLD_SIZE' in os.environ
@@ -262,10 +300,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ranks = None
     if under_launcher:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt, float(local)], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        dts = [float(t_[0]) for t_ in allr]
+        ranks = {'ms_min': min(dts) / a.steps * 1e3, 'ms_max': max(dts) / a.steps * 1e3, 'devices': len({int(t_[1]) for t_ in allr}),
+                 'cpus_per_rank': cpus_pinned}
+        dt = max(dts)                                            # the MAX over the ranks is the job's time
 
     # (every rank runs these extra steps: step() holds the gradient collective)
     # per-kernel durations of the tracer: HIP events on the launch stream around k_sphere_trace, the sampler launches and the secant /
@@ -282,10 +325,12 @@ def main():
         for _ in range(nt):
             step()
             torch.cuda.synchronize()
-            tms.append(st_native.trace_times())
+            tms.append(st_native.times())
         st_native.set_timing(False)
         ms_sphere = float(np.mean([t_[0] for t_ in tms]))
         ms_samples = float(np.mean([t_[1] + t_[2] for t_ in tms]))
+        ms_diff_fwd = float(np.mean([t_[3] for t_ in tms]))
+        ms_diff_bwd = float(np.mean([t_[4] for t_ in tms]))
     else:
         events = []
         model.ray_tracer.events = events
@@ -293,6 +338,7 @@ def main():
             step()
         torch.cuda.synchronize()
         model.ray_tracer.events = None
+        ms_diff_fwd = ms_diff_bwd = None
         ms_sphere = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
         ms_samples = float(np.mean([e[1].elapsed_time(e[2]) + e[3].elapsed_time(e[4]) if len(e) == 5 else e[1].elapsed_time(e[2]) for e in events]))
     collective_ms = None
@@ -334,6 +380,20 @@ def main():
         ms_feat = e0.elapsed_time(e1) / 20
         feat_bytes = 512 * pts.shape[0] * (1 + V)
         total_R = world * R
+        pmc = pmc_entry(a.workload, a.dtype, a.width) if world == 1 else None
+        # the differentiable half (always fp32): value + normal forward of every evaluated row, rendering net, their backward incl. the second-order SDF
+        # pass and the weight gradients = the formula's non-T terms; time = HIP events around the forward behind the tracer and around mvsdf_step_backward
+        # (no bubbles on the stream: the distances are kernel time; at c3 / the c5 share the E sample rows run beside the tracer and are not in it)
+        flops_diff = ((R + E) + 2 * (N + E)) * f_s + 3 * (N + E) * f_t + 3 * N * f_r
+        diff_k = None
+        if ms_diff_fwd is not None and ms_diff_bwd:
+            ms_diff = ms_diff_fwd + ms_diff_bwd
+            hb = None if pmc is None else sum(k['hbm_bytes_per_launch'] * k['launches_per_step'] for n_, k in pmc['kernels'].items()
+                                              if n_ in ('k_chain_fwd', 'k_chain_bwd2', 'k_delta_apply', 'k_wgrad_net', 'k_reduce_net', 'k_render_chain_fwd', 'k_render_chain_bwd',
+                                                        'k_step_bwd_assemble', 'k_fold_bwd_net', 'k_step_outputs'))
+            diff_k = {'bound': 'mfma (fp32)', 'flops_per_step': flops_diff, 'ms_per_step': ms_diff, 'ms_forward': ms_diff_fwd, 'ms_backward': ms_diff_bwd,
+                      'achieved': flops_diff / (ms_diff * 1e-3) / 1e12, 'peak': PEAK['f32'], 'frac': flops_diff / (ms_diff * 1e-3) / 1e12 / PEAK['f32'],
+                      'traffic': hb, 'traffic_GBps': None if hb is None else hb / (ms_diff * 1e-3) / 1e9}
         res = {
             'metric': 'traced rays/sec (fwd+bwd, 10 sphere iters, %d src views)' % V, 'value': total_R * a.steps / dt, 'unit': 'rays/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
@@ -346,7 +406,7 @@ def main():
                        'parallelism': 'views sharded over %d rank(s), depth maps replicated; one all-reduce(SUM) on the flat grad buffer (+ 3 loss counts)' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'k_ray_samples (fused 9-layer tracing MLP on the sampler / secant / min-sdf rows)', 'achieved': ach,
                          'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                         'traffic': pmc_traffic(a.workload if (world == 1 and a.dtype == 'f32' and a.width == 256) else None, 'k_ray_samples'),
+                         'traffic': pmc_traffic(pmc, 'k_ray_samples'),
                          'rows_per_launch': rows_samples / n_launch, 'flop_per_row': f_t, 'avg_launch_ms': ms_samples / n_launch,
                          'launches_per_step': n_launch,
                          # the two tracing-MLP kernels side by side (they take about the same time at this size)
@@ -355,16 +415,20 @@ def main():
                              'tracing (k_ray_samples + k_sphere_trace)': {'rows_per_step': rows_samples + rows_sphere, 'ms_per_step': ms_samples + ms_sphere,
                                                                           'achieved': ach_both, 'frac': ach_both / peak},
                              'k_sphere_trace': {'rows_per_step': rows_sphere, 'rows_min_sdf_tail': rows_tail, 'ms_per_step': ms_sphere, 'achieved': ach_sphere, 'frac': ach_sphere / peak,
-                                                'traffic': pmc_traffic(a.workload if (world == 1 and a.dtype == 'f32' and a.width == 256) else None, 'k_sphere_trace')},
+                                                'traffic': pmc_traffic(pmc, 'k_sphere_trace')},
+                             'differentiable': diff_k,
                              'k_feat_corr': {'bound': 'hbm', 'points': int(pts.shape[0]), 'views_per_point': 1 + V, 'bytes': feat_bytes, 'ms': ms_feat,
                                              'achieved_GBps': feat_bytes / (ms_feat * 1e-3) / 1e9, 'peak_GBps': 8000.0,
-                                             'traffic': pmc_traffic(a.workload if (world == 1 and a.dtype == 'f32' and a.width == 256) else None, 'k_feat_corr')}},
+                                             'traffic': pmc_traffic(pmc, 'k_feat_corr')}},
                          'step': {'T_trace_rows': T, 'T_reference_rows': T_ref, 'R': R, 'E': E, 'N_hit': N, 'flops_step': flops_step,
-                                  'achieved': flops_step / (dt / a.steps) / 1e12, 'frac': flops_step / (dt / a.steps) / 1e12 / peak}},
+                                  'achieved': flops_step / (dt / a.steps) / 1e12, 'frac': flops_step / (dt / a.steps) / 1e12 / peak,
+                                  'hbm_bytes': pmc_step_bytes(pmc), 'pmc_source': None if pmc is None else pmc.get('note')}},
             'loss': float(lo['loss'].detach()),
         }
         if collective_ms is not None:
             res['collective_ms'] = collective_ms
+        if ranks is not None:
+            res['ranks'] = ranks
         if world == 1 and a.variants:
             # secondary number, never `value`: the same step with the opt-in IDRNetwork.lazy_unused_outputs (the min-sdf points of non-hit rays,
             # which the training loop never reads, are evaluated only when `points` / `sdf_output` are read -- here: never)

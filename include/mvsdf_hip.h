@@ -418,6 +418,10 @@ int mvsdf_step_backward(void* step, const MvsdfStepParams* prm, int N, int n_tru
  * ms[3] = {sphere tracing, sampler rows, secant + min-sdf rows} of the last forward. */
 int mvsdf_step_set_timing(void* step, int enable);
 int mvsdf_step_trace_times(void* step, float ms[3]);
+/* ... and of the differentiable half (idr.py:240-322 forward, its backward): ms[6] = {the three above, the forward behind the tracer (fused value +
+ * normal evaluation, rendering net, output gather: no bubbles on the stream, so the event distance IS the kernel time; sample rows evaluated on the side
+ * stream beside the tracer are not in it), mvsdf_step_backward, the whole forward from the first tracer launch} of the last step. */
+int mvsdf_step_times(void* step, float ms[6]);
 
 /* ---- IDRLoss.forward / backward (loss.py:176-219) as one call each ---- */
 typedef struct {

@@ -41,8 +41,8 @@ struct Step {
     long long counts_seq;                            // forwards so far: the number the host waits for in counts_host[4]
     hipStream_t counts_stream;                       // the stream of the forward in flight (queried if the number does not arrive)
     int timing;
-    hipEvent_t ev_t[5];
-    bool timed;
+    hipEvent_t ev_t[8];                              // 0-4: around the tracer's launches; 5: end of the forward; 6 / 7: around the backward
+    bool timed, timed_bwd;
     hipStream_t side;                                // the sample rows of the fused evaluation run here, beside the tracer (created on first use)
     hipEvent_t ev_fork, ev_join;
     int split_rows;                                  // -1 undecided, 0 one launch over all rows, 1 samples beside the tracer + rays after it
@@ -205,7 +205,7 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
 void mvsdf_step_destroy(void* step) {
     Step* st = (Step*)step;
     if (!st) return;
-    if (st->timing) for (int i = 0; i < 5; ++i) hipEventDestroy(st->ev_t[i]);
+    if (st->timing) for (int i = 0; i < 8; ++i) hipEventDestroy(st->ev_t[i]);
     if (st->counts_host) { hipEventDestroy(st->ev_counts); hipHostFree(st->counts_host); }
     if (st->side) { hipStreamSynchronize(st->side); hipEventDestroy(st->ev_fork); hipEventDestroy(st->ev_join); hipStreamDestroy(st->side); }
     delete st;
@@ -215,13 +215,13 @@ int mvsdf_step_set_timing(void* step, int enable) {
     Step* st = (Step*)step;
     if (!st) return mv_fail(-1, "mvsdf_step_set_timing: null step");
     if (enable && !st->timing) {
-        for (int i = 0; i < 5; ++i) ST_HIP(hipEventCreate(&st->ev_t[i]));
+        for (int i = 0; i < 8; ++i) ST_HIP(hipEventCreate(&st->ev_t[i]));
         st->timing = 1;
     } else if (!enable && st->timing) {
-        for (int i = 0; i < 5; ++i) hipEventDestroy(st->ev_t[i]);
+        for (int i = 0; i < 8; ++i) hipEventDestroy(st->ev_t[i]);
         st->timing = 0;
     }
-    st->timed = false;
+    st->timed = false; st->timed_bwd = false;
     return 0;
 }
 
@@ -233,6 +233,17 @@ int mvsdf_step_trace_times(void* step, float ms[3]) {
     ST_HIP(hipEventElapsedTime(&b, st->ev_t[1], st->ev_t[2]));
     ST_HIP(hipEventElapsedTime(&c, st->ev_t[3], st->ev_t[4]));
     ms[0] = a; ms[1] = b; ms[2] = c;
+    return 0;
+}
+
+int mvsdf_step_times(void* step, float ms[6]) {
+    Step* st = (Step*)step;
+    if (!st || !ms || !st->timing || !st->timed) return mv_fail(-1, "mvsdf_step_times: timing is off or no forward has run");
+    if (int rc = mvsdf_step_trace_times(step, ms)) return rc;
+    ST_HIP(hipEventElapsedTime(&ms[3], st->ev_t[4], st->ev_t[5]));
+    ms[4] = 0.f;
+    if (st->timed_bwd) ST_HIP(hipEventElapsedTime(&ms[4], st->ev_t[6], st->ev_t[7]));
+    ST_HIP(hipEventElapsedTime(&ms[5], st->ev_t[0], st->ev_t[5]));
     return 0;
 }
 
@@ -300,11 +311,23 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
             if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_least = 0; }
             if (hipStreamCreateWithPriority(&st->side, hipStreamNonBlocking, prio_least) != hipSuccess) { (void)hipGetLastError(); st->side = nullptr; st->split_rows = 0; }
             else if (hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                     hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming) != hipSuccess)
-                return mv_fail(-1, "mvsdf_step_forward: hipEventCreate failed");
+                     hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming) != hipSuccess) {
+                // no events: run without the side stream from now on (every later forward would otherwise find split_rows == 1 with null events)
+                (void)hipGetLastError();
+                if (st->ev_fork) { (void)hipEventDestroy(st->ev_fork); st->ev_fork = nullptr; }
+                if (st->ev_join) { (void)hipEventDestroy(st->ev_join); st->ev_join = nullptr; }
+                (void)hipStreamDestroy(st->side);
+                st->side = nullptr; st->split_rows = 0;
+            }
         }
     }
     bool split = st->split_rows == 1;
+    // Work enqueued on the side stream writes into `fwd`.  If anything fails between the fork and the join, the caller drops the block while that work may
+    // still run, and the caching allocator (which knows the block on the MAIN stream only) could hand the memory out again: wait for the side stream first.
+    struct SideGuard {
+        hipStream_t side; bool armed;
+        ~SideGuard() { if (armed && side) (void)hipStreamSynchronize(side); }
+    } side_guard{st->side, false};
     if (split) ST_HIP(hipEventRecord(st->ev_fork, s));             // (the folded weights are ready here)
     // 2. rays + RayTracing.forward (idr.py:190-199)
     float* points = (float*)(fwd + L.points); uint8_t* mask = (uint8_t*)(fwd + L.mask); float* dists = (float*)(fwd + L.dists);
@@ -319,8 +342,9 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     if (st->timing) ST_HIP(hipEventRecord(st->ev_t[1], s));
     if (split) {                                                  // enqueued AFTER the sphere tracer: its workgroups take the CUs first
         ST_HIP(hipStreamWaitEvent(st->side, st->ev_fork, 0));
+        side_guard.armed = true;
         const int rcs = mv_sdf_forward_gather(&sdf, &sdfT, nullptr, &g, M, M, 0, E, y_eval, n_eval, (float*)(fwd + fo.sdf_ctx), st->side);
-        if (rcs == 1) split = false;                              // per-layer route: nothing was launched, one pass over all rows below
+        if (rcs == 1) { split = false; side_guard.armed = false; }   // per-layer route: nothing was launched, one pass over all rows below
         else if (rcs) return rcs;
         else ST_HIP(hipEventRecord(st->ev_join, st->side));
     }
@@ -342,7 +366,7 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     // 4. ONE fused value + normal evaluation over [samples | rays, hit first], rendering net on every sorted ray, output gather
     {
         // (the rows are gathered inside the chain kernel, which also leaves them in x_eval)
-        if (split) ST_HIP(hipStreamWaitEvent(s, st->ev_join, 0));
+        if (split) { ST_HIP(hipStreamWaitEvent(s, st->ev_join, 0)); side_guard.armed = false; }   // the main stream is ordered behind the side work from here on
         int rcf = mv_sdf_forward_gather(&sdf, &sdfT, nullptr, &g, M, M, split ? E : 0, M, y_eval, n_eval, (float*)(fwd + fo.sdf_ctx), stream);
         if (rcf == 1) {                                           // per-layer route: materialise the rows first
             const int total = M * 3;
@@ -359,6 +383,7 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     ST_TRY(mvsdf_step_outputs(R, d.n_eik, d.n_ds, st->Nout, counts, x_eval, y_eval, n_eval, inv, true_rows, rgb_sorted, d_mask, e_mask,
                               (float*)(fwd + L.rgb_values), (float*)(fwd + L.sdf_output), (float*)(fwd + L.diff_pts), (float*)(fwd + L.eik_out),
                               (float*)(fwd + L.points_hom), (float*)(fwd + L.grad_theta), (float*)(fwd + L.surf), stream));
+    if (st->timing) ST_HIP(hipEventRecord(st->ev_t[5], s));
     return 0;
 }
 
@@ -394,7 +419,7 @@ int mvsdf_step_wait_counts(void* step, long long counts[4]) {
     return 0;
 }
 
-int mvsdf_step_backward(void* step, const MvsdfStepParams* prm, int N, int n_true, int d_mask, int e_mask, int use_geo, const float* d_diff,
+static int step_backward_impl(void* step, const MvsdfStepParams* prm, int N, int n_true, int d_mask, int e_mask, int use_geo, const float* d_diff,
                         const float* d_rgb, const float* d_gth, const float* d_eo, const float* d_si, const void* fwd_, void* bwd_,
                         float* const* dv, float* const* dg, float* const* db, int accumulate, void* stream) {
     Step* st = (Step*)step;
@@ -497,6 +522,18 @@ int mvsdf_step_backward(void* step, const MvsdfStepParams* prm, int N, int n_tru
     const float* dWl[MVSDF_STEP_MAX_LAYERS]; const float* dbl[MVSDF_STEP_MAX_LAYERS];
     for (int l = 0; l < nl; ++l) { dWl[l] = dflat + st->woff[l]; dbl[l] = dflat + st->boff[l]; }
     return mvsdf_fold_backward_net(nl, prm->v, prm->g, dWl, dbl, d.N, d.K, dv, dg, db, accumulate ? 1 : 0, stream);
+}
+
+int mvsdf_step_backward(void* step, const MvsdfStepParams* prm, int N, int n_true, int d_mask, int e_mask, int use_geo, const float* d_diff,
+                        const float* d_rgb, const float* d_gth, const float* d_eo, const float* d_si, const void* fwd_, void* bwd_,
+                        float* const* dv, float* const* dg, float* const* db, int accumulate, void* stream) {
+    Step* st = (Step*)step;
+    const bool timing = st && st->timing;
+    if (timing) ST_HIP(hipEventRecord(st->ev_t[6], (hipStream_t)stream));
+    const int rc = step_backward_impl(step, prm, N, n_true, d_mask, e_mask, use_geo, d_diff, d_rgb, d_gth, d_eo, d_si, fwd_, bwd_, dv, dg, db, accumulate, stream);
+    if (rc) return rc;
+    if (timing) { ST_HIP(hipEventRecord(st->ev_t[7], (hipStream_t)stream)); st->timed_bwd = true; }
+    return 0;
 }
 
 }  // extern "C"

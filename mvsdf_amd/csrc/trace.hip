@@ -272,12 +272,38 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams
                         // kernel then ends ~70 us after its slowest tracer)
                         if (__hip_atomic_load(&counters[MV_CNT_TAIL_WGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (unsigned long long)tail.stop_left >= (unsigned long long)gridDim.x) break;
                         const long long head = (long long)__hip_atomic_load(&counters[MV_CNT_TAIL_NEXT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // a consistent look at (reserved, ready): reserved read BEFORE and AFTER ready, compiler barriers between the loads (a wave's loads
+                        // return in order; relaxed atomics on different addresses may be reordered by the compiler only).  reserved only grows and ready
+                        // follows it, so res0 == rdy == res1 means no append was in flight when `rdy` was read.
+                        const unsigned long long res0 = __hip_atomic_load(&counters[MV_CNT_N_MINSDF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("" ::: "memory");
                         const unsigned long long rdy = __hip_atomic_load(&counters[MV_CNT_TAIL_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("" ::: "memory");
                         const unsigned long long res = __hip_atomic_load(&counters[MV_CNT_N_MINSDF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const long long rows = (long long)res * tp.n_steps;
-                        if (rdy == res && head + ((long long)gridDim.x + 1) * ROWS <= rows) {
+                        long long rows = (long long)res * tp.n_steps;
+                        if (res0 == res && rdy == res && head + ((long long)gridDim.x + 1) * ROWS <= rows) {
                             take = (long long)__hip_atomic_fetch_add(&counters[MV_CNT_TAIL_NEXT], (unsigned long long)ROWS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             n_items = (int)res;
+                            // The margin assumes every other workgroup claims at most one tile between the look and the fetch-add.  A workgroup that was
+                            // stalled longer than that (another process on the GPU) may have claimed rows that do not exist YET: it owns them all the same
+                            // (the launch that follows starts behind TAIL_NEXT), so it waits until they are published or the list is final -- the tracing
+                            // workgroups do not depend on any helper, so this ends -- and evaluates what exists of the tile.  Never a dropped row.
+                            while (take + ROWS > rows) {
+                                const unsigned long long wgs = __hip_atomic_load(&counters[MV_CNT_TAIL_WGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                asm volatile("" ::: "memory");
+                                const unsigned long long a0 = __hip_atomic_load(&counters[MV_CNT_N_MINSDF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                asm volatile("" ::: "memory");
+                                const unsigned long long r1 = __hip_atomic_load(&counters[MV_CNT_TAIL_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                asm volatile("" ::: "memory");
+                                const unsigned long long a1 = __hip_atomic_load(&counters[MV_CNT_N_MINSDF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (a0 == a1 && r1 == a1) {
+                                    rows = (long long)a1 * tp.n_steps;
+                                    n_items = (int)a1;
+                                    if (wgs >= (unsigned long long)gridDim.x) break;      // every workgroup has appended: the list is final
+                                }
+                                __builtin_amdgcn_s_sleep(127);
+                            }
+                            if (take >= rows) take = -1;                                   // (claimed behind the end of the final list: nothing there)
                             break;
                         }
                         if (!tail.spin) break;

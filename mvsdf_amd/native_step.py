@@ -71,6 +71,7 @@ def _bind():
         L.mvsdf_step_backward.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 10 + [C.c_int, C.c_void_p]
         L.mvsdf_step_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.mvsdf_step_trace_times.argtypes = [C.c_void_p, C.c_void_p]
+        L.mvsdf_step_times.argtypes = [C.c_void_p, C.c_void_p]
         L.mvsdf_loss_layout.argtypes = [C.c_void_p, C.c_void_p]
         L.mvsdf_loss_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mvsdf_loss_backward.argtypes = [C.c_void_p] * 9
@@ -205,6 +206,13 @@ class NativeStep:
         check(lib().mvsdf_step_trace_times(self._h, ms), 'mvsdf_step_trace_times')
         return tuple(ms)
 
+    def times(self):
+        """-> (sphere tracing, sampler rows, secant + min-sdf rows, forward behind the tracer, backward, whole forward) in ms of the last step; the
+        stream must have been synchronised."""
+        ms = (C.c_float * 6)()
+        check(lib().mvsdf_step_times(self._h, ms), 'mvsdf_step_times')
+        return tuple(ms)
+
 
 class StepRecord:
     """What one forward leaves behind for its backward and for the output dict."""
@@ -235,6 +243,9 @@ class _NativeStepFn(torch.autograd.Function):
         eo = f.f(L.eik_out, (1, nd))
         surf = f.f(L.surf, (n_true + d.n_eik,))
         rec.keep = (nd, ne)
+        # the backward reads the parameters again (weight-norm fold backward over prm->v / g): an in-place update between this forward and its backward
+        # (forward A, forward B, backward B, opt.step(), backward A) must raise like autograd's saved-tensor check does, not mix old activations with new weights
+        rec.versions = tuple(p._version for p in rec.params if p is not None)
         ctx.rec = rec
         return diff, rgb, gth, eo, surf
 
@@ -245,6 +256,9 @@ class _NativeStepFn(torch.autograd.Function):
         if getattr(rec, 'done', False):
             raise RuntimeError('the backward of this step already ran through FlatAdam.backward (its buffers are released after one backward, '
                                'like autograd\'s)')
+        if tuple(p._version for p in rec.params if p is not None) != rec.versions:
+            raise RuntimeError('one of the variables needed for gradient computation has been modified by an inplace operation: a parameter of the '
+                               'network changed between this step\'s forward and its backward (e.g. optimizer.step() in between)')
         st = rec.step
         ups = [None if t is None else (t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()) for t in (d_diff, d_rgb, d_gth, d_eo, d_si)]
         vs, gs, bs = rec.vs, rec.gs, rec.bs
@@ -343,6 +357,8 @@ def direct_backward(loss):
         return False
     for k, t in enumerate((pts, rgb, gth, eo, sf)):              # the step node's outputs in its order, nothing else in between
         if t is None or t.grad_fn is not snode or t.output_nr != k:
+            return False
+        if t._backward_hooks or t.retains_grad:                  # register_hook / retain_grad on a step output: only the autograd engine honours them
             return False
     if not all(getattr(p, '_mv_grad_sink', False) and p.requires_grad for p in rec.params if p is not None):
         return False

@@ -16,6 +16,13 @@ from ._lib import lib, check
 from .parallel import all_reduce_sum_
 
 
+try:                                                             # torch's global optimizer step hooks (private names: absent / renamed in another build = no global hooks)
+    from torch.optim.optimizer import _global_optimizer_post_hooks as _gpost, _global_optimizer_pre_hooks as _gpre
+    _GLOBAL_HOOKS = (_gpre, _gpost)
+except ImportError:
+    _GLOBAL_HOOKS = ({}, {})
+
+
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
         params = [p for p in params if p.requires_grad]
@@ -116,7 +123,7 @@ class FlatAdam(torch.optim.Optimizer):
         torch.optim.Optimizer's step pre / post hooks run if any are registered (the profiler range torch wraps around step() is skipped:
         it costs more host time than the two launches)."""
         assert closure is None
-        from torch.optim.optimizer import _global_optimizer_post_hooks, _global_optimizer_pre_hooks
+        _global_optimizer_pre_hooks, _global_optimizer_post_hooks = _GLOBAL_HOOKS
         hooks = bool(self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _global_optimizer_pre_hooks or _global_optimizer_post_hooks)
         args, kwargs = (self,), {'closure': closure, 'grad_cap': grad_cap}
         if hooks:

@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'perf: a timing gate (relative to a micro-kernel timed in the same run); deselect with -m "gpu and not perf" on a shared GPU')
 
 
 def golden(name):
