@@ -216,7 +216,7 @@ class NativeStep:
 
 class StepRecord:
     """What one forward leaves behind for its backward and for the output dict."""
-    __slots__ = ('step', 'fwd', 'prm', 'params', 'N', 'n_true', 'counts', 'd_mask', 'e_mask', 'use_geo', 'n_layers', 'vs', 'gs', 'bs', 'keep', 'done')
+    __slots__ = ('step', 'fwd', 'prm', 'params', 'N', 'n_true', 'counts', 'd_mask', 'e_mask', 'use_geo', 'n_layers', 'vs', 'gs', 'bs', 'keep', 'done', 'versions')
 
 
 class _NativeStepFn(torch.autograd.Function):

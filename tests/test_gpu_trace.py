@@ -45,7 +45,7 @@ def test_fold_and_mlp_bitwise(oracle, W):
     x = rs.uniform(-1.2, 1.2, size=(1000, 3)).astype(np.float32)
     ref = oracle.sdf_forward(onet, x, ncols=1)[:, 0]
     # 1 / 2 / 4 row tiles per workgroup; 49: the sphere tracer's form (weight ring carried across layers)
-    for mt in (1, 2, 4, 49):
+    for mt in ((1, 2, 4, 49) if W <= 256 else (1, 2, 4)):
         y = ops.sdf_col0(net, t(x), mt=mt).cpu().numpy()
         assert np.array_equal(y, ref), 'mt=%d max diff %g' % (mt, np.abs(y - ref).max())
     g = golden('sdf_w%d' % W)
