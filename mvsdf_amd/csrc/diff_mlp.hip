@@ -219,7 +219,15 @@ static hipError_t wgrad_launch(WgradNetArgs& a, hipStream_t s) {
         L.blk0 = blk; blk += L.nbx * L.nby * L.nch;
     }
     if (a.colX) { a.col_blk0 = blk; blk += ((a.col_n + 63) / 64) * a.col_nch; }
-    if (blk > 0) hipLaunchKernelGGL(k_wgrad_net, dim3(blk), dim3(MV_THREADS), 0, s, a);
+    // XCD-aware block order (layer_kernels.h; same blocks, same arithmetic, another placement): on by default, MVSDF_WG_XCD=0 turns it off.  Round 4, rocprofv3:
+    // 92.9 -> 85.0 us at c2, 154.6 -> 153.9 at the c5 share, 310.7 -> 304.0 at c3 (round 2's two orders -- a contiguous range per XCD, and this one at c2 on the
+    // older kernel -- measured nothing)
+    static int xcd_env = -2;
+    if (xcd_env == -2) { const char* e = getenv("MVSDF_WG_XCD"); xcd_env = (e && *e) ? atoi(e) : -1; }
+    a.nblocks = blk;
+    a.xcd_runs = xcd_env >= 0 ? (xcd_env != 0) : 1;
+    const int grid = a.xcd_runs ? ((blk + 127) / 128) * 128 : blk;
+    if (blk > 0) hipLaunchKernelGGL(k_wgrad_net, dim3(grid), dim3(MV_THREADS), 0, s, a);
     return hipGetLastError();
 }
 static hipError_t wgrad_reduce(WgradNetArgs& a, hipStream_t s) {

@@ -278,6 +278,7 @@ struct WgradNetArgs {
     const float* colX; int col_ld, col_M, col_n, col_layer, col_nchunks, col_ch0, col_nch, col_blk0;
     float* colslab;
     unsigned wtotal, btotal;
+    int xcd_runs, nblocks;             // xcd_runs: runs of 16 consecutive logical blocks per XCD (the launch grid is padded to a multiple of 128); nblocks: logical blocks
 };
 
 // `scratch`: 256 floats of LDS (the caller's operand tile: a static array of its own here would push k_wgrad_net from 40 960 to 41 984 bytes of LDS, i.e.
@@ -300,12 +301,17 @@ __global__ __launch_bounds__(MV_THREADS) void k_wgrad_net(WgradNetArgs a) {
     constexpr int LD = 80;
     __shared__ __attribute__((aligned(16))) float Pt[64 * LD];
     __shared__ __attribute__((aligned(16))) float Qt[64 * LD];
-    if (a.colX && (int)blockIdx.x >= a.col_blk0) { mv_colsum_block(a, blockIdx.x - a.col_blk0, Pt); return; }
+    int bid = blockIdx.x;
+    if (a.xcd_runs) {
+        // The dispatcher places workgroup b on XCD b % 8.  The 16 output blocks of one (layer, 256-row chunk) share their operand tiles: in launch order
+        // every tile is pulled into several L2s.  Here each XCD takes RUNS of 16 consecutive logical blocks: workgroup b = 8 i + x  ->  logical block
+        // ((i >> 4) * 8 + x) * 16 + (i & 15).
+        const int x = bid & 7, i = bid >> 3;
+        bid = (((i >> 4) << 3) + x) * 16 + (i & 15);
+        if (bid >= a.nblocks) return;
+    }
+    if (a.colX && bid >= a.col_blk0) { mv_colsum_block(a, bid - a.col_blk0, Pt); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-    // (XCD-aware block orders were measured and not kept: the 16 blocks of one (layer, chunk) share their operand tiles and the dispatcher places
-    // block b on XCD b % 8, so in launch order every tile is fetched by several L2s.  A contiguous range of the logical order per XCD: 94 -> 112 us
-    // (the layers differ in cost, the XCDs get unequal shares); runs of 16 consecutive blocks per XCD, round-robin: 89-95 us, i.e. nothing.)
-    const int bid = blockIdx.x;
     int l = 0;
     while (l + 1 < a.n_layers && bid >= a.L[l + 1].blk0) ++l;
     const WgradLayer& L = a.L[l];
