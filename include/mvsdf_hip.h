@@ -8,6 +8,16 @@
  * masks are uint8 (0/1); `stream` is a hipStream_t passed as void*; every call is asynchronous on that
  * stream and returns 0 on success or a nonzero code (hipError_t value, or negative for bad arguments);
  * mvsdf_last_error() gives a message.  No call allocates or synchronises.
+ *
+ * What this boundary REFUSES (the call returns a negative code and mvsdf_last_error() names the reason; the Python mirror raises
+ * NotImplementedError / ValueError before it gets here) -- every other constructor option of the reference's three modules is accepted:
+ *   1. a skip connection into the LAST Linear of the SDF network (`skip_in` containing num_layers - 2: idr.py:46-49,86).  The tracing engines would
+ *      take it; the fused value / normal / double-backward chains start their normal chain from row 0 of the last weight matrix over ITS OWN input
+ *      width and have no PE-adjoint term there.  No conf of the reference has one (confs/ *.conf: skip_in = [4]).
+ *   2. `d_in != 3` for ImplicitNetwork (idr.py:22,34): points are 3-vectors everywhere on this path (camera rays, PE of 3 + 6 * multires columns).
+ *   3. hidden widths above 512 (column tiles per wave of the fused engines: 2 up to 256, 4 up to 512), and more than MVSDF_MAX_LAYERS = 12 Linears.
+ *   4. quaternion poses in get_camera_params (rend_util.py:49-54: the `pose.shape[1] == 7` branch): the reference switches it off
+ *      (exp_runner.py:40 train_cameras = False; scene_dataset.py hands 4 x 4 matrices); mvsdf_camera_rays takes pose[B][4][4] only.
  */
 #ifndef MVSDF_HIP_H
 #define MVSDF_HIP_H
