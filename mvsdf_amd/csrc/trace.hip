@@ -657,6 +657,8 @@ __global__ __launch_bounds__(64 * NW) void k_ray_samples(NET net, MvTraceParams 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int b = blockIdx.x;
     if (b < sec_blocks) {
+        // (s_setprio 3 for these chain waves: no change with the fp32 engine (round 2: one datapath) nor with the bf16 family (round 4: c5share bf16x2
+        // k_ray_samples 0.436-0.441 ms either way))
         mv_secant_rays<(MT > 1 ? 1 : MT), NTW, NW, NET>(net, tp, c, (int)c.counters[MV_CNT_N_SECANT], b, smem);
         return;
     }
