@@ -213,6 +213,7 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=sorted(PEAK), help="arithmetic of the no-grad tracing MLP (IDRNetwork.set_trace_dtype); the differentiable half is always fp32")
     ap.add_argument('--width', type=int, default=256, help='hidden width of both MLPs: 256 = BASELINE.json (8x256), 512 = the reference\'s shipped conf (mvsdf_dtu.conf:24,35)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shard', default='', help="R/W (tests): run as ONE process on the shard rank R of a W-rank job would get (its views, its pixels per view, its seed); no process group")
     ap.add_argument('--variants', action='store_true', help='also time the opt-in lazy_unused_outputs step (secondary number; off by default so that a profile of this command holds the headline step only)')
     a = ap.parse_args()
     global W
@@ -256,8 +257,12 @@ def main():
         dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
 
     P_unit, V = WORKLOADS[a.workload]
-    P = P_unit * world                                           # pixels per view: 2048 (c2) rays per GPU at every world size
-    per = B // world
+    srank, sworld = rank, world                                  # whose shard of how many (== rank / world unless --shard)
+    if a.shard:
+        assert world == 1, '--shard is for single-process runs'
+        srank, sworld = (int(v) for v in a.shard.split('/'))
+    P = P_unit * sworld                                          # pixels per view: 2048 (c2) rays per GPU at every world size
+    per = B // sworld
     R = per * P                                                  # rays of this rank
     conf = synth.model_conf(W)
     model = IDRNetwork(ConfigDict(conf))
@@ -268,7 +273,7 @@ def main():
     # frozen weights (lr = 0): a step on random GT collapses the scene.  Parameters, gradients and Adam moments
     # live in flat buffers: one memset, one all-reduce, two launches for grad-norm + clip + Adam.
     opt = FlatAdam(model.parameters(), lr=0.0)
-    inp, gt = make_inputs(dev, rank, world, P, V)
+    inp, gt = make_inputs(dev, srank, sworld, P, V)
 
     grad_events = None                                           # set to a list during the extra steps: (start, end) events around the gradient all-reduce
 
@@ -287,7 +292,7 @@ def main():
         opt.step(grad_cap=2.0)                                   # grad-norm + clip + Adam (idr_train.py:289-302, conf.grad_cap)
         return out, lo
 
-    torch.manual_seed(rank)                                      # ranks draw different eikonal points / min-sdf steps
+    torch.manual_seed(srank)                                     # ranks draw different eikonal points / min-sdf steps
     for _ in range(a.warmup):
         step()
     if under_launcher:

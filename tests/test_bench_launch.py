@@ -67,14 +67,24 @@ def test_eight_ranks_on_one_gpu_gloo_c4_shape_and_collective_timings():
 
 
 @pytest.mark.gpu
-def test_eight_ranks_on_one_gpu_c5_share_bf16_smoke():
-    """BASELINE configs[4] as the 8-rank run it is: --workload c5share --dtype bf16 --gpus 8 (32768 rays in total, bf16 tracing MLP)."""
-    rc, lines, err = _run(['--gpus', '8', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--workload', 'c5share', '--dtype', 'bf16'],
-                          {'MVSDF_DIST_BACKEND': 'gloo', 'OMP_NUM_THREADS': '2'}, timeout=1200)
+def test_eight_ranks_on_one_gpu_c5_share_bf16x2_against_the_single_process_shard():
+    """BASELINE configs[4] as the 8-rank run it is: --workload c5share --dtype bf16x2 --gpus 8 (32768 rays in total, bf16 weights in the tracing MLP).
+    Rank 0's tracer results must not depend on the company it keeps: its hit count and its evaluated tracer rows equal those of ONE process running
+    rank 0's shard alone (same views, same pixels, same seed)."""
+    args = ['--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--workload', 'c5share', '--dtype', 'bf16x2']
+    rc, lines, err = _run(['--gpus', '8'] + args, {'MVSDF_DIST_BACKEND': 'gloo', 'OMP_NUM_THREADS': '2'}, timeout=1200)
     assert rc == 0, err
     d = json.loads(lines[-1])
-    assert d['n_gpus'] == 8 and d['config']['rays_total'] == 32768 and d['dtype'] == 'bf16' and d['value'] > 0
+    assert d['n_gpus'] == 8 and d['config']['rays_total'] == 32768 and d['dtype'] == 'bf16x2' and d['value'] > 0
     assert d['collective_ms']['grad_all_reduce'] > 0
+    assert d['ranks']['devices'] == 1 and d['ranks']['ms_min'] <= d['ranks']['ms_max']
+    rc1, lines1, err1 = _run(['--shard', '0/8'] + args, {})
+    assert rc1 == 0, err1
+    d1 = json.loads(lines1[-1])
+    s8, s1 = d['roofline']['step'], d1['roofline']['step']
+    print('rank 0 of 8: %d hits, %d tracer rows; its shard alone: %d hits, %d tracer rows' % (s8['N_hit'], s8['T_trace_rows'], s1['N_hit'], s1['T_trace_rows']))
+    assert s8['R'] == s1['R'] == 4096
+    assert s8['N_hit'] == s1['N_hit'] and s8['T_trace_rows'] == s1['T_trace_rows'] and s8['T_reference_rows'] == s1['T_reference_rows']
 
 
 @pytest.mark.gpu

@@ -191,10 +191,11 @@ def test_bf16_step_at_the_c5_per_gpu_shape_vs_the_fp32_reference():
     rel = np.abs(depth - dref)[both] / dref[both]
     lo = IDRLoss()(out, {k: t(v) for k, v in gt.items()}, tp, B)
     print('c5 share, bf16 tracer vs fp32 reference: masks agree %.4f, depth rel p99 %.3g max %.3g' % (agree, np.percentile(rel, 99), rel.max()))
-    assert agree >= 0.995 and np.percentile(rel, 99) < 2e-3
-    n_bad = int((rel > 1e-2).sum())                               # the tail (measured: max 6e-3, none beyond 1e-2)
+    # the budget at its MEASURED values (round 3: masks 99.95 % = 3 flips of 4096, p99 1.5e-3, max 8.5e-3): a regression that triples the flips fails
+    assert agree >= 0.999 and np.percentile(rel, 99) < 2e-3
+    n_bad = int((rel > 1e-2).sum())
     print('   tail: rays with depth error > 1e-2: %d of %d' % (n_bad, rel.size))
-    assert rel.max() < 1.5e-2 and n_bad <= 1
+    assert rel.max() < 1e-2 and n_bad == 0
     for k in ('loss', 'rgb_loss', 'eikonal_loss', 'depth_loss', 'feat_loss', 'surf_loss'):
         v, ref = float(lo[k].detach().reshape(-1)[0]), float(g['loss_' + k])
         print('   %s %.6g (reference %.6g)' % (k, v, ref))
