@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- traced rays/s for one MVSDF training step (forward + loss + backward + grad-norm/clip + Adam) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5share] [--dtype f32|bf16|bf16w|bf16x2|bf16x3] [--width 256|512]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5share] [--dtype f32|f32x3|bf16|bf16w|bf16x2|bf16x3] [--width 256|512]
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process (which never touches the GPU) starts
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a child, relays
@@ -50,9 +50,9 @@ WORKLOADS = {                     # name: (pixels per view and GPU-count unit, s
 }
 FEAT_HW = (600, 800)
 P, V = WORKLOADS['c2']            # defaults of make_inputs (dev tools under tools/ set bench.B / bench.P / bench.V and call it)
-PEAK = {'f32': 157.3, 'bf16w': 157.3, 'bf16': 2500.0, 'bf16x2': 2500.0, 'bf16x3': 2500.0}    # dense MFMA TFLOP/s of the tracing MLP's matrix instruction,
+PEAK = {'f32': 157.3, 'bf16w': 157.3, 'bf16': 2500.0, 'bf16x2': 2500.0, 'bf16x3': 2500.0, 'f32x3': 2500.0}    # dense MFMA TFLOP/s of the tracing MLP's matrix instruction,
 # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32 / v_mfma_f32_16x16x32_bf16); bf16x2 / bf16x3 issue 2 / 3 bf16 matrix instructions per
-# ALGORITHMIC multiply-add (activations as bf16 terms): `achieved` counts the algorithmic FLOPs once
+# ALGORITHMIC multiply-add (activations as bf16 terms), f32x3 six (fp32 weights as three terms too): `achieved` counts the algorithmic FLOPs once
 
 
 def reference_cpu():

@@ -43,7 +43,8 @@ typedef struct {
     int skip_layer;                     /* layer whose input is cat([x, PE(x)])/sqrt(2) (idr.py:86-87), -1 if none (see skip_mask for several) */
     int multires;                       /* positional-encoding frequencies (embedder.py:38-50) */
     const void* wp16[MVSDF_MAX_LAYERS]; /* trace_dtype 1: bf16 packs made by mvsdf_pack_bf16_net (BASELINE configs[4]); 2: fp32 packs of the rounded weights
-                                         * (mvsdf_pack_bf16w_net); 3 / 4: bf16 packs made by mvsdf_pack_bf16s_net; NULL for trace_dtype 0 */
+                                         * (mvsdf_pack_bf16w_net); 3 / 4: bf16 packs made by mvsdf_pack_bf16s_net; 5: three-term packs made by mvsdf_pack_bf16x3_net;
+                                         * NULL for trace_dtype 0 */
     int trace_dtype;                    /* arithmetic of the no-grad tracing MLP (mvsdf_trace, mvsdf_sdf_col0): 0 = fp32 weights and fp32-input
                                          * MFMA (bit-exact against the oracle), 1 = bf16 weights / activations on the bf16 MFMA, fp32 accumulate,
                                          * 2 = bf16-ROUNDED WEIGHTS ONLY: wp16[l] holds an fp32 pack (mvsdf_packed_floats(N, K) floats, made by
@@ -52,7 +53,11 @@ typedef struct {
                                          * 3 / 4 = bf16 weights on the bf16 MFMA with every activation carried as 2 / 3 bf16 TERMS (a = t0 + t1 [+ t2], 16 / all 24
                                          * mantissa bits; csrc/tile_engine_bf16s.h): the arithmetic of mode 2 (idr.py:77-94 on bf16-rounded weights) up to the order
                                          * of the fp32 additions inside the matrix core -- the fast mode that is parity-checked against that oracle (hit masks
-                                         * equal except at recorded ties, depths 1e-4).  bias[] is read like in mode 1 */
+                                         * equal except at recorded ties, depths 1e-4).  bias[] is read like in mode 1,
+                                         * 5 = the fp32 weights UNROUNDED as three bf16 terms too (w = w0 + w1 + w2 exactly): the reference's fp32 Linear
+                                         * (idr.py:89) from the six exact products a_s w_j, s + j <= 2, on the bf16 MFMA -- fp32-accurate (measured closer to an
+                                         * fp64 evaluation than mode 0's fmaf chain), checked against the fp32 oracle like modes 3 / 4 against theirs; not bit-identical
+                                         * to mode 0.  bias[] is read like in mode 1 */
     unsigned skip_mask;                 /* several skip connections (skip_in with more than one entry, idr.py:46,86): bit l set = the input of layer l
                                          * is cat([x, PE(x)])/sqrt(2).  0 = use skip_layer alone.  Layer 0 and the last layer cannot be skip layers. */
 } MvsdfNetDesc;
@@ -132,6 +137,9 @@ int mvsdf_pack_bf16_net_skips(int n_layers, const float* const* w, const int* N,
 /* trace_dtype = 3 / 4: bf16 packs in the layout of mode 1 WITHOUT duplicated columns (the positional-encoding inputs are split into bf16 terms like
  * every other activation); wp16[l]: mvsdf_packed_bf16_bytes(N, K, 0) bytes.  idr.py:77-94 on bf16-rounded weights. */
 int mvsdf_pack_bf16s_net(int n_layers, const float* const* w, const int* N, const int* K, void* const* wp16, void* stream);
+/* trace_dtype = 5: the folded fp32 weights as three bf16 terms (t0 = bf16(w), t1 = bf16(w - t0), t2 = bf16(w - t0 - t1)), layout of mvsdf_pack_bf16s_net
+ * with a k-block's three term fragments behind each other; wp16[l]: 3 * mvsdf_packed_bf16_bytes(N, K, 0) bytes.  idr.py:77-94 on the fp32 weights. */
+int mvsdf_pack_bf16x3_net(int n_layers, const float* const* w, const int* N, const int* K, void* const* wp16, void* stream);
 
 /* ImplicitNetwork.forward(x)[:, 0] (idr.py:77-94) for n points: the tracing MLP alone. */
 int mvsdf_sdf_col0(const MvsdfNetDesc* net, const float* x, int n, float* y, int mt, void* stream);

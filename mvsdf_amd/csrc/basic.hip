@@ -252,6 +252,26 @@ __global__ void k_pack_bf16_net(PackBfArgs a) {
     }
 }
 
+// trace_dtype = 5: the packs of tile_engine_bf16s.h's weight-term engine: w = t0 + t1 + t2 exactly, wp[((ct * KB + kb) * 3 + term) * 64 + lane][8]
+__global__ void k_pack_bf16x3_net(PackBfArgs a) {
+    const int l = blockIdx.y;
+    const int N = a.N[l], K = a.K[l], KB = mv_bf_kb(K, 0);
+    const size_t total = 3 * mv_packed_bf16_elems(N, K, 0);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = idx & 7, lane = (idx >> 3) & 63;
+        const size_t blk = idx >> 9;
+        const int term = (int)(blk % 3), kb = (int)((blk / 3) % KB), ct = (int)(blk / 3 / KB);
+        const int o = ct * 16 + (lane & 15), kp = kb * 32 + 8 * (lane >> 4) + i;
+        uint16_t v = 0;
+        if (o < N && kp < K) {
+            float r = a.w[l][(size_t)o * K + kp];
+            v = mv_f2bf(r);
+            for (int t = 0; t < term; ++t) { r = r - mv_bf2f(v); v = mv_f2bf(r); }       // every subtraction is exact
+        }
+        a.wp[l][idx] = v;
+    }
+}
+
 // trace_dtype = 2: fp32 packs of the bf16-rounded weights (layout of k_pack, non-transposed)
 __global__ void k_pack_round_net(PackBfArgs a) {
     const int l = blockIdx.y;
@@ -478,6 +498,23 @@ int mvsdf_pack_bf16s_net(int n_layers, const float* const* w, const int* N, cons
     return mv_check(hipGetLastError(), "mvsdf_pack_bf16s_net");
 }
 
+/* trace_dtype = 5: three-term bf16 packs of the fp32 weights (3 x mvsdf_packed_bf16_bytes(N, K, 0) bytes per layer) */
+int mvsdf_pack_bf16x3_net(int n_layers, const float* const* w, const int* N, const int* K, void* const* wp16, void* stream) {
+    if (n_layers < 1 || n_layers > MV_MAXL || !w || !N || !K || !wp16) return mv_fail(-1, "mvsdf_pack_bf16x3_net: bad arguments");
+    PackBfArgs a;
+    memset(&a, 0, sizeof(a));
+    size_t maxTot = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!w[l] || !wp16[l] || N[l] <= 0 || K[l] <= 0) return mv_fail(-1, "mvsdf_pack_bf16x3_net: null layer pointer / bad dims");
+        a.w[l] = w[l]; a.wp[l] = (uint16_t*)wp16[l]; a.N[l] = N[l]; a.K[l] = K[l]; a.nsplit[l] = 0;
+        const size_t t = 3 * mv_packed_bf16_elems(N[l], K[l], 0);
+        if (t > maxTot) maxTot = t;
+    }
+    const int blocks = (int)((maxTot + 255) / 256 < 512 ? (maxTot + 255) / 256 : 512);
+    hipLaunchKernelGGL(k_pack_bf16x3_net, dim3(blocks, n_layers), dim3(256), 0, (hipStream_t)stream, a);
+    return mv_check(hipGetLastError(), "mvsdf_pack_bf16x3_net");
+}
+
 int mvsdf_pack_bf16w_net(int n_layers, const float* const* w, const int* N, const int* K, float* const* wp_rounded, void* stream) {
     if (n_layers < 1 || n_layers > MV_MAXL || !w || !N || !K || !wp_rounded) return mv_fail(-1, "mvsdf_pack_bf16w_net: bad arguments");
     PackBfArgs a;
@@ -509,6 +546,12 @@ int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, in
         int rcb = desc->trace_dtype == 3 ? mv_make_net_bs(desc, &n2, 2) : mv_make_net_bs(desc, &n3, 3);
         if (rcb) return rcb;
         return desc->trace_dtype == 3 ? dispatch_col0_bf(n2, x, n, y, mt, s) : dispatch_col0_bf(n3, x, n, y, mt, s);
+    }
+    if (desc && desc->trace_dtype == 5) {                       // fp32 weights and activations as three bf16 terms each, six products
+        MvNetBs<3, 3> n33;
+        int rcb = mv_make_net_bs(desc, &n33, 3);
+        if (rcb) return rcb;
+        return dispatch_col0_bf(n33, x, n, y, mt, s);
     }
     MvNet net;
     int rc = mv_make_net_trace(desc, &net);
@@ -550,7 +593,7 @@ struct ProloArgs {
     FoldNetArgs f;
     int blk0[MV_FOLD_MAXL + 1];          // first workgroup of each layer; blk0[n_layers] = first ray workgroup
     uint16_t* wp16[MV_FOLD_MAXL]; int nsplit[MV_FOLD_MAXL];
-    int wp16_fp32;                       // 1: wp16[l] receives the fp32 pack of the bf16-rounded weights (trace_dtype = 2) instead of the bf16 pack
+    int wp16_mode;                       // 0: bf16 pack; 1: wp16[l] receives the fp32 pack of the bf16-rounded weights (trace_dtype = 2); 2: the three-term bf16 pack (trace_dtype = 5)
     const float* uv; const float* pose; const float* Kin; int B, P; float* dirs; float* cam_loc;
     uint8_t* ones;                       // optional [B * P]: filled with 1 (the all-ones object mask of the output dict, idr.py:187)
     unsigned long long* counters;        // optional [16]: zeroed (the tracer's device counters: saves its memset node)
@@ -677,12 +720,26 @@ __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
         }
     }
     // ---- bf16 pack of the tracing MLP: tile row ct = rg
-    if (a.wp16[l] && rg < NT && a.wp16_fp32) {                                 // trace_dtype = 2: the W pack again, values rounded to bf16
+    if (a.wp16[l] && rg < NT && a.wp16_mode == 1) {                                 // trace_dtype = 2: the W pack again, values rounded to bf16
         float* dst = (float*)a.wp16[l] + (size_t)rg * KB * 256;
         for (int idx = tid; idx < KB * 256; idx += 1024) {
             const int s = idx & 3, ln = (idx >> 2) & 63, kb = idx >> 8;
             const int ol = ln & 15, i = kb * 16 + 4 * s + (ln >> 4);
             dst[idx] = (i < K) ? mv_bf2f(mv_f2bf(tile[ol * ld + i])) : 0.0f;
+        }
+    } else if (a.wp16[l] && rg < NT && a.wp16_mode == 2) {                     // trace_dtype = 5: three bf16 terms of every weight (k_pack_bf16x3_net's layout)
+        const int KB32 = mv_bf_kb(K, 0);
+        uint16_t* dst = a.wp16[l] + (size_t)rg * KB32 * 3 * 512;
+        for (int idx = tid; idx < KB32 * 3 * 512; idx += 1024) {
+            const int i = idx & 7, ln = (idx >> 3) & 63, blk = idx >> 9, term = blk % 3, kb = blk / 3;
+            const int ol = ln & 15, kp = kb * 32 + 8 * (ln >> 4) + i;
+            uint16_t v = 0;
+            if (16 * rg + ol < N && kp < K) {
+                float r = tile[ol * ld + kp];
+                v = mv_f2bf(r);
+                for (int t = 0; t < term; ++t) { r = r - mv_bf2f(v); v = mv_f2bf(r); }
+            }
+            dst[idx] = v;
         }
     } else if (a.wp16[l] && rg < NT) {
         const int ns = a.nsplit[l], KB32 = mv_bf_kb(K, ns);
@@ -697,7 +754,7 @@ __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
 }
 
 int mv_step_prologue(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w, float* const* wp,
-                     float* const* wpT, void* const* wp16, const int* nsplit, int wp16_fp32, const float* uv, const float* pose, const float* intrinsics, int B, int P,
+                     float* const* wpT, void* const* wp16, const int* nsplit, int wp16_mode, const float* uv, const float* pose, const float* intrinsics, int B, int P,
                      float* ray_dirs, float* cam_loc, uint8_t* ones, unsigned long long* counters, const float* stage_src, float* stage_a, int stage_na,
                      float* stage_b, int stage_nb, void* stream) {
     ProloArgs a;
@@ -716,7 +773,7 @@ int mv_step_prologue(int n_layers, const float* const* v, const float* const* g,
     for (int l = n_layers; l < MV_FOLD_MAXL; ++l) { a.wp16[l] = nullptr; a.nsplit[l] = 0; a.blk0[l] = blk; }
     a.blk0[n_layers] = blk;
     a.uv = uv; a.pose = pose; a.Kin = intrinsics; a.B = B; a.P = P; a.dirs = ray_dirs; a.cam_loc = cam_loc;
-    a.wp16_fp32 = wp16_fp32 ? 1 : 0;
+    a.wp16_mode = wp16_mode;
     a.ones = ones; a.counters = counters;
     a.stage_src = stage_src; a.stage_a = stage_a; a.stage_b = stage_b; a.stage_na = stage_src ? stage_na : 0; a.stage_nb = stage_src ? stage_nb : 0;
     if (stage_src && (!stage_a || !stage_b || stage_na < 0 || stage_nb < 0)) return mv_fail(-1, "mv_step_prologue: staged inputs without targets");

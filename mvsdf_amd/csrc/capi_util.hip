@@ -85,7 +85,7 @@ int mv_make_net_bs(const MvsdfNetDesc* d, MvNetBf* net, int ns) {
     memset(net, 0, sizeof(*net));
     int maxk = 0;
     for (int l = 0; l < d->n_layers; ++l) {
-        if (!d->wp16[l]) return mv_fail(-2, "net descriptor: trace_dtype = 3 / 4 without bf16 packs (mvsdf_pack_bf16s_net)");
+        if (!d->wp16[l]) return mv_fail(-2, "net descriptor: trace_dtype = 3 / 4 / 5 without bf16 packs (mvsdf_pack_bf16s_net / mvsdf_pack_bf16x3_net)");
         MvLayerBf& L = net->L[l];
         L.wp = (const uint4*)d->wp16[l];
         L.bias = d->bias[l];

@@ -71,7 +71,7 @@ void make_descs(const Step& st, const MvsdfStepParams* prm, const char* fwd, Mvs
             o->skip_layer = oT->skip_layer = m ? (single >= 0 ? single : __builtin_ctz(m)) : -1;
             o->skip_mask = (m && single < 0) ? m : 0;
             o->multires = oT->multires = d.multires;
-            o->trace_dtype = (d.trace_dtype >= 1 && d.trace_dtype <= 4) ? d.trace_dtype : 0;
+            o->trace_dtype = (d.trace_dtype >= 1 && d.trace_dtype <= 5) ? d.trace_dtype : 0;
         } else {
             o->skip_layer = oT->skip_layer = -1;
         }
@@ -154,6 +154,8 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
             fo.wp16[l] = take(mvsdf_packed_floats(d.N[l], d.K[l]) * 4);
         } else if (l < d.n_sdf && (d.trace_dtype == 3 || d.trace_dtype == 4)) {
             fo.wp16[l] = take(mvsdf_packed_bf16_bytes(d.N[l], d.K[l], 0));      // no duplicated columns: the activations are split into bf16 terms in LDS
+        } else if (l < d.n_sdf && d.trace_dtype == 5) {
+            fo.wp16[l] = take(3 * mvsdf_packed_bf16_bytes(d.N[l], d.K[l], 0));  // ... and so are the fp32 weights (three terms)
         }
     }
     L.perm = take((size_t)R * 8); fo.inv = take((size_t)R * 8); fo.true_rows = take((size_t)R * 8); fo.true_rank = take((size_t)R * 4); fo.counts = take(4 * 8);
@@ -289,7 +291,7 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
                 return mv_fail(-1, "mvsdf_step_forward: host_stage is not device-visible pinned memory");
             }
         }
-        ST_TRY(mv_step_prologue(nl, prm->v, prm->g, d.N, d.K, w, wp, wpT, wp16, nsplit, d.trace_dtype == 2 ? 1 : 0, in->uv, in->pose, in->intrinsics, d.B, d.P, ray_dirs, cam_loc,
+        ST_TRY(mv_step_prologue(nl, prm->v, prm->g, d.N, d.K, w, wp, wpT, wp16, nsplit, d.trace_dtype == 2 ? 1 : (d.trace_dtype == 5 ? 2 : 0), in->uv, in->pose, in->intrinsics, d.B, d.P, ray_dirs, cam_loc,
                                 (uint8_t*)(fwd + L.object_mask_out), (unsigned long long*)(fwd + L.counters), stage_dev, (float*)in->minsdf_steps, d.tp.n_steps,
                                 (float*)in->eik_points, 3 * d.n_eik, stream));
     }

@@ -20,8 +20,9 @@
 #pragma once
 #include "tile_engine_bf16.h"
 
-template <int NS>
+template <int NS, int WT = 1>
 struct MvNetBs : MvNetBf {};        // S = NS * (32 * KBmax + 8) / 2 floats per row (all term tiles); L[l].nsplit == 0
+                                    // WT = 3 (trace_dtype 5): fp32 WEIGHTS as three bf16 terms too (packs of mvsdf_pack_bf16x3_net), see mv_gemm_rolling_bw
 
 __host__ __device__ constexpr int mv_bs_pa(int NS) { return NS == 1 ? 4 : 2; }          // activation k-blocks in flight (LDS), CARRIED
 #ifndef MV_BS_PAR3
@@ -228,10 +229,92 @@ __device__ __forceinline__ void mv_gemm_rolling_dispatch_bs(int KB, const uint16
     }
 }
 
+// ---- trace_dtype 5 ("f32x3"): fp32 weights AND fp32 activations as three bf16 terms each ----
+// w = w0 + w1 + w2 and a = a0 + a1 + a2 exactly, every bf16 x bf16 product is exact in fp32, so
+//     a w = sum over s + j <= 2 of a_s w_j  +  (a1 w2 + a2 w1 + a2 w2 <= 3 * 2^-24 |a w|):
+// the fp32 Linear of the reference (idr.py:89) from SIX matrix instructions of 16 cycles per 32-wide k-block instead of eight of 32 cycles, accumulated by
+// the matrix core (measured against an fp64 evaluation the three-term engine is CLOSER than the k-ascending fp32 fmaf chain: rms 2.0e-7 vs 4.2e-7 on
+// |sdf| ~ 1, tools/micro/f32s/acc_probe.py).  Pack layout: wp[((ct * KB + kb) * WT + j) * 64 + lane] (a wave's WT fragments of a k-block are adjacent).
+// ROLLING fetch only (a carried ring would hold WT x the registers); DEEP (k_sphere_trace, one workgroup per CU): four k-blocks of weights in flight, else two.
+template <int MTc, int NT, int NTW, int PD, int NS, int WT>
+__device__ __forceinline__ void mv_gemm_rolling_bw(int KB, const uint16_t* __restrict__ act, int S16, int TS, const uint4* __restrict__ wp, f32x4 (&acc)[MTc][NTW], int lane) {
+    constexpr int TOP = (NS > WT ? NS : WT) - 1;                    // products a_s w_j with s + j <= TOP
+    const uint16_t* arow = act + (lane & 15) * S16 + 8 * (lane >> 4);
+    uint4 b[PD][NT][WT], a[MTc][NS];
+    const uint4* wt[NT];                                            // column tile t of this wave: k-block kb's term j at wt[t][(kb * WT + j) * 64] (j * 1 KiB: an immediate offset)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wt[t] = wp + (size_t)t * KB * WT * 64;
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+        const int kb = d < KB ? d : KB - 1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < WT; ++j) b[d][t][j] = wt[t][(kb * WT + j) * 64];
+    }
+#pragma unroll
+    for (int r = 0; r < MTc; ++r)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a[r][s] = *(const uint4*)(arow + s * TS + r * 16 * S16);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kb0 = 0; kb0 < KB; kb0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            if (kb0 + d < KB) {
+#pragma unroll
+                for (int o = TOP; o >= 0; --o)                       // smallest products first
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const int j = o - s;
+                        if (j >= 0 && j < WT) {
+#pragma unroll
+                            for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                                for (int t = 0; t < NT; ++t)
+                                    acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mv_bf8, b[d][t][j]), __builtin_bit_cast(mv_bf8, a[r][s]), acc[r][t], 0, 0, 0);
+                        }
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = (kb0 + d + PD < KB) ? kb0 + d + PD : KB - 1;
+            const int ka = (kb0 + d + 1 < KB) ? kb0 + d + 1 : KB - 1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < WT; ++j) b[d][t][j] = wt[t][(kn * WT + j) * 64];
+#pragma unroll
+            for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) a[r][s] = *(const uint4*)(arow + s * TS + r * 16 * S16 + ka * 32);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int MTc, int NTW, int NS, int WT, bool DEEP>
+__device__ __forceinline__ void mv_gemm_rolling_dispatch_bw(int KB, const uint16_t* act, int S16, int TS, const uint4* wp, int ntw, f32x4 (&acc)[MTc][NTW], int lane) {
+    constexpr int PD = (DEEP && MTc * NTW <= 4) ? 4 : 2;
+    if (ntw == NTW) { mv_gemm_rolling_bw<MTc, NTW, NTW, PD, NS, WT>(KB, act, S16, TS, wp, acc, lane); return; }
+    if (NTW >= 4 && ntw == 3) { mv_gemm_rolling_bw<MTc, (NTW >= 4 ? 3 : 1), NTW, 2, NS, WT>(KB, act, S16, TS, wp, acc, lane); return; }
+    if (NTW >= 2 && ntw == 2) { mv_gemm_rolling_bw<MTc, (NTW >= 2 ? 2 : 1), NTW, PD, NS, WT>(KB, act, S16, TS, wp, acc, lane); return; }
+    if (ntw == 1) { mv_gemm_rolling_bw<MTc, 1, NTW, 4, NS, WT>(KB, act, S16, TS, wp, acc, lane); return; }
+    for (int t0 = 0; t0 < ntw; ++t0) {                              // 5..NTW-1 tiles (wide nets only): one by one
+        f32x4 tmp[MTc][NTW];
+#pragma unroll
+        for (int r = 0; r < MTc; ++r) tmp[r][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mv_gemm_rolling_bw<MTc, 1, NTW, 4, NS, WT>(KB, act, S16, TS, wp + (size_t)t0 * KB * WT * 64, tmp, lane);
+#pragma unroll
+        for (int r = 0; r < MTc; ++r)
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) if (u == t0) acc[r][u] += tmp[r][0];
+    }
+}
+
 // ImplicitNetwork.forward(...)[:, 0] for MTc*16 rows (points in LDS `pts`), bf16 weights x NS-term activations.  Result -> LDS out[row].
 // `actf` is the activation region (rows * net.S floats) = NS term tiles of bf16 [rows][S16].  All 64*NW threads must call; ends with a barrier.
-template <int MTc, int NTW, int NW = 8, bool CARRY = false, int NS = 2>
-__device__ void mv_sdf_eval_col0(const MvNetBs<NS>& net, float* actf, float* pe, const float* pts, float* out, int tid) {
+template <int MTc, int NTW, int NW = 8, bool CARRY_ = false, int NS = 2, int WT = 1>
+__device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float* pe, const float* pts, float* out, int tid) {
+    constexpr bool CARRY = CARRY_ && WT == 1;                       // weight terms: ROLLING only (CARRY_ selects the deeper ring there)
     constexpr int NTHREADS = 64 * NW, PD = mv_bf_pd(NTW, CARRY), PDR = mv_bf_pdr(NTW, CARRY);
     uint16_t* act = (uint16_t*)actf;
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
@@ -249,7 +332,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS>& net, float* actf, float* pe,
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             const int tile = c0 + t < NTn ? c0 + t : NTn - 1;                                // tiles past the layer's last: clamped (loaded, unused)
-            wnext[t] = Ln.wp + (size_t)tile * kbnext * 64 + lane;
+            wnext[t] = Ln.wp + (size_t)tile * kbnext * 64 * WT + lane;
             bias4[t] = *(const f32x4*)(Ln.bias + tile * 16 + 4 * q);
         }
     };
@@ -286,6 +369,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS>& net, float* actf, float* pe,
         prep_bias(l + 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // inputs of layer l complete (LDS)
         if constexpr (CARRY) mv_gemm_carried_bs<MTc, NTW, PD, PDR, NS>(KB, act, S16, TS, wcur, ntw, acc, lane, b, wnext, kbnext);
+        else if constexpr (WT > 1) { if (ntw > 0) mv_gemm_rolling_dispatch_bw<MTc, NTW, NS, WT, CARRY_>(KB, act, S16, TS, wcur[0], ntw, acc, lane); }
         else if (ntw > 0) mv_gemm_rolling_dispatch_bs<MTc, NTW, NS>(KB, act, S16, TS, wcur[0], ntw, acc, lane);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every wave done reading act (in-place update)
         {
@@ -354,6 +438,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS>& net, float* actf, float* pe,
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (w == 0) {
             if constexpr (CARRY) mv_gemm_carried_bs<MTc, NTW, PD, 0, NS>(kbnext, act, S16, TS, wcur, 1, acc, lane, b, wcur, 1);
+            else if constexpr (WT > 1) mv_gemm_rolling_bw<MTc, 1, NTW, 4, NS, WT>(kbnext, act, S16, TS, wcur[0], acc, lane);
             else mv_gemm_rolling_bs<MTc, 1, NTW, 4, NS>(kbnext, act, S16, TS, wcur[0], acc, lane);
             if (q == 0) {
 #pragma unroll

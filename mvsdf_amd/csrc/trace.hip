@@ -45,7 +45,7 @@ __device__ __forceinline__ bool mv_sphere_isect(const float* c, const float* d, 
     return hit;
 }
 
-// NET = MvNet (fp32 weights, fp32-input MFMA, bit-exact vs the oracle), MvNetBf (bf16 weights / activations, bf16 MFMA) or MvNetBs<NS> (bf16 weights,
+// NET = MvNet (fp32 weights, fp32-input MFMA, bit-exact vs the oracle), MvNetBf (bf16 weights / activations, bf16 MFMA) or MvNetBs<NS, WT> (bf16 weights, or with WT = 3 fp32 weights as three bf16 terms;
 // activations as NS bf16 terms, bf16 MFMA: tile_engine_bf16s.h): overloads of mv_sdf_eval_col0
 // XR: the weight fetch of the next layer runs under this layer's work (fp32 engine: ring carried across layers, one row tile only; bf16 engine:
 // the CARRIED scheme of tile_engine_bf16.h) -- for k_sphere_trace, whose evaluations wait for each other; costs registers
@@ -652,8 +652,11 @@ __device__ void mv_secant_rays(const NET& net, const MvTraceParams& tp, const Sa
 // launch would (same engine arithmetic: bit-identical).
 // The first sec_blocks workgroups run secant chains, the others evaluate sample rows of up to two row segments: the dependent
 // secant chains of a few dozen workgroups overlap with the throughput-shaped sampling.
+// (three weight terms: the 16 / 32-row shapes are held to 128 registers = two workgroups per CU like every other engine of the family)
+template <class NET> struct mv_net_wt { static constexpr int v = 1; };
+template <int NS, int WT> struct mv_net_wt<MvNetBs<NS, WT>> { static constexpr int v = WT; };
 template <int MT, int NTW, int NW, class NET>
-__global__ __launch_bounds__(64 * NW) void k_ray_samples(NET net, MvTraceParams tp, SampleCtx c, RowSeg s0, RowSeg s1, int sec_blocks) {
+__global__ __launch_bounds__(64 * NW, (mv_net_wt<NET>::v == 3 && NTW == 2 && MT <= 2 && NW == 8) ? 4 : NW / 4) void k_ray_samples(NET net, MvTraceParams tp, SampleCtx c, RowSeg s0, RowSeg s1, int sec_blocks) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int b = blockIdx.x;
     if (b < sec_blocks) {
@@ -1128,9 +1131,11 @@ static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTracePara
     MvNetBf netb;
     MvNetBs<2> net2;
     MvNetBs<3> net3;
+    MvNetBs<3, 3> net33;
     const int td = desc ? desc->trace_dtype : 0;
     const bool bf = td == 1;
-    int rc = bf ? mv_make_net_bf(desc, &netb) : (td == 3 ? mv_make_net_bs(desc, &net2, 2) : (td == 4 ? mv_make_net_bs(desc, &net3, 3) : mv_make_net_trace(desc, &net)));
+    int rc = bf ? mv_make_net_bf(desc, &netb) : (td == 3 ? mv_make_net_bs(desc, &net2, 2) : (td == 4 ? mv_make_net_bs(desc, &net3, 3) :
+             (td == 5 ? mv_make_net_bs(desc, &net33, 3) : mv_make_net_trace(desc, &net))));
     if (rc) return rc;
     if (!tp || !cam_loc || !ray_dirs || !object_mask || !intervals || !points || !mask || !dists || !counters || !workspace)
         return mv_fail(-1, "mvsdf_trace: null argument");
@@ -1153,6 +1158,9 @@ static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTracePara
                             minsdf_steps ? minsdf_steps : intervals, points, mask, dists, (float*)workspace, counters, s);
     else if (td == 4)
         e = mv_trace_launch(stages, net3, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,
+                            minsdf_steps ? minsdf_steps : intervals, points, mask, dists, (float*)workspace, counters, s);
+    else if (td == 5)
+        e = mv_trace_launch(stages, net33, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,
                             minsdf_steps ? minsdf_steps : intervals, points, mask, dists, (float*)workspace, counters, s);
     else
         e = mv_trace_launch(stages, net, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,

@@ -278,6 +278,8 @@ class IDRNetwork(nn.Module):
         self.object_bounding_sphere = conf.get_float('ray_tracer.object_bounding_sphere')
         self.last_stats = {}
         self.trace_dtype = 'f32'                                 # 'bf16': the no-grad tracing MLP runs with bf16 weights on the bf16 MFMA (set_trace_dtype)
+        if os.environ.get('MVSDF_TRACE_DTYPE'):                  # (tests: the reference fixtures on another tracing arithmetic, tests/test_gpu_f32x3.py)
+            self.set_trace_dtype(os.environ['MVSDF_TRACE_DTYPE'])
         self._counts_host = None                                 # pinned [N hit, N hit & true mask], filled while the tracer still runs
         self._counts_event = None
         self._draw = PinnedUniform()
@@ -298,7 +300,10 @@ class IDRNetwork(nn.Module):
         stay fp32 on the fp32 MFMA: bit-exact against the oracle on the rounded weights; the control that prices the activation rounding.
         'bf16x2' / 'bf16x3': bf16 weights on the bf16 MFMA, every activation carried as 2 / 3 bf16 terms (16 / all 24 mantissa bits,
         csrc/tile_engine_bf16s.h): the arithmetic of 'bf16w' up to the order of the fp32 additions inside the matrix core -- the configs[4] mode
-        that is fast AND parity-checked (hit masks equal to the oracle's on the rounded weights except at recorded ties, depths 1e-4)."""
+        that is fast AND parity-checked (hit masks equal to the oracle's on the rounded weights except at recorded ties, depths 1e-4).
+        'f32x3': the fp32 weights unrounded, as three bf16 terms like the activations: the reference's fp32 arithmetic from six exact bf16 products per
+        element pair on the bf16 MFMA -- fp32-accurate (measured closer to an fp64 evaluation than the 'f32' fmaf chain), parity-checked against the
+        fp32 oracle and the reference fixtures with the same tie rule; not bit-identical to 'f32'."""
         assert dtype in ops.TRACE_DTYPES
         self.trace_dtype = dtype
         self.implicit_network.trace_dtype = dtype

@@ -24,7 +24,7 @@ class PackedNet:
         self.skip_layers = tuple(sorted(int(s) for s in skip_layer)) if isinstance(skip_layer, (tuple, list)) else ((int(skip_layer),) if skip_layer >= 0 else ())
         self.layers, self.multires = layers, multires
         self.skip_layer = self.skip_layers[0] if self.skip_layers else -1
-        self.trace_dtype = 0                # 1: the tracing MLP runs on the bf16 packs (pack_bf16_net); 2: on fp32 packs of the bf16-rounded weights; 3 / 4: bf16 packs, activations as 2 / 3 bf16 terms
+        self.trace_dtype = 0                # 1: the tracing MLP runs on the bf16 packs (pack_bf16_net); 2: on fp32 packs of the bf16-rounded weights; 3 / 4: bf16 packs, activations as 2 / 3 bf16 terms; 5: three-term packs of the fp32 weights
 
     def desc(self, transposed=False):
         """ctypes descriptor (cached: a PackedNet is immutable once its packs exist; pack_bf16_net drops the cache)."""
@@ -43,7 +43,7 @@ class PackedNet:
         d.skip_layer, d.multires = self.skip_layer, self.multires
         if len(self.skip_layers) > 1 and not transposed:
             d.skip_mask = sum(1 << s for s in self.skip_layers)
-        if not transposed and self.trace_dtype in (1, 2, 3, 4):
+        if not transposed and self.trace_dtype in (1, 2, 3, 4, 5):
             for i, L in enumerate(self.layers):
                 d.wp16[i] = L.wp16.data_ptr()
             d.trace_dtype = self.trace_dtype
@@ -222,34 +222,38 @@ def pack_net(vs, gs, biases, skip_layer, multires, want_t=True):
     return PackedNet(layers, skip_layer, multires)
 
 
-TRACE_DTYPES = {'f32': 0, 'bf16': 1, 'bf16w': 2, 'bf16x2': 3, 'bf16x3': 4}
+TRACE_DTYPES = {'f32': 0, 'bf16': 1, 'bf16w': 2, 'bf16x2': 3, 'bf16x3': 4, 'f32x3': 5}
 
 
 def pack_trace_net(net, dtype):
     """Switch the tracing MLP of a folded SDF network to one of TRACE_DTYPES (IDRNetwork.set_trace_dtype)."""
     if dtype == 'f32':
         return net
-    return pack_bf16_net(net, weights_only=(dtype == 'bf16w'), terms={'bf16x2': 2, 'bf16x3': 3}.get(dtype, 0))
+    return pack_bf16_net(net, weights_only=(dtype == 'bf16w'), terms={'bf16x2': 2, 'bf16x3': 3, 'f32x3': 3}.get(dtype, 0), weight_terms=3 if dtype == 'f32x3' else 1)
 
 
-def pack_bf16_net(net, weights_only=False, terms=0):
+def pack_bf16_net(net, weights_only=False, terms=0, weight_terms=1):
     """bf16 MFMA packs of a folded SDF network (BASELINE configs[4], csrc/tile_engine_bf16.h): one launch; switches the network's tracing
     MLP (ops.trace, ops.sdf_col0) to bf16 weights / activations.  The differentiable passes keep the fp32 weights.
     weights_only: only the WEIGHTS are rounded to bf16 (fp32 packs of the rounded values, fp32 activations on the fp32 MFMA, trace_dtype 2):
     bit-exact against the oracle on the rounded weights.
     terms = 2 / 3: bf16 weights on the bf16 MFMA, every activation carried as 2 / 3 bf16 terms (16 / all 24 mantissa bits;
-    csrc/tile_engine_bf16s.h, trace_dtype 3 / 4): the arithmetic of weights_only up to the order of the fp32 additions, at bf16-MFMA speed."""
+    csrc/tile_engine_bf16s.h, trace_dtype 3 / 4): the arithmetic of weights_only up to the order of the fp32 additions, at bf16-MFMA speed.
+    terms = 3, weight_terms = 3 ('f32x3', trace_dtype 5): the fp32 weights UNROUNDED, as three bf16 terms like the activations -- the reference's fp32
+    Linear (idr.py:89) from six exact bf16 products per element pair on the bf16 MFMA; fp32-accurate (closer to an fp64 evaluation than the fp32
+    fmaf chain), not bit-identical to it."""
     n = len(net.layers)
     if terms:
-        assert terms in (2, 3) and not weights_only
+        assert terms in (2, 3) and not weights_only and weight_terms in (1, 3) and (weight_terms == 1 or terms == 3)
         dev = net.layers[0].bias.device
         for L in net.layers:
-            L.wp16 = torch.empty(lib().mvsdf_packed_bf16_bytes(L.N, L.K, 0), dtype=torch.uint8, device=dev)
+            L.wp16 = torch.empty(weight_terms * lib().mvsdf_packed_bf16_bytes(L.N, L.K, 0), dtype=torch.uint8, device=dev)
         N = (C.c_int * n)(*[L.N for L in net.layers])
         K = (C.c_int * n)(*[L.K for L in net.layers])
-        check(lib().mvsdf_pack_bf16s_net(n, _int_ptr_array([L.w.data_ptr() if L.w is not None else L.w_ptr for L in net.layers]), N, K,
-                                         _ptr_array([L.wp16 for L in net.layers]), stream_of(net.layers[0].bias)), 'mvsdf_pack_bf16s_net')
-        net.trace_dtype = 1 + terms
+        fn = lib().mvsdf_pack_bf16x3_net if weight_terms == 3 else lib().mvsdf_pack_bf16s_net
+        check(fn(n, _int_ptr_array([L.w.data_ptr() if L.w is not None else L.w_ptr for L in net.layers]), N, K,
+                 _ptr_array([L.wp16 for L in net.layers]), stream_of(net.layers[0].bias)), 'mvsdf_pack_bf16s_net / mvsdf_pack_bf16x3_net')
+        net.trace_dtype = 5 if weight_terms == 3 else 1 + terms
         net.__dict__.pop('_d', None)
         return net
     if weights_only:

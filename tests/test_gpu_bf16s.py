@@ -75,14 +75,15 @@ def test_the_two_weight_fetch_schemes_of_the_split_engine_agree_bit_for_bit(tmp_
         assert np.array_equal(res[0][k], res[1][k]), k
 
 
-def _compare_with_oracle(tag, oracle, sd, W, cam, dirs, om, training, steps, terms, mt, mt_samples):
-    """tracer on the split engine vs oracle.trace on the rounded weights (with the oracle's per-ray decision margins)"""
-    net = _net(sd, terms)
+def _compare_with_oracle(tag, oracle, sd, W, cam, dirs, om, training, steps, terms, mt, mt_samples, net=None, onet=None):
+    """tracer on the split engine vs oracle.trace on the rounded weights (with the oracle's per-ray decision margins)
+    net / onet: another packed network / oracle network (tests/test_gpu_f32x3.py: the three-term weights against the fp32 oracle)"""
+    net = _net(sd, terms) if net is None else net
     B, P = dirs.shape[:2]
     iv = torch.linspace(0, 1, 100)
     pts, mask, dists, cnt = ops.trace(net, t(cam), t(dirs), t(om), trace_params(W), training, iv.cuda(), t(steps), mt=mt, mt_samples=mt_samples)
     mask, dists, cnt = mask.cpu().numpy(), dists.cpu().numpy(), cnt.cpu().numpy()
-    p_o, m_o, d_o, rows, mg = oracle.trace(oracle.Net(sd, bf16='weights'), cam, dirs, om, training, steps, iv.numpy(), margins=True,
+    p_o, m_o, d_o, rows, mg = oracle.trace(oracle.Net(sd, bf16='weights') if onet is None else onet, cam, dirs, om, training, steps, iv.numpy(), margins=True,
                                            **synth.model_conf(W)['ray_tracer'])
     margin = mg.min(axis=1)
     diff = np.nonzero(mask != m_o)[0]

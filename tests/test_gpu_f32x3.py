@@ -1,0 +1,140 @@
+"""trace_dtype 'f32x3': the reference's fp32 tracing arithmetic (idr.py:77-94 inside ray_tracing.py:27-98, fp32 weights UNROUNDED) on gfx950's bf16
+matrix cores -- weights and activations as three bf16 terms each (w = w0 + w1 + w2, a = a0 + a1 + a2 exactly), the six exact products a_s w_j with
+s + j <= 2, fp32 accumulators (csrc/tile_engine_bf16s.h::mv_gemm_rolling_bw).
+
+It is not the k-ascending fmaf chain of 'f32' (whose bits the oracle reproduces), so it is checked the way 'bf16x2' / 'bf16x3' are against their
+oracle -- here against the fp32 oracle and the reference's own fixtures:
+  * SDF values: no further from an fp64 evaluation of the same network than the fp32 chain is (the claim "fp32-accurate" as a measurement);
+  * tracer: hit masks IDENTICAL to the oracle's except rays whose recorded decision margin is below 1e-6 (printed), hit depths within 1e-4;
+  * every end-to-end reference fixture of tests/test_gpu_idr.py (outputs of the imported PyTorch reference) passes with this tracer unchanged."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden
+from helpers import sdf_packed_net, t, trace_params
+from mvsdf_amd import ops
+from mvsdf_amd.utils import synth
+from test_gpu_bf16s import _compare_with_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(sd):
+    return ops.pack_bf16_net(sdf_packed_net(sd), terms=3, weight_terms=3)
+
+
+def _f64_sdf(onet, x):
+    """the oracle network's folded fp32 weights evaluated in fp64 with exact elementary functions (oracle/oracle_np.py)"""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import oracle_np
+
+    class N:
+        pass
+    m = N()
+    m.W = [w.astype(np.float64) for w in onet.W]
+    m.b = [b.astype(np.float64) for b in onet.b]
+    m.n_layers, m.multires, m.skip_layers = onet.n_layers, onet.multires, onet.skip_in
+    return oracle_np.sdf_forward(m, x, need_normal=False)[0][:, 0]
+
+
+@pytest.mark.parametrize('W', [64, 256, 512])
+def test_three_term_mlp_is_as_close_to_fp64_as_the_fp32_chain(oracle, W):
+    sd = synth.make_state_dict(W, 0)
+    x = np.random.RandomState(3).uniform(-1.2, 1.2, size=(20000, 3)).astype(np.float32)
+    onet = oracle.Net(sd)
+    ref = _f64_sdf(onet, x)
+    chain = oracle.sdf_forward(onet, x, ncols=1)[:, 0].astype(np.float64)
+    net = _net(sd)
+    ys = [ops.sdf_col0(net, t(x), mt=mt).cpu().numpy() for mt in (1, 2, 4)]
+    assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2])          # row tiling does not change a row's arithmetic
+    y = ys[0].astype(np.float64)
+    rms = lambda d: float(np.sqrt((d ** 2).mean()))
+    e_chain, e_split = chain - ref, y - ref
+    print('W=%d: |fp32 chain - fp64| max %.3g rms %.3g;  |f32x3 - fp64| max %.3g rms %.3g;  |f32x3 - chain| max %.3g' % (
+        W, np.abs(e_chain).max(), rms(e_chain), np.abs(e_split).max(), rms(e_split), np.abs(y - chain).max()))
+    assert not np.array_equal(y, chain)                                            # (another arithmetic: a bit-equal result would mean the fp32 engine ran)
+    assert rms(e_split) <= 1.1 * rms(e_chain) and np.abs(e_split).max() <= 1.5 * np.abs(e_chain).max()
+    assert np.abs(y - chain).max() < 5e-6
+
+
+@pytest.mark.parametrize('W,mode', [(64, 'train'), (256, 'eval'), (256, 'train'), (512, 'train')])
+def test_three_term_tracer_vs_the_fp32_oracle(oracle, W, mode):
+    g = golden('trace_mlp_w%d_%s' % (W, mode))
+    sd = synth.make_state_dict(W, int(g['seed']))
+    B, P = int(g['B']), int(g['P'])
+    dirs = g['ray_dirs'].reshape(B, P, 3)
+    mask, dists, ndiff = _compare_with_oracle('trace_mlp_w%d_%s f32' % (W, mode), oracle, sd, W, g['cam_loc'], dirs, np.ones(B * P, bool), mode == 'train',
+                                              g['minsdf_steps'], 3, 1, 2, net=_net(sd), onet=oracle.Net(sd))
+    iv = torch.linspace(0, 1, 100)
+    p2, m2, d2, _ = ops.trace(_net(sd), t(g['cam_loc']), t(dirs), torch.ones(B * P, dtype=torch.bool, device='cuda'), trace_params(W), mode == 'train', iv.cuda(),
+                              t(g['minsdf_steps']), mt=2, mt_samples=4)
+    assert np.array_equal(m2.cpu().numpy(), mask) and np.array_equal(d2.cpu().numpy(), dists)      # all chunkings give the same result
+    # and against the imported PyTorch reference's own outputs on these rays (the fixture): the same bar as the bit-exact engine's test
+    both = mask & g['mask']
+    rel = np.abs(dists - g['dists'])[both] / np.abs(g['dists'][both])
+    print('   vs the reference fixture: masks differ on %d rays, hit depth rel max %.3g' % (int((mask != g['mask']).sum()), rel.max()))
+    assert int((mask != g['mask']).sum()) <= ndiff + 1 and np.percentile(rel, 99.9) < 1e-4
+
+
+@pytest.mark.parametrize('name', ['idr_c2', 'idr_c3', 'idr_c5share'])
+def test_three_term_tracer_at_the_baseline_shares_vs_oracle(oracle, name):
+    """the ray batches of BASELINE configs[1], [2] and one GPU's share of [4] (training mode, the object mask of the batch)"""
+    g = golden(name)
+    W, B, P, V, seed = int(g['W']), int(g['B']), int(g['P']), int(g['V']), int(g['seed'])
+    sd = synth.make_state_dict(W, seed)
+    inp, _ = synth.make_batch(B, P, V, seed=seed, size=float(g['scene_size']), center=tuple(g['scene_center']),
+                              feat_hw=tuple(int(v) for v in g['feat_hw']), focal_scale=float(g['focal_scale']))
+    dirs, cam = ops.camera_rays(t(inp['uv']), t(inp['pose']), t(inp['intrinsics']))
+    steps = np.random.RandomState(seed).uniform(size=100).astype(np.float32)
+    om = np.asarray(inp['object_mask']).reshape(-1).astype(bool)
+    _compare_with_oracle(name, oracle, sd, W, cam.cpu().numpy(), dirs.cpu().numpy(), om, True, steps, 3, 2, 2, net=_net(sd), onet=oracle.Net(sd))
+
+
+def test_reference_fixtures_pass_with_the_three_term_tracer():
+    """Every end-to-end fixture of the imported reference (tests/test_gpu_idr.py: c1, c2, c3, the c5 share, W = 512, phase 0, the 4-step replay) with
+    MVSDF_TRACE_DTYPE=f32x3 -- same assertions, same tolerances as with the bit-exact tracer."""
+    e = dict(os.environ, MVSDF_TRACE_DTYPE='f32x3')
+    p = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', 'tests/test_gpu_idr.py'], cwd=ROOT, env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    tail = p.stdout.decode(errors='replace')[-2500:]
+    assert p.returncode == 0, tail
+    assert ' passed' in tail and 'failed' not in tail, tail
+
+
+def test_three_term_step_vs_the_bit_exact_step_at_c2():
+    """The whole training step of BASELINE configs[1] (2048 rays, 4 source views) with the f32x3 tracer against the same step with the bit-exact tracer."""
+    from mvsdf_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from mvsdf_amd.model.loss import IDRLoss
+    from mvsdf_amd.utils.config import ConfigDict
+    g = golden('idr_c2')
+    W, B, P, V, seed, tp = int(g['W']), int(g['B']), int(g['P']), int(g['V']), int(g['seed']), float(g['tp'])
+    inp, gt = synth.make_batch(B, P, V, seed=seed, size=float(g['scene_size']), center=tuple(g['scene_center']),
+                               feat_hw=tuple(int(v) for v in g['feat_hw']), focal_scale=float(g['focal_scale']))
+    cam = np.repeat(inp['pose'][:, :3, 3], P, axis=0)
+    res = {}
+    for dt in ('f32', 'f32x3'):
+        m = IDRNetwork(ConfigDict(synth.model_conf(W)))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(W, seed).items()})
+        m = m.cuda().train().set_trace_dtype(dt)
+        torch.manual_seed(seed + 5)
+        out = m({k: t(v) for k, v in inp.items()}, tp)
+        lo = IDRLoss()(out, {k: t(v) for k, v in gt.items()}, tp, B)
+        lo['loss'].backward()
+        gn = float(torch.cat([p.grad.flatten() for p in m.parameters()]).norm())
+        mask = out['network_object_mask'].cpu().numpy()
+        depth = np.linalg.norm(out['points'].detach().cpu().numpy() - cam, axis=1)
+        res[dt] = (mask, depth, {k: float(lo[k].detach().reshape(-1)[0]) for k in ('loss', 'rgb_loss', 'eikonal_loss', 'depth_loss', 'feat_loss', 'surf_loss')}, gn)
+    (m0, d0, l0, g0), (m1, d1, l1, g1) = res['f32'], res['f32x3']
+    ndiff = int((m0 != m1).sum())
+    both = m0 & m1
+    rel = np.abs(d1 - d0)[both] / d0[both]
+    dl = max(abs(l1[k] - l0[k]) / max(abs(l0[k]), 1e-3) for k in l0)
+    print('c2 step, f32x3 vs f32: masks differ on %d rays, hit depth rel max %.3g p99 %.3g, %d rays beyond 1e-4, worst loss term off by %.3g, |grad| %.6g vs %.6g' % (
+        ndiff, rel.max(), np.percentile(rel, 99), int((rel > 1e-4).sum()), dl, g1, g0))
+    assert ndiff <= 1 and int((rel > 1e-4).sum()) <= 1 and np.percentile(rel, 99) < 5e-6
+    assert dl <= 2e-4 and abs(g1 - g0) <= 1e-3 * g0
