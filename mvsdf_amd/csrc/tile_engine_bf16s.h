@@ -291,6 +291,65 @@ __device__ __forceinline__ void mv_gemm_rolling_bw(int KB, const uint16_t* __res
     }
 }
 
+// CARRIED form of the above (k_sphere_trace: its evaluations wait for each other, so the L2 latency of a layer's first weight fragments is exposed 9 times per
+// evaluation).  `b` arrives holding this layer's k-blocks 0 .. PD-1 (slot d = k-block d); inside the ring a slot whose k-block was the layer's last for it is
+// refilled with the NEXT layer's k-block of that slot (pointers wnext, count kbnext): those loads land under the last PD k-blocks' matrix instructions and the
+// epilogue.  All NTW column tiles are fetched (the pointers of tiles past the layer's last are clamped by the caller), the matrix instructions of t >= ntw skipped.
+// NT: the column tiles this wave multiplies (its first NT of NTW; 0: a wave without tiles in this layer only keeps the ring going)
+template <int MTc, int NT, int NTW, int PD, int NS, int WT>
+__device__ __forceinline__ void mv_gemm_carried_bw(int KB, const uint16_t* __restrict__ act, int S16, int TS, const uint4* const (&wcur)[NTW], f32x4 (&acc)[MTc][NTW], int lane,
+                                                   uint4 (&b)[PD][NTW][WT], const uint4* const (&wnext)[NTW], int kbnext) {
+    constexpr int TOP = (NS > WT ? NS : WT) - 1;
+    const uint16_t* arow = act + (lane & 15) * S16 + 8 * (lane >> 4);
+    uint4 a[MTc][NS];
+    if constexpr (NT > 0) {
+#pragma unroll
+        for (int r = 0; r < MTc; ++r)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) a[r][s] = *(const uint4*)(arow + s * TS + r * 16 * S16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kb0 = 0; kb0 < KB; kb0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            if (NT > 0 && kb0 + d < KB) {
+#pragma unroll
+                for (int o = TOP; o >= 0; --o)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const int j = o - s;
+                        if (j >= 0 && j < WT) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                for (int r = 0; r < MTc; ++r)
+                                    acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mv_bf8, b[d][t][j]), __builtin_bit_cast(mv_bf8, a[r][s]), acc[r][t], 0, 0, 0);
+                        }
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                // slot d: this layer's k-block kb0 + d + PD if it has one, else the next layer's k-block d (clamped: no branch around a load)
+                const bool more = kb0 + d + PD < KB;
+                const int kn = more ? kb0 + d + PD : (d < kbnext ? d : kbnext - 1);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const uint4* src = (more ? wcur[t] : wnext[t]) + (size_t)kn * WT * 64;
+#pragma unroll
+                    for (int j = 0; j < WT; ++j) b[d][t][j] = src[j * 64];
+                }
+                if constexpr (NT > 0) {
+                    const int ka = (kb0 + d + 1 < KB) ? kb0 + d + 1 : KB - 1;
+#pragma unroll
+                    for (int r = 0; r < MTc; ++r)
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) a[r][s] = *(const uint4*)(arow + s * TS + r * 16 * S16 + ka * 32);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
 template <int MTc, int NTW, int NS, int WT, bool DEEP>
 __device__ __forceinline__ void mv_gemm_rolling_dispatch_bw(int KB, const uint16_t* act, int S16, int TS, const uint4* wp, int ntw, f32x4 (&acc)[MTc][NTW], int lane) {
     constexpr int PD = (DEEP && MTc * NTW <= 4) ? 4 : 2;
@@ -321,6 +380,9 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
     const int S16 = 2 * net.S / NS, rows = MTc * 16, d0 = 3 + 6 * net.multires, TS = rows * S16;
     const int nl = net.n_layers;
     uint4 b[CARRY ? PD : 1][NTW];                                   // CARRIED: weights of the current / coming layer's first k-blocks
+    constexpr bool CARRYW = CARRY_ && WT > 1 && MTc * NTW <= 4;      // ... with weight terms (mv_gemm_carried_bw): one or two row tiles of two column tiles
+    constexpr int PDW = MTc * NTW <= 2 ? 4 : 2;
+    uint4 bw[CARRYW ? PDW : 1][NTW][WT];
     f32x4 bias4[NTW];                                               // the coming layer's biases
     const uint4* wcur[NTW];                                         // the current layer's column tiles of this wave (+ lane)
     const uint4* wnext[NTW];                                        // the coming layer's, its k-block count
@@ -352,6 +414,17 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
     };
     prep_bias(0);
     prep_chunk(0, 0, 1);
+    if constexpr (CARRYW) {                                         // layer 0's first k-blocks, requested before the positional encoding
+#pragma unroll
+        for (int d = 0; d < PDW; ++d) {
+            const int kb = d < kbnext ? d : kbnext - 1;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int j = 0; j < WT; ++j) bw[d][t][j] = wnext[t][((size_t)kb * WT + j) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     mv_pe_rows_bs<NTHREADS, NS>(pts, pe, act, S16, TS, rows, net.multires, net.L[0].KB * 32, tid);
     for (int l = 0; l < nl - 1; ++l) {
         const MvLayerBf& L = net.L[l];
@@ -369,6 +442,9 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
         prep_bias(l + 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // inputs of layer l complete (LDS)
         if constexpr (CARRY) mv_gemm_carried_bs<MTc, NTW, PD, PDR, NS>(KB, act, S16, TS, wcur, ntw, acc, lane, b, wnext, kbnext);
+        // (every wave multiplies all NTW tiles: the tiles past its share are clamped copies whose results the epilogue drops -- the waves move in lock step,
+        // a branch per tile count costs registers at the merge (72 spills) and buys nothing)
+        else if constexpr (CARRYW) mv_gemm_carried_bw<MTc, NTW, NTW, PDW, NS, WT>(KB, act, S16, TS, wcur, acc, lane, bw, wnext, kbnext);
         else if constexpr (WT > 1) { if (ntw > 0) mv_gemm_rolling_dispatch_bw<MTc, NTW, NS, WT, CARRY_>(KB, act, S16, TS, wcur[0], ntw, acc, lane); }
         else if (ntw > 0) mv_gemm_rolling_dispatch_bs<MTc, NTW, NS>(KB, act, S16, TS, wcur[0], ntw, acc, lane);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every wave done reading act (in-place update)
@@ -438,6 +514,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (w == 0) {
             if constexpr (CARRY) mv_gemm_carried_bs<MTc, NTW, PD, 0, NS>(kbnext, act, S16, TS, wcur, 1, acc, lane, b, wcur, 1);
+            else if constexpr (CARRYW) mv_gemm_carried_bw<MTc, 1, NTW, PDW, NS, WT>(kbnext, act, S16, TS, wcur, acc, lane, bw, wcur, 1);
             else if constexpr (WT > 1) mv_gemm_rolling_bw<MTc, 1, NTW, 4, NS, WT>(kbnext, act, S16, TS, wcur[0], acc, lane);
             else mv_gemm_rolling_bs<MTc, 1, NTW, 4, NS>(kbnext, act, S16, TS, wcur[0], acc, lane);
             if (q == 0) {

@@ -487,7 +487,7 @@ class IDRNetwork(nn.Module):
         """The NativeStep of this batch shape (created on first use: host-side state only)."""
         inet, rnet, rt = self.implicit_network, self.rendering_network, self.ray_tracer
         R = B * P
-        mt, mt_samples = rt.tiling(R)
+        mt, mt_samples = rt.tiling(R, ops.TRACE_DTYPES[self.trace_dtype])
         tpv = rt._params()
         key = (B, P, n_ds, str(dev), self.trace_dtype, mt, mt_samples, tpv, bool(conf.use_mask))
         st = self._steps.get(key)

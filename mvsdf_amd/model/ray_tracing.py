@@ -60,13 +60,15 @@ class RayTracing(nn.Module):
             self._intervals = (key, torch.linspace(0, 1, steps=self.n_steps).to(dev))
         return self._intervals[1]
 
-    def tiling(self, R):
+    def tiling(self, R, trace_dtype=0):
         """(row tiles per sphere-tracing workgroup, row tiles per chunk of the sample-row kernels) for R rays.  Rays per sphere-tracing
         workgroup = 8 * mt: one workgroup per CU (256 of them) while the batch allows it -- the kernel is a chain of dependent evaluations, so
         fewer, fuller workgroups beat two contending ones per CU (4096 rays: 4.17 -> 3.97 ms per step with mt = 2); 4 tiles once the chip is
         over-subscribed anyway (finer compaction of the rays still active; +6 % at 8k-32k rays)."""
         mt = self.mt or int(os.environ.get('MVSDF_MT', '0')) or (1 if R <= 2048 else (2 if R <= 4096 else 4))
-        mt_samples = self.mt_samples or int(os.environ.get('MVSDF_MT_SAMPLES', '2'))
+        # sample-row kernels: two row tiles per workgroup, two workgroups per CU; the three-weight-term engine ('f32x3', trace_dtype 5) streams 1.5x the
+        # fp32 pack per evaluation: at 2048 rays four tiles, one workgroup per CU (c2 1.60 -> 1.53 ms; 4096 rays 2.27 -> 2.31, 8192 rays equal)
+        mt_samples = self.mt_samples or int(os.environ.get('MVSDF_MT_SAMPLES', '0')) or (4 if (trace_dtype == 5 and R <= 2048) else 2)
         return mt, mt_samples
 
     def forward(self, sdf, cam_loc, object_mask, ray_directions, minsdf_steps=None, mask_ready=None, defer_minsdf=None):
@@ -92,7 +94,7 @@ class RayTracing(nn.Module):
                 mask_ready(mask)
             return pts, mask, dists
         R = ray_directions.shape[0] * ray_directions.shape[1]
-        mt, mt_samples = self.tiling(R)
+        mt, mt_samples = self.tiling(R, getattr(net, 'trace_dtype', 0))
         pts, mask, dists, counters = ops.trace(net, cam_loc, ray_directions, object_mask, self._params(), self.training, intervals,
                                                minsdf_steps, mt=mt, mt_samples=mt_samples, events=self.events,
                                                mask_ready=mask_ready, defer_minsdf=defer_minsdf)
