@@ -314,7 +314,9 @@ __device__ void mv_sdf_eval_col0(const MvNetBf& net, float* actf, float* pe, con
         MV_PH(7)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // inputs of layer l complete (LDS)
         MV_PH(1)
-        if constexpr (CARRY) mv_gemm_carried_bf<MTc, NTW, PD, PDR>(KB, act, S16, wcur, ntw, acc, lane, b, wnext, kbnext);
+        // (CARRIED: every wave multiplies all NTW column-tile slots -- the tiles past its share are clamped copies whose results the epilogue drops; the waves
+        // move in lock step, and a branch per tile count splits the matrix-instruction runs of the ring)
+        if constexpr (CARRY) mv_gemm_carried_bf<MTc, NTW, PD, PDR>(KB, act, S16, wcur, NTW, acc, lane, b, wnext, kbnext);
         else if (ntw > 0) mv_gemm_rolling_dispatch_bf<MTc, NTW>(KB, act, S16, wcur[0], ntw, acc, lane);
         MV_PH(6)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every wave done reading act (in-place update)

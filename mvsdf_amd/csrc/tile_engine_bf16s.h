@@ -441,7 +441,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
         }
         prep_bias(l + 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // inputs of layer l complete (LDS)
-        if constexpr (CARRY) mv_gemm_carried_bs<MTc, NTW, PD, PDR, NS>(KB, act, S16, TS, wcur, ntw, acc, lane, b, wnext, kbnext);
+        if constexpr (CARRY) mv_gemm_carried_bs<MTc, NTW, PD, PDR, NS>(KB, act, S16, TS, wcur, NTW, acc, lane, b, wnext, kbnext);      // (all tile slots: see mv_gemm_carried_bw)
         // (every wave multiplies all NTW tiles: the tiles past its share are clamped copies whose results the epilogue drops -- the waves move in lock step,
         // a branch per tile count costs registers at the merge (72 spills) and buys nothing)
         else if constexpr (CARRYW) mv_gemm_carried_bw<MTc, NTW, NTW, PDW, NS, WT>(KB, act, S16, TS, wcur, acc, lane, bw, wnext, kbnext);

@@ -11,7 +11,7 @@ B="python3 $R/bench.py"
 # workload tags: name:bench flags
 CFGS=("c2_f32:" "c2_bf16x2:--dtype bf16x2" "c5share_bf16x2:--workload c5share --dtype bf16x2" "c5share_bf16x3:--workload c5share --dtype bf16x3" \
       "c5share_bf16:--workload c5share --dtype bf16" "c5share_f32:--workload c5share" "c3_f32:--workload c3" "c3_bf16x2:--workload c3 --dtype bf16x2" \
-      "w512_f32:--width 512 --steps 60")
+      "w512_f32:--width 512 --steps 60" "c2_f32x3:--dtype f32x3" "c3_f32x3:--workload c3 --dtype f32x3" "c5share_f32x3:--workload c5share --dtype f32x3")
 # ---- bench lines (default flags; the headline one with the CPU baseline)
 for cfg in "${CFGS[@]}"; do
   tag=${cfg%%:*}; args=${cfg#*:}
@@ -20,12 +20,12 @@ done
 # the collective path at world size 1 (RCCL): what the process-group hand-off costs per step
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29533 $R/bench.py --gpus 1 --no-cpu-baseline > $O/bench_line_c2_f32_rccl1.json 2>/dev/null
 # ---- kernel stats
-for cfg in "c2_f32:" "c5share_bf16x2:--workload c5share --dtype bf16x2" "c3_f32:--workload c3" "c3_bf16x2:--workload c3 --dtype bf16x2" "w512_f32:--width 512"; do
+for cfg in "c2_f32:" "c5share_bf16x2:--workload c5share --dtype bf16x2" "c3_f32:--workload c3" "c3_bf16x2:--workload c3 --dtype bf16x2" "w512_f32:--width 512" "c2_f32x3:--dtype f32x3" "c3_f32x3:--workload c3 --dtype f32x3"; do
   tag=${cfg%%:*}; args=${cfg#*:}
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$tag -- $B --steps 20 --warmup 3 --no-cpu-baseline $args > /dev/null 2>&1
 done
 # ---- PMC passes (each its own run; no trace domains besides --kernel-trace)
-for cfg in "c2_f32:" "c5share_bf16x2:--workload c5share --dtype bf16x2" "c3_f32:--workload c3" "c3_bf16x2:--workload c3 --dtype bf16x2" "w512_f32:--width 512"; do
+for cfg in "c2_f32:" "c5share_bf16x2:--workload c5share --dtype bf16x2" "c3_f32:--workload c3" "c3_bf16x2:--workload c3 --dtype bf16x2" "w512_f32:--width 512" "c2_f32x3:--dtype f32x3" "c3_f32x3:--workload c3 --dtype f32x3"; do
   tag=${cfg%%:*}; args=${cfg#*:}
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_$tag/fetch --output-format csv -- $B --steps 5 --warmup 2 --no-cpu-baseline $args > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_$tag/write --output-format csv -- $B --steps 5 --warmup 2 --no-cpu-baseline $args > /dev/null 2>&1
