@@ -138,3 +138,47 @@ def test_three_term_step_vs_the_bit_exact_step_at_c2():
         ndiff, rel.max(), np.percentile(rel, 99), int((rel > 1e-4).sum()), dl, g1, g0))
     assert ndiff <= 1 and int((rel > 1e-4).sum()) <= 1 and np.percentile(rel, 99) < 5e-6
     assert dl <= 2e-4 and abs(g1 - g0) <= 1e-3 * g0
+
+
+@pytest.mark.parametrize('seed', [11, 12, 13, 14, 15, 16])
+def test_three_term_tracer_fuzz_vs_oracle(oracle, seed):
+    """Randomised scenes / cameras / masks / tracer parameters (the draws of tests/test_gpu_trace.py::test_trace_fuzz_bit_exact_vs_oracle, W = 64 and 256):
+    hit masks equal to the fp32 oracle's except rays whose recorded decision margin is below 1e-6, hit depths within 1e-4, identical results
+    for every chunking."""
+    rs = np.random.RandomState(seed)
+    W = 64 if seed % 2 else 256
+    sd = synth.make_state_dict(W, seed)
+    onet, net = oracle.Net(sd), _net(sd)
+    B, P = int(rs.randint(1, 4)), int(rs.randint(40, 300))
+    inp, _ = synth.make_batch(B, P, 0, seed=seed, radius=float(rs.uniform(1.6, 3.0)), height=float(rs.uniform(-0.5, 1.2)),
+                              focal_scale=float(rs.uniform(0.8, 2.5)), with_features=False)
+    dirs, cam = oracle.camera_rays(inp['uv'], inp['pose'], inp['intrinsics'])
+    om = rs.uniform(size=B * P) < rs.choice([1.1, 0.6])
+    tr = dict(synth.model_conf(W)['ray_tracer'])
+    tr['n_steps'] = int(rs.choice([100, 37, 16, 9]))
+    tr['sphere_tracing_iters'] = int(rs.choice([10, 3, 1]))
+    tr['n_secant_steps'] = int(rs.choice([8, 3]))
+    tr['line_step_iters'] = int(rs.choice([3, 1, 0]))
+    iv = torch.linspace(0, 1, steps=tr['n_steps']).numpy()
+    steps = rs.uniform(size=tr['n_steps']).astype(np.float32)
+    params = (tr['object_bounding_sphere'], tr['sdf_threshold'], tr['line_search_step'], tr['line_step_iters'], tr['sphere_tracing_iters'],
+              tr['n_steps'], tr['n_secant_steps'], 0.5)
+    for training in (True, False):
+        p_o, m_o, d_o, rows_o, mg = oracle.trace(onet, cam, dirs, om, training, steps, iv, margins=True, **tr)
+        margin = mg.min(axis=1)
+        first = None
+        for mt, mts in ((1, 1), (2, 2), (4, 4)):
+            pts, mask, dists, cnt = ops.trace(net, t(cam), t(dirs), t(om), params, training, t(iv), t(steps), mt=mt, mt_samples=mts)
+            mask, dists = mask.cpu().numpy(), dists.cpu().numpy()
+            if first is None:
+                first = (mask, dists)
+                diff = np.nonzero(mask != m_o)[0]
+                both = mask & m_o
+                rel = np.abs(dists - d_o) / np.maximum(np.abs(d_o), 1e-12)
+                bad = np.nonzero(both & (rel > 1e-4))[0]
+                print('seed %d W=%d %s (%d rays, n_steps %d, iters %d): masks differ on %d, rays beyond 1e-4: %d, hit depth rel max %.3g' % (
+                    seed, W, 'train' if training else 'eval', B * P, tr['n_steps'], tr['sphere_tracing_iters'], diff.size, bad.size, rel[both].max() if both.any() else 0.0))
+                assert all(margin[i] < 1e-6 for i in diff), [(int(i), float(margin[i])) for i in diff]
+                assert all(margin[i] < 1e-6 for i in bad), [(int(i), float(rel[i]), float(margin[i])) for i in bad]
+            else:
+                assert np.array_equal(mask, first[0]) and np.array_equal(dists, first[1]), (training, mt)
