@@ -11,7 +11,7 @@ B="python3 $R/bench.py"
 # workload tags: name:bench flags
 CFGS=("c2_f32:" "c2_bf16x2:--dtype bf16x2" "c5share_bf16x2:--workload c5share --dtype bf16x2" "c5share_bf16x3:--workload c5share --dtype bf16x3" \
       "c5share_bf16:--workload c5share --dtype bf16" "c5share_f32:--workload c5share" "c3_f32:--workload c3" "c3_bf16x2:--workload c3 --dtype bf16x2" \
-      "w512_f32:--width 512 --steps 60" "c2_f32x3:--dtype f32x3" "c3_f32x3:--workload c3 --dtype f32x3" "c5share_f32x3:--workload c5share --dtype f32x3")
+      "w512_f32:--width 512 --steps 60" "c2_f32x3:--dtype f32x3" "c3_f32x3:--workload c3 --dtype f32x3" "c5share_f32x3:--workload c5share --dtype f32x3" "w512_f32x3:--width 512 --steps 60 --dtype f32x3")
 # ---- bench lines (default flags; the headline one with the CPU baseline)
 for cfg in "${CFGS[@]}"; do
   tag=${cfg%%:*}; args=${cfg#*:}
