@@ -11,7 +11,7 @@ ap.add_argument('--W', type=int, default=256)
 ap.add_argument('--n', default='4096,16384,65536,262144')
 ap.add_argument('--mt', default='1,2,4')
 ap.add_argument('--bf16', action='store_true')
-ap.add_argument('--dtype', default='', help='f32 | bf16 | bf16w | bf16x2 | bf16x3 (overrides --bf16)')
+ap.add_argument('--dtype', default='', help='f32 | f32x3 | bf16 | bf16w | bf16x2 | bf16x3 (overrides --bf16)')
 a = ap.parse_args()
 net = sdf_packed_net(synth.make_state_dict(a.W, 0), bf16=a.bf16 and not a.dtype)
 if a.dtype:
