@@ -17,6 +17,11 @@
 //   * softplus: max(z, 0) + (ln 2 / 100) log2(1 + 2^(-100 log2(e) |z|)) by v_exp_f32 / v_log_f32: absolute error <= 8e-9, the accuracy class of
 //     det_math's at a quarter of its instructions (mv_softplus100_acc1 below);
 //   * everything else (bias as the accumulator's start value, transposed accumulators, the two weight-fetch schemes) as in tile_engine_bf16.h.
+//
+// Measured against an fp64 evaluation the three-term engine is CLOSER than the fp32 fmaf chain (the matrix instruction adds eight exact products per
+// rounding: tools/micro/mfma_bf16_model/), so the same engine also runs the reference's fp32 arithmetic on UNROUNDED weights: MvNetBs<3, 3>
+// (trace_dtype 5, "f32x3") splits the fp32 weights into three bf16 terms too and multiplies the six pairs a_s w_j with s + j <= 2
+// (mv_gemm_rolling_bw / mv_gemm_carried_bw below; packs by mvsdf_pack_bf16x3_net; tests/test_gpu_f32x3.py).
 #pragma once
 #include "tile_engine_bf16.h"
 
