@@ -430,6 +430,11 @@ def main():
                                   'hbm_bytes': pmc_step_bytes(pmc), 'pmc_source': None if pmc is None else pmc.get('note')}},
             'loss': float(lo['loss'].detach()),
         }
+        mul = {'bf16x2': 2, 'bf16x3': 3, 'f32x3': 6}.get(a.dtype)
+        if mul:
+            # the term engines issue `mul` bf16 matrix instructions per ALGORITHMIC multiply-add: the rate they can reach is peak / mul
+            res['roofline']['matrix_instructions_per_mac'] = mul
+            res['roofline']['frac_of_peak_over_instructions_per_mac'] = ach * mul / peak
         if collective_ms is not None:
             res['collective_ms'] = collective_ms
         if ranks is not None:
