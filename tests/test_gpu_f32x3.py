@@ -106,6 +106,20 @@ def test_reference_fixtures_pass_with_the_three_term_tracer():
     assert ' passed' in tail and 'failed' not in tail, tail
 
 
+def test_step_driver_lazy_outputs_options_and_data_parallel_suites_pass_with_the_three_term_tracer():
+    """The suites that exercise the tracer through the rest of the product (native step driver vs the Python route, deferred outputs, constructor
+    options, eval rendering / mesh grid, 8 ranks on one GPU) with MVSDF_TRACE_DTYPE=f32x3.  Deselected: the one assertion that compares the mesh grid
+    with the CPU oracle BIT FOR BIT -- the property only the 'f32' engine has."""
+    e = dict(os.environ, MVSDF_TRACE_DTYPE='f32x3')
+    p = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', 'tests/test_gpu_shapes.py', 'tests/test_gpu_native_step.py',
+                        'tests/test_gpu_lazy.py', 'tests/test_gpu_options.py', 'tests/test_gpu_dp.py',
+                        '--deselect', 'tests/test_gpu_shapes.py::test_sdf_grid_for_mesh_extraction_matches_pointwise_eval'], cwd=ROOT, env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    tail = p.stdout.decode(errors='replace')[-2500:]
+    assert p.returncode == 0, tail
+    assert ' passed' in tail and 'failed' not in tail, tail
+
+
 def test_three_term_step_vs_the_bit_exact_step_at_c2():
     """The whole training step of BASELINE configs[1] (2048 rays, 4 source views) with the f32x3 tracer against the same step with the bit-exact tracer."""
     from mvsdf_amd.model.implicit_differentiable_renderer import IDRNetwork
