@@ -51,6 +51,13 @@ __device__ __forceinline__ float mv_softplus100_acc1(float z) {
 }
 __device__ __forceinline__ dm_f2 mv_softplus100_acc2(dm_f2 z) { return dm_f2{mv_softplus100_acc1(z.x), mv_softplus100_acc1(z.y)}; }
 
+// trace_dtype 5 ("f32x3") is reproduced BIT FOR BIT by the CPU oracle (oracle/oracle_mvsdf.c::sdf_row_f32x3 models the matrix instruction: tools/micro/mfma_bf16_model/),
+// so its activation is det_math's softplus (IEEE operations only), not the hardware exp / log form above, and every value that enters the matrix core is first
+// flushed to zero below 2^-60 (no bf16 term is ever denormal, no product leaves the exponent range the instruction model was verified on; 1e-18 on values up to 10)
+#define MV_X3_FLUSH 8.673617379884035e-19f                          // 2^-60
+__device__ __forceinline__ float mv_x3_flush(float v) { return fabsf(v) < MV_X3_FLUSH ? 0.0f : v; }
+__device__ __forceinline__ dm_f2 mv_x3_flush2(dm_f2 v) { return dm_f2{mv_x3_flush(v.x), mv_x3_flush(v.y)}; }
+
 __device__ __forceinline__ dm_f2 mv_bf_unpack2(uint32_t p) { return dm_f2{__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)}; }
 
 // two activations -> NS packed pairs of bf16 terms
@@ -74,7 +81,7 @@ __device__ __forceinline__ void mv_split_1(float v, uint16_t (&p)[NS]) {
 }
 
 // positional encoding -> pe[rows][d0] (fp32, kept for the skip connection) and the layer-0 input rows of the NS term tiles (zero padded to kpad)
-template <int NTHREADS, int NS>
+template <int NTHREADS, int NS, bool FLUSH = false>
 __device__ __forceinline__ void mv_pe_rows_bs(const float* pts, float* pe, uint16_t* act, int S16, int TS, int rows, int multires, int kpad, int tid) {
     const int d0 = 3 + 6 * multires, T = 3 * multires + 1;
     for (int task = tid; task < rows * T; task += NTHREADS) {
@@ -85,7 +92,7 @@ __device__ __forceinline__ void mv_pe_rows_bs(const float* pts, float* pe, uint1
         auto put = [&](int col, float v) {
             pr[col] = v;
             uint16_t p[NS];
-            mv_split_1<NS>(v, p);
+            mv_split_1<NS>(FLUSH ? mv_x3_flush(v) : v, p);
 #pragma unroll
             for (int s = 0; s < NS; ++s) ar[s * TS + col] = p[s];
         };
@@ -430,7 +437,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    mv_pe_rows_bs<NTHREADS, NS>(pts, pe, act, S16, TS, rows, net.multires, net.L[0].KB * 32, tid);
+    mv_pe_rows_bs<NTHREADS, NS, (WT > 1)>(pts, pe, act, S16, TS, rows, net.multires, net.L[0].KB * 32, tid);
     for (int l = 0; l < nl - 1; ++l) {
         const MvLayerBf& L = net.L[l];
         const int NT = L.NT, KB = kbnext;
@@ -462,8 +469,14 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
 #pragma unroll
                 for (int a = 0; a < MTc; ++a) {
                     if (t < ntw) {
-                        const dm_f2 h0 = mv_softplus100_acc2(dm_f2{acc[a][t][0], acc[a][t][1]}) * dm2_s(sc);      // Softplus(beta=100), idr.py:91-92
-                        const dm_f2 h1 = mv_softplus100_acc2(dm_f2{acc[a][t][2], acc[a][t][3]}) * dm2_s(sc);
+                        dm_f2 h0, h1;                                                                             // Softplus(beta=100), idr.py:91-92
+                        if constexpr (WT > 1) {
+                            h0 = mv_x3_flush2(dm2_softplus100(dm_f2{acc[a][t][0], acc[a][t][1]}) * dm2_s(sc));
+                            h1 = mv_x3_flush2(dm2_softplus100(dm_f2{acc[a][t][2], acc[a][t][3]}) * dm2_s(sc));
+                        } else {
+                            h0 = mv_softplus100_acc2(dm_f2{acc[a][t][0], acc[a][t][1]}) * dm2_s(sc);
+                            h1 = mv_softplus100_acc2(dm_f2{acc[a][t][2], acc[a][t][3]}) * dm2_s(sc);
+                        }
                         uint32_t p0[NS], p1[NS];
                         mv_split_pk<NS>(h0, p0);
                         mv_split_pk<NS>(h1, p1);
@@ -493,7 +506,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
                 for (int idx = tid; idx < rows * d0; idx += NTHREADS) {
                     const int row = idx / d0, j = idx - row * d0;
                     uint16_t p[NS];
-                    mv_split_1<NS>(dm_div_sqrt2(pe[row * d0 + j]), p);
+                    mv_split_1<NS>(WT > 1 ? mv_x3_flush(dm_div_sqrt2(pe[row * d0 + j])) : dm_div_sqrt2(pe[row * d0 + j]), p);
 #pragma unroll
                     for (int s = 0; s < NS; ++s) act[s * TS + row * S16 + N + j] = p[s];
                 }

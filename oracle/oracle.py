@@ -50,7 +50,12 @@ class Net:
         self.multires = multires
         # bf16 twin (BASELINE configs[4]): weights rounded here, activations in C.  bf16='weights': only the weights are rounded (the twin of
         # trace_dtype 2: fp32 activations and arithmetic on bf16-rounded weights)
-        self.bf16 = bool(bf16) and bf16 != 'weights'
+        # bf16='f32x3': the fp32 weights UNROUNDED, arithmetic of trace_dtype 5 (three bf16 terms per weight and activation on a bit-level model of
+        # v_mfma_f32_16x16x32_bf16: oracle_mvsdf.c::sdf_row_f32x3) -- reproduces that engine bit for bit
+        self.mode = 3 if bf16 == 'f32x3' else (1 if (bool(bf16) and bf16 != 'weights') else 0)
+        self.bf16 = self.mode == 1
+        if bf16 == 'f32x3':
+            bf16 = False
         self.W, self.b = [], []
         l = 0
         while '%s.lin%d.weight_v' % (prefix, l) in state:
@@ -92,7 +97,7 @@ def sdf_forward(net, x, ncols=None):
     x = _f(x)
     ncols = int(net.outs[-1]) if ncols is None else ncols
     y = np.empty((x.shape[0], ncols), np.float32)
-    lib().orc_set_bf16(C.c_int(1 if net.bf16 else 0))
+    lib().orc_set_bf16(C.c_int(getattr(net, 'mode', 1 if net.bf16 else 0)))
     lib().orc_sdf_forward(*net.args(), _p(x), C.c_int(x.shape[0]), C.c_int(ncols), _p(y))
     lib().orc_set_bf16(C.c_int(0))
     return y
@@ -147,7 +152,7 @@ def trace(net, cam_loc, dirs, object_mask, training, minsdf_steps=None, interval
         nargs = (C.c_int(0), _p(z), _p(z), C.c_int(-1), C.c_int(0), None, None)
     else:
         nargs = net.args()
-    lib().orc_set_bf16(C.c_int(1 if (net is not None and getattr(net, 'bf16', False)) else 0))
+    lib().orc_set_bf16(C.c_int(getattr(net, 'mode', 0) if net is not None else 0))
     mg = np.empty((R, 2), np.float32) if margins else None
     lib().orc_trace_m(C.c_int(1 if analytic else 0), *nargs, _p(cam_loc), _p(dirs), _p(om), C.c_int(B), C.c_int(P),
                       C.c_float(object_bounding_sphere), C.c_float(sdf_threshold), C.c_float(line_search_step),
