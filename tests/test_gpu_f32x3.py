@@ -2,11 +2,14 @@
 matrix cores -- weights and activations as three bf16 terms each (w = w0 + w1 + w2, a = a0 + a1 + a2 exactly), the six exact products a_s w_j with
 s + j <= 2, fp32 accumulators (csrc/tile_engine_bf16s.h::mv_gemm_rolling_bw).
 
-It is not the k-ascending fmaf chain of 'f32' (whose bits the oracle reproduces), so it is checked the way 'bf16x2' / 'bf16x3' are against their
-oracle -- here against the fp32 oracle and the reference's own fixtures:
-  * SDF values: no further from an fp64 evaluation of the same network than the fp32 chain is (the claim "fp32-accurate" as a measurement);
-  * tracer: hit masks IDENTICAL to the oracle's except rays whose recorded decision margin is below 1e-6 (printed), hit depths within 1e-4;
-  * every end-to-end reference fixture of tests/test_gpu_idr.py (outputs of the imported PyTorch reference) passes with this tracer unchanged."""
+Two oracles:
+  * `oracle.Net(sd, bf16='f32x3')` restates THIS arithmetic, matrix instruction included (oracle_mvsdf.c::sdf_row_f32x3, the model of
+    v_mfma_f32_16x16x32_bf16 from tools/micro/mfma_bf16_model/): the engine equals it BIT FOR BIT -- MLP values and every tracer output
+    (masks, dists, points, row counters), like the 'f32' engine equals the fmaf-chain oracle; that oracle is pinned to the reference's fixtures on CPU
+    (tests/test_oracle_golden.py);
+  * against the fmaf-chain oracle (another summation order) and the reference's own fixtures: SDF values no further from an fp64 evaluation than
+    the fp32 chain is; hit masks identical except rays whose recorded decision margin is below 1e-6 (none so far), hit depths within 1e-4; every
+    end-to-end reference fixture of tests/test_gpu_idr.py passes with this tracer unchanged."""
 import os
 import subprocess
 import sys
@@ -40,6 +43,47 @@ def _f64_sdf(onet, x):
     m.b = [b.astype(np.float64) for b in onet.b]
     m.n_layers, m.multires, m.skip_layers = onet.n_layers, onet.multires, onet.skip_in
     return oracle_np.sdf_forward(m, x, need_normal=False)[0][:, 0]
+
+
+@pytest.mark.parametrize('W,n', [(64, 20000), (256, 4000), (512, 1200)])
+def test_three_term_mlp_bit_exact_vs_its_oracle(oracle, W, n):
+    """every row tiling and both weight-fetch schemes against the oracle's model of the matrix instruction"""
+    for seed in (0, 7):
+        sd = synth.make_state_dict(W, seed)
+        x = np.random.RandomState(3 + seed).uniform(-1.2, 1.2, size=(n, 3)).astype(np.float32)
+        x[:8] *= 1e-3                                                                  # near the origin: sin(2^m x) ~ x, tiny positional-encoding terms
+        x[8:16] = 0.0
+        x[16:24] = np.float32(1e-30)                                                   # below the engine's 2^-60 flush
+        ref = oracle.sdf_forward(oracle.Net(sd, bf16='f32x3'), x, ncols=1)[:, 0]
+        net = _net(sd)
+        for mt in (1, 2, 4, 49):
+            if mt == 49 and W > 256:
+                continue
+            y = ops.sdf_col0(net, t(x), mt=mt).cpu().numpy()
+            bad = np.nonzero(y.view(np.uint32) != ref.view(np.uint32))[0]
+            assert bad.size == 0, (W, seed, mt, bad[:5], y[bad[:5]], ref[bad[:5]])
+
+
+@pytest.mark.parametrize('W,mode,views,rays', [(64, 'train', 4, 1024), (64, 'eval', 4, 1024), (256, 'train', 1, 256), (256, 'eval', 2, 256), (512, 'train', 1, 64)])
+def test_three_term_tracer_bit_exact_vs_its_oracle(oracle, W, mode, views, rays):
+    """RayTracing.forward on the trace_mlp fixtures' rays (a subset at the wider nets: the instruction model costs the CPU ~100x the fmaf chain):
+    masks, dists, points and the row counters equal the oracle's bit for bit, for every chunking"""
+    g = golden('trace_mlp_w%d_%s' % (W, mode))
+    sd = synth.make_state_dict(W, int(g['seed']))
+    B, P = int(g['B']), int(g['P'])
+    dirs = np.ascontiguousarray(g['ray_dirs'].reshape(B, P, 3)[:views, :rays])
+    cam = np.ascontiguousarray(g['cam_loc'][:views])
+    om = np.ones(views * rays, bool)
+    iv = torch.linspace(0, 1, 100)
+    p_o, m_o, d_o, rows = oracle.trace(oracle.Net(sd, bf16='f32x3'), cam, dirs, om, mode == 'train', g['minsdf_steps'], iv.numpy(), **synth.model_conf(W)['ray_tracer'])
+    net = _net(sd)
+    for mt, mts in ((1, 2), (2, 4), (4, 1)):
+        pts, mask, dists, cnt = ops.trace(net, t(cam), t(dirs), t(om), trace_params(W), mode == 'train', iv.cuda(), t(g['minsdf_steps']), mt=mt, mt_samples=mts)
+        assert np.array_equal(mask.cpu().numpy(), m_o), (mt, mts)
+        assert np.array_equal(dists.cpu().numpy(), d_o), (mt, mts)
+        assert np.array_equal(pts.cpu().numpy(), p_o), (mt, mts)
+        c = cnt.cpu().numpy()
+        assert np.array_equal(c[:4], rows) and c[8] <= c[1]
 
 
 @pytest.mark.parametrize('W', [64, 256, 512])
@@ -181,6 +225,11 @@ def test_three_term_tracer_fuzz_vs_oracle(oracle, seed):
         p_o, m_o, d_o, rows_o, mg = oracle.trace(onet, cam, dirs, om, training, steps, iv, margins=True, **tr)
         margin = mg.min(axis=1)
         first = None
+        if W == 64:                                      # ... and against this arithmetic's own oracle: everything bit for bit
+            p3, m3, d3, rows3 = oracle.trace(oracle.Net(sd, bf16='f32x3'), cam, dirs, om, training, steps, iv, **tr)
+            pts, mask, dists, cnt = ops.trace(net, t(cam), t(dirs), t(om), params, training, t(iv), t(steps), mt=1, mt_samples=2)
+            assert np.array_equal(mask.cpu().numpy(), m3) and np.array_equal(dists.cpu().numpy(), d3) and np.array_equal(pts.cpu().numpy(), p3)
+            assert np.array_equal(cnt.cpu().numpy()[:4], rows3)
         for mt, mts in ((1, 1), (2, 2), (4, 4)):
             pts, mask, dists, cnt = ops.trace(net, t(cam), t(dirs), t(om), params, training, t(iv), t(steps), mt=mt, mt_samples=mts)
             mask, dists = mask.cpu().numpy(), dists.cpu().numpy()

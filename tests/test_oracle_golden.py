@@ -117,3 +117,31 @@ def report_margins(tag, g, hit, depth_err, limit=2e-5):
     line += '; smallest margin of any hit ray %.3g' % float(mg[hit].min())
     print(line)
     return line
+
+
+# ---- the oracle's model of trace_dtype 5 ("f32x3": the bf16 matrix instruction with three-term weights and activations, oracle_mvsdf.c::sdf_row_f32x3) pinned
+# to the same reference fixtures as the fp32 chain above: it is a second restatement of idr.py:77-94 (another summation order), held to the same bar
+
+@pytest.mark.parametrize('W,n', [(64, 2000), (256, 300)])
+def test_sdf_forward_three_term_model(oracle, W, n):
+    g = golden('sdf_w%d' % W)
+    sd = synth.make_state_dict(int(g['W']), int(g['seed']))
+    y3 = oracle.sdf_forward(oracle.Net(sd, bf16='f32x3'), g['x'][:n], ncols=1)[:, 0]
+    np.testing.assert_allclose(y3, g['out'][:n, 0], rtol=1e-4, atol=3e-6)                     # the reference's own values
+    y0 = oracle.sdf_forward(oracle.Net(sd), g['x'][:n], ncols=1)[:, 0]
+    assert 0 < np.abs(y3 - y0).max() < 4e-6                                                   # another arithmetic, fp32-close to the fmaf chain
+
+
+@pytest.mark.parametrize('W,mode,rays', [(64, 'eval', 512), (64, 'train', 384), (256, 'eval', 96)])
+def test_tracer_three_term_model(oracle, W, mode, rays):
+    """the first `rays` rays of view 0 of the trace_mlp fixtures: hit masks bit-exact, hit depths 1e-4 against the reference"""
+    g = golden('trace_mlp_w%d_%s' % (W, mode))
+    sd = synth.make_state_dict(W, int(g['seed']))
+    B, P = int(g['B']), int(g['P'])
+    dirs = g['ray_dirs'].reshape(B, P, 3)[:1, :rays]
+    tr = synth.model_conf(W)['ray_tracer']
+    pts, mask, dists, rows = oracle.trace(oracle.Net(sd, bf16='f32x3'), g['cam_loc'][:1], dirs, np.ones(rays, bool), mode == 'train', g['minsdf_steps'], g['intervals'], **tr)
+    ref_mask, ref_d = g['mask'].reshape(B, P)[0, :rays], g['dists'].reshape(B, P)[0, :rays]
+    assert np.array_equal(mask, ref_mask)
+    rel = np.abs(dists - ref_d) / np.abs(ref_d).clip(1e-6)
+    assert rel[ref_mask].max() < 1e-4
