@@ -458,9 +458,10 @@ def main():
                                                        'note': 'opt-in, default off; loss and gradients identical (tests/test_gpu_lazy.py); not the headline value'}}
         if not a.no_cpu_baseline and world == 1 and a.dtype == 'f32':
             # secondary number, never `value`: the same step with the tracing MLP on the bf16 matrix cores at fp32 accuracy ('f32x3': weights and
-            # activations as three bf16 terms each, six exact products; tests/test_gpu_f32x3.py: closer to an fp64 evaluation than the fp32 fmaf chain,
-            # hit masks equal to the fp32 oracle's on every fixture, every reference fixture passes).  Same run, same inputs, same frozen weights:
-            # the hit masks of the two arithmetics are compared here too.  (Not in profile runs: they pass --no-cpu-baseline.)
+            # activations as three bf16 terms each, six exact products; tests/test_gpu_f32x3.py: bit-exact against its own oracle -- a model of the
+            # matrix instruction --, closer to an fp64 evaluation than the fp32 fmaf chain, hit masks equal to the fmaf-chain oracle's on every fixture,
+            # every reference fixture passes).  Same run, same inputs, same frozen weights: the hit masks of the two arithmetics are compared here too.
+            # (Not in profile runs: they pass --no-cpu-baseline.)
             mask_f32 = out['network_object_mask'].clone()
             loss_f32 = float(lo['loss'].detach())
             model.set_trace_dtype('f32x3')
@@ -478,8 +479,8 @@ def main():
                 'hit_masks_differing_from_f32': int((out3['network_object_mask'] != mask_f32).sum()), 'rays': R,
                 'loss_f32': loss_f32, 'loss_f32x3': float(lo3['loss'].detach()),
                 'note': "IDRNetwork.set_trace_dtype('f32x3') / bench.py --dtype f32x3: fp32-accurate tracing on v_mfma_f32_16x16x32_bf16 (6 instructions per "
-                        "32-wide k-block instead of 8 fp32 ones of twice the cycles); not bit-identical to the k-ascending fmaf chain the oracle "
-                        "reproduces, hence reported beside `value`, not as it (the losses differ by the eikonal / min-sdf draws of the two loops too)"}
+                        "32-wide k-block instead of 8 fp32 ones of twice the cycles), reproduced bit for bit by the oracle's model of that instruction; `value` "
+                        "stays on the fmaf-chain engine the earlier rounds measured (the losses differ by the eikonal / min-sdf draws of the two loops too)"}
         if not a.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(V)
         print(json.dumps(res), flush=True)

@@ -302,8 +302,8 @@ class IDRNetwork(nn.Module):
         csrc/tile_engine_bf16s.h): the arithmetic of 'bf16w' up to the order of the fp32 additions inside the matrix core -- the configs[4] mode
         that is fast AND parity-checked (hit masks equal to the oracle's on the rounded weights except at recorded ties, depths 1e-4).
         'f32x3': the fp32 weights unrounded, as three bf16 terms like the activations: the reference's fp32 arithmetic from six exact bf16 products per
-        element pair on the bf16 MFMA -- fp32-accurate (measured closer to an fp64 evaluation than the 'f32' fmaf chain), parity-checked against the
-        fp32 oracle and the reference fixtures with the same tie rule; not bit-identical to 'f32'."""
+        element pair on the bf16 MFMA -- fp32-accurate (measured closer to an fp64 evaluation than the 'f32' fmaf chain), bit-exact against its own
+        CPU oracle (a model of the matrix instruction) and parity-checked against the fmaf-chain oracle and the reference fixtures; not bit-identical to 'f32'."""
         assert dtype in ops.TRACE_DTYPES
         self.trace_dtype = dtype
         self.implicit_network.trace_dtype = dtype

@@ -241,7 +241,7 @@ def pack_bf16_net(net, weights_only=False, terms=0, weight_terms=1):
     csrc/tile_engine_bf16s.h, trace_dtype 3 / 4): the arithmetic of weights_only up to the order of the fp32 additions, at bf16-MFMA speed.
     terms = 3, weight_terms = 3 ('f32x3', trace_dtype 5): the fp32 weights UNROUNDED, as three bf16 terms like the activations -- the reference's fp32
     Linear (idr.py:89) from six exact bf16 products per element pair on the bf16 MFMA; fp32-accurate (closer to an fp64 evaluation than the fp32
-    fmaf chain), not bit-identical to it."""
+    fmaf chain) and bit-exact against oracle.Net(sd, bf16='f32x3') (a model of the matrix instruction); not bit-identical to 'f32'."""
     n = len(net.layers)
     if terms:
         assert terms in (2, 3) and not weights_only and weight_terms in (1, 3) and (weight_terms == 1 or terms == 3)
