@@ -591,7 +591,7 @@ void orc_trace_m(int analytic, int n_layers, const int *in, const int *out, int 
     sdf_ctx sc = {&net, analytic};
     trace_params tp = {r, thr, line_search_step, line_step_iters, st_iters, n_steps, n_secant, dist_clip};
     long long r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-#pragma omp parallel for schedule(dynamic, 8) reduction(+ : r0, r1, r2, r3)
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : r0, r1, r2, r3)
     for (int q = 0; q < B * P; ++q) {
         long long rr[4] = {0, 0, 0, 0};
         float *mg = margins ? margins + 2 * (size_t)q : NULL;

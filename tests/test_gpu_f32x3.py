@@ -45,7 +45,7 @@ def _f64_sdf(onet, x):
     return oracle_np.sdf_forward(m, x, need_normal=False)[0][:, 0]
 
 
-@pytest.mark.parametrize('W,n', [(64, 20000), (256, 4000), (512, 1200)])
+@pytest.mark.parametrize('W,n', [(64, 20000), (256, 2500), (512, 600)])
 def test_three_term_mlp_bit_exact_vs_its_oracle(oracle, W, n):
     """every row tiling and both weight-fetch schemes against the oracle's model of the matrix instruction"""
     for seed in (0, 7):
@@ -64,7 +64,7 @@ def test_three_term_mlp_bit_exact_vs_its_oracle(oracle, W, n):
             assert bad.size == 0, (W, seed, mt, bad[:5], y[bad[:5]], ref[bad[:5]])
 
 
-@pytest.mark.parametrize('W,mode,views,rays', [(64, 'train', 4, 1024), (64, 'eval', 4, 1024), (256, 'train', 1, 256), (256, 'eval', 2, 256), (512, 'train', 1, 64)])
+@pytest.mark.parametrize('W,mode,views,rays', [(64, 'train', 4, 1024), (64, 'eval', 4, 1024), (256, 'train', 1, 128), (256, 'eval', 2, 192), (512, 'train', 1, 24)])
 def test_three_term_tracer_bit_exact_vs_its_oracle(oracle, W, mode, views, rays):
     """RayTracing.forward on the trace_mlp fixtures' rays (a subset at the wider nets: the instruction model costs the CPU ~100x the fmaf chain):
     masks, dists, points and the row counters equal the oracle's bit for bit, for every chunking"""
