@@ -57,7 +57,7 @@ typedef struct {
                                          * 5 = the fp32 weights UNROUNDED as three bf16 terms too (w = w0 + w1 + w2 exactly): the reference's fp32 Linear
                                          * (idr.py:89) from the six exact products a_s w_j, s + j <= 2, on the bf16 MFMA -- fp32-accurate (measured closer to an
                                          * fp64 evaluation than mode 0's fmaf chain) and reproduced BIT FOR BIT by the oracle's model of the matrix instruction
-                                         * (oracle_mvsdf.c::sdf_row_f32x3); det_math's softplus like mode 0; values below 2^-60 count as zero.  Not bit-identical
+                                         * (oracle_mvsdf.c::sdf_row_f32x3); det_math's softplus like mode 0; values below 2^-40 count as zero.  Not bit-identical
                                          * to mode 0 (another summation order).  bias[] is read like in mode 1 */
     unsigned skip_mask;                 /* several skip connections (skip_in with more than one entry, idr.py:46,86): bit l set = the input of layer l
                                          * is cat([x, PE(x)])/sqrt(2).  0 = use skip_layer alone.  Layer 0 and the last layer cannot be skip layers. */

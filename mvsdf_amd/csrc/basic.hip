@@ -265,7 +265,7 @@ __global__ void k_pack_bf16x3_net(PackBfArgs a) {
         uint16_t v = 0;
         if (o < N && kp < K) {
             float r = a.w[l][(size_t)o * K + kp];
-            if (fabsf(r) < 8.673617379884035e-19f) r = 0.0f;                            // |w| < 2^-60 -> 0 (tile_engine_bf16s.h, MV_X3_FLUSH: the oracle does the same)
+            if (fabsf(r) < 9.094947017729282e-13f) r = 0.0f;                            // |w| < 2^-40 -> 0 (tile_engine_bf16s.h, MV_X3_FLUSH: the oracle does the same)
             v = mv_f2bf(r);
             for (int t = 0; t < term; ++t) { r = r - mv_bf2f(v); v = mv_f2bf(r); }       // every subtraction is exact
         }
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
             uint16_t v = 0;
             if (16 * rg + ol < N && kp < K) {
                 float r = tile[ol * ld + kp];
-                if (fabsf(r) < 8.673617379884035e-19f) r = 0.0f;
+                if (fabsf(r) < 9.094947017729282e-13f) r = 0.0f;
                 v = mv_f2bf(r);
                 for (int t = 0; t < term; ++t) { r = r - mv_bf2f(v); v = mv_f2bf(r); }
             }

@@ -53,8 +53,9 @@ __device__ __forceinline__ dm_f2 mv_softplus100_acc2(dm_f2 z) { return dm_f2{mv_
 
 // trace_dtype 5 ("f32x3") is reproduced BIT FOR BIT by the CPU oracle (oracle/oracle_mvsdf.c::sdf_row_f32x3 models the matrix instruction: tools/micro/mfma_bf16_model/),
 // so its activation is det_math's softplus (IEEE operations only), not the hardware exp / log form above, and every value that enters the matrix core is first
-// flushed to zero below 2^-60 (no bf16 term is ever denormal, no product leaves the exponent range the instruction model was verified on; 1e-18 on values up to 10)
-#define MV_X3_FLUSH 8.673617379884035e-19f                          // 2^-60
+// flushed to zero below 2^-40 (no bf16 term is ever denormal, every product stays above 2^-112: the instruction model is verified on products inside the fp32 normal
+// range -- below it the hardware deviates, tools/micro/mfma_bf16_model/mfma_fuzz.hip `tiny`; 1e-12 on values up to 10)
+#define MV_X3_FLUSH 9.094947017729282e-13f                          // 2^-40
 __device__ __forceinline__ float mv_x3_flush(float v) { return fabsf(v) < MV_X3_FLUSH ? 0.0f : v; }
 __device__ __forceinline__ dm_f2 mv_x3_flush2(dm_f2 v) { return dm_f2{mv_x3_flush(v.x), mv_x3_flush(v.y)}; }
 

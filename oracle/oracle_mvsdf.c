@@ -135,7 +135,7 @@ static void sdf_row_bf16(const orc_net *net, const float *x, int ncols, float *y
  *     acc' = floor(acc / u) u                                                             (two's complement: toward -inf)
  *     t    = acc' + S;  v = 2^(exp(t) - 31);  t = floor(t / v) v                             (seven guard bits below the 24 of the result, no sticky)
  *     acc  = round_to_nearest_even_fp32(t)
- * Zero operands take no part (a step of zeros leaves acc unchanged).  The engine never feeds denormal terms (values below 2^-60 are flushed to zero before
+ * Zero operands take no part (a step of zeros leaves acc unchanged).  The engine never feeds denormal terms (values below 2^-40 are flushed to zero before
  * they are split, here and there). ---- */
 typedef __int128 orc_i128;
 static int hibit128(unsigned __int128 a) {                      /* position of the highest set bit (a != 0) */
@@ -200,8 +200,8 @@ static uint16_t bf16bits(float f) {                            /* round to neare
     return (uint16_t)(u >> 16);
 }
 static float bf16val(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
-static void split3(float v, uint16_t *t0, uint16_t *t1, uint16_t *t2) {   /* v = t0 + t1 + t2 exactly (|v| < 2^-60 -> 0: MV_X3_FLUSH) */
-    if (fabsf(v) < 0x1p-60f) v = 0.0f;
+static void split3(float v, uint16_t *t0, uint16_t *t1, uint16_t *t2) {   /* v = t0 + t1 + t2 exactly (|v| < 2^-40 -> 0: MV_X3_FLUSH) */
+    if (fabsf(v) < 0x1p-40f) v = 0.0f;
     *t0 = bf16bits(v); v = v - bf16val(*t0);
     *t1 = bf16bits(v); v = v - bf16val(*t1);
     *t2 = bf16bits(v);

@@ -53,7 +53,7 @@ def test_three_term_mlp_bit_exact_vs_its_oracle(oracle, W, n):
         x = np.random.RandomState(3 + seed).uniform(-1.2, 1.2, size=(n, 3)).astype(np.float32)
         x[:8] *= 1e-3                                                                  # near the origin: sin(2^m x) ~ x, tiny positional-encoding terms
         x[8:16] = 0.0
-        x[16:24] = np.float32(1e-30)                                                   # below the engine's 2^-60 flush
+        x[16:24] = np.float32(1e-30)                                                   # below the engine's 2^-40 flush
         ref = oracle.sdf_forward(oracle.Net(sd, bf16='f32x3'), x, ncols=1)[:, 0]
         net = _net(sd)
         for mt in (1, 2, 4, 49):
