@@ -859,7 +859,8 @@ hipError_t mv_trace_launch(int stages, const NET& net, const MvTraceParams& tp, 
     if (mtf_env < 0) { const char* e2 = getenv("MVSDF_MT_FIRST"); mtf_env = e2 ? atoi(e2) : 0; }
     for (int part = 1; part <= 8; part <<= 1) {
         if (!((stages >> 1) & part)) continue;
-        const int mtp = part == 1 ? (mtf_env > 0 ? mtf_env : ((long long)B * P <= 4096 ? 1 : mt2)) : mt2;
+        // (three weight terms: a 16-row evaluation is bound by its 3.1 MB weight stream, two tiles share it: c2 1.687 -> 1.664 ms, c5 share 2.539 -> 2.483)
+        const int mtp = part == 1 ? (mtf_env > 0 ? mtf_env : (mv_net_wt<NET>::v == 3 ? (mt2 > 2 ? 2 : mt2) : ((long long)B * P <= 4096 ? 1 : mt2))) : mt2;
         const int st_ = stages;
         stages = (stages & 1) | (part << 1);                    // MV_S2 reads `stages` for the parts to launch
         if (eight) {
