@@ -347,6 +347,8 @@ __global__ void k_det_math(int op, const float* __restrict__ x, int n, float* __
         case 3: dm_sincos(v, &a, &b); break;
         case 4: a = dm_div100(v); b = dm_div_sqrt2(v); break;
         case 6: { const dm_f2 h = dm2_softplus100(dm_f2{v, -v}); a = h.x; b = h.y; break; }   // two-wide softplus: y0 = f(x), y1 = f(-x)
+        case 7: a = dm_softplus100_lean(v); b = dm_softplus100_lean(-v); break;                  // the f32x3 engine's activation, scalar form
+        case 8: { const dm_f2 h = dm2_softplus100_lean(dm_f2{v, -v}); a = h.x; b = h.y; break; }   // ... and the two-wide form the epilogue runs
         default: a = sqrtf(fabsf(v)); b = 1.0f / v; break;
     }
     y0[i] = a;

@@ -55,3 +55,30 @@ __device__ __forceinline__ dm_f2 dm2_softplus100(dm_f2 z) {
     const dm_f2 r = s * dm2_s(0.009999999776482582f);            // dm_div100
     return dm_f2{y.x > 20.0f ? z.x : r.x, y.y > 20.0f ? z.y : r.y};
 }
+
+// Softplus(beta=100, threshold=20), the LEAN form of the f32x3 tracing arithmetic (dm_softplus100_lean: same operations per element, bit-identical;
+// mvsdf_det_math op 8 checks it on the device).  Per activation: one v_med3 (|z| clamped), one v_med3 (max(z, 0)), one v_lshl_add_u32 and sixteen
+// two-wide fma / add halves = 11 instructions (dm2_softplus100: 27).
+__device__ __forceinline__ dm_f2 dm2_softplus100_lean(dm_f2 z) {
+    const dm_f2 za = dm_f2{__builtin_amdgcn_fmed3f(fabsf(z.x), 0.0f, 0.2f), __builtin_amdgcn_fmed3f(fabsf(z.y), 0.0f, 0.2f)};
+    const dm_f2 magic = dm2_s(12582912.0f), c = dm2_s(-144.26950073242188f);
+    const dm_f2 tm = dm2_fma(za, c, magic);
+    const dm_f2 nf = tm - magic;
+    const dm_f2 fr = dm2_fma(za, c, -nf);
+    dm_f2 p = dm2_s(1.341362135e-03f);
+    p = dm2_fma(p, fr, dm2_s(9.671657346e-03f));
+    p = dm2_fma(p, fr, dm2_s(5.550281703e-02f));
+    p = dm2_fma(p, fr, dm2_s(2.402223945e-01f));
+    p = dm2_fma(p, fr, dm2_s(6.931472421e-01f));
+    p = dm2_fma(p, fr, dm2_s(1.0f));
+    const dm_f2 t = dm_f2{dm_from_bits(dm_to_bits(p.x) + (dm_to_bits(tm.x) << 23)), dm_from_bits(dm_to_bits(p.y) + (dm_to_bits(tm.y) << 23))};
+    dm_f2 g = dm2_s(-6.453247624e-05f);
+    g = dm2_fma(g, t, dm2_s(3.608817351e-04f));
+    g = dm2_fma(g, t, dm2_s(-9.533045813e-04f));
+    g = dm2_fma(g, t, dm2_s(1.676565735e-03f));
+    g = dm2_fma(g, t, dm2_s(-2.407359425e-03f));
+    g = dm2_fma(g, t, dm2_s(3.317999188e-03f));
+    g = dm2_fma(g, t, dm2_s(-4.998743068e-03f));
+    g = dm2_fma(g, t, dm2_s(9.999964386e-03f));
+    return dm2_fma(g, t, dm_f2{__builtin_amdgcn_fmed3f(z.x, 0.0f, 3.0e38f), __builtin_amdgcn_fmed3f(z.y, 0.0f, 3.0e38f)});
+}

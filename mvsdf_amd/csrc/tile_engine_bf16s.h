@@ -472,8 +472,8 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
                     if (t < ntw) {
                         dm_f2 h0, h1;                                                                             // Softplus(beta=100), idr.py:91-92
                         if constexpr (WT > 1) {
-                            h0 = mv_x3_flush2(dm2_softplus100(dm_f2{acc[a][t][0], acc[a][t][1]}) * dm2_s(sc));
-                            h1 = mv_x3_flush2(dm2_softplus100(dm_f2{acc[a][t][2], acc[a][t][3]}) * dm2_s(sc));
+                            h0 = dm2_softplus100_lean(dm_f2{acc[a][t][0], acc[a][t][1]}) * dm2_s(sc);     // >= 1.4e-11: above the 2^-40 flush by itself
+                            h1 = dm2_softplus100_lean(dm_f2{acc[a][t][2], acc[a][t][3]}) * dm2_s(sc);
                         } else {
                             h0 = mv_softplus100_acc2(dm_f2{acc[a][t][0], acc[a][t][1]}) * dm2_s(sc);
                             h1 = mv_softplus100_acc2(dm_f2{acc[a][t][2], acc[a][t][3]}) * dm2_s(sc);

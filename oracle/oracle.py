@@ -173,6 +173,7 @@ def _unary(name, x, nout=1):
 
 
 def softplus100(x): return _unary('orc_softplus100', x)
+def softplus100_lean(x): return _unary('orc_softplus100_lean', x)   # the f32x3 mode's activation (det_math.h::dm_softplus100_lean)
 def softplus100_arr(x): return _unary('orc_softplus100_arr', x)      # the branch-free array form the MLP rows use
 def expneg(x): return _unary('orc_expneg', x)
 def log1p01(x): return _unary('orc_log1p01', x)

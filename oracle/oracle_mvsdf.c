@@ -21,6 +21,9 @@
 #include <string.h>
 #include <math.h>
 #include "det_math.h"
+#if defined(__AVX2__)
+#include <immintrin.h>
+#endif
 
 #define MAXL 16
 #define MAXW 1024
@@ -37,6 +40,8 @@ typedef struct {
     int ldt[MAXL];
     uint16_t *Wx[MAXL];      /* mode 3 ("f32x3"): the weights as three bf16 terms, [3][out][kp] (kp = in rounded up to 32, zero padded) */
     int kp[MAXL];
+    int16_t *We[MAXL], *Wm[MAXL]; /* mode 3, eight-columns-per-instruction form (sdf_row_f32x3_v8): biased exponent field / signed 8-bit mantissa of every
+                              * weight term, [3][kp][ldt] (column index innermost); a zero term: exponent X3_ZERO_E, mantissa 0 */
 } orc_net;
 
 /* ---- weight norm: w = v * (g / ||v||_row)   (idr.py:70-71; torch._weight_norm, dim=0) ---- */
@@ -206,6 +211,68 @@ static void split3(float v, uint16_t *t0, uint16_t *t1, uint16_t *t2) {   /* v =
     *t1 = bf16bits(v); v = v - bf16val(*t1);
     *t2 = bf16bits(v);
 }
+/* ---- the same arithmetic, EIGHT output columns per instruction (AVX2): what makes full-size ray batches (188 k MLP rows at BASELINE configs[1]) checkable
+ * against the instruction model inside the test suite.  Per lane exactly mfma_step8 above, restated so that every intermediate fits the vector units:
+ *   * S (the eight products cut at u = 2^(E - 24)) is below 2^29: 32-bit integer lanes (variable shifts: counts beyond 31 give 0, like the `>= 17` rule);
+ *   * floor(acc / u) is below 2^52 (exp(acc) - E <= 27), S + that below 2^53: exact in DOUBLE lanes; floor() = the two's-complement shift;
+ *   * the 32-bit cut floor(t / v) v: a scaling by a power of two, floor(), scaling back -- exact; the final round-to-nearest-even is the double -> float
+ *     conversion of the scaled total (results stay in the fp32 normal range: the same assumption as f32_from_scaled).
+ * tests/test_oracle_golden.py::test_x3_vector_model_equals_the_scalar_model compares the two forms bit for bit (random networks, adversarial exponents).
+ * g_x3_scalar = 1 (orc_set_x3_scalar) selects the scalar form above. ---- */
+#define X3_ZERO_E (-20000)
+static int g_x3_scalar = 0;
+void orc_set_x3_scalar(int on) { g_x3_scalar = on; }
+#if defined(__AVX2__)
+static inline __m256d x3_pow2(__m128i e) {                     /* 2^e, four lanes, e in [-1000, 1000] */
+    return _mm256_castsi256_pd(_mm256_slli_epi64(_mm256_add_epi64(_mm256_cvtepi32_epi64(e), _mm256_set1_epi64x(1023)), 52));
+}
+static inline __m128 x3_step_half(__m128 acc, __m128i S, __m128i emax, __m128i keep /* all ones: lane unchanged */) {
+    const __m256d sdn = x3_pow2(_mm_sub_epi32(_mm_set1_epi32(24), emax)), sup = x3_pow2(_mm_sub_epi32(emax, _mm_set1_epi32(24)));
+    const __m256d au = _mm256_floor_pd(_mm256_mul_pd(_mm256_cvtps_pd(acc), sdn));                        /* floor(acc / u) */
+    __m256d tot = _mm256_add_pd(au, _mm256_cvtepi32_pd(S));
+    const __m256i tb = _mm256_castpd_si256(tot);
+    const __m256i hb = _mm256_sub_epi64(_mm256_and_si256(_mm256_srli_epi64(tb, 52), _mm256_set1_epi64x(0x7ff)), _mm256_set1_epi64x(1023 + 31));   /* cut2 */
+    const __m256i pos = _mm256_cmpgt_epi64(hb, _mm256_setzero_si256());
+    const __m256i c = _mm256_and_si256(hb, pos);                                                          /* max(cut2, 0) (tot = 0: hb < 0) */
+    const __m256d cdn = _mm256_castsi256_pd(_mm256_slli_epi64(_mm256_sub_epi64(_mm256_set1_epi64x(1023), c), 52));
+    const __m256d cup = _mm256_castsi256_pd(_mm256_slli_epi64(_mm256_add_epi64(_mm256_set1_epi64x(1023), c), 52));
+    tot = _mm256_mul_pd(_mm256_floor_pd(_mm256_mul_pd(tot, cdn)), cup);
+    const __m128 res = _mm256_cvtpd_ps(_mm256_mul_pd(tot, sup));                                          /* round to nearest even */
+    return _mm_blendv_ps(res, acc, _mm_castsi128_ps(keep));
+}
+/* acc[8] += one lane group (k = 0..7) of one matrix instruction; we / wm: [8 k][ldt] (this block's eight columns at +0..7), ea / ma: the activation terms */
+static inline __m256 x3_step8_v8(__m256 acc, const int16_t *we, const int16_t *wm, int ldt, const int32_t *ea, const int32_t *ma) {
+    __m256i e[8], emax = _mm256_set1_epi32(-100000);
+    for (int k = 0; k < 8; ++k) {
+        e[k] = _mm256_add_epi32(_mm256_cvtepi16_epi32(_mm_loadu_si128((const __m128i *)(we + (size_t)k * ldt))), _mm256_set1_epi32(ea[k] - 254));
+        emax = _mm256_max_epi32(emax, e[k]);
+    }
+    __m256i S = _mm256_setzero_si256();
+    for (int k = 0; k < 8; ++k) {
+        const __m256i p = _mm256_mullo_epi32(_mm256_cvtepi16_epi32(_mm_loadu_si128((const __m128i *)(wm + (size_t)k * ldt))), _mm256_set1_epi32(ma[k]));
+        const __m256i mag = _mm256_abs_epi32(p);
+        const __m256i sh = _mm256_add_epi32(_mm256_sub_epi32(e[k], emax), _mm256_set1_epi32(10));       /* <= 10 */
+        const __m256i t = _mm256_or_si256(_mm256_sllv_epi32(mag, sh), _mm256_srlv_epi32(mag, _mm256_sub_epi32(_mm256_setzero_si256(), sh)));
+        S = _mm256_add_epi32(S, _mm256_sign_epi32(t, p));
+    }
+    const __m256i none = _mm256_cmpgt_epi32(_mm256_set1_epi32(-10000), emax);                             /* no non-zero product: unchanged */
+    const __m256i ab = _mm256_castps_si256(acc);
+    const __m256i eacc = _mm256_sub_epi32(_mm256_and_si256(_mm256_srli_epi32(ab, 23), _mm256_set1_epi32(0xff)), _mm256_set1_epi32(127));
+    const __m256i nz = _mm256_castps_si256(_mm256_cmp_ps(acc, _mm256_setzero_ps(), _CMP_NEQ_OQ));
+    const __m256i far = _mm256_and_si256(nz, _mm256_cmpgt_epi32(_mm256_sub_epi32(eacc, emax), _mm256_set1_epi32(27)));   /* exp(acc) - E >= 28 */
+    const __m256i keep = _mm256_or_si256(none, far);
+    const __m256i em = _mm256_andnot_si256(none, emax);                                                   /* (a harmless exponent for the lanes that stay) */
+    const __m128 lo = x3_step_half(_mm256_castps256_ps128(acc), _mm256_castsi256_si128(S), _mm256_castsi256_si128(em), _mm256_castsi256_si128(keep));
+    const __m128 hi = x3_step_half(_mm256_extractf128_ps(acc, 1), _mm256_extracti128_si256(S, 1), _mm256_extracti128_si256(em, 1), _mm256_extracti128_si256(keep, 1));
+    return _mm256_insertf128_ps(_mm256_castps128_ps256(lo), hi, 1);
+}
+#endif
+static inline void x3_fields(uint16_t h, int32_t *e, int32_t *m) {   /* bf16 term -> biased exponent field (X3_ZERO_E for zero / denormal) and signed mantissa */
+    if ((h & 0x7f80) == 0) { *e = X3_ZERO_E; *m = 0; return; }
+    *e = (h >> 7) & 0xff;
+    *m = (h & 0x8000) ? -(int32_t)(0x80 | (h & 0x7f)) : (int32_t)(0x80 | (h & 0x7f));
+}
+
 static void sdf_row_f32x3(const orc_net *net, const float *x, int ncols, float *y) {
     float pe[64], z[MAXW];
     static const int OS[6] = {0, 1, 2, 0, 1, 0}, OJ[6] = {2, 1, 0, 1, 0, 0};     /* the engine's order: a_s w_j with s + j = 2, then 1, then 0 (smallest products first) */
@@ -226,6 +293,27 @@ static void sdf_row_f32x3(const orc_net *net, const float *x, int ncols, float *
         const int no = last ? ncols : net->out[l];
         const uint16_t *Wx = net->Wx[l];
         const size_t ts = (size_t)net->out[l] * kp;
+#if defined(__AVX2__)
+        if (!g_x3_scalar && net->We[l]) {
+            int32_t ea[3][MAXW + 64], ma[3][MAXW + 64];
+            for (int s = 0; s < 3; ++s) for (int k = 0; k < kp; ++k) x3_fields(at[s][k], &ea[s][k], &ma[s][k]);
+            const int ldt = net->ldt[l];
+            const size_t tsv = (size_t)kp * ldt;
+            for (int j0 = 0; j0 < no; j0 += 8) {
+                float bb[8];
+                for (int jj = 0; jj < 8; ++jj) bb[jj] = j0 + jj < net->out[l] ? net->b[l][j0 + jj] : 0.0f;
+                __m256 acc = _mm256_loadu_ps(bb);
+                for (int kb = 0; kb < kp; kb += 32)
+                    for (int o = 0; o < 6; ++o) {
+                        const int16_t *we = net->We[l] + OJ[o] * tsv + (size_t)kb * ldt + j0, *wm = net->Wm[l] + OJ[o] * tsv + (size_t)kb * ldt + j0;
+                        for (int g = 0; g < 4; ++g)
+                            acc = x3_step8_v8(acc, we + (size_t)8 * g * ldt, wm + (size_t)8 * g * ldt, ldt, ea[OS[o]] + kb + 8 * g, ma[OS[o]] + kb + 8 * g);
+                    }
+                _mm256_storeu_ps(bb, acc);
+                for (int jj = 0; jj < 8 && j0 + jj < no; ++jj) z[j0 + jj] = bb[jj];
+            }
+        } else
+#endif
         for (int j = 0; j < no; ++j) {
             float acc = net->b[l][j];
             for (int kb = 0; kb < kp; kb += 32)
@@ -238,7 +326,7 @@ static void sdf_row_f32x3(const orc_net *net, const float *x, int ncols, float *
         if (last) { memcpy(y, z, sizeof(float) * no); return; }
         const int to_skip = (net->skip_mask >> (l + 1)) & 1;
         for (int j = 0; j < no; ++j) {
-            float h = dm_softplus100(z[j]);
+            float h = dm_softplus100_lean(z[j]);                 /* the engine's activation in this mode (det_math.h) */
             if (to_skip) h = dm_div_sqrt2(h);
             split3(h, &at[0][j], &at[1][j], &at[2][j]);
         }
@@ -353,10 +441,13 @@ static void make_net(orc_net *net, int n_layers, const int *in, const int *out, 
         if (net->Wt[l])
             for (int j = 0; j < out[l]; ++j)
                 for (int k = 0; k < in[l]; ++k) net->Wt[l][(size_t)k * ldt + j] = net->W[l][(size_t)j * in[l] + k];
-        net->Wx[l] = NULL; net->kp[l] = (in[l] + 31) & ~31;
+        net->Wx[l] = NULL; net->We[l] = NULL; net->Wm[l] = NULL; net->kp[l] = (in[l] + 31) & ~31;
         if (g_bf16 == 3) {
             const int kp = net->kp[l];
             net->Wx[l] = (uint16_t *)calloc((size_t)3 * out[l] * kp, sizeof(uint16_t));
+            net->We[l] = (int16_t *)malloc((size_t)3 * kp * ldt * sizeof(int16_t));
+            net->Wm[l] = (int16_t *)calloc((size_t)3 * kp * ldt, sizeof(int16_t));
+            if (net->We[l]) for (size_t i = 0; i < (size_t)3 * kp * ldt; ++i) net->We[l][i] = X3_ZERO_E;
             for (int j = 0; j < out[l]; ++j)
                 for (int k = 0; k < in[l]; ++k) {
                     uint16_t t0, t1, t2;
@@ -364,12 +455,22 @@ static void make_net(orc_net *net, int n_layers, const int *in, const int *out, 
                     net->Wx[l][((size_t)0 * out[l] + j) * kp + k] = t0;
                     net->Wx[l][((size_t)1 * out[l] + j) * kp + k] = t1;
                     net->Wx[l][((size_t)2 * out[l] + j) * kp + k] = t2;
+                    if (net->We[l] && net->Wm[l]) {
+                        const uint16_t tt[3] = {t0, t1, t2};
+                        for (int q = 0; q < 3; ++q) {
+                            int32_t e, m;
+                            x3_fields(tt[q], &e, &m);
+                            net->We[l][((size_t)q * kp + k) * ldt + j] = (int16_t)e;
+                            net->Wm[l][((size_t)q * kp + k) * ldt + j] = (int16_t)m;
+                        }
+                    }
                 }
         }
     }
 }
 static void free_net(orc_net *net) {
-    for (int l = 0; l < net->n_layers; ++l) { free(net->Wt[l]); net->Wt[l] = NULL; free(net->Wx[l]); net->Wx[l] = NULL; }
+    for (int l = 0; l < net->n_layers; ++l) { free(net->Wt[l]); net->Wt[l] = NULL; free(net->Wx[l]); net->Wx[l] = NULL;
+                                               free(net->We[l]); net->We[l] = NULL; free(net->Wm[l]); net->Wm[l] = NULL; }
 }
 
 void orc_sdf_forward(int n_layers, const int *in, const int *out, int skip_mask, int multires,
@@ -618,6 +719,7 @@ void orc_analytic_sdf(const float *x, int n, float *y) {
     for (int i = 0; i < n; ++i) y[i] = analytic_sdf(x + 3 * i);
 }
 void orc_softplus100(const float *x, int n, float *y) { for (int i = 0; i < n; ++i) y[i] = dm_softplus100(x[i]); }
+void orc_softplus100_lean(const float *x, int n, float *y) { for (int i = 0; i < n; ++i) y[i] = dm_softplus100_lean(x[i]); }
 void orc_sincos(const float *x, int n, float *s, float *c) { for (int i = 0; i < n; ++i) dm_sincos(x[i], s + i, c + i); }
 void orc_expneg(const float *x, int n, float *y) { for (int i = 0; i < n; ++i) y[i] = dm_expneg(x[i]); }
 void orc_log1p01(const float *x, int n, float *y) { for (int i = 0; i < n; ++i) y[i] = dm_log1p01(x[i]); }
