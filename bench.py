@@ -52,7 +52,9 @@ FEAT_HW = (600, 800)
 P, V = WORKLOADS['c2']            # defaults of make_inputs (dev tools under tools/ set bench.B / bench.P / bench.V and call it)
 PEAK = {'f32': 157.3, 'bf16w': 157.3, 'bf16': 2500.0, 'bf16x2': 2500.0, 'bf16x3': 2500.0, 'f32x3': 2500.0}    # dense MFMA TFLOP/s of the tracing MLP's matrix instruction,
 # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32 / v_mfma_f32_16x16x32_bf16); bf16x2 / bf16x3 issue 2 / 3 bf16 matrix instructions per
-# ALGORITHMIC multiply-add (activations as bf16 terms), f32x3 six (fp32 weights as three terms too): `achieved` counts the algorithmic FLOPs once
+# ALGORITHMIC multiply-add (activations as bf16 terms), f32x3 six (fp32 weights as three terms too): `achieved` counts the algorithmic FLOPs once and
+# `roofline.peak` is the instruction's dense peak divided by MUL (the rate at which the matrix pipe can deliver ALGORITHMIC multiply-adds in that arithmetic)
+MUL = {'bf16x2': 2, 'bf16x3': 3, 'f32x3': 6}
 
 
 def reference_cpu():
@@ -210,7 +212,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)          # ~3 ms per step: the default run still takes seconds
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
-    ap.add_argument('--dtype', default='f32', choices=sorted(PEAK), help="arithmetic of the no-grad tracing MLP (IDRNetwork.set_trace_dtype); the differentiable half is always fp32")
+    ap.add_argument('--dtype', default='f32x3', choices=sorted(PEAK), help="arithmetic of the no-grad tracing MLP (IDRNetwork.set_trace_dtype); the differentiable half is always fp32")
     ap.add_argument('--width', type=int, default=256, help='hidden width of both MLPs: 256 = BASELINE.json (8x256), 512 = the reference\'s shipped conf (mvsdf_dtu.conf:24,35)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shard', default='', help="R/W (tests): run as ONE process on the shard rank R of a W-rank job would get (its views, its pixels per view, its seed); no process group")
@@ -356,7 +358,7 @@ def main():
         grad_events, loss_fn.collective_events = None, None
     if rank == 0:
         f_t, f_s, f_r = flops_per_row(W)
-        peak = PEAK[a.dtype]
+        peak = PEAK[a.dtype] / MUL.get(a.dtype, 1)
         st = model.last_stats
         cnt = st['counters'].cpu().numpy()
         # tracer rows actually evaluated: counters[8] = ray-sampler rows up to each ray's first sign change (the reference also
@@ -430,11 +432,14 @@ def main():
                                   'hbm_bytes': pmc_step_bytes(pmc), 'pmc_source': None if pmc is None else pmc.get('note')}},
             'loss': float(lo['loss'].detach()),
         }
-        mul = {'bf16x2': 2, 'bf16x3': 3, 'f32x3': 6}.get(a.dtype)
+        mul = MUL.get(a.dtype)
         if mul:
-            # the term engines issue `mul` bf16 matrix instructions per ALGORITHMIC multiply-add: the rate they can reach is peak / mul
+            # the term engines issue `mul` bf16 matrix instructions per ALGORITHMIC multiply-add: `peak` above is the instruction's dense peak / mul
             res['roofline']['matrix_instructions_per_mac'] = mul
-            res['roofline']['frac_of_peak_over_instructions_per_mac'] = ach * mul / peak
+            res['roofline']['instruction_peak'] = PEAK[a.dtype]
+            res['roofline']['frac_of_instruction_peak_counting_algorithmic_flops_once'] = ach / PEAK[a.dtype]
+            if a.dtype == 'f32x3':
+                res['roofline']['frac_of_fp32_mfma_peak'] = ach / PEAK['f32']           # against what the fp32 matrix instruction could deliver for the same arithmetic
         if collective_ms is not None:
             res['collective_ms'] = collective_ms
         if ranks is not None:
@@ -456,15 +461,13 @@ def main():
             res['variants'] = {'lazy_unused_outputs': {'ms_per_step': dtv * 1e3, 'rays_per_s': R / dtv, 'steps': nv,
                                                        'rows_not_evaluated_per_step': int(cnt[3]),
                                                        'note': 'opt-in, default off; loss and gradients identical (tests/test_gpu_lazy.py); not the headline value'}}
-        if not a.no_cpu_baseline and world == 1 and a.dtype == 'f32':
-            # secondary number, never `value`: the same step with the tracing MLP on the bf16 matrix cores at fp32 accuracy ('f32x3': weights and
-            # activations as three bf16 terms each, six exact products; tests/test_gpu_f32x3.py: bit-exact against its own oracle -- a model of the
-            # matrix instruction --, closer to an fp64 evaluation than the fp32 fmaf chain, hit masks equal to the fmaf-chain oracle's on every fixture,
-            # every reference fixture passes).  Same run, same inputs, same frozen weights: the hit masks of the two arithmetics are compared here too.
-            # (Not in profile runs: they pass --no-cpu-baseline.)
-            mask_f32 = out['network_object_mask'].clone()
-            loss_f32 = float(lo['loss'].detach())
-            model.set_trace_dtype('f32x3')
+        if not a.no_cpu_baseline and world == 1 and a.dtype == 'f32x3':
+            # secondary number, never `value`: the same step with the tracing MLP as a k-ascending fmaf chain on the fp32 matrix instruction
+            # (IDRNetwork.set_trace_dtype('f32'): the arithmetic `value` was quoted on in rounds 1-4; bit-exact against the fmaf-chain oracle).  Same run, same
+            # inputs, same frozen weights: the hit masks of the two arithmetics are compared here too.  (Not in profile runs: they pass --no-cpu-baseline.)
+            mask_def = out['network_object_mask'].clone()
+            loss_def = float(lo['loss'].detach())
+            model.set_trace_dtype('f32')
             for _ in range(max(5, a.warmup // 2)):
                 step()
             torch.cuda.synchronize()
@@ -474,13 +477,14 @@ def main():
             torch.cuda.synchronize()
             dt3 = (time.perf_counter() - t0) / a.steps
             model.set_trace_dtype(a.dtype)
-            res['trace_arithmetic_f32x3'] = {
-                'ms_per_step': dt3 * 1e3, 'rays_per_s': R / dt3, 'steps': a.steps, 'speedup_vs_value': (dt / a.steps) / dt3,
-                'hit_masks_differing_from_f32': int((out3['network_object_mask'] != mask_f32).sum()), 'rays': R,
-                'loss_f32': loss_f32, 'loss_f32x3': float(lo3['loss'].detach()),
-                'note': "IDRNetwork.set_trace_dtype('f32x3') / bench.py --dtype f32x3: fp32-accurate tracing on v_mfma_f32_16x16x32_bf16 (6 instructions per "
-                        "32-wide k-block instead of 8 fp32 ones of twice the cycles), reproduced bit for bit by the oracle's model of that instruction; `value` "
-                        "stays on the fmaf-chain engine the earlier rounds measured (the losses differ by the eikonal / min-sdf draws of the two loops too)"}
+            res['trace_arithmetic_f32'] = {
+                'ms_per_step': dt3 * 1e3, 'rays_per_s': R / dt3, 'steps': a.steps, 'value_speedup_over_it': dt3 / (dt / a.steps),
+                'hit_masks_differing_from_value_run': int((out3['network_object_mask'] != mask_def).sum()), 'rays': R,
+                'loss_f32x3': loss_def, 'loss_f32': float(lo3['loss'].detach()),
+                'note': "IDRNetwork.set_trace_dtype('f32') / bench.py --dtype f32: the fmaf-chain arithmetic on v_mfma_f32_16x16x4_f32 (8 instructions of 32 cycles per "
+                        "32-wide k-block; `value` runs the product default 'f32x3': the same fp32 arithmetic from 6 bf16 instructions of 16 cycles, reproduced bit for bit "
+                        "by the oracle's model of that instruction at the full batch size, tests/test_gpu_f32x3.py; the losses differ by the eikonal / min-sdf draws of "
+                        "the two loops too)"}
         if not a.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(V)
         print(json.dumps(res), flush=True)

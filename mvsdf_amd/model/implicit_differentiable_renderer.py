@@ -32,6 +32,11 @@ if os.environ.get('IDR_USE_ENV', '0') == '1' and os.environ.get('IDR_CONF', '') 
     print('override conf: ', os.environ.get('IDR_CONF'))
     conf = importlib.import_module(os.environ.get('IDR_CONF'))
 
+# Arithmetic of the no-grad tracing MLP of every IDRNetwork / ImplicitNetwork.native_sdf() built afterwards (IDRNetwork.set_trace_dtype changes one model).
+# 'f32x3' since round 5: bit-exact against its own CPU oracle at the full BASELINE batch sizes (tests/test_gpu_f32x3.py), hit masks identical to the fmaf-chain
+# arithmetic 'f32' on every reference fixture, 1.3x faster.  (Tests switch it through tests/conftest.py, not through the environment.)
+DEFAULT_TRACE_DTYPE = 'f32x3'
+
 
 class _WNLinear(nn.Module):
     """Parameters of a weight-normed nn.Linear in torch.nn.utils.weight_norm's layout: bias, weight_g [out,1], weight_v [out,in]."""
@@ -115,7 +120,7 @@ class ImplicitNetwork(nn.Module):
 
     def native_sdf(self):
         net = self.fold()[0]
-        td = getattr(self, 'trace_dtype', 'f32')
+        td = getattr(self, 'trace_dtype', None) or DEFAULT_TRACE_DTYPE
         ops.pack_trace_net(net, td)
         return NativeSDF(net)
 
@@ -277,9 +282,7 @@ class IDRNetwork(nn.Module):
         self.sample_network = SampleNetwork()
         self.object_bounding_sphere = conf.get_float('ray_tracer.object_bounding_sphere')
         self.last_stats = {}
-        self.trace_dtype = 'f32'                                 # 'bf16': the no-grad tracing MLP runs with bf16 weights on the bf16 MFMA (set_trace_dtype)
-        if os.environ.get('MVSDF_TRACE_DTYPE'):                  # (tests: the reference fixtures on another tracing arithmetic, tests/test_gpu_f32x3.py)
-            self.set_trace_dtype(os.environ['MVSDF_TRACE_DTYPE'])
+        self.set_trace_dtype(DEFAULT_TRACE_DTYPE)                # arithmetic of the no-grad tracing MLP (see set_trace_dtype)
         self._counts_host = None                                 # pinned [N hit, N hit & true mask], filled while the tracer still runs
         self._counts_event = None
         self._draw = PinnedUniform()
@@ -293,7 +296,10 @@ class IDRNetwork(nn.Module):
         self._ones = None                                        # all-ones object mask handed to the tracer when conf.use_mask is off
 
     def set_trace_dtype(self, dtype):
-        """'f32' (default: fp32 weights, fp32-input MFMA, bit-exact against the oracle) or 'bf16' (BASELINE configs[4]: the ray tracer's SDF
+        """'f32x3' (the default, DEFAULT_TRACE_DTYPE): the reference's fp32 arithmetic (idr.py:77-94 inside ray_tracing.py:27-98, fp32 weights unrounded) from
+        six exact bf16 products per element pair on v_mfma_f32_16x16x32_bf16, bit-exact against its CPU oracle (a model of that instruction).
+        'f32': the same arithmetic as a k-ascending fmaf chain on v_mfma_f32_16x16x4_f32, bit-exact against the fmaf-chain oracle (the default of rounds
+        1-4; 1.3x slower, slightly further from an fp64 evaluation).  'bf16' (BASELINE configs[4]: the ray tracer's SDF
         evaluations -- ~90 % of the step's FLOPs, all under no_grad -- use bf16-rounded weights and activations on the bf16 MFMA with fp32
         accumulation; the differentiable passes keep fp32).  Outside the 1e-4 parity claim: see DESIGN.md for the accuracy budget.
         'bf16w': only the tracing MLP's WEIGHTS are rounded to bf16 (BASELINE configs[4] says "bf16 MLP weights"), activations and arithmetic
@@ -304,7 +310,8 @@ class IDRNetwork(nn.Module):
         'f32x3': the fp32 weights unrounded, as three bf16 terms like the activations: the reference's fp32 arithmetic from six exact bf16 products per
         element pair on the bf16 MFMA -- fp32-accurate (measured closer to an fp64 evaluation than the 'f32' fmaf chain), bit-exact against its own
         CPU oracle (a model of the matrix instruction) and parity-checked against the fmaf-chain oracle and the reference fixtures; not bit-identical to 'f32'."""
-        assert dtype in ops.TRACE_DTYPES
+        if dtype not in ops.TRACE_DTYPES:
+            raise ValueError('IDRNetwork.set_trace_dtype(%r): expected one of %s' % (dtype, ', '.join(sorted(ops.TRACE_DTYPES))))
         self.trace_dtype = dtype
         self.implicit_network.trace_dtype = dtype
         return self

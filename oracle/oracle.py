@@ -172,6 +172,20 @@ def _unary(name, x, nout=1):
     return outs[0] if nout == 1 else outs
 
 
+def mfma_tiles(A, B, Cin, vector=False):
+    """The oracle's model of v_mfma_f32_16x16x32_bf16 on n tiles: A [n,16,32] / B [n,16,32] bf16 bit patterns (uint16), Cin [n,16,16] fp32 -> D [n,16,16]
+    (D[i][j] = Cin[i][j] + sum_k A[i][k] B[j][k] in the instruction's own order and roundings).  vector: the eight-column AVX2 form the MLP rows use."""
+    A = np.ascontiguousarray(A, np.uint16); B = np.ascontiguousarray(B, np.uint16); Cin = _f(Cin)
+    D = np.empty_like(Cin)
+    lib().orc_mfma_tiles(_p(A), _p(B), _p(Cin), _p(D), C.c_int(A.shape[0]), C.c_int(1 if vector else 0))
+    return D
+
+
+def set_x3_scalar(on):
+    """f32x3 rows through the scalar form of the instruction model (True) instead of the eight-column AVX2 form (default)."""
+    lib().orc_set_x3_scalar(C.c_int(1 if on else 0))
+
+
 def softplus100(x): return _unary('orc_softplus100', x)
 def softplus100_lean(x): return _unary('orc_softplus100_lean', x)   # the f32x3 mode's activation (det_math.h::dm_softplus100_lean)
 def softplus100_arr(x): return _unary('orc_softplus100_arr', x)      # the branch-free array form the MLP rows use

@@ -13,6 +13,15 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'perf: a timing gate (relative to a micro-kernel timed in the same run); deselect with -m "gpu and not perf" on a shared GPU')
+    # MVSDF_TEST_TRACE_DTYPE=f32|...: run the suite's IDRNetwork models on another tracing arithmetic than the product default ('f32x3') -- how
+    # tests/test_gpu_f32x3.py re-runs the reference fixtures on the fmaf-chain engine.  A test-harness switch: the product reads no such variable.
+    td = os.environ.get('MVSDF_TEST_TRACE_DTYPE')
+    if td:
+        from mvsdf_amd import ops
+        from mvsdf_amd.model import implicit_differentiable_renderer as idr
+        if td not in ops.TRACE_DTYPES:
+            raise pytest.UsageError('MVSDF_TEST_TRACE_DTYPE=%r: expected one of %s' % (td, ', '.join(sorted(ops.TRACE_DTYPES))))
+        idr.DEFAULT_TRACE_DTYPE = td
 
 
 def golden(name):

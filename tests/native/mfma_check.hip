@@ -1,3 +1,8 @@
+// TEST INFRASTRUCTURE (tests/test_gpu_mfma_model.py; built by tests/native/build_native.py into tests/native/libmfma_check.so, not part of the product library).
+// Re-verifies, on whatever GPU runs the suite, the bit-level model of v_mfma_f32_16x16x32_bf16 that the `f32x3` oracle rests on
+// (oracle/oracle_mvsdf.c::mfma_step8, tools/micro/mfma_bf16_model/README.md):
+//   * mfma_fuzz_run: the model evaluated ON the GPU in 64-bit integers beside the instruction (operands from a counter-based hash): ~10^9 outputs per second;
+//   * mfma_exec_tiles: the bare instruction on caller-supplied tiles, so that the test can compare the hardware with the ORACLE's C model directly.
 // The instruction model of README.md against v_mfma_f32_16x16x32_bf16 ON the GPU: every lane regenerates the operands of its four outputs from a counter-based
 // hash, evaluates the model in 64-bit integers and compares with what the matrix core returned.  Billions of instruction instances in seconds.
 // Build: hipcc --offload-arch=gfx950 -O2 -o mfma_fuzz mfma_fuzz.hip ; run: ./mfma_fuzz [blocks] [iterations] [seed] [tiny: operands near 2^-60 .. 2^-75, products below the fp32 normal range | low: operands 2^-20 .. 2^-49, the smallest the f32x3 engine feeds]
@@ -98,6 +103,53 @@ __global__ __launch_bounds__(64) void k_fuzz(uint64_t seed, int iters, int tiny,
     if (bad) atomicAdd(nbad, bad);
     if (lane == 0) atomicAdd(ntot, (unsigned long long)iters * 256);
 }
+__global__ __launch_bounds__(64) void k_exec(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, const float* __restrict__ C, float* __restrict__ D) {
+    // tile t: A[t][16 rows i][32 k], B[t][16 columns j][32 k], C / D[t][i][j];  D[i][j] = C[i][j] + sum_k A[i][k] B[j][k]
+    const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    const size_t t = blockIdx.x;
+    const uint4 ap = *(const uint4*)(A + (t * 16 + r) * 32 + 8 * q), bp = *(const uint4*)(B + (t * 16 + r) * 32 + 8 * q);
+    f32x4 c;
+    for (int i = 0; i < 4; ++i) c[i] = C[(t * 16 + 4 * q + i) * 16 + r];
+    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, ap), __builtin_bit_cast(bf8, bp), c, 0, 0, 0);
+    for (int i = 0; i < 4; ++i) D[(t * 16 + 4 * q + i) * 16 + r] = d[i];
+}
+
+extern "C" {
+// mode 0: operands around 1 (exponent windows of 1 .. 24 octaves), accumulators 2^-40 .. 2^54 times the products; mode 1 ('low'): operands 2^-20 .. 2^-49 (the
+// smallest the f32x3 engine feeds: it flushes below 2^-40), accumulators 2^-100 .. 2^4.   out[0] = outputs that differ from the model, out[1] = outputs compared,
+// out[2] = (first differing instance * 256 + output) | 2^63.   Returns 0, or the HIP error code.
+int mfma_fuzz_run(unsigned long long seed, int blocks, int iters, int mode, unsigned long long* out) {
+    unsigned long long *d = nullptr, h[3] = {0, 0, 0};
+    hipError_t e = hipMalloc(&d, 24);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpy(d, h, 24, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_fuzz, dim3(blocks), dim3(64), 0, 0, (uint64_t)seed * 0x100000000ull, iters, mode == 1 ? 128 : (mode == 2 ? 64 : 0), d, d + 1, (uint64_t*)(d + 2));
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d, 24, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return (int)e;
+}
+// host pointers; n tiles
+int mfma_exec_tiles(const uint16_t* A, const uint16_t* B, const float* C, float* D, int n) {
+    uint16_t *dA = nullptr, *dB = nullptr; float *dC = nullptr, *dD = nullptr;
+    const size_t sa = (size_t)n * 16 * 32 * 2, sc = (size_t)n * 256 * 4;
+    hipError_t e = hipMalloc(&dA, sa);
+    if (e == hipSuccess) e = hipMalloc(&dB, sa);
+    if (e == hipSuccess) e = hipMalloc(&dC, sc);
+    if (e == hipSuccess) e = hipMalloc(&dD, sc);
+    if (e == hipSuccess) e = hipMemcpy(dA, A, sa, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dB, B, sa, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dC, C, sc, hipMemcpyHostToDevice);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_exec, dim3(n), dim3(64), 0, 0, dA, dB, dC, dD); e = hipDeviceSynchronize(); }
+    if (e == hipSuccess) e = hipMemcpy(D, dD, sc, hipMemcpyDeviceToHost);
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dD);
+    return (int)e;
+}
+}
+
+#ifdef MFMA_CHECK_MAIN
 int main(int argc, char** argv) {
     const int blocks = argc > 1 ? atoi(argv[1]) : 4096, iters = argc > 2 ? atoi(argv[2]) : 256;
     const uint64_t seed = argc > 3 ? strtoull(argv[3], 0, 10) : 1;
@@ -111,3 +163,4 @@ int main(int argc, char** argv) {
     printf("\n");
     return 0;
 }
+#endif

@@ -19,13 +19,17 @@ def _scene(B, P, W=256, seed=0):
     return sd, net, dirs, cam
 
 
-@pytest.mark.parametrize('B,P,mt,name', [(8, 256, 1, 'c2'), (8, 512, 2, 'c5 share'), (8, 1024, 4, 'c3'), (8, 4096, 4, 'c5 whole batch')])
-def test_full_size_tracer_bit_exact_vs_oracle(oracle, B, P, mt, name):
+@pytest.mark.parametrize('B,P,mt,name,dtype', [(8, 256, 1, 'c2', 'f32x3'), (8, 512, 2, 'c5 share', 'f32x3'), (8, 1024, 4, 'c3', 'f32x3'),
+                                               (8, 256, 1, 'c2', 'f32'), (8, 512, 2, 'c5 share', 'f32'), (8, 1024, 4, 'c3', 'f32'), (8, 4096, 4, 'c5 whole batch', 'f32')])
+def test_full_size_tracer_bit_exact_vs_oracle(oracle, B, P, mt, name, dtype):
     """BASELINE's batches -- c2: 2048 rays, c5's per-GPU share: 4096, c3: 8192, the whole c5 batch: 32768 -- through the 8x256 MLP in training mode with the row-tile
-    settings RayTracing picks at that size: masks, dists, points and the per-stage row counters equal the CPU oracle bit for bit (the
-    oracle's rows are evaluated eight columns at a time on the host: c3's 585 k rows take about a second, c5's 2.3 M a few)."""
+    settings RayTracing picks at that size: masks, dists, points and the per-stage row counters equal the CPU oracle bit for bit, for the product's default
+    tracing arithmetic 'f32x3' (oracle: the model of v_mfma_f32_16x16x32_bf16, eight columns per AVX2 instruction: ~2.6 ms per MLP row and host thread, c3's
+    585 k rows ~15 s on the GPU box's 128 threads) and for the fmaf-chain arithmetic 'f32' (c3 about a second, the whole c5 batch's 2.3 M rows a few)."""
     sd, net, dirs, cam = _scene(B, P)
-    onet = oracle.Net(sd)
+    if dtype == 'f32x3':
+        net = ops.pack_bf16_net(net, terms=3, weight_terms=3)
+    onet = oracle.Net(sd, bf16='f32x3' if dtype == 'f32x3' else False)
     R = B * P
     iv = torch.linspace(0, 1, 100)
     steps = np.random.RandomState(1).uniform(size=100).astype(np.float32)

@@ -122,7 +122,7 @@ def report_margins(tag, g, hit, depth_err, limit=2e-5):
 # ---- the oracle's model of trace_dtype 5 ("f32x3": the bf16 matrix instruction with three-term weights and activations, oracle_mvsdf.c::sdf_row_f32x3) pinned
 # to the same reference fixtures as the fp32 chain above: it is a second restatement of idr.py:77-94 (another summation order), held to the same bar
 
-@pytest.mark.parametrize('W,n', [(64, 2000), (256, 300)])
+@pytest.mark.parametrize('W,n', [(64, 4000), (256, 2000), (512, 300)])
 def test_sdf_forward_three_term_model(oracle, W, n):
     g = golden('sdf_w%d' % W)
     sd = synth.make_state_dict(int(g['W']), int(g['seed']))
@@ -132,7 +132,7 @@ def test_sdf_forward_three_term_model(oracle, W, n):
     assert 0 < np.abs(y3 - y0).max() < 4e-6                                                   # another arithmetic, fp32-close to the fmaf chain
 
 
-@pytest.mark.parametrize('W,mode,rays', [(64, 'eval', 512), (64, 'train', 384), (256, 'eval', 96)])
+@pytest.mark.parametrize('W,mode,rays', [(64, 'eval', 1024), (64, 'train', 1024), (256, 'eval', 256), (256, 'train', 128), (512, 'train', 32)])
 def test_tracer_three_term_model(oracle, W, mode, rays):
     """the first `rays` rays of view 0 of the trace_mlp fixtures: hit masks bit-exact, hit depths 1e-4 against the reference"""
     g = golden('trace_mlp_w%d_%s' % (W, mode))
@@ -145,3 +145,38 @@ def test_tracer_three_term_model(oracle, W, mode, rays):
     assert np.array_equal(mask, ref_mask)
     rel = np.abs(dists - ref_d) / np.abs(ref_d).clip(1e-6)
     assert rel[ref_mask].max() < 1e-4
+
+
+@pytest.mark.parametrize('W,n', [(64, 1500), (256, 160), (512, 24)])
+def test_x3_vector_model_equals_the_scalar_model(oracle, W, n):
+    """The eight-columns-per-instruction (AVX2) form of the matrix-instruction model == the scalar form (mfma_step8: 128-bit integers) bit for bit: all 258
+    output columns of random networks whose weight rows mix magnitudes over 20 octaves (so that products are cut, shifted out, cancel), points at / near the
+    origin (tiny and flushed positional-encoding terms); and on raw tiles with exponent windows up to 24 octaves, zeros, signed-zero and far-away accumulators."""
+    rs = np.random.RandomState(W)
+    sd = {k: v.copy() for k, v in synth.make_state_dict(W, 3).items()}
+    for k in sd:
+        if k.startswith('implicit_network') and k.endswith('weight_v'):
+            sd[k] = (sd[k] * np.exp2(-rs.randint(0, 21, size=sd[k].shape) * (rs.uniform(size=sd[k].shape) < 0.5))).astype(np.float32)
+    x = rs.uniform(-1.2, 1.2, size=(n, 3)).astype(np.float32)
+    x[:4] *= 1e-3
+    x[4:8] = 0.0
+    x[8:12] = np.float32(1e-30)
+    net = oracle.Net(sd, bf16='f32x3')
+    yv = oracle.sdf_forward(net, x)
+    oracle.set_x3_scalar(True)
+    try:
+        ys = oracle.sdf_forward(net, x)
+    finally:
+        oracle.set_x3_scalar(False)
+    assert yv.shape == (n, 258) and np.array_equal(yv.view(np.uint32), ys.view(np.uint32))
+    m = 3000
+    for low in (False, True):
+        e = (127 - (rs.randint(20, 36, size=(m, 1, 1)) if low else rs.choice([0, 6], size=(m, 1, 1)))) - rs.randint(0, 1 << 16, size=(2, m, 16, 32)) % rs.choice([1, 2, 4, 8, 24] if not low else [1, 2, 4, 8], size=(m, 1, 1))
+        ops_ = ((rs.randint(0, 2, size=e.shape) << 15) | (e << 7) | rs.randint(0, 128, size=e.shape)).astype(np.uint16)
+        ops_[rs.randint(0, 48, size=e.shape) == 0] = 0
+        ce = (27 + rs.randint(0, 104, size=(m, 16, 16))) if low else (87 + rs.randint(0, 94, size=(m, 16, 16)))
+        cb = (rs.randint(0, 2, size=ce.shape).astype(np.uint32) << 31) | (ce.astype(np.uint32) << 23) | rs.randint(0, 1 << 23, size=ce.shape).astype(np.uint32)
+        cb[rs.randint(0, 24, size=ce.shape) == 0] = 0
+        cb[rs.randint(0, 48, size=ce.shape) == 0] = 0x80000000
+        a, b = oracle.mfma_tiles(ops_[0], ops_[1], cb.view(np.float32), False), oracle.mfma_tiles(ops_[0], ops_[1], cb.view(np.float32), True)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.isfinite(a).all()
