@@ -263,8 +263,10 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams
                     // 150 tiles in 190 us) -- but only when it is CERTAIN to lie inside the rows that already exist: every list item published
                     // (ready == reserved, read in that order: no append in flight, so all `reserved` items are complete) and a margin of one tile per
                     // workgroup of the grid beyond the queue head (between this look and the fetch-add every other workgroup can claim at most one
-                    // tile).  So a claim never has to wait for rows to appear and is never abandoned -- nothing here can deadlock or lose rows, also when
-                    // other processes share the GPU; the margin (<= 256 tiles of a few thousand) is simply left to the launch that follows.
+                    // tile).  So a claim normally never has to wait for rows to appear and is never abandoned; the margin (<= 256 tiles of a few thousand) is
+                    // simply left to the launch that follows.  The one exception -- a workgroup stalled between its look and its fetch-add (another process on
+                    // the GPU) -- is the bounded-by-construction wait below: it ends when the tracing workgroups have published, and those never wait for a
+                    // helper's slot because the grid fits the device (mv_tail_on: at most one workgroup per compute unit).
                     long long take = -1;
                     int n_items = 0;                              // the item count the tile was validated against (>= what it touches)
                     for (int tries = 0; tries < 64; ++tries) {
@@ -705,11 +707,23 @@ static float* mv_minsdf_sv(float* ws, int R, int n_steps) {
 
 // is the tail filling on for this call?  (mt1: row tiles per sphere-tracing workgroup.)  Only for grids of <= 256 workgroups (one per CU): with more,
 // a finished workgroup's slot is wanted by a tracing workgroup that has not started yet -- helping would delay it.
+static int mv_cu_count() {                                         // compute units of the current device (256 on an unpartitioned MI355X)
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 1; }
+        n = v;
+    }
+    return n;
+}
+// The bound is also what makes the helpers' one wait safe (a helper that over-claimed a tile sleeps until the rows it owns are published, see the claim
+// loop in k_sphere_trace): with at most one workgroup per compute unit OF THIS DEVICE every workgroup of the grid can be resident at once, so the tracing
+// workgroups a waiting helper depends on never wait for its slot.  (A partitioned device reports fewer compute units and gets no tail filling at c2.)
 template <class NET>
 static bool mv_tail_on(int training, const float* steps, int R, int mt1) {
     constexpr bool is_bf = !std::is_same<NET, MvNet>::value;
     const int grid1 = (R + 8 * mt1 - 1) / (8 * mt1);
-    return training && steps && mv_tail_mode() >= (is_bf ? 2 : 1) && grid1 <= 256;
+    return training && steps && mv_tail_mode() >= (is_bf ? 2 : 1) && grid1 <= mv_cu_count();
 }
 
 template <class NET>

@@ -142,6 +142,10 @@ class FlatAdam(torch.optim.Optimizer):
                                            self.norm_and_coef.data_ptr(), self._ws.data_ptr(),
                                            C.c_void_p(torch.cuda.current_stream(fp.device).cuda_stream)), 'mvsdf_adam_step_scaled')
         self._grad_scale = 1.0
+        # the launch wrote the parameters through a raw pointer: tell autograd (an in-place update), so that a backward whose forward ran BEFORE this step
+        # raises like it does after torch.optim.Adam.step() instead of mixing old activations with the new weights (native_step._NativeStepFn.backward and
+        # autograd's own saved-tensor check compare these version counters)
+        torch.autograd.graph.increment_version(g['params'])
         if hooks:
             for h in list(self._optimizer_step_post_hooks.values()) + list(_global_optimizer_post_hooks.values()):
                 h(self, args, kwargs)

@@ -149,6 +149,34 @@ def test_two_forwards_before_the_first_backward():
     _same(grads('interleaved'), grads('alone'), 'gradient of the first forward')
 
 
+@pytest.mark.parametrize('direct', [True, False])
+def test_a_backward_after_an_optimizer_step_in_between_raises(direct):
+    """forward A, forward B, backward B, FlatAdam.step() (which writes the parameters through a raw pointer), backward A: A's saved activations belong to the
+    OLD weights while its weight-norm fold backward would read the NEW ones -- the step must raise like autograd does after torch.optim.Adam.step(), through
+    FlatAdam.backward's direct route and through loss.backward() alike (FlatAdam.step bumps the parameters' version counters)."""
+    m = _model(64, True)
+    opt = FlatAdam(m.parameters(), lr=1e-3)
+    inp_a, gt_a = _batch(2, 200, 2, seed=3)
+    inp_b, gt_b = _batch(2, 200, 2, seed=4)
+    loss_fn = IDRLoss()
+    torch.manual_seed(5)
+    lo_a = loss_fn(m(inp_a, 0.3), dict(gt_a), 0.3, 2)
+    lo_b = loss_fn(m(inp_b, 0.3), dict(gt_b), 0.3, 2)
+    v0 = [p._version for p in m.parameters()]
+    opt.zero_grad()
+    opt.backward(lo_b['loss']) if direct else lo_b['loss'].backward()
+    opt.step()
+    assert all(p._version > v for p, v in zip(m.parameters(), v0))
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        opt.backward(lo_a['loss']) if direct else lo_a['loss'].backward()
+    # and the ordinary order keeps working after it
+    opt.zero_grad()
+    lo_c = loss_fn(m(inp_a, 0.3), dict(gt_a), 0.3, 2)
+    opt.backward(lo_c['loss'])
+    opt.step()
+    assert torch.isfinite(torch.cat([p.flatten() for p in m.parameters()])).all()
+
+
 def test_native_loss_accepts_foreign_outputs():
     """IDRLoss's fused route is generic: it takes any output dict (here: tensors made by plain torch ops with autograd leaves)."""
     m = _model(64, True)
