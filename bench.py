@@ -46,15 +46,19 @@ W, B, TP = 256, 8, 0.3
 WORKLOADS = {                     # name: (pixels per view and GPU-count unit, source views)
     'c2': (256, 4),               # BASELINE configs[1]: 2048 rays, 4 source views (the configuration the metric is quoted on)
     'c3': (1024, 8),              # configs[2]: 8192 rays, 8 source views
-    'c5share': (512, 8),          # configs[4] per-GPU share: 32768 rays / 8 GPUs = 4096 rays, 8 source views (meant for --dtype bf16)
+    'c5share': (512, 8),          # configs[4] per-GPU share: 32768 rays / 8 GPUs = 4096 rays, 8 source views (meant for --dtype bf16x2)
+    # the reference's REAL default training step on one GPU (not a BASELINE config; secondary line only): 8 views x 4096 px = 32768 rays (README.md:38 batch size,
+    # confs/mvsdf_dtu.conf:4 num_pixels), 8x512 SDF net / 4x512 rendering net (mvsdf_dtu.conf:24,35), num_src = 2 source views (datasets/scene_dataset.py:104)
+    'shipped': (4096, 2),
 }
+WORKLOAD_WIDTH = {'shipped': 512}
 FEAT_HW = (600, 800)
 P, V = WORKLOADS['c2']            # defaults of make_inputs (dev tools under tools/ set bench.B / bench.P / bench.V and call it)
-PEAK = {'f32': 157.3, 'bf16w': 157.3, 'bf16': 2500.0, 'bf16x2': 2500.0, 'bf16x3': 2500.0, 'f32x3': 2500.0}    # dense MFMA TFLOP/s of the tracing MLP's matrix instruction,
-# /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32 / v_mfma_f32_16x16x32_bf16); bf16x2 / bf16x3 issue 2 / 3 bf16 matrix instructions per
+PEAK = {'f32x3': 2500.0, 'f32': 157.3, 'bf16x2': 2500.0, 'bf16w': 157.3}    # dense MFMA TFLOP/s of the tracing MLP's matrix instruction,
+# /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32 / v_mfma_f32_16x16x32_bf16); bf16x2 issues 2 bf16 matrix instructions per
 # ALGORITHMIC multiply-add (activations as bf16 terms), f32x3 six (fp32 weights as three terms too): `achieved` counts the algorithmic FLOPs once and
 # `roofline.peak` is the instruction's dense peak divided by MUL (the rate at which the matrix pipe can deliver ALGORITHMIC multiply-adds in that arithmetic)
-MUL = {'bf16x2': 2, 'bf16x3': 3, 'f32x3': 6}
+MUL = {'bf16x2': 2, 'f32x3': 6}
 
 
 def reference_cpu():
@@ -213,13 +217,16 @@ def main():
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--dtype', default='f32x3', choices=sorted(PEAK), help="arithmetic of the no-grad tracing MLP (IDRNetwork.set_trace_dtype); the differentiable half is always fp32")
-    ap.add_argument('--width', type=int, default=256, help='hidden width of both MLPs: 256 = BASELINE.json (8x256), 512 = the reference\'s shipped conf (mvsdf_dtu.conf:24,35)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'], help="--gpus N: 'weak' (default) keeps the rays per GPU fixed (views sharded, px per view x N: N = 8 is the c4 shape); "
+                    "'strong' keeps the JOB fixed at the workload's N = 8 shape (c2: c4's 8 views x 2048 px = 16384 rays in total) and shards its views: N = 1 runs all of it on one GPU")
+    ap.add_argument('--width', type=int, default=0, help='hidden width of both MLPs: 256 = BASELINE.json (8x256), 512 = the reference\'s shipped conf (mvsdf_dtu.conf:24,35)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shard', default='', help="R/W (tests): run as ONE process on the shard rank R of a W-rank job would get (its views, its pixels per view, its seed); no process group")
     ap.add_argument('--variants', action='store_true', help='also time the opt-in lazy_unused_outputs step (secondary number; off by default so that a profile of this command holds the headline step only)')
     a = ap.parse_args()
     global W
-    W = a.width
+    W = a.width or WORKLOAD_WIDTH.get(a.workload, 256)
+    a.width = W
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(a))
@@ -263,7 +270,9 @@ def main():
     if a.shard:
         assert world == 1, '--shard is for single-process runs'
         srank, sworld = (int(v) for v in a.shard.split('/'))
-    P = P_unit * sworld                                          # pixels per view: 2048 (c2) rays per GPU at every world size
+    # pixels per view.  weak: P_unit x ranks -- 2048 (c2) rays per GPU at every world size; strong: the 8-rank shape at every world size -- the job is fixed,
+    # a rank gets B / world of its views (c2: 16384 rays in total = BASELINE configs[3]; one GPU runs all of them)
+    P = P_unit * (B if a.scaling == 'strong' else sworld)
     per = B // sworld
     R = per * P                                                  # rays of this rank
     conf = synth.model_conf(W)
@@ -356,6 +365,13 @@ def main():
                          'loss_counts_all_reduce': ms(loss_fn.collective_events),
                          'note': 'mean over %d steps outside the timed region; events on the compute stream around each call (the time the stream is held, incl. waiting for the slowest rank)' % nt}
         grad_events, loss_fn.collective_events = None, None
+    # job-level invariants for the scaling tests: hits over all ranks (the hit masks do not depend on the sharding) and the norm of the rank-averaged gradient
+    hits_total = int(model.last_stats['N'])
+    grad_norm = float(opt.grad_norm())
+    if under_launcher:
+        hv = torch.tensor([float(hits_total)], device=dev, dtype=torch.float64)
+        dist.all_reduce(hv)
+        hits_total = int(hv.item())
     if rank == 0:
         f_t, f_s, f_r = flops_per_row(W)
         peak = PEAK[a.dtype] / MUL.get(a.dtype, 1)
@@ -404,11 +420,11 @@ def main():
         res = {
             'metric': 'traced rays/sec (fwd+bwd, 10 sphere iters, %d src views)' % V, 'value': total_R * a.steps / dt, 'unit': 'rays/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'scaling': a.scaling, 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': '%s: DTU-scan24-shaped synthetic scene, %d views x %d px = %d rays in total, %d rays/GPU (%d view(s) per GPU), %d src views, 8x%d SDF MLP, '
-                                   'full fwd+loss+bwd+clip+Adam(lr=0)' % (a.workload if world == 1 else a.workload + ' x%d (c4 shape at 8 GPUs)' % world,
+                                   'full fwd+loss+bwd+clip+Adam(lr=0)' % (a.workload if (world == 1 and a.scaling == 'weak') else a.workload + (' x%d (c4 shape at 8 GPUs)' % world if a.scaling == 'weak' else ' strong scaling: the 8-rank job (c4 shape for c2) on %d GPU(s)' % world),
                                                                           B, P, total_R, R, per, V, W),
-                       'rays_per_gpu': R, 'rays_total': total_R, 'views_total': B, 'src_views': V, 'sdf_width': W, 'train_progress': TP,
+                       'rays_per_gpu': R, 'rays_total': total_R, 'hits_total': hits_total, 'grad_norm_after_all_reduce': grad_norm, 'views_total': B, 'src_views': V, 'sdf_width': W, 'train_progress': TP,
                        'feature_maps': '32x%dx%d channels-last' % FEAT_HW,
                        'parallelism': 'views sharded over %d rank(s), depth maps replicated; one all-reduce(SUM) on the flat grad buffer (+ 3 loss counts)' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'k_ray_samples (fused 9-layer tracing MLP on the sampler / secant / min-sdf rows)', 'achieved': ach,

@@ -36,29 +36,29 @@ typedef struct {
     int K[MVSDF_MAX_LAYERS];            /* in features per Linear */
     int N[MVSDF_MAX_LAYERS];            /* out features per Linear */
     const float* wp[MVSDF_MAX_LAYERS];  /* packed weights, mvsdf_packed_floats(N, K) floats */
-    const float* bias[MVSDF_MAX_LAYERS]; /* [N] floats.  trace_dtype == 1 reads each vector with 16-byte loads up to the next multiple of 16 entries (the
+    const float* bias[MVSDF_MAX_LAYERS]; /* [N] floats.  trace_dtype 3 / 4 / 5 read each vector with 16-byte loads up to the next multiple of 16 entries (the
                                          * entries past N are loaded and never used): the buffer must be readable that far, which every hipMalloc'd or
                                          * torch-allocated buffer is (allocation granularity >= 64 bytes) */
     const float* w[MVSDF_MAX_LAYERS];   /* folded weights, row-major [N][K] (only the last layer's row 0 is read: u_L = W_L[0,:]); may be NULL when no normals are needed */
     int skip_layer;                     /* layer whose input is cat([x, PE(x)])/sqrt(2) (idr.py:86-87), -1 if none (see skip_mask for several) */
     int multires;                       /* positional-encoding frequencies (embedder.py:38-50) */
-    const void* wp16[MVSDF_MAX_LAYERS]; /* trace_dtype 1: bf16 packs made by mvsdf_pack_bf16_net (BASELINE configs[4]); 2: fp32 packs of the rounded weights
+    const void* wp16[MVSDF_MAX_LAYERS]; /* trace_dtype 2: fp32 packs of the rounded weights
                                          * (mvsdf_pack_bf16w_net); 3 / 4: bf16 packs made by mvsdf_pack_bf16s_net; 5: three-term packs made by mvsdf_pack_bf16x3_net;
                                          * NULL for trace_dtype 0 */
     int trace_dtype;                    /* arithmetic of the no-grad tracing MLP (mvsdf_trace, mvsdf_sdf_col0): 0 = fp32 weights and fp32-input
-                                         * MFMA (bit-exact against the oracle), 1 = bf16 weights / activations on the bf16 MFMA, fp32 accumulate,
+                                         * MFMA (bit-exact against the fmaf-chain oracle), 1 = REMOVED in round 5 (bf16 weights AND 8-bit activations: every entry point refuses it),
                                          * 2 = bf16-ROUNDED WEIGHTS ONLY: wp16[l] holds an fp32 pack (mvsdf_packed_floats(N, K) floats, made by
                                          * mvsdf_pack_bf16w_net) of the weights rounded to bf16, activations stay fp32 on the fp32-input MFMA -- bit-exact
-                                         * against the oracle run on the rounded weights; what rounding the activations too (mode 1) costs is then a number,
+                                         * against the oracle run on the rounded weights,
                                          * 3 / 4 = bf16 weights on the bf16 MFMA with every activation carried as 2 / 3 bf16 TERMS (a = t0 + t1 [+ t2], 16 / all 24
                                          * mantissa bits; csrc/tile_engine_bf16s.h): the arithmetic of mode 2 (idr.py:77-94 on bf16-rounded weights) up to the order
                                          * of the fp32 additions inside the matrix core -- the fast mode that is parity-checked against that oracle (hit masks
-                                         * equal except at recorded ties, depths 1e-4).  bias[] is read like in mode 1,
+                                         * equal except at recorded ties, depths 1e-4).  bias[] is read with 16-byte loads up to the next multiple of 16 entries,
                                          * 5 = the fp32 weights UNROUNDED as three bf16 terms too (w = w0 + w1 + w2 exactly): the reference's fp32 Linear
                                          * (idr.py:89) from the six exact products a_s w_j, s + j <= 2, on the bf16 MFMA -- fp32-accurate (measured closer to an
                                          * fp64 evaluation than mode 0's fmaf chain) and reproduced BIT FOR BIT by the oracle's model of the matrix instruction
                                          * (oracle_mvsdf.c::sdf_row_f32x3); det_math's softplus like mode 0; values below 2^-40 count as zero.  Not bit-identical
-                                         * to mode 0 (another summation order).  bias[] is read like in mode 1 */
+                                         * to mode 0 (another summation order).  bias[] is read like in modes 3 / 4 */
     unsigned skip_mask;                 /* several skip connections (skip_in with more than one entry, idr.py:46,86): bit l set = the input of layer l
                                          * is cat([x, PE(x)])/sqrt(2).  0 = use skip_layer alone.  Layer 0 and the last layer cannot be skip layers. */
 } MvsdfNetDesc;
@@ -124,18 +124,12 @@ int mvsdf_fold_backward_net(int n_layers, const float* const* v, const float* co
 /* backward of the fold: dW[N][K] -> dv[N][K], dg[N]    */
 int mvsdf_fold_backward(const float* v, const float* g, const float* dW, int N, int K, float* dv, float* dg, void* stream);
 
-/* bf16 packs of an SDF network for trace_dtype = 1: the folded fp32 weights w[l] ([N][K] row-major, device) rounded to bf16 (nearest even)
- * in the layout of v_mfma_f32_16x16x32_bf16.  Positional-encoding input columns (all of layer 0, the last 3 + 6*multires of the skip
- * layer) are stored twice: those inputs enter as hi + lo bf16 pairs (csrc/tile_engine_bf16.h).  wp16[l]: mvsdf_packed_bf16_bytes(...) bytes. */
+/* bytes of one layer's bf16 pack in the layout of v_mfma_f32_16x16x32_bf16 (wp16[l] of trace_dtype 3 / 4; three times that for trace_dtype 5);
+ * nsplit = 0 (duplicated hi / lo input columns belonged to trace_dtype 1, removed in round 5). */
 size_t mvsdf_packed_bf16_bytes(int N, int K, int nsplit);
-int mvsdf_pack_bf16_net(int n_layers, const float* const* w, const int* N, const int* K, int skip_layer, int multires, void* const* wp16,
-                        void* stream);
 /* trace_dtype = 2: fp32 MFMA packs (layout of mvsdf_fold_pack's wp) of the folded weights w[l] rounded to bf16 (nearest even) */
 int mvsdf_pack_bf16w_net(int n_layers, const float* const* w, const int* N, const int* K, float* const* wp_rounded, void* stream);
-/* mvsdf_pack_bf16_net for a network with several skip connections (MvsdfNetDesc.skip_mask) */
-int mvsdf_pack_bf16_net_skips(int n_layers, const float* const* w, const int* N, const int* K, unsigned skip_mask, int multires, void* const* wp16,
-                              void* stream);
-/* trace_dtype = 3 / 4: bf16 packs in the layout of mode 1 WITHOUT duplicated columns (the positional-encoding inputs are split into bf16 terms like
+/* trace_dtype = 3 / 4: bf16 packs (v_mfma_f32_16x16x32_bf16 B-operand layout) WITHOUT duplicated columns (the positional-encoding inputs are split into bf16 terms like
  * every other activation); wp16[l]: mvsdf_packed_bf16_bytes(N, K, 0) bytes.  idr.py:77-94 on bf16-rounded weights. */
 int mvsdf_pack_bf16s_net(int n_layers, const float* const* w, const int* N, const int* K, void* const* wp16, void* stream);
 /* trace_dtype = 5: the folded fp32 weights as three bf16 terms (t0 = bf16(w), t1 = bf16(w - t0), t2 = bf16(w - t0 - t1)), layout of mvsdf_pack_bf16s_net
@@ -268,13 +262,14 @@ int mvsdf_depth_carve(const float* pts, int pts_ld, int M, const float* depths, 
 /* ---- the elementwise terms of IDRLoss.forward + weighted total (loss.py:21-35, 58-61, 167-174, 206-210), one launch ----
  * rgb[R][3], rgb_gt[R][3], rgb_mask[R] (network_object_mask & object_mask); grad_theta[n_eik][3]; eik_out / dist_r / dweight[n_depth]
  * (dist_r, dweight from mvsdf_depth_carve); surf[n_surf] logits with targets (i < *n_pos); feat_pp[n_feat] from mvsdf_feat_corr or NULL.
+ * smooth: 0 = the L1 depth term (loss.py:60), s > 0 = SmoothL1(eikonal_output / s, -dist_r / s) * s (loss.py:57-58).
  * out[6] = {loss, rgb_loss, eikonal_loss, depth_loss, feat_loss, surf_loss}; d_*: unit gradients of each term w.r.t. its input.
  * inv_counts (device, [3], may be NULL): replaces 1/n_eik, 1/n_depth, 1/n_surf of the three count-normalised means -- with
  * world_size / (count summed over the data-parallel ranks) the rank-averaged gradient equals the single-process one. */
 int mvsdf_loss_terms(const float* rgb, const float* rgb_gt, const uint8_t* rgb_mask, int R, const float* grad_theta, int n_eik,
                      const float* eik_out, const float* dist_r, const float* dweight, int n_depth, const float* surf, int n_surf,
                      const long long* n_pos, const float* feat_pp, int n_feat, float w_rgb, float w_eik, float w_surf, float w_feat,
-                     float w_depth, int surf_on, int feat_on, const float* inv_counts, float* out, float* d_rgb, float* d_grad,
+                     float w_depth, float smooth, int surf_on, int feat_on, const float* inv_counts, float* out, float* d_rgb, float* d_grad,
                      float* d_eik_out, float* d_surf, void* stream);
 
 /* ---- bookkeeping of one training step of IDRNetwork.forward (idr.py:202-304) between the big kernels ----
@@ -457,6 +452,7 @@ typedef struct {
     const float* depths; int dB, dh, dw; const float* depth_cams;                    /* [dB][dh][dw], [dB][2][4][4] */
     float out_thresh_perc, far_thresh, far_att, near_thresh, near_att;
     float w_rgb, w_eik, w_surf, w_feat, w_depth;
+    float smooth;                          /* depth term: 0 = L1, s > 0 = SmoothL1(eikonal_output / s, -dist_r / s) * s (loss.py:57-58: conf.smooth(train_progress)) */
     const float* inv_counts;               /* see mvsdf_loss_terms */
 } MvsdfLossArgs;
 typedef struct {

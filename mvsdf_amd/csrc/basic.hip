@@ -315,7 +315,7 @@ static int launch_col0_bf(const NET& net, const float* x, int n, float* y, hipSt
     // MVSDF_BF_CARRY=1 (dev / tests): the weight-fetch scheme of k_sphere_trace (tile_engine_bf16.h, CARRIED) instead of the row-sample kernels' (ROLLING);
     // same arithmetic, bit-identical results (tests/test_gpu_bf16.py)
     static int carry = -1;
-    if (carry < 0) { const char* ev = getenv("MVSDF_BF_CARRY"); carry = ev ? atoi(ev) : 0; }
+    if (carry < 0) { const char* ev = mv_dev_env("MVSDF_BF_CARRY"); carry = ev ? atoi(ev) : 0; }
     hipError_t e = carry ? hipFuncSetAttribute((const void*)k_sdf_col0_bf<MT, NTW, true, NET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                          : hipFuncSetAttribute((const void*)k_sdf_col0_bf<MT, NTW, false, NET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return mv_check(e, "mvsdf_sdf_col0: LDS attribute");
@@ -461,28 +461,6 @@ int mvsdf_sphere_intersection(const float* cam_loc, const float* ray_dirs, int B
 
 size_t mvsdf_packed_bf16_bytes(int N, int K, int nsplit) { return mv_packed_bf16_elems(N, K, nsplit) * 2; }
 
-int mvsdf_pack_bf16_net(int n_layers, const float* const* w, const int* N, const int* K, int skip_layer, int multires, void* const* wp16,
-                        void* stream) {
-    return mvsdf_pack_bf16_net_skips(n_layers, w, N, K, skip_layer >= 0 ? 1u << skip_layer : 0u, multires, wp16, stream);
-}
-
-int mvsdf_pack_bf16_net_skips(int n_layers, const float* const* w, const int* N, const int* K, unsigned skip_mask, int multires, void* const* wp16,
-                              void* stream) {
-    if (n_layers < 1 || n_layers > MV_MAXL || !w || !N || !K || !wp16) return mv_fail(-1, "mvsdf_pack_bf16_net: bad arguments");
-    PackBfArgs a;
-    size_t maxTot = 0;
-    for (int l = 0; l < n_layers; ++l) {
-        if (!w[l] || !wp16[l] || N[l] <= 0 || K[l] <= 0) return mv_fail(-1, "mvsdf_pack_bf16_net: null layer pointer / bad dims");
-        a.w[l] = w[l]; a.wp[l] = (uint16_t*)wp16[l]; a.N[l] = N[l]; a.K[l] = K[l];
-        a.nsplit[l] = (l == 0 || mv_skip_at(skip_mask, l)) ? 3 + 6 * multires : 0;
-        const size_t t = mv_packed_bf16_elems(N[l], K[l], a.nsplit[l]);
-        if (t > maxTot) maxTot = t;
-    }
-    const int blocks = (int)((maxTot + 255) / 256 < 256 ? (maxTot + 255) / 256 : 256);
-    hipLaunchKernelGGL(k_pack_bf16_net, dim3(blocks, n_layers), dim3(256), 0, (hipStream_t)stream, a);
-    return mv_check(hipGetLastError(), "mvsdf_pack_bf16_net");
-}
-
 /* trace_dtype = 3 / 4: the bf16 packs without duplicated columns (every activation, the positional encoding included, is split into bf16
  * terms in LDS: tile_engine_bf16s.h) */
 int mvsdf_pack_bf16s_net(int n_layers, const float* const* w, const int* N, const int* K, void* const* wp16, void* stream) {
@@ -537,12 +515,7 @@ int mvsdf_pack_bf16w_net(int n_layers, const float* const* w, const int* N, cons
 int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, int mt, void* stream) {
     if (!x || !y || n <= 0) return mv_fail(-1, "mvsdf_sdf_col0: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (desc && desc->trace_dtype == 1) {                       // bf16 weights / activations on the bf16 MFMA
-        MvNetBf nb;
-        int rcb = mv_make_net_bf(desc, &nb);
-        if (rcb) return rcb;
-        return dispatch_col0_bf(nb, x, n, y, mt, s);
-    }
+    if (desc && desc->trace_dtype == 1) return mv_fail(-2, "mvsdf_sdf_col0: trace_dtype 1 (bf16 weights AND 8-bit activations) was removed in round 5: use 3 (bf16x2: same speed, parity-checked)");
     if (desc && (desc->trace_dtype == 3 || desc->trace_dtype == 4)) {   // bf16 weights x activations carried as 2 / 3 bf16 terms
         MvNetBs<2> n2;
         MvNetBs<3> n3;
@@ -559,12 +532,14 @@ int mvsdf_sdf_col0(const MvsdfNetDesc* desc, const float* x, int n, float* y, in
     MvNet net;
     int rc = mv_make_net_trace(desc, &net);
     if (rc) return rc;
-    if (mt == 49) return launch_col0<1, 2, 8, true>(net, x, n, y, s);     // the sphere tracer's engine: weight ring carried across layers
-    const char* e = getenv("MVSDF_NW");
-    const int nw_env = e ? atoi(e) : 0;
+    if (mt != 1 && mt != 2 && mt != 4 && mt != 49) return mv_fail(-1, "mvsdf_sdf_col0: mt must be 1, 2, 4 (row tiles per workgroup) or 49 (the sphere tracer's carried-ring engine)");
+    if (mt == 49) {                                                        // the sphere tracer's engine: weight ring carried across layers (two column tiles per wave: width <= 256)
+        if (mv_wide(net)) return mv_fail(-1, "mvsdf_sdf_col0: mt = 49 needs a hidden width <= 256");
+        return launch_col0<1, 2, 8, true>(net, x, n, y, s);
+    }
     int maxnt = 0;
     for (int l = 0; l < net.n_layers - 1; ++l) maxnt = net.L[l].NT > maxnt ? net.L[l].NT : maxnt;
-    const bool eight = (nw_env == 8) || (nw_env != 4 && maxnt >= 16);
+    const bool eight = maxnt >= 16;                              // 8 waves x 2 column tiles from width 256 on; narrow nets: 4 waves x 4 tiles
     if (eight) {
         if (mv_wide(net)) return mt >= 2 ? launch_col0<2, 4, 8>(net, x, n, y, s) : launch_col0<1, 4, 8>(net, x, n, y, s);
         if (mt >= 4) return launch_col0<4, 2, 8>(net, x, n, y, s);

@@ -6,12 +6,24 @@
 #include "tile_engine_bf16s.h"
 #include "../../include/mvsdf_hip.h"
 
+#include <stdlib.h>
 int mv_fail(int code, const char* msg);          // records msg, returns code
+// Development / A-B switches (alternative launch paths that are independent implementations of the same passes: MVSDF_FUSE, MVSDF_SPLIT_CHAINS, MVSDF_CHAIN_W8,
+// MVSDF_CHAIN_MT, MVSDF_DELTA_CHAIN, MVSDF_LAYER_MT, MVSDF_WG_XCD, MVSDF_BF_CARRY, MVSDF_TAIL_STOP, MVSDF_NFIRST, MVSDF_MT_FIRST) exist only in a library built with
+// -DMVSDF_DEV_SWITCHES (mvsdf_amd/build.py: build(tag='dev'); tests/test_gpu_alt_paths.py and the sweep tools load it through MVSDF_LIB).  The product library never
+// reads them: its behaviour does not depend on stray environment variables.  (Product switches, read with getenv directly: MVSDF_TAIL, MVSDF_SPLIT_ROWS.)
+static inline const char* mv_dev_env(const char* name) {
+#ifdef MVSDF_DEV_SWITCHES
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 int mv_check(hipError_t e, const char* where);   // 0 on success
 // mode 0: SDF net (PE input + skip chaining checked); 1: plain chain; 2: transposed packs (no chaining check)
 int mv_make_net_mode(const MvsdfNetDesc* d, MvNet* net, int mode);
 static inline int mv_make_net(const MvsdfNetDesc* d, MvNet* net) { return mv_make_net_mode(d, net, 0); }
-int mv_make_net_bf(const MvsdfNetDesc* d, MvNetBf* net);      // SDF net on the bf16 packs (trace_dtype == 1)
 int mv_make_net_bs(const MvsdfNetDesc* d, MvNetBf* net, int ns); // SDF net on the bf16 packs without duplicated columns, activations as ns bf16 terms (trace_dtype 3 / 4; net = an MvNetBs<ns>)
 int mv_make_net_trace(const MvsdfNetDesc* d, MvNet* net);     // the fp32-engine tracing net: the fp32 packs, or (trace_dtype == 2) the fp32 packs of the bf16-rounded weights
 // skip layers of a descriptor as a bit mask (skip_mask wins; else the single skip_layer)

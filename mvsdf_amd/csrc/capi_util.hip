@@ -56,27 +56,6 @@ int mv_make_net_trace(const MvsdfNetDesc* d, MvNet* net) {
     return mv_make_net(&r, net);
 }
 
-int mv_make_net_bf(const MvsdfNetDesc* d, MvNetBf* net) {
-    MvNet chk;
-    int rc = mv_make_net_mode(d, &chk, 0);                       // same structural checks as the fp32 net
-    if (rc) return rc;
-    memset(net, 0, sizeof(*net));
-    int maxk = 0;
-    for (int l = 0; l < d->n_layers; ++l) {
-        if (!d->wp16[l]) return mv_fail(-2, "net descriptor: trace_dtype = bf16 without bf16 packs (mvsdf_pack_bf16_net)");
-        MvLayerBf& L = net->L[l];
-        L.wp = (const uint4*)d->wp16[l];
-        L.bias = d->bias[l];
-        L.K = d->K[l]; L.N = d->N[l];
-        L.nsplit = mv_bf_nsplit(d, l);
-        L.KB = mv_bf_kb(L.K, L.nsplit); L.NT = mv_ceil16(d->N[l]) / 16;
-        if (L.KB * 32 > maxk) maxk = L.KB * 32;
-    }
-    net->n_layers = d->n_layers; net->skip_mask = chk.skip_mask; net->multires = d->multires;
-    net->S = (maxk + 8) / 2;                                      // bf16 row = 32*KB + 8 elements = 64*KB + 16 bytes (odd multiple of 16: conflict-free b128 reads)
-    return 0;
-}
-
 int mv_make_net_bs(const MvsdfNetDesc* d, MvNetBf* net, int ns) {
     MvNet chk;
     int rc = mv_make_net_mode(d, &chk, 0);

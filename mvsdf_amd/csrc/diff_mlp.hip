@@ -116,7 +116,7 @@ static hipError_t launch_layer(LayerArgs& a, hipStream_t s) {
     // rows per workgroup: 16 while that still leaves the chip under-subscribed (one workgroup per CU), else 32 (weights
     // reused by two row tiles).  MVSDF_LAYER_MT overrides (dev).
     static int mt_env = -1;
-    if (mt_env < 0) { const char* e = getenv("MVSDF_LAYER_MT"); mt_env = e ? atoi(e) : 0; }
+    if (mt_env < 0) { const char* e = mv_dev_env("MVSDF_LAYER_MT"); mt_env = e ? atoi(e) : 0; }
     const bool small = mt_env ? (mt_env == 1) : (a.M <= 16 * 512);
     return small ? launch_layer_mt<PRO, EPI, 1>(a, s) : launch_layer_mt<PRO, EPI, 2>(a, s);
 }
@@ -130,7 +130,7 @@ static LayerArgs base_args(const MvLayer& L, int S, int M) {
 
 static bool mv_chain_w8() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("MVSDF_CHAIN_W8"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char* e = mv_dev_env("MVSDF_CHAIN_W8"); v = e ? atoi(e) : 0; }
     return v != 0;
 }
 
@@ -223,7 +223,7 @@ static hipError_t wgrad_launch(WgradNetArgs& a, hipStream_t s) {
     // 92.9 -> 85.0 us at c2, 154.6 -> 153.9 at the c5 share, 310.7 -> 304.0 at c3 (round 2's two orders -- a contiguous range per XCD, and this one at c2 on the
     // older kernel -- measured nothing)
     static int xcd_env = -2;
-    if (xcd_env == -2) { const char* e = getenv("MVSDF_WG_XCD"); xcd_env = (e && *e) ? atoi(e) : -1; }
+    if (xcd_env == -2) { const char* e = mv_dev_env("MVSDF_WG_XCD"); xcd_env = (e && *e) ? atoi(e) : -1; }
     a.nblocks = blk;
     a.xcd_runs = xcd_env >= 0 ? (xcd_env != 0) : 1;
     const int grid = a.xcd_runs ? ((blk + 127) / 128) * 128 : blk;
@@ -265,7 +265,7 @@ static int mv_single_skip(const MvNet& net) {
 // fragments), so two tiles pay only when they save a round of the 256 CUs: 257..512 tiles (c5's per-GPU share: 248 -> 215 us), not
 // 513..768 (c3).  Four tiles never pay (3.8x).  MVSDF_CHAIN_MT=1|2 overrides (dev A/B).
 static int mv_chain_mt(int tiles16) {
-    static const int env = [] { const char* e = getenv("MVSDF_CHAIN_MT"); return e ? atoi(e) : 0; }();
+    static const int env = [] { const char* e = mv_dev_env("MVSDF_CHAIN_MT"); return e ? atoi(e) : 0; }();
     if (env == 1 || env == 2) return env;
     const int rounds1 = (tiles16 + 255) / 256, rounds2 = (tiles16 + 511) / 512;
     return 1.76 * rounds2 < rounds1 ? 2 : 1;
@@ -326,7 +326,7 @@ int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const f
     const int nl = lo.nl, S = Mg > 0 ? stride_for(net, netT) : net.S;
     float* H0 = ctx + lo.H0;
     static int fuse_fwd = -1;
-    if (fuse_fwd < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_fwd = e ? atoi(e) : 1; }
+    if (fuse_fwd < 0) { const char* e = mv_dev_env("MVSDF_FUSE"); fuse_fwd = e ? atoi(e) : 1; }
     const int ntw_f = mv_chain_ntw(net);
     if (fuse_fwd && ntw_f && net.L[nl - 1].NT <= 8 * ntw_f * 4) {                  // value + normal of a row tile in one launch
         FwdArgs f;
@@ -434,7 +434,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
     const float* G0 = ctx + lo.G0 + r0 * lo.ld0;
     // ---- the whole pass in one launch per row tile (gbar_0, E.1, E.2, input adjoint) when the chain kernels fit the network ----
     static int fuse_all = -1;
-    if (fuse_all < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_all = e ? atoi(e) : 1; if (getenv("MVSDF_SPLIT_CHAINS")) fuse_all = 0; }
+    if (fuse_all < 0) { const char* e = mv_dev_env("MVSDF_FUSE"); fuse_all = e ? atoi(e) : 1; if (mv_dev_env("MVSDF_SPLIT_CHAINS")) fuse_all = 0; }
     const int ntw_b = mv_chain_ntw(net);
     bool chains_done = false;
     if (fuse_all >= 1 && ntw_b) {                               // MVSDF_SPLIT_CHAINS=1: the separate E.1 / E.2 launches (dev A/B)
@@ -467,7 +467,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
                            net.multires, ws + bl.VB[0], lo.ld0, sk > 0 ? ws + bl.VB[sk] : nullptr, sk > 0 ? net.L[sk].K : 0,
                            sk > 0 ? net.L[sk].K - lo.d0 : 0);
         static int fuse1_env = -1;
-        if (fuse1_env < 0) { const char* e = getenv("MVSDF_FUSE"); fuse1_env = e ? atoi(e) : 1; }
+        if (fuse1_env < 0) { const char* e = mv_dev_env("MVSDF_FUSE"); fuse1_env = e ? atoi(e) : 1; }
         const int ntw_1 = mv_chain_ntw(net);
         if (fuse1_env && ntw_1) {                                // the whole ascending chain in one launch
             ChainArgs c;
@@ -500,7 +500,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
     // ---- E.2: adjoint of the value chain (descending) ----
     if (!chains_done) {
     static int fuse_env = -1;
-    if (fuse_env < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_env = e ? atoi(e) : 1; }
+    if (fuse_env < 0) { const char* e = mv_dev_env("MVSDF_FUSE"); fuse_env = e ? atoi(e) : 1; }
     const int ntw_2 = mv_chain_ntw(net);
     if (fuse_env && ntw_2) {                                    // all layers in one launch, the running adjoint stays in LDS
         ChainArgs c;
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void k_delta_apply(DeltaArgs a) {
 }
 static int mv_delta_chain() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("MVSDF_DELTA_CHAIN"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char* e = mv_dev_env("MVSDF_DELTA_CHAIN"); v = e ? atoi(e) : 0; }
     return v;
 }
 int mv_delta_is_chain() { return mv_delta_chain(); }
@@ -842,7 +842,7 @@ int mvsdf_render_forward(const MvsdfNetDesc* d, const float* points, const float
     hipStream_t s = (hipStream_t)stream;
     const RenderLayout lo = render_layout(net, N);
     static int fuse_r = -1;
-    if (fuse_r < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_r = e ? atoi(e) : 1; }
+    if (fuse_r < 0) { const char* e = mv_dev_env("MVSDF_FUSE"); fuse_r = e ? atoi(e) : 1; }
     const int ntw_r = mv_chain_ntw(net);
     if (fuse_r && ntw_r && net.L[nl - 1].NT <= 2) {                                // the whole network in one launch per row tile
         RenderChainArgs c;
@@ -884,7 +884,7 @@ static int render_backward_chain(const MvNet& net, const MvNet& netT, int N, int
     const RenderLayout lo = render_layout(net, Nctx);        // the forward context holds Nctx rows; the backward covers the first N
     const RenderBwdLayout bl = render_bwd_layout(net, N);
     static int fuse_rb = -1;
-    if (fuse_rb < 0) { const char* e = getenv("MVSDF_FUSE"); fuse_rb = e ? atoi(e) : 1; }
+    if (fuse_rb < 0) { const char* e = mv_dev_env("MVSDF_FUSE"); fuse_rb = e ? atoi(e) : 1; }
     const int ntw_rb = mv_chain_ntw(net);
     bool fused_bwd = fuse_rb && ntw_rb;
     for (int l = 1; l < nl; ++l) fused_bwd = fused_bwd && netT.L[l].NT <= 8 * ntw_rb;   // one column-tile group per wave above the first layer

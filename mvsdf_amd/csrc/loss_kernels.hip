@@ -262,6 +262,7 @@ struct LossArgs {
     const float* surf; int n_surf; const long long* n_pos;                           // logits[n_surf], targets = (i < *n_pos)
     const float* feat_pp; int n_feat;                                                // per-point feature-loss terms (may be null)
     float w_rgb, w_eik, w_surf, w_feat, w_depth; int surf_on, feat_on;
+    float smooth;                                                                    // depth term: 0 = L1 (loss.py:60), s > 0 = SmoothL1(eo / s, -dist_r / s) * s (loss.py:57-58, conf.smooth)
     const float* inv_counts;                                                         // optional [3]: 1/count of the eikonal / depth / surf means (data-parallel exact mode)
     float* out;                                                                      // [6]: loss, rgb, eikonal, depth, feat, surf
     float* d_rgb; float* d_grad; float* d_eik_out; float* d_surf;                    // unit gradients (same shapes as the inputs)
@@ -326,11 +327,17 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
                 if (a.s_grad) { a.s_grad[3 * i] = (k * gx) * a.w_eik; a.s_grad[3 * i + 1] = (k * gy) * a.w_eik; a.s_grad[3 * i + 2] = (k * gz) * a.w_eik; }
             }
         } else if (w < 13) {
-            // depth: mean(|eikonal_output + dist_r| * weight)                                        loss.py:58-61
+            // depth: mean(|eikonal_output + dist_r| * weight); with conf.smooth = s: SmoothL1(eo / s, -dist_r / s) * s (beta = 1)      loss.py:57-61
             for (int i = slice * 192 + (w - 10) * 64 + lane; i < a.n_depth; i += MV_LOSS_SLICES * 192) {
                 const float df = a.eik_out[i] + a.dist_r[i], wgt = a.dweight[i];
-                s += fabsf(df) * wgt;
-                const float de = (df > 0.f ? wgt : (df < 0.f ? -wgt : 0.f)) * invD;
+                float el = fabsf(df), gu = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);           // term and its derivative w.r.t. eikonal_output
+                if (a.smooth > 0.f) {
+                    const float x = a.eik_out[i] / a.smooth - (-a.dist_r[i] / a.smooth), ax = fabsf(x);
+                    el = (ax < 1.f ? 0.5f * x * x : ax - 0.5f) * a.smooth;
+                    gu = ax < 1.f ? x : (x > 0.f ? 1.f : -1.f);                                    // (d/d eo of s * h(eo / s) = h')
+                }
+                s += el * wgt;
+                const float de = gu * wgt * invD;
                 a.d_eik_out[i] = de;
                 if (a.s_eik_out) a.s_eik_out[i] = de * a.w_depth;
             }
@@ -395,7 +402,7 @@ extern "C" {
 int mvsdf_loss_terms(const float* rgb, const float* rgb_gt, const uint8_t* rgb_mask, int R, const float* grad_theta, int n_eik,
                      const float* eik_out, const float* dist_r, const float* dweight, int n_depth, const float* surf, int n_surf,
                      const long long* n_pos, const float* feat_pp, int n_feat, float w_rgb, float w_eik, float w_surf, float w_feat,
-                     float w_depth, int surf_on, int feat_on, const float* inv_counts, float* out, float* d_rgb, float* d_grad, float* d_eik_out,
+                     float w_depth, float smooth, int surf_on, int feat_on, const float* inv_counts, float* out, float* d_rgb, float* d_grad, float* d_eik_out,
                      float* d_surf, void* stream) {
     if (!rgb || !rgb_gt || !rgb_mask || R <= 0 || !out || !d_rgb || (n_eik > 0 && (!grad_theta || !d_grad)) ||
         (n_depth > 0 && (!eik_out || !dist_r || !dweight || !d_eik_out)) || (n_surf > 0 && (!surf || !d_surf || !n_pos)))
@@ -406,6 +413,7 @@ int mvsdf_loss_terms(const float* rgb, const float* rgb_gt, const uint8_t* rgb_m
     a.rgb = rgb; a.rgb_gt = rgb_gt; a.rgb_mask = rgb_mask; a.R = R; a.grad_theta = grad_theta; a.n_eik = n_eik;
     a.eik_out = eik_out; a.dist_r = dist_r; a.dweight = dweight; a.n_depth = n_depth; a.surf = surf; a.n_surf = n_surf; a.n_pos = n_pos;
     a.feat_pp = feat_pp; a.n_feat = n_feat; a.w_rgb = w_rgb; a.w_eik = w_eik; a.w_surf = w_surf; a.w_feat = w_feat; a.w_depth = w_depth;
+    a.smooth = smooth > 0.f ? smooth : 0.f;
     a.surf_on = surf_on; a.feat_on = feat_on; a.out = out; a.d_rgb = d_rgb; a.d_grad = d_grad; a.d_eik_out = d_eik_out; a.d_surf = d_surf;
     hipLaunchKernelGGL(k_loss_terms, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     return mv_check(hipGetLastError(), "mvsdf_loss_terms");
@@ -657,6 +665,7 @@ int mvsdf_loss_forward(const MvsdfLossArgs* a, void* blk, void* stream) {
         k.surf = a->n_surf > 0 ? a->surf : nullptr; k.n_surf = a->n_surf; k.n_pos = n_pos;
         k.feat_pp = feat ? (const float*)(b + lo.loss_pp) : nullptr; k.n_feat = feat ? a->N : 0;
         k.w_rgb = a->w_rgb; k.w_eik = a->w_eik; k.w_surf = a->w_surf; k.w_feat = a->w_feat; k.w_depth = a->w_depth;
+        k.smooth = a->smooth > 0.f ? a->smooth : 0.f;
         k.surf_on = a->surf_on; k.feat_on = a->feat_on; k.inv_counts = a->inv_counts;
         k.out = (float*)(b + lo.out); k.d_rgb = (float*)(b + lo.d_rgb); k.d_grad = (float*)(b + lo.d_grad); k.d_eik_out = (float*)(b + lo.d_eo);
         k.d_surf = (float*)(b + lo.d_sf);

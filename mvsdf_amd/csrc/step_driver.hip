@@ -115,6 +115,7 @@ extern "C" {
 
 int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void** out) {
     if (!desc || !layout || !out) return mv_fail(-1, "mvsdf_step_create: null argument");
+    if (desc->trace_dtype == 1) return mv_fail(-2, "mvsdf_step_create: trace_dtype 1 (bf16 weights AND 8-bit activations) was removed in round 5: use 3 (bf16x2)");
     const MvsdfStepDesc& d = *desc;
     const int nl = d.n_sdf + d.n_render;
     if (d.B <= 0 || d.P <= 0 || d.n_eik < 0 || d.n_ds < 0 || d.n_sdf < 2 || d.n_render < 1 || d.n_sdf > MVSDF_MAX_LAYERS || d.n_render > MVSDF_MAX_LAYERS ||
@@ -147,10 +148,7 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
         fo.w[l] = take((size_t)d.N[l] * d.K[l] * 4);
         fo.wp[l] = take(mvsdf_packed_floats(d.N[l], d.K[l]) * 4);
         fo.wpT[l] = take(mvsdf_packed_floats(d.K[l], d.N[l]) * 4);
-        if (l < d.n_sdf && d.trace_dtype == 1) {
-            const int ns = (l == 0 || ((d.skip_mask >> l) & 1u)) ? 3 + 6 * d.multires : 0;
-            fo.wp16[l] = take(mvsdf_packed_bf16_bytes(d.N[l], d.K[l], ns));
-        } else if (l < d.n_sdf && d.trace_dtype == 2) {
+        if (l < d.n_sdf && d.trace_dtype == 2) {
             fo.wp16[l] = take(mvsdf_packed_floats(d.N[l], d.K[l]) * 4);
         } else if (l < d.n_sdf && (d.trace_dtype == 3 || d.trace_dtype == 4)) {
             fo.wp16[l] = take(mvsdf_packed_bf16_bytes(d.N[l], d.K[l], 0));      // no duplicated columns: the activations are split into bf16 terms in LDS
@@ -280,7 +278,7 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
         for (int l = 0; l < nl; ++l) {
             const bool bf = l < d.n_sdf && d.trace_dtype != 0;
             wp16[l] = bf ? (void*)(fwd + fo.wp16[l]) : nullptr;
-            nsplit[l] = (bf && d.trace_dtype == 1 && (l == 0 || ((d.skip_mask >> l) & 1u))) ? 3 + 6 * d.multires : 0;
+            nsplit[l] = 0;                                        // (duplicated hi / lo input columns: the removed trace_dtype 1 only)
         }
         // ... and the camera rays (idr.py:190), all in one launch
         // the CPU-generator draws (min-sdf steps, eikonal points) may arrive in pinned host memory: the prologue reads them from there

@@ -21,6 +21,7 @@
 #include "tile_engine_bf16.h"
 #include "tile_engine_bf16s.h"
 #include "trace_params.h"
+#include "capi_util.h"
 
 struct RayCommon {
     float c[3], d[3];
@@ -755,7 +756,7 @@ static hipError_t launch_stage1(const NET& net, const MvTraceParams& tp, const f
         tail.spin = 1;
         tail.probe = mv_tail_probe();
         static int stop_env = -1;
-        if (stop_env < 0) { const char* e = getenv("MVSDF_TAIL_STOP"); stop_env = e ? atoi(e) : -1; }
+        if (stop_env < 0) { const char* e = mv_dev_env("MVSDF_TAIL_STOP"); stop_env = e ? atoi(e) : -1; }
         tail.stop_left = stop_env >= 0 ? stop_env : grid1 / 4;      // (swept at c2: 0 / 16 / 32 / 48 / 64 of 256 -> tracer 1575 / 1527 / 1521 / 1507 / 1507 us, off: 1549)
     }
     const size_t lds1 = trace_lds_bytes(net, MT, 0, 0);
@@ -792,7 +793,7 @@ static hipError_t launch_stage2(const NET& net, const MvTraceParams& tp, const f
         set2 = lds2;
     }
     static int nf_env = -1;
-    if (nf_env < 0) { const char* e = getenv("MVSDF_NFIRST"); nf_env = e ? atoi(e) : 12; if (nf_env < 2) nf_env = 2; }
+    if (nf_env < 0) { const char* e = mv_dev_env("MVSDF_NFIRST"); nf_env = e ? atoi(e) : 12; if (nf_env < 2) nf_env = 2; }
     const int n = tp.n_steps, nf = nf_env < n ? nf_env : n;
     SampleCtx c;
     c.cam_loc = cam_loc; c.dirs = dirs; c.R = R; c.P = P; c.training = training; c.RPW = 0; c.intervals = intervals; c.steps = steps;
@@ -846,11 +847,9 @@ hipError_t mv_trace_launch(int stages, const NET& net, const MvTraceParams& tp, 
     int maxnt = 0;
     for (int l = 0; l < net.n_layers - 1; ++l) maxnt = net.L[l].NT > maxnt ? net.L[l].NT : maxnt;
     if (maxnt > 32) return hipErrorInvalidValue;
-    // waves per workgroup: 8 (two per SIMD) once there are >= 2 column tiles per wave to share; MVSDF_NW=4 forces 4 (A/B runs)
-    static int nw_env = -1;
-    if (nw_env < 0) { const char* e = getenv("MVSDF_NW"); nw_env = e ? atoi(e) : 0; }
-    constexpr bool is_bf = !std::is_same<NET, MvNet>::value;                    // the bf16 engine is built for 8-wave workgroups only
-    const bool eight = is_bf || (nw_env == 8) || (nw_env != 4 && maxnt >= 16);
+    // waves per workgroup: 8 (two per SIMD) once there are >= 2 column tiles per wave to share (width 256 up; forcing 4 there measured 0.78 -> 0.99 ms, round 3)
+    constexpr bool is_bf = !std::is_same<NET, MvNet>::value;                    // the bf16-MFMA engines are built for 8-wave workgroups only
+    const bool eight = is_bf || maxnt >= 16;
     const bool wide = maxnt > 16;
     hipError_t e = hipSuccess;
     auto eff = [&](int mt) { return wide ? (mt >= 2 ? 2 : 1) : (mt >= 4 ? 4 : (mt >= 2 ? 2 : 1)); };   // the instantiation a requested tile count maps to
@@ -870,7 +869,7 @@ hipError_t mv_trace_launch(int stages, const NET& net, const MvTraceParams& tp, 
     // the two sampler launches are small (about one wave of workgroups at a few thousand rays): 16-row chunks spread them over more
     // CUs (measured 285 -> 241 us at 2048 rays).  MVSDF_MT_FIRST overrides (dev).
     static int mtf_env = -1;
-    if (mtf_env < 0) { const char* e2 = getenv("MVSDF_MT_FIRST"); mtf_env = e2 ? atoi(e2) : 0; }
+    if (mtf_env < 0) { const char* e2 = mv_dev_env("MVSDF_MT_FIRST"); mtf_env = e2 ? atoi(e2) : 0; }
     for (int part = 1; part <= 8; part <<= 1) {
         if (!((stages >> 1) & part)) continue;
         // (three weight terms: a 16-row evaluation is bound by its 3.1 MB weight stream, two tiles share it: c2 1.687 -> 1.664 ms, c5 share 2.539 -> 2.483)
@@ -1132,7 +1131,6 @@ static GenWs mv_gen_ws(void* ws, int R, int n) {
 }
 
 // =============================================================================================================
-#include "capi_util.h"
 extern "C" {
 
 size_t mvsdf_trace_workspace_bytes_n(int R, int n_steps) { return (size_t)(R > 0 ? R : 0) * (44 + 8 * (size_t)(n_steps > 0 ? n_steps : 0)) + 256; }
@@ -1143,13 +1141,12 @@ static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTracePara
                       float* points, uint8_t* mask, float* dists, unsigned long long* counters, void* workspace,
                       size_t workspace_bytes, int mt, int rpw, void* stream) {
     MvNet net;
-    MvNetBf netb;
     MvNetBs<2> net2;
     MvNetBs<3> net3;
     MvNetBs<3, 3> net33;
     const int td = desc ? desc->trace_dtype : 0;
-    const bool bf = td == 1;
-    int rc = bf ? mv_make_net_bf(desc, &netb) : (td == 3 ? mv_make_net_bs(desc, &net2, 2) : (td == 4 ? mv_make_net_bs(desc, &net3, 3) :
+    if (td == 1) return mv_fail(-2, "mvsdf_trace: trace_dtype 1 (bf16 weights AND 8-bit activations) was removed in round 5: use 3 (bf16x2: same speed, parity-checked)");
+    int rc = (td == 3 ? mv_make_net_bs(desc, &net2, 2) : (td == 4 ? mv_make_net_bs(desc, &net3, 3) :
              (td == 5 ? mv_make_net_bs(desc, &net33, 3) : mv_make_net_trace(desc, &net))));
     if (rc) return rc;
     if (!tp || !cam_loc || !ray_dirs || !object_mask || !intervals || !points || !mask || !dists || !counters || !workspace)
@@ -1165,10 +1162,7 @@ static int trace_impl(int stages, const MvsdfNetDesc* desc, const MvsdfTracePara
     hipError_t e = hipSuccess;
     if ((stages & 1) && !(stages & 0x100)) e = hipMemsetAsync(counters, 0, 16 * sizeof(unsigned long long), s);   // 0x100: the caller's previous launch zeroed them
     if (e != hipSuccess) return mv_check(e, "mvsdf_trace: memset");
-    if (bf)
-        e = mv_trace_launch(stages, netb, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,
-                            minsdf_steps ? minsdf_steps : intervals, points, mask, dists, (float*)workspace, counters, s);
-    else if (td == 3)
+    if (td == 3)
         e = mv_trace_launch(stages, net2, *tp, mt, rpw, cam_loc, ray_dirs, object_mask, B, P, training, intervals,
                             minsdf_steps ? minsdf_steps : intervals, points, mask, dists, (float*)workspace, counters, s);
     else if (td == 4)

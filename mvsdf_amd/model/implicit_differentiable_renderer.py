@@ -273,6 +273,8 @@ class LazyOutputs(dict):
 
 
 class IDRNetwork(nn.Module):
+    HOST_STAGE = True                                            # default of self.host_stage (see __init__)
+
     def __init__(self, conf):
         super().__init__()
         self.feature_vector_size = conf.get_int('feature_vector_size')
@@ -292,6 +294,7 @@ class IDRNetwork(nn.Module):
         # training forward / backward through the native step driver (csrc/step_driver.hip: one C call each instead of ~45 ctypes calls and
         # autograd glue).  False: the Python-orchestrated route over the same kernels (kept for A/B tests and the launch-path experiments).
         self.native_step = os.environ.get('MVSDF_NATIVE_STEP', '1') != '0'
+        self.host_stage = type(self).HOST_STAGE                  # the step's CPU-generator draws are read from pinned memory by its first kernel (False: an async copy)
         self._steps = {}                                         # NativeStep per batch shape / phase configuration
         self._ones = None                                        # all-ones object mask handed to the tracer when conf.use_mask is off
 
@@ -299,9 +302,8 @@ class IDRNetwork(nn.Module):
         """'f32x3' (the default, DEFAULT_TRACE_DTYPE): the reference's fp32 arithmetic (idr.py:77-94 inside ray_tracing.py:27-98, fp32 weights unrounded) from
         six exact bf16 products per element pair on v_mfma_f32_16x16x32_bf16, bit-exact against its CPU oracle (a model of that instruction).
         'f32': the same arithmetic as a k-ascending fmaf chain on v_mfma_f32_16x16x4_f32, bit-exact against the fmaf-chain oracle (the default of rounds
-        1-4; 1.3x slower, slightly further from an fp64 evaluation).  'bf16' (BASELINE configs[4]: the ray tracer's SDF
-        evaluations -- ~90 % of the step's FLOPs, all under no_grad -- use bf16-rounded weights and activations on the bf16 MFMA with fp32
-        accumulation; the differentiable passes keep fp32).  Outside the 1e-4 parity claim: see DESIGN.md for the accuracy budget.
+        1-4; 1.3x slower, slightly further from an fp64 evaluation).  BASELINE configs[4] ("bf16 MLP weights"; outside the 1e-4 parity claim against the fp32
+        reference, see DESIGN.md for the accuracy budget; the differentiable passes keep fp32):
         'bf16w': only the tracing MLP's WEIGHTS are rounded to bf16 (BASELINE configs[4] says "bf16 MLP weights"), activations and arithmetic
         stay fp32 on the fp32 MFMA: bit-exact against the oracle on the rounded weights; the control that prices the activation rounding.
         'bf16x2' / 'bf16x3': bf16 weights on the bf16 MFMA, every activation carried as 2 / 3 bf16 terms (16 / all 24 mantissa bits,
@@ -309,7 +311,8 @@ class IDRNetwork(nn.Module):
         that is fast AND parity-checked (hit masks equal to the oracle's on the rounded weights except at recorded ties, depths 1e-4).
         'f32x3': the fp32 weights unrounded, as three bf16 terms like the activations: the reference's fp32 arithmetic from six exact bf16 products per
         element pair on the bf16 MFMA -- fp32-accurate (measured closer to an fp64 evaluation than the 'f32' fmaf chain), bit-exact against its own
-        CPU oracle (a model of the matrix instruction) and parity-checked against the fmaf-chain oracle and the reference fixtures; not bit-identical to 'f32'."""
+        CPU oracle (a model of the matrix instruction) and parity-checked against the fmaf-chain oracle and the reference fixtures; not bit-identical to 'f32'.
+        ('bf16' -- bf16 weights AND 8-bit activations, rounds 2-4 -- was removed in round 5: 'bf16x2' runs at its speed with the oracle's masks.)"""
         if dtype not in ops.TRACE_DTYPES:
             raise ValueError('IDRNetwork.set_trace_dtype(%r): expected one of %s' % (dtype, ', '.join(sorted(ops.TRACE_DTYPES))))
         self.trace_dtype = dtype
@@ -545,8 +548,8 @@ class IDRNetwork(nn.Module):
         n_eik = R // 2
         if isinstance(self._draw, PinnedUniform) and isinstance(rt._draw, PinnedUniform):
             # one pinned staging buffer, NO copy: the step's first kernel reads it (MvsdfStepInputs.host_stage)
-            # (MVSDF_HOST_STAGE=0: one async copy in front of the step instead -- dev A/B)
-            if os.environ.get('MVSDF_HOST_STAGE', '1') != '0':
+            # (self.host_stage = False: one async copy in front of the step instead -- the A/B partner, tests/test_gpu_alt_paths.py)
+            if self.host_stage:
                 minsdf_steps, eik, stage = self._draw.pair((rt.n_steps,), 0.0, 1.0, (n_eik, 3), -bb, bb, dev, defer=True)
             else:
                 (minsdf_steps, eik), stage = self._draw.pair((rt.n_steps,), 0.0, 1.0, (n_eik, 3), -bb, bb, dev), None

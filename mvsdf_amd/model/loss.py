@@ -53,15 +53,19 @@ class IDRLoss(nn.Module):
 
     def get_depth_loss(self, eikonal_points_hom, eikonal_output, depths, cams, size, center, far_thresh, far_att, near_thresh, near_att,
                        smooth):
-        if smooth is not None or conf.use_invalid:
-            raise NotImplementedError('smooth / use_invalid variants are off in the reference conf (model/conf.py:17,25)')
+        if conf.use_invalid:
+            raise NotImplementedError('use_invalid (carving_t) is off in the reference conf (model/conf.py:17)')
         pts = eikonal_points_hom.detach()[0, :, :3, 0]
         B = depths.shape[0]
         dist_r, weight = ops.depth_carve(pts, depths.reshape(B, depths.shape[-2], depths.shape[-1]), cams.reshape(B, 2, 4, 4), size,
                                          center, conf.out_thresh_perc, far_thresh, float(far_att), near_thresh, float(near_att))
         # the reference rescales the (aliased) points to world coordinates in place (loss.py:38,42): keep that side effect
         eikonal_points_hom.detach()[:, :, :3, 0] = pts / 2 * size.view(1, 1, 1) + center.view(1, 1, 3)
-        return ((eikonal_output.view(-1) + dist_r).abs() * weight).mean()         # L1(eikonal_output, -dist_r) * weights, loss.py:58-61
+        if smooth is not None:                                                     # loss.py:57-58
+            el = F.smooth_l1_loss(eikonal_output.view(-1) / smooth, -dist_r / smooth, reduction='none') * smooth
+        else:
+            el = (eikonal_output.view(-1) + dist_r).abs()                          # L1(eikonal_output, -dist_r), loss.py:60
+        return (el * weight).mean()                                                # * far / near weights * in_range, loss.py:61
 
     def get_feat_loss_corr(self, diff_surf_pts, uncerts, feat, cam, feat_src, src_cams, size, center, network_object_mask, object_mask):
         if uncerts is not None:
@@ -102,11 +106,12 @@ class IDRLoss(nn.Module):
 
         ground_truth['size'] = ground_truth['size'][:1]                            # side effects kept (loss.py:181-182)
         ground_truth['center'] = ground_truth['center'][:1]
-        if conf.smooth(train_progress) is not None or conf.use_invalid or not conf.enable_rgb:
-            raise NotImplementedError('smooth / use_invalid / enable_rgb=False are off in the reference conf (model/conf.py:17-25)')
+        if conf.use_invalid or not conf.enable_rgb:
+            raise NotImplementedError('use_invalid / enable_rgb=False are off in the reference conf (model/conf.py:17-25)')
 
+        smooth = conf.smooth(train_progress)                                       # loss.py:57-58: SmoothL1 depth term (None in the shipped conf)
         weights = (conf.rgb_weight(train_progress), conf.eikonal_weight, conf.surf_weight, conf.feat_weight(train_progress),
-                   conf.depth_weight(train_progress))
+                   conf.depth_weight(train_progress), float(smooth) if smooth is not None else 0.0)
         phase1 = conf.phase[0] <= train_progress
         feat_on = bool(phase1 and conf.enable_feat)
         if feat_on and model_outputs.get('uncerts') is not None:
@@ -215,7 +220,7 @@ class IDRLoss(nn.Module):
             return None
         a.out_thresh_perc, a.far_thresh, a.near_thresh = conf.out_thresh_perc, conf.far_thresh, conf.near_thresh
         a.far_att, a.near_att = float(conf.far_att(train_progress)), float(conf.near_att(train_progress))
-        a.w_rgb, a.w_eik, a.w_surf, a.w_feat, a.w_depth = [float(w) for w in weights]
+        a.w_rgb, a.w_eik, a.w_surf, a.w_feat, a.w_depth, a.smooth = [float(w) for w in weights]
         if inv_counts is not None:
             inv_counts = inv_counts.float().contiguous()
             keep.append(inv_counts)

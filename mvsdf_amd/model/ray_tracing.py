@@ -65,10 +65,10 @@ class RayTracing(nn.Module):
         workgroup = 8 * mt: one workgroup per CU (256 of them) while the batch allows it -- the kernel is a chain of dependent evaluations, so
         fewer, fuller workgroups beat two contending ones per CU (4096 rays: 4.17 -> 3.97 ms per step with mt = 2); 4 tiles once the chip is
         over-subscribed anyway (finer compaction of the rays still active; +6 % at 8k-32k rays)."""
-        mt = self.mt or int(os.environ.get('MVSDF_MT', '0')) or (1 if R <= 2048 else (2 if R <= 4096 else 4))
+        mt = self.mt or (1 if R <= 2048 else (2 if R <= 4096 else 4))                                 # (self.mt / self.mt_samples: overrides for sweeps)
         # sample-row kernels: two row tiles per workgroup, two workgroups per CU; the three-weight-term engine ('f32x3', trace_dtype 5) streams 1.5x the
         # fp32 pack per evaluation: at 2048 rays four tiles, one workgroup per CU (c2 1.60 -> 1.53 ms; 4096 rays 2.27 -> 2.31, 8192 rays equal)
-        mt_samples = self.mt_samples or int(os.environ.get('MVSDF_MT_SAMPLES', '0')) or (4 if (trace_dtype == 5 and R <= 2048) else 2)
+        mt_samples = self.mt_samples or (4 if (trace_dtype == 5 and R <= 2048) else 2)
         return mt, mt_samples
 
     def forward(self, sdf, cam_loc, object_mask, ray_directions, minsdf_steps=None, mask_ready=None, defer_minsdf=None):

@@ -24,7 +24,7 @@ class PackedNet:
         self.skip_layers = tuple(sorted(int(s) for s in skip_layer)) if isinstance(skip_layer, (tuple, list)) else ((int(skip_layer),) if skip_layer >= 0 else ())
         self.layers, self.multires = layers, multires
         self.skip_layer = self.skip_layers[0] if self.skip_layers else -1
-        self.trace_dtype = 0                # 1: the tracing MLP runs on the bf16 packs (pack_bf16_net); 2: on fp32 packs of the bf16-rounded weights; 3 / 4: bf16 packs, activations as 2 / 3 bf16 terms; 5: three-term packs of the fp32 weights
+        self.trace_dtype = 0                # 2: the tracing MLP runs on fp32 packs of the bf16-rounded weights; 3 / 4: bf16 packs, activations as 2 / 3 bf16 terms; 5: three-term packs of the fp32 weights
 
     def desc(self, transposed=False):
         """ctypes descriptor (cached: a PackedNet is immutable once its packs exist; pack_bf16_net drops the cache)."""
@@ -222,7 +222,7 @@ def pack_net(vs, gs, biases, skip_layer, multires, want_t=True):
     return PackedNet(layers, skip_layer, multires)
 
 
-TRACE_DTYPES = {'f32': 0, 'bf16': 1, 'bf16w': 2, 'bf16x2': 3, 'bf16x3': 4, 'f32x3': 5}
+TRACE_DTYPES = {'f32': 0, 'bf16w': 2, 'bf16x2': 3, 'bf16x3': 4, 'f32x3': 5}      # (1, 'bf16' -- 8-bit activations too -- was removed in round 5: 'bf16x2' dominates it)
 
 
 def pack_trace_net(net, dtype):
@@ -233,8 +233,8 @@ def pack_trace_net(net, dtype):
 
 
 def pack_bf16_net(net, weights_only=False, terms=0, weight_terms=1):
-    """bf16 MFMA packs of a folded SDF network (BASELINE configs[4], csrc/tile_engine_bf16.h): one launch; switches the network's tracing
-    MLP (ops.trace, ops.sdf_col0) to bf16 weights / activations.  The differentiable passes keep the fp32 weights.
+    """bf16 MFMA packs of a folded SDF network (BASELINE configs[4], csrc/tile_engine_bf16s.h): one launch; switches the network's tracing
+    MLP (ops.trace, ops.sdf_col0) to one of the bf16-matrix-core arithmetics.  The differentiable passes keep the fp32 weights.
     weights_only: only the WEIGHTS are rounded to bf16 (fp32 packs of the rounded values, fp32 activations on the fp32 MFMA, trace_dtype 2):
     bit-exact against the oracle on the rounded weights.
     terms = 2 / 3: bf16 weights on the bf16 MFMA, every activation carried as 2 / 3 bf16 terms (16 / all 24 mantissa bits;
@@ -267,19 +267,8 @@ def pack_bf16_net(net, weights_only=False, terms=0, weight_terms=1):
         net.trace_dtype = 2
         net.__dict__.pop('_d', None)
         return net
-    d0 = 3 + 6 * net.multires
-    dev = net.layers[0].bias.device
-    for i, L in enumerate(net.layers):
-        ns = d0 if (i == 0 or i in net.skip_layers) else 0
-        L.wp16 = torch.empty(lib().mvsdf_packed_bf16_bytes(L.N, L.K, ns), dtype=torch.uint8, device=dev)
-    N = (C.c_int * n)(*[L.N for L in net.layers])
-    K = (C.c_int * n)(*[L.K for L in net.layers])
-    check(lib().mvsdf_pack_bf16_net_skips(n, _int_ptr_array([L.w.data_ptr() if L.w is not None else L.w_ptr for L in net.layers]), N, K,
-                                          C.c_uint(sum(1 << s for s in net.skip_layers)), net.multires,
-                                          _ptr_array([L.wp16 for L in net.layers]), stream_of(net.layers[0].bias)), 'mvsdf_pack_bf16_net_skips')
-    net.trace_dtype = 1
-    net.__dict__.pop('_d', None)
-    return net
+    raise ValueError("pack_bf16_net: give weights_only=True ('bf16w') or terms=2 / 3 ('bf16x2' / 'bf16x3'; with weight_terms=3: 'f32x3') -- the engine that rounded the "
+                     "hidden activations to bf16 too (trace_dtype 1) was removed in round 5")
 
 
 def sdf_col0(net, x, mt=2):
@@ -309,7 +298,7 @@ def sphere_intersection(cam_loc, ray_dirs, r=1.0):
     return t, m.bool()
 
 
-_MINSDF_SIDE_STREAM = __import__('os').environ.get('MVSDF_MINSDF_STREAM', '0') == '1'
+_MINSDF_SIDE_STREAM = False                         # trace stages 5 / 6: the min-sdf rows on a second stream under the sampler launches (measured slower; tests set it)
 _side_streams = {}
 
 
@@ -572,7 +561,8 @@ def depth_carve(pts, depths, cams, size, center, out_thresh_perc, far_thresh, fa
 
 def loss_terms(rgb, rgb_gt, rgb_mask, grad_theta, eik_out, dist_r, dweight, surf, n_pos, feat_pp, weights, surf_on, feat_on, inv_counts=None):
     """-> (out[6] = loss, rgb, eikonal, depth, feat, surf; d_rgb, d_grad, d_eik_out, d_surf).  One launch.
-    inv_counts: optional device float[3] replacing 1/n of the eikonal / depth / surf means (data-parallel exact mode)."""
+    inv_counts: optional device float[3] replacing 1/n of the eikonal / depth / surf means (data-parallel exact mode).
+    weights = (w_rgb, w_eik, w_surf, w_feat, w_depth[, smooth]): smooth > 0 makes the depth term SmoothL1(eo / smooth, -dist_r / smooth) * smooth (loss.py:57-58)."""
     rgb, rgb_gt = _f32(rgb), _f32(rgb_gt).reshape(-1, 3)
     dev = rgb.device
     R = rgb.shape[0]
@@ -588,11 +578,11 @@ def loss_terms(rgb, rgb_gt, rgb_mask, grad_theta, eik_out, dist_r, dweight, surf
     d_sf = torch.empty_like(sf) if sf is not None else None
     npos = n_pos.to(torch.int64).reshape(1).contiguous() if n_pos is not None else None
     fp = _f32(feat_pp) if feat_pp is not None else None
-    w = [float(x) for x in weights]
+    w = [float(x) for x in weights] + [0.0]                       # weights[5] (optional): conf.smooth of the depth term, 0 / None = L1
     check(lib().mvsdf_loss_terms(ptr(rgb), ptr(rgb_gt), ptr(m), R, ptr(gt_), gt_.shape[0] if gt_ is not None else 0, ptr(eo), ptr(_f32(dist_r)),
                                  ptr(_f32(dweight)), eo.numel(), ptr(sf), sf.numel() if sf is not None else 0, ptr(npos), ptr(fp),
                                  fp.numel() if fp is not None else 0, C.c_float(w[0]), C.c_float(w[1]), C.c_float(w[2]), C.c_float(w[3]),
-                                 C.c_float(w[4]), 1 if surf_on else 0, 1 if feat_on else 0, ptr(_f32(inv_counts)) if inv_counts is not None else None,
+                                 C.c_float(w[4]), C.c_float(w[5]), 1 if surf_on else 0, 1 if feat_on else 0, ptr(_f32(inv_counts)) if inv_counts is not None else None,
                                  ptr(out), ptr(d_rgb), ptr(d_grad), ptr(d_eo), ptr(d_sf), stream_of(rgb)), 'mvsdf_loss_terms')
     return out, d_rgb, d_grad, d_eo, d_sf
 
@@ -679,7 +669,7 @@ def loss_scale(gs, weights, unit_grads):
     a = []
     for t, o in zip(unit_grads, outs):
         a += [t.data_ptr() if t is not None else None, o.data_ptr() if o is not None else None, t.numel() if t is not None else 0]
-    w = [float(v) for v in weights]
+    w = [float(v) for v in weights[:5]]
     check(lib().mvsdf_loss_scale(_ptr_array(gs), w[0], w[1], w[2], w[3], w[4], *a, coef.data_ptr(), stream_of(coef).value), 'mvsdf_loss_scale')
     return outs, coef
 

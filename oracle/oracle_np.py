@@ -353,15 +353,20 @@ def carving_t2(points_world, depths, cams, out_thresh_perc=1 / 8):
     return dpos * scene_inside + dneg * scene_outside, scene_inside, scene_valid
 
 
-def depth_loss(eik_points, eik_output, depths, depth_cams, size, center, far_thresh=0.25, far_att=1, near_thresh=0.1, near_att=1):
-    """model/loss.py:37-63 (smooth=None, use_invalid=False).  eik_points [M,3] normalised, eik_output [M]; depths [B,1,1,h,w]."""
+def depth_loss(eik_points, eik_output, depths, depth_cams, size, center, far_thresh=0.25, far_att=1, near_thresh=0.1, near_att=1, smooth=None):
+    """model/loss.py:37-63 (use_invalid=False; smooth: loss.py:57-58, SmoothL1(eo / s, -dist_r / s) * s with beta = 1).  eik_points [M,3] normalised, eik_output [M]; depths [B,1,1,h,w]."""
     pw = np.asarray(eik_points, np.float64) / 2 * float(size) + np.asarray(center, np.float64).reshape(1, 3)
     dist, _, in_range = carving_t2(pw, np.asarray(depths, np.float64)[:, 0, 0], np.asarray(depth_cams, np.float64)[:, 0])
     dist_r = np.clip(dist / float(size) * 2 + (-1.25) * (~in_range), -1.25, 1.25)
     far = np.abs(dist_r) > far_thresh
     near = np.abs(dist_r) < near_thresh
     w = (far * far_att + ~far) * (near * near_att + ~near) * in_range
-    return (np.abs(np.asarray(eik_output, np.float64) + dist_r) * w).mean(), dist_r, w
+    df = np.asarray(eik_output, np.float64) + dist_r
+    el = np.abs(df)
+    if smooth is not None:
+        x = df / smooth
+        el = np.where(np.abs(x) < 1, 0.5 * x * x, np.abs(x) - 0.5) * smooth
+    return (el * w).mean(), dist_r, w
 
 
 def dsurf_unproject(depths, depth_cams, size, center):

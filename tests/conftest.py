@@ -22,6 +22,9 @@ def pytest_configure(config):
         if td not in ops.TRACE_DTYPES:
             raise pytest.UsageError('MVSDF_TEST_TRACE_DTYPE=%r: expected one of %s' % (td, ', '.join(sorted(ops.TRACE_DTYPES))))
         idr.DEFAULT_TRACE_DTYPE = td
+    if os.environ.get('MVSDF_TEST_HOST_STAGE') == '0':             # the step's draws by an async copy instead of pinned reads (tests/test_gpu_alt_paths.py)
+        from mvsdf_amd.model import implicit_differentiable_renderer as idr
+        idr.IDRNetwork.HOST_STAGE = False
 
 
 def golden(name):

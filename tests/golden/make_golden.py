@@ -280,7 +280,12 @@ def g_sample_network(seed):
 SCENE = dict(size=2.6, center=(0.1, -0.2, 0.3), feat_hw=(60, 80), focal_scale=1.4)
 
 
-def g_idr(W, B, P, V, seed, tp, name=None, skip_in=(4,)):
+def g_idr(W, B, P, V, seed, tp, name=None, skip_in=(4,), smooth=None):
+    """smooth: conf.smooth(tp) of the depth term (loss.py:57-58: SmoothL1 instead of L1; None in the shipped conf) -- set on the reference's conf module for this fixture"""
+    import model.loss as ref_loss
+    old_smooth = ref_loss.conf.smooth
+    if smooth is not None:
+        ref_loss.conf.smooth = lambda tp_: smooth
     m, sd = build_model(W, seed, skip_in=skip_in)
     inp, gt = synth.make_batch(B, P, V, seed=seed, **SCENE)
     m.train()
@@ -316,6 +321,9 @@ def g_idr(W, B, P, V, seed, tp, name=None, skip_in=(4,)):
         idx = rs.randint(0, g.size, size=8)
         res['gidx_' + k] = idx
         res['gval_' + k] = g.reshape(-1)[idx]
+    ref_loss.conf.smooth = old_smooth
+    if smooth is not None:
+        res['smooth'] = np.float32(smooth)
     # the eikonal points drawn inside forward (torch CPU generator), for implementations that take them as input
     save(name or 'idr_w%d_tp%s' % (W, str(tp).replace('.', '')), W=W, B=B, P=P, V=V, seed=seed, tp=tp,
          scene_size=SCENE['size'], scene_center=np.array(SCENE['center']), feat_hw=np.array(SCENE['feat_hw']),
@@ -553,3 +561,4 @@ if __name__ == '__main__':
     g_sdf(512, 256, 0)
     g_trace_mlp(512, 2, 512, 0)
     g_idr(512, 8, 128, 2, 0, 0.3, 'idr_w512')
+    g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_smooth', (4,), 0.05)                  # conf.smooth = 0.05: the SmoothL1 depth term (loss.py:57-58), reachable through IDR_CONF

@@ -67,6 +67,43 @@ def test_eight_ranks_on_one_gpu_gloo_c4_shape_and_collective_timings():
 
 
 @pytest.mark.gpu
+def test_strong_scaling_eight_ranks_against_the_whole_job_on_one_gpu():
+    """`bench.py --scaling strong`: the JOB is fixed at the 8-rank shape (c2: BASELINE configs[3], 8 views x 2048 px = 16384 rays) and its views are sharded --
+    `--gpus 8` (one view per rank; here the eight ranks share the test box's GPU over gloo) against `--gpus 1` (all 16384 rays on one GPU, one process): same
+    rays in total, the same hits over all ranks (hit masks do not depend on the sharding), and the norm of the rank-averaged gradient equal to the single-process
+    gradient's up to the ranks' own eikonal / min-sdf draws (the exact equality on shared draws: tests/test_gpu_dp.py[c4x8]).  north_star's ">= 6x at 8 GPUs
+    vs 1" is value(--gpus 8 --scaling strong) / value(--gpus 1 --scaling strong)."""
+    args = ['--scaling', 'strong', '--steps', '2', '--warmup', '1', '--no-cpu-baseline']
+    rc, lines, err = _run(['--gpus', '8'] + args, {'MVSDF_DIST_BACKEND': 'gloo', 'OMP_NUM_THREADS': '2'}, timeout=1200)
+    assert rc == 0, err
+    d8 = json.loads(lines[-1])
+    rc, lines, err = _run(['--gpus', '1'] + args, {}, timeout=600)
+    assert rc == 0, err
+    d1 = json.loads(lines[-1])
+    for d, n in ((d8, 8), (d1, 1)):
+        assert d['scaling'] == 'strong' and d['n_gpus'] == n and d['config']['rays_total'] == 16384 and d['config']['rays_per_gpu'] == 16384 // n, d['config']
+        assert abs(d['value'] - 16384 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    assert d8['config']['hits_total'] == d1['config']['hits_total'] > 4000
+    g8, g1 = d8['config']['grad_norm_after_all_reduce'], d1['config']['grad_norm_after_all_reduce']
+    print('strong scaling on one GPU: 8 ranks %.2f ms, 1 rank %.2f ms per 16384-ray step; hits %d; |grad| %.5g vs %.5g' % (
+        d8['ms_per_step'], d1['ms_per_step'], d1['config']['hits_total'], g8, g1))
+    assert abs(g8 - g1) <= 0.05 * g1
+
+
+@pytest.mark.gpu
+def test_shipped_workload_line():
+    """`--workload shipped` = the reference's real default step on one GPU: 8 views x 4096 px = 32768 rays (README.md:38, mvsdf_dtu.conf:4), 8x512 / 4x512 networks
+    (mvsdf_dtu.conf:24,35), 2 source views (scene_dataset.py:104): a secondary line, same contract."""
+    rc, lines, err = _run(['--workload', 'shipped', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], {}, timeout=900)
+    assert rc == 0, err
+    d = json.loads(lines[-1])
+    c = d['config']
+    assert c['rays_total'] == 32768 and c['sdf_width'] == 512 and c['src_views'] == 2 and c['views_total'] == 8 and d['dtype'] == 'f32x3'
+    assert d['value'] > 0 and 0 < d['roofline']['frac'] < 1 and c['hits_total'] > 8000
+    print('shipped workload (32768 rays, 8x512): %.2f ms per step = %.3g rays/s' % (d['ms_per_step'], d['value']))
+
+
+@pytest.mark.gpu
 def test_eight_ranks_on_one_gpu_c5_share_bf16x2_against_the_single_process_shard():
     """BASELINE configs[4] as the 8-rank run it is: --workload c5share --dtype bf16x2 --gpus 8 (32768 rays in total, bf16 weights in the tracing MLP).
     Rank 0's tracer results must not depend on the company it keeps: its hit count and its evaluated tracer rows equal those of ONE process running

@@ -1,10 +1,11 @@
-"""The library keeps alternative launch paths behind environment switches (tools/README.md): per-layer kernels instead of the fused chain
+"""The DEVELOPMENT build of the library (mvsdf_amd/build.py: build(tag='dev'), -DMVSDF_DEV_SWITCHES; loaded through MVSDF_LIB) keeps alternative launch paths
+behind environment switches the product library does not read (tools/README.md): per-layer kernels instead of the fused chain
 kernels (MVSDF_FUSE=0), the backward pass as separate E.1 / E.2 chain launches (MVSDF_SPLIT_CHAINS=1), 8-wave chain workgroups
 (MVSDF_CHAIN_W8=1), two row tiles per chain workgroup everywhere (MVSDF_CHAIN_MT=2), the delta pass as a chain of GEMMs instead of the
 scaling of the saved s_l (MVSDF_DELTA_CHAIN=1), the Python-orchestrated step (MVSDF_NATIVE_STEP=0), the tracer without tail filling (MVSDF_TAIL=0), the step's sample rows evaluated on a side
 stream beside the tracer at every size (MVSDF_SPLIT_ROWS=1; by default only where the rays' rows alone make a shorter launch), the step's
 CPU-generator draws delivered by an async copy in front of the step instead of being read from pinned memory by its first kernel
-(MVSDF_HOST_STAGE=0).  Each is an independent implementation of the same
+(IDRNetwork.host_stage = False, set through tests/conftest.py's MVSDF_TEST_HOST_STAGE=0).  Each is an independent implementation of the same
 passes: the reference-fixture tests of the differentiable kernels and one end-to-end fixture must pass on every one of them.  The switches
 are read once per process, so each configuration runs in a child pytest."""
 import os
@@ -17,15 +18,21 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(scope='module')
+def dev_lib():
+    from mvsdf_amd import build
+    return build.build(tag='dev')
+
 TARGETS = ['tests/test_gpu_diff.py', 'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w64_tp03]',
            'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w256_tp03]']
 
 
 @pytest.mark.parametrize('env', [{'MVSDF_FUSE': '0'}, {'MVSDF_SPLIT_CHAINS': '1'}, {'MVSDF_CHAIN_W8': '1'}, {'MVSDF_CHAIN_MT': '2'}, {'MVSDF_DELTA_CHAIN': '1'},
-                                 {'MVSDF_NATIVE_STEP': '0'}, {'MVSDF_TAIL': '0'}, {'MVSDF_SPLIT_ROWS': '1'}, {'MVSDF_HOST_STAGE': '0'}],
+                                 {'MVSDF_NATIVE_STEP': '0'}, {'MVSDF_TAIL': '0'}, {'MVSDF_SPLIT_ROWS': '1'}, {'MVSDF_TEST_HOST_STAGE': '0'}],
                          ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()))
-def test_reference_fixtures_pass_on_the_alternative_paths(env):
-    e = dict(os.environ)
+def test_reference_fixtures_pass_on_the_alternative_paths(env, dev_lib):
+    e = dict(os.environ, MVSDF_LIB=dev_lib)
     e.update(env)
     p = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider'] + TARGETS, cwd=ROOT, env=e,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
@@ -34,7 +41,7 @@ def test_reference_fixtures_pass_on_the_alternative_paths(env):
     assert ' passed' in tail and 'failed' not in tail, tail
 
 
-def test_delta_by_scaling_equals_the_delta_chain():
+def test_delta_by_scaling_equals_the_delta_chain(dev_lib):
     """SampleNetwork's scalar enters the SDF backward as one extra upstream per hit row on output column 0.  The library adds its adjoints as
     fbar x s_l (s_l = the forward's saved first-order sensitivities); MVSDF_DELTA_CHAIN=1 runs the 9-phase chain of GEMMs it replaced.  Same
     mathematics, different rounding: the parameter gradients of a whole step agree to ~1e-6 of their largest entry."""
@@ -51,7 +58,7 @@ torch.save(g.cpu(), sys.argv[1])
     with tempfile.TemporaryDirectory() as td:
         for chain in ('0', '1'):
             out = os.path.join(td, 'g%s.pt' % chain)
-            e = dict(os.environ, MVSDF_DELTA_CHAIN=chain)
+            e = dict(os.environ, MVSDF_DELTA_CHAIN=chain, MVSDF_LIB=dev_lib)
             p = subprocess.run([sys.executable, '-c', code, out], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
             assert p.returncode == 0, p.stdout.decode(errors='replace')[-2000:]
             res.append(torch.load(out))

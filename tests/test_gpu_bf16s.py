@@ -13,7 +13,7 @@ import torch
 
 from conftest import golden
 from helpers import sdf_packed_net, t, trace_params
-from mvsdf_amd import ops
+from mvsdf_amd import build, ops
 from mvsdf_amd.utils import synth
 
 pytestmark = pytest.mark.gpu
@@ -68,7 +68,7 @@ def test_the_two_weight_fetch_schemes_of_the_split_engine_agree_bit_for_bit(tmp_
     res = []
     for c in ('0', '1'):
         f = str(tmp_path / ('y%s.npz' % c))
-        subprocess.check_call([sys.executable, '-c', _CARRY_SCRIPT % (root, os.path.join(root, 'tests')), f], env=dict(os.environ, MVSDF_BF_CARRY=c))
+        subprocess.check_call([sys.executable, '-c', _CARRY_SCRIPT % (root, os.path.join(root, 'tests')), f], env=dict(os.environ, MVSDF_BF_CARRY=c, MVSDF_LIB=build.build(tag='dev')))   # a development switch: the dev build of the library reads it
         res.append(np.load(f))
     assert set(res[0].files) == set(res[1].files) and len(res[0].files) == 12
     for k in res[0].files:

@@ -152,7 +152,7 @@ def test_idr_step_without_weight_norm_and_without_normals():
 
 def test_several_skip_connections():
     """skip_in = (3, 6): (1) value / normal / double backward of the HIP chains vs the reference golden, (2) the tracer bit for bit vs the C
-    oracle in fp32 on every engine, (3) the bf16 tracing engine against its oracle twin, (4) a skip into the last Linear is refused."""
+    oracle in fp32 on every engine, (3) the bf16-weight split-activation engine against the oracle on rounded weights, (4) a skip into the last Linear is refused."""
     from conftest import golden
     from helpers import sdf_packed_net, trace_params
     from mvsdf_amd import ops
@@ -193,11 +193,11 @@ def test_several_skip_connections():
     want = O.sdf_forward(onet, xs.cpu().numpy(), ncols=1)[:, 0]
     for mt in (1, 2, 4, 49):                                     # 1 / 2 / 4 row tiles per workgroup, the sphere tracer's carried weight ring
         assert np.array_equal(ops.sdf_col0(net, xs, mt=mt).cpu().numpy(), want), mt
-    # (3) bf16 engine vs its twin
-    ops.pack_bf16_net(net)
-    twin = O.sdf_forward(O.Net(sd, skip_in=skips, bf16=True), xs.cpu().numpy(), ncols=1)[:, 0]
+    # (3) the bf16-weight engine with split activations vs the oracle on rounded weights (masks / values: tests/test_gpu_bf16s.py; here: the skip layout)
+    ops.pack_bf16_net(net, terms=3)
+    twin = O.sdf_forward(O.Net(sd, skip_in=skips, bf16='weights'), xs.cpu().numpy(), ncols=1)[:, 0]
     got = ops.sdf_col0(net, xs).cpu().numpy()
-    assert np.abs(got - twin).max() < 6e-3 and np.abs(got - twin).mean() < 1e-4
+    assert np.abs(got - twin).max() < 4e-6
     assert np.abs(got - want).max() < 2e-2                       # and near the fp32 network
     # (4)
     with pytest.raises(NotImplementedError):

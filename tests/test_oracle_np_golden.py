@@ -155,3 +155,24 @@ def test_several_skip_connections_vs_reference_golden():
     assert _rel(dx1, g['dx_value_only']) < 1e-4
     yc = O.sdf_forward(O.Net(sd, skip_in=skips), g['x'])
     np.testing.assert_allclose(yc, g['out'], rtol=1e-4, atol=3e-6)
+
+
+def test_smooth_depth_term_vs_reference_golden():
+    """conf.smooth = 0.05 (loss.py:57-58: SmoothL1(eikonal_output / s, -dist_r / s) * s instead of L1; None in the shipped conf, reachable through IDR_CONF):
+    the numpy oracle's depth term on the reference's own step outputs against the reference's depth_loss (fixture idr_w64_smooth), and the L1 form against
+    the twin fixture without it."""
+    for name in ('idr_w64_smooth', 'idr_w64_tp03'):
+        g = golden(name)
+        B, P, V, seed = int(g['B']), int(g['P']), int(g['V']), int(g['seed'])
+        _, gt = synth.make_batch(B, P, V, seed=seed, size=float(g['scene_size']), center=tuple(g['scene_center']),
+                                 feat_hw=tuple(int(v) for v in g['feat_hw']), focal_scale=float(g['focal_scale']))
+        smooth = float(g['smooth']) if 'smooth' in g.files else None
+        size, center = float(g['scene_size']), np.asarray(g['scene_center'], np.float64)
+        # the fixture holds eikonal_points_hom AFTER the loss rescaled it to world coordinates in place (loss.py:38,42): back to normalised
+        pts = (g['out_eikonal_points_hom'][0, :, :3, 0].astype(np.float64) - center) / size * 2
+        tp = float(g['tp'])
+        near_att = 1 if tp < 1 / 6 else (0.1 if tp < 0.5 else 0.01)
+        loss, _, _ = ON.depth_loss(pts, g['out_eikonal_output'].reshape(-1), gt['depths'], gt['depth_cams'], size, center, 0.25, 1, 0.1, near_att, smooth=smooth)
+        assert abs(loss - float(g['loss_depth_loss'])) < 2e-5 * max(1.0, float(g['loss_depth_loss'])), (name, loss, float(g['loss_depth_loss']))
+    a, b = golden('idr_w64_smooth'), golden('idr_w64_tp03')
+    assert float(a['loss_depth_loss']) < float(b['loss_depth_loss']) and np.array_equal(a['out_network_object_mask'], b['out_network_object_mask'])
