@@ -70,7 +70,9 @@ def reference_cpu():
         threads = sorted(d['rays_per_s'], key=int)
         return {'what': d['what'], 'workload': d['workload'], 'protocol': d['protocol'], 'host': 'build container, %d cores (%s)' % (d['container_cores'], d['host']),
                 'rays_per_s_1t': d['rays_per_s'].get('1'), 'rays_per_s_all': d['rays_per_s'][threads[-1]], 'threads': int(threads[-1]),
-                'seconds_per_step_all': d['seconds_per_step'][threads[-1]], 'source': 'profiles/reference_cpu.json (tools/time_reference_cpu.py)'}
+                'seconds_per_step_all': d['seconds_per_step'][threads[-1]], 'source': 'profiles/reference_cpu.json (tools/time_reference_cpu.py)',
+                # the CPU port (cpu_port_step: what `cpu_baseline.value` times on this host) timed in the SAME container as the reference
+                'port_rays_per_s_container': d.get('port_rays_per_s'), 'port_sample_container': d.get('port_sample')}
     except (OSError, ValueError, KeyError):
         return None
 
@@ -106,18 +108,19 @@ def make_inputs(dev, rank=0, world=1, P=None, V=None):
     return inp, gt
 
 
-def cpu_baseline(V, rays_per_view=None, views=None):
-    """The CPU oracle (oracle/: C tracer with OpenMP + numpy float64 differentiable half) on a bounded sample of the workload
-    (sized for roughly 10-30 s of CPU work: the whole 2048-ray batch on a many-core host, a quarter of it otherwise)."""
+def cpu_port_step(V, views, rays_per_view, width=None):
+    """-> (one_step() -> (seconds, tracer rows), R): one training step of the CPU PORT (oracle/: C tracer with OpenMP = the fmaf-chain restatement of
+    ray_tracing.py:27-98 + numpy float64 value / normal forward and double backward, rendering net forward / backward, feature-consistency loss WITH its
+    analytic gradient) on `views` x `rays_per_view` rays of the bench scene.  Used by cpu_baseline() below (GPU box host) and by tools/time_reference_cpu.py
+    (build container, beside the reference itself) -- the same function, so the two hosts can be related.  Not in it: the loss backward into the weight-norm
+    parameters' fold, clip and Adam (3 MB of elementwise work)."""
     from oracle import oracle as O
     from oracle import oracle_np as ON
-    if rays_per_view is None:
-        many = O.num_threads() >= 32
-        views, rays_per_view = (B, 256) if many else (2, 256)
-    sd = synth.make_state_dict(W, 0)
+    width = width or W
+    sd = synth.make_state_dict(width, 0)
     onet, nnet, rnet = O.Net(sd), ON.sdf_net(sd), ON.render_net(sd)
     inp, gt = synth.make_batch(views, rays_per_view, V, seed=0, feat_hw=(150, 200))
-    tr = synth.model_conf(W)['ray_tracer']
+    tr = synth.model_conf(width)['ray_tracer']
     R = views * rays_per_view
 
     def one_step():
@@ -132,7 +135,7 @@ def cpu_baseline(V, rays_per_view=None, views=None):
         view = -dirs.reshape(-1, 3)[hit]
         rgb, rc = ON.render_forward(rnet, x_all[:N], n[:N], view, y[:N, 2:])
         counts = mask.reshape(views, -1).sum(1)
-        ON.feat_corr_loss(x_all[:N], counts, gt['feat'], gt['cam'], gt['feat_src'], gt['src_cams'], gt['size'][0], gt['center'][0])
+        ON.feat_corr_loss(x_all[:N], counts, gt['feat'], gt['cam'], gt['feat_src'], gt['src_cams'], gt['size'][0], gt['center'][0], with_grad=True)
         dW, db, dp, dn_r, df = ON.render_backward(rnet, rc, rs.normal(size=rgb.shape))
         dy = np.zeros_like(y)
         dy[:N, 2:] = df
@@ -141,17 +144,35 @@ def cpu_baseline(V, rays_per_view=None, views=None):
         dn[:N + E] += 2 * (np.linalg.norm(n[:N + E], axis=1, keepdims=True) - 1) * n[:N + E] / np.linalg.norm(n[:N + E], axis=1, keepdims=True) / (N + E)
         ON.sdf_backward(nnet, cache, dy, dn)
         return time.time() - t0, rows
-    # protocol of SURVEY 8(d): one warm-up step, then the median of three
+    return one_step, R
+
+
+def cpu_baseline(V, rays_per_view=None, views=None):
+    """The CPU port (cpu_port_step) on a bounded sample of the workload (sized for roughly 10-30 s of CPU work: the whole 2048-ray batch on a many-core
+    host, a quarter of it otherwise), protocol of SURVEY 8(d): one warm-up step, then the median of three."""
+    from oracle import oracle as O
+    if rays_per_view is None:
+        many = O.num_threads() >= 32
+        views, rays_per_view = (B, 256) if many else (2, 256)
+    one_step, R = cpu_port_step(V, views, rays_per_view)
     one_step()
     runs = [one_step() for _ in range(3)]
     dt = sorted(r[0] for r in runs)[1]
     rows = runs[0][1]
+    ref = reference_cpu()
+    if ref is not None and ref.get('port_rays_per_s_container'):
+        # the reference cannot run on this host; the port ran on both: reference(this host) ~ reference(container) x port(this host) / port(container), all threads
+        pc = ref['port_rays_per_s_container']
+        k = max(pc, key=int)
+        ref['reference_on_this_host_estimate_rays_per_s'] = ref['rays_per_s_all'] * (R / dt) / pc[k]
+        ref['estimate_note'] = ('reference (container, %s threads) x port (this host, %d threads) / port (container, %s threads): a stated estimate -- the port is '
+                                'OpenMP C + numpy, the reference PyTorch / MKL, their thread scaling differs' % (ref['threads'], O.num_threads(), k))
     return {'value': R / dt, 'unit': 'rays/s', 'cores': O.num_threads(), 'kind': 'port',
             'sample': '%d views x %d rays of the same scene (W=%d, V=%d): C oracle tracer (OpenMP, %d rows) + numpy float64 value/normal fwd+bwd, '
-                      'rendering fwd+bwd, feature loss fwd (its gradient omitted); median of 3 steps after 1 warm-up, %.1f s per step'
+                      'rendering fwd+bwd, feature loss fwd + analytic gradient; median of 3 steps after 1 warm-up, %.1f s per step'
                       % (views, rays_per_view, W, V, int(rows.sum()), dt),
             # the reference itself (PyTorch CPU, whole step incl. loss backward and Adam) -- measured where /root/reference exists, carried as data
-            'reference': reference_cpu()}
+            'reference': ref}
 
 
 def self_launch(a):

@@ -394,12 +394,16 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
     const int nl = net.n_layers;
     uint4 b[CARRY ? PD : 1][NTW];                                   // CARRIED: weights of the current / coming layer's first k-blocks
     constexpr bool CARRYW = CARRY_ && WT > 1 && MTc * NTW <= 4;      // ... with weight terms (mv_gemm_carried_bw): one or two row tiles of two column tiles
-    constexpr int PDW = MTc * NTW <= 2 ? 4 : 2;
+#ifndef MV_X3_PDW
+#define MV_X3_PDW 4
+#endif
+    constexpr int PDW = MTc * NTW <= 2 ? MV_X3_PDW : 2;          // k-blocks of weight fragments carried in registers (x NTW column tiles x WT terms x 4 VGPRs)
     uint4 bw[CARRYW ? PDW : 1][NTW][WT];
     f32x4 bias4[NTW];                                               // the coming layer's biases
     const uint4* wcur[NTW];                                         // the current layer's column tiles of this wave (+ lane)
     const uint4* wnext[NTW];                                        // the coming layer's, its k-block count
     int kbnext = 1;
+    MV_PH_DECL                                                      // (phase stamps of tools/micro/x3_engine_rounds.hip; nothing in the product build)
     auto prep_bias = [&](int l) {
         const MvLayerBf& Ln = net.L[l];
         const int NTn = (l == nl - 1) ? 1 : Ln.NT, c0 = w * ((NTn + NW - 1) / NW);
@@ -439,6 +443,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
         __builtin_amdgcn_sched_barrier(0);
     }
     mv_pe_rows_bs<NTHREADS, NS, (WT > 1)>(pts, pe, act, S16, TS, rows, net.multires, net.L[0].KB * 32, tid);
+    MV_PH(0)
     for (int l = 0; l < nl - 1; ++l) {
         const MvLayerBf& L = net.L[l];
         const int NT = L.NT, KB = kbnext;
@@ -453,14 +458,18 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
             for (int a = 0; a < MTc; ++a) acc[a][t] = bias4[t];
         }
         prep_bias(l + 1);
+        MV_PH(7)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // inputs of layer l complete (LDS)
+        MV_PH(1)
         if constexpr (CARRY) mv_gemm_carried_bs<MTc, NTW, PD, PDR, NS>(KB, act, S16, TS, wcur, NTW, acc, lane, b, wnext, kbnext);      // (all tile slots: see mv_gemm_carried_bw)
         // (every wave multiplies all NTW tiles: the tiles past its share are clamped copies whose results the epilogue drops -- the waves move in lock step,
         // a branch per tile count costs registers at the merge (72 spills) and buys nothing)
         else if constexpr (CARRYW) mv_gemm_carried_bw<MTc, NTW, NTW, PDW, NS, WT>(KB, act, S16, TS, wcur, acc, lane, bw, wnext, kbnext);
         else if constexpr (WT > 1) { if (ntw > 0) mv_gemm_rolling_dispatch_bw<MTc, NTW, NS, WT, CARRY_>(KB, act, S16, TS, wcur[0], ntw, acc, lane); }
         else if (ntw > 0) mv_gemm_rolling_dispatch_bs<MTc, NTW, NS>(KB, act, S16, TS, wcur[0], ntw, acc, lane);
+        MV_PH(6)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every wave done reading act (in-place update)
+        MV_PH(3)
         {
             const float sc = mv_skip_at(net.skip_mask, l + 1) ? 0.7071067690849304f : 1.0f;   // cat([x, input]) / sqrt(2), idr.py:86-87 (x 1 is exact)
             const int N = L.N;
@@ -521,6 +530,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
                 }
             }
         }
+        MV_PH(4)
     }
     {   // last layer: column 0 only (wave 0)
         f32x4 acc[MTc][NTW];
@@ -531,6 +541,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
             for (int a = 0; a < MTc; ++a) acc[a][t] = bias4[t];
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        MV_PH(1)
         if (w == 0) {
             if constexpr (CARRY) mv_gemm_carried_bs<MTc, NTW, PD, 0, NS>(kbnext, act, S16, TS, wcur, 1, acc, lane, b, wcur, 1);
             else if constexpr (CARRYW) mv_gemm_carried_bw<MTc, 1, NTW, PDW, NS, WT>(kbnext, act, S16, TS, wcur, acc, lane, bw, wcur, 1);
@@ -542,5 +553,8 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
             }
         }
     }
+    MV_PH(2)
     __syncthreads();
+    MV_PH(5)
+    MV_PH_END
 }

@@ -202,3 +202,8 @@ def analytic_sdf(x):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def set_num_threads(n):
+    """OpenMP threads of the C oracle from now on (tools/time_reference_cpu.py times the port at 1 and at all threads)"""
+    lib().orc_set_num_threads(C.c_int(int(n)))

@@ -760,6 +760,14 @@ void orc_log1p01(const float *x, int n, float *y) { for (int i = 0; i < n; ++i) 
 void orc_div(const float *x, int n, float *y100, float *ysqrt2) {
     for (int i = 0; i < n; ++i) { y100[i] = dm_div100(x[i]); ysqrt2[i] = dm_div_sqrt2(x[i]); }
 }
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 int orc_num_threads(void) {
 #ifdef _OPENMP
     extern int omp_get_max_threads(void);

@@ -259,50 +259,90 @@ def _bilinear(fmap, gx, gy):
     return val, dix * (W / 2.0), diy * (H / 2.0)
 
 
+def _project_jac(pts_world, cam):
+    """uv of _project and its jacobian d uv / d x [m,2,3] for an affine extrinsic (last row 0 0 0 1; the 1e-9 guards of the reference enter at 1e-9 relative)"""
+    E, K = np.asarray(cam[0], np.float64), np.asarray(cam[1], np.float64)[:3, :3]
+    c3 = pts_world @ E[:3, :3].T + E[:3, 3]
+    i = c3 @ K.T
+    iz = i[:, 2:3] + 1e-9
+    uv = i[:, :2] / iz
+    dK = (K[None, :2, :] - uv[:, :, None] * K[None, 2:3, :]) / iz[:, :, None]          # d uv / d c3  [m,2,3]
+    return uv, dK @ E[:3, :3]
+
+
 def feat_corr_loss(diff_surf_pts, hit_counts, feat, cam, feat_src, src_cams, size, center, with_grad=False, eps=1e-6):
     """IDRLoss.get_feat_loss_corr (model/loss.py:115-165).  diff_surf_pts [N,3] (hit points, view-major), hit_counts[B].
-    Gradient w.r.t. the points by central differences of the (piecewise smooth) loss when with_grad (oracle only)."""
+    with_grad=True: also the ANALYTIC gradient w.r.t. the points (projection jacobian x bilinear-tap derivatives x the derivative of the normalised
+    correlation; what the reference's autograd and csrc/loss_kernels.hip::k_feat_corr compute); with_grad='fd': central differences of the (piecewise smooth)
+    loss instead -- O(N) evaluations, the cross-check of the analytic form on small inputs (tests/test_oracle_np_golden.py)."""
     pts = np.asarray(diff_surf_pts, np.float64)
+    ctr = np.asarray(center, np.float64).reshape(1, 3)
+    nb = len(hit_counts)
 
-    def total(p):
+    def total(p, grad=None):
         losses, start = [], 0
         for b, cnt in enumerate(hit_counts):
             cnt = int(cnt)
             if cnt == 0:
                 losses.append(0.0)
                 continue
-            pw = p[start:start + cnt] / 2.0 * float(size) + np.asarray(center, np.float64).reshape(1, 3)
-            start += cnt
+            pw = p[start:start + cnt] / 2.0 * float(size) + ctr
             cams = [cam[b]] + [src_cams[b][v] for v in range(src_cams.shape[1])]
             fmaps = [feat[b]] + [feat_src[b][v] for v in range(feat_src.shape[1])]
-            vals, inr = [], []
+            vals, inr, dvals = [], [], []
             for cm, fm in zip(cams, fmaps):
-                uv = _project(pw, np.asarray(cm, np.float64)) / 2.0
+                if grad is None:
+                    uv, J = _project(pw, np.asarray(cm, np.float64)), None
+                else:
+                    uv, J = _project_jac(pw, cm)
+                uv = uv / 2.0
                 H, W = fm.shape[1:]
-                gx = np.clip(uv[:, 0] / W * 2 - 1, -1.1, 1.1)
-                gy = np.clip(uv[:, 1] / H * 2 - 1, -1.1, 1.1)
+                gx_raw, gy_raw = uv[:, 0] / W * 2 - 1, uv[:, 1] / H * 2 - 1
+                gx = np.clip(gx_raw, -1.1, 1.1)
+                gy = np.clip(gy_raw, -1.1, 1.1)
                 inr.append((gx <= 1) & (gx >= -1) & (gy <= 1) & (gy >= -1))
-                vals.append(_bilinear(np.asarray(fm, np.float64), gx, gy)[0])
-            n0 = np.maximum(np.linalg.norm(vals[0], axis=0), 1e-9)
+                val, dgx, dgy = _bilinear(np.asarray(fm, np.float64), gx, gy)
+                vals.append(val)
+                if grad is not None:
+                    # d val / d p [C,m,3]: gx = u / W - 1 with u = uv_proj[0] (the / 2 and * 2 cancel), zero where the clip is active; d pw / d p = size / 2
+                    ux = (np.abs(gx_raw) < 1.1)[None, :, None] * dgx[:, :, None] * J[None, :, 0, :] / W
+                    uy = (np.abs(gy_raw) < 1.1)[None, :, None] * dgy[:, :, None] * J[None, :, 1, :] / H
+                    dvals.append((ux + uy) * (float(size) / 2.0))
+            n0r = np.linalg.norm(vals[0], axis=0)
+            n0 = np.maximum(n0r, 1e-9)
             acc = 0.0
             V = len(cams) - 1
             for v in range(1, V + 1):
-                nv = np.maximum(np.linalg.norm(vals[v], axis=0), 1e-9)
+                nvr = np.linalg.norm(vals[v], axis=0)
+                nv = np.maximum(nvr, 1e-9)
                 corr = (vals[0] * vals[v]).sum(0) / n0 / nv
                 cl = np.abs(1 - corr)
-                acc += (cl * (inr[0] & inr[v]) * (cl < 0.5)).sum()
+                m = (inr[0] & inr[v]) * (cl < 0.5)
+                acc += (cl * m).sum()
+                if grad is not None:
+                    # d corr = <da, b> / (n0 nv) - corr <a, da> / n0^2 (norm above its floor) + the same with a <-> b
+                    a_, b_ = vals[0], vals[v]
+                    dc_da = b_ / (n0 * nv) - (n0r > 1e-9) * corr * a_ / (n0 * n0)
+                    dc_db = a_ / (n0 * nv) - (nvr > 1e-9) * corr * b_ / (nv * nv)
+                    dcorr = np.einsum('cm,cmk->mk', dc_da, dvals[0]) + np.einsum('cm,cmk->mk', dc_db, dvals[v])
+                    grad[start:start + cnt] += (-np.sign(1 - corr) * m)[:, None] * dcorr / (V * cnt) / nb
+            start += cnt
             losses.append(acc / (V * cnt))
         return sum(losses) / len(losses)
-    loss = total(pts)
+    if with_grad == 'fd':
+        loss = total(pts)
+        g = np.zeros_like(pts)
+        for i in range(pts.shape[0]):
+            for c in range(3):
+                p1, p2 = pts.copy(), pts.copy()
+                p1[i, c] += eps
+                p2[i, c] -= eps
+                g[i, c] = (total(p1) - total(p2)) / (2 * eps)
+        return loss, g
     if not with_grad:
-        return loss
+        return total(pts)
     g = np.zeros_like(pts)
-    for i in range(pts.shape[0]):
-        for c in range(3):
-            p1, p2 = pts.copy(), pts.copy()
-            p1[i, c] += eps
-            p2[i, c] -= eps
-            g[i, c] = (total(p1) - total(p2)) / (2 * eps)
+    loss = total(pts, g)
     return loss, g
 
 

@@ -176,3 +176,27 @@ def test_smooth_depth_term_vs_reference_golden():
         assert abs(loss - float(g['loss_depth_loss'])) < 2e-5 * max(1.0, float(g['loss_depth_loss'])), (name, loss, float(g['loss_depth_loss']))
     a, b = golden('idr_w64_smooth'), golden('idr_w64_tp03')
     assert float(a['loss_depth_loss']) < float(b['loss_depth_loss']) and np.array_equal(a['out_network_object_mask'], b['out_network_object_mask'])
+
+
+@pytest.mark.parametrize('name', ['feat_corr', 'feat_corr_v4', 'feat_corr_v8'])
+def test_feat_corr_analytic_gradient_vs_reference_autograd(name):
+    """oracle_np.feat_corr_loss(with_grad=True) -- projection jacobian x bilinear-tap derivatives x derivative of the normalised correlation -- against the
+    d loss / d points the reference's autograd produced (fixture `dpoints`), V = 3 / 4 / 8; and against central differences on a few points."""
+    g = golden(name)
+    B, P, V = int(g['B']), int(g['P']), int(g['V'])
+    _, gt = synth.make_batch(B, P, V, seed=int(g['seed']), size=float(g['scene_size']), center=tuple(g['scene_center']),
+                             feat_hw=tuple(int(v) for v in g['feat_hw']), focal_scale=float(g['focal_scale']))
+    counts = g['hits'].reshape(B, -1).sum(1)
+    args = (counts, gt['feat'], gt['cam'], gt['feat_src'], gt['src_cams'], gt['size'][0], gt['center'][0])
+    loss, gr = ON.feat_corr_loss(g['points'], *args, with_grad=True)
+    assert abs(loss - float(g['loss'])) < 2e-6
+    assert np.abs(gr - g['dpoints']).max() < 2e-5 * np.abs(g['dpoints']).max()
+    if name == 'feat_corr':                                                        # central differences on the first view's first points (O(N) loss evaluations)
+        n = 6
+        c1 = counts.copy()
+        c1[1:] = 0
+        c1[0] = n
+        a1 = (c1,) + args[1:]
+        _, ga = ON.feat_corr_loss(g['points'][:n], *a1, with_grad=True)
+        _, gf = ON.feat_corr_loss(g['points'][:n], *a1, with_grad='fd')
+        assert np.abs(ga - gf).max() < 1e-4 * max(np.abs(gf).max(), 1e-6)

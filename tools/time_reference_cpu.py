@@ -67,6 +67,21 @@ def main():
         res[threads] = ts[1]
         print('%3d thread(s): %.3f s per step = %.0f rays/s (runs: %s)' % (threads, ts[1], R / ts[1], ' '.join('%.3f' % t for t in ts)), flush=True)
     best = min(res, key=res.get)
+    # ... and the CPU PORT (bench.py::cpu_port_step = what `cpu_baseline.value` times on the GPU box's host) on the SAME batch in the SAME container, at 1 and at all
+    # threads: with it the two hosts can be related -- reference(GPU box host) ~ reference(here) x port(GPU box host) / port(here)
+    import bench
+    from oracle import oracle as O
+    from threadpoolctl import threadpool_limits
+    bench.W = a.width
+    port = {}
+    for threads in (1, os.cpu_count()):
+        O.set_num_threads(threads)
+        with threadpool_limits(limits=threads):
+            one_step, Rp = bench.cpu_port_step(a.src, a.views, a.px, a.width)
+            one_step()
+            ts = sorted(one_step()[0] for _ in range(3))
+        port[threads] = ts[1]
+        print('port, %3d thread(s): %.3f s per step = %.0f rays/s (runs: %s)' % (threads, ts[1], Rp / ts[1], ' '.join('%.3f' % t for t in ts)), flush=True)
     out = {
         'what': 'reference PyTorch-CPU training step (forward + loss + backward + grad-norm + clip + Adam) on the bench batch',
         'workload': '%d views x %d px = %d rays, %d src views, 8x%d SDF MLP, train_progress %.2f' % (a.views, a.px, R, a.src, a.width, a.tp),
@@ -75,6 +90,10 @@ def main():
         'seconds_per_step': {str(k): v for k, v in res.items()},
         'rays_per_s': {str(k): R / v for k, v in res.items()},
         'best_threads': best, 'best_rays_per_s': R / res[best],
+        'port_seconds_per_step': {str(k): v for k, v in port.items()},
+        'port_rays_per_s': {str(k): R / v for k, v in port.items()},
+        'port_sample': 'bench.py::cpu_port_step on the same %d x %d rays, V = %d, W = %d: C oracle tracer (OpenMP) + numpy float64 differentiable half + feature loss with gradient; '
+                       '1 warm-up, median of 3' % (a.views, a.px, a.src, a.width),
     }
     path = os.path.join(ROOT, 'profiles', 'reference_cpu.json')
     json.dump(out, open(path, 'w'), indent=1)
