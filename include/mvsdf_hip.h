@@ -254,9 +254,11 @@ int mvsdf_feat_corr(const float* pts, int N, const int* view_start, int B, int V
  * pts[M][pts_ld] (first 3 columns: normalised sample points, e.g. eikonal_points_hom with pts_ld = 4), depths[B][h][w],
  * cams[B][2][4][4] -> dist_r[M], weight[M]; pts_world (may be NULL, may alias pts, same row stride) receives the points rescaled to
  * world coordinates -- the reference does that in place on eikonal_points_hom (loss.py:38,42);
- * loss = mean(|eikonal_output + dist_r| * weight)  (weight = far/near attenuation * in_range). */
+ * loss = mean(|eikonal_output + dist_r| * weight)  (weight = far/near attenuation * in_range).
+ * use_invalid != 0: carving_t (conf.use_invalid, loss.py:43-44 -> my_utils.py:204-266): a view that sees the point but has no depth there counts as half an
+ * 'outside' vote, and `in_range` is "some view sees the point" instead of "some view has a depth there". */
 int mvsdf_depth_carve(const float* pts, int pts_ld, int M, const float* depths, int B, int h, int w, const float* cams, const float* size,
-                      const float* center, float out_thresh_perc, float far_thresh, float far_att, float near_thresh, float near_att,
+                      const float* center, float out_thresh_perc, float far_thresh, float far_att, float near_thresh, float near_att, int use_invalid,
                       float* dist_r, float* weight, float* pts_world, void* stream);
 
 /* ---- the elementwise terms of IDRLoss.forward + weighted total (loss.py:21-35, 58-61, 167-174, 206-210), one launch ----
@@ -452,6 +454,7 @@ typedef struct {
     const float* depths; int dB, dh, dw; const float* depth_cams;                    /* [dB][dh][dw], [dB][2][4][4] */
     float out_thresh_perc, far_thresh, far_att, near_thresh, near_att;
     float w_rgb, w_eik, w_surf, w_feat, w_depth;
+    int use_invalid;                       /* conf.use_invalid: carving_t instead of carving_t2 (see mvsdf_depth_carve) */
     float smooth;                          /* depth term: 0 = L1, s > 0 = SmoothL1(eikonal_output / s, -dist_r / s) * s (loss.py:57-58: conf.smooth(train_progress)) */
     const float* inv_counts;               /* see mvsdf_loss_terms */
 } MvsdfLossArgs;

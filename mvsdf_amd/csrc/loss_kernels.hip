@@ -171,15 +171,16 @@ struct CarveArgs {
     const float* cams;                // [B][2][4][4]
     const float* size; const float* center;
     float out_thresh_perc, far_thresh, far_att, near_thresh, near_att;
+    int use_invalid;                  // conf.use_invalid (loss.py:43-46): carving_t (an in-range view WITHOUT a depth counts as half an 'outside' vote, the in-range mask replaces the valid mask) instead of carving_t2
     float* dist_r; float* weight;     // [M]
 };
 
-// carving_t2 (my_utils.py:269-331) + the weighting of get_depth_loss (loss.py:42-60) for one point per thread.
-struct CarveAcc { float tot_valid, tot_inside, pos_min, neg_max; };
+// carving_t2 / carving_t (my_utils.py:269-331 / 204-266) + the weighting of get_depth_loss (loss.py:42-60) for one point per thread.
+struct CarveAcc { float tot_valid, tot_inside, pos_min, neg_max, tot_in; };
 // the views v0, v0 + vstep, ... of one point (carving_t2's per-view part, my_utils.py:280-312)
 __device__ __forceinline__ CarveAcc mv_carve_views(const CarveArgs& a, const float* pw, int v0, int vstep) {
     const float MAXF = 1e30f / (float)a.B;
-    CarveAcc r = {0.f, 0.f, INFINITY, -INFINITY};
+    CarveAcc r = {0.f, 0.f, INFINITY, -INFINITY, 0.f};
     for (int v = v0; v < a.B; v += vstep) {
         const float* E = a.cams + (size_t)v * 32;
         const float* K = E + 16;
@@ -203,7 +204,7 @@ __device__ __forceinline__ CarveAcc mv_carve_views(const CarveArgs& a, const flo
         const bool inside = (pdepth > gd * 0.99f) && valid;
         const bool outside = valid != inside;
         const float dist = valid ? (pdepth - gd) : 0.0f;
-        r.tot_valid += valid; r.tot_inside += inside;                                             // counts of 0 / 1: exact in any order
+        r.tot_valid += valid; r.tot_inside += inside; r.tot_in += in_range;                       // counts of 0 / 1: exact in any order
         r.pos_min = fminf(r.pos_min, inside ? dist : MAXF);
         r.neg_max = fmaxf(r.neg_max, outside ? dist : -MAXF);
     }
@@ -226,8 +227,11 @@ __device__ __forceinline__ void mv_carve_finish(const CarveArgs& a, int i, const
         return ret * (num > 0.5f ? 1.f : 0.f) + MAXF * sign * (num < 0.5f ? 1.f : 0.f);
     };
     const float dpos = agg(pos_min, 1.f), dneg = agg(neg_max, -1.f);
-    const float outside_perc = (tot_valid - tot_inside) / (tot_valid + 1e-9f);
-    const bool scene_valid = tot_valid > 0.f;
+    // carving_t2: votes among the views that HAVE a depth at the point's pixel (my_utils.py:321-328); carving_t (conf.use_invalid): among the views that see the
+    // point at all, one without a depth there counting as half an 'outside' vote (my_utils.py:256-263) -- and the in-range mask takes the valid mask's place
+    const float tot_in = r.tot_in;
+    const float outside_perc = a.use_invalid ? ((tot_valid - tot_inside) + (tot_in - tot_valid) * 0.5f) / (tot_in + 1e-9f) : (tot_valid - tot_inside) / (tot_valid + 1e-9f);
+    const bool scene_valid = a.use_invalid ? (tot_in > 0.f) : (tot_valid > 0.f);
     const bool scene_outside = (outside_perc > a.out_thresh_perc) && scene_valid;
     const bool scene_inside = scene_valid != scene_outside;
     const float dist = dpos * (scene_inside ? 1.f : 0.f) + dneg * (scene_outside ? 1.f : 0.f);
@@ -443,13 +447,14 @@ int mvsdf_feat_corr(const float* pts, int N, const int* view_start, int B, int V
 /* Depth-carving target of IDRLoss.get_depth_loss (loss.py:37-63, carving_t2): pts[M][3] normalised sample points,
  * depths[B][h][w], cams[B][2][4][4] -> dist_r[M], weight[M];  loss = mean(|eikonal_output + dist_r| * weight). */
 int mvsdf_depth_carve(const float* pts, int pts_ld, int M, const float* depths, int B, int h, int w, const float* cams, const float* size,
-                      const float* center, float out_thresh_perc, float far_thresh, float far_att, float near_thresh, float near_att,
+                      const float* center, float out_thresh_perc, float far_thresh, float far_att, float near_thresh, float near_att, int use_invalid,
                       float* dist_r, float* weight, float* pts_world, void* stream) {
     if (!pts || pts_ld < 3 || !depths || !cams || !size || !center || !dist_r || !weight || M <= 0 || B <= 0 || h <= 0 || w <= 0)
         return mv_fail(-1, "mvsdf_depth_carve: bad arguments");
     CarveArgs a;
     a.pts = pts; a.M = M; a.pts_ld = pts_ld; a.pts_world = pts_world; a.depths = depths; a.B = B; a.h = h; a.w = w; a.cams = cams; a.size = size; a.center = center;
     a.out_thresh_perc = out_thresh_perc; a.far_thresh = far_thresh; a.far_att = far_att; a.near_thresh = near_thresh; a.near_att = near_att;
+    a.use_invalid = use_invalid ? 1 : 0;
     a.dist_r = dist_r; a.weight = weight;
     hipLaunchKernelGGL(k_carve, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     return mv_check(hipGetLastError(), "mvsdf_depth_carve");
@@ -514,19 +519,19 @@ __global__ __launch_bounds__(1024) void k_loss_prep_carve(PrepCarveArgs a) {
         mv_loss_prep_block(a.net_mask, a.obj_mask, a.true_mask, a.R, a.B, a.hit, a.view_start, a.n_pos);
         return;
     }
-    __shared__ float part[16][4][64];
+    __shared__ float part[16][5][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = (blockIdx.x - 1) * 64 + lane;
     const bool in = i < a.c.M;
     float pw[3] = {0.f, 0.f, 0.f};
-    CarveAcc r = {0.f, 0.f, INFINITY, -INFINITY};
+    CarveAcc r = {0.f, 0.f, INFINITY, -INFINITY, 0.f};
     if (in) { mv_carve_world(a.c, i, pw); r = mv_carve_views(a.c, pw, w, 16); }
-    part[w][0][lane] = r.tot_valid; part[w][1][lane] = r.tot_inside; part[w][2][lane] = r.pos_min; part[w][3][lane] = r.neg_max;
+    part[w][0][lane] = r.tot_valid; part[w][1][lane] = r.tot_inside; part[w][2][lane] = r.pos_min; part[w][3][lane] = r.neg_max; part[w][4][lane] = r.tot_in;
     __syncthreads();
     if (w == 0 && in) {
         CarveAcc t = r;
         for (int k = 1; k < 16; ++k) {
-            t.tot_valid += part[k][0][lane]; t.tot_inside += part[k][1][lane];
+            t.tot_valid += part[k][0][lane]; t.tot_inside += part[k][1][lane]; t.tot_in += part[k][4][lane];
             t.pos_min = fminf(t.pos_min, part[k][2][lane]); t.neg_max = fmaxf(t.neg_max, part[k][3][lane]);
         }
         mv_carve_finish(a.c, i, pw, t);
@@ -643,6 +648,7 @@ int mvsdf_loss_forward(const MvsdfLossArgs* a, void* blk, void* stream) {
         c.pts = a->points_hom; c.M = a->n_depth; c.pts_ld = 4; c.pts_world = a->points_hom;      // rescaled in place (loss.py:38,42)
         c.depths = a->depths; c.B = a->dB; c.h = a->dh; c.w = a->dw; c.cams = a->depth_cams; c.size = a->size; c.center = a->center;
         c.out_thresh_perc = a->out_thresh_perc; c.far_thresh = a->far_thresh; c.far_att = a->far_att; c.near_thresh = a->near_thresh; c.near_att = a->near_att;
+        c.use_invalid = a->use_invalid ? 1 : 0;
         c.dist_r = (float*)(b + lo.dist_r); c.weight = (float*)(b + lo.weight);
         hipLaunchKernelGGL(k_loss_prep_carve, dim3(1 + (a->n_depth + 63) / 64), dim3(1024), 0, (hipStream_t)stream, pc);
         rc = mv_check(hipGetLastError(), "mvsdf_loss_forward (prep + carve)");

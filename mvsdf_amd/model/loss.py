@@ -53,12 +53,10 @@ class IDRLoss(nn.Module):
 
     def get_depth_loss(self, eikonal_points_hom, eikonal_output, depths, cams, size, center, far_thresh, far_att, near_thresh, near_att,
                        smooth):
-        if conf.use_invalid:
-            raise NotImplementedError('use_invalid (carving_t) is off in the reference conf (model/conf.py:17)')
         pts = eikonal_points_hom.detach()[0, :, :3, 0]
         B = depths.shape[0]
         dist_r, weight = ops.depth_carve(pts, depths.reshape(B, depths.shape[-2], depths.shape[-1]), cams.reshape(B, 2, 4, 4), size,
-                                         center, conf.out_thresh_perc, far_thresh, float(far_att), near_thresh, float(near_att))
+                                         center, conf.out_thresh_perc, far_thresh, float(far_att), near_thresh, float(near_att), use_invalid=bool(conf.use_invalid))
         # the reference rescales the (aliased) points to world coordinates in place (loss.py:38,42): keep that side effect
         eikonal_points_hom.detach()[:, :, :3, 0] = pts / 2 * size.view(1, 1, 1) + center.view(1, 1, 3)
         if smooth is not None:                                                     # loss.py:57-58
@@ -90,9 +88,9 @@ class IDRLoss(nn.Module):
                 conf.far_thresh, float(conf.far_att(train_progress)), conf.near_thresh, float(conf.near_att(train_progress)))
         if hom.is_contiguous() and hom.dtype == torch.float32 and hom.is_cuda:
             # the kernel reads the [n, 4] rows in place and writes the world-space points back: the side effect of loss.py:38,42
-            return ops.depth_carve(hom.view(-1, 4), *args, world_inplace=True)
+            return ops.depth_carve(hom.view(-1, 4), *args, world_inplace=True, use_invalid=bool(conf.use_invalid))
         pts = hom[0, :, :3, 0]
-        dist_r, weight = ops.depth_carve(pts, *args)
+        dist_r, weight = ops.depth_carve(pts, *args, use_invalid=bool(conf.use_invalid))
         hom[:, :, :3, 0] = pts / 2 * size.view(1, 1, 1) + center.view(1, 1, 3)
         return dist_r, weight
 
@@ -106,8 +104,8 @@ class IDRLoss(nn.Module):
 
         ground_truth['size'] = ground_truth['size'][:1]                            # side effects kept (loss.py:181-182)
         ground_truth['center'] = ground_truth['center'][:1]
-        if conf.use_invalid or not conf.enable_rgb:
-            raise NotImplementedError('use_invalid / enable_rgb=False are off in the reference conf (model/conf.py:17-25)')
+        if not conf.enable_rgb:
+            raise NotImplementedError('enable_rgb=False is off in the reference conf (model/conf.py:20)')
 
         smooth = conf.smooth(train_progress)                                       # loss.py:57-58: SmoothL1 depth term (None in the shipped conf)
         weights = (conf.rgb_weight(train_progress), conf.eikonal_weight, conf.surf_weight, conf.feat_weight(train_progress),
@@ -219,6 +217,7 @@ class IDRLoss(nn.Module):
         if depths.numel() != dB * a.dh * a.dw or dcams.numel() != dB * 32:
             return None
         a.out_thresh_perc, a.far_thresh, a.near_thresh = conf.out_thresh_perc, conf.far_thresh, conf.near_thresh
+        a.use_invalid = 1 if conf.use_invalid else 0
         a.far_att, a.near_att = float(conf.far_att(train_progress)), float(conf.near_att(train_progress))
         a.w_rgb, a.w_eik, a.w_surf, a.w_feat, a.w_depth, a.smooth = [float(w) for w in weights]
         if inv_counts is not None:

@@ -48,7 +48,7 @@ class LossArgs(C.Structure):
                 ('depths', C.c_void_p), ('dB', C.c_int), ('dh', C.c_int), ('dw', C.c_int), ('depth_cams', C.c_void_p),
                 ('out_thresh_perc', C.c_float), ('far_thresh', C.c_float), ('far_att', C.c_float), ('near_thresh', C.c_float), ('near_att', C.c_float),
                 ('w_rgb', C.c_float), ('w_eik', C.c_float), ('w_surf', C.c_float), ('w_feat', C.c_float), ('w_depth', C.c_float),
-                ('smooth', C.c_float), ('inv_counts', C.c_void_p)]
+                ('use_invalid', C.c_int), ('smooth', C.c_float), ('inv_counts', C.c_void_p)]
 
 
 class LossLayout(C.Structure):

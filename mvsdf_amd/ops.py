@@ -544,9 +544,10 @@ def feat_corr(pts, view_start, feat, feat_src, cam, src_cams, size, center):
     return loss_pp, dpts
 
 
-def depth_carve(pts, depths, cams, size, center, out_thresh_perc, far_thresh, far_att, near_thresh, near_att, world_inplace=False):
+def depth_carve(pts, depths, cams, size, center, out_thresh_perc, far_thresh, far_att, near_thresh, near_att, world_inplace=False, use_invalid=False):
     """pts [M,3] or [M,4] (hom, contiguous) normalised; depths [B,h,w]; cams [B,2,4,4] -> (dist_r[M], weight[M]).
-    world_inplace: also overwrite pts[:, :3] with the world-space points (the reference's side effect, loss.py:38,42)."""
+    world_inplace: also overwrite pts[:, :3] with the world-space points (the reference's side effect, loss.py:38,42).
+    use_invalid: carving_t instead of carving_t2 (conf.use_invalid, loss.py:43-46)."""
     pts, depths, cams = _f32(pts), _f32(depths), _f32(cams)
     M, dev = pts.shape[0], pts.device
     B, h, w = depths.shape
@@ -554,7 +555,7 @@ def depth_carve(pts, depths, cams, size, center, out_thresh_perc, far_thresh, fa
     weight = torch.empty(M, dtype=torch.float32, device=dev)
     check(lib().mvsdf_depth_carve(ptr(pts), pts.shape[1], M, ptr(depths), B, h, w, ptr(cams), ptr(_f32(size).reshape(-1)),
                                   ptr(_f32(center).reshape(-1)), C.c_float(out_thresh_perc), C.c_float(far_thresh), C.c_float(far_att),
-                                  C.c_float(near_thresh), C.c_float(near_att), ptr(dist_r), ptr(weight), ptr(pts) if world_inplace else None,
+                                  C.c_float(near_thresh), C.c_float(near_att), 1 if use_invalid else 0, ptr(dist_r), ptr(weight), ptr(pts) if world_inplace else None,
                                   stream_of(pts)), 'mvsdf_depth_carve')
     return dist_r, weight
 

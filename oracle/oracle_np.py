@@ -347,8 +347,9 @@ def feat_corr_loss(diff_surf_pts, hit_counts, feat, cam, feat_src, src_cams, siz
 
 
 # ------------------------------------------------------------------------------------------------ depth carving + loss terms
-def carving_t2(points_world, depths, cams, out_thresh_perc=1 / 8):
-    """utils/my_utils.py:269-331 for n = 1: points [m,3] world, depths [v,h,w], cams [v,2,4,4] -> dist[m], inside[m], valid[m]"""
+def carving_t2(points_world, depths, cams, out_thresh_perc=1 / 8, use_invalid=False):
+    """utils/my_utils.py:269-331 for n = 1: points [m,3] world, depths [v,h,w], cams [v,2,4,4] -> dist[m], inside[m], valid[m].
+    use_invalid: carving_t (my_utils.py:204-266, conf.use_invalid): an in-range view without a depth is half an 'outside' vote; third result = in-range mask."""
     m, v = points_world.shape[0], depths.shape[0]
     MAXF = 1e30 / v
     tot_in, tot_valid, tot_inside = np.zeros(m), np.zeros(m), np.zeros(m)
@@ -386,17 +387,21 @@ def carving_t2(points_world, depths, cams, out_thresh_perc=1 / 8):
         ret = (res * validm) / (num + 1e-9)
         return ret * (num > 0.5) + MAXF * sign * (num < 0.5)
     dpos, dneg = agg(pos_min, 1), agg(neg_max, -1)
-    outside_perc = (tot_valid - tot_inside) / (tot_valid + 1e-9)
-    scene_valid = tot_valid > 0
+    if use_invalid:
+        outside_perc = ((tot_valid - tot_inside) + (tot_in - tot_valid) * 0.5) / (tot_in + 1e-9)
+        scene_valid = tot_in > 0
+    else:
+        outside_perc = (tot_valid - tot_inside) / (tot_valid + 1e-9)
+        scene_valid = tot_valid > 0
     scene_outside = (outside_perc > out_thresh_perc) & scene_valid
     scene_inside = scene_valid ^ scene_outside
     return dpos * scene_inside + dneg * scene_outside, scene_inside, scene_valid
 
 
-def depth_loss(eik_points, eik_output, depths, depth_cams, size, center, far_thresh=0.25, far_att=1, near_thresh=0.1, near_att=1, smooth=None):
+def depth_loss(eik_points, eik_output, depths, depth_cams, size, center, far_thresh=0.25, far_att=1, near_thresh=0.1, near_att=1, smooth=None, use_invalid=False):
     """model/loss.py:37-63 (use_invalid=False; smooth: loss.py:57-58, SmoothL1(eo / s, -dist_r / s) * s with beta = 1).  eik_points [M,3] normalised, eik_output [M]; depths [B,1,1,h,w]."""
     pw = np.asarray(eik_points, np.float64) / 2 * float(size) + np.asarray(center, np.float64).reshape(1, 3)
-    dist, _, in_range = carving_t2(pw, np.asarray(depths, np.float64)[:, 0, 0], np.asarray(depth_cams, np.float64)[:, 0])
+    dist, _, in_range = carving_t2(pw, np.asarray(depths, np.float64)[:, 0, 0], np.asarray(depth_cams, np.float64)[:, 0], use_invalid=use_invalid)
     dist_r = np.clip(dist / float(size) * 2 + (-1.25) * (~in_range), -1.25, 1.25)
     far = np.abs(dist_r) > far_thresh
     near = np.abs(dist_r) < near_thresh

@@ -280,14 +280,17 @@ def g_sample_network(seed):
 SCENE = dict(size=2.6, center=(0.1, -0.2, 0.3), feat_hw=(60, 80), focal_scale=1.4)
 
 
-def g_idr(W, B, P, V, seed, tp, name=None, skip_in=(4,), smooth=None):
+def g_idr(W, B, P, V, seed, tp, name=None, skip_in=(4,), smooth=None, use_invalid=False):
     """smooth: conf.smooth(tp) of the depth term (loss.py:57-58: SmoothL1 instead of L1; None in the shipped conf) -- set on the reference's conf module for this fixture"""
     import model.loss as ref_loss
-    old_smooth = ref_loss.conf.smooth
+    old_smooth, old_ui = ref_loss.conf.smooth, ref_loss.conf.use_invalid
+    ref_loss.conf.use_invalid = bool(use_invalid)
     if smooth is not None:
         ref_loss.conf.smooth = lambda tp_: smooth
     m, sd = build_model(W, seed, skip_in=skip_in)
     inp, gt = synth.make_batch(B, P, V, seed=seed, **SCENE)
+    if use_invalid:                                                            # depth maps with holes: that is where carving_t and carving_t2 differ
+        inp['depths'] = gt['depths'] = synth.make_depth_maps(inp['depth_cams'], SCENE['size'], SCENE['center'], seed=seed, hole_frac=0.3)
     m.train()
     torch.manual_seed(seed + 5)
     mi = {k: T(v) for k, v in inp.items()}
@@ -321,7 +324,10 @@ def g_idr(W, B, P, V, seed, tp, name=None, skip_in=(4,), smooth=None):
         idx = rs.randint(0, g.size, size=8)
         res['gidx_' + k] = idx
         res['gval_' + k] = g.reshape(-1)[idx]
-    ref_loss.conf.smooth = old_smooth
+    ref_loss.conf.smooth, ref_loss.conf.use_invalid = old_smooth, old_ui
+    if use_invalid:
+        res['use_invalid'] = np.int32(1)
+        res['depth_hole_frac'] = np.float32(0.3)
     if smooth is not None:
         res['smooth'] = np.float32(smooth)
     # the eikonal points drawn inside forward (torch CPU generator), for implementations that take them as input
@@ -351,10 +357,13 @@ def g_feat(seed, B=2, P=300, V=3, name='feat_corr'):
          focal_scale=SCENE['focal_scale'])
 
 
-def g_carve(seed):
+def g_carve(seed, use_invalid=False, name='carve'):
     """carving_t2 (my_utils.py:269-331) + get_depth_loss (loss.py:37-63) on bumpy depth maps with holes, a depth step and per-view scale
     errors: points inside / outside the surface, near it (views disagree: out_thresh_perc voting) and outside every frustum."""
-    from utils.my_utils import carving_t2
+    from utils.my_utils import carving_t, carving_t2
+    import model.loss as ref_loss
+    old_ui = ref_loss.conf.use_invalid
+    ref_loss.conf.use_invalid = bool(use_invalid)                                  # conf.use_invalid: carving_t instead of carving_t2 (loss.py:43-46)
     B, hw, M = 5, (48, 64), 4000
     inp, _ = synth.make_batch(B, 8, 1, seed=seed, size=SCENE['size'], center=SCENE['center'], feat_hw=hw, focal_scale=1.4, with_features=False)
     depths = synth.make_depth_maps(inp['depth_cams'], SCENE['size'], SCENE['center'], seed=seed)
@@ -370,14 +379,16 @@ def g_carve(seed):
     world = hom.clone()
     world[:, :, :3, 0] = world[:, :, :3, 0] / 2 * size.view(1, 1, 1) + center.view(1, 1, 3)
     dp, cp = T(depths).permute(1, 0, 2, 3, 4), T(inp['depth_cams']).permute(1, 0, 2, 3, 4)
-    dist, occ, in_range = carving_t2(world, dp, cp, out_thresh_perc=1 / 8)
+    dist, occ, in_range = (carving_t if use_invalid else carving_t2)(world, dp, cp, out_thresh_perc=1 / 8)
     res = dict(seed=seed, depths=depths, depth_cams=inp['depth_cams'], size=inp['size'], center=inp['center'], points=pts, eik_out=eik_out,
                dist=dist.numpy()[0], occ=occ.numpy()[0], in_range=in_range.numpy()[0])
     for tag, (fa, na) in dict(a=(1.0, 1.0), b=(1.0, 0.1), c=(0.5, 0.01)).items():
         loss = IDRLoss().get_depth_loss(hom.clone(), T(eik_out), T(depths), T(inp['depth_cams']), size, center, 0.25, fa, 0.1, na, None)
         res['loss_' + tag] = loss.item()
         res['att_' + tag] = np.array([fa, na])
-    save('carve', **res)
+    ref_loss.conf.use_invalid = old_ui
+    res['use_invalid'] = np.int32(1 if use_invalid else 0)
+    save(name, **res)
 
 
 def g_idr_phase0(W, B, P, V, seed, tp):
@@ -561,4 +572,6 @@ if __name__ == '__main__':
     g_sdf(512, 256, 0)
     g_trace_mlp(512, 2, 512, 0)
     g_idr(512, 8, 128, 2, 0, 0.3, 'idr_w512')
-    g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_smooth', (4,), 0.05)                  # conf.smooth = 0.05: the SmoothL1 depth term (loss.py:57-58), reachable through IDR_CONF
+    g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_smooth', (4,), 0.05)
+    g_carve(0, True, 'carve_invalid')                                           # conf.use_invalid: carving_t (loss.py:43-44)
+    g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_invalid', (4,), None, True)                  # conf.smooth = 0.05: the SmoothL1 depth term (loss.py:57-58), reachable through IDR_CONF

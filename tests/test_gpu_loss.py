@@ -43,10 +43,12 @@ def test_feat_corr_loss_and_dpoints_vs_reference(name, layout):
     assert (np.abs(ref).sum(1) > 0).mean() > 0.5              # the fixture's gradient is not trivially zero
 
 
-def test_depth_carve_vs_reference():
-    """carving_t2 + the weighting of get_depth_loss (my_utils.py:269-331, loss.py:37-63) on bumpy depth maps with holes and a depth step;
-    the fp32 decisions (nearest pixel, depth > 0.99 * gathered, in-range) may differ from torch's on a handful of boundary points."""
-    g = golden('carve')
+@pytest.mark.parametrize('name', ['carve', 'carve_invalid'])
+def test_depth_carve_vs_reference(name):
+    """carving_t2 (`carve`) / carving_t (`carve_invalid`: conf.use_invalid, loss.py:43-46) + the weighting of get_depth_loss (my_utils.py:204-331, loss.py:37-63) on bumpy
+    depth maps with holes and a depth step; the fp32 decisions (nearest pixel, depth > 0.99 * gathered, in-range) may differ from torch's on a handful of boundary points."""
+    g = golden(name)
+    ui = bool(int(g['use_invalid'])) if 'use_invalid' in g.files else False
     size, center = g['size'][:1], g['center'][:1]
     depths, cams = t(g['depths'][:, 0, 0]), t(g['depth_cams'][:, 0])
     dist_ref = g['dist'] / float(size[0]) * 2 + (-1.25) * (~g['in_range'])
@@ -55,7 +57,7 @@ def test_depth_carve_vs_reference():
     for tag in 'abc':
         fa, na = [float(v) for v in g['att_' + tag]]
         pts = t(g['points'])
-        dist_r, w = ops.depth_carve(pts, depths, cams, t(size), t(center), 1 / 8, 0.25, fa, 0.1, na)
+        dist_r, w = ops.depth_carve(pts, depths, cams, t(size), t(center), 1 / 8, 0.25, fa, 0.1, na, use_invalid=ui)
         dist_r, w = dist_r.cpu().numpy(), w.cpu().numpy()
         far, near = np.abs(dist_ref) > 0.25, np.abs(dist_ref) < 0.1
         w_ref = (far * fa + ~far) * (near * na + ~near) * g['in_range']
@@ -67,10 +69,10 @@ def test_depth_carve_vs_reference():
         assert abs(loss - float(g['loss_' + tag])) <= 2e-3 * float(g['loss_' + tag]) * max(1, bad.sum()) + 1e-6, (tag, loss, float(g['loss_' + tag]))
     # homogeneous [M,4] points rescaled in place: the side effect of loss.py:38,42
     hom = torch.cat([t(g['points']), torch.ones(M, 1, device='cuda')], 1).contiguous()
-    d2, w2 = ops.depth_carve(hom, depths, cams, t(size), t(center), 1 / 8, 0.25, 1.0, 0.1, 1.0, world_inplace=True)
+    d2, w2 = ops.depth_carve(hom, depths, cams, t(size), t(center), 1 / 8, 0.25, 1.0, 0.1, 1.0, world_inplace=True, use_invalid=ui)
     world = g['points'] / 2 * float(size[0]) + center
     assert np.abs(hom[:, :3].cpu().numpy() - world).max() < 1e-6 and torch.equal(hom[:, 3], torch.ones(M, device='cuda'))
-    d1, _ = ops.depth_carve(t(g['points']), depths, cams, t(size), t(center), 1 / 8, 0.25, 1.0, 0.1, 1.0)
+    d1, _ = ops.depth_carve(t(g['points']), depths, cams, t(size), t(center), 1 / 8, 0.25, 1.0, 0.1, 1.0, use_invalid=ui)
     assert torch.equal(d1, d2)
 
 

@@ -113,13 +113,15 @@ def test_feat_corr_more_source_views(name):
     assert abs(loss - float(g['loss'])) < 2e-6
 
 
-def test_carving_and_depth_loss_vs_reference_golden():
+@pytest.mark.parametrize('name', ['carve', 'carve_invalid'])
+def test_carving_and_depth_loss_vs_reference_golden(name):
     """oracle_np.carving_t2 / depth_loss == the reference's carving_t2 + get_depth_loss (my_utils.py:269-331, loss.py:37-63) on bumpy
     depth maps with holes: inside / outside voting across views, points no view sees, both attenuation classes."""
-    g = golden('carve')
+    g = golden(name)                                           # carve_invalid: carving_t (conf.use_invalid, my_utils.py:204-266)
+    ui = bool(int(g['use_invalid'])) if 'use_invalid' in g.files else False
     size, center = float(g['size'][0]), g['center'][0]
     pw = g['points'].astype(np.float64) / 2 * size + center.astype(np.float64)
-    dist, occ, valid = ON.carving_t2(pw, g['depths'][:, 0, 0].astype(np.float64), g['depth_cams'][:, 0].astype(np.float64))
+    dist, occ, valid = ON.carving_t2(pw, g['depths'][:, 0, 0].astype(np.float64), g['depth_cams'][:, 0].astype(np.float64), use_invalid=ui)
     assert 0.1 < valid.mean() < 0.95 and 0.2 < occ.mean() < 0.8 and (~valid).sum() > 100          # every branch is populated
     bad = (valid != g['in_range']) | (occ != g['occ'])
     assert bad.sum() <= 4, bad.sum()                              # fp32 (reference) vs float64 decisions at pixel / 0.99-depth boundaries
@@ -127,7 +129,7 @@ def test_carving_and_depth_loss_vs_reference_golden():
     assert np.abs(dist[ok] - g['dist'][ok]).max() < 2e-5 * max(1.0, np.abs(g['dist'][ok & valid]).max())
     for tag in 'abc':
         fa, na = g['att_' + tag]
-        loss, dist_r, w = ON.depth_loss(g['points'], g['eik_out'][0], g['depths'], g['depth_cams'], size, center, 0.25, fa, 0.1, na)
+        loss, dist_r, w = ON.depth_loss(g['points'], g['eik_out'][0], g['depths'], g['depth_cams'], size, center, 0.25, fa, 0.1, na, use_invalid=ui)
         assert abs(loss - float(g["loss_" + tag])) < 2e-6 * float(g["loss_" + tag]), (tag, loss, float(g["loss_" + tag]))
 
 
