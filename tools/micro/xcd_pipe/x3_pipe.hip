@@ -129,10 +129,15 @@ __device__ void pe_stage(const MvNetBs<3, 3>& net, const PipeBufs& p, int x, int
     }
 }
 
-// ---- a layer's workgroup: 4 waves = 4 column tiles (layer 0: 4 x 4), row tiles of one parity.  The tile's A fragments (24 KiB) are fetched ONCE per workgroup
-// into LDS (each thread six 16-byte loads, issued while the previous tile is multiplied), then every wave multiplies its column tile(s) from LDS. ----
+// ---- a layer's workgroup: 4 waves = 4 column tiles (layer 0: 4 x 4); ITEMS of TPI row tiles (TPI independent accumulators per wave: the matrix instructions of
+// one tile are a dependent chain), items of one parity.  The item's A fragments (TPI x 24 KiB) are fetched ONCE per workgroup into LDS (requested while the
+// previous item is multiplied), then every wave multiplies its column tile(s) from LDS. ----
+#ifndef PIPE_TPI
+#define PIPE_TPI 2
+#endif
 template <int NTW, int KBM>
 __device__ void layer_wg(const MvNetBs<3, 3>& net, const PipeBufs& p, int x, int l, int c, int par, int w, int lane, uint4* lds) {
+    constexpr int TPI = PIPE_TPI, NPRE = 6 * TPI;
     const int r = lane & 15, q = lane >> 4, tid = w * 64 + lane;
     const MvLayerBf& L = net.L[l];
     const int nl = net.n_layers, NT = L.NT, N = L.N, KB = L.KB, d0 = 3 + 6 * net.multires;
@@ -154,19 +159,30 @@ __device__ void layer_wg(const MvNetBs<3, 3>& net, const PipeBufs& p, int x, int
     }
     const float sc = to_skip ? 0.7071067690849304f : 1.0f;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.abuf, 0, 0x7fffffff, 0x00020000);
-    const int nt = (p.T - par + 1) / 2, items = p.rounds * nt;
-    uint4 pre[6];
-    auto issue = [&](int it) {                                                       // the six fragment quarters of item `it` -> registers
-        const int t = par + 2 * (it % nt);
-        const size_t base = pb_frag(p, x, t, l & 1, 0, 0);
+    const int nitem_all = (p.T + TPI - 1) / TPI, nt = (nitem_all - par + 1) / 2, items = p.rounds * nt;
+    uint4 pre[NPRE];
+    auto tile_of = [&](int it, int u) { return (par + 2 * (it % nt)) * TPI + u; };
+    auto issue = [&](int it) {                                                       // the item's fragments -> registers (6 per thread and tile)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) pre[i] = ld_frag(rs, base + 256 * i, tid);
+        for (int u = 0; u < TPI; ++u) {
+            const int t = tile_of(it, u) < p.T ? tile_of(it, u) : p.T - 1;
+            const size_t base = pb_frag(p, x, t, l & 1, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) pre[6 * u + i] = ld_frag(rs, base + 256 * i, tid);
+        }
     };
     auto ready = [&](int it, bool block) -> int {                                    // 1 ready, 0 not yet, -1 abort
-        const int rd = 1 + it / nt, t = par + 2 * (it % nt);
-        if (block) return wait_flags(p, pb_flag(p, x, t, l), nprod, (unsigned)rd, lane) ? 1 : -1;
-        const unsigned v = lane < nprod ? ld_flag(pb_flag(p, x, t, l) + lane) : (unsigned)rd;
-        return __all((int)(v >= (unsigned)rd)) ? 1 : 0;
+        const int rd = 1 + it / nt;
+        for (int u = 0; u < TPI; ++u) {
+            const int t = tile_of(it, u);
+            if (t >= p.T) continue;
+            if (block) { if (!wait_flags(p, pb_flag(p, x, t, l), nprod, (unsigned)rd, lane)) return -1; }
+            else {
+                const unsigned v = lane < nprod ? ld_flag(pb_flag(p, x, t, l) + lane) : (unsigned)rd;
+                if (!__all((int)(v >= (unsigned)rd))) return 0;
+            }
+        }
+        return 1;
     };
     if (items <= 0) return;
     if (ready(0, true) < 0) return;
@@ -175,66 +191,80 @@ __device__ void layer_wg(const MvNetBs<3, 3>& net, const PipeBufs& p, int x, int
     unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_ = wall_clock64();
 #define PH(i) { const unsigned long long t_ = wall_clock64(); ph_[i] += t_ - tp_; tp_ = t_; }
     for (int it = 0; it < items; ++it) {
-        const int rd = 1 + it / nt, t = par + 2 * (it % nt), buf = it & 1;
-        uint4* A = lds + buf * (3 * PIPE_KBMAX * 64);
+        const int rd = 1 + it / nt;
+        __syncthreads();                                                             // everyone is done reading the previous item's fragments
 #pragma unroll
-        for (int i = 0; i < 6; ++i) A[tid + 256 * i] = pre[i];
+        for (int i = 0; i < NPRE; ++i) lds[(i / 6) * (3 * PIPE_KBMAX * 64) + tid + 256 * (i % 6)] = pre[i];
         PH(0)
-        __syncthreads();                                                             // the tile's fragments are in LDS (and everyone is done with the buffer of item it - 1)
+        __syncthreads();                                                             // the item's fragments are in LDS
         PH(1)
-        bool fetched = it + 1 >= items;
-        const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)p.flags, 0, 0x7fffffff, 0x00020000);
-        const int rdn = 1 + (it + 1) / nt, tn = par + 2 * ((it + 1) % nt);
-        const int foff = (int)(((((size_t)x * p.T + tn) * 10 + l) * 16 + (lane < nprod ? lane : 0)) * 4);
-        unsigned fv = 0;
-        if (!fetched) fv = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rf, foff, 0, 0x11);          // asynchronous look at the next item's flags
+        bool fetched = false;
+        if (it + 1 < items && ready(it + 1, false) == 1) { issue(it + 1); fetched = true; }
         PH(2)
 #pragma unroll
         for (int tt = 0; tt < NTW; ++tt) {
             const int ct = ct0 + tt;
             if (ct >= ntot) continue;
-            f32x4 acc = bias4[tt];
+            f32x4 acc[TPI];
+#pragma unroll
+            for (int u = 0; u < TPI; ++u) acc[u] = bias4[tt];
             if (ct < NT) {
 #pragma unroll
                 for (int kb = 0; kb < KBM; ++kb) {
                     if (kb < KB) {
-                        uint4 a[3];
+                        uint4 a[TPI][3];
 #pragma unroll
-                        for (int s = 0; s < 3; ++s) a[s] = A[(s * PIPE_KBMAX + kb) * 64 + lane];
-                        acc = kblock_mfma(acc, b[kb][tt], a);
-                    }
-                    if ((kb & 1) == 1 && !fetched) {                                 // every two k-blocks: did the next item's inputs arrive?  then request them now
-                        if (__all((int)((lane < nprod ? fv : (unsigned)rdn) >= (unsigned)rdn))) { issue(it + 1); fetched = true; }
-                        else {
-                            asm volatile("" ::: "memory");
-                            fv = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rf, foff, 0, 0x11);
-                        }
+                        for (int u = 0; u < TPI; ++u)
+#pragma unroll
+                            for (int s = 0; s < 3; ++s) a[u][s] = lds[u * (3 * PIPE_KBMAX * 64) + (s * PIPE_KBMAX + kb) * 64 + lane];
+                        // the tiles' chains interleaved instruction by instruction (each accumulator still sees its six products in the engine's order)
+#pragma unroll
+                        for (int o = 2; o >= 0; --o)
+#pragma unroll
+                            for (int s = 0; s < 3; ++s) {
+                                const int j = o - s;
+                                if (j >= 0 && j < 3) {
+#pragma unroll
+                                    for (int u = 0; u < TPI; ++u)
+                                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mv_bf8, b[kb][tt][j]), __builtin_bit_cast(mv_bf8, a[u][s]), acc[u], 0, 0, 0);
+                                }
+                            }
                     }
                 }
             }
-            if (last) {
-                if (q == 0) p.out[((size_t)x * p.T + t) * 16 + r] = acc[0];
-                set_flag(pb_flag(p, x, t, 9), (unsigned)rd);
-            } else {
-                dm_f2 h0 = dm2_softplus100_lean(dm_f2{acc[0], acc[1]}) * dm2_s(sc), h1 = dm2_softplus100_lean(dm_f2{acc[2], acc[3]}) * dm2_s(sc);
-                float hv[4] = {h0.x, h0.y, h1.x, h1.y};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {                                        // columns past N: the PE part of the skip input (idr.py:86-87), else zero padding
-                    const int col = ct * 16 + 4 * q + e;
-                    if (col >= N) {
-                        const int j = col - N;
-                        float v = 0.0f;
-                        if (to_skip && j < d0) v = mv_x3_flush(__uint_as_float(ld_flag((const unsigned*)(p.pe_side + (((size_t)x * p.T + t) * 40 + j) * 16 + r))));
-                        hv[e] = v;
+            for (int u = 0; u < TPI; ++u) {
+                const int t = tile_of(it, u);
+                if (t >= p.T) continue;
+                if (last) {
+                    if (q == 0) p.out[((size_t)x * p.T + t) * 16 + r] = acc[u][0];
+                } else {
+                    dm_f2 h0 = dm2_softplus100_lean(dm_f2{acc[u][0], acc[u][1]}) * dm2_s(sc), h1 = dm2_softplus100_lean(dm_f2{acc[u][2], acc[u][3]}) * dm2_s(sc);
+                    float hv[4] = {h0.x, h0.y, h1.x, h1.y};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {                                    // columns past N: the PE part of the skip input (idr.py:86-87), else zero padding
+                        const int col = ct * 16 + 4 * q + e;
+                        if (col >= N) {
+                            const int j = col - N;
+                            float v = 0.0f;
+                            if (to_skip && j < d0) v = mv_x3_flush(__uint_as_float(ld_flag((const unsigned*)(p.pe_side + (((size_t)x * p.T + t) * 40 + j) * 16 + r))));
+                            hv[e] = v;
+                        }
                     }
+                    store_cols(p, x, t, (l + 1) & 1, ct, r, q, dm_f2{hv[0], hv[1]}, dm_f2{hv[2], hv[3]});
                 }
-                store_cols(p, x, t, (l + 1) & 1, ct, r, q, dm_f2{hv[0], hv[1]}, dm_f2{hv[2], hv[3]});
             }
         }
         PH(3)
-        if (!last) {
 #pragma unroll
-            for (int tt = 0; tt < NTW; ++tt) if (ct0 + tt < ntot) set_flag(pb_flag(p, x, t, l + 1) + ct0 + tt, (unsigned)rd);
+        for (int u = 0; u < TPI; ++u) {
+            const int t = tile_of(it, u);
+            if (t >= p.T) continue;
+            if (last) { if (ct0 < ntot) set_flag(pb_flag(p, x, t, 9), (unsigned)rd); }
+            else {
+#pragma unroll
+                for (int tt = 0; tt < NTW; ++tt) if (ct0 + tt < ntot) set_flag(pb_flag(p, x, t, l + 1) + ct0 + tt, (unsigned)rd);
+            }
         }
         PH(4)
         if (it + 1 < items && !fetched) {
@@ -246,7 +276,6 @@ __device__ void layer_wg(const MvNetBs<3, 3>& net, const PipeBufs& p, int x, int
     }
     if (probe) for (int i = 0; i < 8; ++i) p.ph[i] = ph_[i];
 }
-
 
 // ---- last layer (column 0 only): wave-level, tiles t = w (mod nw); all 24 fragments of a tile requested at once ----
 __device__ void last_stage(const MvNetBs<3, 3>& net, const PipeBufs& p, int x, int w, int nw, int lane) {
@@ -385,7 +414,7 @@ int main(int argc, char** argv) {
                 for (int c = 0; c < 3; ++c) hp[(((size_t)x * T + t) * 16 + r) * 4 + c] = hx[((size_t)b * 16 + r) * 3 + c];
         }
     float ms = 0;
-    const size_t plds = (size_t)2 * 3 * PIPE_KBMAX * 64 * 16;
+    const size_t plds = (size_t)PIPE_TPI * 3 * PIPE_KBMAX * 64 * 16;
     (void)hipFuncSetAttribute((const void*)k_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
     std::vector<float> y((size_t)tiles * 16);
     unsigned ab = 0;
@@ -416,7 +445,7 @@ int main(int argc, char** argv) {
     printf("%d tiles of 16 rows (%d per XCD), %d dependent rounds: engine (one workgroup per tile, weights streamed) %.1f us per round; pipeline (weights in registers, %d workgroups of 256) %.1f us per round\n",
            tiles, T, rounds, 1e3 * ms_ref / rounds, 8 * (8 + 8 * (nl - 2)), 1e3 * ms / rounds);
     unsigned long long hph[8]; (void)hipMemcpy(hph, p.ph, 64, hipMemcpyDeviceToHost);
-    const double ni = (double)rounds * ((T + 1) / 2);
+    const double ni = (double)rounds * ((((T + PIPE_TPI - 1) / PIPE_TPI) + 1) / 2);
     printf("layer-2 workgroup, us per item: regs->LDS %.2f | barrier %.2f | try-poll + issue next %.2f | multiply + epilogue + stores %.2f | store ack + flag %.2f | blocking wait + issue %.2f  (blocking waits: %.0f of %.0f items)\n",
            hph[0] * 0.01 / ni, hph[1] * 0.01 / ni, hph[2] * 0.01 / ni, hph[3] * 0.01 / ni, hph[4] * 0.01 / ni, hph[5] * 0.01 / ni, (double)hph[7], ni);
     printf("outputs differing from the engine bit for bit: %zu of %d (max |d| %.3g); sample %g %g\n", bad, tiles * 16, maxd, yo[0], yref[0]);
