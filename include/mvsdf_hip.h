@@ -11,12 +11,11 @@
  *
  * What this boundary REFUSES (the call returns a negative code and mvsdf_last_error() names the reason; the Python mirror raises
  * NotImplementedError / ValueError before it gets here) -- every other constructor option of the reference's three modules is accepted:
- *   1. a skip connection into the LAST Linear of the SDF network (`skip_in` containing num_layers - 2: idr.py:46-49,86).  The tracing engines would
- *      take it; the fused value / normal / double-backward chains start their normal chain from row 0 of the last weight matrix over ITS OWN input
- *      width and have no PE-adjoint term there.  No conf of the reference has one (confs/ *.conf: skip_in = [4]).
- *   2. `d_in != 3` for ImplicitNetwork (idr.py:22,34): points are 3-vectors everywhere on this path (camera rays, PE of 3 + 6 * multires columns).
- *   3. hidden widths above 512 (column tiles per wave of the fused engines: 2 up to 256, 4 up to 512), and more than MVSDF_MAX_LAYERS = 12 Linears.
- *   4. quaternion poses in get_camera_params (rend_util.py:49-54: the `pose.shape[1] == 7` branch): the reference switches it off
+ *      (a skip connection into the LAST Linear of the SDF network, `skip_in` containing num_layers - 2 (idr.py:46-49,86), is accepted since round 5:
+ *      u_L = W_L[0, :] splits like any skip layer's adjoint, its PE columns start the PE adjoint of the normal chain)
+ *   1. `d_in != 3` for ImplicitNetwork (idr.py:22,34): points are 3-vectors everywhere on this path (camera rays, PE of 3 + 6 * multires columns).
+ *   2. hidden widths above 512 (column tiles per wave of the fused engines: 2 up to 256, 4 up to 512), and more than MVSDF_MAX_LAYERS = 12 Linears.
+ *   3. quaternion poses in get_camera_params (rend_util.py:49-54: the `pose.shape[1] == 7` branch): the reference switches it off
  *      (exp_runner.py:40 train_cameras = False; scene_dataset.py hands 4 x 4 matrices); mvsdf_camera_rays takes pose[B][4][4] only.
  */
 #ifndef MVSDF_HIP_H
@@ -60,7 +59,7 @@ typedef struct {
                                          * (oracle_mvsdf.c::sdf_row_f32x3); det_math's softplus like mode 0; values below 2^-40 count as zero.  Not bit-identical
                                          * to mode 0 (another summation order).  bias[] is read like in modes 3 / 4 */
     unsigned skip_mask;                 /* several skip connections (skip_in with more than one entry, idr.py:46,86): bit l set = the input of layer l
-                                         * is cat([x, PE(x)])/sqrt(2).  0 = use skip_layer alone.  Layer 0 and the last layer cannot be skip layers. */
+                                         * is cat([x, PE(x)])/sqrt(2).  0 = use skip_layer alone.  Any layer but layer 0 (the last Linear included). */
 } MvsdfNetDesc;
 
 /* RayTracing constructor arguments (ray_tracing.py:7-25) + the hard-coded dist_clip (ray_tracing.py:127-131). */

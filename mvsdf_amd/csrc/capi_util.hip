@@ -18,7 +18,8 @@ int mv_make_net_mode(const MvsdfNetDesc* d, MvNet* net, int mode) {
     memset(net, 0, sizeof(*net));
     int maxk = 0;
     const unsigned skm = mode == 0 ? mv_desc_skip_mask(d) : 0u;
-    if (skm & 1u || skm >> (d->n_layers - 1)) return mv_fail(-2, "net descriptor: layer 0 and the last layer cannot be skip layers");
+    // (idr.py:46-49,86: any layer but the first may take cat([x, PE]) / sqrt(2) -- the last Linear included)
+    if (skm & 1u || skm >> d->n_layers) return mv_fail(-2, "net descriptor: layer 0 cannot be a skip layer / skip mask beyond the last layer");
     for (int l = 0; l < d->n_layers; ++l) {
         if (!d->wp[l] || !d->bias[l] || d->K[l] <= 0 || d->N[l] <= 0) return mv_fail(-2, "net descriptor: null pointer or bad dims");
         if (mode == 0) {

@@ -91,6 +91,14 @@ __global__ void k_pe_input_bwd(const float* __restrict__ H0, int ldh, const floa
     dx[idx] = v;
 }
 
+// E[row][j] = W_L[0, tail0 + j] / sqrt(2): the PE adjoint a skip connection into the LAST Linear starts the normal chain with (per-layer route)
+__global__ void k_pe_adj_top(const float* __restrict__ w_last_row0, int tail0, int d0, int Mg, float* __restrict__ E, int ld) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Mg * d0) return;
+    const int row = idx / d0, j = idx - row * d0;
+    E[(size_t)row * ld + j] = dm_div_sqrt2(w_last_row0[tail0 + j]);
+}
+
 __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] += src[i];
@@ -378,11 +386,13 @@ int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const f
         const int sk1 = mv_single_skip(net);
         if (sk1 == -2) return mv_fail(-4, "mvsdf_sdf_forward: several skip connections need the fused chain kernels (MVSDF_FUSE unset)");
         const float* w8 = d->w[nl - 1];                                           // row 0 of the last layer = u_{nl-1}
+        if (sk1 == nl - 1)                                                        // skip into the last Linear: its PE columns start the PE adjoint
+            hipLaunchKernelGGL(k_pe_adj_top, dim3((Mg * lo.d0 + 255) / 256), dim3(256), 0, s, w8, net.L[nl - 1].K - lo.d0, lo.d0, Mg, ctx + lo.E, lo.ld0);
         for (int l = nl - 2; l >= 0; --l) {
             LayerArgs a = base_args(netT.L[l], S, Mg);
             a.Z = ctx + lo.Z[l]; a.ldz = net.L[l].N;
             const bool top = (l == nl - 2);
-            if (top) a.bcast = w8; else { a.U = ctx + lo.U[l + 1]; a.ldu = net.L[l].N; }
+            if (top) { a.bcast = w8; a.bcast_sqrt2 = (sk1 == nl - 1); } else { a.U = ctx + lo.U[l + 1]; a.ldu = net.L[l].N; }
             a.out2 = ctx + lo.Sg[l]; a.ld2 = net.L[l].N;                            // keep s_l for the weight gradient
             if (l == sk1) {
                 a.csplit = net.L[l].K - lo.d0; a.scale_sqrt2 = 1;
@@ -490,7 +500,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
             LayerArgs a = base_args(net.L[l], S, Mb);
             a.A = ws + bl.VB[l]; a.lda = ldA(l);
             a.Z = Zof(l); a.ldz = net.L[l].N;
-            if (l == nl - 2) a.bcast = w8; else { a.U = Uof(l + 1); a.ldu = net.L[l].N; }
+            if (l == nl - 2) { a.bcast = w8; a.bcast_sqrt2 = (sk == nl - 1); } else { a.U = Uof(l + 1); a.ldu = net.L[l].N; }
             a.out0 = ws + bl.VB[l + 1]; a.ld0 = net.L[l + 1].K;
             a.out1 = ws + bl.ZB2[l]; a.ld1 = net.L[l].N;
             a.skip_next = (l + 1 == sk);
@@ -520,6 +530,10 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         LayerArgs a = base_args(netT.L[nl - 1], S, Mb);
         a.A = dy; a.lda = net.L[nl - 1].N;
         a.csplit = net.L[nl - 1].K; a.out0 = ws + bl.HB[cur]; a.ld0 = net.L[nl - 1].K;
+        if (sk == nl - 1) {                                                        // skip into the last Linear: hidden part / PE part, both / sqrt(2)
+            a.csplit = net.L[nl - 1].K - lo.d0; a.scale_sqrt2 = 1; a.ld0 = net.L[nl - 2].N;
+            a.out1 = ws + bl.H0B; a.ld1 = lo.ld0;
+        }
         MV_TRY((launch_layer<PRO_PLAIN, EPI_SPLIT>(a, s)));
     }
     if (sk <= 0) MV_TRY(hipMemsetAsync(ws + bl.H0B, 0, (size_t)Mb * lo.ld0 * sizeof(float), s));

@@ -40,7 +40,7 @@ struct LayerArgs {
     const float* A; int lda;
     const float* Z; int ldz;
     const float* U; int ldu;
-    const float* bcast;
+    const float* bcast; int bcast_sqrt2;   // bcast_sqrt2: the last Linear is a skip layer, u_L reaches sigma_{L-1} as W_L[0, :N] / sqrt(2)
     const float* add; int ldadd;
     float* out0; int ld0;
     float* out1; int ld1;
@@ -56,7 +56,7 @@ template <int PRO>
 __device__ __forceinline__ float mv_prologue(const LayerArgs& a, int row, int k) {
     if (PRO == PRO_PLAIN) return a.A[(size_t)row * a.lda + k];
     if (PRO == PRO_SIG_MUL || PRO == PRO_SIG_BCAST) {
-        const float u = PRO == PRO_SIG_MUL ? a.U[(size_t)row * a.ldu + k] : a.bcast[k];
+        const float u = PRO == PRO_SIG_MUL ? a.U[(size_t)row * a.ldu + k] : (a.bcast_sqrt2 ? dm_div_sqrt2(a.bcast[k]) : a.bcast[k]);
         const float sv = a.Z[(size_t)row * a.ldz + k] * u;
         if (a.out2) a.out2[(size_t)row * a.ld2 + k] = sv;                       // s_l, kept for the weight gradient (E.1)
         return sv;
@@ -83,7 +83,7 @@ template <int EPI>
 __device__ __forceinline__ EpiIn mv_epilogue_load(const LayerArgs& a, int row, int col) {
     EpiIn e = {0.f, 0.f, 0.f};
     if (EPI == EPI_SPLIT) { if (a.add) e.add = a.add[(size_t)row * a.ldadd + col]; }
-    else if (EPI == EPI_SBAR) { e.z = a.Z[(size_t)row * a.ldz + col]; e.u = a.U ? a.U[(size_t)row * a.ldu + col] : a.bcast[col]; }
+    else if (EPI == EPI_SBAR) { e.z = a.Z[(size_t)row * a.ldz + col]; e.u = a.U ? a.U[(size_t)row * a.ldu + col] : (a.bcast_sqrt2 ? dm_div_sqrt2(a.bcast[col]) : a.bcast[col]); }
     else if (EPI == EPI_RELU_MASK) e.add = a.add[(size_t)row * a.ldadd + col];
     return e;
 }
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_e1(ChainArgs a) {
                     zz[t][m][i] = 0.f; uu[t][m][i] = 0.f;
                     if (t < ntw && col < N && row < a.M) {
                         zz[t][m][i] = a.Z[l][(size_t)row * N + col];
-                        uu[t][m][i] = top ? a.w_last_row0[col] : a.U[l + 1][(size_t)row * N + col];
+                        uu[t][m][i] = top ? (to_skip ? dm_div_sqrt2(a.w_last_row0[col]) : a.w_last_row0[col]) : a.U[l + 1][(size_t)row * N + col];
                     }
                 }
         }
@@ -737,7 +737,7 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
                         zz[t][m][i] = 0.f; uu[t][m][i] = 0.f;
                         if (t < ntw && col < N && row < a.M) {
                             zz[t][m][i] = a.Z[l][(size_t)row * N + col];
-                            uu[t][m][i] = top ? a.w_last_row0[col] : a.U[l + 1][(size_t)row * N + col];
+                            uu[t][m][i] = top ? (to_skip ? dm_div_sqrt2(a.w_last_row0[col]) : a.w_last_row0[col]) : a.U[l + 1][(size_t)row * N + col];
                         }
                     }
             }
@@ -1072,7 +1072,9 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
     CH_PH(5)
     if (row0 >= a.Mg) return;                                    // workgroup-uniform: no normals for these rows
     // ---- normal chain (rows >= Mg inside the tile carry zeros)
-    for (int i = tid; i < ROWS * d0; i += NTH) padj[i] = 0.0f;
+    // (a skip connection into the LAST Linear, idr.py:46-49,86: u_L = W_L[0, :] splits like any skip layer's adjoint -- its PE part starts the PE adjoint)
+    const bool top_skip = mv_skip_at(skm, nl - 1);
+    for (int i = tid; i < ROWS * d0; i += NTH) padj[i] = top_skip ? dm_div_sqrt2(a.w_last_row0[a.net.L[nl - 1].K - d0 + (i % d0)]) : 0.0f;
     // sigma_l of this thread's elements of a layer's prologue, requested one layer ahead (before the GEMM of the layer above): the prologue is a
     // load, a multiply and two stores per element, and with the load issued on the spot it was 2 us of exposed L2 latency per layer (probe: 16-18
     // of the kernel's 124 us at c2).  Covers the first ZPF passes of a prologue (all of it up to 32 rows x 256 columns).  No branch around the
@@ -1106,7 +1108,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
                 const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
                 v[u] = 0.0f;
                 if (idx < ROWS * Kp && row < a.Mg && k < K) {
-                    const float uu = top ? a.w_last_row0[k] : act[rr * S + mv_perm(k)];
+                    const float uu = top ? (top_skip ? dm_div_sqrt2(a.w_last_row0[k]) : a.w_last_row0[k]) : act[rr * S + mv_perm(k)];
                     v[u] = (zp ? zp[u] : a.Z[l][(size_t)row * K + k]) * uu;
                     a.Sg[l][(size_t)row * K + k] = v[u];
                 }

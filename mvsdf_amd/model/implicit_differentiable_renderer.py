@@ -80,9 +80,7 @@ class ImplicitNetwork(nn.Module):
         dims[0] = 3 + 6 * multires
         self.num_layers = len(dims)
         self.skip_in = tuple(skip_in)
-        if self.num_layers - 2 in self.skip_in:
-            raise NotImplementedError('a skip connection into the LAST Linear is not supported by the native kernels (no shipped conf has one)')
-        if len([s for s in self.skip_in if 0 < s < self.num_layers - 2]) > 1 and max(dims[1:-1]) > 512:
+        if len([s for s in self.skip_in if 0 < s < self.num_layers - 1]) > 1 and max(dims[1:-1]) > 512:
             raise NotImplementedError('several skip connections need the fused chain kernels (hidden width <= 512)')
         self.d_out = d_out
         for l in range(self.num_layers - 1):

@@ -54,6 +54,8 @@ def make_state_dict(W, seed=0, noise=0.02, bias=0.6, n_hidden=8, n_hidden_r=4, s
         if l == L - 1:
             w = rs.normal(np.sqrt(np.pi) / np.sqrt(i), 1e-4, size=(o, i))
             b = np.full((o,), -bias)
+            if l in skip_in:                                     # a skip into the last Linear: small PE columns keep the synthetic surface near the sphere
+                w[:, -d0:] = rs.normal(0.0, 0.01, size=(o, d0))
         elif l == 0:
             w = np.zeros((o, i))
             w[:, :3] = rs.normal(0.0, np.sqrt(2) / np.sqrt(o), size=(o, 3))

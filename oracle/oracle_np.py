@@ -103,8 +103,12 @@ def sdf_forward(net, x, need_normal=True):
         return y, None, cache
     M = x.shape[0]
     U = [None] * (L + 1)                       # U[l+1] multiplies sigma_l
-    U[L - 1] = np.broadcast_to(net.W[L - 1][0], (M, net.W[L - 1].shape[1]))
+    wl = net.W[L - 1][0]
     e = np.zeros((M, d0))
+    if (L - 1) in net.skip_layers:             # a skip into the last Linear (idr.py:46-49,86): u_L splits like any skip layer's adjoint
+        e = e + wl[-d0:] / SQRT2
+        wl = wl[:-d0] / SQRT2
+    U[L - 1] = np.broadcast_to(wl, (M, wl.shape[0]))
     for l in range(L - 2, -1, -1):
         s = sigmoid100(Z[l]) * U[l + 1]
         v = s @ net.W[l]
@@ -160,11 +164,15 @@ def sdf_backward(net, cache, dy, dn=None, want_dx=True):
             dW[l] += (sig * U[l + 1]).T @ vb
             ub = sig * sb
             ZB2[l] = U[l + 1] * sb * sigmoid100_prime(Z[l])
-        dW[L - 1][0] += ub.sum(0)
+        vb = np.concatenate([ub, gb0], 1) / SQRT2 if (L - 1) in net.skip_layers else ub
+        dW[L - 1][0] += vb.sum(0)
     dW[L - 1] += dy.T @ A[L - 1]
     db[L - 1] += dy.sum(0)
     hb = dy @ net.W[L - 1]
     h0b = np.zeros((M, d0))
+    if (L - 1) in net.skip_layers:
+        h0b += hb[:, -d0:] / SQRT2
+        hb = hb[:, :-d0] / SQRT2
     for l in range(L - 2, -1, -1):
         zb = sigmoid100(Z[l]) * hb + ZB2[l]
         dW[l] += zb.T @ A[l]

@@ -25,7 +25,10 @@ def dev_lib():
     return build.build(tag='dev')
 
 TARGETS = ['tests/test_gpu_diff.py', 'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w64_tp03]',
-           'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w256_tp03]']
+           'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w256_tp03]',
+           # a skip connection into the LAST Linear (idr.py:46-49,86): the one layout the per-layer route treats apart (k_pe_adj_top, bcast_sqrt2)
+           'tests/test_gpu_options.py::test_several_skip_connections[sdf_bwd_w64_skip8]',
+           'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w64_skip8]']
 
 
 @pytest.mark.parametrize('env', [{'MVSDF_FUSE': '0'}, {'MVSDF_SPLIT_CHAINS': '1'}, {'MVSDF_CHAIN_W8': '1'}, {'MVSDF_CHAIN_MT': '2'}, {'MVSDF_DELTA_CHAIN': '1'},

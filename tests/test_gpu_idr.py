@@ -34,17 +34,17 @@ def _dsurf_override(model, g):
     model._dsurf_samples = lambda input, n_dsurf_points, bb: (on, jit, torch.full((2,), n, dtype=torch.int64, device='cuda'))
 
 
-SKIPS = {'idr_w64_skips36': (3, 6)}                          # fixtures of networks with several skip connections (idr.py:46,86)
+SKIPS = {'idr_w64_skips36': (3, 6), 'idr_w64_skip8': (8,)}                          # fixtures of networks with several skip connections (idr.py:46,86)
 
 
-@pytest.mark.parametrize('name', ['idr_w64_tp03', 'idr_w64_tp06', 'idr_w256_tp03', 'idr_c1', 'idr_c2', 'idr_c3', 'idr_c5share', 'idr_w512', 'idr_w64_phase0', 'idr_w64_skips36', 'idr_w64_smooth', 'idr_w64_invalid'])
+@pytest.mark.parametrize('name', ['idr_w64_tp03', 'idr_w64_tp06', 'idr_w256_tp03', 'idr_c1', 'idr_c2', 'idr_c3', 'idr_c5share', 'idr_w512', 'idr_w64_phase0', 'idr_w64_skips36', 'idr_w64_skip8', 'idr_w64_smooth', 'idr_w64_invalid'])
 def test_forward_loss_backward_vs_reference(name, monkeypatch):
     """idr_c1 = BASELINE configs[0] at its own shape (B = 1 view x 512 rays, V = 4, 8x256 networks); idr_w512 = the reference's SHIPPED
     configuration (8x512 SDF net, 4x512 rendering net, confs/mvsdf_dtu.conf:24,35; num_src = 2, scene_dataset.py:104) on 8 views x 128 px;
     idr_c2 = the bench shape (8 views x 256 px, V = 4, 8x256 networks); idr_c3 = BASELINE configs[2] (8 views x 1024 px = 8192 rays, V = 8); idr_c5share = one GPU's share of BASELINE configs[4] (8 views x 512 px = 4096 rays, V = 8), here in fp32 (its bf16 budget: test_gpu_bf16.py); idr_w64_phase0 = train_progress < 1/6: depth-surface groups
     in the depth / eikonal terms, rgb gradient through the features only (idr.py:331-334), no feature / surface loss; idr_w64_smooth = conf.smooth = 0.05
     (the SmoothL1 depth term of loss.py:57-58, off in the shipped conf, reachable through IDR_CONF); idr_w64_invalid = conf.use_invalid (carving_t, loss.py:43-44) on
-    depth maps with 30 % holes."""
+    depth maps with 30 % holes; idr_w64_skip8 = skip_in (8,): a skip connection into the LAST Linear (idr.py:46-49,86)."""
     g = golden(name)
     if 'smooth' in g.files:
         from mvsdf_amd.model import loss as loss_mod

@@ -150,14 +150,16 @@ def test_idr_step_without_weight_norm_and_without_normals():
             assert torch.allclose(lb.bias.grad, la.bias.grad, rtol=1e-6, atol=1e-9)
 
 
-def test_several_skip_connections():
-    """skip_in = (3, 6): (1) value / normal / double backward of the HIP chains vs the reference golden, (2) the tracer bit for bit vs the C
-    oracle in fp32 on every engine, (3) the bf16-weight split-activation engine against the oracle on rounded weights, (4) a skip into the last Linear is refused."""
+@pytest.mark.parametrize('name', ['sdf_bwd_w64_skips36', 'sdf_bwd_w64_skip8', 'sdf_bwd_w64_skips48'])
+def test_several_skip_connections(name):
+    """skip_in = (3, 6), (8,) = a skip into the LAST Linear (idr.py:46-49,86) and (4, 8): (1) value / normal / double backward of the HIP chains
+    vs the reference golden, (2) the tracer bit for bit vs the C oracle in fp32 on every engine, (3) the bf16-weight split-activation engine against
+    the oracle on rounded weights, (4) the f32x3 engine bit for bit vs its instruction-model oracle, (5) the layer shapes of the module."""
     from conftest import golden
     from helpers import sdf_packed_net, trace_params
     from mvsdf_amd import ops
     from oracle import oracle as O
-    g = golden('sdf_bwd_w64_skips36')
+    g = golden(name)
     skips = tuple(int(v) for v in g['skip_in'])
     sd = synth.make_state_dict(64, int(g['seed']), skip_in=skips)
     net = sdf_packed_net(sd, skip_layer=skips)
@@ -199,8 +201,17 @@ def test_several_skip_connections():
     got = ops.sdf_col0(net, xs).cpu().numpy()
     assert np.abs(got - twin).max() < 4e-6
     assert np.abs(got - want).max() < 2e-2                       # and near the fp32 network
-    # (4)
-    with pytest.raises(NotImplementedError):
-        ImplicitNetwork(256, 3, 1, [64] * 8, skip_in=(4, 8), multires=6)
-    m2 = ImplicitNetwork(256, 3, 1, [64] * 8, skip_in=(3, 6), multires=6)
-    assert m2.lin2.weight_v.shape == (25, 64) and m2.lin5.weight_v.shape == (25, 64) and m2.fold_spec()[3] == (3, 6)
+    # (4) the product default: fp32 weights and activations as three bf16 terms each, against the oracle's model of the matrix instruction
+    net3 = sdf_packed_net(sd, skip_layer=skips)
+    ops.pack_trace_net(net3, 'f32x3')
+    o3 = O.Net(sd, skip_in=skips, bf16='f32x3')
+    assert np.array_equal(ops.sdf_col0(net3, xs).cpu().numpy(), O.sdf_forward(o3, xs.cpu().numpy(), ncols=1)[:, 0])
+    p_o, m_o, d_o, rows = O.trace(o3, cam.cpu().numpy(), dirs.cpu().numpy(), np.ones(320, bool), True, steps, iv.numpy(), **synth.model_conf(64)['ray_tracer'])
+    pts, mask, dists, cnt = ops.trace(net3, cam, dirs, om, trace_params(64), True, iv.cuda(), t(steps))
+    assert np.array_equal(mask.cpu().numpy(), m_o) and np.array_equal(dists.cpu().numpy(), d_o) and np.array_equal(pts.cpu().numpy(), p_o)
+    assert np.array_equal(cnt.cpu().numpy()[:4], rows)
+    # (5)
+    m2 = ImplicitNetwork(256, 3, 1, [64] * 8, skip_in=skips, multires=6)
+    for sk in skips:
+        assert getattr(m2, 'lin%d' % (sk - 1)).weight_v.shape == (25, 64) and getattr(m2, 'lin%d' % sk).weight_v.shape[1] == 64
+    assert m2.fold_spec()[3] == (skips if len(skips) > 1 else skips[0])

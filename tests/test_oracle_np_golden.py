@@ -133,15 +133,19 @@ def test_carving_and_depth_loss_vs_reference_golden(name):
         assert abs(loss - float(g["loss_" + tag])) < 2e-6 * float(g["loss_" + tag]), (tag, loss, float(g["loss_" + tag]))
 
 
-def test_several_skip_connections_vs_reference_golden():
-    """skip_in = (3, 6) (idr.py:46,86: every listed layer takes cat([x, PE]) / sqrt(2)): value, normal and the double backward of the numpy
-    oracle, and the value of the C oracle, against the reference's outputs."""
+@pytest.mark.parametrize('name', ['sdf_bwd_w64_skips36', 'sdf_bwd_w64_skip8', 'sdf_bwd_w64_skips48'])
+def test_several_skip_connections_vs_reference_golden(name):
+    """skip_in = (3, 6) (idr.py:46,86: every listed layer takes cat([x, PE]) / sqrt(2)), (8,) = a skip into the LAST Linear (idr.py:46-49: the
+    layer before it is W - d0 wide, u_L = W_L[0, :] splits like any skip layer's adjoint) and (4, 8): value, normal and the double backward of the
+    numpy oracle, and the value of the C oracle, against the reference's outputs."""
     from oracle import oracle as O
-    g = golden('sdf_bwd_w64_skips36')
+    g = golden(name)
     skips = tuple(int(v) for v in g['skip_in'])
     sd = synth.make_state_dict(int(g['W']), int(g['seed']), skip_in=skips)
     np.testing.assert_allclose(synth.state_checksum(sd), g['checksum'], rtol=0, atol=0)
-    assert sd['implicit_network.lin2.weight_v'].shape == (64 - 39, 64) and sd['implicit_network.lin5.weight_v'].shape == (64 - 39, 64)   # out = W - d0 before a skip
+    for sk in skips:                                                                                       # out = W - d0 before a skip
+        assert sd['implicit_network.lin%d.weight_v' % (sk - 1)].shape == (64 - 39, 64 if (sk - 1) not in skips else 64)
+        assert sd['implicit_network.lin%d.weight_v' % sk].shape[1] == 64
     net = ON.sdf_net(sd, skip_in=skips)
     y, n, cache = ON.sdf_forward(net, g['x'])
     np.testing.assert_allclose(y, g['out'], rtol=1e-4, atol=3e-6)
