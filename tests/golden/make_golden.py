@@ -575,3 +575,6 @@ if __name__ == '__main__':
     g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_smooth', (4,), 0.05)
     g_carve(0, True, 'carve_invalid')                                           # conf.use_invalid: carving_t (loss.py:43-44)
     g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_invalid', (4,), None, True)                  # conf.smooth = 0.05: the SmoothL1 depth term (loss.py:57-58), reachable through IDR_CONF
+    g_sdf_bwd(64, 150, 0, (8,), 'sdf_bwd_w64_skip8')                            # a skip connection into the LAST Linear (idr.py:46-49,86)
+    g_sdf_bwd(64, 150, 0, (4, 8), 'sdf_bwd_w64_skips48')
+    g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_skip8', (8,))
