@@ -60,6 +60,11 @@ typedef struct {
                                          * to mode 0 (another summation order).  bias[] is read like in modes 3 / 4 */
     unsigned skip_mask;                 /* several skip connections (skip_in with more than one entry, idr.py:46,86): bit l set = the input of layer l
                                          * is cat([x, PE(x)])/sqrt(2).  0 = use skip_layer alone.  Any layer but layer 0 (the last Linear included). */
+    const void* wx3[MVSDF_MAX_LAYERS];  /* optional: three-term bf16 packs of THIS descriptor's matrices (mvsdf_pack_bf16x3_net for W_l; mvsdf_pack_bf16x3t_net for the
+                                         * transposed descriptor's W_l^T).  When every layer of both descriptors has one, the differentiable passes of the SDF network
+                                         * (mvsdf_sdf_forward / _backward / _backward_pair, the training step) run their fused chains in the three-term fp32 arithmetic
+                                         * on the bf16 matrix cores (csrc/chain_x3.h) instead of the fp32-input MFMA chains; NULL: the fp32 chains.  bias[] is then read
+                                         * like in trace_dtype 3 / 4 / 5 */
 } MvsdfNetDesc;
 
 /* RayTracing constructor arguments (ray_tracing.py:7-25) + the hard-coded dist_clip (ray_tracing.py:127-131). */
@@ -134,6 +139,8 @@ int mvsdf_pack_bf16s_net(int n_layers, const float* const* w, const int* N, cons
 /* trace_dtype = 5: the folded fp32 weights as three bf16 terms (t0 = bf16(w), t1 = bf16(w - t0), t2 = bf16(w - t0 - t1)), layout of mvsdf_pack_bf16s_net
  * with a k-block's three term fragments behind each other; wp16[l]: 3 * mvsdf_packed_bf16_bytes(N, K, 0) bytes.  idr.py:77-94 on the fp32 weights. */
 int mvsdf_pack_bf16x3_net(int n_layers, const float* const* w, const int* N, const int* K, void* const* wp16, void* stream);
+/* the same three-term pack of W_l^T (N, K are W_l's dims): 3 * mvsdf_packed_bf16_bytes(K, N, 0) bytes per layer -- MvsdfNetDesc.wx3 of the transposed descriptor */
+int mvsdf_pack_bf16x3t_net(int n_layers, const float* const* w, const int* N, const int* K, void* const* wx3t, void* stream);
 
 /* ImplicitNetwork.forward(x)[:, 0] (idr.py:77-94) for n points: the tracing MLP alone. */
 int mvsdf_sdf_col0(const MvsdfNetDesc* net, const float* x, int n, float* y, int mt, void* stream);

@@ -14,7 +14,7 @@ _lib = None
 class NetDesc(C.Structure):
     _fields_ = [('n_layers', C.c_int), ('K', C.c_int * MAX_LAYERS), ('N', C.c_int * MAX_LAYERS),
                 ('wp', C.c_void_p * MAX_LAYERS), ('bias', C.c_void_p * MAX_LAYERS), ('w', C.c_void_p * MAX_LAYERS),
-                ('skip_layer', C.c_int), ('multires', C.c_int), ('wp16', C.c_void_p * MAX_LAYERS), ('trace_dtype', C.c_int), ('skip_mask', C.c_uint)]
+                ('skip_layer', C.c_int), ('multires', C.c_int), ('wp16', C.c_void_p * MAX_LAYERS), ('trace_dtype', C.c_int), ('skip_mask', C.c_uint), ('wx3', C.c_void_p * MAX_LAYERS)]
 
 
 class TraceParams(C.Structure):
@@ -59,7 +59,7 @@ def lib():
 
 # every symbol include/mvsdf_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
 EXPORTS = [
-    'mvsdf_version', 'mvsdf_abi_struct_sizes', 'mvsdf_last_error', 'mvsdf_packed_floats', 'mvsdf_fold_pack', 'mvsdf_fold_backward', 'mvsdf_fold_pack_net', 'mvsdf_fold_backward_net', 'mvsdf_packed_bf16_bytes', 'mvsdf_pack_bf16w_net', 'mvsdf_pack_bf16s_net', 'mvsdf_pack_bf16x3_net',
+    'mvsdf_version', 'mvsdf_abi_struct_sizes', 'mvsdf_last_error', 'mvsdf_packed_floats', 'mvsdf_fold_pack', 'mvsdf_fold_backward', 'mvsdf_fold_pack_net', 'mvsdf_fold_backward_net', 'mvsdf_packed_bf16_bytes', 'mvsdf_pack_bf16w_net', 'mvsdf_pack_bf16s_net', 'mvsdf_pack_bf16x3_net', 'mvsdf_pack_bf16x3t_net',
     'mvsdf_sdf_col0', 'mvsdf_camera_rays', 'mvsdf_sphere_intersection', 'mvsdf_trace_workspace_bytes', 'mvsdf_trace_workspace_bytes_n', 'mvsdf_trace', 'mvsdf_trace_stage', 'mvsdf_det_math',
     'mvsdf_tracegen_state_bytes', 'mvsdf_tracegen_init', 'mvsdf_tracegen_step', 'mvsdf_tracegen_finish', 'mvsdf_tracegen_rows', 'mvsdf_tracegen_reduce',
     'mvsdf_tracegen_secant',

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64 * NW) void k_sdf_col0(MvNet net, const float* __
 }
 
 // bf16 packs (tile_engine_bf16.h): one thread per packed element
-struct PackBfArgs { const float* w[MV_MAXL]; uint16_t* wp[MV_MAXL]; int N[MV_MAXL], K[MV_MAXL], nsplit[MV_MAXL]; };
+struct PackBfArgs { const float* w[MV_MAXL]; uint16_t* wp[MV_MAXL]; int N[MV_MAXL], K[MV_MAXL], nsplit[MV_MAXL]; int tr; };   // tr (k_pack_bf16x3_net): pack W^T (N, K stay W's dims)
 __global__ void k_pack_bf16_net(PackBfArgs a) {
     const int l = blockIdx.y;
     const int N = a.N[l], K = a.K[l], ns = a.nsplit[l], KB = mv_bf_kb(K, ns);
@@ -255,7 +255,7 @@ __global__ void k_pack_bf16_net(PackBfArgs a) {
 // trace_dtype = 5: the packs of tile_engine_bf16s.h's weight-term engine: w = t0 + t1 + t2 exactly, wp[((ct * KB + kb) * 3 + term) * 64 + lane][8]
 __global__ void k_pack_bf16x3_net(PackBfArgs a) {
     const int l = blockIdx.y;
-    const int N = a.N[l], K = a.K[l], KB = mv_bf_kb(K, 0);
+    const int N = a.tr ? a.K[l] : a.N[l], K = a.tr ? a.N[l] : a.K[l], KB = mv_bf_kb(K, 0);      // dims of the matrix being packed (W or W^T)
     const size_t total = 3 * mv_packed_bf16_elems(N, K, 0);
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int i = idx & 7, lane = (idx >> 3) & 63;
@@ -264,7 +264,7 @@ __global__ void k_pack_bf16x3_net(PackBfArgs a) {
         const int o = ct * 16 + (lane & 15), kp = kb * 32 + 8 * (lane >> 4) + i;
         uint16_t v = 0;
         if (o < N && kp < K) {
-            float r = a.w[l][(size_t)o * K + kp];
+            float r = a.tr ? a.w[l][(size_t)kp * N + o] : a.w[l][(size_t)o * K + kp];
             if (fabsf(r) < 9.094947017729282e-13f) r = 0.0f;                            // |w| < 2^-40 -> 0 (tile_engine_bf16s.h, MV_X3_FLUSH: the oracle does the same)
             v = mv_f2bf(r);
             for (int t = 0; t < term; ++t) { r = r - mv_bf2f(v); v = mv_f2bf(r); }       // every subtraction is exact
@@ -480,20 +480,28 @@ int mvsdf_pack_bf16s_net(int n_layers, const float* const* w, const int* N, cons
 }
 
 /* trace_dtype = 5: three-term bf16 packs of the fp32 weights (3 x mvsdf_packed_bf16_bytes(N, K, 0) bytes per layer) */
-int mvsdf_pack_bf16x3_net(int n_layers, const float* const* w, const int* N, const int* K, void* const* wp16, void* stream) {
-    if (n_layers < 1 || n_layers > MV_MAXL || !w || !N || !K || !wp16) return mv_fail(-1, "mvsdf_pack_bf16x3_net: bad arguments");
+static int pack_x3_net(int n_layers, const float* const* w, const int* N, const int* K, void* const* out, int tr, void* stream) {
+    if (n_layers < 1 || n_layers > MV_MAXL || !w || !N || !K || !out) return mv_fail(-1, "mvsdf_pack_bf16x3_net / mvsdf_pack_bf16x3t_net: bad arguments");
     PackBfArgs a;
     memset(&a, 0, sizeof(a));
+    a.tr = tr;
     size_t maxTot = 0;
     for (int l = 0; l < n_layers; ++l) {
-        if (!w[l] || !wp16[l] || N[l] <= 0 || K[l] <= 0) return mv_fail(-1, "mvsdf_pack_bf16x3_net: null layer pointer / bad dims");
-        a.w[l] = w[l]; a.wp[l] = (uint16_t*)wp16[l]; a.N[l] = N[l]; a.K[l] = K[l]; a.nsplit[l] = 0;
-        const size_t t = 3 * mv_packed_bf16_elems(N[l], K[l], 0);
+        if (!w[l] || !out[l] || N[l] <= 0 || K[l] <= 0) return mv_fail(-1, "mvsdf_pack_bf16x3_net / mvsdf_pack_bf16x3t_net: null layer pointer / bad dims");
+        a.w[l] = w[l]; a.wp[l] = (uint16_t*)out[l]; a.N[l] = N[l]; a.K[l] = K[l]; a.nsplit[l] = 0;
+        const size_t t = 3 * (tr ? mv_packed_bf16_elems(K[l], N[l], 0) : mv_packed_bf16_elems(N[l], K[l], 0));
         if (t > maxTot) maxTot = t;
     }
     const int blocks = (int)((maxTot + 255) / 256 < 512 ? (maxTot + 255) / 256 : 512);
     hipLaunchKernelGGL(k_pack_bf16x3_net, dim3(blocks, n_layers), dim3(256), 0, (hipStream_t)stream, a);
     return mv_check(hipGetLastError(), "mvsdf_pack_bf16x3_net");
+}
+int mvsdf_pack_bf16x3_net(int n_layers, const float* const* w, const int* N, const int* K, void* const* wp16, void* stream) {
+    return pack_x3_net(n_layers, w, N, K, wp16, 0, stream);
+}
+/* the same pack of W^T (N, K: W's dims; 3 x mvsdf_packed_bf16_bytes(K, N, 0) bytes per layer): MvsdfNetDesc.wx3 of the transposed descriptor */
+int mvsdf_pack_bf16x3t_net(int n_layers, const float* const* w, const int* N, const int* K, void* const* wx3t, void* stream) {
+    return pack_x3_net(n_layers, w, N, K, wx3t, 1, stream);
 }
 
 int mvsdf_pack_bf16w_net(int n_layers, const float* const* w, const int* N, const int* K, float* const* wp_rounded, void* stream) {

@@ -25,6 +25,7 @@ int mv_check(hipError_t e, const char* where);   // 0 on success
 int mv_make_net_mode(const MvsdfNetDesc* d, MvNet* net, int mode);
 static inline int mv_make_net(const MvsdfNetDesc* d, MvNet* net) { return mv_make_net_mode(d, net, 0); }
 int mv_make_net_bs(const MvsdfNetDesc* d, MvNetBf* net, int ns); // SDF net on the bf16 packs without duplicated columns, activations as ns bf16 terms (trace_dtype 3 / 4; net = an MvNetBs<ns>)
+int mv_make_net_x3(const MvsdfNetDesc* d, MvNetBf* net);        // the three-term packs d->wx3 of the differentiable chains (chain_x3.h); 1: a layer has none (-> the fp32 chains)
 int mv_make_net_trace(const MvsdfNetDesc* d, MvNet* net);     // the fp32-engine tracing net: the fp32 packs, or (trace_dtype == 2) the fp32 packs of the bf16-rounded weights
 // skip layers of a descriptor as a bit mask (skip_mask wins; else the single skip_layer)
 static inline unsigned mv_desc_skip_mask(const MvsdfNetDesc* d) { return d->skip_mask ? d->skip_mask : (d->skip_layer >= 0 ? 1u << d->skip_layer : 0u); }

@@ -57,6 +57,25 @@ int mv_make_net_trace(const MvsdfNetDesc* d, MvNet* net) {
     return mv_make_net(&r, net);
 }
 
+int mv_make_net_x3(const MvsdfNetDesc* d, MvNetBf* net) {
+    if (!d || d->n_layers < 2 || d->n_layers > MV_MAXL) return 1;
+    memset(net, 0, sizeof(*net));
+    int maxkb = 0;
+    for (int l = 0; l < d->n_layers; ++l) {
+        if (!d->wx3[l] || !d->bias[l]) return 1;
+        MvLayerBf& L = net->L[l];
+        L.wp = (const uint4*)d->wx3[l];
+        L.bias = d->bias[l];
+        L.K = d->K[l]; L.N = d->N[l];
+        L.nsplit = 0;
+        L.KB = mv_bf_kb(L.K, 0); L.NT = mv_ceil16(L.N) / 16;
+        if (L.KB > maxkb) maxkb = L.KB;
+    }
+    net->n_layers = d->n_layers; net->skip_mask = mv_desc_skip_mask(d); net->multires = d->multires;
+    net->S = 32 * maxkb + 8;                                       // bf16 elements per LDS row of one term tile (64 KB + 16 bytes: conflict-free b128 reads)
+    return 0;
+}
+
 int mv_make_net_bs(const MvsdfNetDesc* d, MvNetBf* net, int ns) {
     MvNet chk;
     int rc = mv_make_net_mode(d, &chk, 0);

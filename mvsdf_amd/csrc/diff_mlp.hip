@@ -4,6 +4,7 @@
 // torch.autograd does behind loss.backward() for both (idr_train.py:287).
 #include <stdlib.h>
 #include "layer_kernels.h"
+#include "chain_x3.h"
 #include "capi_util.h"
 #include "step_internal.h"
 
@@ -287,6 +288,31 @@ int mv_chain_split_pays(const MvsdfNetDesc* d, int E, int M) {
     return cost((M - E + 15) / 16) < cost((M + 15) / 16) ? 1 : 0;
 }
 
+// The fused chains in the three-term bf16 arithmetic (chain_x3.h) run when both descriptors carry the packs (MvsdfNetDesc.wx3); the dev library's
+// MVSDF_CHAIN_X3=0 keeps the fp32-input MFMA chains (A/B, tests/test_gpu_alt_paths.py).
+static bool mv_chain_x3_on() {
+    static const int env = [] { const char* e = mv_dev_env("MVSDF_CHAIN_X3"); return e ? atoi(e) : 1; }();
+    return env != 0;
+}
+// -> 0 and both nets when the x3 chains can run this network (needT: the transposed packs too)
+static int mv_x3_nets(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, bool needT, MvNetBf* xn, MvNetBf* xnT) {
+    if (!mv_chain_x3_on() || mv_make_net_x3(d, xn)) return 1;
+    if (needT) { if (!dT || mv_make_net_x3(dT, xnT)) return 1; }
+    else *xnT = *xn;
+    xnT->skip_mask = xn->skip_mask; xnT->multires = xn->multires;
+    const int S16 = xn->S > xnT->S ? xn->S : xnT->S;
+    xn->S = xnT->S = S16;
+    return 0;
+}
+// row tiles per workgroup of the x3 chains: two tiles share the weight stream that bounds a phase (tile_engine_bf16s.h: 56 vs 41 us per evaluation), so
+// they pay as soon as they save a round of the 256 CUs
+static int mv_chain_mt_x3(int tiles16) {
+    static const int env = [] { const char* e = mv_dev_env("MVSDF_CHAIN_MT"); return e ? atoi(e) : 0; }();
+    if (env == 1 || env == 2) return env;
+    const int rounds1 = (tiles16 + 255) / 256, rounds2 = (tiles16 + 511) / 512;
+    return 1.45 * rounds2 < rounds1 ? 2 : 1;
+}
+
 #define MV_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mv_check(e_, #expr); } while (0)
 
 extern "C" {
@@ -336,6 +362,30 @@ int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const f
     static int fuse_fwd = -1;
     if (fuse_fwd < 0) { const char* e = mv_dev_env("MVSDF_FUSE"); fuse_fwd = e ? atoi(e) : 1; }
     const int ntw_f = mv_chain_ntw(net);
+    MvNetBf xn, xnT;
+    if (fuse_fwd && ntw_f && nl >= 2 && net.L[nl - 1].NT <= 8 * ntw_f * 4 && !mv_x3_nets(d, dT, Mg > 0, &xn, &xnT)) {   // ... in the three-term bf16 arithmetic
+        FwdArgsX3 f;
+        memset(&f, 0, sizeof(f));
+        f.net = xn; f.netT = xnT;
+        const int Mr = r_end - r_begin;
+        f.S = xn.S; f.M = r_end; f.Mg = Mg < r_end ? Mg : r_end; f.row_base = r_begin; f.ld0 = lo.ld0; f.x = x; f.H0 = H0;
+        for (int l = 1; l < nl; ++l) f.A[l] = ctx + lo.A[l];
+        for (int l = 0; l < nl - 1; ++l) { f.Z[l] = ctx + lo.Z[l]; f.Sg[l] = ctx + lo.Sg[l]; }
+        for (int l = 1; l < nl - 1; ++l) f.U[l] = ctx + lo.U[l];
+        f.G0 = ctx + lo.G0; f.y = y; f.ldy = net.L[nl - 1].N; f.w_last_row0 = d->w[nl - 1]; f.nrm = nrm;
+        if (g) f.g = *g;
+        const int mt = ntw_f == 2 ? mv_chain_mt_x3((Mr + 15) / 16) : 1;
+        const size_t lds = (size_t)3 * 16 * mt * xn.S * 2 + ((size_t)2 * ((16 * mt * lo.d0 + 3) & ~3) + 16 * mt * 4) * sizeof(float);
+        const dim3 grid((Mr + 16 * mt - 1) / (16 * mt));
+        // hidden width <= 256: 16 waves x 1 column tile; up to 512: 16 waves x 2 tiles
+        if (mt == 2) {
+            MV_TRY(hipFuncSetAttribute((const void*)k_chain_fwd_x3<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_chain_fwd_x3<2, 1, 16>), grid, dim3(1024), lds, s, f);
+        }
+        else if (ntw_f == 2) hipLaunchKernelGGL((k_chain_fwd_x3<1, 1, 16>), grid, dim3(1024), lds, s, f);
+        else hipLaunchKernelGGL((k_chain_fwd_x3<1, 2, 16>), grid, dim3(1024), lds, s, f);
+        return mv_check(hipGetLastError(), "mvsdf_sdf_forward (x3 chain)");
+    }
     if (fuse_fwd && ntw_f && net.L[nl - 1].NT <= 8 * ntw_f * 4) {                  // value + normal of a row tile in one launch
         FwdArgs f;
         memset(&f, 0, sizeof(f));
@@ -447,7 +497,27 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
     if (fuse_all < 0) { const char* e = mv_dev_env("MVSDF_FUSE"); fuse_all = e ? atoi(e) : 1; if (mv_dev_env("MVSDF_SPLIT_CHAINS")) fuse_all = 0; }
     const int ntw_b = mv_chain_ntw(net);
     bool chains_done = false;
-    if (fuse_all >= 1 && ntw_b) {                               // MVSDF_SPLIT_CHAINS=1: the separate E.1 / E.2 launches (dev A/B)
+    MvNetBf xn, xnT;
+    if (fuse_all >= 1 && ntw_b && nl >= 2 && !mv_x3_nets(d, dT, true, &xn, &xnT)) {     // the whole pass in the three-term bf16 arithmetic (chain_x3.h)
+        ChainArgsX3 c;
+        memset(&c, 0, sizeof(c));
+        c.net = xn; c.netT = xnT; c.S = xn.S; c.M = Mb; c.row_ld0 = lo.ld0;
+        c.dy = dy; c.ld_dy = net.L[nl - 1].N; c.w_last_row0 = w8;
+        for (int l = 0; l < nl - 1; ++l) {
+            c.Z[l] = Zof(l); c.ZB[l] = ws + bl.ZB[l];
+            c.ZB2[l] = dn ? ws + bl.ZB2[l] : nullptr; c.ZB2o[l] = ws + bl.ZB2[l];
+            if (l + 1 < nl - 1) c.U[l + 1] = Uof(l + 1);
+            c.VB[l + 1] = ws + bl.VB[l + 1];
+        }
+        c.H0B = ws + bl.H0B; c.H0 = H0; c.G0 = G0; c.dn_in = dn; c.VB0w = ws + bl.VB[0]; c.dx = dx;
+        const size_t lds = (size_t)3 * 16 * xn.S * 2 + (size_t)16 * lo.d0 * sizeof(float);
+        const dim3 grid((Mb + 15) / 16);
+        if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd_x3<1, 1, 16>), grid, dim3(1024), lds, s, c);
+        else hipLaunchKernelGGL((k_chain_bwd_x3<1, 2, 16>), grid, dim3(1024), lds, s, c);
+        MV_TRY(hipGetLastError());
+        chains_done = true;
+    }
+    else if (fuse_all >= 1 && ntw_b) {                          // MVSDF_SPLIT_CHAINS=1: the separate E.1 / E.2 launches (dev A/B)
         ChainArgs c;
         memset(&c, 0, sizeof(c));
         c.net = net; c.netT = netT; c.S = S; c.M = Mb; c.row_ld0 = lo.ld0;
@@ -587,14 +657,17 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
     return mv_check(hipGetLastError(), "mvsdf_sdf_backward");
 }
 
+}  // extern "C"
+
 // ---- the training step's SDF backward as two launches of chain passes instead of three sequential ones (functional._IdrStep.backward) ----
 // fill the arguments of one fused chain pass over rows [row0, row0 + Mb) of a forward context
-static void fill_chain_args(ChainArgs& c, const MvNet& net, const MvNet& netT, int S, const SdfLayout& lo, const SdfBwdLayout& bl, const float* ctx,
+template <class NETX>
+static void fill_chain_args(ChainArgsT<NETX>& c, const MvNet& net, const NETX& xnet, const NETX& xnetT, int S, const SdfLayout& lo, const SdfBwdLayout& bl, const float* ctx,
                             int row0, int Mb, const float* dy, const float* dn, float* ws, float* dx, const float* w8) {
     memset(&c, 0, sizeof(c));
     const int nl = lo.nl;
     const size_t r0 = (size_t)row0;
-    c.net = net; c.netT = netT; c.S = S; c.M = Mb; c.row_ld0 = lo.ld0;
+    c.net = xnet; c.netT = xnetT; c.S = S; c.M = Mb; c.row_ld0 = lo.ld0;
     c.dy = dy; c.ld_dy = net.L[nl - 1].N; c.w_last_row0 = w8;
     for (int l = 0; l < nl - 1; ++l) {
         c.Z[l] = ctx + lo.Z[l] + r0 * net.L[l].N; c.ZB[l] = ws + bl.ZB[l];
@@ -604,6 +677,8 @@ static void fill_chain_args(ChainArgs& c, const MvNet& net, const MvNet& netT, i
     }
     c.H0B = ws + bl.H0B; c.H0 = ctx + lo.H0 + r0 * lo.ld0; c.G0 = ctx + lo.G0 + r0 * lo.ld0; c.dn_in = dn; c.VB0w = ws + bl.VB[0]; c.dx = dx;
 }
+
+extern "C" {
 
 /* Pass A: full first/second-order backward over rows [0, MbA) with upstream (dyA, dnA); keeps every per-layer adjoint in wsA
  * (mvsdf_sdf_bwd_ws_floats(net, MbA) floats) for mvsdf_sdf_backward_finish -- no weight gradients yet.
@@ -626,9 +701,26 @@ int mvsdf_sdf_backward_pair(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M
     hipStream_t s = (hipStream_t)stream;
     const SdfLayout lo = sdf_ctx_layout(net, M, Mg);
     const int S = stride_for(net, netT);
+    MvNetBf xn, xnT;
+    if (net.n_layers >= 2 && !mv_x3_nets(d, dT, true, &xn, &xnT)) {                 // both passes in the three-term bf16 arithmetic (chain_x3.h)
+        ChainArgsX3 a, b;
+        fill_chain_args(a, net, xn, xnT, xn.S, lo, sdf_bwd_layout(net, MbA), ctx, 0, MbA, dyA, dnA, wsA, nullptr, w8);
+        fill_chain_args(b, net, xn, xnT, xn.S, lo, sdf_bwd_layout(net, MbX), ctx, row0X, MbX, dyX, dnX, wsX, dx, w8);
+        const int mt = ntw_b == 2 ? mv_chain_mt_x3((MbA + 15) / 16 + (MbX + 15) / 16) : 1;
+        const size_t lds = (size_t)3 * 16 * mt * xn.S * 2 + (size_t)16 * mt * lo.d0 * sizeof(float);
+        const int na = (MbA + 16 * mt - 1) / (16 * mt), nb = (MbX + 16 * mt - 1) / (16 * mt);
+        const dim3 grid(na + nb);
+        if (mt == 2) {
+            MV_TRY(hipFuncSetAttribute((const void*)k_chain_bwd2_x3<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_chain_bwd2_x3<2, 1, 16>), grid, dim3(1024), lds, s, a, b, na);
+        }
+        else if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd2_x3<1, 1, 16>), grid, dim3(1024), lds, s, a, b, na);
+        else hipLaunchKernelGGL((k_chain_bwd2_x3<1, 2, 16>), grid, dim3(1024), lds, s, a, b, na);
+        return mv_check(hipGetLastError(), "mvsdf_sdf_backward_pair (x3 chains)");
+    }
     ChainArgs a, b;
-    fill_chain_args(a, net, netT, S, lo, sdf_bwd_layout(net, MbA), ctx, 0, MbA, dyA, dnA, wsA, nullptr, w8);
-    fill_chain_args(b, net, netT, S, lo, sdf_bwd_layout(net, MbX), ctx, row0X, MbX, dyX, dnX, wsX, dx, w8);
+    fill_chain_args(a, net, net, netT, S, lo, sdf_bwd_layout(net, MbA), ctx, 0, MbA, dyA, dnA, wsA, nullptr, w8);
+    fill_chain_args(b, net, net, netT, S, lo, sdf_bwd_layout(net, MbX), ctx, row0X, MbX, dyX, dnX, wsX, dx, w8);
     const bool w8w = mv_chain_w8();
     const int mt = (ntw_b == 2 && !w8w) ? mv_chain_mt((MbA + 15) / 16 + (MbX + 15) / 16) : 1;
     const size_t lds = (size_t)16 * mt * (S + lo.d0) * sizeof(float);

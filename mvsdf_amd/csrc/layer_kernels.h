@@ -493,9 +493,10 @@ __global__ void k_colsum(const float* __restrict__ X, int ld, int M, int n, int 
 // ---------------------------------------------------------------------------------------------------------------
 // Fused chains: all layers of one backward chain in ONE launch, the running activation tile never leaves LDS.
 // 16*MT rows per workgroup, NW waves.  Same arithmetic as the per-layer kernels (k_layer) they replace.
-struct ChainArgs {
-    MvNet net;                 // packs of W_l   (E.1)
-    MvNet netT;                // packs of W_l^T (E.2)
+template <class NET>
+struct ChainArgsT {
+    NET net;                   // packs of W_l   (E.1)
+    NET netT;                  // packs of W_l^T (E.2)
     int S, M, row_ld0;         // LDS stride; rows; padded PE row length (ld0)
     const float* dy; int ld_dy;                // E.2: upstream of the outputs [M][Nout]
     const float* Z[MV_MAXL]; const float* U[MV_MAXL];       // forward context (already offset to the first row): Z_l [M][N_l], u_l [M][N_{l-1}]
@@ -515,6 +516,7 @@ struct ChainArgs {
     const float* dy_col0;                      // [M] (null: the full dy)
     int accum;                                 // 1: ZB[l] += zbar_l (H0B may be null: not written)
 };
+typedef ChainArgsT<MvNet> ChainArgs;           // (ChainArgsT<MvNetBf>: the three-term bf16 chains of chain_x3.h)
 
 // E.2 (descending): hb_L = dy W_L;  for l = L-1..0: zb_l = sigma_l . hb_{l+1} + zb2_l (stored), ab_l = zb_l W_l, split at the skip layer.
 template <int MT, int NTW, int NW>
@@ -928,8 +930,9 @@ __global__ __launch_bounds__(64 * NW) void k_chain_bwd2(ChainArgs a, ChainArgs b
 //   normal (descending, idr.py:96-107 = VJP of output 0): u_L = W_L[0,:]; s_l = sigma(100 z_l) . u_{l+1}; u_l = s_l W_l (split and
 //           /sqrt2 at the skip layer); g_0 = u_0 (+ PE part of the skip layer); n = J_PE^T g_0; stores Sg_l, U_l, G0, n.
 // The running activation / adjoint tile never leaves LDS.  Same arithmetic as the per-layer kernels it replaces.
-struct FwdArgs {
-    MvNet net, netT;
+template <class NET>
+struct FwdArgsT {
+    NET net, netT;
     int S, M, Mg, ld0;                         // M / Mg: END of the rows this launch evaluates / gives normals to ...
     int row_base;                              // ... which start at row_base (workgroup b owns the rows row_base + 16 MT b ..)
     const float* x;                            // [M][3]
@@ -942,6 +945,7 @@ struct FwdArgs {
     float* nrm;                                // [Mg][3]
     FwdGather g;                               // g.pts != null: x is gathered (x is ignored)
 };
+typedef FwdArgsT<MvNet> FwdArgs;
 
 template <int MT, int NTW, int NW>
 __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {

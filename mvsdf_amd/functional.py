@@ -122,7 +122,7 @@ def fold_networks_flat(specs, cache):
     flat = _FoldNetFlat.apply(plan, layers, *vs_all, *gs_all, *bs_all)
     nets, lo = [], 0
     for (vs, gs, bs, skip_layer, multires), hi in zip(specs, cuts):
-        nets.append(ops.PackedNet(layers[lo:hi], skip_layer, multires))
+        nets.append(ops.maybe_pack_x3_chain(ops.PackedNet(layers[lo:hi], skip_layer, multires)))
         lo = hi
     for net in nets:
         net._keep = flat                                         # raw pointers into `flat` / its packs: keep them alive with the net
@@ -146,7 +146,7 @@ def fold_networks(specs):
     out = _FoldNet.apply(layers, *vs_all, *gs_all, *bs_all)
     res, lo = [], 0
     for (vs, gs, bs, skip_layer, multires), hi in zip(specs, cuts):
-        res.append((ops.PackedNet(layers[lo:hi], skip_layer, multires), list(out[lo:hi]), list(out[n + lo:n + hi])))
+        res.append((ops.maybe_pack_x3_chain(ops.PackedNet(layers[lo:hi], skip_layer, multires)), list(out[lo:hi]), list(out[n + lo:n + hi])))
         lo = hi
     return res
 
@@ -162,7 +162,7 @@ def fold_network(vs, gs, bs, skip_layer, multires):
         layers.append(L)
     n = len(vs)
     out = _FoldNet.apply(layers, *vs, *gs, *bs)
-    return ops.PackedNet(layers, skip_layer, multires), list(out[:n]), list(out[n:])
+    return ops.maybe_pack_x3_chain(ops.PackedNet(layers, skip_layer, multires)), list(out[:n]), list(out[n:])
 
 
 class SharedSdfEval:

@@ -13,7 +13,7 @@ def _f32(t):
 
 
 class PackedLayer:
-    __slots__ = ('w', 'wp', 'wpT', 'bias', 'K', 'N', 'wp16', 'wp_ptr', 'wpT_ptr', 'w_ptr', 'keep')
+    __slots__ = ('w', 'wp', 'wpT', 'bias', 'K', 'N', 'wp16', 'wp_ptr', 'wpT_ptr', 'w_ptr', 'keep', 'wx3', 'wx3T')
 
 
 class PackedNet:
@@ -43,6 +43,10 @@ class PackedNet:
         d.skip_layer, d.multires = self.skip_layer, self.multires
         if len(self.skip_layers) > 1 and not transposed:
             d.skip_mask = sum(1 << s for s in self.skip_layers)
+        for i, L in enumerate(self.layers):                     # three-term packs of W_l / W_l^T: the differentiable chains on the bf16 matrix cores (csrc/chain_x3.h)
+            x3 = getattr(L, 'wx3T' if transposed else 'wx3', None)
+            if x3 is not None:
+                d.wx3[i] = x3 if isinstance(x3, int) else x3.data_ptr()
         if not transposed and self.trace_dtype in (1, 2, 3, 4, 5):
             for i, L in enumerate(self.layers):
                 d.wp16[i] = L.wp16.data_ptr()
@@ -210,7 +214,28 @@ def fold_backward_net(vs, gs, dWs, dbs=None, sinks=None):
     return dvs, [g.reshape(-1, 1) if g is not None else None for g in dgs]
 
 
-def pack_net(vs, gs, biases, skip_layer, multires, want_t=True):
+CHAIN_X3 = True          # SDF networks get the three-term packs of W_l and W_l^T: their differentiable chains run on the bf16 matrix cores (csrc/chain_x3.h)
+
+
+def pack_x3_chain(net):
+    """Three-term bf16 packs of every W_l and W_l^T of a folded SDF network (MvsdfNetDesc.wx3 of both descriptors)."""
+    n = len(net.layers)
+    dev = net.layers[0].bias.device
+    N = (C.c_int * n)(*[L.N for L in net.layers])
+    K = (C.c_int * n)(*[L.K for L in net.layers])
+    ws = _int_ptr_array([L.w.data_ptr() if L.w is not None else L.w_ptr for L in net.layers])
+    for L in net.layers:
+        L.wx3 = torch.empty(3 * lib().mvsdf_packed_bf16_bytes(L.N, L.K, 0), dtype=torch.uint8, device=dev)
+        L.wx3T = torch.empty(3 * lib().mvsdf_packed_bf16_bytes(L.K, L.N, 0), dtype=torch.uint8, device=dev)
+    s = stream_of(net.layers[0].bias)
+    check(lib().mvsdf_pack_bf16x3_net(n, ws, N, K, _ptr_array([L.wx3 for L in net.layers]), s), 'mvsdf_pack_bf16x3_net')
+    check(lib().mvsdf_pack_bf16x3t_net(n, ws, N, K, _ptr_array([L.wx3T for L in net.layers]), s), 'mvsdf_pack_bf16x3t_net')
+    net.__dict__.pop('_d', None)
+    net.__dict__.pop('_dT', None)
+    return net
+
+
+def pack_net(vs, gs, biases, skip_layer, multires, want_t=True, x3=None):
     layers = []
     for v, g, b in zip(vs, gs, biases):
         L = PackedLayer()
@@ -218,8 +243,19 @@ def pack_net(vs, gs, biases, skip_layer, multires, want_t=True):
         L.bias = _f32(b)
         L.N, L.K = v.shape
         L.wp16 = None
+        L.wx3 = L.wx3T = None
         layers.append(L)
-    return PackedNet(layers, skip_layer, multires)
+    net = PackedNet(layers, skip_layer, multires)
+    if (CHAIN_X3 if x3 is None else x3) and want_t:
+        maybe_pack_x3_chain(net)
+    return net
+
+
+def maybe_pack_x3_chain(net):
+    """pack_x3_chain for SDF networks (first Linear over the positional encoding of a 3-D point); the rendering network's chains stay on the fp32-input MFMA."""
+    if CHAIN_X3 and len(net.layers) >= 2 and net.layers[0].K == 3 + 6 * max(net.multires, 0):
+        pack_x3_chain(net)
+    return net
 
 
 TRACE_DTYPES = {'f32': 0, 'bf16w': 2, 'bf16x2': 3, 'bf16x3': 4, 'f32x3': 5}      # (1, 'bf16' -- 8-bit activations too -- was removed in round 5: 'bf16x2' dominates it)
