@@ -578,7 +578,8 @@ int mvsdf_det_math(int op, const float* x, int n, float* y0, float* y1, void* st
 struct ProloArgs {
     FoldNetArgs f;
     int blk0[MV_FOLD_MAXL + 1];          // first workgroup of each layer; blk0[n_layers] = first ray workgroup
-    uint16_t* wp16[MV_FOLD_MAXL]; int nsplit[MV_FOLD_MAXL];
+ uint16_t* wp16[MV_FOLD_MAXL]; int nsplit[MV_FOLD_MAXL];
+    uint16_t* wx3[MV_FOLD_MAXL]; uint16_t* wx3T[MV_FOLD_MAXL];   // optional three-term bf16 packs of W_l / W_l^T (the differentiable chains of chain_x3.h)
     int wp16_mode;                       // 0: bf16 pack; 1: wp16[l] receives the fp32 pack of the bf16-rounded weights (trace_dtype = 2); 2: the three-term bf16 pack (trace_dtype = 5)
     const float* uv; const float* pose; const float* Kin; int B, P; float* dirs; float* cam_loc;
     uint8_t* ones;                       // optional [B * P]: filled with 1 (the all-ones object mask of the output dict, idr.py:187)
@@ -728,7 +729,48 @@ __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
             }
             dst[idx] = v;
         }
-    } else if (a.wp16[l] && rg < NT) {
+    }
+    if (a.wx3[l] && rg < NT) {                                                  // three bf16 terms of every weight (k_pack_bf16x3_net's layout) for the differentiable chains
+        const int KB32 = mv_bf_kb(K, 0);
+        uint16_t* dst = a.wx3[l] + (size_t)rg * KB32 * 3 * 512;
+        for (int idx = tid; idx < KB32 * 3 * 512; idx += 1024) {
+            const int i = idx & 7, ln = (idx >> 3) & 63, blk = idx >> 9, term = blk % 3, kb = blk / 3;
+            const int ol = ln & 15, kp = kb * 32 + 8 * (ln >> 4) + i;
+            uint16_t v = 0;
+            if (16 * rg + ol < N && kp < K) {
+                float r = tile[ol * ld + kp];
+                if (fabsf(r) < 9.094947017729282e-13f) r = 0.0f;
+                v = mv_f2bf(r);
+                for (int t = 0; t < term; ++t) { r = r - mv_bf2f(v); v = mv_f2bf(r); }
+            }
+            dst[idx] = v;
+        }
+    }
+    if (a.wx3T[l]) {                                                            // ... and of W^T: this workgroup's 16 rows of W are half a k-block of every column tile
+        const int NTt = mv_ceil16(K) / 16, KBt = mv_bf_kb(N, 0);
+        const int kbt = rg >> 1, qh = 2 * (rg & 1);                             // k-block of W^T, lane quarter (lane >> 4) of the first 8 of the 16 rows
+        for (int g = tid; g < NTt * 3 * 32; g += 1024) {                        // one 16-byte group (8 consecutive k of one lane) per iteration
+            const int jh = g & 1, rl = (g >> 1) & 15, term = (g >> 5) % 3, ct = (g >> 5) / 3;
+            const int o = ct * 16 + rl;                                         // column of W = row of W^T
+            uint16_t v8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint16_t v = 0;
+                if (o < K) {                                                    // (rows >= N are zero in the tile)
+                    float r = tile[(8 * jh + i) * ld + o];
+                    if (fabsf(r) < 9.094947017729282e-13f) r = 0.0f;
+                    v = mv_f2bf(r);
+                    for (int t = 0; t < term; ++t) { r = r - mv_bf2f(v); v = mv_f2bf(r); }
+                }
+                v8[i] = v;
+            }
+            const int ln = 16 * (qh + jh) + rl;
+            uint4 pk;
+            pk.x = v8[0] | ((uint32_t)v8[1] << 16); pk.y = v8[2] | ((uint32_t)v8[3] << 16); pk.z = v8[4] | ((uint32_t)v8[5] << 16); pk.w = v8[6] | ((uint32_t)v8[7] << 16);
+            if (kbt < KBt) *(uint4*)(a.wx3T[l] + ((((size_t)ct * KBt + kbt) * 3 + term) * 64 + ln) * 8) = pk;
+        }
+    }
+    if (a.wp16[l] && rg < NT && a.wp16_mode != 1 && a.wp16_mode != 2) {
         const int ns = a.nsplit[l], KB32 = mv_bf_kb(K, ns);
         uint16_t* dst = a.wp16[l] + (size_t)rg * KB32 * 512;
         for (int idx = tid; idx < KB32 * 512; idx += 1024) {
@@ -741,7 +783,8 @@ __global__ __launch_bounds__(1024) void k_step_prologue(ProloArgs a) {
 }
 
 int mv_step_prologue(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w, float* const* wp,
-                     float* const* wpT, void* const* wp16, const int* nsplit, int wp16_mode, const float* uv, const float* pose, const float* intrinsics, int B, int P,
+                     float* const* wpT, void* const* wp16, const int* nsplit, int wp16_mode, void* const* wx3, void* const* wx3T, const float* uv, const float* pose,
+                     const float* intrinsics, int B, int P,
                      float* ray_dirs, float* cam_loc, uint8_t* ones, unsigned long long* counters, const float* stage_src, float* stage_a, int stage_na,
                      float* stage_b, int stage_nb, void* stream) {
     ProloArgs a;
@@ -754,10 +797,11 @@ int mv_step_prologue(int n_layers, const float* const* v, const float* const* g,
         if (!v[l] || !w[l] || !wp[l] || !wpT[l]) return mv_fail(-1, "mv_step_prologue: null layer pointer");
         a.f.v[l] = v[l]; a.f.g[l] = g[l]; a.f.w[l] = w[l]; a.f.wp[l] = wp[l]; a.f.wpT[l] = wpT[l];
         a.wp16[l] = wp16 ? (uint16_t*)wp16[l] : nullptr; a.nsplit[l] = nsplit ? nsplit[l] : 0;
+        a.wx3[l] = wx3 ? (uint16_t*)wx3[l] : nullptr; a.wx3T[l] = wx3T ? (uint16_t*)wx3T[l] : nullptr;
         a.blk0[l] = blk; blk += mv_kpad(N[l]) / 16;                              // row groups incl. the W^T pack's zero padding (N padded to 32)
         if (K[l] > maxK) maxK = K[l];
     }
-    for (int l = n_layers; l < MV_FOLD_MAXL; ++l) { a.wp16[l] = nullptr; a.nsplit[l] = 0; a.blk0[l] = blk; }
+    for (int l = n_layers; l < MV_FOLD_MAXL; ++l) { a.wp16[l] = nullptr; a.wx3[l] = a.wx3T[l] = nullptr; a.nsplit[l] = 0; a.blk0[l] = blk; }
     a.blk0[n_layers] = blk;
     a.uv = uv; a.pose = pose; a.Kin = intrinsics; a.B = B; a.P = P; a.dirs = ray_dirs; a.cam_loc = cam_loc;
     a.wp16_mode = wp16_mode;

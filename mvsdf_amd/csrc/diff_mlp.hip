@@ -294,6 +294,7 @@ static bool mv_chain_x3_on() {
     static const int env = [] { const char* e = mv_dev_env("MVSDF_CHAIN_X3"); return e ? atoi(e) : 1; }();
     return env != 0;
 }
+int mv_chain_x3_enabled() { return mv_chain_x3_on() ? 1 : 0; }
 // -> 0 and both nets when the x3 chains can run this network (needT: the transposed packs too)
 static int mv_x3_nets(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, bool needT, MvNetBf* xn, MvNetBf* xnT) {
     if (!mv_chain_x3_on() || mv_make_net_x3(d, xn)) return 1;

@@ -18,6 +18,8 @@ inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct FwdOffsets {
     size_t w[MVSDF_STEP_MAX_LAYERS], wp[MVSDF_STEP_MAX_LAYERS], wpT[MVSDF_STEP_MAX_LAYERS], wp16[MVSDF_STEP_MAX_LAYERS];
+    size_t wx3[MVSDF_STEP_MAX_LAYERS], wx3T[MVSDF_STEP_MAX_LAYERS];   // SDF layers: three-term bf16 packs of W_l / W_l^T for the differentiable chains (chain_x3.h); wx3 == wp16 under trace_dtype 5
+    int chain_x3;
     size_t trace_ws, trace_ws_bytes;
     size_t inv, true_rows, true_rank, counts, view_sorted;
     size_t x_eval, y_eval, n_eval, sdf_ctx, rgb_sorted, render_ctx;
@@ -64,6 +66,7 @@ void make_descs(const Step& st, const MvsdfStepParams* prm, const char* fwd, Mvs
             o->bias[i] = oT->bias[i] = prm->b[l];
             o->w[i] = oT->w[i] = (const float*)(fwd + st.fo.w[l]);
             if (is_sdf && d.trace_dtype != 0) o->wp16[i] = fwd + st.fo.wp16[l];
+            if (is_sdf && st.fo.chain_x3) { o->wx3[i] = fwd + st.fo.wx3[l]; oT->wx3[i] = fwd + st.fo.wx3T[l]; }
         }
         if (is_sdf) {
             const unsigned m = d.skip_mask;
@@ -144,6 +147,7 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
     L.object_mask_out = take((size_t)R);
     fo.trace_ws_bytes = mvsdf_trace_workspace_bytes_n(R, d.tp.n_steps);
     fo.trace_ws = take(fo.trace_ws_bytes);
+    fo.chain_x3 = mv_chain_x3_enabled();
     for (int l = 0; l < nl; ++l) {
         fo.w[l] = take((size_t)d.N[l] * d.K[l] * 4);
         fo.wp[l] = take(mvsdf_packed_floats(d.N[l], d.K[l]) * 4);
@@ -154,6 +158,10 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
             fo.wp16[l] = take(mvsdf_packed_bf16_bytes(d.N[l], d.K[l], 0));      // no duplicated columns: the activations are split into bf16 terms in LDS
         } else if (l < d.n_sdf && d.trace_dtype == 5) {
             fo.wp16[l] = take(3 * mvsdf_packed_bf16_bytes(d.N[l], d.K[l], 0));  // ... and so are the fp32 weights (three terms)
+        }
+        if (l < d.n_sdf && fo.chain_x3) {                                     // the differentiable chains' three-term packs (the tracer's own under trace_dtype 5)
+            fo.wx3[l] = d.trace_dtype == 5 ? fo.wp16[l] : take(3 * mvsdf_packed_bf16_bytes(d.N[l], d.K[l], 0));
+            fo.wx3T[l] = take(3 * mvsdf_packed_bf16_bytes(d.K[l], d.N[l], 0));
         }
     }
     L.perm = take((size_t)R * 8); fo.inv = take((size_t)R * 8); fo.true_rows = take((size_t)R * 8); fo.true_rank = take((size_t)R * 4); fo.counts = take(4 * 8);
@@ -275,9 +283,13 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     float* ray_dirs = (float*)(fwd + L.ray_dirs); float* cam_loc = (float*)(fwd + L.cam_loc);
     {
         void* wp16[MVSDF_STEP_MAX_LAYERS]; int nsplit[MVSDF_STEP_MAX_LAYERS];
+        void* wx3[MVSDF_STEP_MAX_LAYERS]; void* wx3T[MVSDF_STEP_MAX_LAYERS];
         for (int l = 0; l < nl; ++l) {
             const bool bf = l < d.n_sdf && d.trace_dtype != 0;
             wp16[l] = bf ? (void*)(fwd + fo.wp16[l]) : nullptr;
+            const bool x3 = l < d.n_sdf && fo.chain_x3;
+            wx3[l] = (x3 && d.trace_dtype != 5) ? (void*)(fwd + fo.wx3[l]) : nullptr;       // (trace_dtype 5: the tracer's pack IS this pack)
+            wx3T[l] = x3 ? (void*)(fwd + fo.wx3T[l]) : nullptr;
             nsplit[l] = 0;                                        // (duplicated hi / lo input columns: the removed trace_dtype 1 only)
         }
         // ... and the camera rays (idr.py:190), all in one launch
@@ -289,7 +301,7 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
                 return mv_fail(-1, "mvsdf_step_forward: host_stage is not device-visible pinned memory");
             }
         }
-        ST_TRY(mv_step_prologue(nl, prm->v, prm->g, d.N, d.K, w, wp, wpT, wp16, nsplit, d.trace_dtype == 2 ? 1 : (d.trace_dtype == 5 ? 2 : 0), in->uv, in->pose, in->intrinsics, d.B, d.P, ray_dirs, cam_loc,
+        ST_TRY(mv_step_prologue(nl, prm->v, prm->g, d.N, d.K, w, wp, wpT, wp16, nsplit, d.trace_dtype == 2 ? 1 : (d.trace_dtype == 5 ? 2 : 0), wx3, wx3T, in->uv, in->pose, in->intrinsics, d.B, d.P, ray_dirs, cam_loc,
                                 (uint8_t*)(fwd + L.object_mask_out), (unsigned long long*)(fwd + L.counters), stage_dev, (float*)in->minsdf_steps, d.tp.n_steps,
                                 (float*)in->eik_points, 3 * d.n_eik, stream));
     }

@@ -43,9 +43,13 @@ int mv_step_wgrad(const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int M, int Mg,
 // fold + MFMA packs (+ bf16 packs where wp16[l] is set: nsplit[l] = its PE split width) of every layer + the camera rays in ONE launch
 // (basic.hip::k_step_prologue): the work of mvsdf_fold_pack_net, mvsdf_pack_bf16_net_skips and mvsdf_camera_rays, same results
 int mv_step_prologue(int n_layers, const float* const* v, const float* const* g, const int* N, const int* K, float* const* w, float* const* wp,
-                     float* const* wpT, void* const* wp16, const int* nsplit, int wp16_mode, const float* uv, const float* pose, const float* intrinsics, int B, int P,
+                     float* const* wpT, void* const* wp16, const int* nsplit, int wp16_mode, void* const* wx3, void* const* wx3T, const float* uv, const float* pose,
+                     const float* intrinsics, int B, int P,
                      float* ray_dirs, float* cam_loc, uint8_t* ones, unsigned long long* counters, const float* stage_src, float* stage_a, int stage_na,
                      float* stage_b, int stage_nb, void* stream);   // stage_src (optional): device-visible pinned host memory [na | nb] -> stage_a, stage_b
+                                                                    // wx3 / wx3T (optional, per layer, entries may be null): the three-term bf16 packs of W_l / W_l^T
+                                                                    // of the differentiable chains (chain_x3.h; layouts of mvsdf_pack_bf16x3_net / _bf16x3t_net)
+int mv_chain_x3_enabled();                                          // the fused SDF chains run in the three-term bf16 arithmetic when the packs exist (dev: MVSDF_CHAIN_X3=0)
 // stage 1 of mvsdf_trace_stage for a caller whose previous launch (mv_step_prologue) zeroed the counters
 extern "C" int mv_trace_stage1_prezeroed(const MvsdfNetDesc* desc, const MvsdfTraceParams* tp, const float* cam_loc, const float* ray_dirs, const uint8_t* object_mask,
                               int B, int P, int training, const float* intervals, const float* minsdf_steps, float* points, uint8_t* mask, float* dists,

@@ -336,6 +336,41 @@ def g_idr(W, B, P, V, seed, tp, name=None, skip_in=(4,), smooth=None, use_invali
          focal_scale=SCENE['focal_scale'], checksum=synth.state_checksum(sd), **res)
 
 
+IDR_FIXTURES = {   # name: (W, B, P, V, seed, tp, skip_in) of the g_idr fixtures (the rendering network's forward does not depend on their other options)
+    'idr_w64_tp03': (64, 2, 256, 3, 0, 0.3, (4,)), 'idr_w64_tp06': (64, 2, 256, 3, 0, 0.6, (4,)), 'idr_w256_tp03': (256, 2, 128, 2, 0, 0.3, (4,)),
+    'idr_c1': (256, 1, 512, 4, 0, 0.3, (4,)), 'idr_c2': (256, 8, 256, 4, 0, 0.3, (4,)), 'idr_c3': (256, 8, 1024, 8, 0, 0.3, (4,)),
+    'idr_c5share': (256, 8, 512, 8, 0, 0.3, (4,)), 'idr_w512': (512, 8, 128, 2, 0, 0.3, (4,)), 'idr_w64_skips36': (64, 2, 256, 3, 0, 0.3, (3, 6)),
+    'idr_w64_skip8': (64, 2, 256, 3, 0, 0.3, (8,)), 'idr_w64_smooth': (64, 2, 256, 3, 0, 0.3, (4,)), 'idr_w64_invalid': (64, 2, 256, 3, 0, 0.3, (4,)),
+}
+
+
+def g_idr_relu_margins():
+    """Decision margins of the RENDERING network's ReLUs in the reference forward of every g_idr fixture: min |pre-activation| per hidden layer over the
+    hit rows (idr.py:160-165).  A pre-activation within the forward noise of zero (1e-6 .. 1e-5: the features and normals it is computed from agree with the
+    reference to ~2e-6) may take the other branch in an implementation with another fp32 summation order: one row's contribution to that unit's gradient
+    flips, which moves the entries of the (small) rendering-network gradients of that layer and the layers below it by up to ~1e-2 of their scale -- a tie, like
+    the tracer's recorded margins.  tests/test_gpu_idr.py widens the sampled-entry tolerance of exactly those layers when a margin is below 1e-5."""
+    res = {}
+    for name, (W, B, P, V, seed, tp, skip_in) in IDR_FIXTURES.items():
+        m, sd = build_model(W, seed, skip_in=skip_in)
+        inp, gt = synth.make_batch(B, P, V, seed=seed, **SCENE)
+        m.train()
+        torch.manual_seed(seed + 5)
+        rn = m.rendering_network
+        mins = {}
+        hooks = []
+        for l in range(rn.num_layers - 2):                       # the Linears followed by a ReLU
+            hooks.append(getattr(rn, 'lin%d' % l).register_forward_hook(
+                lambda mod, i, o, l=l: mins.__setitem__(l, min(mins.get(l, np.inf), float(o.detach().abs().min())))))
+        with quiet():
+            m({k: T(v) for k, v in inp.items()}, tp)
+        for h in hooks:
+            h.remove()
+        res[name] = np.array([mins[l] for l in range(rn.num_layers - 2)], np.float64)
+        print('%-18s min |pre-activation| per rendering layer: %s' % (name, ' '.join('%.2e' % v for v in res[name])))
+    save('idr_relu_margins', **res)
+
+
 def g_feat(seed, B=2, P=300, V=3, name='feat_corr'):
     """get_feat_loss_corr alone on fixed points + d loss / d points (V = 3 / 4 / 8 source views)."""
     inp, gt = synth.make_batch(B, P, V, seed=seed, **SCENE)
@@ -578,3 +613,4 @@ if __name__ == '__main__':
     g_sdf_bwd(64, 150, 0, (8,), 'sdf_bwd_w64_skip8')                            # a skip connection into the LAST Linear (idr.py:46-49,86)
     g_sdf_bwd(64, 150, 0, (4, 8), 'sdf_bwd_w64_skips48')
     g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_skip8', (8,))
+    g_idr_relu_margins()

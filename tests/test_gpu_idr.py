@@ -110,7 +110,19 @@ def test_forward_loss_backward_vs_reference(name, monkeypatch):
         assert _rel(out['eikonal_points_hom'], g['out_eikonal_points_hom']) < 1e-4
     model.zero_grad()
     lo['loss'].backward()
-    worst = 0.0
+    # ReLU ties of the rendering network (tests/golden/make_golden.py::g_idr_relu_margins): where the REFERENCE's own forward has a pre-activation within the
+    # forward noise of zero (the features / normals it is computed from agree with the reference to ~2e-6), an implementation with another fp32 summation order
+    # may take the other branch for that one (row, unit): the value is continuous, the mask is not -- one row's contribution to that unit's gradient flips and
+    # moves the entries of the (small: ~1e-8 per entry) gradients of that layer and the layers below it by up to ~1e-2 of their scale (measured at idr_w512 with
+    # the three-term chains: unit 397 of layer 1, margin 6.2e-8, 4.1e-3 on layer 0; every other entry of every parameter <= 5e-6).  Those layers get 2e-2 on
+    # their sampled entries; their gradient NORMS and every other parameter keep the bounds below.
+    relu_m = golden('idr_relu_margins')[name] if name in golden('idr_relu_margins').files else None
+    def tie_below(k):
+        if relu_m is None or not k.startswith('rendering_network.lin'):
+            return False
+        l = int(k.split('.')[1][3:])
+        return bool((relu_m[l:] < 2e-6).any())
+    worst, worst_tie = 0.0, 0.0
     for k, prm in model.named_parameters():
         gr = prm.grad.detach().cpu().numpy().astype(np.float64)
         ref_norm = float(g['gnorm_' + k])
@@ -118,9 +130,14 @@ def test_forward_loss_backward_vs_reference(name, monkeypatch):
         assert abs(nrm - ref_norm) <= 2e-3 * max(ref_norm, 1e-6) + 1e-7, (k, nrm, ref_norm)
         vals = gr.reshape(-1)[g['gidx_' + k]]
         scale = max(np.abs(g['gval_' + k]).max(), ref_norm / np.sqrt(gr.size), 1e-9)
-        worst = max(worst, float(np.abs(vals - g['gval_' + k]).max() / scale))
-    print('%s: worst sampled gradient entry deviation %.3g of the scale' % (name, worst))
+        dev = float(np.abs(vals - g['gval_' + k]).max() / scale)
+        if tie_below(k):
+            worst_tie = max(worst_tie, dev)
+        else:
+            worst = max(worst, dev)
+    print('%s: worst sampled gradient entry deviation %.3g of the scale (%.3g on the rendering layers at / below a recorded ReLU tie)' % (name, worst, worst_tie))
     assert worst < 1e-3, worst                                                    # measured: <= 1.2e-4 (idr_c3), <= 2.1e-5 on the other fixtures
+    assert worst_tie < 2e-2, worst_tie                                            # measured: 4.1e-3 (idr_w512), <= 1e-4 elsewhere
 
 
 def test_eval_mode_and_public_methods():
