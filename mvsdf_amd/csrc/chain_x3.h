@@ -347,6 +347,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd_x3(FwdArgsX3 a) {
 template <int MT, int NTW, int NW>
 __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int blk, float* smem) {
     constexpr int ROWS = 16 * MT, NTH = 64 * NW;
+    constexpr bool PF = MT * NTW <= 4;                              // side inputs of an epilogue requested before the phase's matrix instructions
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
     const int row0 = blk * ROWS, S16 = a.S, TS = ROWS * S16, nl = a.net.n_layers, d0 = 3 + 6 * a.net.multires;
     const unsigned skm = a.net.skip_mask;
@@ -383,22 +384,25 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
             const bool vn = (N & 3) == 0;
             const int ldn = a.net.L[l + 1].K;                        // row length of vbar_{l+1}
             const bool vv = (ldn & 3) == 0;
-            // side inputs of the epilogue (sigma_l, u_{l+1}): requested BEFORE the matrix instructions
-            f32x4 zz[MT][NTW], uu[MT][NTW];
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
+            // side inputs of the epilogue (sigma_l, u_{l+1}): requested BEFORE the matrix instructions (PF), or -- the 2-row-tile x 4-column-tile wide form,
+            // whose accumulators and weight ring leave no registers for them -- inside the epilogue
+            f32x4 zz[PF ? MT : 1][PF ? NTW : 1], uu[PF ? MT : 1][PF ? NTW : 1];
+            auto side = [&](int t, int m, f32x4& z, f32x4& u) {
                 const int col0 = (ct0 + t) * 16 + 4 * q, nv = N - col0;
+                const int row = row0 + m * 16 + r;
+                const bool ok = t < ntw && row < a.M && nv > 0;
+                z = mv_ld4(a.Z[l] + (ok ? (size_t)row * N + col0 : 0), ok && vn && nv >= 4, ok ? nv : 0);
+                if (top) {
+                    f32x4 wl = mv_ld4(a.w_last_row0 + (ok ? col0 : 0), false, ok ? nv : 0);
+                    if (to_skip) { for (int i = 0; i < 4; ++i) wl[i] = dm_div_sqrt2(wl[i]); }
+                    u = wl;
+                } else u = mv_ld4(a.U[l + 1] + (ok ? (size_t)row * N + col0 : 0), ok && vn && nv >= 4, ok ? nv : 0);
+            };
+            if constexpr (PF) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int row = row0 + m * 16 + r;
-                    const bool ok = t < ntw && row < a.M && nv > 0;
-                    zz[m][t] = mv_ld4(a.Z[l] + (ok ? (size_t)row * N + col0 : 0), ok && vn && nv >= 4, ok ? nv : 0);
-                    if (top) {
-                        f32x4 wl = mv_ld4(a.w_last_row0 + (ok ? col0 : 0), false, ok ? nv : 0);
-                        if (to_skip) { for (int i = 0; i < 4; ++i) wl[i] = dm_div_sqrt2(wl[i]); }
-                        uu[m][t] = wl;
-                    } else uu[m][t] = mv_ld4(a.U[l + 1] + (ok ? (size_t)row * N + col0 : 0), ok && vn && nv >= 4, ok ? nv : 0);
-                }
+                for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) side(t, m, zz[m][t], uu[m][t]);
             }
             f32x4 acc[MT][NTW];
             mv_zero_acc<MT, NTW>(acc);
@@ -412,13 +416,14 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const int rr = m * 16 + r, row = row0 + rr;
-                        f32x4 ub, z2;
+                        f32x4 ub, z2, zs, us;
+                        if constexpr (PF) { zs = zz[m][t]; us = uu[m][t]; } else side(t, m, zs, us);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const float sb = acc[m][t][i], sig = zz[m][t][i];
+                            const float sb = acc[m][t][i], sig = zs[i];
                             const float u = sig * sb;
                             ub[i] = to_skip ? dm_div_sqrt2(u) : u;
-                            z2[i] = uu[m][t][i] * sb * dm_sigmoid_prime100(sig);
+                            z2[i] = us[i] * sb * dm_sigmoid_prime100(sig);
                         }
                         mv_x3_put4(act, S16, TS, rr, col0, ub, nv);
                         if (row < a.M && nv > 0) {
@@ -457,21 +462,23 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
         const int Nh = sk ? N - d0 : N;
         const bool vh = (Nh & 3) == 0;
         // sigma_{l-1}, zbar2_{l-1} (and, accumulating, zbar_{l-1}) of this lane's output elements: requested before the matrix instructions
-        f32x4 zz[MT][NTW], z2[MT][NTW], zo[MT][NTW];
+        f32x4 zz[PF ? MT : 1][PF ? NTW : 1], z2[PF ? MT : 1][PF ? NTW : 1], zo[PF ? MT : 1][PF ? NTW : 1];
         const int lm = l > 0 ? l - 1 : 0;
         const bool has2 = a.ZB2[lm] != nullptr;
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
+        auto side = [&](int t, int m, f32x4& z, f32x4& zb2, f32x4& zold) {
             const int col0 = (ct0 + t) * 16 + 4 * q, nv = Nh - col0;
+            const int row = row0 + m * 16 + r;
+            const bool ok = l > 0 && t < ntw && row < a.M && nv > 0;
+            const size_t off = ok ? (size_t)row * Nh + col0 : 0;
+            z = mv_ld4(a.Z[lm] + off, ok && vh && nv >= 4, ok ? nv : 0);
+            zb2 = mv_ld4((has2 ? a.ZB2[lm] : a.Z[lm]) + off, ok && vh && nv >= 4, ok ? nv : 0);
+            zold = a.accum ? mv_ld4(a.ZB[lm] + off, ok && vh && nv >= 4, ok ? nv : 0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        if constexpr (PF) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int row = row0 + m * 16 + r;
-                const bool ok = l > 0 && t < ntw && row < a.M && nv > 0;
-                const size_t off = ok ? (size_t)row * Nh + col0 : 0;
-                zz[m][t] = mv_ld4(a.Z[lm] + off, ok && vh && nv >= 4, ok ? nv : 0);
-                z2[m][t] = mv_ld4((has2 ? a.ZB2[lm] : a.Z[lm]) + off, ok && vh && nv >= 4, ok ? nv : 0);
-                zo[m][t] = a.accum ? mv_ld4(a.ZB[lm] + off, ok && vh && nv >= 4, ok ? nv : 0) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) side(t, m, zz[m][t], z2[m][t], zo[m][t]);
         }
         f32x4 acc[MT][NTW];
         mv_zero_acc<MT, NTW>(acc);
@@ -500,17 +507,18 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
                     } else {
                         const int nv = Nh - col0;
                         if (nv > 0) {
-                            f32x4 zb;
+                            f32x4 zb, zs, z2s, zos;
+                            if constexpr (PF) { zs = zz[m][t]; z2s = z2[m][t]; zos = zo[m][t]; } else side(t, m, zs, z2s, zos);
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                float x = zz[m][t][i] * v[i];
-                                if (has2) x += z2[m][t][i];
+                                float x = zs[i] * v[i];
+                                if (has2) x += z2s[i];
                                 zb[i] = (row < a.M && i < nv) ? x : 0.0f;
                             }
                             mv_x3_put4(act, S16, TS, rr, col0, zb, nv);             // the chain continues with THIS pass's zbar
                             if (row < a.M) {
                                 f32x4 st = zb;
-                                if (a.accum) { for (int i = 0; i < 4; ++i) st[i] = zo[m][t][i] + zb[i]; }
+                                if (a.accum) { for (int i = 0; i < 4; ++i) st[i] = zos[i] + zb[i]; }
                                 mv_st4(a.ZB[l - 1] + (size_t)row * Nh + col0, st, vh && nv >= 4, nv);
                             }
                         }

@@ -375,9 +375,16 @@ int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const f
         for (int l = 1; l < nl - 1; ++l) f.U[l] = ctx + lo.U[l];
         f.G0 = ctx + lo.G0; f.y = y; f.ldy = net.L[nl - 1].N; f.w_last_row0 = d->w[nl - 1]; f.nrm = nrm;
         if (g) f.g = *g;
-        const int mt = ntw_f == 2 ? mv_chain_mt_x3((Mr + 15) / 16) : 1;
+        // (hidden width 257 .. 512, two row tiles: 8 waves x 4 column tiles -- a 16-row tile streams 1.57 MB of weight terms per phase, more than its matrix
+        // instructions take; at 37 000 rows of the 8x512 network 4208 (fp32 chain) / 3842 (one tile) / 2761 us (two tiles))
+        const int mt = mv_chain_mt_x3((Mr + 15) / 16);
         const size_t lds = (size_t)3 * 16 * mt * xn.S * 2 + ((size_t)2 * ((16 * mt * lo.d0 + 3) & ~3) + 16 * mt * 4) * sizeof(float);
         const dim3 grid((Mr + 16 * mt - 1) / (16 * mt));
+        if (ntw_f == 4 && mt == 2) {
+            MV_TRY(hipFuncSetAttribute((const void*)k_chain_fwd_x3<2, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_chain_fwd_x3<2, 4, 8>), grid, dim3(512), lds, s, f);
+            return mv_check(hipGetLastError(), "mvsdf_sdf_forward (x3 chain)");
+        }
         // hidden width <= 256: 16 waves x 1 column tile; up to 512: 16 waves x 2 tiles
         if (mt == 2) {
             MV_TRY(hipFuncSetAttribute((const void*)k_chain_fwd_x3<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -707,11 +714,15 @@ int mvsdf_sdf_backward_pair(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M
         ChainArgsX3 a, b;
         fill_chain_args(a, net, xn, xnT, xn.S, lo, sdf_bwd_layout(net, MbA), ctx, 0, MbA, dyA, dnA, wsA, nullptr, w8);
         fill_chain_args(b, net, xn, xnT, xn.S, lo, sdf_bwd_layout(net, MbX), ctx, row0X, MbX, dyX, dnX, wsX, dx, w8);
-        const int mt = ntw_b == 2 ? mv_chain_mt_x3((MbA + 15) / 16 + (MbX + 15) / 16) : 1;
+        const int mt = mv_chain_mt_x3((MbA + 15) / 16 + (MbX + 15) / 16);
         const size_t lds = (size_t)3 * 16 * mt * xn.S * 2 + (size_t)16 * mt * lo.d0 * sizeof(float);
         const int na = (MbA + 16 * mt - 1) / (16 * mt), nb = (MbX + 16 * mt - 1) / (16 * mt);
         const dim3 grid(na + nb);
-        if (mt == 2) {
+        if (mt == 2 && ntw_b == 4) {
+            MV_TRY(hipFuncSetAttribute((const void*)k_chain_bwd2_x3<2, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_chain_bwd2_x3<2, 4, 8>), grid, dim3(512), lds, s, a, b, na);
+        }
+        else if (mt == 2) {
             MV_TRY(hipFuncSetAttribute((const void*)k_chain_bwd2_x3<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((k_chain_bwd2_x3<2, 1, 16>), grid, dim3(1024), lds, s, a, b, na);
         }

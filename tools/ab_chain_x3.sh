@@ -1,0 +1,19 @@
+# A/B of the differentiable chains on one box: the three-term bf16 chains (default) vs the fp32-input MFMA chains (dev library, MVSDF_CHAIN_X3=0).
+# /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/ab_chain_x3.sh'
+cd $GRAFT_REPO_ROOT
+DEV=$PWD/mvsdf_amd/libmvsdf_hip_dev.so
+run() { tag=$1; shift; env "$@" python bench.py --no-cpu-baseline ${EXTRA:-} 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['roofline']['kernels']; print('%-22s' % '$tag', 'ms %.4f'%d['ms_per_step'], 'sphere %.3f samples %.3f diff %.3f (fwd %.3f bwd %.3f)'%(k['k_sphere_trace']['ms_per_step'], k['k_ray_samples']['ms_per_step'], k['differentiable']['ms_per_step'], k['differentiable']['ms_forward'], k['differentiable']['ms_backward']))"; }
+for rep in 1 2; do
+  run c2-x3 MVSDF_LIB=$DEV
+  run c2-f32chain MVSDF_LIB=$DEV MVSDF_CHAIN_X3=0
+done
+EXTRA="--workload c5share --dtype bf16x2" run c5share-bf16x2-x3 MVSDF_LIB=$DEV
+EXTRA="--workload c5share --dtype bf16x2" run c5share-bf16x2-f32 MVSDF_LIB=$DEV MVSDF_CHAIN_X3=0
+EXTRA="--workload c5share" run c5share-x3 MVSDF_LIB=$DEV
+EXTRA="--workload c5share" run c5share-f32chain MVSDF_LIB=$DEV MVSDF_CHAIN_X3=0
+EXTRA="--workload c3" run c3-x3 MVSDF_LIB=$DEV
+EXTRA="--workload c3" run c3-f32chain MVSDF_LIB=$DEV MVSDF_CHAIN_X3=0
+EXTRA="--width 512 --steps 60" run w512-x3 MVSDF_LIB=$DEV
+EXTRA="--width 512 --steps 60" run w512-f32chain MVSDF_LIB=$DEV MVSDF_CHAIN_X3=0
+EXTRA="--workload shipped --steps 10 --warmup 2" run shipped-x3 MVSDF_LIB=$DEV
+EXTRA="--workload shipped --steps 10 --warmup 2" run shipped-f32chain MVSDF_LIB=$DEV MVSDF_CHAIN_X3=0

@@ -39,7 +39,9 @@ def run(W, M, skips=(4,), reps=30):
     print('   x3 vs f32: y max %.3g, n max %.3g' % (np.abs(res['x3'][0] - res['f32'][0]).max(), np.abs(res['x3'][1] - res['f32'][1]).max()))
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) > 2:
+    run(int(sys.argv[1]), int(sys.argv[2]), reps=10)
+elif __name__ == '__main__':
     run(64, 700)
     run(64, 300, (3, 6))
     run(64, 300, (8,))
