@@ -237,7 +237,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)          # ~3 ms per step: the default run still takes seconds
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
-    ap.add_argument('--dtype', default='f32x3', choices=sorted(PEAK), help="arithmetic of the no-grad tracing MLP (IDRNetwork.set_trace_dtype); the differentiable half is always fp32")
+    ap.add_argument('--dtype', default='f32x3', choices=sorted(PEAK), help="arithmetic of the no-grad tracing MLP (IDRNetwork.set_trace_dtype); the differentiable half computes in fp32 (SDF chains: three bf16 terms per value on the bf16 matrix cores, csrc/chain_x3.h)")
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'], help="--gpus N: 'weak' (default) keeps the rays per GPU fixed (views sharded, px per view x N: N = 8 is the c4 shape); "
                     "'strong' keeps the JOB fixed at the workload's N = 8 shape (c2: c4's 8 views x 2048 px = 16384 rays in total) and shards its views: N = 1 runs all of it on one GPU")
     ap.add_argument('--width', type=int, default=0, help='hidden width of both MLPs: 256 = BASELINE.json (8x256), 512 = the reference\'s shipped conf (mvsdf_dtu.conf:24,35)')
@@ -425,7 +425,7 @@ def main():
         feat_bytes = 512 * pts.shape[0] * (1 + V)
         total_R = world * R
         pmc = pmc_entry(a.workload, a.dtype, a.width) if world == 1 else None
-        # the differentiable half (always fp32): value + normal forward of every evaluated row, rendering net, their backward incl. the second-order SDF
+        # the differentiable half (fp32 arithmetic; its SDF chains as three bf16 terms per value since round 5): value + normal forward of every evaluated row, rendering net, their backward incl. the second-order SDF
         # pass and the weight gradients = the formula's non-T terms; time = HIP events around the forward behind the tracer and around mvsdf_step_backward
         # (no bubbles on the stream: the distances are kernel time; at c3 / the c5 share the E sample rows run beside the tracer and are not in it)
         flops_diff = ((R + E) + 2 * (N + E)) * f_s + 3 * (N + E) * f_t + 3 * N * f_r
@@ -433,9 +433,11 @@ def main():
         if ms_diff_fwd is not None and ms_diff_bwd:
             ms_diff = ms_diff_fwd + ms_diff_bwd
             hb = None if pmc is None else sum(k['hbm_bytes_per_launch'] * k['launches_per_step'] for n_, k in pmc['kernels'].items()
-                                              if n_ in ('k_chain_fwd', 'k_chain_bwd2', 'k_delta_apply', 'k_wgrad_net', 'k_reduce_net', 'k_render_chain_fwd', 'k_render_chain_bwd',
+                                              if n_ in ('k_chain_fwd', 'k_chain_bwd2', 'k_chain_fwd_x3', 'k_chain_bwd2_x3', 'k_delta_apply', 'k_wgrad_net', 'k_reduce_net', 'k_render_chain_fwd', 'k_render_chain_bwd',
                                                         'k_step_bwd_assemble', 'k_fold_bwd_net', 'k_step_outputs'))
-            diff_k = {'bound': 'mfma (fp32)', 'flops_per_step': flops_diff, 'ms_per_step': ms_diff, 'ms_forward': ms_diff_fwd, 'ms_backward': ms_diff_bwd,
+            diff_k = {'bound': 'mfma (SDF chains: fp32 values as three bf16 terms on v_mfma_f32_16x16x32_bf16, csrc/chain_x3.h -- ceiling 2500 / 6 TF/s; rendering chains and weight '
+                               'gradients: v_mfma_f32_16x16x4_f32; peak = the fp32 instruction, what the same arithmetic could reach without the term split)',
+                      'flops_per_step': flops_diff, 'ms_per_step': ms_diff, 'ms_forward': ms_diff_fwd, 'ms_backward': ms_diff_bwd,
                       'achieved': flops_diff / (ms_diff * 1e-3) / 1e12, 'peak': PEAK['f32'], 'frac': flops_diff / (ms_diff * 1e-3) / 1e12 / PEAK['f32'],
                       'traffic': hb, 'traffic_GBps': None if hb is None else hb / (ms_diff * 1e-3) / 1e9}
         res = {

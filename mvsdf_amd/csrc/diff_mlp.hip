@@ -291,7 +291,12 @@ int mv_chain_split_pays(const MvsdfNetDesc* d, int E, int M) {
 // The fused chains in the three-term bf16 arithmetic (chain_x3.h) run when both descriptors carry the packs (MvsdfNetDesc.wx3); the dev library's
 // MVSDF_CHAIN_X3=0 keeps the fp32-input MFMA chains (A/B, tests/test_gpu_alt_paths.py).
 static bool mv_chain_x3_on() {
-    static const int env = [] { const char* e = mv_dev_env("MVSDF_CHAIN_X3"); return e ? atoi(e) : 1; }();
+    static const int env = [] {
+        const char* e = mv_dev_env("MVSDF_CHAIN_X3");
+        const char* f = mv_dev_env("MVSDF_FUSE");                 // (the dev switches that pick the per-layer / split fp32 launches mean the fp32 arithmetic everywhere)
+        if ((f && atoi(f) == 0) || mv_dev_env("MVSDF_SPLIT_CHAINS") || mv_dev_env("MVSDF_CHAIN_W8")) return 0;
+        return e ? atoi(e) : 1;
+    }();
     return env != 0;
 }
 int mv_chain_x3_enabled() { return mv_chain_x3_on() ? 1 : 0; }

@@ -2,7 +2,7 @@
 behind environment switches the product library does not read (tools/README.md): per-layer kernels instead of the fused chain
 kernels (MVSDF_FUSE=0), the backward pass as separate E.1 / E.2 chain launches (MVSDF_SPLIT_CHAINS=1), 8-wave chain workgroups
 (MVSDF_CHAIN_W8=1), two row tiles per chain workgroup everywhere (MVSDF_CHAIN_MT=2), the delta pass as a chain of GEMMs instead of the
-scaling of the saved s_l (MVSDF_DELTA_CHAIN=1), the Python-orchestrated step (MVSDF_NATIVE_STEP=0), the tracer without tail filling (MVSDF_TAIL=0), the step's sample rows evaluated on a side
+scaling of the saved s_l (MVSDF_DELTA_CHAIN=1), the Python-orchestrated step (MVSDF_NATIVE_STEP=0), the fused SDF chains on the fp32-input MFMA instead of the three-term bf16 form (MVSDF_CHAIN_X3=0), the tracer without tail filling (MVSDF_TAIL=0), the step's sample rows evaluated on a side
 stream beside the tracer at every size (MVSDF_SPLIT_ROWS=1; by default only where the rays' rows alone make a shorter launch), the step's
 CPU-generator draws delivered by an async copy in front of the step instead of being read from pinned memory by its first kernel
 (IDRNetwork.host_stage = False, set through tests/conftest.py's MVSDF_TEST_HOST_STAGE=0).  Each is an independent implementation of the same
@@ -32,7 +32,7 @@ TARGETS = ['tests/test_gpu_diff.py', 'tests/test_gpu_idr.py::test_forward_loss_b
 
 
 @pytest.mark.parametrize('env', [{'MVSDF_FUSE': '0'}, {'MVSDF_SPLIT_CHAINS': '1'}, {'MVSDF_CHAIN_W8': '1'}, {'MVSDF_CHAIN_MT': '2'}, {'MVSDF_DELTA_CHAIN': '1'},
-                                 {'MVSDF_NATIVE_STEP': '0'}, {'MVSDF_TAIL': '0'}, {'MVSDF_SPLIT_ROWS': '1'}, {'MVSDF_TEST_HOST_STAGE': '0'}],
+                                 {'MVSDF_NATIVE_STEP': '0'}, {'MVSDF_CHAIN_X3': '0'}, {'MVSDF_TAIL': '0'}, {'MVSDF_SPLIT_ROWS': '1'}, {'MVSDF_TEST_HOST_STAGE': '0'}],
                          ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()))
 def test_reference_fixtures_pass_on_the_alternative_paths(env, dev_lib):
     e = dict(os.environ, MVSDF_LIB=dev_lib)

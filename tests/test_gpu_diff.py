@@ -12,6 +12,14 @@ from oracle import oracle_np as ON
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=['x3', 'f32'])
+def chain_arithmetic(request, monkeypatch):
+    """Every test of this file runs on both forms of the fused SDF chains: 'x3' (the product: three bf16 terms per fp32 value on v_mfma_f32_16x16x32_bf16,
+    csrc/chain_x3.h -- taken when the network carries the wx3 packs) and 'f32' (the fp32-input MFMA chains: networks packed without them)."""
+    monkeypatch.setattr(ops, 'CHAIN_X3', request.param == 'x3')
+    return request.param
+
+
 def _rel(a, b):
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
@@ -106,11 +114,12 @@ def test_render_forward_backward_vs_golden():
         assert _rel(db, g['d_lin%d.bias' % l]) < 5e-4
 
 
-def test_two_tile_chain_workgroups_equal_one_tile():
-    """257..512 row tiles per launch run the fused chain kernels with two 16-row tiles per workgroup (diff_mlp.hip, mv_chain_mt): rows are
-    independent, so forward outputs, saved context use and input adjoints must equal, bit for bit, those of launches small enough to use
-    one tile per workgroup; the weight gradients agree to summation order."""
-    sd = synth.make_state_dict(256, 0)
+@pytest.mark.parametrize('W', [256, 512])
+def test_two_tile_chain_workgroups_equal_one_tile(W):
+    """257..512 row tiles per launch run the fused chain kernels with two 16-row tiles per workgroup (diff_mlp.hip, mv_chain_mt / mv_chain_mt_x3; hidden
+    width 512: the x3 chains' 8-wave x 4-column-tile form): rows are independent, so forward outputs, saved context use and input adjoints must equal, bit
+    for bit, those of launches small enough to use one tile per workgroup; the weight gradients agree to summation order."""
+    sd = synth.make_state_dict(W, 0)
     net = sdf_packed_net(sd)
     M = 4500                                                     # 282 tiles -> two per workgroup;  1500 rows (94 tiles) -> one
     gen = torch.Generator().manual_seed(5)
