@@ -95,9 +95,59 @@ __device__ __forceinline__ void mv_x3_gemm(const MvLayerBf& L, const uint16_t* a
 // Non-temporal stores of the saved tensors: 112 -> 129 us (sigma_l is re-read by the normal chain of the same launch).  Non-temporal weight loads: 164 us.
 // Without any store: 100 us.  A phase's matrix loop is the 393 KB weight stream at ~85 GB/s per CU (half of the L2's rate: the ring drains at every phase end).
 
+// The weight fetch of a chain of phases.  PDW > 0 (hidden width <= 256, one column tile per wave): tile_engine_bf16s.h's CARRIED ring -- the first PDW k-blocks of
+// the NEXT phase's weight fragments are requested by the slots of the current phase's matrix loop that have no k-block of their own left, and land under its
+// epilogue: a phase starts with PDW of its KB k-blocks on the CU.
+template <int MT, int NTW, int NW, int PDW>
+struct MvX3Ring {
+    static constexpr bool CARRY = PDW > 0;
+    uint4 bw[CARRY ? PDW : 1][NTW][3];
+    const uint4* wcur[NTW];
+    const uint4* wnext[NTW];
+    int kbnext;
+    // (layers are handed over as (pack, k-blocks, column tiles), never as pointers into the kernel arguments: taking such an address makes the compiler copy
+    // the whole argument block to scratch memory -- 1.5 KB per lane, and the kernel twice as slow)
+    __device__ __forceinline__ void prep(const uint4* wp, int KB, int NT, int w, int lane) {
+        const int per = (NT + NW - 1) / NW, c0 = w * per;
+        kbnext = KB;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int tile = c0 + t < NT ? c0 + t : NT - 1;
+            wnext[t] = wp + (size_t)tile * kbnext * 3 * 64 + lane;
+        }
+    }
+    __device__ __forceinline__ void fill() {                        // the very first phase: nothing to hide the request behind
+        if constexpr (CARRY) {
+#pragma unroll
+            for (int d = 0; d < PDW; ++d) {
+                const int kb = d < kbnext ? d : kbnext - 1;
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) bw[d][t][j] = wnext[t][((size_t)kb * 3 + j) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // one phase: acc += act x L (the layer prep()'d last); (nwp, nkb, nnt): the layer of the phase after it (nwp null: none -- the ring re-requests this layer's
+    // k-block 0, unused)
+    __device__ __forceinline__ void gemm(const MvLayerBf& L, const uint4* nwp, int nkb, int nnt, const uint16_t* act, int S16, int TS, int ct0, int ntw,
+                                         f32x4 (&acc)[MT][NTW], int w, int lane) {
+        if constexpr (CARRY) {
+            const int KB = kbnext;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) wcur[t] = wnext[t];
+            if (nwp) prep(nwp, nkb, nnt, w, lane); else kbnext = 1;
+            mv_gemm_carried_bw<MT, NTW, NTW, PDW, 3, 3>(KB, act, S16, TS, wcur, acc, lane, bw, wnext, kbnext);
+        } else {
+            mv_x3_gemm<MT, NTW>(L, act, S16, TS, ct0, ntw, acc, lane);
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // Forward value + normal (k_chain_fwd's passes and outputs)
-template <int MT, int NTW, int NW>
+template <int MT, int NTW, int NW, int PDW = 0>
 __global__ __launch_bounds__(64 * NW) void k_chain_fwd_x3(FwdArgsX3 a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT, NTH = 64 * NW;
@@ -109,6 +159,9 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd_x3(FwdArgsX3 a) {
     float* padj = pe + ((ROWS * d0 + 3) & ~3);                      // [ROWS][d0] PE adjoint of the skip layer(s), then g_0
     float* pts = padj + ((ROWS * d0 + 3) & ~3);                     // [ROWS][3]
     CH_PH_DECL
+    MvX3Ring<MT, NTW, NW, PDW> ring;
+    ring.prep(a.net.L[0].wp, a.net.L[0].KB, a.net.L[0].NT, w, lane);
+    ring.fill();                                                    // layer 0's first k-blocks, requested before the positional encoding
     for (int i = tid; i < ROWS * 3; i += NTH) {
         const int row = row0 + i / 3, c = i - 3 * (i / 3);
         float v = 0.0f;
@@ -152,7 +205,12 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd_x3(FwdArgsX3 a) {
         }
         mv_barrier_lds();
         CH_PH(1)
-        mv_x3_gemm<MT, NTW>(L, act, S16, TS, ct0, ntw, acc, lane);
+        // (after the last hidden layer the ring prefetches for the normal chain's first phase: the last Linear in between fetches its own)
+        {
+            const bool inner = l + 1 < nl - 1;
+            const MvLayerBf& Ln = inner ? a.net.L[l + 1] : a.netT.L[nl - 2];
+            ring.gemm(L, (inner || row0 < a.Mg) ? Ln.wp : nullptr, Ln.KB, Ln.NT, act, S16, TS, ct0, ntw, acc, w, lane);
+        }
         CH_PH(2)
         mv_barrier_lds();
         CH_PH(3)
@@ -219,7 +277,9 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd_x3(FwdArgsX3 a) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[m][t] = b4;
             }
-            mv_x3_gemm<MT, NTW>(L, act, S16, TS, ct0, ntw, acc, lane);
+            if constexpr (PDW > 0 && NTW == 1) {                      // (two k-blocks in flight here: the carried ring's registers stay live across this layer)
+                if (ntw > 0) mv_gemm_rolling_bw<MT, 1, NTW, 2, 3, 3>(L.KB, act, S16, TS, L.wp + (size_t)ct0 * L.KB * 3 * 64 + lane, acc, lane);
+            } else mv_x3_gemm<MT, NTW>(L, act, S16, TS, ct0, ntw, acc, lane);
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 if (t < ntw) {
@@ -275,7 +335,10 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd_x3(FwdArgsX3 a) {
         CH_PH(7)
         mv_barrier_lds();
         CH_PH(8)
-        mv_x3_gemm<MT, NTW>(L, act, S16, TS, ct0, ntw, acc, lane);
+        {
+            const MvLayerBf& Ln = a.netT.L[l > 0 ? l - 1 : 0];
+            ring.gemm(L, l > 0 ? Ln.wp : nullptr, Ln.KB, Ln.NT, act, S16, TS, ct0, ntw, acc, w, lane);
+        }
         CH_PH(9)
         mv_barrier_lds();
         CH_PH(10)
@@ -344,7 +407,7 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd_x3(FwdArgsX3 a) {
 // ---------------------------------------------------------------------------------------------------------------
 // One backward pass per row tile (mv_chain_bwd_body's passes and outputs): gbar_0 = J_PE nbar, the ascending E.1 chain, the descending E.2 chain, the
 // input adjoint.  dn_in == NULL: E.2 only.
-template <int MT, int NTW, int NW>
+template <int MT, int NTW, int NW, int PDW>
 __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int blk, float* smem) {
     constexpr int ROWS = 16 * MT, NTH = 64 * NW;
     constexpr bool PF = MT * NTW <= 4;                              // side inputs of an epilogue requested before the phase's matrix instructions
@@ -355,6 +418,12 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
     float* g0s = smem + (3 * TS) / 2;                               // [ROWS][d0]: gbar_0 (E.1), then the PE adjoint (E.2)
     float* pe_adj = g0s;
     const bool top_skip = mv_skip_at(skm, nl - 1);
+    MvX3Ring<MT, NTW, NW, PDW> ring;
+    {
+        const MvLayerBf& L0 = a.dn_in ? a.net.L[0] : a.netT.L[nl - 1];
+        ring.prep(L0.wp, L0.KB, L0.NT, w, lane);
+        ring.fill();                                                // the first phase's first k-blocks, requested before its input is built
+    }
     if (a.dn_in) {
         {   // gbar_0 = J_PE nbar
             const int Kp0 = a.net.L[0].KB * 32;
@@ -407,7 +476,10 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
             f32x4 acc[MT][NTW];
             mv_zero_acc<MT, NTW>(acc);
             mv_barrier_lds();
-            mv_x3_gemm<MT, NTW>(L, act, S16, TS, ct0, ntw, acc, lane);
+            {
+                const MvLayerBf& Ln = l + 1 < nl - 1 ? a.net.L[l + 1] : a.netT.L[nl - 1];     // (after E.1's last phase: E.2's first)
+                ring.gemm(L, Ln.wp, Ln.KB, Ln.NT, act, S16, TS, ct0, ntw, acc, w, lane);
+            }
             mv_barrier_lds();
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
@@ -483,7 +555,10 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
         f32x4 acc[MT][NTW];
         mv_zero_acc<MT, NTW>(acc);
         mv_barrier_lds();
-        mv_x3_gemm<MT, NTW>(L, act, S16, TS, ct0, ntw, acc, lane);
+        {
+            const MvLayerBf& Ln = a.netT.L[l > 0 ? l - 1 : 0];
+            ring.gemm(L, l > 0 ? Ln.wp : nullptr, Ln.KB, Ln.NT, act, S16, TS, ct0, ntw, acc, w, lane);
+        }
         mv_barrier_lds();
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
@@ -558,15 +633,15 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
     }
 }
 
-template <int MT, int NTW, int NW>
+template <int MT, int NTW, int NW, int PDW = 0>
 __global__ __launch_bounds__(64 * NW) void k_chain_bwd_x3(ChainArgsX3 a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    mv_chain_bwd_body_x3<MT, NTW, NW>(a, blockIdx.x, smem);
+    mv_chain_bwd_body_x3<MT, NTW, NW, PDW>(a, blockIdx.x, smem);
 }
 static_assert(2 * sizeof(ChainArgsX3) + 16 <= 4096, "kernel arguments of k_chain_bwd2_x3 exceed 4 KiB");
-template <int MT, int NTW, int NW>
+template <int MT, int NTW, int NW, int PDW = 0>
 __global__ __launch_bounds__(64 * NW) void k_chain_bwd2_x3(ChainArgsX3 a, ChainArgsX3 b, int na) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((int)blockIdx.x < na) mv_chain_bwd_body_x3<MT, NTW, NW>(a, blockIdx.x, smem);
-    else mv_chain_bwd_body_x3<MT, NTW, NW>(b, blockIdx.x - na, smem);
+    if ((int)blockIdx.x < na) mv_chain_bwd_body_x3<MT, NTW, NW, PDW>(a, blockIdx.x, smem);
+    else mv_chain_bwd_body_x3<MT, NTW, NW, PDW>(b, blockIdx.x - na, smem);
 }

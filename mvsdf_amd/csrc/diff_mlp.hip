@@ -319,6 +319,13 @@ static int mv_chain_mt_x3(int tiles16) {
     return 1.45 * rounds2 < rounds1 ? 2 : 1;
 }
 
+// Carried-ring depth (k-blocks of the next phase's weights requested early, chain_x3.h) of the x3 chains.  One row tile per workgroup (<= 256 tiles: c2): 4 --
+// k_chain_fwd_x3 111 -> 97 us, the c2 step 1.503 -> 1.485 ms.  Two row tiles: 0 (the rolling fetch): with 2 the c5-share step went 1.51-1.55 -> 1.57-1.61 ms and c3
+// 4.04 -> 4.20 ms -- at those sizes the sample rows' chain runs BESIDE the tracer (mv_chain_split_pays), and a chain that keeps the L2 busy through its epilogues
+// takes that bandwidth from the tracer's own weight stream (k_ray_samples 0.446 -> 0.478 ms, k_sphere_trace 1.17 -> 1.27 ms at c3).
+#define MV_X3_PD1 4
+#define MV_X3_PD2 0
+
 #define MV_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mv_check(e_, #expr); } while (0)
 
 extern "C" {
@@ -392,10 +399,10 @@ int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const f
         }
         // hidden width <= 256: 16 waves x 1 column tile; up to 512: 16 waves x 2 tiles
         if (mt == 2) {
-            MV_TRY(hipFuncSetAttribute((const void*)k_chain_fwd_x3<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_chain_fwd_x3<2, 1, 16>), grid, dim3(1024), lds, s, f);
+            MV_TRY(hipFuncSetAttribute((const void*)k_chain_fwd_x3<2, 1, 16, MV_X3_PD2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_chain_fwd_x3<2, 1, 16, MV_X3_PD2>), grid, dim3(1024), lds, s, f);
         }
-        else if (ntw_f == 2) hipLaunchKernelGGL((k_chain_fwd_x3<1, 1, 16>), grid, dim3(1024), lds, s, f);
+        else if (ntw_f == 2) hipLaunchKernelGGL((k_chain_fwd_x3<1, 1, 16, MV_X3_PD1>), grid, dim3(1024), lds, s, f);
         else hipLaunchKernelGGL((k_chain_fwd_x3<1, 2, 16>), grid, dim3(1024), lds, s, f);
         return mv_check(hipGetLastError(), "mvsdf_sdf_forward (x3 chain)");
     }
@@ -525,7 +532,7 @@ int mvsdf_sdf_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const floa
         c.H0B = ws + bl.H0B; c.H0 = H0; c.G0 = G0; c.dn_in = dn; c.VB0w = ws + bl.VB[0]; c.dx = dx;
         const size_t lds = (size_t)3 * 16 * xn.S * 2 + (size_t)16 * lo.d0 * sizeof(float);
         const dim3 grid((Mb + 15) / 16);
-        if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd_x3<1, 1, 16>), grid, dim3(1024), lds, s, c);
+        if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd_x3<1, 1, 16, MV_X3_PD1>), grid, dim3(1024), lds, s, c);
         else hipLaunchKernelGGL((k_chain_bwd_x3<1, 2, 16>), grid, dim3(1024), lds, s, c);
         MV_TRY(hipGetLastError());
         chains_done = true;
@@ -728,10 +735,10 @@ int mvsdf_sdf_backward_pair(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M
             hipLaunchKernelGGL((k_chain_bwd2_x3<2, 4, 8>), grid, dim3(512), lds, s, a, b, na);
         }
         else if (mt == 2) {
-            MV_TRY(hipFuncSetAttribute((const void*)k_chain_bwd2_x3<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_chain_bwd2_x3<2, 1, 16>), grid, dim3(1024), lds, s, a, b, na);
+            MV_TRY(hipFuncSetAttribute((const void*)k_chain_bwd2_x3<2, 1, 16, MV_X3_PD2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_chain_bwd2_x3<2, 1, 16, MV_X3_PD2>), grid, dim3(1024), lds, s, a, b, na);
         }
-        else if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd2_x3<1, 1, 16>), grid, dim3(1024), lds, s, a, b, na);
+        else if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd2_x3<1, 1, 16, MV_X3_PD1>), grid, dim3(1024), lds, s, a, b, na);
         else hipLaunchKernelGGL((k_chain_bwd2_x3<1, 2, 16>), grid, dim3(1024), lds, s, a, b, na);
         return mv_check(hipGetLastError(), "mvsdf_sdf_backward_pair (x3 chains)");
     }

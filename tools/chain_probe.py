@@ -1,4 +1,4 @@
-"""Where does k_chain_fwd spend its time?  Side build of the library with -DMV_CHAIN_PROBE (clock stamps between the phases of workgroup 0, per
+"""Where does k_chain_fwd / k_chain_fwd_x3 (the product default; MVSDF_CHAIN_X3=0 with -DMVSDF_DEV_SWITCHES: the fp32 chain) spend its time?  Side build of the library with -DMV_CHAIN_PROBE (clock stamps between the phases of workgroup 0, per
 wave), the bench step on it, the mean per launch.   python tools/chain_probe.py [c2|c3|c5share]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,7 +34,7 @@ for _ in range(n): step()
 torch.cuda.synchronize()
 L.mv_chain_probe_read(buf, 0)
 a = np.array(list(buf), dtype=np.float64).reshape(16, 16) * 0.01 / n
-names = ['gather + PE + H0', 'V: wait in', 'V: gemm', 'V: wait readers', 'V: epilogue', 'last layer', 'N: wait', 'N: prologue (sigma * u -> LDS)', 'N: wait in', 'N: gemm',
+names = ['gather + PE + H0', 'V: wait in', 'V: gemm', 'V: wait readers', 'V: epilogue', 'last layer', 'N: wait / start', 'N: prologue (fp32 chain) / side loads (x3)', 'N: wait in', 'N: gemm',
          'N: wait readers', 'N: epilogue', 'normal from g0']
 print('workload %s: k_chain_fwd, workgroup 0, us per launch (value chain V, normal chain N)' % wl)
 print('%-34s' % 'phase' + ''.join('  w%-4d' % w for w in (0, 1, 4, 5, 8, 12, 15)) + '   max over waves')
