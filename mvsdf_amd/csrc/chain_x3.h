@@ -645,147 +645,3 @@ __global__ __launch_bounds__(64 * NW) void k_chain_bwd2_x3(ChainArgsX3 a, ChainA
     if ((int)blockIdx.x < na) mv_chain_bwd_body_x3<MT, NTW, NW, PDW>(a, blockIdx.x, smem);
     else mv_chain_bwd_body_x3<MT, NTW, NW, PDW>(b, blockIdx.x - na, smem);
 }
-
-// ---------------------------------------------------------------------------------------------------------------
-// Rendering network (idr.py:145-167) in the same arithmetic: k_render_chain_fwd / k_render_chain_bwd's passes and outputs.
-//   forward : a_0 = cat[points, view, PE(view), normals, feat]; a_{l+1} = relu(a_l W_l^T + b_l); rgb = tanh(a_L W_L^T + b_L); stores a_l, rgb
-//   backward: zb_L = drgb (1 - rgb^2); ab_l = zb_l W_l; zb_{l-1} = ab_l [a_l > 0]; stores zb_l (for the weight gradients) and din = ab_0
-typedef RenderChainArgsT<MvNetBf> RenderChainArgsX3;
-
-template <int MT, int NTW, int NW, int PDW = 0>
-__global__ __launch_bounds__(64 * NW) void k_render_chain_fwd_x3(RenderChainArgsX3 a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int ROWS = 16 * MT, NTH = 64 * NW;
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * ROWS, S16 = a.S, TS = ROWS * S16, nl = a.net.n_layers;
-    uint16_t* act = (uint16_t*)smem;
-    MvX3Ring<MT, NTW, NW, PDW> ring;
-    ring.prep(a.net.L[0].wp, a.net.L[0].KB, a.net.L[0].NT, w, lane);
-    ring.fill();
-    {
-        const int K0 = a.K0, Kp0 = a.net.L[0].KB * 32;
-        for (int idx = tid; idx < ROWS * Kp0; idx += NTH) {
-            const int rr = idx / Kp0, k = idx - rr * Kp0, row = row0 + rr;
-            float v = 0.0f;
-            if (row < a.N && k < K0) { v = mv_render_input(a, row, k); a.A[0][(size_t)row * K0 + k] = v; }
-            mv_x3_put1(act, S16, TS, rr, k, v);
-        }
-    }
-    for (int l = 0; l < nl; ++l) {
-        const MvLayerBf& L = a.net.L[l];
-        const bool last = (l == nl - 1);
-        const int N = L.N;
-        MV_X3_TILES(L)
-        f32x4 acc[MT][NTW];
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const int tile = ct0 + t < NT ? ct0 + t : NT - 1;
-            const f32x4 b4 = *(const f32x4*)(L.bias + tile * 16 + 4 * q);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][t] = b4;
-        }
-        mv_barrier_lds();
-        {
-            const MvLayerBf& Ln = a.net.L[last ? l : l + 1];
-            ring.gemm(L, last ? nullptr : Ln.wp, Ln.KB, Ln.NT, act, S16, TS, ct0, ntw, acc, w, lane);
-        }
-        mv_barrier_lds();
-        const bool vn = (N & 3) == 0;
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            if (t < ntw) {
-                const int col0 = (ct0 + t) * 16 + 4 * q, nv = N - col0;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int rr = m * 16 + r, row = row0 + rr;
-                    f32x4 h;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) h[i] = last ? tanhf(acc[m][t][i]) : fmaxf(acc[m][t][i], 0.0f);
-                    if (last) {
-                        if (row < a.N) { mv_st4(a.rgb + (size_t)row * N + col0, h, false, nv); mv_st4(a.rgb_ctx + (size_t)row * N + col0, h, false, nv); }
-                    } else {
-                        mv_x3_put4(act, S16, TS, rr, col0, h, nv);
-                        if (row < a.N) mv_st4(a.A[l + 1] + (size_t)row * N + col0, h, vn && nv >= 4, nv);
-                    }
-                }
-            }
-        }
-        if (!last) mv_x3_zero_cols<ROWS, NTH>(act, S16, TS, N, a.net.L[l + 1].KB * 32, tid);
-    }
-}
-
-template <int MT, int NTW, int NW, int PDW = 0>
-__global__ __launch_bounds__(64 * NW) void k_render_chain_bwd_x3(RenderChainArgsX3 a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int ROWS = 16 * MT, NTH = 64 * NW;
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * ROWS, S16 = a.S, TS = ROWS * S16, nl = a.net.n_layers;
-    uint16_t* act = (uint16_t*)smem;
-    MvX3Ring<MT, NTW, NW, PDW> ring;
-    ring.prep(a.netT.L[nl - 1].wp, a.netT.L[nl - 1].KB, a.netT.L[nl - 1].NT, w, lane);
-    ring.fill();
-    {   // zb_L = drgb (1 - rgb^2)
-        const int K = a.netT.L[nl - 1].K, Kp = a.netT.L[nl - 1].KB * 32;
-        for (int idx = tid; idx < ROWS * Kp; idx += NTH) {
-            const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
-            float v = 0.0f;
-            if (row < a.N && k < K) {
-                const float y = a.rgbc[(size_t)row * K + k];
-                v = a.drgb[(size_t)(a.drgb_rows ? a.drgb_rows[row] : row) * K + k] * (1.0f - y * y);
-                a.ZB[nl - 1][(size_t)row * K + k] = v;
-            }
-            mv_x3_put1(act, S16, TS, rr, k, v);
-        }
-    }
-    for (int l = nl - 1; l >= 0; --l) {
-        const MvLayerBf& L = a.netT.L[l];                           // contraction over out_l (K), produces in_l columns (N)
-        const int N = L.N, NT = L.NT, per = (NT + NW - 1) / NW;
-        const bool vn = (N & 3) == 0;
-        mv_barrier_lds();
-        // (l > 0: one group of column tiles per wave -- the launcher checks per <= NTW --, the outputs replace the tile; l == 0, N = K0 > 256: several groups, the
-        // outputs go to global memory only)
-        for (int g0 = 0; g0 < per; g0 += NTW) {
-            const int ct0 = w * per + g0;
-            int ntw = min(per - g0, NT - ct0);
-            ntw = ntw < 0 ? 0 : (ntw > NTW ? NTW : ntw);
-            f32x4 am[MT][NTW];                                      // the ReLU masks of this wave's outputs (post-activation values): requested before the matrix instructions
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                const int col0 = (ct0 + t) * 16 + 4 * q, nv = N - col0;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int row = row0 + m * 16 + r;
-                    const bool ok = l > 0 && t < ntw && row < a.N && nv > 0;
-                    am[m][t] = mv_ld4((l > 0 ? a.Ac[l] : a.rgbc) + (ok ? (size_t)row * N + col0 : 0), ok && vn && nv >= 4, ok ? nv : 0);
-                }
-            }
-            f32x4 acc[MT][NTW];
-            mv_zero_acc<MT, NTW>(acc);
-            if (l > 0) {
-                const MvLayerBf& Ln = a.netT.L[l - 1];
-                ring.gemm(L, l > 1 ? Ln.wp : nullptr, Ln.KB, Ln.NT, act, S16, TS, ct0, ntw, acc, w, lane);     // (the first layer's groups fetch their own)
-                mv_barrier_lds();
-            } else if constexpr (PDW > 0 && NTW == 1) {             // (two k-blocks in flight: the carried ring's registers are still allocated)
-                if (ntw > 0) mv_gemm_rolling_bw<MT, 1, NTW, 2, 3, 3>(L.KB, act, S16, TS, L.wp + (size_t)ct0 * L.KB * 3 * 64 + lane, acc, lane);
-            } else mv_x3_gemm<MT, NTW>(L, act, S16, TS, ct0, ntw, acc, lane);
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                if (t < ntw) {
-                    const int col0 = (ct0 + t) * 16 + 4 * q, nv = N - col0;
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const int rr = m * 16 + r, row = row0 + rr;
-                        if (l > 0) {
-                            f32x4 zb;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) zb[i] = (row < a.N && i < nv && am[m][t][i] > 0.0f) ? acc[m][t][i] : 0.0f;   // relu mask: stored post-activation > 0
-                            mv_x3_put4(act, S16, TS, rr, col0, zb, nv);
-                            if (row < a.N && nv > 0) mv_st4(a.ZB[l - 1] + (size_t)row * N + col0, zb, vn && nv >= 4, nv);
-                        } else if (row < a.N && nv > 0) mv_st4(a.din + (size_t)row * N + col0, acc[m][t], vn && nv >= 4, nv);
-                    }
-                }
-            }
-        }
-        if (l > 0) mv_x3_zero_cols<ROWS, NTH>(act, S16, TS, N, a.netT.L[l - 1].KB * 32, tid);
-    }
-}

@@ -974,20 +974,6 @@ int mvsdf_render_forward(const MvsdfNetDesc* d, const float* points, const float
     static int fuse_r = -1;
     if (fuse_r < 0) { const char* e = mv_dev_env("MVSDF_FUSE"); fuse_r = e ? atoi(e) : 1; }
     const int ntw_r = mv_chain_ntw(net);
-    MvNetBf xn;
-    if (fuse_r && ntw_r && net.L[nl - 1].NT <= 2 && mv_chain_x3_on() && !mv_make_net_x3(d, &xn)) {     // ... in the three-term bf16 arithmetic (chain_x3.h)
-        RenderChainArgsX3 c;
-        memset(&c, 0, sizeof(c));
-        c.net = xn; c.S = xn.S; c.N = N; c.mv = multires_view; c.K0 = K0;
-        c.points = points; c.view = view; c.normals = normals; c.feat = feat; c.ldfeat = ldfeat;
-        for (int l = 0; l < nl; ++l) c.A[l] = ctx + lo.A[l];
-        c.rgb_ctx = ctx + lo.rgb; c.rgb = rgb;
-        const dim3 grid((N + 15) / 16);
-        const size_t ldsr = (size_t)3 * 16 * xn.S * 2;
-        if (ntw_r == 2) hipLaunchKernelGGL((k_render_chain_fwd_x3<1, 1, 16, MV_X3_PD1>), grid, dim3(1024), ldsr, s, c);
-        else hipLaunchKernelGGL((k_render_chain_fwd_x3<1, 2, 16>), grid, dim3(1024), ldsr, s, c);
-        return mv_check(hipGetLastError(), "mvsdf_render_forward (x3 chain)");
-    }
     if (fuse_r && ntw_r && net.L[nl - 1].NT <= 2) {                                // the whole network in one launch per row tile
         RenderChainArgs c;
         memset(&c, 0, sizeof(c));
@@ -1022,8 +1008,8 @@ int mvsdf_render_forward(const MvsdfNetDesc* d, const float* points, const float
 }  // extern "C"
 
 // the descending chain of the rendering net's backward: drgb[N][3] -> per-layer adjoints in `ws` + din[N][K0]
-static int render_backward_chain(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const MvNet& net, const MvNet& netT, int N, int Nctx, const float* drgb, const float* ctx,
-                                 float* din, float* ws, hipStream_t s, const long long* drgb_rows = nullptr) {
+static int render_backward_chain(const MvNet& net, const MvNet& netT, int N, int Nctx, const float* drgb, const float* ctx, float* din, float* ws,
+                                 hipStream_t s, const long long* drgb_rows = nullptr) {
     const int nl = net.n_layers, S = stride_for(net, netT);
     const RenderLayout lo = render_layout(net, Nctx);        // the forward context holds Nctx rows; the backward covers the first N
     const RenderBwdLayout bl = render_bwd_layout(net, N);
@@ -1032,19 +1018,6 @@ static int render_backward_chain(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, 
     const int ntw_rb = mv_chain_ntw(net);
     bool fused_bwd = fuse_rb && ntw_rb;
     for (int l = 1; l < nl; ++l) fused_bwd = fused_bwd && netT.L[l].NT <= 8 * ntw_rb;   // one column-tile group per wave above the first layer
-    MvNetBf xn, xnT;
-    if (fused_bwd && !mv_x3_nets(d, dT, true, &xn, &xnT)) {                       // ... in the three-term bf16 arithmetic (chain_x3.h)
-        RenderChainArgsX3 c;
-        memset(&c, 0, sizeof(c));
-        c.net = xn; c.netT = xnT; c.S = xn.S; c.N = N; c.K0 = net.L[0].K;
-        c.drgb = drgb; c.rgbc = ctx + lo.rgb; c.din = din; c.drgb_rows = drgb_rows;
-        for (int l = 0; l < nl; ++l) { c.Ac[l] = ctx + lo.A[l]; c.ZB[l] = ws + bl.ZB[l]; }
-        const dim3 grid((N + 15) / 16);
-        const size_t ldsr = (size_t)3 * 16 * xn.S * 2;
-        if (ntw_rb == 2) hipLaunchKernelGGL((k_render_chain_bwd_x3<1, 1, 16, 2>), grid, dim3(1024), ldsr, s, c);
-        else hipLaunchKernelGGL((k_render_chain_bwd_x3<1, 2, 16>), grid, dim3(1024), ldsr, s, c);
-        MV_TRY(hipGetLastError());
-    } else
     if (fused_bwd) {
         RenderChainArgs c;
         memset(&c, 0, sizeof(c));
@@ -1101,7 +1074,7 @@ int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, 
     if (rc) return rc;
     if (!drgb || !ctx || !dW_cat || !db_cat || !din || !ws || N <= 0 || Nctx < N) return mv_fail(-1, "mvsdf_render_backward: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    rc = render_backward_chain(d, dT, net, netT, N, Nctx, drgb, ctx, din, ws, s);
+    rc = render_backward_chain(net, netT, N, Nctx, drgb, ctx, din, ws, s);
     if (rc) return rc;
     const RenderLayout lo = render_layout(net, Nctx);
     const RenderBwdLayout bl = render_bwd_layout(net, N);
@@ -1126,7 +1099,7 @@ int mv_render_backward_chain(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int 
     rc = mv_make_net_mode(dT, &netT, 2);
     if (rc) return rc;
     if (!drgb || !ctx || !din || !ws || N <= 0 || Nctx < N) return mv_fail(-1, "mv_render_backward_chain: bad arguments");
-    rc = render_backward_chain(d, dT, net, netT, N, Nctx, drgb, ctx, din, ws, (hipStream_t)stream, drgb_rows);
+    rc = render_backward_chain(net, netT, N, Nctx, drgb, ctx, din, ws, (hipStream_t)stream, drgb_rows);
     return rc ? rc : mv_check(hipGetLastError(), "mv_render_backward_chain");
 }
 

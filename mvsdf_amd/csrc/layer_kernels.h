@@ -1192,16 +1192,14 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd(FwdArgs a) {
 // Rendering network (idr.py:145-167, mode 'idr') as one forward and one backward launch per 16*MT rows.
 //   forward : a_0 = cat[points, view, PE(view), normals, feat]; a_{l+1} = relu(a_l W_l^T + b_l); rgb = tanh(a_L W_L^T + b_L); stores a_l, rgb
 //   backward: zb_L = drgb (1 - rgb^2); ab_l = zb_l W_l; zb_{l-1} = ab_l [a_l > 0]; stores zb_l (for the weight gradients) and din = ab_0
-template <class NET>
-struct RenderChainArgsT {
-    NET net, netT;
+struct RenderChainArgs {
+    MvNet net, netT;
     int S, N, mv, K0;
     const float* points; const float* view; const float* normals; const float* feat; int ldfeat;   // forward inputs
     float* A[MV_MAXL]; float* rgb_ctx; float* rgb;                                                   // forward outputs
     const float* drgb; const float* Ac[MV_MAXL]; const float* rgbc; float* ZB[MV_MAXL]; float* din;  // backward
     const long long* drgb_rows;                // backward: row r reads drgb[drgb_rows[r]] (null: drgb[r]) -- the step's upstream arrives in ray order, the net ran on sorted rows
 };
-typedef RenderChainArgsT<MvNet> RenderChainArgs;
 
 // `mv` packs the input layout of RenderingNetwork.forward (idr.py:145-154): low 8 bits = multires_view; bit 8 set = mode 'no_view_dir'
 // (cat[points, normals, feat]); bit 9 set = mode 'no_normal' (cat[points, PE(view), feat]); neither = mode 'idr'.
@@ -1222,8 +1220,7 @@ __device__ __forceinline__ float mv_render_input_raw(const float* points, const 
     if (k < 3 + dv + dn) return normals[(size_t)row * 3 + (k - 3 - dv)];
     return feat[(size_t)row * ldfeat + (k - 3 - dv - dn)];
 }
-template <class NET>
-__device__ __forceinline__ float mv_render_input(const RenderChainArgsT<NET>& a, int row, int k) {
+__device__ __forceinline__ float mv_render_input(const RenderChainArgs& a, int row, int k) {
     return mv_render_input_raw(a.points, a.view, a.normals, a.feat, a.ldfeat, a.mv, row, k);
 }
 

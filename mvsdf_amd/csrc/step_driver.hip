@@ -66,7 +66,7 @@ void make_descs(const Step& st, const MvsdfStepParams* prm, const char* fwd, Mvs
             o->bias[i] = oT->bias[i] = prm->b[l];
             o->w[i] = oT->w[i] = (const float*)(fwd + st.fo.w[l]);
             if (is_sdf && d.trace_dtype != 0) o->wp16[i] = fwd + st.fo.wp16[l];
-            if (st.fo.chain_x3) { o->wx3[i] = fwd + st.fo.wx3[l]; oT->wx3[i] = fwd + st.fo.wx3T[l]; }
+            if (is_sdf && st.fo.chain_x3) { o->wx3[i] = fwd + st.fo.wx3[l]; oT->wx3[i] = fwd + st.fo.wx3T[l]; }
         }
         if (is_sdf) {
             const unsigned m = d.skip_mask;
@@ -159,8 +159,8 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
         } else if (l < d.n_sdf && d.trace_dtype == 5) {
             fo.wp16[l] = take(3 * mvsdf_packed_bf16_bytes(d.N[l], d.K[l], 0));  // ... and so are the fp32 weights (three terms)
         }
-        if (fo.chain_x3) {                                                    // the differentiable chains' three-term packs, both networks (SDF layers: the tracer's own under trace_dtype 5)
-            fo.wx3[l] = (l < d.n_sdf && d.trace_dtype == 5) ? fo.wp16[l] : take(3 * mvsdf_packed_bf16_bytes(d.N[l], d.K[l], 0));
+        if (l < d.n_sdf && fo.chain_x3) {                                     // the differentiable chains' three-term packs (the tracer's own under trace_dtype 5)
+            fo.wx3[l] = d.trace_dtype == 5 ? fo.wp16[l] : take(3 * mvsdf_packed_bf16_bytes(d.N[l], d.K[l], 0));
             fo.wx3T[l] = take(3 * mvsdf_packed_bf16_bytes(d.K[l], d.N[l], 0));
         }
     }
@@ -287,8 +287,8 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
         for (int l = 0; l < nl; ++l) {
             const bool bf = l < d.n_sdf && d.trace_dtype != 0;
             wp16[l] = bf ? (void*)(fwd + fo.wp16[l]) : nullptr;
-            const bool x3 = fo.chain_x3 != 0;
-            wx3[l] = (x3 && !(l < d.n_sdf && d.trace_dtype == 5)) ? (void*)(fwd + fo.wx3[l]) : nullptr;       // (trace_dtype 5: the tracer's pack IS the SDF layers' pack)
+            const bool x3 = l < d.n_sdf && fo.chain_x3;
+            wx3[l] = (x3 && d.trace_dtype != 5) ? (void*)(fwd + fo.wx3[l]) : nullptr;       // (trace_dtype 5: the tracer's pack IS this pack)
             wx3T[l] = x3 ? (void*)(fwd + fo.wx3T[l]) : nullptr;
             nsplit[l] = 0;                                        // (duplicated hi / lo input columns: the removed trace_dtype 1 only)
         }

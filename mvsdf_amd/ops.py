@@ -252,8 +252,8 @@ def pack_net(vs, gs, biases, skip_layer, multires, want_t=True, x3=None):
 
 
 def maybe_pack_x3_chain(net):
-    """pack_x3_chain (the SDF network AND the rendering network: both run their fused chains on the bf16 matrix cores when the packs exist)."""
-    if CHAIN_X3 and len(net.layers) >= 2:
+    """pack_x3_chain for SDF networks (first Linear over the positional encoding of a 3-D point); the rendering network's chains stay on the fp32-input MFMA."""
+    if CHAIN_X3 and len(net.layers) >= 2 and net.layers[0].K == 3 + 6 * max(net.multires, 0):
         pack_x3_chain(net)
     return net
 
