@@ -157,3 +157,24 @@ def test_backward_rejects_upstream_of_the_wrong_width():
         ops.sdf_backward(net, x, 40, 40, 40, torch.zeros(40, y.shape[1] - 1).cuda(), None, ctx, True)
     with pytest.raises(ValueError, match='dn must be'):
         ops.sdf_backward(net, x, 40, 40, 40, torch.zeros_like(y), torch.zeros(39, 3).cuda(), ctx, True)
+
+
+def test_transposed_three_term_pack_equals_the_pack_of_the_transposed_matrix():
+    """mvsdf_pack_bf16x3t_net (the W_l^T packs of the x3 chains, MvsdfNetDesc.wx3 of the transposed descriptor) must write what mvsdf_pack_bf16x3_net writes
+    for the explicitly transposed matrix -- ragged shapes included (39 x 64, 217 x 256, 258 x 256: partial column tiles and k-blocks, zero padding)."""
+    import ctypes as C
+    from mvsdf_amd._lib import check, lib, stream_of
+    gen = torch.Generator().manual_seed(3)
+    ws = [torch.randn(n, k, generator=gen).cuda() for n, k in ((64, 39), (217, 256), (258, 256), (3, 64))]
+    wts = [w.t().contiguous() for w in ws]
+    n = len(ws)
+    N = (C.c_int * n)(*[w.shape[0] for w in ws]); K = (C.c_int * n)(*[w.shape[1] for w in ws])
+    Nt = (C.c_int * n)(*[w.shape[0] for w in wts]); Kt = (C.c_int * n)(*[w.shape[1] for w in wts])
+    size = lambda nn, kk: 3 * lib().mvsdf_packed_bf16_bytes(nn, kk, 0)
+    a = [torch.full((size(w.shape[1], w.shape[0]),), 0x5a, dtype=torch.uint8, device='cuda') for w in ws]       # pack of W^T through the transposing entry point
+    b = [torch.full((size(w.shape[0], w.shape[1]),), 0xa5, dtype=torch.uint8, device='cuda') for w in wts]     # pack of the explicit transpose
+    s = stream_of(ws[0])
+    check(lib().mvsdf_pack_bf16x3t_net(n, ops._ptr_array(ws), N, K, ops._ptr_array(a), s), 'mvsdf_pack_bf16x3t_net')
+    check(lib().mvsdf_pack_bf16x3_net(n, ops._ptr_array(wts), Nt, Kt, ops._ptr_array(b), s), 'mvsdf_pack_bf16x3_net')
+    for l in range(n):
+        assert a[l].numel() == b[l].numel() and torch.equal(a[l], b[l]), l

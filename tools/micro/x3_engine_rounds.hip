@@ -85,6 +85,7 @@ int main(int argc, char** argv) {
         if (e != hipSuccess) printf("error: %s\n", hipGetErrorString(e));
     };
     run(k_rounds<1, 2, true>, 1, "carried (k_sphere_trace) MT=1");
+    run(k_rounds<1, 1, true, 16>, 1, "carried 16 waves x 1 tile MT=1", 1024);
     run(k_rounds<1, 2, false>, 1, "rolling MT=1");
     run(k_rounds<2, 2, true>, 2, "carried MT=2");
     run(k_rounds<2, 2, false>, 2, "rolling MT=2");
