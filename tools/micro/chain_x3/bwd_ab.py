@@ -51,3 +51,5 @@ if __name__ == '__main__':
     run(256, 3100)
     run(256, 6200)
     run(512, 1500)
+    run(64, 301)            # odd row counts x odd widths: the saved tensors' bases are only 4-byte aligned
+    run(64, 77, (3, 6))
