@@ -296,7 +296,8 @@ __global__ __launch_bounds__(64 * NW) void k_chain_fwd_x3(FwdArgsX3 a) {
     CH_PH(5)
     if (row0 >= a.Mg) return;                                       // workgroup-uniform: no normals for these rows
     // ---- normal chain (rows >= Mg inside the tile carry zeros).  u_L = W_L[0, :]; with a skip into the last Linear its PE part starts the PE adjoint.
-    mv_barrier_lds();                                               // every wave done reading the last layer's input
+    __syncthreads();                                                // every wave done reading the last layer's input -- and (vmcnt(0)) every sigma_l of this tile stored: the
+                                                                    // normal chain reads them back (each lane its own elements, but nothing here should rest on that)
     {
         const MvLayerBf& L = a.net.L[nl - 2];
         MV_X3_TILES(L)
