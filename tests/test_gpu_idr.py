@@ -114,7 +114,7 @@ def test_forward_loss_backward_vs_reference(name, monkeypatch):
     # forward noise of zero (the features / normals it is computed from agree with the reference to ~2e-6), an implementation with another fp32 summation order
     # may take the other branch for that one (row, unit): the value is continuous, the mask is not -- one row's contribution to that unit's gradient flips and
     # moves the entries of the (small: ~1e-8 per entry) gradients of that layer and the layers below it by up to ~1e-2 of their scale (measured at idr_w512 with
-    # the three-term chains: unit 397 of layer 1, margin 6.2e-8, 4.1e-3 on layer 0; every other entry of every parameter <= 5e-6).  Those layers get 2e-2 on
+    # the three-term chains: unit 397 of layer 1, margin 6.2e-8, 4.1e-3 on layer 0; every other entry of every parameter <= 5e-6).  Those layers get 1e-2 on
     # their sampled entries; their gradient NORMS and every other parameter keep the bounds below.
     relu_m = golden('idr_relu_margins')[name] if name in golden('idr_relu_margins').files else None
     def tie_below(k):
@@ -137,7 +137,7 @@ def test_forward_loss_backward_vs_reference(name, monkeypatch):
             worst = max(worst, dev)
     print('%s: worst sampled gradient entry deviation %.3g of the scale (%.3g on the rendering layers at / below a recorded ReLU tie)' % (name, worst, worst_tie))
     assert worst < 1e-3, worst                                                    # measured: <= 1.2e-4 (idr_c3), <= 2.1e-5 on the other fixtures
-    assert worst_tie < 2e-2, worst_tie                                            # measured: 4.1e-3 (idr_w512), <= 1e-4 elsewhere
+    assert worst_tie < 1e-2, worst_tie                                            # measured: 4.1e-3 (idr_w512), <= 2.4e-5 elsewhere
 
 
 def test_eval_mode_and_public_methods():
