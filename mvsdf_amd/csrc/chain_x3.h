@@ -89,11 +89,11 @@ __device__ __forceinline__ void mv_x3_gemm(const MvLayerBf& L, const uint16_t* a
     if (ntw > 0) mv_gemm_rolling_dispatch_bw<MT, NTW, 3, 3, (NTW == 1)>(L.KB, act, S16, TS, L.wp + (size_t)ct0 * L.KB * 3 * 64 + lane, ntw, acc, lane);
 }
 
-// Measured and not kept (tools/micro/chain_x3/fwd_probe.py, 3100 rows of the 8x256 network, one 16-row tile per CU): tile_engine_bf16s.h's CARRIED weight ring
-// (the next phase's first k-blocks requested inside the current phase) as 8 waves x 2 column tiles: the matrix loops 4.6 -> 3.8 us per phase, the epilogues (a
-// wave's loads / stores of the saved tensors, latency-bound per wave) 1.0 -> 2.7 us: 112 -> 136 us; as 16 waves x 1 tile it does not fit 128 registers (231 us).
-// Non-temporal stores of the saved tensors: 112 -> 129 us (sigma_l is re-read by the normal chain of the same launch).  Non-temporal weight loads: 164 us.
-// Without any store: 100 us.  A phase's matrix loop is the 393 KB weight stream at ~85 GB/s per CU (half of the L2's rate: the ring drains at every phase end).
+// Measured (tools/micro/chain_x3/fwd_probe.py, 3100 rows of the 8x256 network, one 16-row tile per CU).  With the rolling weight fetch a phase's matrix loop is the 393 KB
+// weight stream at ~85 GB/s per CU (half of what the L2 delivers to the tracer's continuously running ring: a chain's ring drains at every phase end): 4.6 us per phase,
+// 111 us per launch.  With tile_engine_bf16s.h's CARRIED ring (below) as 16 waves x 1 tile, four k-blocks deep: 3.4 us per phase, 97 us; two k-blocks 99, three 102; as 8
+// waves x 2 tiles 103 (a wave's epilogue -- its loads / stores of the saved tensors -- is latency-bound per wave: 16 waves halve it).  Not kept: non-temporal stores of the
+// saved tensors (112 -> 129 us: sigma_l is re-read by the normal chain of the same launch), non-temporal weight loads (164 us).  Without any store: 100 us.
 
 // The weight fetch of a chain of phases.  PDW > 0 (hidden width <= 256, one column tile per wave): tile_engine_bf16s.h's CARRIED ring -- the first PDW k-blocks of
 // the NEXT phase's weight fragments are requested by the slots of the current phase's matrix loop that have no k-block of their own left, and land under its
