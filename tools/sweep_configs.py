@@ -12,9 +12,9 @@ from mvsdf_amd.utils.config import ConfigDict
 dev = torch.device('cuda', 0)
 t = lambda d: {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in d.items()}
 cfgs = [  # W, B, P, V, tp, dtype
-    (256, 8, 256, 4, 0.3, 'f32'), (256, 8, 256, 4, 0.05, 'f32'), (256, 8, 256, 4, 0.7, 'bf16'), (256, 1, 2048, 4, 0.3, 'f32'),
-    (256, 8, 1024, 8, 0.3, 'f32'), (256, 8, 2048, 8, 0.3, 'bf16'), (256, 8, 4096, 8, 0.3, 'bf16'), (512, 8, 256, 2, 0.3, 'f32'),
-    (512, 8, 512, 2, 0.3, 'bf16'), (64, 3, 37, 2, 0.3, 'f32'), (128, 2, 1000, 3, 0.3, 'bf16'),
+    (256, 8, 256, 4, 0.3, 'f32'), (256, 8, 256, 4, 0.05, 'f32'), (256, 8, 256, 4, 0.7, 'bf16x2'), (256, 1, 2048, 4, 0.3, 'f32'),
+    (256, 8, 1024, 8, 0.3, 'f32'), (256, 8, 2048, 8, 0.3, 'bf16x2'), (256, 8, 4096, 8, 0.3, 'f32x3'), (512, 8, 256, 2, 0.3, 'f32'),
+    (512, 8, 512, 2, 0.3, 'f32x3'), (64, 3, 37, 2, 0.3, 'f32'), (128, 2, 1000, 3, 0.3, 'f32x3'), (384, 2, 700, 3, 0.3, 'f32x3'), (320, 4, 2100, 2, 0.3, 'f32x3'),
 ]
 for (W, B, P, V, tp, dt) in cfgs:
     model = IDRNetwork(ConfigDict(synth.model_conf(W)))
