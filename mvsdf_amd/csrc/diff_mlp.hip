@@ -323,8 +323,12 @@ static int mv_chain_mt_x3(int tiles16) {
 // k_chain_fwd_x3 111 -> 97 us, the c2 step 1.503 -> 1.485 ms.  Two row tiles: 0 (the rolling fetch): with 2 the c5-share step went 1.51-1.55 -> 1.57-1.61 ms and c3
 // 4.04 -> 4.20 ms -- at those sizes the sample rows' chain runs BESIDE the tracer (mv_chain_split_pays), and a chain that keeps the L2 busy through its epilogues
 // takes that bandwidth from the tracer's own weight stream (k_ray_samples 0.446 -> 0.478 ms, k_sphere_trace 1.17 -> 1.27 ms at c3).
+#ifndef MV_X3_PD1
 #define MV_X3_PD1 4
+#endif
+#ifndef MV_X3_PD2
 #define MV_X3_PD2 0
+#endif
 
 #define MV_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mv_check(e_, #expr); } while (0)
 
