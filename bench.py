@@ -192,17 +192,21 @@ def self_launch(a):
 _PMC = None
 
 
-def pmc_entry(workload, dtype, width):
-    """The PMC record of this exact command (workload, tracing dtype, width) from profiles/pmc_traffic.json, or None.  tools/pmc_to_json.py writes the
-    file from separate --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 5 --warmup 2 --no-cpu-baseline [...]` (2 x FETCH_SIZE KB + WRITE_SIZE KB
-    per the guide's gfx950 correction); the counters cannot be read from inside the process."""
+def pmc_entry(workload, dtype, width, scaling='weak', rays=None):
+    """The PMC record of this exact command (workload, tracing dtype, width, scaling mode, rays per GPU) from profiles/pmc_traffic.json, or None when no
+    PMC pass of that command exists (a strong-scaling line must not carry the weak c2 step's traffic).  tools/pmc_to_json.py writes the file from separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 5 --warmup 2 --no-cpu-baseline [...]` (2 x FETCH_SIZE KB + WRITE_SIZE KB per the guide's
+    gfx950 correction); the counters cannot be read from inside the process."""
     global _PMC
     if _PMC is None:
         try:
             _PMC = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
         except (OSError, ValueError):
             _PMC = {}
-    return _PMC.get('entries', {}).get('%s|%s|%d' % (workload, dtype, width))
+    e = _PMC.get('entries', {}).get('%s|%s|%d|%s' % (workload, dtype, width, scaling))
+    if e is not None and rays is not None and e.get('rays_per_gpu') not in (None, rays):
+        return None
+    return e
 
 
 def pmc_traffic(entry, kernel):
@@ -308,20 +312,38 @@ def main():
     inp, gt = make_inputs(dev, srank, sworld, P, V)
 
     grad_events = None                                           # set to a list during the extra steps: (start, end) events around the gradient all-reduce
+    sect = None                                                  # set to a dict during the extra steps: host seconds per section + (start, end) events around the optimiser calls
 
     def step():
-        opt.zero_grad()
+        # idr_train.py:253-315 without its per-step print: with the deferred step (IDRNetwork.deferred_step, the default) nothing below waits for the GPU
+        if sect is None:
+            opt.zero_grad()
+            out = model(inp, TP)
+            lo = loss_fn(out, dict(gt), TP, per)
+            opt.backward(lo['loss'])                             # loss.backward() with the direct gradient sink (one launch for all dv/dg/db)
+            opt.all_reduce_mean(defer_scale=True)                # ONE all-reduce(SUM) of the flat gradient buffer; / world inside Adam
+            opt.step(grad_cap=2.0)                               # grad-norm + clip + Adam (idr_train.py:289-302, conf.grad_cap)
+            return out, lo
+        # the same calls with the host's clock between them and HIP events (launch stream) around the optimiser's launches
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        t0 = time.perf_counter()
+        ev[0].record(); opt.zero_grad(); ev[1].record()
+        t1 = time.perf_counter()
         out = model(inp, TP)
+        t2 = time.perf_counter()
         lo = loss_fn(out, dict(gt), TP, per)
-        opt.backward(lo['loss'])                                 # loss.backward() with the direct gradient sink (one launch for all dv/dg/db)
+        t3 = time.perf_counter()
+        opt.backward(lo['loss'])
+        t4 = time.perf_counter()
+        ev[2].record(); opt.all_reduce_mean(defer_scale=True); ev[3].record()
+        t5 = time.perf_counter()
+        ev[4].record(); opt.step(grad_cap=2.0); ev[5].record()
+        t6 = time.perf_counter()
+        for k, v in (('zero_grad', t1 - t0), ('forward', t2 - t1), ('loss', t3 - t2), ('backward', t4 - t3), ('all_reduce', t5 - t4), ('optimizer', t6 - t5)):
+            sect['host'][k] = sect['host'].get(k, 0.0) + v
+        sect['events'].append(ev)
         if grad_events is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        opt.all_reduce_mean(defer_scale=True)                    # ONE all-reduce(SUM) of the flat gradient buffer; / world inside Adam
-        if grad_events is not None:
-            ev[1].record()
-            grad_events.append(ev)
-        opt.step(grad_cap=2.0)                                   # grad-norm + clip + Adam (idr_train.py:289-302, conf.grad_cap)
+            grad_events.append((ev[2], ev[3]))
         return out, lo
 
     torch.manual_seed(srank)                                     # ranks draw different eikonal points / min-sdf steps
@@ -330,13 +352,18 @@ def main():
     if under_launcher:
         dist.barrier()
     torch.cuda.synchronize()
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    g0.record()                                                  # GPU-side clock of the same region (launch stream): first launch of step 1 .. last launch of step K
     for _ in range(a.steps):
         out, lo = step()
+    g1.record()
+    t_host = time.perf_counter() - t0                            # the host is done enqueueing here; the GPU may still be steps behind (deferred step)
     if under_launcher:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gpu_ms = g0.elapsed_time(g1) / a.steps
     ranks = None
     if under_launcher:
         mine = torch.tensor([dt, float(local)], device=dev, dtype=torch.float64)
@@ -357,6 +384,9 @@ def main():
     if under_launcher:                                           # ... and of the two collectives (HIP events on the compute stream around each call)
         grad_events = []
         loss_fn.collective_events = []
+    from mvsdf_amd import native_step as NS
+    sect = {'host': {}, 'events': []}
+    NS.loss_timing = []
     if st_native is not None:
         st_native.set_timing(True)
         for _ in range(nt):
@@ -378,6 +408,19 @@ def main():
         ms_diff_fwd = ms_diff_bwd = None
         ms_sphere = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
         ms_samples = float(np.mean([e[1].elapsed_time(e[2]) + e[3].elapsed_time(e[4]) if len(e) == 5 else e[1].elapsed_time(e[2]) for e in events]))
+    # time of the step's own launches: HIP events on the launch stream around each C call (every call enqueues all its launches in tens of microseconds, so
+    # the distance between its two events is kernel time) -- forward (fold .. output gather), IDRLoss, backward, gradient collective, optimiser, zero_grad
+    torch.cuda.synchronize()
+    evs = sect['events']
+    loss_ms = [e0.elapsed_time(e1) for e0, e1 in NS.loss_timing]
+    NS.loss_timing = None
+    evm = lambda i, j: float(np.mean([e[i].elapsed_time(e[j]) for e in evs])) if evs else None
+    host_ms = {k: v / max(1, len(evs)) * 1e3 for k, v in sect['host'].items()}
+    kernel_parts = None
+    if tms and evs:
+        kernel_parts = {'forward': float(np.mean([t_[5] for t_ in tms])), 'loss': float(np.mean(loss_ms)) if loss_ms else None,
+                        'backward': float(np.mean([t_[4] for t_ in tms])), 'all_reduce': evm(2, 3) if world > 1 else 0.0, 'optimizer': evm(4, 5), 'zero_grad': evm(0, 1)}
+    sect = None
     collective_ms = None
     if under_launcher:
         torch.cuda.synchronize()
@@ -424,7 +467,7 @@ def main():
         ms_feat = e0.elapsed_time(e1) / 20
         feat_bytes = 512 * pts.shape[0] * (1 + V)
         total_R = world * R
-        pmc = pmc_entry(a.workload, a.dtype, a.width) if world == 1 else None
+        pmc = pmc_entry(a.workload, a.dtype, a.width, a.scaling, R) if world == 1 else None
         # the differentiable half (fp32 arithmetic; its SDF chains as three bf16 terms per value since round 5): value + normal forward of every evaluated row, rendering net, their backward incl. the second-order SDF
         # pass and the weight gradients = the formula's non-T terms; time = HIP events around the forward behind the tracer and around mvsdf_step_backward
         # (no bubbles on the stream: the distances are kernel time; at c3 / the c5 share the E sample rows run beside the tracer and are not in it)
@@ -450,13 +493,16 @@ def main():
                        'rays_per_gpu': R, 'rays_total': total_R, 'hits_total': hits_total, 'grad_norm_after_all_reduce': grad_norm, 'views_total': B, 'src_views': V, 'sdf_width': W, 'train_progress': TP,
                        'feature_maps': '32x%dx%d channels-last' % FEAT_HW,
                        'parallelism': 'views sharded over %d rank(s), depth maps replicated; one all-reduce(SUM) on the flat grad buffer (+ 3 loss counts)' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_ray_samples (fused 9-layer tracing MLP on the sampler / secant / min-sdf rows)', 'achieved': ach,
-                         'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                         'traffic': pmc_traffic(pmc, 'k_ray_samples'),
-                         'rows_per_launch': rows_samples / n_launch, 'flop_per_row': f_t, 'avg_launch_ms': ms_samples / n_launch,
-                         'launches_per_step': n_launch,
+            # the DOMINANT kernel of this run: whichever of the two tracing-MLP kernels took longer per step (k_sphere_trace: 1 launch, k_ray_samples: 3)
+            'roofline': dict({'bound': 'mfma'}, **({
+                             'kernel': 'k_sphere_trace (fused 9-layer tracing MLP inside the sphere-tracing state machine, ray_tracing.py:101-196)', 'achieved': ach_sphere,
+                             'peak': peak, 'unit': 'TFLOP/s', 'frac': ach_sphere / peak, 'traffic': pmc_traffic(pmc, 'k_sphere_trace'),
+                             'rows_per_launch': rows_sphere, 'flop_per_row': f_t, 'avg_launch_ms': ms_sphere, 'launches_per_step': 1} if ms_sphere >= ms_samples else {
+                             'kernel': 'k_ray_samples (fused 9-layer tracing MLP on the sampler / secant / min-sdf rows)', 'achieved': ach,
+                             'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': pmc_traffic(pmc, 'k_ray_samples'),
+                             'rows_per_launch': rows_samples / n_launch, 'flop_per_row': f_t, 'avg_launch_ms': ms_samples / n_launch, 'launches_per_step': n_launch}),
                          # the two tracing-MLP kernels side by side (they take about the same time at this size)
-                         'kernels': {
+                         kernels={
                              'k_ray_samples': {'rows_per_step': rows_samples, 'ms_per_step': ms_samples, 'achieved': ach, 'frac': ach / peak},
                              'tracing (k_ray_samples + k_sphere_trace)': {'rows_per_step': rows_samples + rows_sphere, 'ms_per_step': ms_samples + ms_sphere,
                                                                           'achieved': ach_both, 'frac': ach_both / peak},
@@ -466,11 +512,23 @@ def main():
                              'k_feat_corr': {'bound': 'hbm', 'points': int(pts.shape[0]), 'views_per_point': 1 + V, 'bytes': feat_bytes, 'ms': ms_feat,
                                              'achieved_GBps': feat_bytes / (ms_feat * 1e-3) / 1e9, 'peak_GBps': 8000.0,
                                              'traffic': pmc_traffic(pmc, 'k_feat_corr')}},
-                         'step': {'T_trace_rows': T, 'T_reference_rows': T_ref, 'R': R, 'E': E, 'N_hit': N, 'flops_step': flops_step,
-                                  'achieved': flops_step / (dt / a.steps) / 1e12, 'frac': flops_step / (dt / a.steps) / 1e12 / peak,
-                                  'hbm_bytes': pmc_step_bytes(pmc), 'pmc_source': None if pmc is None else pmc.get('note')}},
+                         step={'T_trace_rows': T, 'T_reference_rows': T_ref, 'R': R, 'E': E, 'N_hit': N, 'flops_step': flops_step,
+                               'achieved': flops_step / (dt / a.steps) / 1e12, 'frac': flops_step / (dt / a.steps) / 1e12 / peak,
+                               'hbm_bytes': pmc_step_bytes(pmc), 'pmc_source': None if pmc is None else pmc.get('note')}),
             'loss': float(lo['loss'].detach()),
         }
+        # Does the wall clock of the timed region equal the GPU's own time?  gpu_ms_per_step: two HIP events on the launch stream around the K timed steps.
+        # kernel_ms_per_step: sum over one step's C calls of the event distance around each (measured over the 20 extra steps; inside a call the launches are
+        # back to back).  gpu_idle_frac = 1 - kernel / gpu: the share of the timed region in which the stream had nothing to run (a host that cannot keep up).
+        # host_ms: host clock per section of a step (enqueue cost; with the deferred step none of them waits for the GPU) and in the whole timed loop.
+        kms = None
+        if kernel_parts is not None and all(v is not None for v in kernel_parts.values()):
+            kms = sum(kernel_parts.values())
+        res['timing'] = {'gpu_ms_per_step': gpu_ms, 'kernel_ms_per_step': kms, 'gpu_idle_frac': None if kms is None else max(0.0, 1.0 - kms / gpu_ms),
+                         'wall_over_kernel': None if kms is None else (dt / a.steps * 1e3) / kms, 'kernel_ms': kernel_parts,
+                         'host_ms_per_step_enqueue_loop': t_host / a.steps * 1e3, 'host_ms': host_ms,
+                         'deferred_step': bool(getattr(model, 'deferred_step', False) and st_native is not None and st_native.can_defer),
+                         'note': 'kernel_ms: HIP events around each C call of a step, mean of %d steps after the timed region; gpu_ms: events around the timed region' % nt}
         mul = MUL.get(a.dtype)
         if mul:
             # the term engines issue `mul` bf16 matrix instructions per ALGORITHMIC multiply-add: `peak` above is the instruction's dense peak / mul

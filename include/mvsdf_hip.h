@@ -426,10 +426,30 @@ void mvsdf_step_destroy(void* step);
  * d_mask / e_mask: point groups of the depth / eikonal terms (see mvsdf_step_outputs). */
 int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepInputs* in, int d_mask, int e_mask, void* fwd, void* stream);
 /* blocks until the counts of the last mvsdf_step_forward are on the host: {N hit, N hit & true mask, depth-surface samples found per set x 2}.
- * The ONE host wait of a training step; the fused evaluation enqueued behind the count copy keeps the GPU busy meanwhile. */
+ * The one host wait of a CLASSIC training step (the fused evaluation enqueued behind the count record keeps the GPU busy meanwhile); a DEFERRED
+ * step (below) never calls it. */
 int mvsdf_step_wait_counts(void* step, long long counts[4]);
+/* ---- the deferred step: no host wait between the forward and the optimiser ----
+ * The counts stay on the device: mvsdf_loss_forward with MvsdfLossArgs.counts_dev set and mvsdf_step_backward with N < 0 take {N, n_true} from
+ * the forward block (written by the ray partition), size their launches for N = R and bound every row loop by the device values, so a training
+ * loop `forward -> loss -> backward -> optimiser` enqueues whole steps ahead of the GPU and its rate no longer depends on the host's latency
+ * (idr_train.py:253-315 is the loop; its per-step print is the only reader of host-side numbers).  Results are bit-identical to the classic step.
+ * mvsdf_step_seq: sequence number (1, 2, ...) of the last mvsdf_step_forward of this step object.
+ * mvsdf_step_counts_offset: byte offset inside `fwd` of its int64 counts[4] = {N, n_true, ds found x 2} (the `counts_dev` of that forward).
+ * mvsdf_step_wait_counts_seq: blocks until forward `seq` has delivered its counts (a short spin, then sleeps); -4 when that record was overwritten
+ *   (more than MVSDF_STEP_COUNT_RING forwards ago: read the counts from the forward block instead).
+ * mvsdf_step_done_seq: newest forward whose partition kernel is known to have run (non-blocking; its counts -> counts[4] when not NULL).
+ * mvsdf_step_can_defer: 1 when mvsdf_step_backward accepts N < 0 for this step's networks (every launch has a fused device-count form). */
+#define MVSDF_STEP_COUNT_RING 64
+long long mvsdf_step_seq(void* step);
+size_t mvsdf_step_counts_offset(void* step);
+int mvsdf_step_wait_counts_seq(void* step, long long seq, long long counts[4]);
+long long mvsdf_step_done_seq(void* step, long long counts[4]);
+int mvsdf_step_can_defer(void* step);
 /* backward of mvsdf_step_forward: upstream gradients of diff_surf_pts [N][3], rgb_values [R][3], grad_theta, eikonal_output,
- * surf_indicator_output (any may be NULL = zero) -> gradient of every raw parameter.  N, n_true: the counts mvsdf_step_wait_counts returned.
+ * surf_indicator_output (any may be NULL = zero) -> gradient of every raw parameter.  N, n_true: the counts mvsdf_step_wait_counts returned;
+ * N < 0: the deferred step -- both counts are read on the device from `fwd`, the upstream tensors hold their valid rows first (sized for N = R),
+ * and n_true carries a HINT of N (a recent step's, or < 0 for none) that only selects kernel forms.
  * use_geo: 0 = points / normals / view directions detached in front of the rendering net (idr.py:331-334).
  * dv / dg / db: per-layer targets (device pointers; dg[l] NULL where g[l] is); accumulate != 0 ADDS into them (the parameters' .grad). */
 int mvsdf_step_backward(void* step, const MvsdfStepParams* prm, int N, int n_true, int d_mask, int e_mask, int use_geo, const float* d_diff,
@@ -442,7 +462,8 @@ int mvsdf_step_set_timing(void* step, int enable);
 int mvsdf_step_trace_times(void* step, float ms[3]);
 /* ... and of the differentiable half (idr.py:240-322 forward, its backward): ms[6] = {the three above, the forward behind the tracer (fused value +
  * normal evaluation, rendering net, output gather: no bubbles on the stream, so the event distance IS the kernel time; sample rows evaluated on the side
- * stream beside the tracer are not in it), mvsdf_step_backward, the whole forward from the first tracer launch} of the last step. */
+ * stream beside the tracer are not in it), mvsdf_step_backward, the whole mvsdf_step_forward from its first launch (fold + packs + rays) to its last} of the
+ * last step. */
 int mvsdf_step_times(void* step, float ms[6]);
 
 /* ---- IDRLoss.forward / backward (loss.py:176-219) as one call each ---- */
@@ -463,6 +484,11 @@ typedef struct {
     int use_invalid;                       /* conf.use_invalid: carving_t instead of carving_t2 (see mvsdf_depth_carve) */
     float smooth;                          /* depth term: 0 = L1, s > 0 = SmoothL1(eikonal_output / s, -dist_r / s) * s (loss.py:57-58: conf.smooth(train_progress)) */
     const float* inv_counts;               /* see mvsdf_loss_terms */
+    /* deferred step: device pointer to {N, n_true} (int64, the forward block's counts).  N / n_grad / n_depth / n_surf above are then UPPER BOUNDS
+     * (N = R) that size the block's layout and the grids; the kernels derive the true row counts from the device values and the step's point groups:
+     * n_grad / n_depth = rows of the groups e_mask / d_mask select among [N hit | n_eik | n_ds | n_ds] (mvsdf_step_outputs), n_surf = n_true + n_eik. */
+    const long long* counts_dev;
+    int n_eik, n_ds, d_mask, e_mask;
 } MvsdfLossArgs;
 typedef struct {
     size_t bytes, out, hit, view_start, n_pos, loss_pp, dpts, dist_r, weight, d_rgb, d_grad, d_eo, d_sf;

@@ -415,6 +415,8 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
     const int row0 = blk * ROWS, S16 = a.S, TS = ROWS * S16, nl = a.net.n_layers, d0 = 3 + 6 * a.net.multires;
     const unsigned skm = a.net.skip_mask;
+    const int Mr = mv_chain_rows(a);                             // (deferred step: the true row count comes from device memory, the grid covers its upper bound)
+    if (row0 >= Mr) return;
     uint16_t* act = (uint16_t*)smem;
     float* g0s = smem + (3 * TS) / 2;                               // [ROWS][d0]: gbar_0 (E.1), then the PE adjoint (E.2)
     float* pe_adj = g0s;
@@ -431,7 +433,7 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
             for (int idx = tid; idx < ROWS * Kp0; idx += NTH) {
                 const int rr = idx / Kp0, k = idx - rr * Kp0, row = row0 + rr;
                 float v = 0.0f;
-                if (row < a.M && k < d0) {
+                if (row < Mr && k < d0) {
                     const float* h = a.H0 + (size_t)row * a.row_ld0;
                     const float* nb = a.dn_in + (size_t)row * 3;
                     if (k < 3) v = nb[k];
@@ -441,7 +443,7 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
                         v = rem < 3 ? f * h[6 + 6 * m + c] * nb[c] : -f * h[3 + 6 * m + c] * nb[c];
                     }
                 }
-                if (row < a.M && k < a.row_ld0) a.VB0w[(size_t)row * a.row_ld0 + k] = v;    // vbar_0 for the weight gradient
+                if (row < Mr && k < a.row_ld0) a.VB0w[(size_t)row * a.row_ld0 + k] = v;    // vbar_0 for the weight gradient
                 mv_x3_put1(act, S16, TS, rr, k, v);
                 if (k < d0) g0s[rr * d0 + k] = v;
             }
@@ -460,7 +462,7 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
             auto side = [&](int t, int m, f32x4& z, f32x4& u) {
                 const int col0 = (ct0 + t) * 16 + 4 * q, nv = N - col0;
                 const int row = row0 + m * 16 + r;
-                const bool ok = t < ntw && row < a.M && nv > 0;
+                const bool ok = t < ntw && row < Mr && nv > 0;
                 z = mv_ld4(a.Z[l] + (ok ? (size_t)row * N + col0 : 0), ok && vn && nv >= 4, ok ? nv : 0);
                 if (top) {
                     f32x4 wl = mv_ld4(a.w_last_row0 + (ok ? col0 : 0), false, ok ? nv : 0);
@@ -499,7 +501,7 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
                             z2[i] = us[i] * sb * dm_sigmoid_prime100(sig);
                         }
                         mv_x3_put4(act, S16, TS, rr, col0, ub, nv);
-                        if (row < a.M && nv > 0) {
+                        if (row < Mr && nv > 0) {
                             mv_st4(a.VB[l + 1] + (size_t)row * ldn + col0, ub, vv && nv >= 4, nv);
                             mv_st4(a.ZB2o[l] + (size_t)row * N + col0, z2, vn && nv >= 4, nv);
                         }
@@ -511,7 +513,7 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
                     const int rr = idx / d0, j = idx - rr * d0, row = row0 + rr;
                     const float tv = dm_div_sqrt2(g0s[rr * d0 + j]);
                     mv_x3_put1(act, S16, TS, rr, N + j, tv);
-                    if (row < a.M) a.VB[l + 1][(size_t)row * ldn + N + j] = tv;     // PE tail of the skip layer's vbar
+                    if (row < Mr) a.VB[l + 1][(size_t)row * ldn + N + j] = tv;     // PE tail of the skip layer's vbar
                 }
             mv_x3_zero_cols<ROWS, NTH>(act, S16, TS, ldn, a.net.L[l + 1].KB * 32, tid);
         }
@@ -523,7 +525,7 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
         for (int idx = tid; idx < ROWS * Kp; idx += NTH) {
             const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
             float v = 0.0f;
-            if (row < a.M && k < K) v = a.dy_col0 ? (k == 0 ? a.dy_col0[row] : 0.0f) : a.dy[(size_t)row * a.ld_dy + k];
+            if (row < Mr && k < K) v = a.dy_col0 ? (k == 0 ? a.dy_col0[row] : 0.0f) : a.dy[(size_t)row * a.ld_dy + k];
             mv_x3_put1(act, S16, TS, rr, k, v);
         }
     }
@@ -541,7 +543,7 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
         auto side = [&](int t, int m, f32x4& z, f32x4& zb2, f32x4& zold) {
             const int col0 = (ct0 + t) * 16 + 4 * q, nv = Nh - col0;
             const int row = row0 + m * 16 + r;
-            const bool ok = l > 0 && t < ntw && row < a.M && nv > 0;
+            const bool ok = l > 0 && t < ntw && row < Mr && nv > 0;
             const size_t off = ok ? (size_t)row * Nh + col0 : 0;
             z = mv_ld4(a.Z[lm] + off, ok && vh && nv >= 4, ok ? nv : 0);
             zb2 = mv_ld4((has2 ? a.ZB2[lm] : a.Z[lm]) + off, ok && vh && nv >= 4, ok ? nv : 0);
@@ -577,7 +579,7 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
                             if (col < N) {
                                 const float hb0 = pe_adj[rr * d0 + col] + v[i];
                                 pe_adj[rr * d0 + col] = hb0;                       // kept for the input adjoint below
-                                if (row < a.M && a.H0B) a.H0B[(size_t)row * a.row_ld0 + col] = hb0;
+                                if (row < Mr && a.H0B) a.H0B[(size_t)row * a.row_ld0 + col] = hb0;
                             }
                         }
                     } else {
@@ -589,10 +591,10 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
                             for (int i = 0; i < 4; ++i) {
                                 float x = zs[i] * v[i];
                                 if (has2) x += z2s[i];
-                                zb[i] = (row < a.M && i < nv) ? x : 0.0f;
+                                zb[i] = (row < Mr && i < nv) ? x : 0.0f;
                             }
                             mv_x3_put4(act, S16, TS, rr, col0, zb, nv);             // the chain continues with THIS pass's zbar
-                            if (row < a.M) {
+                            if (row < Mr) {
                                 f32x4 st = zb;
                                 if (a.accum) { for (int i = 0; i < 4; ++i) st[i] = zos[i] + zb[i]; }
                                 mv_st4(a.ZB[l - 1] + (size_t)row * Nh + col0, st, vh && nv >= 4, nv);
@@ -615,7 +617,7 @@ __device__ __forceinline__ void mv_chain_bwd_body_x3(const ChainArgsX3& a, int b
         __syncthreads();
         for (int idx = tid; idx < ROWS * 3; idx += NTH) {           // xbar = J_PE^T hbar_0 + sum_k PE''_k g0[k] nbar[c(k)]
             const int rr = idx / 3, c = idx - 3 * rr, row = row0 + rr;
-            if (row >= a.M) continue;
+            if (row >= Mr) continue;
             const float* h = a.H0 + (size_t)row * a.row_ld0;
             const float* hb = pe_adj + rr * d0;
             float v = hb[c], second = 0.0f;

@@ -331,6 +331,15 @@ static int mv_chain_mt_x3(int tiles16) {
 #endif
 
 #define MV_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mv_check(e_, #expr); } while (0)
+// dynamic-LDS limit of one kernel instance, raised only when a launch needs more than any launch before it (`hw`: one static high-water mark per site;
+// the runtime call costs a few microseconds of host time, a training step would make four of them)
+template <class K>
+static hipError_t mv_lds_limit(K kern, size_t bytes, size_t& hw) {
+    if (bytes <= hw) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) hw = bytes;
+    return e;
+}
 
 extern "C" {
 
@@ -397,13 +406,13 @@ int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const f
         const size_t lds = (size_t)3 * 16 * mt * xn.S * 2 + ((size_t)2 * ((16 * mt * lo.d0 + 3) & ~3) + 16 * mt * 4) * sizeof(float);
         const dim3 grid((Mr + 16 * mt - 1) / (16 * mt));
         if (ntw_f == 4 && mt == 2) {
-            MV_TRY(hipFuncSetAttribute((const void*)k_chain_fwd_x3<2, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            { static size_t hw = 0; MV_TRY(mv_lds_limit(k_chain_fwd_x3<2, 4, 8>, lds, hw)); }
             hipLaunchKernelGGL((k_chain_fwd_x3<2, 4, 8>), grid, dim3(512), lds, s, f);
             return mv_check(hipGetLastError(), "mvsdf_sdf_forward (x3 chain)");
         }
         // hidden width <= 256: 16 waves x 1 column tile; up to 512: 16 waves x 2 tiles
         if (mt == 2) {
-            MV_TRY(hipFuncSetAttribute((const void*)k_chain_fwd_x3<2, 1, 16, MV_X3_PD2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            { static size_t hw = 0; MV_TRY(mv_lds_limit(k_chain_fwd_x3<2, 1, 16, MV_X3_PD2>, lds, hw)); }
             hipLaunchKernelGGL((k_chain_fwd_x3<2, 1, 16, MV_X3_PD2>), grid, dim3(1024), lds, s, f);
         }
         else if (ntw_f == 2) hipLaunchKernelGGL((k_chain_fwd_x3<1, 1, 16, MV_X3_PD1>), grid, dim3(1024), lds, s, f);
@@ -432,7 +441,7 @@ int mv_sdf_forward_gather(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, const f
         if (mt > 1) {
             const size_t ldsm = ((size_t)16 * mt * S + 2 * ((16 * mt * lo.d0 + 3) & ~3) + 16 * mt * 4) * sizeof(float);
             const dim3 gridm((Mr + 16 * mt - 1) / (16 * mt));
-            MV_TRY(hipFuncSetAttribute((const void*)k_chain_fwd<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm));
+            { static size_t hw = 0; MV_TRY(mv_lds_limit(k_chain_fwd<2, 1, 16>, ldsm, hw)); }
             hipLaunchKernelGGL((k_chain_fwd<2, 1, 16>), gridm, dim3(1024), ldsm, s, f);
         }
         else if (ntw_f == 2 && !w8) hipLaunchKernelGGL((k_chain_fwd<MTC, 1, 16>), grid, dim3(1024), lds, s, f);
@@ -711,6 +720,17 @@ extern "C" {
  * mvsdf_sdf_backward). */
 int mvsdf_sdf_backward_pair(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M, int Mg, int MbA, const float* dyA, const float* dnA, float* wsA,
                             int row0X, int MbX, const float* dyX, const float* dnX, float* wsX, float* dx, const float* ctx, void* stream) {
+    return mv_sdf_backward_pair_cnt(d, dT, M, Mg, MbA, dyA, dnA, wsA, row0X, MbX, dyX, dnX, wsX, dx, ctx, nullptr, 0, stream);
+}
+
+}  // extern "C"
+
+// ... with device-side counts (the deferred step, step_internal.h): cnt != NULL -> pass A covers rows [0, row0X + cnt[0]) and pass X the cnt[0] rows from row0X;
+// MbA / MbX are then the UPPER BOUNDS (row0X + MbX == MbA) the workspaces, their layouts and the grid are sized for, and n_hint (a recent cnt[0], or MbX) only
+// picks the kernel form.  Same kernels, same arithmetic per row.
+int mv_sdf_backward_pair_cnt(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M, int Mg, int MbA, const float* dyA, const float* dnA, float* wsA,
+                             int row0X, int MbX, const float* dyX, const float* dnX, float* wsX, float* dx, const float* ctx, const long long* cnt, int n_hint,
+                             void* stream) {
     MvNet net, netT;
     int rc = mv_make_net(d, &net);
     if (rc) return rc;
@@ -718,6 +738,9 @@ int mvsdf_sdf_backward_pair(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M
     if (rc) return rc;
     if (!dyA || !dnA || !wsA || !dyX || !wsX || !dx || !ctx || MbA <= 0 || MbX <= 0 || MbA > Mg || row0X < 0 || row0X + MbX > Mg || Mg > M)
         return mv_fail(-1, "mvsdf_sdf_backward_pair: bad arguments");
+    if (cnt && row0X + MbX != MbA) return mv_fail(-1, "mv_sdf_backward_pair_cnt: the bounds of the two passes must end on the same row");
+    if (n_hint < 0 || n_hint > MbX) n_hint = MbX;
+    const int tiles_hint = cnt ? (row0X + n_hint + 15) / 16 + (n_hint + 15) / 16 : (MbA + 15) / 16 + (MbX + 15) / 16;
     const int ntw_b = mv_chain_ntw(net);
     if (!ntw_b) return mv_fail(-3, "mvsdf_sdf_backward_pair: network too wide for the fused chain kernels");
     const float* w8 = d->w[net.n_layers - 1];
@@ -730,16 +753,17 @@ int mvsdf_sdf_backward_pair(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M
         ChainArgsX3 a, b;
         fill_chain_args(a, net, xn, xnT, xn.S, lo, sdf_bwd_layout(net, MbA), ctx, 0, MbA, dyA, dnA, wsA, nullptr, w8);
         fill_chain_args(b, net, xn, xnT, xn.S, lo, sdf_bwd_layout(net, MbX), ctx, row0X, MbX, dyX, dnX, wsX, dx, w8);
-        const int mt = mv_chain_mt_x3((MbA + 15) / 16 + (MbX + 15) / 16);
+        a.cnt = b.cnt = cnt; a.cnt_base = row0X; b.cnt_base = 0;
+        const int mt = mv_chain_mt_x3(tiles_hint);
         const size_t lds = (size_t)3 * 16 * mt * xn.S * 2 + (size_t)16 * mt * lo.d0 * sizeof(float);
         const int na = (MbA + 16 * mt - 1) / (16 * mt), nb = (MbX + 16 * mt - 1) / (16 * mt);
         const dim3 grid(na + nb);
         if (mt == 2 && ntw_b == 4) {
-            MV_TRY(hipFuncSetAttribute((const void*)k_chain_bwd2_x3<2, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            { static size_t hw = 0; MV_TRY(mv_lds_limit(k_chain_bwd2_x3<2, 4, 8>, lds, hw)); }
             hipLaunchKernelGGL((k_chain_bwd2_x3<2, 4, 8>), grid, dim3(512), lds, s, a, b, na);
         }
         else if (mt == 2) {
-            MV_TRY(hipFuncSetAttribute((const void*)k_chain_bwd2_x3<2, 1, 16, MV_X3_PD2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            { static size_t hw = 0; MV_TRY(mv_lds_limit(k_chain_bwd2_x3<2, 1, 16, MV_X3_PD2>, lds, hw)); }
             hipLaunchKernelGGL((k_chain_bwd2_x3<2, 1, 16, MV_X3_PD2>), grid, dim3(1024), lds, s, a, b, na);
         }
         else if (ntw_b == 2) hipLaunchKernelGGL((k_chain_bwd2_x3<1, 1, 16, MV_X3_PD1>), grid, dim3(1024), lds, s, a, b, na);
@@ -749,13 +773,14 @@ int mvsdf_sdf_backward_pair(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M
     ChainArgs a, b;
     fill_chain_args(a, net, net, netT, S, lo, sdf_bwd_layout(net, MbA), ctx, 0, MbA, dyA, dnA, wsA, nullptr, w8);
     fill_chain_args(b, net, net, netT, S, lo, sdf_bwd_layout(net, MbX), ctx, row0X, MbX, dyX, dnX, wsX, dx, w8);
+    a.cnt = b.cnt = cnt; a.cnt_base = row0X; b.cnt_base = 0;
     const bool w8w = mv_chain_w8();
-    const int mt = (ntw_b == 2 && !w8w) ? mv_chain_mt((MbA + 15) / 16 + (MbX + 15) / 16) : 1;
+    const int mt = (ntw_b == 2 && !w8w) ? mv_chain_mt(tiles_hint) : 1;
     const size_t lds = (size_t)16 * mt * (S + lo.d0) * sizeof(float);
     const int na = (MbA + 16 * mt - 1) / (16 * mt), nb = (MbX + 16 * mt - 1) / (16 * mt);
     const dim3 grid(na + nb);
     if (mt == 2) {
-        MV_TRY(hipFuncSetAttribute((const void*)k_chain_bwd2<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { static size_t hw = 0; MV_TRY(mv_lds_limit(k_chain_bwd2<2, 1, 16>, lds, hw)); }
         hipLaunchKernelGGL((k_chain_bwd2<2, 1, 16>), grid, dim3(1024), lds, s, a, b, na);
     }
     else if (ntw_b == 2 && !w8w) hipLaunchKernelGGL((k_chain_bwd2<1, 1, 16>), grid, dim3(1024), lds, s, a, b, na);
@@ -764,8 +789,6 @@ int mvsdf_sdf_backward_pair(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M
     else hipLaunchKernelGGL((k_chain_bwd2<1, 4, 8>), grid, dim3(512), lds, s, a, b, na);
     return mv_check(hipGetLastError(), "mvsdf_sdf_backward_pair");
 }
-
-}  // extern "C"
 
 // delta pass of the training step's SDF backward: extra upstream fbar[MbD] on output column 0 of rows [row0D, row0D + MbD); its first-order zbar_l
 // are ADDED to the adjoints pass A stored in `ws` (linearity)
@@ -783,10 +806,12 @@ struct DeltaArgs {
     const float* d_diff; const float* din; const float* dx; const float* view_sorted; const float* n_hit;   // n_hit: normals of the hit rows
     int din_ld, use_geo, Nout;
     float* dy_hit; float* fbar_out;          // dy already offset to the first hit row
+    const long long* cnt;                    // deferred step: the hit rows are cnt[0] (the grid covers the upper bound `rows`)
 };
 template <bool FB>
 __global__ __launch_bounds__(256) void k_delta_apply(DeltaArgs a) {
     const int row = blockIdx.x;
+    if (a.cnt && row >= (int)a.cnt[0]) return;
     if (FB) {                                                     // one workgroup per row, all layers: fbar once, then 8 independent streams per thread
         float dot = 0.f, num = 0.f;
         for (int c = 0; c < 3; ++c) {
@@ -847,7 +872,7 @@ static int sdf_delta_pass(const MvNet& net, const MvNet& netT, const SdfLayout& 
     const size_t lds = (size_t)16 * mt * (S + lo.d0) * sizeof(float);
     const dim3 grid((MbD + 16 * mt - 1) / (16 * mt));
     if (mt == 2) {
-        MV_TRY(hipFuncSetAttribute((const void*)k_chain_bwd<2, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { static size_t hw = 0; MV_TRY(mv_lds_limit(k_chain_bwd<2, 1, 16>, lds, hw)); }
         hipLaunchKernelGGL((k_chain_bwd<2, 1, 16>), grid, dim3(1024), lds, s, c);
     }
     else if (ntw_b == 2 && !w8w) hipLaunchKernelGGL((k_chain_bwd<1, 1, 16>), grid, dim3(1024), lds, s, c);
@@ -1013,7 +1038,7 @@ int mvsdf_render_forward(const MvsdfNetDesc* d, const float* points, const float
 
 // the descending chain of the rendering net's backward: drgb[N][3] -> per-layer adjoints in `ws` + din[N][K0]
 static int render_backward_chain(const MvNet& net, const MvNet& netT, int N, int Nctx, const float* drgb, const float* ctx, float* din, float* ws,
-                                 hipStream_t s, const long long* drgb_rows = nullptr) {
+                                 hipStream_t s, const long long* drgb_rows = nullptr, const long long* cnt = nullptr) {
     const int nl = net.n_layers, S = stride_for(net, netT);
     const RenderLayout lo = render_layout(net, Nctx);        // the forward context holds Nctx rows; the backward covers the first N
     const RenderBwdLayout bl = render_bwd_layout(net, N);
@@ -1026,7 +1051,7 @@ static int render_backward_chain(const MvNet& net, const MvNet& netT, int N, int
         RenderChainArgs c;
         memset(&c, 0, sizeof(c));
         c.net = net; c.netT = netT; c.S = S; c.N = N; c.K0 = net.L[0].K;
-        c.drgb = drgb; c.rgbc = ctx + lo.rgb; c.din = din; c.drgb_rows = drgb_rows;
+        c.drgb = drgb; c.rgbc = ctx + lo.rgb; c.din = din; c.drgb_rows = drgb_rows; c.cnt = cnt;
         for (int l = 0; l < nl; ++l) { c.Ac[l] = ctx + lo.A[l]; c.ZB[l] = ws + bl.ZB[l]; }
         constexpr int MTC = 1, NWC = 8;
         const bool w8 = mv_chain_w8();
@@ -1038,7 +1063,7 @@ static int render_backward_chain(const MvNet& net, const MvNet& netT, int N, int
         else hipLaunchKernelGGL((k_render_chain_bwd<MTC, 4, NWC>), grid, dim3(64 * NWC), ldsr, s, c);
         MV_TRY(hipGetLastError());
     } else {
-    if (drgb_rows) return mv_fail(-3, "render_backward_chain: row indirection needs the fused chain kernel");
+    if (drgb_rows || cnt) return mv_fail(-3, "render_backward_chain: row indirection / device-side counts need the fused chain kernel");
     for (int l = nl - 1; l >= 0; --l) {                      // abar_l = zbar_l W_l ; zbar_{l-1} = abar_l . relu'(z_{l-1})
         LayerArgs a = base_args(netT.L[l], S, N);
         const bool last = (l == nl - 1);
@@ -1096,14 +1121,14 @@ int mvsdf_render_backward(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, 
 // ================================================================================================ step driver pieces (step_internal.h)
 // The backward of a training step in pieces: rendering-net chain, delta, and the weight gradients of BOTH networks in one k_wgrad_net / k_reduce_net pair.
 int mv_render_backward_chain(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, int Nctx, const float* drgb, const long long* drgb_rows, const float* ctx,
-                             float* din, float* ws, void* stream) {
+                             float* din, float* ws, const long long* cnt, void* stream) {
     MvNet net, netT;
     int rc = mv_make_net_mode(d, &net, 1);
     if (rc) return rc;
     rc = mv_make_net_mode(dT, &netT, 2);
     if (rc) return rc;
     if (!drgb || !ctx || !din || !ws || N <= 0 || Nctx < N) return mv_fail(-1, "mv_render_backward_chain: bad arguments");
-    rc = render_backward_chain(net, netT, N, Nctx, drgb, ctx, din, ws, (hipStream_t)stream, drgb_rows);
+    rc = render_backward_chain(net, netT, N, Nctx, drgb, ctx, din, ws, (hipStream_t)stream, drgb_rows, cnt);
     return rc ? rc : mv_check(hipGetLastError(), "mv_render_backward_chain");
 }
 
@@ -1123,7 +1148,7 @@ int mv_sdf_backward_delta(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M, 
 // [row0D, row0D + MbD) of the evaluation, dy / n_eval are the evaluation's [M][Nout] / [M][3]
 int mv_sdf_backward_delta_fbar(const MvsdfNetDesc* d, int M, int Mg, int Mb, const float* ctx, float* ws, int row0D, int MbD, int Nout, const float* din,
                                int din_ld, int use_geo, const float* d_diff, const float* dx, const float* view_sorted, const float* n_eval, float* dy,
-                               float* fbar, void* stream) {
+                               float* fbar, const long long* cnt, void* stream) {
     MvNet net;
     int rc = mv_make_net(d, &net);
     if (rc) return rc;
@@ -1140,7 +1165,7 @@ int mv_sdf_backward_delta_fbar(const MvsdfNetDesc* d, int M, int Mg, int Mb, con
         a.ZB[l] = ws + bl.ZB[l] + (size_t)row0D * net.L[l].N;
     }
     a.d_diff = d_diff; a.din = din; a.dx = dx; a.view_sorted = view_sorted; a.n_hit = n_eval + 3 * (size_t)row0D;
-    a.din_ld = din_ld; a.use_geo = use_geo; a.Nout = Nout; a.dy_hit = dy + (size_t)row0D * Nout; a.fbar_out = fbar;
+    a.din_ld = din_ld; a.use_geo = use_geo; a.Nout = Nout; a.dy_hit = dy + (size_t)row0D * Nout; a.fbar_out = fbar; a.cnt = cnt;
     hipLaunchKernelGGL(k_delta_apply<true>, dim3(MbD), dim3(256), 0, (hipStream_t)stream, a);
     return mv_check(hipGetLastError(), "mv_sdf_backward_delta_fbar");
 }
@@ -1149,7 +1174,7 @@ int mv_sdf_backward_delta_fbar(const MvsdfNetDesc* d, int M, int Mg, int Mb, con
  * ONE reduction of all slabs -> dW_s / db_s / dW_r / db_r.  The rendering net takes part when N > 0 and rctx / rws are given; otherwise the caller
  * zero-fills its targets. */
 int mv_step_wgrad(const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int M, int Mg, int Mb, const float* dy, const float* ctx, float* wsA, int N, int Nctx,
-                  const float* rctx, float* rws, float* dW_s, float* db_s, float* dW_r, float* db_r, void* stream) {
+                  const float* rctx, float* rws, float* dW_s, float* db_s, float* dW_r, float* db_r, const long long* cnt, int cnt_base, void* stream) {
     MvNet net, rnet;
     int rc = mv_make_net(sd, &net);
     if (rc) return rc;
@@ -1175,8 +1200,28 @@ int mv_step_wgrad(const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int M, int Mg,
     }
     const int Ki = net.L[nl - 1].K;
     wgrad_colsum(wa, wsA + bl.VB[nl - 1], Ki, Mb, Ki, nl - 1, bl.nchunks, wsA + bl.slabB);
+    if (cnt) {                                                  // deferred step: SDF layers cover cnt_base + cnt[0] rows, rendering layers cnt[0]
+        wa.cnt = cnt; wa.col_mbase = cnt_base;
+        for (int l = 0; l < nl; ++l) wa.L[l].mbase = cnt_base;
+        for (int l = nl; l < nl + nr; ++l) wa.L[l].mbase = 0;
+    }
     MV_TRY(launch_wgrad_net(wa, (hipStream_t)stream));
     return mv_check(hipGetLastError(), "mv_step_wgrad");
+}
+
+// Can mvsdf_step_backward run these networks with device-side counts?  Every launch of that route must be one of the fused forms that take them: the SDF
+// chains (any arithmetic), the elementwise delta, the rendering net's fused descending chain, k_wgrad_net.  (The per-layer fall-backs size their grids from host
+// numbers: a step on such a network waits for the counts as before.)
+int mv_step_can_defer(const MvsdfNetDesc* sdf, const MvsdfNetDesc* sdfT, const MvsdfNetDesc* rnd, const MvsdfNetDesc* rndT) {
+    MvNet net, netT, rnet, rnetT;
+    if (mv_make_net(sdf, &net) || mv_make_net_mode(sdfT, &netT, 2) || mv_make_net_mode(rnd, &rnet, 1) || mv_make_net_mode(rndT, &rnetT, 2)) return 0;
+    if (!mv_chain_ntw(net) || mv_delta_chain()) return 0;
+    const char* e = mv_dev_env("MVSDF_FUSE");
+    if (e && atoi(e) == 0) return 0;
+    const int ntw_rb = mv_chain_ntw(rnet);
+    if (!ntw_rb) return 0;
+    for (int l = 1; l < rnet.n_layers; ++l) if (rnetT.L[l].NT > 8 * ntw_rb) return 0;
+    return net.n_layers + rnet.n_layers <= MV_WG_MAXL ? 1 : 0;
 }
 
 #ifdef MV_CHAIN_PROBE

@@ -262,7 +262,8 @@ struct WgradLayer {
     const float* P1; const float* Q1; const float* P2; const float* Q2;   // [M, No], [M, Ki]; P2 null: single pair
     int ldp1, ldq1, ldp2, ldq2;
     int No, Ki, nbx, nby;
-    int M;                         // rows of this layer's operands
+    int M;                         // rows of this layer's operands (deferred step, WgradNetArgs.cnt set: mbase + cnt[0]; M then bounds the slabs)
+    int mbase;
     int nchunks;                   // 128-row chunks of M = slabs of this layer
     int ch0, nch;                  // the chunks THIS launch computes (a caller may split a layer's chunks over two launches)
     int blk0;                      // first workgroup of this layer in this launch
@@ -278,8 +279,12 @@ struct WgradNetArgs {
     const float* colX; int col_ld, col_M, col_n, col_layer, col_nchunks, col_ch0, col_nch, col_blk0;
     float* colslab;
     unsigned wtotal, btotal;
+    const long long* cnt; int col_mbase;   // deferred step: device-side row counts (step_internal.h); the chunks beyond the true rows are neither computed nor summed
     int xcd_runs, nblocks;             // xcd_runs: runs of 16 consecutive logical blocks per XCD (the launch grid is padded to a multiple of 128); nblocks: logical blocks
 };
+
+__device__ __forceinline__ int mv_wg_rows(const WgradNetArgs& a, const WgradLayer& L) { return a.cnt ? L.mbase + (int)a.cnt[0] : L.M; }
+__device__ __forceinline__ int mv_wg_col_rows(const WgradNetArgs& a) { return a.cnt ? a.col_mbase + (int)a.cnt[0] : a.col_M; }
 
 // `scratch`: 256 floats of LDS (the caller's operand tile: a static array of its own here would push k_wgrad_net from 40 960 to 41 984 bytes of LDS, i.e.
 // from FOUR to THREE workgroups per CU)
@@ -288,7 +293,8 @@ __device__ __forceinline__ void mv_colsum_block(const WgradNetArgs& a, int local
     const int nbx = (a.col_n + 63) / 64;
     const int ch = a.col_ch0 + local / nbx, bx = local - (local / nbx) * nbx;
     const int c = bx * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-    const int rbeg = ch * a.chunk, rend = min(a.col_M, rbeg + a.chunk);
+    const int rbeg = ch * a.chunk, rend = min(mv_wg_col_rows(a), rbeg + a.chunk);
+    if (rbeg >= rend && a.cnt) return;                            // (deferred step: a chunk beyond the true rows; k_reduce_net does not read it)
     float s = 0.0f;
     if (c < a.col_n)
         for (int row = rbeg + g; row < rend; row += 4) s += a.colX[(size_t)row * a.col_ld + c];
@@ -319,7 +325,8 @@ __global__ __launch_bounds__(MV_THREADS) void k_wgrad_net(WgradNetArgs a) {
     const int chl = local / nb, rem = local - chl * nb, by = rem / L.nbx, bx = rem - by * L.nbx;
     const int ch = L.ch0 + chl;
     const int i0 = bx * 64, o0 = by * 64, No = L.No, Ki = L.Ki;
-    const int rbeg = ch * a.chunk, rend = min(L.M, rbeg + a.chunk);
+    const int rbeg = ch * a.chunk, rend = min(mv_wg_rows(a, L), rbeg + a.chunk);
+    if (rbeg >= rend && a.cnt) return;                            // (deferred step: a chunk beyond the true rows; k_reduce_net does not read its slab)
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -456,13 +463,14 @@ __global__ void k_reduce_net(WgradNetArgs a) {
         if (isb) {
             const unsigned j = k - L.boff;
             const float* sp = L.bslab + j;
-            for (int c = 0; c < L.nchunks; ++c) v += sp[(size_t)c * L.No];
+            const int nchb = a.cnt ? (mv_wg_rows(a, L) + a.chunk - 1) / a.chunk : L.nchunks;
+            for (int c = 0; c < nchb; ++c) v += sp[(size_t)c * L.No];
             L.db[j] = v;
         } else {
             const unsigned j = k - L.woff;
             const size_t nk = (size_t)L.No * L.Ki;
             const float* sp = L.slab + j;
-            const int nch = L.nchunks;
+            const int nch = a.cnt ? (mv_wg_rows(a, L) + a.chunk - 1) / a.chunk : L.nchunks;
             for (int c = 0; c < nch; c += 8) {                    // eight slabs requested at once (clamped), added in slab order
                 float t[8];
 #pragma unroll
@@ -470,8 +478,10 @@ __global__ void k_reduce_net(WgradNetArgs a) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (c + u < nch) v += t[u];
             }
-            if (a.colslab && l == a.col_layer && j < (unsigned)a.col_n)
-                for (int c = 0; c < a.col_nchunks; ++c) v += a.colslab[(size_t)c * a.col_n + j];
+            if (a.colslab && l == a.col_layer && j < (unsigned)a.col_n) {
+                const int ncc = a.cnt ? (mv_wg_col_rows(a) + a.chunk - 1) / a.chunk : a.col_nchunks;
+                for (int c = 0; c < ncc; ++c) v += a.colslab[(size_t)c * a.col_n + j];
+            }
             L.dW[j] = v;
         }
     }
@@ -515,8 +525,12 @@ struct ChainArgsT {
     // delta pass (E.2 only, dn_in == NULL): the upstream is one scalar per row on output column 0, and zbar_l is ADDED to the stored one
     const float* dy_col0;                      // [M] (null: the full dy)
     int accum;                                 // 1: ZB[l] += zbar_l (H0B may be null: not written)
+    // deferred step (step_internal.h, "device-side counts"): rows = cnt_base + cnt[0] instead of M (M then is the upper bound the grid was sized for)
+    const long long* cnt; int cnt_base;
 };
 typedef ChainArgsT<MvNet> ChainArgs;           // (ChainArgsT<MvNetBf>: the three-term bf16 chains of chain_x3.h)
+template <class NET>
+__device__ __forceinline__ int mv_chain_rows(const ChainArgsT<NET>& a) { return a.cnt ? a.cnt_base + (int)a.cnt[0] : a.M; }
 
 // E.2 (descending): hb_L = dy W_L;  for l = L-1..0: zb_l = sigma_l . hb_{l+1} + zb2_l (stored), ab_l = zb_l W_l, split at the skip layer.
 template <int MT, int NTW, int NW>
@@ -694,6 +708,8 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
     const int row0 = blk * ROWS, S = a.S, nl = a.net.n_layers, d0 = 3 + 6 * a.net.multires;
     const unsigned skm = a.net.skip_mask;
+    const int Mr = mv_chain_rows(a);                             // (deferred step: the true row count comes from device memory, the grid covers its upper bound)
+    if (row0 >= Mr) return;
     float* act = smem;
     float* g0s = smem + ROWS * S;                                // [ROWS][d0]: gbar_0 (E.1), then the PE adjoint (E.2)
     float* pe_adj = g0s;
@@ -703,7 +719,7 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
             for (int idx = tid; idx < ROWS * Kp0; idx += NTH) {
                 const int rr = idx / Kp0, k = idx - rr * Kp0, row = row0 + rr;
                 float v = 0.0f;
-                if (row < a.M && k < d0) {
+                if (row < Mr && k < d0) {
                     const float* h = a.H0 + (size_t)row * a.row_ld0;
                     const float* nb = a.dn_in + (size_t)row * 3;
                     if (k < 3) v = nb[k];
@@ -713,7 +729,7 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
                         v = rem < 3 ? f * h[6 + 6 * m + c] * nb[c] : -f * h[3 + 6 * m + c] * nb[c];
                     }
                 }
-                if (row < a.M && k < a.row_ld0) a.VB0w[(size_t)row * a.row_ld0 + k] = v;    // vbar_0 for the weight gradient
+                if (row < Mr && k < a.row_ld0) a.VB0w[(size_t)row * a.row_ld0 + k] = v;    // vbar_0 for the weight gradient
                 act[rr * S + mv_perm(k)] = v;
                 if (k < d0) g0s[rr * d0 + k] = v;
             }
@@ -737,7 +753,7 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
                     for (int i = 0; i < 4; ++i) {
                         const int row = row0 + m * 16 + 4 * q + i;
                         zz[t][m][i] = 0.f; uu[t][m][i] = 0.f;
-                        if (t < ntw && col < N && row < a.M) {
+                        if (t < ntw && col < N && row < Mr) {
                             zz[t][m][i] = a.Z[l][(size_t)row * N + col];
                             uu[t][m][i] = top ? (to_skip ? dm_div_sqrt2(a.w_last_row0[col]) : a.w_last_row0[col]) : a.U[l + 1][(size_t)row * N + col];
                         }
@@ -762,7 +778,7 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
                                 float ub = sig * sb;
                                 if (to_skip) ub = dm_div_sqrt2(ub);
                                 act[rr * S + mv_perm(col)] = ub;
-                                if (row < a.M) {
+                                if (row < Mr) {
                                     a.VB[l + 1][(size_t)row * ldn + col] = ub;
                                     a.ZB2o[l][(size_t)row * N + col] = uu[t][m][i] * sb * dm_sigmoid_prime100(sig);
                                 }
@@ -777,7 +793,7 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
                         const int rr = idx / d0, j = idx - rr * d0, row = row0 + rr;
                         const float tv = dm_div_sqrt2(g0s[rr * d0 + j]);
                         act[rr * S + mv_perm(N + j)] = tv;
-                        if (row < a.M) a.VB[l + 1][(size_t)row * ldn + N + j] = tv;     // PE tail of the skip layer's vbar
+                        if (row < Mr) a.VB[l + 1][(size_t)row * ldn + N + j] = tv;     // PE tail of the skip layer's vbar
                     }
                 if (Kpn > Kn) {
                     const int pad = Kpn - Kn;
@@ -804,7 +820,7 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
             for (int u = 0; u < 4; ++u) {
                 const int idx = it * NTH * 4 + u * NTH + tid;
                 const int rr = idx / Kpq, k = idx - rr * Kpq, row = row0 + rr;
-                const bool ok = idx < ROWS * Kpq && row < a.M && k < Kq;
+                const bool ok = idx < ROWS * Kpq && row < Mr && k < Kq;
                 const size_t off = ok ? (size_t)row * Kq + k : 0;
                 zpre[it][u] = a.Z[lq][off];
                 z2pre[it][u] = z2[off];
@@ -821,7 +837,7 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
                 const int idx = base + u * NTH + tid;
                 const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
                 v[u] = 0.0f;
-                if (idx < ROWS * Kp && row < a.M && k < K) {
+                if (idx < ROWS * Kp && row < Mr && k < K) {
                     if (l == nl - 1) v[u] = a.dy_col0 ? (k == 0 ? a.dy_col0[row] : 0.0f) : a.dy[(size_t)row * a.ld_dy + k];
                     else {
                         float zb = (zp ? zp[u] : a.Z[l][(size_t)row * K + k]) * act[rr * S + mv_perm(k)];
@@ -874,7 +890,7 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
                             } else if (l == 0) {
                                 const float hb0 = pe_adj[rr * d0 + col] + v;
                                 pe_adj[rr * d0 + col] = hb0;                       // kept for the input adjoint below
-                                if (row < a.M && a.H0B) a.H0B[(size_t)row * a.row_ld0 + col] = hb0;
+                                if (row < Mr && a.H0B) a.H0B[(size_t)row * a.row_ld0 + col] = hb0;
                             } else {
                                 act[rr * S + mv_perm(col)] = v;
                             }
@@ -889,7 +905,7 @@ __device__ __forceinline__ void mv_chain_bwd_body(const ChainArgs& a, int blk, f
         __syncthreads();
         for (int idx = tid; idx < ROWS * 3; idx += NTH) {        // xbar = J_PE^T hbar_0 + sum_k PE''_k g0[k] nbar[c(k)]
             const int rr = idx / 3, c = idx - 3 * rr, row = row0 + rr;
-            if (row >= a.M) continue;
+            if (row >= Mr) continue;
             const float* h = a.H0 + (size_t)row * a.row_ld0;
             const float* hb = pe_adj + rr * d0;
             float v = hb[c], second = 0.0f;
@@ -1199,6 +1215,7 @@ struct RenderChainArgs {
     float* A[MV_MAXL]; float* rgb_ctx; float* rgb;                                                   // forward outputs
     const float* drgb; const float* Ac[MV_MAXL]; const float* rgbc; float* ZB[MV_MAXL]; float* din;  // backward
     const long long* drgb_rows;                // backward: row r reads drgb[drgb_rows[r]] (null: drgb[r]) -- the step's upstream arrives in ray order, the net ran on sorted rows
+    const long long* cnt;                      // backward, deferred step: the row count is cnt[0] (N then is the upper bound the grid was sized for)
 };
 
 // `mv` packs the input layout of RenderingNetwork.forward (idr.py:145-154): low 8 bits = multires_view; bit 8 set = mode 'no_view_dir'
@@ -1300,13 +1317,15 @@ __global__ __launch_bounds__(64 * NW) void k_render_chain_bwd(RenderChainArgs a)
     constexpr int ROWS = 16 * MT, NTH = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
     const int row0 = blockIdx.x * ROWS, S = a.S, nl = a.net.n_layers;
+    const int Nr = a.cnt ? (int)a.cnt[0] : a.N;
+    if (row0 >= Nr) return;
     float* act = smem;
     {   // zb_L = drgb (1 - rgb^2)
         const int K = a.net.L[nl - 1].N, Kp = a.netT.L[nl - 1].KB * 16;
         for (int idx = tid; idx < ROWS * Kp; idx += NTH) {
             const int rr = idx / Kp, k = idx - rr * Kp, row = row0 + rr;
             float v = 0.0f;
-            if (row < a.N && k < K) {
+            if (row < Nr && k < K) {
                 const float y = a.rgbc[(size_t)row * K + k];
                 v = a.drgb[(size_t)(a.drgb_rows ? a.drgb_rows[row] : row) * K + k] * (1.0f - y * y);
                 a.ZB[nl - 1][(size_t)row * K + k] = v;
@@ -1338,7 +1357,7 @@ __global__ __launch_bounds__(64 * NW) void k_render_chain_bwd(RenderChainArgs a)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int row = row0 + m * 16 + 4 * q + i;
-                            const bool ok = l > 0 && t < ntw && col >= 0 && col < N && row < a.N;
+                            const bool ok = l > 0 && t < ntw && col >= 0 && col < N && row < Nr;
                             am[t][m][i] = Acl[ok ? (size_t)row * N + col : 0];
                         }
                 }
@@ -1358,12 +1377,12 @@ __global__ __launch_bounds__(64 * NW) void k_render_chain_bwd(RenderChainArgs a)
                                 const float ab = acc[m][t][i];
                                 if (l > 0) {
                                     float zb = 0.0f;
-                                    if (row < a.N) {
+                                    if (row < Nr) {
                                         zb = am[t][m][i] > 0.0f ? ab : 0.0f;                          // relu mask: stored post-activation > 0
                                         a.ZB[l - 1][(size_t)row * N + col] = zb;
                                     }
                                     act[rr * S + mv_perm(col)] = zb;
-                                } else if (row < a.N) a.din[(size_t)row * N + col] = ab;
+                                } else if (row < Nr) a.din[(size_t)row * N + col] = ab;
                             }
                     }
                 }

@@ -14,6 +14,14 @@
 #include <string.h>
 #include "capi_util.h"
 
+// Device-side counts of a deferred training step (include/mvsdf_hip.h, MvsdfLossArgs.counts_dev): p = {N, n_true}; the rows of a term are the point groups its
+// mask selects among [N hit | n_eik | n_ds | n_ds] (step_kernels.hip, mv_group_total).  p == NULL: the by-value counts of the argument structs are exact.
+struct MvDevCounts { const long long* p; int n_eik, n_ds, d_mask, e_mask; };
+__device__ __forceinline__ int mv_dc_group_rows(const MvDevCounts& c, int mask) {
+    const int N = (int)c.p[0];
+    return ((mask & 1) ? N : 0) + ((mask & 2) ? c.n_eik : 0) + ((mask & 4) ? c.n_ds : 0) + ((mask & 8) ? c.n_ds : 0);
+}
+
 struct Proj {
     float u, v;          // image coordinates
     float ju[3], jv[3];  // d(u,v)/d(world point)
@@ -93,12 +101,13 @@ struct FeatArgs {
     const float* center;       // [3]
     float* loss_pp;            // [N]   per-point loss, already weighted by 1 / (B * V * m_b)
     float* dpts;               // [N][3] d(total loss)/d(point)
+    const long long* cnt;      // deferred step: the points are cnt[0] (N bounds the grid)
 };
 
 __global__ __launch_bounds__(256) void k_feat_corr(FeatArgs a) {
     const int lane = threadIdx.x & 63, half = lane >> 5, ch = lane & 31;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= a.N) return;
+    if (i >= (a.cnt ? (int)a.cnt[0] : a.N)) return;
     int b = 0;
     while (b + 1 < a.B && i >= a.view_start[b + 1]) ++b;
     const int m_b = a.view_start[b + 1] - a.view_start[b];
@@ -275,6 +284,7 @@ struct LossArgs {
     float* s_rgb; float* s_grad; float* s_eik_out; float* s_surf; const float* dpts; float* s_diff; int n_dpts;
     // launch over MV_LOSS_SLICES workgroups (mvsdf_loss_forward): partial[MV_LOSS_SLICES][8] and a ticket counter zeroed before the launch; both null: one workgroup
     float* partial; unsigned* ticket;
+    MvDevCounts dc;                                                                  // dc.p set (deferred step): n_eik / n_depth / n_surf / n_feat / n_dpts above are upper bounds
 };
 
 // sum over the 1024 threads of the workgroup, the same value in every thread; fixed order (butterfly inside a wave, then the 16 wave sums in
@@ -299,10 +309,17 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
     __shared__ float s_part[MV_LOSS_SLICES][5];
     __shared__ unsigned s_last;
     const int tid = threadIdx.x, G = gridDim.x, STR = MV_LOSS_SLICES * 1024;
+    // row counts of the terms: by value, or (deferred step) derived from the device-side {N, n_true}
+    const bool dev = a.dc.p != nullptr;
+    const int n_eik = dev ? min(a.n_eik, mv_dc_group_rows(a.dc, a.dc.e_mask)) : a.n_eik;
+    const int n_depth = dev ? min(a.n_depth, mv_dc_group_rows(a.dc, a.dc.d_mask)) : a.n_depth;
+    const int n_surf = dev ? min(a.n_surf, (int)a.dc.p[1] + a.dc.n_eik) : a.n_surf;
+    const int n_feat = dev ? min(a.n_feat, (int)a.dc.p[0]) : a.n_feat;
+    const int n_dpts = dev ? min(a.n_dpts, 3 * (int)a.dc.p[0]) : a.n_dpts;
     const float invR = 1.0f / (float)a.R;
-    const float invE = a.n_eik > 0 ? (a.inv_counts ? a.inv_counts[0] : 1.0f / (float)a.n_eik) : 0.f;
-    const float invD = a.n_depth > 0 ? (a.inv_counts ? a.inv_counts[1] : 1.0f / (float)a.n_depth) : 0.f;
-    const float invS = a.n_surf > 0 ? (a.inv_counts ? a.inv_counts[2] : 1.0f / (float)a.n_surf) : 0.f;
+    const float invE = n_eik > 0 ? (a.inv_counts ? a.inv_counts[0] : 1.0f / (float)n_eik) : 0.f;
+    const float invD = n_depth > 0 ? (a.inv_counts ? a.inv_counts[1] : 1.0f / (float)n_depth) : 0.f;
+    const float invS = n_surf > 0 ? (a.inv_counts ? a.inv_counts[2] : 1.0f / (float)n_surf) : 0.f;
     const long long npos = a.surf_on ? *a.n_pos : 0;
     // the five terms run side by side on disjoint groups of the 16 waves (rgb 6, eikonal 4, depth 3, surface 2, feature 1): their loads are
     // in flight together instead of one term after the other behind a workgroup sum each (5 x ~3 us of load latency)
@@ -321,7 +338,7 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
             }
         } else if (w < 10) {
             // eikonal: mean((||g|| - 1)^2)                                                           loss.py:30-35
-            for (int i = slice * 256 + (w - 6) * 64 + lane; i < a.n_eik; i += MV_LOSS_SLICES * 256) {
+            for (int i = slice * 256 + (w - 6) * 64 + lane; i < n_eik; i += MV_LOSS_SLICES * 256) {
                 const float gx = a.grad_theta[3 * i], gy = a.grad_theta[3 * i + 1], gz = a.grad_theta[3 * i + 2];
                 const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
                 const float e = nrm - 1.0f;
@@ -332,7 +349,7 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
             }
         } else if (w < 13) {
             // depth: mean(|eikonal_output + dist_r| * weight); with conf.smooth = s: SmoothL1(eo / s, -dist_r / s) * s (beta = 1)      loss.py:57-61
-            for (int i = slice * 192 + (w - 10) * 64 + lane; i < a.n_depth; i += MV_LOSS_SLICES * 192) {
+            for (int i = slice * 192 + (w - 10) * 64 + lane; i < n_depth; i += MV_LOSS_SLICES * 192) {
                 const float df = a.eik_out[i] + a.dist_r[i], wgt = a.dweight[i];
                 float el = fabsf(df), gu = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);           // term and its derivative w.r.t. eikonal_output
                 if (a.smooth > 0.f) {
@@ -347,7 +364,7 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
             }
         } else if (w < 15) {
             // surface indicator: BCEWithLogits(mean) against [1]*n_pos + [0]*rest                    loss.py:167-174
-            for (int i = slice * 128 + (w - 13) * 64 + lane; i < a.n_surf; i += MV_LOSS_SLICES * 128) {
+            for (int i = slice * 128 + (w - 13) * 64 + lane; i < n_surf; i += MV_LOSS_SLICES * 128) {
                 if (a.surf_on) {
                     const float x = a.surf[i], t = (long long)i < npos ? 1.0f : 0.0f;
                     s += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
@@ -358,9 +375,9 @@ __global__ __launch_bounds__(1024) void k_loss_terms(LossArgs a) {
             }
         } else {
             // feature consistency: sum of the per-point terms of k_feat_corr
-            if (a.feat_on && a.feat_pp) for (int i = slice * 64 + lane; i < a.n_feat; i += MV_LOSS_SLICES * 64) s += a.feat_pp[i];
+            if (a.feat_on && a.feat_pp) for (int i = slice * 64 + lane; i < n_feat; i += MV_LOSS_SLICES * 64) s += a.feat_pp[i];
         }
-        if (a.s_diff && a.dpts) for (int i = slice * 1024 + tid; i < a.n_dpts; i += STR) a.s_diff[i] = a.dpts[i] * a.w_feat;
+        if (a.s_diff && a.dpts) for (int i = slice * 1024 + tid; i < n_dpts; i += STR) a.s_diff[i] = a.dpts[i] * a.w_feat;
         // the five sums of this slice: butterfly inside every wave, then the waves of each term in index order
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) red[w] = s;
@@ -427,9 +444,18 @@ int mvsdf_loss_terms(const float* rgb, const float* rgb_gt, const uint8_t* rgb_m
  * pts[N][3]: diff_surf_pts (hit points, view-major); view_start[B+1] (device int32): prefix sums of per-view hit counts.
  * feat[B][C][H][W] / feat_src[B][V][C][H][W] addressed by element strides (NCHW or channels_last).
  * cam[B][2][4][4], src_cams[B][V][2][4][4], size[1], center[3] (device).  Outputs: loss_pp[N] (sum = the loss), dpts[N][3]. */
+static int mv_feat_corr_cnt(const float* pts, int N, const int* view_start, int B, int V, int C, int H, int W, const float* feat,
+                            const long long* feat_strides, const float* feat_src, const long long* src_strides, const float* cam,
+                            const float* src_cams, const float* size, const float* center, float* loss_pp, float* dpts, const long long* cnt, void* stream);
 int mvsdf_feat_corr(const float* pts, int N, const int* view_start, int B, int V, int C, int H, int W, const float* feat,
                     const long long* feat_strides, const float* feat_src, const long long* src_strides, const float* cam,
                     const float* src_cams, const float* size, const float* center, float* loss_pp, float* dpts, void* stream) {
+    return mv_feat_corr_cnt(pts, N, view_start, B, V, C, H, W, feat, feat_strides, feat_src, src_strides, cam, src_cams, size, center, loss_pp, dpts, nullptr, stream);
+}
+// cnt (device, optional): the points are cnt[0]; N then bounds the grid (the deferred step)
+static int mv_feat_corr_cnt(const float* pts, int N, const int* view_start, int B, int V, int C, int H, int W, const float* feat,
+                            const long long* feat_strides, const float* feat_src, const long long* src_strides, const float* cam,
+                            const float* src_cams, const float* size, const float* center, float* loss_pp, float* dpts, const long long* cnt, void* stream) {
     if (!pts || !view_start || !feat || !feat_src || !cam || !src_cams || !size || !center || !loss_pp || !dpts || !feat_strides || !src_strides)
         return mv_fail(-1, "mvsdf_feat_corr: null argument");
     if (N <= 0 || B <= 0 || V <= 0 || H <= 0 || W <= 0) return mv_fail(-1, "mvsdf_feat_corr: bad sizes");
@@ -439,7 +465,7 @@ int mvsdf_feat_corr(const float* pts, int N, const int* view_start, int B, int V
     a.feat = feat; a.feat_src = feat_src;
     for (int i = 0; i < 4; ++i) a.fs[i] = feat_strides[i];
     for (int i = 0; i < 5; ++i) a.ss[i] = src_strides[i];
-    a.cam = cam; a.src_cams = src_cams; a.size = size; a.center = center; a.loss_pp = loss_pp; a.dpts = dpts;
+    a.cam = cam; a.src_cams = src_cams; a.size = size; a.center = center; a.loss_pp = loss_pp; a.dpts = dpts; a.cnt = cnt;
     hipLaunchKernelGGL(k_feat_corr, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     return mv_check(hipGetLastError(), "mvsdf_feat_corr");
 }
@@ -510,6 +536,7 @@ struct PrepCarveArgs {
     const uint8_t* net_mask; const uint8_t* obj_mask; const uint8_t* true_mask; int R, B; uint8_t* hit; int* view_start; long long* n_pos;
     unsigned* ticket;                     // zeroed here for k_loss_terms' last-workgroup-done count
     CarveArgs c;
+    MvDevCounts dc;                       // dc.p set (deferred step): c.M is an upper bound, the points are the rows of the groups dc.d_mask selects
 };
 // carve workgroups: 64 points each, the 16 waves split the views (wave w takes views w, w + 16, ...): the per-view counts and min / max combine
 // exactly in any order, so the result equals the one-thread-per-point kernel's bit for bit at a sixteenth of its latency
@@ -522,7 +549,9 @@ __global__ __launch_bounds__(1024) void k_loss_prep_carve(PrepCarveArgs a) {
     __shared__ float part[16][5][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = (blockIdx.x - 1) * 64 + lane;
-    const bool in = i < a.c.M;
+    const int Mc = a.dc.p ? min(a.c.M, mv_dc_group_rows(a.dc, a.dc.d_mask)) : a.c.M;
+    if ((int)(blockIdx.x - 1) * 64 >= Mc) return;                 // (workgroup-uniform)
+    const bool in = i < Mc;
     float pw[3] = {0.f, 0.f, 0.f};
     CarveAcc r = {0.f, 0.f, INFINITY, -INFINITY, 0.f};
     if (in) { mv_carve_world(a.c, i, pw); r = mv_carve_views(a.c, pw, w, 16); }
@@ -543,16 +572,22 @@ struct LossScaleArgs {
     float w_rgb, w_eik, w_surf, w_feat, w_depth;
     const float* src[5]; float* dst[5]; int n[5];      // unit gradients of rgb / grad_theta / eikonal_output / surf / diff_surf_pts (k_feat_corr's dpts) -> scaled copies
     float* coef_feat;                     // [1]: dL/d(sum of the per-point feature terms)
+    MvDevCounts dc;                       // dc.p set (deferred step): n[1..4] are upper bounds
 };
 __global__ void k_loss_scale(LossScaleArgs a) {
     float g[6];
     for (int k = 0; k < 6; ++k) g[k] = a.g[k] ? a.g[k][0] : 0.0f;
     const float g0 = g[0];
     const float c[5] = {g0 * a.w_rgb + g[1], g0 * a.w_eik + g[2], g0 * a.w_depth + g[3], g0 * a.w_surf + g[5], g0 * a.w_feat + g[4]};
-    const int total = a.n[0] + a.n[1] + a.n[2] + a.n[3] + a.n[4];
+    int n[5] = {a.n[0], a.n[1], a.n[2], a.n[3], a.n[4]};
+    if (a.dc.p) {
+        n[1] = min(n[1], 3 * mv_dc_group_rows(a.dc, a.dc.e_mask)); n[2] = min(n[2], mv_dc_group_rows(a.dc, a.dc.d_mask));
+        n[3] = min(n[3], (int)a.dc.p[1] + a.dc.n_eik); n[4] = min(n[4], 3 * (int)a.dc.p[0]);
+    }
+    const int total = n[0] + n[1] + n[2] + n[3] + n[4];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         int k = i, t = 0;
-        while (t < 4 && k >= a.n[t]) { k -= a.n[t]; ++t; }
+        while (t < 4 && k >= n[t]) { k -= n[t]; ++t; }
         a.dst[t][k] = a.src[t][k] * c[t];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.coef_feat) a.coef_feat[0] = g0 * a.w_feat + g[4];
@@ -585,6 +620,7 @@ int mvsdf_loss_scale(const float* const* g, float w_rgb, float w_eik, float w_su
     }
     a.src[4] = nullptr; a.dst[4] = nullptr; a.n[4] = 0;
     a.coef_feat = coef_feat;
+    memset(&a.dc, 0, sizeof(a.dc));
     const int blocks = total > 0 ? (total + 255) / 256 : 1;
     hipLaunchKernelGGL(k_loss_scale, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, (hipStream_t)stream, a);
     return mv_check(hipGetLastError(), "mvsdf_loss_scale");
@@ -638,6 +674,13 @@ int mvsdf_loss_forward(const MvsdfLossArgs* a, void* blk, void* stream) {
     if (a->B > 1024 || a->R % a->B) return mv_fail(-1, "mvsdf_loss_forward: R must be a multiple of B <= 1024");
     if (a->n_depth > 0 && (!a->points_hom || !a->depths || !a->depth_cams || !a->size || !a->center || a->dB <= 0 || a->dh <= 0 || a->dw <= 0))
         return mv_fail(-1, "mvsdf_loss_forward: depth term without depth maps / cameras");
+    // deferred step: the counts above are upper bounds, the kernels take {N, n_true} from the device
+    MvDevCounts dc;
+    memset(&dc, 0, sizeof(dc));
+    if (a->counts_dev) {
+        if (a->n_eik < 0 || a->n_ds < 0 || (a->d_mask & ~15) || (a->e_mask & ~15)) return mv_fail(-1, "mvsdf_loss_forward: bad point groups beside counts_dev");
+        dc.p = a->counts_dev; dc.n_eik = a->n_eik; dc.n_ds = a->n_ds; dc.d_mask = a->d_mask; dc.e_mask = a->e_mask;
+    }
     {
         PrepCarveArgs pc;
         memset(&pc, 0, sizeof(pc));
@@ -650,14 +693,15 @@ int mvsdf_loss_forward(const MvsdfLossArgs* a, void* blk, void* stream) {
         c.out_thresh_perc = a->out_thresh_perc; c.far_thresh = a->far_thresh; c.far_att = a->far_att; c.near_thresh = a->near_thresh; c.near_att = a->near_att;
         c.use_invalid = a->use_invalid ? 1 : 0;
         c.dist_r = (float*)(b + lo.dist_r); c.weight = (float*)(b + lo.weight);
+        pc.dc = dc;
         hipLaunchKernelGGL(k_loss_prep_carve, dim3(1 + (a->n_depth + 63) / 64), dim3(1024), 0, (hipStream_t)stream, pc);
         rc = mv_check(hipGetLastError(), "mvsdf_loss_forward (prep + carve)");
         if (rc) return rc;
     }
     const bool feat = a->feat_on && a->N > 0;
     if (feat) {
-        rc = mvsdf_feat_corr(a->diff_pts, a->N, view_start, a->B, a->V, a->C, a->H, a->W, a->feat, a->feat_strides, a->feat_src, a->src_strides, a->cam,
-                             a->src_cams, a->size, a->center, (float*)(b + lo.loss_pp), (float*)(b + lo.dpts), stream);
+        rc = mv_feat_corr_cnt(a->diff_pts, a->N, view_start, a->B, a->V, a->C, a->H, a->W, a->feat, a->feat_strides, a->feat_src, a->src_strides, a->cam,
+                              a->src_cams, a->size, a->center, (float*)(b + lo.loss_pp), (float*)(b + lo.dpts), a->counts_dev, stream);
         if (rc) return rc;
     }
     {
@@ -679,6 +723,7 @@ int mvsdf_loss_forward(const MvsdfLossArgs* a, void* blk, void* stream) {
         k.s_rgb = (float*)(b + lo.s_rgb); k.s_grad = (float*)(b + lo.s_grad); k.s_eik_out = (float*)(b + lo.s_eo); k.s_surf = (float*)(b + lo.s_sf);
         k.dpts = feat ? (const float*)(b + lo.dpts) : nullptr; k.s_diff = feat ? (float*)(b + lo.s_diff) : nullptr; k.n_dpts = feat ? a->N * 3 : 0;
         k.partial = (float*)(b + loss_scratch(a, lo)); k.ticket = (unsigned*)(b + loss_scratch(a, lo) + MV_LOSS_SLICES * 8 * 4);
+        k.dc = dc;
         hipLaunchKernelGGL(k_loss_terms, dim3(MV_LOSS_SLICES), dim3(1024), 0, (hipStream_t)stream, k);
         return mv_check(hipGetLastError(), "mvsdf_loss_forward (terms)");
     }
@@ -704,6 +749,8 @@ int mvsdf_loss_backward(const MvsdfLossArgs* a, const void* blk, const float* co
         s.src[t] = src[t]; s.dst[t] = dst[t]; s.n[t] = dst[t] ? n[t] : 0; total += s.n[t];
     }
     s.coef_feat = nullptr;
+    memset(&s.dc, 0, sizeof(s.dc));
+    if (a->counts_dev) { s.dc.p = a->counts_dev; s.dc.n_eik = a->n_eik; s.dc.n_ds = a->n_ds; s.dc.d_mask = a->d_mask; s.dc.e_mask = a->e_mask; }
     const int blocks = total > 0 ? (total + 255) / 256 : 1;
     hipLaunchKernelGGL(k_loss_scale, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, (hipStream_t)stream, s);
     return mv_check(hipGetLastError(), "mvsdf_loss_backward");

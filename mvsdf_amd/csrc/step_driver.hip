@@ -11,6 +11,7 @@
 #include "capi_util.h"
 #include "step_internal.h"
 #include <sched.h>
+#include <time.h>
 
 namespace {
 
@@ -36,14 +37,16 @@ struct Step {
     int R, E, M, Nout, K0r, nl;                      // rays, sample rows, evaluation rows, SDF output width, rendering-net input width, layers in total
     size_t woff[MVSDF_STEP_MAX_LAYERS], boff[MVSDF_STEP_MAX_LAYERS];   // float offsets inside dflat: [W | b of the SDF net | W | b of the rendering net]
     size_t seg[2][3];                                // per network: first weight, first bias, end
-    long long* counts_host;                          // pinned, host-mapped [5]: the 4 counts + the sequence number of the forward that wrote them
-    long long* counts_host_dev;                      // its device address (nullptr: not mapped, the counts travel by a copy + ev_counts)
+    long long* counts_host;                          // pinned, host-mapped ring [MVSDF_STEP_COUNT_RING][8]: per slot the 4 counts + (entry 4) the sequence number of the
+                                                     // forward that wrote them; forward `seq` owns slot seq % RING (a host that runs steps ahead can still ask for older ones)
+    long long* counts_host_dev;                      // its device address (nullptr: not mapped, the counts travel by a copy + ev_counts into slot 0)
+    int can_defer;                                   // every launch of the backward has a device-count form for these networks (mv_step_can_defer)
     hipEvent_t ev_counts;
     bool counts_pending;
     long long counts_seq;                            // forwards so far: the number the host waits for in counts_host[4]
     hipStream_t counts_stream;                       // the stream of the forward in flight (queried if the number does not arrive)
     int timing;
-    hipEvent_t ev_t[8];                              // 0-4: around the tracer's launches; 5: end of the forward; 6 / 7: around the backward
+    hipEvent_t ev_t[9];                              // 0-4: around the tracer's launches; 5: end of the forward; 6 / 7: around the backward; 8: entry of the forward
     bool timed, timed_bwd;
     hipStream_t side;                                // the sample rows of the fused evaluation run here, beside the tracer (created on first use)
     hipEvent_t ev_fork, ev_join;
@@ -173,6 +176,7 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
     for (int i = 0; i < d.n_render; ++i) { rnd.wp[i] = rndT.wp[i] = &dummy; }
     const size_t ctx_f = mvsdf_sdf_ctx_floats(&sdf, M, M), rctx_f = mvsdf_render_ctx_floats(&rnd, R);
     if (!ctx_f || !rctx_f) { delete st; return mv_fail(-2, "mvsdf_step_create: network descriptor rejected (layer dims / skip mask)"); }
+    st->can_defer = (d.n_ds == 0 && mv_step_can_defer(&sdf, &sdfT, &rnd, &rndT)) ? 1 : 0;   // (phase 0 checks its depth-surface sample counts on the host: idr.py:244)
     fo.sdf_ctx = take(ctx_f * 4);
     fo.rgb_sorted = take((size_t)R * 12);
     fo.render_ctx = take(rctx_f * 4);
@@ -213,7 +217,7 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
 void mvsdf_step_destroy(void* step) {
     Step* st = (Step*)step;
     if (!st) return;
-    if (st->timing) for (int i = 0; i < 8; ++i) hipEventDestroy(st->ev_t[i]);
+    if (st->timing) for (int i = 0; i < 9; ++i) hipEventDestroy(st->ev_t[i]);
     if (st->counts_host) { hipEventDestroy(st->ev_counts); hipHostFree(st->counts_host); }
     if (st->side) { hipStreamSynchronize(st->side); hipEventDestroy(st->ev_fork); hipEventDestroy(st->ev_join); hipStreamDestroy(st->side); }
     delete st;
@@ -223,10 +227,10 @@ int mvsdf_step_set_timing(void* step, int enable) {
     Step* st = (Step*)step;
     if (!st) return mv_fail(-1, "mvsdf_step_set_timing: null step");
     if (enable && !st->timing) {
-        for (int i = 0; i < 8; ++i) ST_HIP(hipEventCreate(&st->ev_t[i]));
+        for (int i = 0; i < 9; ++i) ST_HIP(hipEventCreate(&st->ev_t[i]));
         st->timing = 1;
     } else if (!enable && st->timing) {
-        for (int i = 0; i < 8; ++i) hipEventDestroy(st->ev_t[i]);
+        for (int i = 0; i < 9; ++i) hipEventDestroy(st->ev_t[i]);
         st->timing = 0;
     }
     st->timed = false; st->timed_bwd = false;
@@ -251,7 +255,7 @@ int mvsdf_step_times(void* step, float ms[6]) {
     ST_HIP(hipEventElapsedTime(&ms[3], st->ev_t[4], st->ev_t[5]));
     ms[4] = 0.f;
     if (st->timed_bwd) ST_HIP(hipEventElapsedTime(&ms[4], st->ev_t[6], st->ev_t[7]));
-    ST_HIP(hipEventElapsedTime(&ms[5], st->ev_t[0], st->ev_t[5]));
+    ST_HIP(hipEventElapsedTime(&ms[5], st->ev_t[8], st->ev_t[5]));
     return 0;
 }
 
@@ -264,8 +268,8 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
         return mv_fail(-1, "mvsdf_step_forward: missing input");
     hipStream_t s = (hipStream_t)stream;
     if (!st->counts_host) {                                       // first forward: host-side staging for the hit counts
-        ST_HIP(hipHostMalloc((void**)&st->counts_host, 5 * sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
-        st->counts_host[4] = 0;
+        ST_HIP(hipHostMalloc((void**)&st->counts_host, MVSDF_STEP_COUNT_RING * 8 * sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(st->counts_host, 0, MVSDF_STEP_COUNT_RING * 8 * sizeof(long long));
         // the partition kernel writes the counts straight into this buffer (no D2H copy node between two kernels)
         if (hipHostGetDevicePointer((void**)&st->counts_host_dev, st->counts_host, 0) != hipSuccess) { (void)hipGetLastError(); st->counts_host_dev = nullptr; }
         if (hipEventCreateWithFlags(&st->ev_counts, hipEventDisableTiming) != hipSuccess) {
@@ -277,6 +281,7 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     const MvsdfStepLayout& L = st->lay;
     const FwdOffsets& fo = st->fo;
     const int R = st->R, E = st->E, M = st->M, nl = st->nl;
+    if (st->timing) ST_HIP(hipEventRecord(st->ev_t[8], s));
     // 1. weight-norm fold + MFMA packs of both networks (idr.py:70-71; one fold per step instead of one per network call)
     float* w[MVSDF_STEP_MAX_LAYERS]; float* wp[MVSDF_STEP_MAX_LAYERS]; float* wpT[MVSDF_STEP_MAX_LAYERS];
     for (int l = 0; l < nl; ++l) { w[l] = (float*)(fwd + fo.w[l]); wp[l] = (float*)(fwd + fo.wp[l]); wpT[l] = (float*)(fwd + fo.wpT[l]); }
@@ -366,7 +371,9 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     long long* perm = (long long*)(fwd + L.perm); long long* inv = (long long*)(fwd + fo.inv); long long* true_rows = (long long*)(fwd + fo.true_rows);
     long long* counts = (long long*)(fwd + fo.counts); float* view_sorted = (float*)(fwd + fo.view_sorted);
     ST_TRY(mv_partition_rays_step(mask, d.use_object_mask ? in->object_mask : nullptr, in->object_mask_true, ray_dirs, R, perm, inv, true_rows, counts,
-                                  view_sorted, (int*)(fwd + fo.true_rank), d.n_ds > 0 ? in->ds_counts : nullptr, st->counts_host_dev, ++st->counts_seq, stream));
+                                  view_sorted, (int*)(fwd + fo.true_rank), d.n_ds > 0 ? in->ds_counts : nullptr,
+                                  st->counts_host_dev ? st->counts_host_dev + 8 * ((st->counts_seq + 1) % MVSDF_STEP_COUNT_RING) : nullptr, st->counts_seq + 1, stream));
+    ++st->counts_seq;
     if (!st->counts_host_dev) {                                   // (pinned memory not mapped: a copy and an event)
         ST_HIP(hipMemcpyAsync(st->counts_host, counts, 4 * sizeof(long long), hipMemcpyDeviceToHost, s));
         ST_HIP(hipEventRecord(st->ev_counts, s));
@@ -399,35 +406,81 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     return 0;
 }
 
+// wait (bounded spin, then short sleeps: a rank that shares its cores with others must not burn them) until forward `seq` has stored its record
+static int step_wait_seq(Step* st, long long seq, long long counts[4]) {
+    long long* slot = st->counts_host + 8 * (seq % MVSDF_STEP_COUNT_RING);
+    // the partition kernel stores the forward's sequence number behind the counts (release, system scope): poll it.  Should it never arrive
+    // (the stream drained or failed without the kernel having run), the stream's status ends the wait.
+    for (unsigned long long it = 1;; ++it) {
+        const long long have = __atomic_load_n(&slot[4], __ATOMIC_ACQUIRE);
+        if (have == seq) break;
+        if (have > seq) return mv_fail(-4, "mvsdf_step_wait_counts_seq: the record of that forward was overwritten (read the counts from its forward block)");
+        if (it < 5000) { __builtin_ia32_pause(); continue; }       // ~50-100 us of spinning: the common case (the kernel is about to run)
+        struct timespec ts = {0, 20000};                            // then 20 us naps
+        nanosleep(&ts, nullptr);
+        if ((it & 0x3ff) == 0 && seq == st->counts_seq) {
+            const hipError_t q = hipStreamQuery(st->counts_stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(&slot[4], __ATOMIC_ACQUIRE) == seq) break;
+                return mv_fail(-1, "mvsdf_step_wait_counts: the forward finished without delivering its counts");
+            }
+            if (q != hipErrorNotReady) return mv_check(q, "mvsdf_step_wait_counts (hipStreamQuery)");
+        }
+    }
+    for (int i = 0; i < 4; ++i) counts[i] = slot[i];
+    // the slot may have been rewritten while we copied (a forward RING steps later): the number decides
+    if (__atomic_load_n(&slot[4], __ATOMIC_ACQUIRE) != seq) return mv_fail(-4, "mvsdf_step_wait_counts_seq: the record of that forward was overwritten (read the counts from its forward block)");
+    return 0;
+}
+
 int mvsdf_step_wait_counts(void* step, long long counts[4]) {
     Step* st = (Step*)step;
     if (!st || !counts) return mv_fail(-1, "mvsdf_step_wait_counts: null argument");
     if (!st->counts_pending) return mv_fail(-1, "mvsdf_step_wait_counts: no forward is in flight");
     if (!st->counts_host_dev) {
         ST_HIP(hipEventSynchronize(st->ev_counts));
-    } else {
-        // the partition kernel stores this forward's sequence number behind the counts (release, system scope): poll it.  Should it never arrive
-        // (the stream drained or failed without the kernel having run), the stream's status ends the wait.
-        const long long want = st->counts_seq;
-        for (unsigned long long it = 1; __atomic_load_n(&st->counts_host[4], __ATOMIC_ACQUIRE) != want; ++it) {
-            if ((it & 0x3ff) == 0) {
-                sched_yield();
-                if ((it & 0xfffff) == 0) {
-                    const hipError_t q = hipStreamQuery(st->counts_stream);
-                    if (q == hipSuccess) {
-                        if (__atomic_load_n(&st->counts_host[4], __ATOMIC_ACQUIRE) == want) break;
-                        st->counts_pending = false;
-                        return mv_fail(-1, "mvsdf_step_wait_counts: the forward finished without delivering its counts");
-                    }
-                    if (q != hipErrorNotReady) { st->counts_pending = false; return mv_check(q, "mvsdf_step_wait_counts (hipStreamQuery)"); }
-                }
-            } else {
-                __builtin_ia32_pause();
-            }
-        }
+        for (int i = 0; i < 4; ++i) counts[i] = st->counts_host[i];
+        st->counts_pending = false;
+        return 0;
     }
-    for (int i = 0; i < 4; ++i) counts[i] = st->counts_host[i];
+    const int rc = step_wait_seq(st, st->counts_seq, counts);
     st->counts_pending = false;
+    return rc;
+}
+
+long long mvsdf_step_seq(void* step) { return step ? ((Step*)step)->counts_seq : -1; }
+size_t mvsdf_step_counts_offset(void* step) { return step ? ((Step*)step)->fo.counts : 0; }
+int mvsdf_step_can_defer(void* step) { Step* st = (Step*)step; return (st && st->can_defer) ? 1 : 0; }
+
+int mvsdf_step_wait_counts_seq(void* step, long long seq, long long counts[4]) {
+    Step* st = (Step*)step;
+    if (!st || !counts) return mv_fail(-1, "mvsdf_step_wait_counts_seq: null argument");
+    if (seq <= 0 || seq > st->counts_seq || !st->counts_host) return mv_fail(-1, "mvsdf_step_wait_counts_seq: no such forward");
+    if (!st->counts_host_dev) {                                   // (unmapped pinned memory: one record, the last forward's)
+        if (seq != st->counts_seq) return mv_fail(-4, "mvsdf_step_wait_counts_seq: the record of that forward was overwritten (read the counts from its forward block)");
+        ST_HIP(hipEventSynchronize(st->ev_counts));
+        for (int i = 0; i < 4; ++i) counts[i] = st->counts_host[i];
+        return 0;
+    }
+    if (seq + MVSDF_STEP_COUNT_RING <= st->counts_seq) return mv_fail(-4, "mvsdf_step_wait_counts_seq: the record of that forward was overwritten (read the counts from its forward block)");
+    const int rc = step_wait_seq(st, seq, counts);
+    if (rc == 0 && seq == st->counts_seq) st->counts_pending = false;
+    return rc;
+}
+
+long long mvsdf_step_done_seq(void* step, long long counts[4]) {
+    Step* st = (Step*)step;
+    if (!st || !st->counts_host || !st->counts_host_dev) return 0;
+    // kernels of one stream finish in order: walk back from the newest forward to the first slot that carries its own number
+    for (long long seq = st->counts_seq; seq > 0 && seq + MVSDF_STEP_COUNT_RING > st->counts_seq; --seq) {
+        long long* slot = st->counts_host + 8 * (seq % MVSDF_STEP_COUNT_RING);
+        if (__atomic_load_n(&slot[4], __ATOMIC_ACQUIRE) != seq) continue;
+        if (counts) {
+            for (int i = 0; i < 4; ++i) counts[i] = slot[i];
+            if (__atomic_load_n(&slot[4], __ATOMIC_ACQUIRE) != seq) continue;
+        }
+        return seq;
+    }
     return 0;
 }
 
@@ -438,9 +491,19 @@ static int step_backward_impl(void* step, const MvsdfStepParams* prm, int N, int
     if (!st || !prm || !fwd_ || !bwd_ || !dv || !dg || !db) return mv_fail(-1, "mvsdf_step_backward: null argument");
     const MvsdfStepDesc& d = st->d;
     const int R = st->R, E = st->E, M = st->M, nl = st->nl, Nout = st->Nout;
-    if (N < 0 || N > R || n_true < 0 || n_true > N) return mv_fail(-1, "mvsdf_step_backward: bad counts");
     hipStream_t s = (hipStream_t)stream;
     const char* fwd = (const char*)fwd_;
+    // N < 0: the deferred step.  {N, n_true} stay on the device (`cnt`, written by this forward's ray partition); every launch below is sized for N = R and bounds
+    // its rows by them (step_internal.h, "device-side counts").  n_true then carries a hint of N that only selects kernel forms.
+    const long long* cnt = nullptr;
+    int n_hint = -1;
+    if (N < 0) {
+        if (!st->can_defer) return mv_fail(-3, "mvsdf_step_backward: N < 0 (device-side counts) is not available for this step (mvsdf_step_can_defer)");
+        cnt = (const long long*)(fwd + st->fo.counts);
+        n_hint = (n_true >= 0 && n_true <= R) ? n_true : R;
+        N = R; n_true = R;
+    }
+    if (N < 0 || N > R || n_true < 0 || n_true > N) return mv_fail(-1, "mvsdf_step_backward: bad counts");
     char* bwd = (char*)bwd_;
     const MvsdfStepLayout& L = st->lay;
     const FwdOffsets& fo = st->fo;
@@ -469,10 +532,10 @@ static int step_backward_impl(void* step, const MvsdfStepParams* prm, int N, int
             float* drgb_sorted = (float*)(bwd + bo.drgb_sorted);
             float* din_w = (float*)(bwd + bo.din);
             int rcb = mv_render_backward_chain(&rnd, &rndT, N, R, d_rgb, (const long long*)(fwd + L.perm), (const float*)(fwd + fo.render_ctx), din_w,
-                                               (float*)(bwd + bo.render_ws), stream);
-            if (rcb == -3) {                                                            // per-layer route: gather first
+                                               (float*)(bwd + bo.render_ws), cnt, stream);
+            if (rcb == -3 && !cnt) {                                                            // per-layer route: gather first
                 hipLaunchKernelGGL(k_step_gather_drgb, dim3((3 * N + 255) / 256), dim3(256), 0, s, d_rgb, (const long long*)(fwd + L.perm), N, drgb_sorted);
-                rcb = mv_render_backward_chain(&rnd, &rndT, N, R, drgb_sorted, nullptr, (const float*)(fwd + fo.render_ctx), din_w, (float*)(bwd + bo.render_ws), stream);
+                rcb = mv_render_backward_chain(&rnd, &rndT, N, R, drgb_sorted, nullptr, (const float*)(fwd + fo.render_ctx), din_w, (float*)(bwd + bo.render_ws), nullptr, stream);
             }
             if (rcb) return rcb;
             din = din_w;
@@ -483,29 +546,30 @@ static int step_backward_impl(void* step, const MvsdfStepParams* prm, int N, int
         float* rws = with_r ? (float*)(bwd + bo.render_ws) : nullptr;
         float* wsA = (float*)(bwd + bo.wsA);
         bool done = false;
+        if (cnt && !(din && N > 0)) return mv_fail(-3, "mvsdf_step_backward: device-side counts need the upstream of rgb_values (the fused route)");
         if (din && N > 0) {
             // (X) input adjoint of the surface points for the rendering net's upstream alone, (A) the full pass with every upstream except
             // SampleNetwork's scalar: independent, one grid; then fbar = -xbar.v / n.v and a first-order delta pass.
             // Both upstreams come out of ONE gather pass (the staged route: zero-fill + rendering-net adjoints, two row-block copies, scatter).
             float* dy_x = (float*)(bwd + bo.dy_x); float* dn_x = (float*)(bwd + bo.dn_x);
             ST_TRY(mv_step_backward_assemble(d.n_eik, d.n_ds, N, Nout, n_true, din, st->K0r, feat0, nrm0, use_geo, (const int*)(fwd + fo.true_rank), d_eo,
-                                             d_gth, d_si, d_mask, e_mask, dy, dn, dy_x, dn_x, stream));
+                                             d_gth, d_si, d_mask, e_mask, dy, dn, dy_x, dn_x, cnt, stream));
             float* dx = (float*)(bwd + bo.dx);
-            int rc = mvsdf_sdf_backward_pair(&sdf, &sdfT, M, M, Mb, dy, dn, wsA, E, N, dy_x, use_geo ? dn_x : nullptr, (float*)(bwd + bo.wsX), dx, ctx, stream);
+            int rc = mv_sdf_backward_pair_cnt(&sdf, &sdfT, M, M, Mb, dy, dn, wsA, E, N, dy_x, use_geo ? dn_x : nullptr, (float*)(bwd + bo.wsX), dx, ctx, cnt, n_hint, stream);
             if (rc == 0) {
                 // SampleNetwork's scalar (f = -xbar.v / n.v, App. E.6), its adjoints as fbar x s_l (one elementwise launch: the forward saved s_l), then the
                 // weight gradients of BOTH networks in one k_wgrad_net / k_reduce_net pair.  (Round 3 ran the chunks that do not depend on fbar on a
                 // second stream beside a 9-phase delta chain; with the delta reduced to ~10 us the split measured no gain and is gone.)
                 float* fbar = (float*)(bwd + bo.fbar);
-                if (mv_delta_is_chain()) {                                              // MVSDF_DELTA_CHAIN=1: the cross-check route
+                if (mv_delta_is_chain() && !cnt) {                                      // MVSDF_DELTA_CHAIN=1: the cross-check route
                     ST_TRY(mvsdf_step_backward_fbar(d.n_eik, d.n_ds, N, Nout, din, st->K0r, use_geo, d_diff, dx, view_sorted, n_eval, dy, fbar, stream));
                     ST_TRY(mv_sdf_backward_delta(&sdf, &sdfT, M, M, Mb, ctx, wsA, E, N, fbar, stream));
                 } else {
-                    ST_TRY(mv_sdf_backward_delta_fbar(&sdf, M, M, Mb, ctx, wsA, E, N, Nout, din, st->K0r, use_geo, d_diff, dx, view_sorted, n_eval, dy, fbar, stream));
+                    ST_TRY(mv_sdf_backward_delta_fbar(&sdf, M, M, Mb, ctx, wsA, E, N, Nout, din, st->K0r, use_geo, d_diff, dx, view_sorted, n_eval, dy, fbar, cnt, stream));
                 }
-                ST_TRY(mv_step_wgrad(&sdf, &rnd, M, M, Mb, dy, ctx, wsA, with_r ? N : 0, R, rctx, rws, dW_s, db_s, dW_r, db_r, stream));
+                ST_TRY(mv_step_wgrad(&sdf, &rnd, M, M, Mb, dy, ctx, wsA, with_r ? N : 0, R, rctx, rws, dW_s, db_s, dW_r, db_r, cnt, E, stream));
                 done = true;
-            } else if (rc == -3) {                                                      // network too wide for the fused chains: the sequential route
+            } else if (rc == -3 && !cnt) {                                                      // network too wide for the fused chains: the sequential route
                 ST_TRY(mvsdf_sdf_backward(&sdf, &sdfT, x_eval + 3 * (size_t)E, M, M, E, N, dy_x, use_geo ? dn_x : nullptr, ctx, nullptr, nullptr, dx, wsA, stream));
                 float* fbar = (float*)(bwd + bo.fbar);
                 ST_TRY(mvsdf_step_backward_fbar(d.n_eik, d.n_ds, N, Nout, din, st->K0r, use_geo, d_diff, dx, view_sorted, n_eval, dy, fbar, stream));

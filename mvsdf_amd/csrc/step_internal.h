@@ -16,7 +16,19 @@ int mv_partition_rays_step(const uint8_t* net_mask, const uint8_t* object_mask, 
 // dy / dn (full pass A upstream without SampleNetwork's scalar) and dy_x / dn_x (rendering-net adjoints alone on the hit rows) in one gather pass
 int mv_step_backward_assemble(int n_eik, int n_ds, int N, int Nout, int n_true, const float* din, int din_ld, int din_feat0, int din_nrm0, int use_geo,
                               const int* true_rank, const float* d_eo, const float* d_gth, const float* d_si, int d_mask, int e_mask, float* dy,
-                              float* dn, float* dy_x, float* dn_x, void* stream);
+                              float* dn, float* dy_x, float* dn_x, const long long* cnt, void* stream);
+
+// ---- device-side counts (the deferred step) ------------------------------------------------------------------------------------------------
+// A training step whose host never learns the hit counts: k_partition_rays leaves counts = {N hit rows, n_true of them inside the true mask} in the forward
+// block, and every N-dependent launch behind it takes them from there.  Convention of the `cnt` parameters below and of the kernels' argument structs:
+// cnt == NULL: the row counts passed by value are exact (the classic step; grids, layouts and bounds follow them).  cnt != NULL: cnt[0] = N, cnt[1] = n_true on
+// the DEVICE; the by-value counts are then UPPER BOUNDS (N = R): workspaces, their layouts and the grids are sized for them, every kernel bounds its rows by
+// the device values, and workgroups wholly beyond them leave at once.  Results are bit-identical to the classic step's (tests/test_gpu_deferred.py).
+int mv_sdf_backward_pair_cnt(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M, int Mg, int MbA, const float* dyA, const float* dnA, float* wsA,
+                             int row0X, int MbX, const float* dyX, const float* dnX, float* wsX, float* dx, const float* ctx, const long long* cnt, int n_hint,
+                             void* stream);
+// 1 when every launch of mvsdf_step_backward has a device-count form for these networks (the fused chain kernels cover them), else 0
+int mv_step_can_defer(const MvsdfNetDesc* sdf, const MvsdfNetDesc* sdfT, const MvsdfNetDesc* rnd, const MvsdfNetDesc* rndT);
 
 // mvsdf_sdf_forward with the step's evaluation rows gathered inside the fused chain kernel; `gather` = const FwdGather* (layer_kernels.h) or NULL;
 // -> 1 when the per-layer route would run (nothing launched: gather yourself and call with x)
@@ -30,15 +42,15 @@ int mv_chain_split_pays(const MvsdfNetDesc* d, int E, int M);
 // gradients of BOTH networks as one k_wgrad_net / k_reduce_net pair
 // drgb_rows (may be NULL): sorted row r takes its upstream from drgb[drgb_rows[r]]; -3 when that needs the fused chain kernel and it does not apply
 int mv_render_backward_chain(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int N, int Nctx, const float* drgb, const long long* drgb_rows, const float* ctx,
-                             float* din, float* ws, void* stream);
+                             float* din, float* ws, const long long* cnt, void* stream);
 int mv_delta_is_chain();                                       // MVSDF_DELTA_CHAIN=1
 int mv_sdf_backward_delta_fbar(const MvsdfNetDesc* d, int M, int Mg, int Mb, const float* ctx, float* ws, int row0D, int MbD, int Nout, const float* din,
                                int din_ld, int use_geo, const float* d_diff, const float* dx, const float* view_sorted, const float* n_eval, float* dy,
-                               float* fbar, void* stream);
+                               float* fbar, const long long* cnt, void* stream);
 int mv_sdf_backward_delta(const MvsdfNetDesc* d, const MvsdfNetDesc* dT, int M, int Mg, int Mb, const float* ctx, float* ws, int row0D, int MbD,
                           const float* fbar, void* stream);
 int mv_step_wgrad(const MvsdfNetDesc* sd, const MvsdfNetDesc* rd, int M, int Mg, int Mb, const float* dy, const float* ctx, float* wsA, int N, int Nctx,
-                  const float* rctx, float* rws, float* dW_s, float* db_s, float* dW_r, float* db_r, void* stream);
+                  const float* rctx, float* rws, float* dW_s, float* db_s, float* dW_r, float* db_r, const long long* cnt, int cnt_base, void* stream);
 
 // fold + MFMA packs (+ bf16 packs where wp16[l] is set: nsplit[l] = its PE split width) of every layer + the camera rays in ONE launch
 // (basic.hip::k_step_prologue): the work of mvsdf_fold_pack_net, mvsdf_pack_bf16_net_skips and mvsdf_camera_rays, same results

@@ -240,12 +240,14 @@ struct StepAsmArgs {
     StepBwdArgs b;
     const int* true_rank;                 // [>= N] rank of sorted hit row k among the true-mask hit rows, -1 outside
     float* dy_x; float* dn_x;             // [N][Nout], [N][3]
+    const long long* cnt;                 // deferred step (step_internal.h): {N, n_true} on the device; b.N / b.Mb / b.n_true are then upper bounds
 };
 __global__ void k_step_bwd_assemble(StepAsmArgs s) {
     const StepBwdArgs& a = s.b;
-    const StepGroups gd = {a.n_eik, a.n_ds, a.E, a.N, a.d_mask}, ge = {a.n_eik, a.n_ds, a.E, a.N, a.e_mask};
+    const int N = s.cnt ? (int)s.cnt[0] : a.N, n_true = s.cnt ? (int)s.cnt[1] : a.n_true;
+    const StepGroups gd = {a.n_eik, a.n_ds, a.E, N, a.d_mask}, ge = {a.n_eik, a.n_ds, a.E, N, a.e_mask};
     const int W = a.Nout + 3;
-    const size_t total = (size_t)a.Mb * W;
+    const size_t total = (size_t)(a.E + N) * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(i / W), c = (int)(i - (size_t)row * W);
         const int k = row - a.E;
@@ -258,7 +260,7 @@ __global__ void k_step_bwd_assemble(StepAsmArgs s) {
                 const int idx = mv_group_index(gd, row);
                 if (idx >= 0) v = v0 + a.d_eo[idx];
             } else if (c == 1 && a.d_si) {
-                const int idx = k >= 0 ? s.true_rank[k] : (row < a.n_eik ? a.n_true + row : -1);
+                const int idx = k >= 0 ? s.true_rank[k] : (row < a.n_eik ? n_true + row : -1);
                 if (idx >= 0) v = v0 + a.d_si[idx];
             }
             a.dy[(size_t)row * a.Nout + c] = v;
@@ -279,7 +281,7 @@ __global__ void k_step_bwd_assemble(StepAsmArgs s) {
 
 int mv_step_backward_assemble(int n_eik, int n_ds, int N, int Nout, int n_true, const float* din, int din_ld, int din_feat0, int din_nrm0, int use_geo,
                               const int* true_rank, const float* d_eo, const float* d_gth, const float* d_si, int d_mask, int e_mask, float* dy,
-                              float* dn, float* dy_x, float* dn_x, void* stream) {
+                              float* dn, float* dy_x, float* dn_x, const long long* cnt, void* stream) {
     const int E = n_eik + 2 * n_ds;
     if (n_eik < 0 || n_ds < 0 || N <= 0 || !dy || !dn || !dy_x || !dn_x || !true_rank || (d_mask & ~15) || (e_mask & ~15))
         return mv_fail(-1, "mv_step_backward_assemble: bad arguments");
@@ -289,7 +291,7 @@ int mv_step_backward_assemble(int n_eik, int n_ds, int N, int Nout, int n_true, 
     a.E = E; a.N = N; a.Nout = Nout; a.Mb = E + N; a.n_true = n_true; a.n_eik = n_eik; a.n_ds = n_ds; a.d_mask = d_mask; a.e_mask = e_mask;
     a.din = din; a.din_ld = din_ld; a.din_feat0 = din_feat0; a.din_nrm0 = din_nrm0; a.use_geo = use_geo;
     a.d_eo = d_eo; a.d_gth = d_gth; a.d_si = d_si; a.dy = dy; a.dn = dn;
-    s.true_rank = true_rank; s.dy_x = dy_x; s.dn_x = dn_x;
+    s.true_rank = true_rank; s.dy_x = dy_x; s.dn_x = dn_x; s.cnt = cnt;
     const size_t total = (size_t)a.Mb * (Nout + 3);
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(k_step_bwd_assemble, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s);

@@ -270,8 +270,44 @@ class LazyOutputs(dict):
         return (dict, (self.copy(),))
 
 
+class PendingOutputs(LazyOutputs):
+    """The output dict of a DEFERRED training forward (IDRNetwork.deferred_step): the forward is enqueued, the host has not waited for the hit counts.  The
+    keys whose shapes follow the counts -- and `rgb_values`, which carries the autograd link -- become tensors the first time any of them is read (one wait
+    for the counts, the classic autograd node over the same forward block); `IDRLoss.forward` does not read them: it recognises the pending step (`_mv_rec`)
+    and runs loss and backward with the counts taken on the device (native_step._DeferredStepLossFn).  Same values either way."""
+    _LAZY = ('diff_surf_pts', 'rgb_values', 'grad_theta', 'eikonal_points_hom', 'eikonal_output', 'surf_indicator_output')
+
+    def __init__(self, data, materialize, rec):
+        super().__init__(data, materialize)
+        self._mv_rec = rec
+
+    def pending_rec(self):
+        """The step record while no N-shaped output has been read, else None."""
+        return self._mv_rec if self._pending is not None else None
+
+    def raw(self, k):
+        return dict.__getitem__(self, k)
+
+
+class _StepStats(dict):
+    """IDRNetwork.last_stats of a deferred step: 'N' is looked up (one wait for the counts) when somebody reads it."""
+
+    def __init__(self, rec, **kw):
+        super().__init__(**kw)
+        self._rec = rec
+
+    def __getitem__(self, k):
+        if k == 'N' and not dict.__contains__(self, 'N'):
+            dict.__setitem__(self, 'N', self._rec.resolve()[0])
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        return self[k] if (k == 'N' or k in self) else default
+
+
 class IDRNetwork(nn.Module):
     HOST_STAGE = True                                            # default of self.host_stage (see __init__)
+    DEFERRED_STEP = os.environ.get('MVSDF_DEFERRED_STEP', '1') != '0'   # default of self.deferred_step
 
     def __init__(self, conf):
         super().__init__()
@@ -293,6 +329,9 @@ class IDRNetwork(nn.Module):
         # autograd glue).  False: the Python-orchestrated route over the same kernels (kept for A/B tests and the launch-path experiments).
         self.native_step = os.environ.get('MVSDF_NATIVE_STEP', '1') != '0'
         self.host_stage = type(self).HOST_STAGE                  # the step's CPU-generator draws are read from pinned memory by its first kernel (False: an async copy)
+        # training forward without the host wait for the hit counts (PendingOutputs; IDRLoss + backward then read them on the device): the step's rate no longer
+        # depends on host latency.  False: the classic step (one wait per forward).  Phase 0 (depth-surface samples, idr.py:226-247) always waits.
+        self.deferred_step = type(self).DEFERRED_STEP
         self._steps = {}                                         # NativeStep per batch shape / phase configuration
         self._ones = None                                        # all-ones object mask handed to the tracer when conf.use_mask is off
 
@@ -544,11 +583,12 @@ class IDRNetwork(nn.Module):
         dsurf = self._dsurf_samples(input, n_ds, self.object_bounding_sphere) if use_ds else None
         bb = self.object_bounding_sphere
         n_eik = R // 2
+        stage_slot = None
         if isinstance(self._draw, PinnedUniform) and isinstance(rt._draw, PinnedUniform):
             # one pinned staging buffer, NO copy: the step's first kernel reads it (MvsdfStepInputs.host_stage)
             # (self.host_stage = False: one async copy in front of the step instead -- the A/B partner, tests/test_gpu_alt_paths.py)
             if self.host_stage:
-                minsdf_steps, eik, stage = self._draw.pair((rt.n_steps,), 0.0, 1.0, (n_eik, 3), -bb, bb, dev, defer=True)
+                minsdf_steps, eik, stage, stage_slot = self._draw.pair_staged((rt.n_steps,), 0.0, 1.0, (n_eik, 3), -bb, bb, dev)
             else:
                 (minsdf_steps, eik), stage = self._draw.pair((rt.n_steps,), 0.0, 1.0, (n_eik, 3), -bb, bb, dev), None
         else:                                                    # (someone replaced a draw hook: the two separate draws of the Python route)
@@ -584,30 +624,44 @@ class IDRNetwork(nn.Module):
         rec.prm = st.params(vs, gs, bs)
         rec.d_mask, rec.e_mask = self._group_masks(train_progress, n_eik, n_ds)
         rec.use_geo = not bool(train_progress < conf.phase[0] or conf.disable_rgb_grad)                       # idr.py:331-334
-        diff_pts, rgb_values, grad_theta, eik_out, surf = NS.run_step(rec)
-        if dsurf is not None and min(int(rec.counts[2]), int(rec.counts[3])) < n_ds:
-            raise ValueError("Cannot take a larger sample than population when 'replace=False'")          # np.random.choice, idr.py:244
-        L, f, N = st.layout, rec.fwd, rec.N
-        nd, _ = rec.keep
-        rec.keep = keep                                          # the inputs stay alive as long as the step's autograd node does
+        rec.inputs_keep = keep                                   # the inputs stay alive as long as the step's record does
+        NS.enqueue_forward(rec)                                  # everything of this forward is on the stream now; nothing waited for
+        if stage_slot is not None:                               # the pinned draws may be rewritten once this forward's first kernel has read them
+            stage_slot[2] = (st, rec.seq)
+        L, f = st.layout, rec.fwd
         counters = f.b(L.counters, (128,)).view(torch.int64)
         rt.last_counters = counters
-        out = {
+        self._last_step = st
+        eager = {
             'points': f.f(L.points, (R, 3)),
-            'diff_surf_pts': diff_pts,
-            'rgb_values': rgb_values,
+            'diff_surf_pts': None,
+            'rgb_values': None,
             'sdf_output': f.f(L.sdf_output, (R, 1)),
             'network_object_mask': f.b(L.mask, (R,)).view(torch.bool),
             'object_mask': object_mask_true if conf.use_mask else f.b(L.object_mask_out, (R,)).view(torch.bool),
             'object_mask_true': object_mask_true,
-            'grad_theta': grad_theta,
-            'eikonal_points_hom': f.f(L.points_hom, (1, nd, 4, 1)),
-            'eikonal_output': eik_out,
-            'surf_indicator_output': surf,
+            'grad_theta': None,
+            'eikonal_points_hom': None,
+            'eikonal_output': None,
+            'surf_indicator_output': None,
         }
-        self.last_stats = {'R': R, 'N': N, 'E': st.E, 'counters': counters}
-        self._last_step = st
-        return out
+
+        def materialize(target):
+            diff_pts, rgb_values, grad_theta, eik_out, surf = NS.run_step(rec)      # waits for the counts; the autograd node over this forward block
+            if dsurf is not None and min(int(rec.counts[2]), int(rec.counts[3])) < n_ds:
+                raise ValueError("Cannot take a larger sample than population when 'replace=False'")          # np.random.choice, idr.py:244
+            nd, _ = rec.keep
+            dict.update(target, {'diff_surf_pts': diff_pts, 'rgb_values': rgb_values, 'grad_theta': grad_theta,
+                                 'eikonal_points_hom': f.f(L.points_hom, (1, nd, 4, 1)), 'eikonal_output': eik_out, 'surf_indicator_output': surf})
+
+        if self.deferred_step and st.can_defer and dsurf is None and torch.is_grad_enabled():
+            out = PendingOutputs(eager, None, rec)
+            out._pending = lambda: materialize(out)
+            self.last_stats = _StepStats(rec, R=R, E=st.E, counters=counters)
+            return out
+        materialize(eager)                                       # the classic step: its one host wait
+        self.last_stats = {'R': R, 'N': rec.N, 'E': st.E, 'counters': counters}
+        return eager
 
     def _step_params(self):
         """(weight_v list, weight_g list, bias list, all of them as one tuple) of both networks, SDF layers first.  The Parameter OBJECTS of a

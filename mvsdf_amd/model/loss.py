@@ -97,6 +97,12 @@ class IDRLoss(nn.Module):
     def forward(self, model_outputs, ground_truth, train_progress, n_img):
         """Same outputs as the reference (loss.py:176-219).  The feature term and the depth-carving target are HIP kernels; the
         remaining elementwise terms and the weighted sum are ONE more launch (csrc/loss_kernels.hip::k_loss_terms)."""
+        # a DEFERRED step (IDRNetwork.deferred_step): the forward is enqueued, the host does not know the hit counts and nothing here asks for them
+        rec = model_outputs.pending_rec() if (self.native and hasattr(model_outputs, 'pending_rec')) else None
+        if rec is not None:
+            out = self._forward_deferred(rec, model_outputs, ground_truth, train_progress)
+            if out is not None:
+                return out
         dev = model_outputs['rgb_values'].device
         rgb_gt = ground_truth['rgb'].to(dev)
         network_object_mask = model_outputs['network_object_mask']
@@ -164,6 +170,99 @@ class IDRLoss(nn.Module):
         out = Fn.loss_terms(model_outputs['rgb_values'], model_outputs['grad_theta'], model_outputs['eikonal_output'],
                             model_outputs['surf_indicator_output'], feat_pp, rgb_gt, hit_mask, dist_r, dweight,
                             n_pos, weights, bool(phase1), feat_on, inv_counts)
+        return {'loss': out[0], 'rgb_loss': out[1], 'eikonal_loss': out[2], 'depth_loss': out[3], 'feat_loss': out[4], 'surf_loss': out[5]}
+
+    def _forward_deferred(self, rec, mo, gt, train_progress):
+        """IDRLoss.forward on a pending step: ONE C call (mvsdf_loss_forward with MvsdfLossArgs.counts_dev) whose kernels take the hit counts from the
+        forward block on the device, behind one autograd node over the network's parameters whose backward is mvsdf_loss_backward + mvsdf_step_backward(N < 0).
+        -> the reference's dict of six scalars, or None when an input is not a plain contiguous fp32 / mask tensor on the step's device (the caller then reads
+        the outputs, which waits for the counts, and takes the classic route: same numbers)."""
+        st = rec.step
+        dev = st.device
+        if not conf.enable_rgb or mo.get('uncerts') is not None:
+            return None
+        f32 = lambda t: t is not None and t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.is_contiguous()
+        rgb_gt = gt['rgb']
+        if not rgb_gt.is_cuda:
+            rgb_gt = rgb_gt.to(dev)
+        depths, dcams = gt['depths'], gt['depth_cams']
+        size1, center1 = gt['size'][:1], gt['center'][:1]
+        if not all(f32(t) for t in (rgb_gt, depths, dcams, size1, center1)):
+            return None
+        masks = []
+        for k in ('network_object_mask', 'object_mask', 'object_mask_true'):
+            m = mo.raw(k).reshape(-1)
+            if not (m.is_cuda and m.dtype in (torch.bool, torch.uint8) and m.is_contiguous()):
+                return None
+            masks.append(m)
+        d, L, f = st.desc, st.layout, rec.fwd
+        R = st.R
+        if masks[0].numel() != R or rgb_gt.numel() != 3 * R:
+            return None
+        smooth = conf.smooth(train_progress)
+        weights = (conf.rgb_weight(train_progress), conf.eikonal_weight, conf.surf_weight, conf.feat_weight(train_progress),
+                   conf.depth_weight(train_progress), float(smooth) if smooth is not None else 0.0)
+        phase1 = conf.phase[0] <= train_progress
+        feat_on = bool(phase1 and conf.enable_feat)
+        a = NS.LossArgs()
+        nd_max, ne_max = rec.group_rows(R)                        # upper bounds (N = R): they size the block; the kernels bound their rows by the device counts
+        a.R, a.N, a.n_grad, a.n_depth, a.n_surf = R, R, ne_max, nd_max, R + d.n_eik
+        base = f.data_ptr()
+        a.counts_dev = base + st.counts_off
+        a.n_eik, a.n_ds, a.d_mask, a.e_mask = d.n_eik, d.n_ds, rec.d_mask, rec.e_mask
+        a.net_mask, a.obj_mask, a.true_mask = masks[0].data_ptr(), masks[1].data_ptr(), masks[2].data_ptr()
+        a.rgb, a.rgb_gt = base + L.rgb_values, rgb_gt.data_ptr()
+        a.grad_theta, a.eik_out, a.surf, a.diff_pts = base + L.grad_theta, base + L.eik_out, base + L.surf, base + L.diff_pts
+        a.points_hom = base + L.points_hom                        # rescaled to world coordinates in place: the side effect of loss.py:38,42
+        a.feat_on, a.surf_on = int(feat_on), int(bool(phase1))
+        a.B = 1
+        keep = [rgb_gt, depths, dcams, size1, center1] + masks
+        if feat_on:
+            feat, fsrc = gt['feat'], gt['feat_src']
+            if not (feat.is_cuda and fsrc.is_cuda and feat.dtype == torch.float32 and fsrc.dtype == torch.float32 and feat.shape[1] <= 32
+                    and f32(gt['cam']) and f32(gt['src_cams'])):
+                return None
+            a.B, a.C, a.H, a.W = feat.shape
+            a.V = fsrc.shape[1]
+            a.feat, a.feat_src, a.cam, a.src_cams = feat.data_ptr(), fsrc.data_ptr(), gt['cam'].data_ptr(), gt['src_cams'].data_ptr()
+            for i, v in enumerate(feat.stride()):
+                a.feat_strides[i] = v
+            for i, v in enumerate(fsrc.stride()):
+                a.src_strides[i] = v
+            keep += [feat, fsrc, gt['cam'], gt['src_cams']]
+        elif 'feat' in gt:
+            a.B = gt['feat'].size()[0]
+        if R % a.B:
+            return None
+        dB = depths.shape[0]
+        if depths.numel() != dB * depths.shape[-2] * depths.shape[-1] or dcams.numel() != dB * 32:
+            return None
+        gt['size'], gt['center'] = size1, center1                 # side effects kept (loss.py:181-182)
+        a.size, a.center = size1.data_ptr(), center1.data_ptr()
+        a.depths, a.dB, a.dh, a.dw, a.depth_cams = depths.data_ptr(), dB, depths.shape[-2], depths.shape[-1], dcams.data_ptr()
+        a.out_thresh_perc, a.far_thresh, a.near_thresh = conf.out_thresh_perc, conf.far_thresh, conf.near_thresh
+        a.use_invalid = 1 if conf.use_invalid else 0
+        a.far_att, a.near_att = float(conf.far_att(train_progress)), float(conf.near_att(train_progress))
+        a.w_rgb, a.w_eik, a.w_surf, a.w_feat, a.w_depth, a.smooth = [float(w) for w in weights]
+        if self.exact_data_parallel and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # the three count-normalised means divide by the GLOBAL counts (see forward): here they are computed on the device from {N, n_true}
+            cnt4 = f.u8[st.counts_off:st.counts_off + 32].view(torch.int64)
+            nf, tf = cnt4[0].to(torch.float32), cnt4[1].to(torch.float32)
+            e_hit, d_hit = float(rec.e_mask & 1), float(rec.d_mask & 1)
+            nd0, ne0 = rec.group_rows(0)
+            cnt = torch.stack([nf * e_hit + float(ne0), nf * d_hit + float(nd0), tf + float(d.n_eik)])
+            ev = None
+            if self.collective_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+            if ev is not None:
+                ev[1].record()
+                self.collective_events.append(ev)
+            inv_counts = (float(dist.get_world_size()) / cnt.clamp(min=1.0)).contiguous()
+            keep.append(inv_counts)
+            a.inv_counts = inv_counts.data_ptr()
+        out = NS.deferred_loss_forward(rec, a, keep)
         return {'loss': out[0], 'rgb_loss': out[1], 'eikonal_loss': out[2], 'depth_loss': out[3], 'feat_loss': out[4], 'surf_loss': out[5]}
 
     def _forward_native(self, mo, gt, rgb_gt, train_progress, weights, surf_on, feat_on, inv_counts):

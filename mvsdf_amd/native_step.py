@@ -48,7 +48,9 @@ class LossArgs(C.Structure):
                 ('depths', C.c_void_p), ('dB', C.c_int), ('dh', C.c_int), ('dw', C.c_int), ('depth_cams', C.c_void_p),
                 ('out_thresh_perc', C.c_float), ('far_thresh', C.c_float), ('far_att', C.c_float), ('near_thresh', C.c_float), ('near_att', C.c_float),
                 ('w_rgb', C.c_float), ('w_eik', C.c_float), ('w_surf', C.c_float), ('w_feat', C.c_float), ('w_depth', C.c_float),
-                ('use_invalid', C.c_int), ('smooth', C.c_float), ('inv_counts', C.c_void_p)]
+                ('use_invalid', C.c_int), ('smooth', C.c_float), ('inv_counts', C.c_void_p),
+                # deferred step: device pointer to {N, n_true}; N / n_grad / n_depth / n_surf above are then upper bounds (N = R), see include/mvsdf_hip.h
+                ('counts_dev', C.c_void_p), ('n_eik', C.c_int), ('n_ds', C.c_int), ('d_mask', C.c_int), ('e_mask', C.c_int)]
 
 
 class LossLayout(C.Structure):
@@ -68,6 +70,14 @@ def _bind():
         L.mvsdf_step_destroy.restype = None
         L.mvsdf_step_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.mvsdf_step_wait_counts.argtypes = [C.c_void_p, C.c_void_p]
+        L.mvsdf_step_seq.argtypes = [C.c_void_p]
+        L.mvsdf_step_seq.restype = C.c_longlong
+        L.mvsdf_step_counts_offset.argtypes = [C.c_void_p]
+        L.mvsdf_step_counts_offset.restype = C.c_size_t
+        L.mvsdf_step_wait_counts_seq.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p]
+        L.mvsdf_step_done_seq.argtypes = [C.c_void_p, C.c_void_p]
+        L.mvsdf_step_done_seq.restype = C.c_longlong
+        L.mvsdf_step_can_defer.argtypes = [C.c_void_p]
         L.mvsdf_step_backward.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 10 + [C.c_int, C.c_void_p]
         L.mvsdf_step_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.mvsdf_step_trace_times.argtypes = [C.c_void_p, C.c_void_p]
@@ -77,6 +87,20 @@ def _bind():
         L.mvsdf_loss_backward.argtypes = [C.c_void_p] * 9
         _bound = True
     return L
+
+
+loss_timing = None                                             # bench.py sets a list: (start, end) events around every mvsdf_loss_forward are appended
+
+
+def _timed_loss_forward(L, args, blk, dev):
+    if loss_timing is None:
+        check(L.mvsdf_loss_forward(C.byref(args), blk.data_ptr(), _stream(dev)), 'mvsdf_loss_forward')
+        return
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record()
+    check(L.mvsdf_loss_forward(C.byref(args), blk.data_ptr(), _stream(dev)), 'mvsdf_loss_forward')
+    ev[1].record()
+    loss_timing.append(ev)
 
 
 def _region(block, off, nbytes, dtype, shape):
@@ -133,8 +157,11 @@ class NativeStep:
         self._prm_key, self._prm = None, None
         self._grad_key, self._grad_arrays = None, None
         self._counts = (C.c_longlong * 4)()
+        self._counts_peek = (C.c_longlong * 4)()
         self.inputs = StepInputs()
         self.timing = False
+        self.can_defer = bool(L.mvsdf_step_can_defer(h))          # every launch of the backward has a device-count form (the deferred step)
+        self.counts_off = int(L.mvsdf_step_counts_offset(h))      # int64 counts[4] inside a forward block
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -175,6 +202,7 @@ class NativeStep:
 
     # ---- calls
     def forward(self, prm, d_mask, e_mask):
+        """-> the forward block (enqueued, nothing waited for); self.seq() names this forward."""
         fwd = Block(self.layout.fwd_bytes, self.device)
         check(lib().mvsdf_step_forward(self._h, C.byref(prm), C.byref(self.inputs), d_mask, e_mask, fwd.data_ptr(), _stream(self.device)),
               'mvsdf_step_forward')
@@ -183,6 +211,31 @@ class NativeStep:
     def wait_counts(self):
         check(lib().mvsdf_step_wait_counts(self._h, self._counts), 'mvsdf_step_wait_counts')
         return tuple(self._counts)
+
+    def seq(self):
+        """Sequence number of the last forward of this step object (the deferred step keeps it to ask for that forward's counts later)."""
+        return int(lib().mvsdf_step_seq(self._h))
+
+    def wait_counts_seq(self, seq, fwd):
+        """The counts of forward `seq` (blocks until its ray partition has run).  A record older than the pinned ring (64 forwards) is read from the
+        forward block itself after a stream synchronisation."""
+        rc = lib().mvsdf_step_wait_counts_seq(self._h, seq, self._counts)
+        if rc == -4:
+            torch.cuda.current_stream(self.device).synchronize()
+            return tuple(int(v) for v in fwd.u8[self.counts_off:self.counts_off + 32].view(torch.int64).cpu())
+        check(rc, 'mvsdf_step_wait_counts_seq')
+        return tuple(self._counts)
+
+    def partition_done(self, seq):
+        """Blocks until the ray partition of forward `seq` has run (everything enqueued before it -- the prologue reading the pinned draws -- is then done)."""
+        rc = lib().mvsdf_step_wait_counts_seq(self._h, seq, self._counts)
+        if rc != -4:                                              # (-4: overwritten by a forward 64 steps later, i.e. long done)
+            check(rc, 'mvsdf_step_wait_counts_seq')
+
+    def hint_N(self):
+        """N of the newest forward whose counts have arrived (no waiting), or -1: only selects kernel forms of a deferred backward."""
+        return int(self._counts_peek[0]) if lib().mvsdf_step_done_seq(self._h, self._counts_peek) > 0 else -1
+
 
     def bwd_block(self):
         if self._bwd is None:
@@ -216,7 +269,26 @@ class NativeStep:
 
 class StepRecord:
     """What one forward leaves behind for its backward and for the output dict."""
-    __slots__ = ('step', 'fwd', 'prm', 'params', 'N', 'n_true', 'counts', 'd_mask', 'e_mask', 'use_geo', 'n_layers', 'vs', 'gs', 'bs', 'keep', 'done', 'versions')
+    __slots__ = ('step', 'fwd', 'prm', 'params', 'N', 'n_true', 'counts', 'd_mask', 'e_mask', 'use_geo', 'n_layers', 'vs', 'gs', 'bs', 'keep', 'done', 'versions',
+                 'seq', 'inputs_keep')
+
+    def __init__(self):
+        self.fwd = self.N = self.n_true = self.counts = self.seq = None
+        self.done = False
+
+    def resolve(self):
+        """(N, n_true): host-side counts of this forward -- the classic step asks right after its forward, a deferred step only when somebody reads an
+        N-shaped output (its loss / backward / optimiser never do)."""
+        if self.N is None:
+            self.counts = self.step.wait_counts_seq(self.seq, self.fwd)
+            self.N, self.n_true = int(self.counts[0]), int(self.counts[1])
+        return self.N, self.n_true
+
+    def group_rows(self, N):
+        """(nd, ne): rows of eikonal_output / grad_theta for N hit rows (point groups [hit | eikonal | on-surface | jittered], idr.py:253-286)."""
+        d = self.step.desc
+        sizes = (N, d.n_eik, d.n_ds, d.n_ds)
+        return (sum(c for g, c in enumerate(sizes) if self.d_mask >> g & 1), sum(c for g, c in enumerate(sizes) if self.e_mask >> g & 1))
 
 
 class _NativeStepFn(torch.autograd.Function):
@@ -228,24 +300,17 @@ class _NativeStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rec, *params):
         st = rec.step
-        rec.fwd = st.forward(rec.prm, rec.d_mask, rec.e_mask)
-        counts = st.wait_counts()                                 # the one host wait of the training forward
-        rec.counts = counts
-        N, n_true = int(counts[0]), int(counts[1])
-        rec.N, rec.n_true = N, n_true
+        if rec.fwd is None:                                       # (a deferred step that is being materialised has run its forward already)
+            enqueue_forward(rec)
+        N, n_true = rec.resolve()                                 # the one host wait of the classic training forward
         L, d, R, E, f = st.layout, st.desc, st.R, st.E, rec.fwd
-        sizes = (N, d.n_eik, d.n_ds, d.n_ds)
-        nd = sum(c for g, c in enumerate(sizes) if rec.d_mask >> g & 1)
-        ne = sum(c for g, c in enumerate(sizes) if rec.e_mask >> g & 1)
+        nd, ne = rec.group_rows(N)
         diff = f.f(L.diff_pts, (N, 3))
         rgb = f.f(L.rgb_values, (R, 3))
         gth = f.f(L.grad_theta, (ne, 3))
         eo = f.f(L.eik_out, (1, nd))
         surf = f.f(L.surf, (n_true + d.n_eik,))
         rec.keep = (nd, ne)
-        # the backward reads the parameters again (weight-norm fold backward over prm->v / g): an in-place update between this forward and its backward
-        # (forward A, forward B, backward B, opt.step(), backward A) must raise like autograd's saved-tensor check does, not mix old activations with new weights
-        rec.versions = tuple(p._version for p in rec.params if p is not None)
         ctx.rec = rec
         return diff, rgb, gth, eo, surf
 
@@ -253,12 +318,7 @@ class _NativeStepFn(torch.autograd.Function):
     def backward(ctx, d_diff, d_rgb, d_gth, d_eo, d_si):
         from .functional import grad_sink
         rec = ctx.rec
-        if getattr(rec, 'done', False):
-            raise RuntimeError('the backward of this step already ran through FlatAdam.backward (its buffers are released after one backward, '
-                               'like autograd\'s)')
-        if tuple(p._version for p in rec.params if p is not None) != rec.versions:
-            raise RuntimeError('one of the variables needed for gradient computation has been modified by an inplace operation: a parameter of the '
-                               'network changed between this step\'s forward and its backward (e.g. optimizer.step() in between)')
+        _check_backward_allowed(rec)
         st = rec.step
         ups = [None if t is None else (t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()) for t in (d_diff, d_rgb, d_gth, d_eo, d_si)]
         vs, gs, bs = rec.vs, rec.gs, rec.bs
@@ -284,6 +344,25 @@ class _NativeStepFn(torch.autograd.Function):
         return (None,) + tuple(dvs) + tuple(dgs) + tuple(dbs)
 
 
+def enqueue_forward(rec):
+    """mvsdf_step_forward for this record: everything of IDRNetwork.forward is on the stream when this returns; nothing is waited for."""
+    st = rec.step
+    rec.fwd = st.forward(rec.prm, rec.d_mask, rec.e_mask)
+    rec.seq = st.seq()
+    # the backward reads the parameters again (weight-norm fold backward over prm->v / g): an in-place update between this forward and its backward
+    # (forward A, forward B, backward B, opt.step(), backward A) must raise like autograd's saved-tensor check does, not mix old activations with new weights
+    rec.versions = tuple(p._version for p in rec.params if p is not None)
+
+
+def _check_backward_allowed(rec):
+    if getattr(rec, 'done', False):
+        raise RuntimeError('the backward of this step already ran through FlatAdam.backward (its buffers are released after one backward, '
+                           'like autograd\'s)')
+    if tuple(p._version for p in rec.params if p is not None) != rec.versions:
+        raise RuntimeError('one of the variables needed for gradient computation has been modified by an inplace operation: a parameter of the '
+                           'network changed between this step\'s forward and its backward (e.g. optimizer.step() in between)')
+
+
 def run_step(rec):
     """-> (diff_surf_pts, rgb_values, grad_theta, eikonal_output, surf_indicator_output) linked to autograd; rec.fwd / N / n_true set."""
     return _NativeStepFn.apply(rec, *rec.params)
@@ -301,7 +380,7 @@ class _NativeLossFn(torch.autograd.Function):
         check(L.mvsdf_loss_layout(C.byref(args), C.byref(lo)), 'mvsdf_loss_layout')
         dev = rgb.device
         blk = torch.empty(lo.bytes, dtype=torch.uint8, device=dev)
-        check(L.mvsdf_loss_forward(C.byref(args), blk.data_ptr(), _stream(dev)), 'mvsdf_loss_forward')
+        _timed_loss_forward(L, args, blk, dev)
         ctx.args, ctx.blk, ctx.keep, ctx.lo = args, blk, keep, lo
         ctx.ins = (rgb, grad_theta, eik_out, surf, diff_pts)     # (for direct_backward: which node produced them)
         ctx.shapes = (rgb.shape, grad_theta.shape if grad_theta is not None else None, eik_out.shape, surf.shape if surf is not None else None,
@@ -337,6 +416,83 @@ def loss_forward(args, keep, rgb, grad_theta, eik_out, surf, diff_pts):
     return _NativeLossFn.apply(args, keep, rgb, grad_theta, eik_out, surf, diff_pts)
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+class _DeferredStepLossFn(torch.autograd.Function):
+    """IDRLoss.forward on the outputs of a DEFERRED step (IDRNetwork.forward returned before the host knew the hit counts) as ONE node over the raw
+    parameters: forward = mvsdf_loss_forward with the counts read on the device (MvsdfLossArgs.counts_dev), backward = mvsdf_loss_backward +
+    mvsdf_step_backward(N < 0).  No host wait anywhere: a loop `forward -> loss -> backward -> optimiser` enqueues whole steps ahead of the GPU.
+    Same kernels and the same bits as the classic two-node graph (tests/test_gpu_deferred.py)."""
+
+    @staticmethod
+    def forward(ctx, rec, args, keep, *params):
+        L = _bind()
+        lo = LossLayout()
+        check(L.mvsdf_loss_layout(C.byref(args), C.byref(lo)), 'mvsdf_loss_layout')
+        st = rec.step
+        dev = st.device
+        blk = torch.empty(lo.bytes, dtype=torch.uint8, device=dev)
+        _timed_loss_forward(L, args, blk, dev)
+        ctx.rec, ctx.args, ctx.blk, ctx.keep, ctx.lo = rec, args, blk, keep, lo
+        ctx.set_materialize_grads(False)
+        out = _region(blk, lo.out, 24, torch.float32, (6,))
+        return tuple(out.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        rec, a, lo, blk = ctx.rec, ctx.args, ctx.lo, ctx.blk
+        dev = blk.device
+        garr = (C.c_void_p * 6)()
+        keep = []
+        for k, g in enumerate(gs):
+            if g is not None:
+                g = g.reshape(1).float().contiguous()
+                keep.append(g)
+                garr[k] = g.data_ptr()
+        feat = bool(a.feat_on) and a.N > 0
+        sizes = [a.R * 3, a.n_grad * 3, a.n_depth, a.n_surf if a.surf_on else 0, a.N * 3 if feat else 0]      # upper bounds: the valid rows lead
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        g_rgb, g_grad, g_eo, g_sf, g_diff = torch.split(flat, sizes)
+        p = lambda t, on=True: C.c_void_p(t.data_ptr()) if (on and t.numel() > 0) else None
+        check(lib().mvsdf_loss_backward(C.byref(a), blk.data_ptr(), garr, p(g_rgb), p(g_grad), p(g_eo), p(g_sf, bool(a.surf_on)),
+                                        p(g_diff, feat), _stream(dev)), 'mvsdf_loss_backward')
+        ups = (g_diff if feat else None, g_rgb, g_grad if a.n_grad > 0 else None, g_eo if a.n_depth > 0 else None,
+               g_sf if (a.surf_on and a.n_surf > 0) else None)
+        return (None, None, None) + _deferred_step_backward(rec, ups)
+
+
+def _deferred_step_backward(rec, ups):
+    """mvsdf_step_backward with device-side counts for a deferred step; -> the gradients of rec.params (None each when they went into the sink)."""
+    from .functional import grad_sink
+    _check_backward_allowed(rec)
+    st = rec.step
+    vs, gs, bs = rec.vs, rec.gs, rec.bs
+    n = len(vs)
+    hint = rec.N if rec.N is not None else st.hint_N()
+    sink = None
+    if grad_sink.depth > 0 and all(getattr(p, '_mv_grad_sink', False) and p.requires_grad for p in rec.params if p is not None):
+        sink = st.grad_arrays(vs, gs, bs)
+    if sink is not None:
+        st.backward(rec.prm, -1, hint, rec.d_mask, rec.e_mask, rec.use_geo, ups, rec.fwd, sink, True)
+        return (None,) * (3 * n)
+    sizes = [v.numel() for v in vs] + [0 if g is None else g.numel() for g in gs] + [b.numel() for b in bs]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=st.device)
+    parts = list(torch.split(flat, sizes))
+    dvs = [t.view_as(v) for t, v in zip(parts[:n], vs)]
+    dgs = [None if g is None else t.view_as(g) for t, g in zip(parts[n:2 * n], gs)]
+    dbs = [t.view_as(b) for t, b in zip(parts[2 * n:], bs)]
+    m = STEP_MAX_LAYERS
+    dv, dg, db = (C.c_void_p * m)(), (C.c_void_p * m)(), (C.c_void_p * m)()
+    for l in range(n):
+        dv[l], dg[l], db[l] = dvs[l].data_ptr(), (dgs[l].data_ptr() if dgs[l] is not None else None), dbs[l].data_ptr()
+    st.backward(rec.prm, -1, hint, rec.d_mask, rec.e_mask, rec.use_geo, ups, rec.fwd, (dv, dg, db), False)
+    return tuple(dvs) + tuple(dgs) + tuple(dbs)
+
+
+def deferred_loss_forward(rec, args, keep):
+    """The six loss scalars of a deferred step (see _DeferredStepLossFn)."""
+    return _DeferredStepLossFn.apply(rec, args, keep, *rec.params)
+
+
 _one = {}
 
 
@@ -348,6 +504,8 @@ def direct_backward(loss):
     loss.backward(): same numbers)."""
     from .functional import grad_sink
     node = loss.grad_fn
+    if node is not None and isinstance(getattr(node, 'rec', None), StepRecord) and hasattr(node, 'lo') and grad_sink.depth > 0:
+        return _direct_backward_deferred(loss, node)
     if node is None or getattr(node, 'ins', None) is None or not hasattr(node, 'args') or grad_sink.depth <= 0:
         return False
     rgb, gth, eo, sf, pts = node.ins
@@ -385,5 +543,35 @@ def direct_backward(loss):
         gs[loss.output_nr] = one
         grads = _NativeLossFn.backward(node, *gs)
         _NativeStepFn.backward(snode, grads[6], grads[2], grads[3], grads[4], grads[5])
+    rec.done = True
+    return True
+
+
+def _direct_backward_deferred(loss, node):
+    """direct_backward for the one-node graph of a deferred step (_DeferredStepLossFn): still no host wait."""
+    rec = node.rec
+    if getattr(rec, 'done', False) or loss._backward_hooks or loss.retains_grad:
+        return False
+    if not all(getattr(p, '_mv_grad_sink', False) and p.requires_grad for p in rec.params if p is not None):
+        return False
+    if rec.step.grad_arrays(rec.vs, rec.gs, rec.bs) is None:
+        return False
+    if loss.output_nr == 0:
+        # d(total loss): mvsdf_loss_forward already left the weighted gradients in its block (regions sized for N = R, the valid rows lead)
+        a, lo, blk = node.args, node.lo, node.blk
+        f32 = blk.view(torch.float32)
+        cut = lambda off, n, shape: torch.as_strided(f32, shape, _strides(shape), off >> 2) if n > 0 else None
+        feat = bool(a.feat_on) and a.N > 0
+        ups = (cut(lo.s_diff, a.N, (a.N, 3)) if feat else None, cut(lo.s_rgb, a.R, (a.R, 3)), cut(lo.s_grad, a.n_grad, (a.n_grad, 3)),
+               cut(lo.s_eo, a.n_depth, (a.n_depth,)), cut(lo.s_sf, a.n_surf, (a.n_surf,)) if a.surf_on else None)
+        _deferred_step_backward(rec, ups)
+    else:
+        dev = loss.device
+        one = _one.get(dev)
+        if one is None:
+            one = _one[dev] = torch.ones((), dtype=torch.float32, device=dev)
+        gs = [None] * 6
+        gs[loss.output_nr] = one
+        _DeferredStepLossFn.backward(node, *gs)
     rec.done = True
     return True

@@ -54,6 +54,34 @@ class PinnedUniform:
             slot[1].record()
         return out
 
+    STAGE_DEPTH = 8
+
+    def pair_staged(self, shape_a, lo_a, hi_a, shape_b, lo_b, hi_b, device):
+        """Two consecutive draws (a, then b: the same values as two separate calls) left in a pinned staging buffer for the CONSUMER to read on the device
+        (the native step's first kernel reads the pinned memory directly: no copy node in front of the step).  -> (a, b, staging, slot): a / b are
+        UNINITIALISED device tensors (views of one buffer) the consumer fills; the consumer sets slot[2] = (step, seq) of the forward that reads the
+        staging buffer, and the buffer -- one of STAGE_DEPTH that take turns -- is redrawn only after that forward's ray partition has run
+        (NativeStep.partition_done: a host that enqueues steps ahead of the GPU waits here once it is STAGE_DEPTH forwards ahead)."""
+        shape_a, shape_b = tuple(shape_a), tuple(shape_b)
+        na, nb = 1, 1
+        for v in shape_a:
+            na *= v
+        for v in shape_b:
+            nb *= v
+        key = ('staged', shape_a, shape_b, self._k % self.STAGE_DEPTH)
+        self._k += 1
+        slot = self._bufs.get(key)
+        if slot is None:
+            slot = self._bufs[key] = [torch.empty(na + nb).pin_memory(), None, None]
+        buf, _, reader = slot
+        if reader is not None:
+            reader[0].partition_done(reader[1])
+            slot[2] = None
+        buf[:na].uniform_(lo_a, hi_a)
+        buf[na:].uniform_(lo_b, hi_b)
+        out = torch.empty(na + nb, dtype=buf.dtype, device=device)
+        return out[:na].view(shape_a), out[na:].view(shape_b), buf, slot
+
     def pair(self, shape_a, lo_a, hi_a, shape_b, lo_b, hi_b, device, defer=False):
         """Two consecutive draws (a, then b: the same values as two separate calls) staged in ONE pinned buffer and delivered by ONE async copy.
         defer=True: no copy at all -- returns (a, b, staging) with a / b UNINITIALISED device tensors (views of one buffer) and the pinned staging

@@ -1,0 +1,232 @@
+"""The DEFERRED training step (IDRNetwork.deferred_step, the default): forward -> IDRLoss -> backward -> optimiser without a single host wait -- the hit
+counts stay on the device (MvsdfLossArgs.counts_dev, mvsdf_step_backward(N < 0)), every N-dependent launch is sized for N = R and bounds its rows by
+the device values.  Against the CLASSIC step (one wait per forward, exact launch sizes) on the same inputs every loss term, every gradient entry and every
+output must be IDENTICAL bit for bit; a host that runs many steps ahead of the GPU (real Adam updates, so N changes from step to step) must arrive at the same
+parameters; outputs read later (PendingOutputs) equal the classic ones; records older than the pinned count ring are still served."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import t
+from mvsdf_amd import native_step as NS
+from mvsdf_amd.model.implicit_differentiable_renderer import IDRNetwork, PendingOutputs
+from mvsdf_amd.model.loss import IDRLoss
+from mvsdf_amd.optim import FlatAdam
+from mvsdf_amd.utils import synth
+from mvsdf_amd.utils.config import ConfigDict
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(W, deferred, skip_in=(4,)):
+    m = IDRNetwork(ConfigDict(synth.model_conf(W, skip_in=skip_in)))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict(W, 0, skip_in=skip_in).items()})
+    m = m.cuda().train()
+    m.deferred_step = deferred
+    return m
+
+
+def _batch(B, P, V, seed=3, focal_scale=1.4):
+    inp, gt = synth.make_batch(B, P, V, seed=seed, feat_hw=(60, 80), focal_scale=focal_scale)
+    return {k: t(v) for k, v in inp.items()}, {k: t(v) for k, v in gt.items()}
+
+
+def _same(a, b, what):
+    assert a.shape == b.shape and a.dtype == b.dtype, (what, a.shape, b.shape, a.dtype, b.dtype)
+    assert torch.equal(a, b), '%s differs: max |d| = %g' % (what, float((a.float() - b.float()).abs().max()))
+
+
+def _grads(m):
+    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in m.parameters()]).clone()
+
+
+def _run(deferred, W=64, B=2, P=300, V=2, tp=0.3, sink=True, term='loss', skip_in=(4,), uv_shift=None, object_mask=None):
+    m = _model(W, deferred, skip_in)
+    inp, gt = _batch(B, P, V)
+    if uv_shift is not None:
+        inp['uv'] = inp['uv'] * 0 + uv_shift
+    if object_mask is not None:
+        inp['object_mask'] = object_mask
+    loss_fn = IDRLoss()
+    opt = FlatAdam(m.parameters(), lr=0.0) if sink else None
+    torch.manual_seed(11)
+    out = m(inp, tp)
+    was_pending = isinstance(out, PendingOutputs) and out.pending_rec() is not None
+    lo = loss_fn(out, dict(gt), tp, B)
+    still_pending = isinstance(out, PendingOutputs) and out.pending_rec() is not None
+    if sink:
+        opt.zero_grad()
+        opt.backward(lo[term])
+    else:
+        m.zero_grad()
+        lo[term].backward()
+    torch.cuda.synchronize()
+    g = _grads(m)
+    outs = {k: v.detach().clone() for k, v in out.items() if torch.is_tensor(v)}     # (reads every output: a pending dict resolves here)
+    return outs, {k: v.detach().clone() for k, v in lo.items()}, g, (was_pending, still_pending), m
+
+
+def _compare(**kw):
+    o_d, l_d, g_d, pend, m_d = _run(True, **kw)
+    o_c, l_c, g_c, pend_c, _ = _run(False, **kw)
+    assert pend == (True, True), 'the deferred route did not run (forward pending, still pending after IDRLoss): %s' % (pend,)
+    assert pend_c == (False, False)
+    assert set(o_d) == set(o_c)
+    for k in l_c:
+        _same(l_d[k], l_c[k], k)
+    _same(g_d, g_c, 'gradient')
+    for k in o_c:
+        _same(o_d[k], o_c[k], k)
+    return o_d, l_d, g_d
+
+
+@pytest.mark.parametrize('sink', [True, False])
+@pytest.mark.parametrize('W,tp', [(64, 0.3), (64, 0.6), (256, 0.3), (512, 0.3)])
+def test_deferred_equals_classic(W, tp, sink):
+    o, l, g = _compare(W=W, tp=tp, sink=sink)
+    n_hit = int(o['network_object_mask'].sum())
+    assert 0 < n_hit < o['network_object_mask'].numel() and float(g.abs().max()) > 0
+    assert o['diff_surf_pts'].shape == (n_hit, 3)
+
+
+def test_deferred_upstream_on_another_term_and_skips_and_mask():
+    _compare(term='eikonal_loss', sink=False)
+    _compare(term='rgb_loss', sink=True)
+    _compare(term='depth_loss', sink=True)
+    om = (torch.rand(2, 300, generator=torch.Generator().manual_seed(5)) < 0.7).cuda()
+    _compare(skip_in=(3, 6), object_mask=om, sink=True)
+
+
+def test_deferred_no_hit_at_all():
+    """N = 0 on the device: every hit-row launch finds nothing to do, the sample rows still train the SDF net."""
+    o, l, g = _compare(uv_shift=5000.0)
+    assert int(o['network_object_mask'].sum()) == 0 and o['diff_surf_pts'].shape == (0, 3)
+    assert float(g.abs().max()) > 0
+
+
+def test_deferred_all_rays_hit_bound():
+    """A batch where (nearly) every ray hits: N close to its upper bound R."""
+    o, _, _ = _compare(P=256, tp=0.3, W=64, sink=True, object_mask=None, uv_shift=None, B=2, V=2, skip_in=(4,), term='loss')
+    assert int(o['network_object_mask'].sum()) > 0
+
+
+def _train(deferred, steps, W=64, sync_every=0, lr=5e-4):
+    m = _model(W, deferred)
+    loss_fn = IDRLoss()
+    opt = FlatAdam(m.parameters(), lr=lr)
+    batches = [_batch(2, 256, 2, seed=20 + k) for k in range(4)]
+    torch.manual_seed(7)
+    losses, hits = [], []
+    for it in range(steps):
+        inp, gt = batches[it % 4]
+        opt.zero_grad()
+        out = m(inp, 0.3)
+        lo = loss_fn(out, dict(gt), 0.3, 2)
+        opt.backward(lo['loss'])
+        opt.step(grad_cap=2.0)
+        losses.append(lo['loss'].detach())
+        hits.append(out.raw('network_object_mask').sum() if isinstance(out, PendingOutputs) else out['network_object_mask'].sum())
+        if sync_every and (it + 1) % sync_every == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    return (torch.stack(losses).cpu(), torch.stack(hits).cpu(), torch.cat([p.detach().flatten() for p in m.parameters()]).clone(), m)
+
+
+def test_host_runs_steps_ahead_with_real_updates():
+    """80 optimiser steps with lr > 0 and NO synchronisation (the host is dozens of forwards ahead of the GPU: count ring, staging ring and the per-forward
+    blocks all turn over) against the classic loop: same losses, same hit counts (they change as the surface moves), same final parameters."""
+    l_d, h_d, p_d, m_d = _train(True, 80)
+    l_c, h_c, p_c, _ = _train(False, 80)
+    assert len(set(h_c.tolist())) > 3, 'the hit count should move with the weights: %s' % h_c.tolist()[:10]
+    _same(h_d, h_c, 'hit counts per step')
+    _same(l_d, l_c, 'loss per step')
+    _same(p_d, p_c, 'parameters after 80 steps')
+
+
+def test_old_record_beyond_the_count_ring():
+    """A step's outputs read after more than MVSDF_STEP_COUNT_RING (64) later forwards: its record in the pinned ring is gone, the counts come from its own
+    forward block."""
+    m = _model(64, True)
+    loss_fn = IDRLoss()
+    opt = FlatAdam(m.parameters(), lr=0.0)
+    inp, gt = _batch(2, 200, 2)
+    torch.manual_seed(3)
+    first = m(inp, 0.3)
+    assert first.pending_rec() is not None
+    for _ in range(70):
+        opt.zero_grad()
+        out = m(inp, 0.3)
+        lo = loss_fn(out, dict(gt), 0.3, 2)
+        opt.backward(lo['loss'])
+    n = int(first.raw('network_object_mask').sum())
+    assert first['diff_surf_pts'].shape == (n, 3) and first.pending_rec() is None
+    assert m.last_stats['N'] == int(out.raw('network_object_mask').sum())
+
+
+def test_reading_outputs_between_forward_and_loss_takes_the_classic_route():
+    """Reading an N-shaped output resolves the pending dict (one wait); IDRLoss then runs its classic node on the resolved tensors: same numbers."""
+    res = []
+    for touch in (False, True):
+        m = _model(64, True)
+        inp, gt = _batch(2, 300, 2)
+        loss_fn = IDRLoss()
+        torch.manual_seed(11)
+        out = m(inp, 0.3)
+        if touch:
+            assert out['rgb_values'].requires_grad and out.pending_rec() is None
+        lo = loss_fn(out, dict(gt), 0.3, 2)
+        m.zero_grad()
+        lo['loss'].backward()
+        res.append(({k: v.detach().clone() for k, v in lo.items()}, _grads(m)))
+    for k in res[0][0]:
+        _same(res[0][0][k], res[1][0][k], k)
+    _same(res[0][1], res[1][1], 'gradient')
+
+
+def test_user_loss_on_a_resolved_output_after_the_deferred_loss():
+    """The deferred loss node and, later, a user's own term on a resolved output both reach the parameters (two nodes over one forward block)."""
+    m = _model(64, True)
+    inp, gt = _batch(2, 300, 2)
+    loss_fn = IDRLoss()
+    torch.manual_seed(11)
+    out = m(inp, 0.3)
+    lo = loss_fn(out, dict(gt), 0.3, 2)
+    extra = (out['rgb_values'] ** 2).mean()                       # resolves the dict, its own autograd node
+    m.zero_grad()
+    (lo['loss'] + extra).backward()
+    g_both = _grads(m)
+    m2 = _model(64, False)
+    torch.manual_seed(11)
+    out2 = m2(inp, 0.3)
+    lo2 = loss_fn(out2, dict(gt), 0.3, 2)
+    m2.zero_grad()
+    (lo2['loss'] + (out2['rgb_values'] ** 2).mean()).backward()
+    g_ref = _grads(m2)
+    assert torch.allclose(g_both, g_ref, rtol=1e-4, atol=1e-7), float((g_both - g_ref).abs().max())
+
+
+def test_no_host_wait_in_a_deferred_step():
+    """The point: a deferred step never calls the count wait (the classic one calls it once per forward)."""
+    calls = {'n': 0}
+    orig = NS.NativeStep.wait_counts_seq
+
+    def counted(self, seq, fwd):
+        calls['n'] += 1
+        return orig(self, seq, fwd)
+    NS.NativeStep.wait_counts_seq = counted
+    try:
+        for deferred, expect in ((True, 0), (False, 10)):
+            m = _model(64, deferred)
+            loss_fn = IDRLoss()
+            opt = FlatAdam(m.parameters(), lr=0.0)
+            inp, gt = _batch(2, 200, 2)
+            calls['n'] = 0
+            for _ in range(10):
+                opt.zero_grad()
+                lo = loss_fn(m(inp, 0.3), dict(gt), 0.3, 2)
+                opt.backward(lo['loss'])
+                opt.step(grad_cap=2.0)
+            torch.cuda.synchronize()
+            assert calls['n'] == expect, (deferred, calls['n'])
+    finally:
+        NS.NativeStep.wait_counts_seq = orig

@@ -3,9 +3,10 @@ profiles/pmc_traffic.json, the file bench.py reads `roofline.traffic`, `roofline
 HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE / WRITE_SIZE are in KB and on gfx950 FETCH_SIZE counts half the bytes of a wide
 coalesced read (/opt/skills/guides/MI355X_MICROARCH.md, HBM section).
 
-    python tools/pmc_to_json.py <dir with the counter_collection CSVs> <workload> <dtype> <width> <out.json> [note]
+    python tools/pmc_to_json.py <dir with the counter_collection CSVs> <workload> <dtype> <width> <out.json> [note] [scaling] [rays per GPU]
 
-The entry key is "<workload>|<dtype>|<width>"; other entries of an existing <out.json> are kept."""
+The entry key is "<workload>|<dtype>|<width>|<scaling>" (scaling: weak | strong, default weak) and the entry records the rays per GPU of the profiled command:
+bench.py returns no traffic for a line whose command differs in either.  Other entries of an existing <out.json> are kept."""
 import collections
 import csv
 import glob
@@ -15,6 +16,8 @@ import sys
 
 src, workload, dtype, width, dst = sys.argv[1:6]
 note = sys.argv[6] if len(sys.argv) > 6 else ''
+scaling = sys.argv[7] if len(sys.argv) > 7 else 'weak'
+rays = int(sys.argv[8]) if len(sys.argv) > 8 else None
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(src + '/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(f)):
@@ -40,6 +43,6 @@ if os.path.exists(dst):
 if 'entries' not in doc:
     doc = {'formula': 'hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, mean over the launches of the kernel (all template instances); '
                       'launches_per_step = launches sampled / launches of k_step_prologue (one per step)', 'entries': {}}
-doc['entries']['%s|%s|%s' % (workload, dtype, width)] = {'note': note, 'steps_sampled': steps, 'kernels': kernels}
+doc['entries']['%s|%s|%s|%s' % (workload, dtype, width, scaling)] = {'note': note, 'steps_sampled': steps, 'rays_per_gpu': rays, 'kernels': kernels}
 json.dump(doc, open(dst, 'w'), indent=1)
-print('wrote', dst, '%s|%s|%s' % (workload, dtype, width), len(kernels), 'kernels,', steps, 'steps')
+print('wrote', dst, '%s|%s|%s|%s' % (workload, dtype, width, scaling), len(kernels), 'kernels,', steps, 'steps')
