@@ -446,6 +446,11 @@ size_t mvsdf_step_counts_offset(void* step);
 int mvsdf_step_wait_counts_seq(void* step, long long seq, long long counts[4]);
 long long mvsdf_step_done_seq(void* step, long long counts[4]);
 int mvsdf_step_can_defer(void* step);
+/* byte offsets inside `fwd` of what the forward saved for the backward, for inspection (tests read the rendering net's own ReLU masks there):
+ * out[6] = {x_eval [E+R][3] evaluation rows [samples | rays, hit first], y_eval [E+R][Nout], n_eval [E+R][3], view_sorted [R][3],
+ * render_ctx (mvsdf_render_forward's context for R rows: the input [R][K_0], then the post-ReLU activations [R][K_l] of layers 1.., then rgb),
+ * rgb_sorted [R][3]} */
+int mvsdf_step_saved_offsets(void* step, size_t out[6]);
 /* backward of mvsdf_step_forward: upstream gradients of diff_surf_pts [N][3], rgb_values [R][3], grad_theta, eikonal_output,
  * surf_indicator_output (any may be NULL = zero) -> gradient of every raw parameter.  N, n_true: the counts mvsdf_step_wait_counts returned;
  * N < 0: the deferred step -- both counts are read on the device from `fwd`, the upstream tensors hold their valid rows first (sized for N = R),

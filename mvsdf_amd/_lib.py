@@ -68,7 +68,7 @@ EXPORTS = [
     'mvsdf_partition_rays', 'mvsdf_step_outputs', 'mvsdf_step_backward_inputs', 'mvsdf_step_backward_fbar', 'mvsdf_dsurf_select', 'mvsdf_dsurf_points',
     'mvsdf_render_ctx_floats', 'mvsdf_render_bwd_ws_floats', 'mvsdf_render_forward', 'mvsdf_render_backward',
     'mvsdf_step_create', 'mvsdf_step_destroy', 'mvsdf_step_forward', 'mvsdf_step_wait_counts', 'mvsdf_step_backward', 'mvsdf_step_set_timing', 'mvsdf_step_trace_times', 'mvsdf_step_times',
-    'mvsdf_step_seq', 'mvsdf_step_counts_offset', 'mvsdf_step_wait_counts_seq', 'mvsdf_step_done_seq', 'mvsdf_step_can_defer',
+    'mvsdf_step_seq', 'mvsdf_step_counts_offset', 'mvsdf_step_wait_counts_seq', 'mvsdf_step_done_seq', 'mvsdf_step_can_defer', 'mvsdf_step_saved_offsets',
     'mvsdf_loss_layout', 'mvsdf_loss_forward', 'mvsdf_loss_backward',
 ]
 

@@ -451,6 +451,12 @@ int mvsdf_step_wait_counts(void* step, long long counts[4]) {
 long long mvsdf_step_seq(void* step) { return step ? ((Step*)step)->counts_seq : -1; }
 size_t mvsdf_step_counts_offset(void* step) { return step ? ((Step*)step)->fo.counts : 0; }
 int mvsdf_step_can_defer(void* step) { Step* st = (Step*)step; return (st && st->can_defer) ? 1 : 0; }
+int mvsdf_step_saved_offsets(void* step, size_t out[6]) {
+    Step* st = (Step*)step;
+    if (!st || !out) return mv_fail(-1, "mvsdf_step_saved_offsets: null argument");
+    out[0] = st->fo.x_eval; out[1] = st->fo.y_eval; out[2] = st->fo.n_eval; out[3] = st->fo.view_sorted; out[4] = st->fo.render_ctx; out[5] = st->fo.rgb_sorted;
+    return 0;
+}
 
 int mvsdf_step_wait_counts_seq(void* step, long long seq, long long counts[4]) {
     Step* st = (Step*)step;

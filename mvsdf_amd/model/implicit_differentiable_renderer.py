@@ -632,6 +632,7 @@ class IDRNetwork(nn.Module):
         counters = f.b(L.counters, (128,)).view(torch.int64)
         rt.last_counters = counters
         self._last_step = st
+        self._last_rec = weakref.ref(rec)                         # (inspection: tests read what the forward saved through NativeStep.saved_offsets)
         eager = {
             'points': f.f(L.points, (R, 3)),
             'diff_surf_pts': None,

@@ -110,11 +110,9 @@ class IDRLoss(nn.Module):
 
         ground_truth['size'] = ground_truth['size'][:1]                            # side effects kept (loss.py:181-182)
         ground_truth['center'] = ground_truth['center'][:1]
-        if not conf.enable_rgb:
-            raise NotImplementedError('enable_rgb=False is off in the reference conf (model/conf.py:20)')
-
         smooth = conf.smooth(train_progress)                                       # loss.py:57-58: SmoothL1 depth term (None in the shipped conf)
-        weights = (conf.rgb_weight(train_progress), conf.eikonal_weight, conf.surf_weight, conf.feat_weight(train_progress),
+        # conf.enable_rgb = False (loss.py:184-187): the rgb term is zeros(1) -- no contribution to the total, no gradient: weight 0, and the scalar is replaced below
+        weights = (conf.rgb_weight(train_progress) if conf.enable_rgb else 0.0, conf.eikonal_weight, conf.surf_weight, conf.feat_weight(train_progress),
                    conf.depth_weight(train_progress), float(smooth) if smooth is not None else 0.0)
         phase1 = conf.phase[0] <= train_progress
         feat_on = bool(phase1 and conf.enable_feat)
@@ -156,7 +154,7 @@ class IDRLoss(nn.Module):
         if self.native:
             out = self._forward_native(model_outputs, ground_truth, rgb_gt, train_progress, weights, bool(phase1), feat_on, inv_counts)
             if out is not None:
-                return {'loss': out[0], 'rgb_loss': out[1], 'eikonal_loss': out[2], 'depth_loss': out[3], 'feat_loss': out[4], 'surf_loss': out[5]}
+                return self._terms(out, dev)
         # masks -> hit mask, per-view row ranges of diff_surf_pts, number of BCE positives: one launch (csrc/loss_kernels.hip::k_loss_prep)
         n_views = ground_truth['feat'].size()[0] if 'feat' in ground_truth else 1
         hit_mask, view_start, n_pos = ops.loss_prep(network_object_mask, object_mask, model_outputs['object_mask_true'], n_views)
@@ -170,7 +168,13 @@ class IDRLoss(nn.Module):
         out = Fn.loss_terms(model_outputs['rgb_values'], model_outputs['grad_theta'], model_outputs['eikonal_output'],
                             model_outputs['surf_indicator_output'], feat_pp, rgb_gt, hit_mask, dist_r, dweight,
                             n_pos, weights, bool(phase1), feat_on, inv_counts)
-        return {'loss': out[0], 'rgb_loss': out[1], 'eikonal_loss': out[2], 'depth_loss': out[3], 'feat_loss': out[4], 'surf_loss': out[5]}
+        return self._terms(out, dev)
+
+    @staticmethod
+    def _terms(out, dev):
+        """The reference's dict of six scalars (loss.py:212-219); with conf.enable_rgb off rgb_loss is the constant zeros(1) of loss.py:187."""
+        return {'loss': out[0], 'rgb_loss': out[1] if conf.enable_rgb else torch.zeros(1, device=dev), 'eikonal_loss': out[2], 'depth_loss': out[3],
+                'feat_loss': out[4], 'surf_loss': out[5]}
 
     def _forward_deferred(self, rec, mo, gt, train_progress):
         """IDRLoss.forward on a pending step: ONE C call (mvsdf_loss_forward with MvsdfLossArgs.counts_dev) whose kernels take the hit counts from the
@@ -179,7 +183,7 @@ class IDRLoss(nn.Module):
         the outputs, which waits for the counts, and takes the classic route: same numbers)."""
         st = rec.step
         dev = st.device
-        if not conf.enable_rgb or mo.get('uncerts') is not None:
+        if dict.get(mo, 'uncerts') is not None:
             return None
         f32 = lambda t: t is not None and t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.is_contiguous()
         rgb_gt = gt['rgb']
@@ -200,7 +204,7 @@ class IDRLoss(nn.Module):
         if masks[0].numel() != R or rgb_gt.numel() != 3 * R:
             return None
         smooth = conf.smooth(train_progress)
-        weights = (conf.rgb_weight(train_progress), conf.eikonal_weight, conf.surf_weight, conf.feat_weight(train_progress),
+        weights = (conf.rgb_weight(train_progress) if conf.enable_rgb else 0.0, conf.eikonal_weight, conf.surf_weight, conf.feat_weight(train_progress),
                    conf.depth_weight(train_progress), float(smooth) if smooth is not None else 0.0)
         phase1 = conf.phase[0] <= train_progress
         feat_on = bool(phase1 and conf.enable_feat)
@@ -262,8 +266,7 @@ class IDRLoss(nn.Module):
             inv_counts = (float(dist.get_world_size()) / cnt.clamp(min=1.0)).contiguous()
             keep.append(inv_counts)
             a.inv_counts = inv_counts.data_ptr()
-        out = NS.deferred_loss_forward(rec, a, keep)
-        return {'loss': out[0], 'rgb_loss': out[1], 'eikonal_loss': out[2], 'depth_loss': out[3], 'feat_loss': out[4], 'surf_loss': out[5]}
+        return self._terms(NS.deferred_loss_forward(rec, a, keep), dev)
 
     def _forward_native(self, mo, gt, rgb_gt, train_progress, weights, surf_on, feat_on, inv_counts):
         """The whole forward as ONE C call (mvsdf_loss_forward: mask bookkeeping, feature consistency, depth carving with the in-place

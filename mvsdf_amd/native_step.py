@@ -78,6 +78,7 @@ def _bind():
         L.mvsdf_step_done_seq.argtypes = [C.c_void_p, C.c_void_p]
         L.mvsdf_step_done_seq.restype = C.c_longlong
         L.mvsdf_step_can_defer.argtypes = [C.c_void_p]
+        L.mvsdf_step_saved_offsets.argtypes = [C.c_void_p, C.c_void_p]
         L.mvsdf_step_backward.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 10 + [C.c_int, C.c_void_p]
         L.mvsdf_step_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.mvsdf_step_trace_times.argtypes = [C.c_void_p, C.c_void_p]
@@ -232,6 +233,12 @@ class NativeStep:
         if rc != -4:                                              # (-4: overwritten by a forward 64 steps later, i.e. long done)
             check(rc, 'mvsdf_step_wait_counts_seq')
 
+    def saved_offsets(self):
+        """Byte offsets inside a forward block of {x_eval, y_eval, n_eval, view_sorted, render_ctx, rgb_sorted} (mvsdf_step_saved_offsets): inspection only."""
+        out = (C.c_size_t * 6)()
+        check(lib().mvsdf_step_saved_offsets(self._h, out), 'mvsdf_step_saved_offsets')
+        return dict(zip(('x_eval', 'y_eval', 'n_eval', 'view_sorted', 'render_ctx', 'rgb_sorted'), (int(v) for v in out)))
+
     def hint_N(self):
         """N of the newest forward whose counts have arrived (no waiting), or -1: only selects kernel forms of a deferred backward."""
         return int(self._counts_peek[0]) if lib().mvsdf_step_done_seq(self._h, self._counts_peek) > 0 else -1
@@ -270,7 +277,7 @@ class NativeStep:
 class StepRecord:
     """What one forward leaves behind for its backward and for the output dict."""
     __slots__ = ('step', 'fwd', 'prm', 'params', 'N', 'n_true', 'counts', 'd_mask', 'e_mask', 'use_geo', 'n_layers', 'vs', 'gs', 'bs', 'keep', 'done', 'versions',
-                 'seq', 'inputs_keep')
+                 'seq', 'inputs_keep', '__weakref__')
 
     def __init__(self):
         self.fwd = self.N = self.n_true = self.counts = self.seq = None

@@ -70,8 +70,11 @@ def build_model(W, seed, skip_in=(4,), **kw):
     return m, sd
 
 
+OUT_DIR = HERE                                                  # --check regenerates into a scratch directory
+
+
 def save(name, **arrs):
-    path = os.path.join(HERE, name + '.npz')
+    path = os.path.join(OUT_DIR, name + '.npz')
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
     print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024))
 
@@ -246,7 +249,23 @@ def g_trace_analytic(seed):
                  points=pts, mask=mask, dists=dists, minsdf_steps=steps, rows=rows, **extra)
 
 
-def g_trace_mlp(W, B, P, seed):
+@contextlib.contextmanager
+def env(**kw):
+    old = {k: os.environ.get(k) for k in kw}
+    os.environ.update({k: str(v) for k, v in kw.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def g_trace_mlp(W, B, P, seed, render=0):
+    """render=1: the reference's rendering variant of the tracer (IDR_USE_ENV=1 IDR_RENDER=1 -> dist_clip 0.05, 40 sphere-tracing iterations,
+    ray_tracing.py:127-131; eval.py / IDR_RENDER runs) -> trace_mlp_w<W>_<mode>_render."""
     m, sd = build_model(W, seed)
     tr = synth.model_conf(W)['ray_tracer']
     inp, _ = synth.make_batch(B, P, 0, seed=seed, focal_scale=1.4, with_features=False)
@@ -256,11 +275,15 @@ def g_trace_mlp(W, B, P, seed):
         dirs, cam_loc = rend_util.get_camera_params(T(inp['uv']), T(inp['pose']), T(inp['intrinsics']))
     om = np.ones((B * P,), dtype=bool)
     for training in (False, True):
-        pts, mask, dists, steps, rows, extra = run_tracer(lambda x: net(x)[:, 0], cam_loc, T(om), dirs, training,
-                                                   seed + 5, margins=True, **tr)
+        with (env(IDR_USE_ENV=1, IDR_RENDER=1) if render else contextlib.nullcontext()):
+            pts, mask, dists, steps, rows, extra = run_tracer(lambda x: net(x)[:, 0], cam_loc, T(om), dirs, training,
+                                                       seed + 5, margins=True, **tr)
         with torch.no_grad():
             sdf_at = net(T(pts))[:, 0].numpy()
-        save('trace_mlp_w%d_%s' % (W, 'train' if training else 'eval'), W=W, seed=seed, B=B, P=P,
+        if render:
+            extra['dist_clip'] = np.float32(0.05)
+            extra['sphere_tracing_iters'] = np.int32(40)
+        save('trace_mlp_w%d_%s%s' % (W, 'train' if training else 'eval', '_render' if render else ''), W=W, seed=seed, B=B, P=P,
              focal_scale=1.4, ray_dirs=dirs.numpy(), cam_loc=cam_loc.numpy(), points=pts, mask=mask,
              dists=dists, sdf_at_points=sdf_at, minsdf_steps=steps, rows=rows, **extra,
              checksum=synth.state_checksum(sd))
@@ -280,10 +303,14 @@ def g_sample_network(seed):
 SCENE = dict(size=2.6, center=(0.1, -0.2, 0.3), feat_hw=(60, 80), focal_scale=1.4)
 
 
-def g_idr(W, B, P, V, seed, tp, name=None, skip_in=(4,), smooth=None, use_invalid=False):
-    """smooth: conf.smooth(tp) of the depth term (loss.py:57-58: SmoothL1 instead of L1; None in the shipped conf) -- set on the reference's conf module for this fixture"""
+def g_idr(W, B, P, V, seed, tp, name=None, skip_in=(4,), smooth=None, use_invalid=False, use_mask=False, enable_rgb=True):
+    """smooth: conf.smooth(tp) of the depth term (loss.py:57-58: SmoothL1 instead of L1; None in the shipped conf) -- set on the reference's conf module for this fixture.
+    use_mask: conf.use_mask = True (idr.py:186: the tracer and the rgb term see input['object_mask']) with a random 70 % object mask (stored in the fixture).
+    enable_rgb=False: conf.enable_rgb off (loss.py:184-187: rgb_loss = zeros(1))."""
     import model.loss as ref_loss
     old_smooth, old_ui = ref_loss.conf.smooth, ref_loss.conf.use_invalid
+    old_um, old_er = ref_loss.conf.use_mask, ref_loss.conf.enable_rgb
+    ref_loss.conf.use_mask, ref_loss.conf.enable_rgb = bool(use_mask), bool(enable_rgb)   # (model.conf: the module idr.py and loss.py share)
     ref_loss.conf.use_invalid = bool(use_invalid)
     if smooth is not None:
         ref_loss.conf.smooth = lambda tp_: smooth
@@ -291,6 +318,8 @@ def g_idr(W, B, P, V, seed, tp, name=None, skip_in=(4,), smooth=None, use_invali
     inp, gt = synth.make_batch(B, P, V, seed=seed, **SCENE)
     if use_invalid:                                                            # depth maps with holes: that is where carving_t and carving_t2 differ
         inp['depths'] = gt['depths'] = synth.make_depth_maps(inp['depth_cams'], SCENE['size'], SCENE['center'], seed=seed, hole_frac=0.3)
+    if use_mask:
+        inp['object_mask'] = np.random.RandomState(seed + 17).uniform(size=inp['object_mask'].shape) < 0.7
     m.train()
     torch.manual_seed(seed + 5)
     mi = {k: T(v) for k, v in inp.items()}
@@ -325,6 +354,12 @@ def g_idr(W, B, P, V, seed, tp, name=None, skip_in=(4,), smooth=None, use_invali
         res['gidx_' + k] = idx
         res['gval_' + k] = g.reshape(-1)[idx]
     ref_loss.conf.smooth, ref_loss.conf.use_invalid = old_smooth, old_ui
+    ref_loss.conf.use_mask, ref_loss.conf.enable_rgb = old_um, old_er
+    if use_mask:
+        res['use_mask'] = np.int32(1)
+        res['in_object_mask'] = inp['object_mask']
+    if not enable_rgb:
+        res['enable_rgb'] = np.int32(0)
     if use_invalid:
         res['use_invalid'] = np.int32(1)
         res['depth_hole_frac'] = np.float32(0.3)
@@ -341,7 +376,24 @@ IDR_FIXTURES = {   # name: (W, B, P, V, seed, tp, skip_in) of the g_idr fixtures
     'idr_c1': (256, 1, 512, 4, 0, 0.3, (4,)), 'idr_c2': (256, 8, 256, 4, 0, 0.3, (4,)), 'idr_c3': (256, 8, 1024, 8, 0, 0.3, (4,)),
     'idr_c5share': (256, 8, 512, 8, 0, 0.3, (4,)), 'idr_w512': (512, 8, 128, 2, 0, 0.3, (4,)), 'idr_w64_skips36': (64, 2, 256, 3, 0, 0.3, (3, 6)),
     'idr_w64_skip8': (64, 2, 256, 3, 0, 0.3, (8,)), 'idr_w64_smooth': (64, 2, 256, 3, 0, 0.3, (4,)), 'idr_w64_invalid': (64, 2, 256, 3, 0, 0.3, (4,)),
+    'idr_w64_usemask': (64, 2, 256, 3, 0, 0.3, (4,)), 'idr_w64_norgb': (64, 2, 256, 3, 0, 0.3, (4,)),
 }
+
+
+def g_idr_eval(W, B, P, seed, render=0, name=None):
+    """IDRNetwork.eval() forward of the reference (idr.py:179-322 with self.training False: tracer in eval mode, rgb_values = ones outside the surface mask, no
+    eikonal keys, grad_theta None) as evaluation/eval.py:145-151 calls it (`model(s)`: train_progress None); render=1: under IDR_USE_ENV=1 IDR_RENDER=1 (40 iterations,
+    dist_clip 0.05)."""
+    m, sd = build_model(W, seed)
+    inp, _ = synth.make_batch(B, P, 0, seed=seed, focal_scale=1.4, with_features=False)
+    m.eval()
+    mi = {k: T(v) for k, v in inp.items()}
+    with (env(IDR_USE_ENV=1, IDR_RENDER=1) if render else contextlib.nullcontext()), quiet():
+        out = m(mi)                                              # (not under no_grad: the reference's normals come from autograd.grad, idr.py:96-107)
+    assert out['grad_theta'] is None and 'eikonal_output' not in out
+    res = {'out_' + k: v.detach().numpy() for k, v in out.items() if v is not None}
+    save(name or 'idr_eval_w%d%s' % (W, '_render' if render else ''), W=W, B=B, P=P, seed=seed, focal_scale=1.4, render=np.int32(render),
+         checksum=synth.state_checksum(sd), out_keys=np.array(sorted(out.keys())), **res)
 
 
 def g_idr_relu_margins():
@@ -565,7 +617,43 @@ def g_dsurf(seed):
          pts_norm=pts_all.numpy(), valid=valid.numpy(), inbound=inbound.numpy())
 
 
+# fixtures `--check NAME ...` can regenerate, and the call that writes each
+RECIPES = {
+    'idr_w64_tp03': lambda: g_idr(64, 2, 256, 3, 0, 0.3), 'idr_w64_tp06': lambda: g_idr(64, 2, 256, 3, 0, 0.6), 'idr_w256_tp03': lambda: g_idr(256, 2, 128, 2, 0, 0.3),
+    'sdf_w64': lambda: g_sdf(64, 1000, 0), 'render_w64': lambda: g_render(64, 300, 0), 'rays': lambda: g_rays(0), 'sample_network': lambda: g_sample_network(0),
+    'feat_corr': lambda: g_feat(0), 'carve': lambda: g_carve(0), 'sdf_bwd_w64': lambda: g_sdf_bwd(64, 150, 0), 'render_bwd_w64': lambda: g_render_bwd(64, 150, 0),
+    'idr_w64_usemask': lambda: g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_usemask', (4,), None, False, True),
+    'idr_w64_norgb': lambda: g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_norgb', (4,), None, False, False, False),
+    'idr_eval_w64': lambda: g_idr_eval(64, 2, 300, 0), 'idr_eval_w64_render': lambda: g_idr_eval(64, 2, 300, 0, 1), 'idr_eval_w256': lambda: g_idr_eval(256, 2, 200, 0),
+    'dsurf_unproject': lambda: g_dsurf(0),
+}
+
+
+def check(names):
+    """`make_golden.py --check NAME ...`: regenerate the named fixtures into a scratch directory and compare them with the committed files array by array,
+    bit for bit (a fixture that drifted from its generator -- arrays missing, values changed -- fails here).  -> number of differing fixtures."""
+    import tempfile
+    global OUT_DIR
+    bad = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT_DIR = tmp
+        try:
+            for n in names:
+                with quiet():
+                    RECIPES[n]()
+                new, old = np.load(os.path.join(tmp, n + '.npz'), allow_pickle=False), np.load(os.path.join(HERE, n + '.npz'), allow_pickle=False)
+                diff = sorted(set(new.files) ^ set(old.files)) + [k for k in new.files if k in old.files and not (
+                    new[k].shape == old[k].shape and new[k].dtype == old[k].dtype and np.array_equal(new[k], old[k], equal_nan=new[k].dtype.kind == 'f'))]
+                print('%-28s %s' % (n, 'identical (%d arrays)' % len(new.files) if not diff else 'DIFFERS: ' + ', '.join(diff)))
+                bad += bool(diff)
+        finally:
+            OUT_DIR = HERE
+    return bad
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 2 and sys.argv[1] == '--check':
+        sys.exit(1 if check(sys.argv[2:]) else 0)
     if len(sys.argv) > 1:                                                       # python make_golden.py g_dsurf 0  (one fixture)
         def _arg(v):
             for conv in (int, float):
@@ -613,4 +701,12 @@ if __name__ == '__main__':
     g_sdf_bwd(64, 150, 0, (8,), 'sdf_bwd_w64_skip8')                            # a skip connection into the LAST Linear (idr.py:46-49,86)
     g_sdf_bwd(64, 150, 0, (4, 8), 'sdf_bwd_w64_skips48')
     g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_skip8', (8,))
+    g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_usemask', (4,), None, False, True)          # conf.use_mask = True (idr.py:186) with a random object mask
+    g_idr(64, 2, 256, 3, 0, 0.3, 'idr_w64_norgb', (4,), None, False, False, False)     # conf.enable_rgb = False (loss.py:184-187)
+    # the rendering variant of the tracer (IDR_RENDER: 40 iterations, dist_clip 0.05, ray_tracing.py:127-131) and IDRNetwork in eval mode (eval.py:145-151)
+    g_trace_mlp(64, 4, 1024, 0, 1)
+    g_trace_mlp(256, 2, 512, 0, 1)
+    g_idr_eval(64, 2, 300, 0)
+    g_idr_eval(64, 2, 300, 0, 1)
+    g_idr_eval(256, 2, 200, 0)
     g_idr_relu_margins()

@@ -21,7 +21,29 @@ def trace_params(W=64, **over):
     tr = dict(synth.model_conf(W)['ray_tracer'])
     tr.update(over)
     return (tr['object_bounding_sphere'], tr['sdf_threshold'], tr['line_search_step'], tr['line_step_iters'],
-            tr['sphere_tracing_iters'], tr['n_steps'], tr['n_secant_steps'], 0.5)
+            tr['sphere_tracing_iters'], tr['n_steps'], tr['n_secant_steps'], tr.get('dist_clip', 0.5))
+
+
+def render_overrides(g):
+    """{} for an ordinary tracer fixture; the reference's IDR_RENDER variant (ray_tracing.py:127-131: dist_clip 0.05, 40 sphere-tracing iterations) for the
+    `*_render` fixtures, which record both numbers."""
+    if 'dist_clip' not in g.files:
+        return {}
+    return {'dist_clip': round(float(g['dist_clip']), 6), 'sphere_tracing_iters': int(g['sphere_tracing_iters'])}
+
+
+def depth_check(g, dists, hit, tol=1e-4):
+    """north_star: intersection depths within 1e-4 rel of the reference's.  A ray the REFERENCE itself recorded within 1e-6 of a decision boundary
+    (make_golden.py::MarginRecorder: min |sdf| or min |sdf - threshold| over its evaluations) may stop an iteration earlier or later in another fp32
+    summation order -- a tie, not a deviation: such rays are exempt (at most 2 per fixture, and still within 1e-3 abs); every other hit ray is held to
+    `tol`.  -> number of exempt rays."""
+    rel = np.abs(dists - g['dists']) / np.abs(g['dists']).clip(1e-6)
+    tie = np.zeros(hit.shape, bool)
+    if 'margin_min_abs_sdf' in g.files:
+        tie = hit & (np.minimum(g['margin_min_abs_sdf'], g['margin_min_thr_gap']) < 1e-6) & (rel >= tol)
+    assert rel[hit & ~tie].max() < tol, float(rel[hit & ~tie].max())
+    assert int(tie.sum()) <= 2 and (not tie.any() or np.abs(dists - g['dists'])[tie].max() < 1e-3), (int(tie.sum()))
+    return int(tie.sum())
 
 
 def t(a, dev='cuda'):

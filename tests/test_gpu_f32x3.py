@@ -64,7 +64,8 @@ def test_three_term_mlp_bit_exact_vs_its_oracle(oracle, W, n):
             assert bad.size == 0, (W, seed, mt, bad[:5], y[bad[:5]], ref[bad[:5]])
 
 
-@pytest.mark.parametrize('W,mode,views,rays', [(64, 'train', 4, 1024), (64, 'eval', 4, 1024), (256, 'train', 4, 256), (256, 'eval', 4, 256), (512, 'train', 2, 192), (512, 'eval', 1, 128)])
+@pytest.mark.parametrize('W,mode,views,rays', [(64, 'train', 4, 1024), (64, 'eval', 4, 1024), (256, 'train', 4, 256), (256, 'eval', 4, 256), (512, 'train', 2, 192), (512, 'eval', 1, 128),
+                                               (64, 'eval_render', 4, 1024), (64, 'train_render', 4, 512), (256, 'eval_render', 2, 256)])
 def test_three_term_tracer_bit_exact_vs_its_oracle(oracle, W, mode, views, rays):
     """RayTracing.forward on the trace_mlp fixtures' rays (all 1024 at W = 256, 384 + 128 at W = 512: the AVX2 form of the instruction model costs the CPU
     2.6 / ~12 ms per MLP row and thread): masks, dists, points and the row counters equal the oracle's bit for bit, for every chunking"""
@@ -75,10 +76,20 @@ def test_three_term_tracer_bit_exact_vs_its_oracle(oracle, W, mode, views, rays)
     cam = np.ascontiguousarray(g['cam_loc'][:views])
     om = np.ones(views * rays, bool)
     iv = torch.linspace(0, 1, 100)
-    p_o, m_o, d_o, rows = oracle.trace(oracle.Net(sd, bf16='f32x3'), cam, dirs, om, mode == 'train', g['minsdf_steps'], iv.numpy(), **synth.model_conf(W)['ray_tracer'])
+    # (*_render: the IDR_RENDER variant -- dist_clip 0.05, 40 iterations, ray_tracing.py:127-131 -- with the same two numbers on both sides)
+    from helpers import render_overrides
+    over = render_overrides(g)
+    assert bool(over) == ('render' in mode)
+    training = mode.startswith('train')
+    p_o, m_o, d_o, rows = oracle.trace(oracle.Net(sd, bf16='f32x3'), cam, dirs, om, training, g['minsdf_steps'], iv.numpy(), **dict(synth.model_conf(W)['ray_tracer'], **over))
+    ref_mask = g['mask'].reshape(B, P)[:views, :rays].reshape(-1)
+    ref_d = g['dists'].reshape(B, P)[:views, :rays].reshape(-1)
+    assert np.array_equal(m_o, ref_mask)                                           # the oracle of this arithmetic against the reference's own masks on these rays
+    rel = np.abs(d_o - ref_d)[ref_mask] / np.abs(ref_d[ref_mask])
+    assert np.sort(rel)[-3 if 'render' in mode else -1] < 1e-4, np.sort(rel)[-4:]  # (render: up to two recorded ties, helpers.depth_check)
     net = _net(sd)
     for mt, mts in ((1, 2), (2, 4), (4, 1)):
-        pts, mask, dists, cnt = ops.trace(net, t(cam), t(dirs), t(om), trace_params(W), mode == 'train', iv.cuda(), t(g['minsdf_steps']), mt=mt, mt_samples=mts)
+        pts, mask, dists, cnt = ops.trace(net, t(cam), t(dirs), t(om), trace_params(W, **over), training, iv.cuda(), t(g['minsdf_steps']), mt=mt, mt_samples=mts)
         assert np.array_equal(mask.cpu().numpy(), m_o), (mt, mts)
         assert np.array_equal(dists.cpu().numpy(), d_o), (mt, mts)
         assert np.array_equal(pts.cpu().numpy(), p_o), (mt, mts)

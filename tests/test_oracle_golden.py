@@ -80,24 +80,30 @@ def test_tracer_tier0_bit_exact(oracle, name):
     assert rows[1] > 0 and rows[2] > 0 and (rows[3] > 0) == ('train' in name)
 
 
-@pytest.mark.parametrize('W,mode', [(64, 'eval'), (64, 'train'), (256, 'eval'), (512, 'eval'), (512, 'train')])
+@pytest.mark.parametrize('W,mode', [(64, 'eval'), (64, 'train'), (256, 'eval'), (512, 'eval'), (512, 'train'),
+                                    (64, 'eval_render'), (64, 'train_render'), (256, 'eval_render')])
 def test_tracer_mlp(oracle, W, mode):
+    """*_render: the reference's rendering variant of the tracer (IDR_USE_ENV=1 IDR_RENDER=1: dist_clip 0.05, 40 iterations, ray_tracing.py:127-131)"""
+    from helpers import render_overrides
     g = golden('trace_mlp_w%d_%s' % (W, mode))
     net = _net(oracle, g)
-    tr = synth.model_conf(W)['ray_tracer']
+    tr = dict(synth.model_conf(W)['ray_tracer'], **render_overrides(g))
+    assert ('render' in mode) == (tr.get('dist_clip') == 0.05 and tr['sphere_tracing_iters'] == 40)
+    mode = mode.split('_')[0]
     pts, mask, dists, rows = oracle.trace(net, g['cam_loc'], g['ray_dirs'], np.ones(g['mask'].shape, bool),
                                           mode == 'train', g['minsdf_steps'], g['intervals'], **tr)
     assert np.array_equal(mask, g['mask'])                                          # hit masks bit-exact
     hit = g['mask']
-    rel = np.abs(dists - g['dists']) / np.abs(g['dists']).clip(1e-6)
-    assert rel[hit].max() < 1e-4                                                    # depths 1e-4 rel
+    from helpers import depth_check
+    n_ties = depth_check(g, dists, hit)                                             # depths 1e-4 rel (recorded ties exempt: helpers.depth_check)
     # non-hit rays: argmin over 100 samples may pick a neighbouring sample (SURVEY section 4): compare SDF there
     far = (~hit) & (np.abs(dists - g['dists']) > 1e-4)
     assert far.mean() < 0.02
     if far.any():
         s_mine = oracle.sdf_forward(net, pts[far], ncols=1)[:, 0]
         assert np.abs(s_mine - g['sdf_at_points'][far]).max() < 2e-4
-    assert abs(int(rows.sum()) - int(g['rows'].sum())) <= 8
+    # every sdf() row the reference evaluated (a ray tied at the convergence threshold enters or skips the 100-sample ray sampler + its secant steps)
+    assert abs(int(rows.sum()) - int(g['rows'].sum())) <= 8 + 110 * n_ties
     report_margins('oracle trace_mlp_w%d_%s' % (W, mode), g, g['mask'], np.abs(dists - g['dists']))
 
 
