@@ -366,12 +366,15 @@ def main():
     gpu_ms = g0.elapsed_time(g1) / a.steps
     ranks = None
     if under_launcher:
-        mine = torch.tensor([dt, float(local)], device=dev, dtype=torch.float64)
+        mine = torch.tensor([dt, float(local), gpu_ms, t_host / a.steps * 1e3], device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         dts = [float(t_[0]) for t_ in allr]
+        # per rank: wall, GPU-side time of the timed region (events on the launch stream) and the host's enqueue loop, ms per step -- a rank whose host
+        # cannot keep up shows host_enqueue close to wall (its GPU waits for launches); with the deferred step the enqueue loop is well below the GPU time
         ranks = {'ms_min': min(dts) / a.steps * 1e3, 'ms_max': max(dts) / a.steps * 1e3, 'devices': len({int(t_[1]) for t_ in allr}),
-                 'cpus_per_rank': cpus_pinned}
+                 'cpus_per_rank': cpus_pinned, 'wall_ms_per_step': [d_ / a.steps * 1e3 for d_ in dts],
+                 'gpu_ms_per_step': [float(t_[2]) for t_ in allr], 'host_enqueue_ms_per_step': [float(t_[3]) for t_ in allr]}
         dt = max(dts)                                            # the MAX over the ranks is the job's time
 
     # (every rank runs these extra steps: step() holds the gradient collective)

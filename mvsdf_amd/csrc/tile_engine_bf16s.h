@@ -382,13 +382,24 @@ __device__ __forceinline__ void mv_gemm_rolling_dispatch_bw(int KB, const uint16
     }
 }
 
+// Which evaluations alternate between two activation tiles (PP of mv_sdf_eval_col0 below): ONE row tile of the three-weight-term arithmetic ('f32x3', the product
+// default).  The callers provide the second tile behind the first (act + 16 * net.S floats): a kernel built for two or more row tiles has it free whenever it
+// evaluates a single tile, a one-tile kernel allocates it (trace.hip: mv_act_rows).
+template <class NET> struct mv_bs_pp { static constexpr bool v = false; };
+template <> struct mv_bs_pp<MvNetBs<3, 3>> { static constexpr bool v = true; };
+
 // ImplicitNetwork.forward(...)[:, 0] for MTc*16 rows (points in LDS `pts`), bf16 weights x NS-term activations.  Result -> LDS out[row].
 // `actf` is the activation region (rows * net.S floats) = NS term tiles of bf16 [rows][S16].  All 64*NW threads must call; ends with a barrier.
-template <int MTc, int NTW, int NW = 8, bool CARRY_ = false, int NS = 2, int WT = 1>
-__device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float* pe, const float* pts, float* out, int tid) {
+// PP (ping-pong, round 6): the layers alternate between `actf` and a second region `actf2` of the same size -- a layer's epilogue writes the tile the NEXT
+// layer reads instead of overwriting the one its own matrix loop read, so the "every wave done reading" barrier between matrix loop and epilogue goes and
+// ONE barrier per layer is left (a wave can only reach layer l + 1's epilogue, which writes the tile layer l read, after the barrier at the top of layer l + 1,
+// i.e. after every wave's layer-l reads).  Same arithmetic, same bits.  Costs a second tile of LDS: used where one is free anyway (mv_bs_pp below).
+template <int MTc, int NTW, int NW = 8, bool CARRY_ = false, int NS = 2, int WT = 1, bool PP = false>
+__device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float* pe, const float* pts, float* out, int tid, float* actf2 = nullptr) {
     constexpr bool CARRY = CARRY_ && WT == 1;                       // weight terms: ROLLING only (CARRY_ selects the deeper ring there)
     constexpr int NTHREADS = 64 * NW, PD = mv_bf_pd(NTW, CARRY), PDR = mv_bf_pdr(NTW, CARRY);
-    uint16_t* act = (uint16_t*)actf;
+    uint16_t* act = (uint16_t*)actf;                                // the tile the current layer READS
+    uint16_t* actw = PP ? (uint16_t*)actf2 : act;                   // ... and the one its epilogue WRITES
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
     const int S16 = 2 * net.S / NS, rows = MTc * 16, d0 = 3 + 6 * net.multires, TS = rows * S16;
     const int nl = net.n_layers;
@@ -468,7 +479,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
         else if constexpr (WT > 1) { if (ntw > 0) mv_gemm_rolling_dispatch_bw<MTc, NTW, NS, WT, CARRY_>(KB, act, S16, TS, wcur[0], ntw, acc, lane); }
         else if (ntw > 0) mv_gemm_rolling_dispatch_bs<MTc, NTW, NS>(KB, act, S16, TS, wcur[0], ntw, acc, lane);
         MV_PH(6)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every wave done reading act (in-place update)
+        if constexpr (!PP) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // every wave done reading act (in-place update)
         MV_PH(3)
         {
             const float sc = mv_skip_at(net.skip_mask, l + 1) ? 0.7071067690849304f : 1.0f;   // cat([x, input]) / sqrt(2), idr.py:86-87 (x 1 is exact)
@@ -490,7 +501,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
                         uint32_t p0[NS], p1[NS];
                         mv_split_pk<NS>(h0, p0);
                         mv_split_pk<NS>(h1, p1);
-                        uint16_t* dst = act + (a * 16 + r) * S16 + col0;
+                        uint16_t* dst = actw + (a * 16 + r) * S16 + col0;
                         if ((ct0 + t) * 16 + 16 <= N) {                                                           // (wave-uniform)
 #pragma unroll
                             for (int s = 0; s < NS; ++s) *(uint2*)(dst + s * TS) = uint2{p0[s], p1[s]};
@@ -518,7 +529,7 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
                     uint16_t p[NS];
                     mv_split_1<NS>(WT > 1 ? mv_x3_flush(dm_div_sqrt2(pe[row * d0 + j])) : dm_div_sqrt2(pe[row * d0 + j]), p);
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) act[s * TS + row * S16 + N + j] = p[s];
+                    for (int s = 0; s < NS; ++s) actw[s * TS + row * S16 + N + j] = p[s];
                 }
             }
             if (Kp > Kb) {
@@ -526,10 +537,11 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
                 for (int idx = tid; idx < rows * pad; idx += NTHREADS) {
                     const int row = idx / pad, j = idx - row * pad;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) act[s * TS + row * S16 + Kb + j] = 0;
+                    for (int s = 0; s < NS; ++s) actw[s * TS + row * S16 + Kb + j] = 0;
                 }
             }
         }
+        if constexpr (PP) { uint16_t* t_ = act; act = actw; actw = t_; }
         MV_PH(4)
     }
     {   // last layer: column 0 only (wave 0)
@@ -557,4 +569,10 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
     __syncthreads();
     MV_PH(5)
     MV_PH_END
+}
+
+// one row tile, ping-pong activation tiles (see mv_sdf_eval_col0): NS / WT deduced from the net
+template <int NTW, int NW, bool CARRY_, int NS, int WT>
+__device__ __forceinline__ void mv_sdf_eval_col0_pp(const MvNetBs<NS, WT>& net, float* actf, float* pe, const float* pts, float* out, int tid) {
+    mv_sdf_eval_col0<1, NTW, NW, CARRY_, NS, WT, true>(net, actf, pe, pts, out, tid, actf + 16 * net.S);
 }

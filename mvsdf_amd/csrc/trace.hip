@@ -64,6 +64,7 @@ __device__ __forceinline__ void mv_eval_dispatch(const NET& net, int ntiles, flo
         else if (MT >= 3 && ntiles == 3) mv_sdf_eval_col0<(MT >= 3 ? 3 : MT), NTW, NW, false>(net, act, pe, pts, out, tid);
         // (four column tiles per wave = 512-wide nets: the carried scheme would hold 4 of their 16 k-blocks and fetch the rest on the spot)
         else if (MT >= 2 && ntiles == 2) mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW, NW, (XR && NTW < 4)>(net, act, pe, pts, out, tid);
+        else if constexpr (mv_bs_pp<NET>::v) mv_sdf_eval_col0_pp<NTW, NW, (XR && NTW < 4)>(net, act, pe, pts, out, tid);   // (second activation tile behind the first: mv_act_rows)
         else mv_sdf_eval_col0<1, NTW, NW, (XR && NTW < 4)>(net, act, pe, pts, out, tid);
     }
 }
@@ -72,10 +73,14 @@ __device__ __forceinline__ void mv_eval_dispatch(const NET& net, int ntiles, flo
 struct TraceLds {
     float* act; float* pe; float* pts; float* sdfv; float* sv; int* misc;
 };
+// rows of activation tiles a kernel keeps for `rows` evaluation rows: the engines that alternate between two tiles when they evaluate ONE row tile
+// (tile_engine_bf16s.h: mv_bs_pp) need the second one even in a one-tile kernel
+template <class NET> __host__ __device__ constexpr int mv_act_rows(int rows) { return (mv_bs_pp<NET>::v && rows < 32) ? 32 : rows; }
+template <class NET>
 __device__ __forceinline__ TraceLds mv_carve(float* base, int rows, int S, int d0, int sv_floats) {
     TraceLds l;
     l.act = base;
-    l.pe = l.act + rows * S;
+    l.pe = l.act + mv_act_rows<NET>(rows) * S;
     l.pts = l.pe + ((rows * d0 + 3) & ~3);
     l.sdfv = l.pts + rows * 4;
     l.sv = l.sdfv + rows;
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams
     const long long clk0 = tail.probe ? (long long)wall_clock64() : 0;
     unsigned n_rounds = 0;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    TraceLds lds = mv_carve(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
+    TraceLds lds = mv_carve<NET>(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
     int* s_n = lds.misc;
 
     // ---- per-ray state (threads 0..NR-1 of wave 0) ----
@@ -445,7 +450,7 @@ __device__ void mv_eval_rows(const NET& net, const MvTraceParams& tp, const Samp
     const long long total = (long long)n_list * ni;
     if (q0 >= total) return;
     const int nr = (int)min((long long)ROWS, total - q0);
-    TraceLds lds = mv_carve(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
+    TraceLds lds = mv_carve<NET>(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
     long long svi = 0;
     if (tid < ROWS) {
         float* p = lds.pts + tid * 3;
@@ -612,7 +617,7 @@ __device__ void mv_secant_rays(const NET& net, const MvTraceParams& tp, const Sa
     const int r0 = block * ROWS;
     if (r0 >= n_list) return;
     const int n = min(ROWS, n_list - r0);
-    TraceLds lds = mv_carve(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
+    TraceLds lds = mv_carve<NET>(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
     const bool mine = tid < n;
     int gid = 0;
     float cc[3] = {0, 0, 0}, d[3] = {0, 0, 0}, z_low = 0, z_high = 0, sdf_low = 0, sdf_high = 1, z_pred = 0;
@@ -730,7 +735,7 @@ static bool mv_tail_on(int training, const float* steps, int R, int mt1) {
 template <class NET>
 static size_t trace_lds_bytes(const NET& net, int MT, int sv_floats, int rpw) {
     const int rows = 16 * MT, d0 = 3 + 6 * net.multires;
-    size_t f = (size_t)rows * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows + sv_floats;
+    size_t f = (size_t)mv_act_rows<NET>(rows) * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows + sv_floats;
     return f * 4 + 16 + (size_t)rpw * (8 * 4 + 4) + 16;
 }
 

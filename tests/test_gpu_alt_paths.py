@@ -24,11 +24,13 @@ def dev_lib():
     from mvsdf_amd import build
     return build.build(tag='dev')
 
-TARGETS = ['tests/test_gpu_diff.py', 'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w64_tp03]',
-           'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w256_tp03]',
+# (the end-to-end fixtures in both orders: 'loss_first' = the deferred step where the configuration has one -- the per-layer routes wait for the counts instead)
+TARGETS = ['tests/test_gpu_diff.py', 'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w64_tp03-outputs_first]',
+           'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w64_tp03-loss_first]',
+           'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w256_tp03-loss_first]',
            # a skip connection into the LAST Linear (idr.py:46-49,86): the one layout the per-layer route treats apart (k_pe_adj_top, bcast_sqrt2)
            'tests/test_gpu_options.py::test_several_skip_connections[sdf_bwd_w64_skip8]',
-           'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w64_skip8]']
+           'tests/test_gpu_idr.py::test_forward_loss_backward_vs_reference[idr_w64_skip8-outputs_first]']
 
 
 @pytest.mark.parametrize('env', [{'MVSDF_FUSE': '0'}, {'MVSDF_SPLIT_CHAINS': '1'}, {'MVSDF_CHAIN_W8': '1'}, {'MVSDF_CHAIN_MT': '2'}, {'MVSDF_DELTA_CHAIN': '1'},
