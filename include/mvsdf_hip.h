@@ -36,8 +36,9 @@ typedef struct {
     int N[MVSDF_MAX_LAYERS];            /* out features per Linear */
     const float* wp[MVSDF_MAX_LAYERS];  /* packed weights, mvsdf_packed_floats(N, K) floats */
     const float* bias[MVSDF_MAX_LAYERS]; /* [N] floats.  trace_dtype 3 / 4 / 5 read each vector with 16-byte loads up to the next multiple of 16 entries (the
-                                         * entries past N are loaded and never used): the buffer must be readable that far, which every hipMalloc'd or
-                                         * torch-allocated buffer is (allocation granularity >= 64 bytes) */
+                                         * entries past N are loaded and never used): the buffer must be READABLE that far.  Every hipMalloc'd or torch-allocated
+                                         * buffer is (allocation granularity >= 64 bytes); a caller that carves biases out of its own arena pads each vector to a
+                                         * multiple of 16 floats (a vector that ends exactly at the end of a mapped range would fault otherwise) */
     const float* w[MVSDF_MAX_LAYERS];   /* folded weights, row-major [N][K] (only the last layer's row 0 is read: u_L = W_L[0,:]); may be NULL when no normals are needed */
     int skip_layer;                     /* layer whose input is cat([x, PE(x)])/sqrt(2) (idr.py:86-87), -1 if none (see skip_mask for several) */
     int multires;                       /* positional-encoding frequencies (embedder.py:38-50) */

@@ -32,10 +32,13 @@ static inline unsigned mv_desc_skip_mask(const MvsdfNetDesc* d) { return d->skip
 static inline int mv_bf_nsplit(const MvsdfNetDesc* d, int l) { return (l == 0 || mv_skip_at(mv_desc_skip_mask(d), l)) ? 3 + 6 * d->multires : 0; }
 
 // column tiles per wave the fused chain kernels need for this network (8 waves per workgroup): 2 up to width 256, 4 up to 512,
-// 0 = too wide for them (per-layer kernels take over)
+// 0 = too wide for them (per-layer kernels take over).  Width = the widest tile row ANY phase of a chain produces: the hidden layers' outputs N_l (value /
+// E.1 chains over W_l) AND their inputs K_l (normal / E.2 chains over W_l^T produce K_l columns) -- a skip layer fed by a wider-than-hidden layer
+// (dims[skip] > the other hidden widths) has K_skip > every N_l.
 static inline int mv_chain_ntw(const MvNet& net) {
     int maxnt = 0;
     for (int l = 0; l < net.n_layers - 1; ++l) maxnt = net.L[l].NT > maxnt ? net.L[l].NT : maxnt;
+    for (int l = 1; l < net.n_layers; ++l) { const int kt = (net.L[l].K + 15) / 16; maxnt = kt > maxnt ? kt : maxnt; }
     return maxnt <= 16 ? 2 : (maxnt <= 32 ? 4 : 0);
 }
 

@@ -19,8 +19,9 @@ typedef short mv_bf8 __attribute__((ext_vector_type(8)));
 
 struct MvLayerBf {
     const uint4* wp;    // packed [NT][KB][64] x 8 bf16
-    const float* bias;  // [N] fp32, READ UP TO THE NEXT MULTIPLE OF 16 ENTRIES (16-byte loads of four columns; entries past N are loaded and never used:
-                        // every hipMalloc'd / torch-allocated buffer is readable that far)
+    const float* bias;  // [N] fp32, READ UP TO THE NEXT MULTIPLE OF 16 ENTRIES (16-byte loads of four columns; entries past N are loaded and never used).  A
+                        // requirement of the C ABI, stated at MvsdfNetDesc.bias in include/mvsdf_hip.h: hipMalloc'd and torch-allocated buffers are readable
+                        // that far; a caller that sub-allocates biases from its own arena pads each to a multiple of 16 floats
     int K, N;           // true in / out
     int nsplit;         // trailing input columns that enter as hi + lo pairs (layer 0: all of them; skip layer: the PE part)
     int KB, NT;         // k-blocks of 32 over K + nsplit, column tiles of 16

@@ -247,13 +247,14 @@ def pack_net(vs, gs, biases, skip_layer, multires, want_t=True, x3=None):
         layers.append(L)
     net = PackedNet(layers, skip_layer, multires)
     if (CHAIN_X3 if x3 is None else x3) and want_t:
-        maybe_pack_x3_chain(net)
+        maybe_pack_x3_chain(net, force=x3)
     return net
 
 
-def maybe_pack_x3_chain(net):
-    """pack_x3_chain for SDF networks (first Linear over the positional encoding of a 3-D point); the rendering network's chains stay on the fp32-input MFMA."""
-    if CHAIN_X3 and len(net.layers) >= 2 and net.layers[0].K == 3 + 6 * max(net.multires, 0):
+def maybe_pack_x3_chain(net, force=None):
+    """pack_x3_chain for SDF networks (first Linear over the positional encoding of a 3-D point); the rendering network's chains stay on the fp32-input MFMA.
+    force: pack_net's `x3` argument (None: the module default CHAIN_X3 decides)."""
+    if (CHAIN_X3 if force is None else force) and len(net.layers) >= 2 and net.layers[0].K == 3 + 6 * max(net.multires, 0):
         pack_x3_chain(net)
     return net
 

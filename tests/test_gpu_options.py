@@ -107,6 +107,37 @@ def test_implicit_network_options_vs_torch(multires, wn):
     assert torch.allclose(y0, y[:, 0], rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize('wide', [288, 304])
+def test_skip_layer_wider_than_the_hidden_layers_vs_torch(wide):
+    """dims[skip] above the other hidden widths (hidden 256, dims[4] = 288 / 304: the skip layer takes 288 / 304 inputs = 18 / 19 column tiles of its W^T phases,
+    more than the 16 the one-tile-per-wave chain forms cover): the fused chains must pick a form wide enough for EVERY phase (capi_util.h::mv_chain_ntw looks
+    at the layers' inputs too) -- value, normal, and first / second-order parameter gradients against the plain PyTorch restatement."""
+    torch.manual_seed(3)
+    dims = [256, 256, 256, wide, 256, 256, 256, 256]
+    net = ImplicitNetwork(256, 3, 1, dims, geometric_init=True, bias=0.6, skip_in=[4], weight_norm=True, multires=6).cuda()
+    assert net.lin3.weight_v.shape[0] == wide - 39 and net.lin4.weight_v.shape[1] == wide
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.02 * p.abs().mean() * torch.randn_like(p))
+    x = (torch.rand(700, 3, generator=torch.Generator().manual_seed(4)) * 2 - 1).cuda()
+    y = net(x)
+    n = net.gradient(x.clone())[:, 0]
+    xr = x.clone().requires_grad_(True)
+    yr = _torch_sdf(net, xr)
+    nr = torch.autograd.grad(yr[:, 0].sum(), xr, create_graph=True)[0]
+    assert torch.allclose(y, yr, rtol=1e-4, atol=5e-6) and torch.allclose(n, nr, rtol=2e-4, atol=2e-5)
+    dy, dn = torch.randn_like(y) * 0.1, torch.randn_like(n)
+    params = list(net.parameters())
+    x2 = x.clone()
+    got = torch.autograd.grad((net(x2) * dy).sum() + (net.gradient(x2)[:, 0] * dn).sum(), params)
+    ref = torch.autograd.grad((yr * dy).sum() + (nr * dn).sum(), params)
+    for (k, _), a, b in zip(net.named_parameters(), got, ref):
+        assert torch.allclose(a, b, rtol=2e-3, atol=1e-3 * float(b.abs().max()) + 1e-8), k
+    from mvsdf_amd import ops
+    y0 = ops.sdf_col0(net.native_sdf().native_net, x)
+    assert torch.allclose(y0, y[:, 0], rtol=1e-5, atol=2e-6)
+
+
 def test_idr_step_without_weight_norm_and_without_normals():
     """A whole training step with weight_norm=False in both networks and rendering mode 'no_normal': same outputs as the weight-normed
     model carrying the same folded weights; gradients chain through the fold (dW of the plain model -> dv, dg of the normed one)."""

@@ -1,11 +1,11 @@
 """gpurun_out/<tag> (written on the GPU box by tools/run_profiles.sh) -> the tracked artefacts under profiles/ (bench lines, rocprofv3 kernel stats,
-PMC summaries, pmc_traffic.json with one entry per PMC'd workload).  usage: python tools/collect_profiles.py [round tag, default r05]"""
+PMC summaries, pmc_traffic.json with one entry per PMC'd workload).  usage: python tools/collect_profiles.py [round tag, default r06]"""
 import glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 src, dst = os.path.join(ROOT, 'gpurun_out', tag), os.path.join(ROOT, 'profiles')
 # gpurun MERGES into gpurun_out/: delete gpurun_out/<tag> before the run, or files of earlier runs mix in
-assert len(glob.glob(src + '/bench_line*.json')) >= 9 and len(glob.glob(src + '/stats_*')) >= 4 and len(glob.glob(src + '/pmc_*')) >= 4, 'incomplete ' + src
+assert len(glob.glob(src + '/bench_line*.json')) >= 9 and len(glob.glob(src + '/stats_*')) >= 3 and len(glob.glob(src + '/pmc_*')) >= 3, 'incomplete ' + src
 for f in sorted(glob.glob(src + '/bench_line*.json')):
     lines = [l for l in open(f).read().splitlines() if l.startswith('{')]
     assert lines, f
@@ -26,6 +26,10 @@ for d in sorted(glob.glob(src + '/pmc_*')):
         workload, width = 'c2', 512
     if workload == 'shipped':
         width = 512
+    rays = {'c2': 2048, 'c3': 8192, 'c5share': 4096, 'shipped': 32768}[workload]
     subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'pmc_to_json.py'), d, workload, dtype, str(width), out,
-                           '%s %s: separate --pmc FETCH_SIZE / WRITE_SIZE passes of python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline [%s] (tools/run_profiles.sh)' % (tag, w, w)])
+                           '%s %s: separate --pmc FETCH_SIZE / WRITE_SIZE passes of python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline [%s] (tools/run_profiles.sh)' % (tag, w, w),
+                           'weak', str(rays)])
+for f in sorted(glob.glob(src + '/step_timeline_*.txt')):
+    shutil.copy(f, os.path.join(dst, '%s_%s' % (tag, os.path.basename(f))))
 print(sorted(json.load(open(out))['entries']))
