@@ -382,11 +382,11 @@ __device__ __forceinline__ void mv_gemm_rolling_dispatch_bw(int KB, const uint16
     }
 }
 
-// Which evaluations alternate between two activation tiles (PP of mv_sdf_eval_col0 below): ONE row tile of the three-weight-term arithmetic ('f32x3', the product
-// default).  The callers provide the second tile behind the first (act + 16 * net.S floats): a kernel built for two or more row tiles has it free whenever it
-// evaluates a single tile, a one-tile kernel allocates it (trace.hip: mv_act_rows).
+// Which evaluations alternate between two activation tiles (PP of mv_sdf_eval_col0 below): every engine of this family when it evaluates ONE row tile, and the
+// sphere tracer's two-tile evaluations (its workgroups run one per CU: the LDS is free).  The callers provide the second region behind the first (act + rows *
+// net.S floats): a kernel built for more row tiles has it free whenever it evaluates fewer, otherwise it allocates it (trace.hip: mv_act_rows).
 template <class NET> struct mv_bs_pp { static constexpr bool v = false; };
-template <> struct mv_bs_pp<MvNetBs<3, 3>> { static constexpr bool v = true; };
+template <int NS, int WT> struct mv_bs_pp<MvNetBs<NS, WT>> { static constexpr bool v = true; };
 
 // ImplicitNetwork.forward(...)[:, 0] for MTc*16 rows (points in LDS `pts`), bf16 weights x NS-term activations.  Result -> LDS out[row].
 // `actf` is the activation region (rows * net.S floats) = NS term tiles of bf16 [rows][S16].  All 64*NW threads must call; ends with a barrier.
@@ -571,8 +571,8 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
     MV_PH_END
 }
 
-// one row tile, ping-pong activation tiles (see mv_sdf_eval_col0): NS / WT deduced from the net
-template <int NTW, int NW, bool CARRY_, int NS, int WT>
+// MTc row tiles, ping-pong activation tiles (see mv_sdf_eval_col0): NS / WT deduced from the net
+template <int MTc, int NTW, int NW, bool CARRY_, int NS, int WT>
 __device__ __forceinline__ void mv_sdf_eval_col0_pp(const MvNetBs<NS, WT>& net, float* actf, float* pe, const float* pts, float* out, int tid) {
-    mv_sdf_eval_col0<1, NTW, NW, CARRY_, NS, WT, true>(net, actf, pe, pts, out, tid, actf + 16 * net.S);
+    mv_sdf_eval_col0<MTc, NTW, NW, CARRY_, NS, WT, true>(net, actf, pe, pts, out, tid, actf + 16 * MTc * net.S);
 }

@@ -63,8 +63,12 @@ __device__ __forceinline__ void mv_eval_dispatch(const NET& net, int ntiles, flo
         if (MT >= 4 && ntiles == 4) mv_sdf_eval_col0<(MT >= 4 ? 4 : MT), NTW, NW, false>(net, act, pe, pts, out, tid);
         else if (MT >= 3 && ntiles == 3) mv_sdf_eval_col0<(MT >= 3 ? 3 : MT), NTW, NW, false>(net, act, pe, pts, out, tid);
         // (four column tiles per wave = 512-wide nets: the carried scheme would hold 4 of their 16 k-blocks and fetch the rest on the spot)
-        else if (MT >= 2 && ntiles == 2) mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW, NW, (XR && NTW < 4)>(net, act, pe, pts, out, tid);
-        else if constexpr (mv_bs_pp<NET>::v) mv_sdf_eval_col0_pp<NTW, NW, (XR && NTW < 4)>(net, act, pe, pts, out, tid);   // (second activation tile behind the first: mv_act_rows)
+        else if (MT >= 2 && ntiles == 2) {
+            // (the sphere tracer's two-tile workgroups -- XR, MT == 2: one per CU -- keep a second pair of tiles: mv_act_rows; not the 512-wide nets, NTW == 4: 224 KB)
+            if constexpr (XR && MT == 2 && NTW < 4 && mv_bs_pp<NET>::v) mv_sdf_eval_col0_pp<2, NTW, NW, (XR && NTW < 4)>(net, act, pe, pts, out, tid);
+            else mv_sdf_eval_col0<(MT >= 2 ? 2 : MT), NTW, NW, (XR && NTW < 4)>(net, act, pe, pts, out, tid);
+        }
+        else if constexpr (mv_bs_pp<NET>::v) mv_sdf_eval_col0_pp<1, NTW, NW, (XR && NTW < 4)>(net, act, pe, pts, out, tid);   // (second activation tile behind the first: mv_act_rows)
         else mv_sdf_eval_col0<1, NTW, NW, (XR && NTW < 4)>(net, act, pe, pts, out, tid);
     }
 }
@@ -75,12 +79,15 @@ struct TraceLds {
 };
 // rows of activation tiles a kernel keeps for `rows` evaluation rows: the engines that alternate between two tiles when they evaluate ONE row tile
 // (tile_engine_bf16s.h: mv_bs_pp) need the second one even in a one-tile kernel
-template <class NET> __host__ __device__ constexpr int mv_act_rows(int rows) { return (mv_bs_pp<NET>::v && rows < 32) ? 32 : rows; }
-template <class NET>
+// (sphere: k_sphere_trace, whose two-tile evaluations alternate too)
+template <class NET> __host__ __device__ constexpr int mv_act_rows(int rows, bool sphere = false) {
+    return !mv_bs_pp<NET>::v ? rows : (rows < 32 ? 32 : ((sphere && rows == 32) ? 64 : rows));
+}
+template <class NET, bool SPHERE = false>
 __device__ __forceinline__ TraceLds mv_carve(float* base, int rows, int S, int d0, int sv_floats) {
     TraceLds l;
     l.act = base;
-    l.pe = l.act + mv_act_rows<NET>(rows) * S;
+    l.pe = l.act + mv_act_rows<NET>(rows, SPHERE) * S;
     l.pts = l.pe + ((rows * d0 + 3) & ~3);
     l.sdfv = l.pts + rows * 4;
     l.sv = l.sdfv + rows;
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(64 * NW) void k_sphere_trace(NET net, MvTraceParams
     const long long clk0 = tail.probe ? (long long)wall_clock64() : 0;
     unsigned n_rounds = 0;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    TraceLds lds = mv_carve<NET>(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
+    TraceLds lds = mv_carve<NET, (NTW < 4)>(smem, ROWS, net.S, 3 + 6 * net.multires, 0);
     int* s_n = lds.misc;
 
     // ---- per-ray state (threads 0..NR-1 of wave 0) ----
@@ -733,9 +740,9 @@ static bool mv_tail_on(int training, const float* steps, int R, int mt1) {
 }
 
 template <class NET>
-static size_t trace_lds_bytes(const NET& net, int MT, int sv_floats, int rpw) {
+static size_t trace_lds_bytes(const NET& net, int MT, int sv_floats, int rpw, bool sphere = false) {
     const int rows = 16 * MT, d0 = 3 + 6 * net.multires;
-    size_t f = (size_t)mv_act_rows<NET>(rows) * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows + sv_floats;
+    size_t f = (size_t)mv_act_rows<NET>(rows, sphere) * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows + sv_floats;
     return f * 4 + 16 + (size_t)rpw * (8 * 4 + 4) + 16;
 }
 
@@ -764,7 +771,7 @@ static hipError_t launch_stage1(const NET& net, const MvTraceParams& tp, const f
         if (stop_env < 0) { const char* e = mv_dev_env("MVSDF_TAIL_STOP"); stop_env = e ? atoi(e) : -1; }
         tail.stop_left = stop_env >= 0 ? stop_env : grid1 / 4;      // (swept at c2: 0 / 16 / 32 / 48 / 64 of 256 -> tracer 1575 / 1527 / 1521 / 1507 / 1507 us, off: 1549)
     }
-    const size_t lds1 = trace_lds_bytes(net, MT, 0, 0);
+    const size_t lds1 = trace_lds_bytes(net, MT, 0, 0, NTW < 4);
     static size_t set1 = 0;                                     // raise the dynamic-LDS cap once per size (per instantiation)
     if (lds1 > set1) {
         hipError_t e = hipFuncSetAttribute((const void*)k_sphere_trace<MT, NTW, NW, NET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
