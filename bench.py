@@ -16,8 +16,13 @@ scene (mvsdf_amd.utils.synth), feature maps 32 x 600 x 800 stored channels-last 
 (Adam lr = 0, clip 2.0 included).  Per step and rank: ONE all-reduce(SUM) of the flat fp32 gradient buffer (RCCL over xGMI), its 1/N folded
 into the Adam launch, plus a 3-float all-reduce of the loss normaliser counts (IDRLoss.exact_data_parallel) that overlaps the forward.
 
-Prints ONE JSON line (rank 0) incl. `roofline` (the tracing-MLP kernels k_ray_samples and k_sphere_trace as peers, HIP events on the
-launch stream; k_feat_corr's gather rate) and `cpu_baseline` (the CPU oracle on a bounded sample of the same workload).
+The timed loop is the reference's training iteration without its per-step print (idr_train.py:253-315): zero_grad, forward, loss, backward, gradient
+all-reduce, clip + Adam.  With the deferred step (IDRNetwork.deferred_step, the default) nothing in it waits for the GPU: the host enqueues whole steps ahead.
+
+Prints ONE JSON line (rank 0) incl. `roofline` (the DOMINANT tracing-MLP kernel of the run -- k_sphere_trace or k_ray_samples, whichever took longer per step --
+with both under `kernels`, HIP events on the launch stream; k_feat_corr's gather rate), `timing` (gpu_ms_per_step: HIP events around the timed region;
+kernel_ms_per_step: event distance around each C call of a step; gpu_idle_frac; host milliseconds per section) and `cpu_baseline` (the CPU oracle on a bounded
+sample of the same workload).
 """
 import argparse
 import json

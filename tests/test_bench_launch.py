@@ -64,6 +64,13 @@ def test_eight_ranks_on_one_gpu_gloo_c4_shape_and_collective_timings():
     c = d['collective_ms']
     assert c['world'] == 8 and c['backend'] == 'gloo' and c['grad_all_reduce'] > 0 and c['loss_counts_all_reduce'] > 0 and c['grad_bytes'] > 3e6
     print('8 ranks on one GPU (gloo): %.1f ms per step, gradient all-reduce %.2f ms, loss-count all-reduce %.2f ms' % (d['ms_per_step'], c['grad_all_reduce'], c['loss_counts_all_reduce']))
+    # per rank: wall, GPU-side time of the timed region and the host's enqueue loop (the readiness record for a node whose ranks share host cores: a rank whose
+    # host cannot keep up shows its enqueue loop at its wall time)
+    r = d['ranks']
+    assert len(r['wall_ms_per_step']) == len(r['gpu_ms_per_step']) == len(r['host_enqueue_ms_per_step']) == 8
+    for k in range(8):
+        print('   rank %d: wall %.2f ms, gpu %.2f ms, host enqueue loop %.2f ms per step' % (k, r['wall_ms_per_step'][k], r['gpu_ms_per_step'][k], r['host_enqueue_ms_per_step'][k]))
+    assert all(h <= w * 1.05 + 0.05 for h, w in zip(r['host_enqueue_ms_per_step'], r['wall_ms_per_step']))
 
 
 @pytest.mark.gpu

@@ -92,3 +92,64 @@ def test_expired_outputs_raise():
         with pytest.raises(RuntimeError, match='lazy_unused_outputs'):
             f()
     assert out['rgb_values'][0] == 7.0
+
+
+# ---- PendingOutputs (the deferred training step): the N-shaped keys and `rgb_values` are placeholders until somebody reads one of them
+def make_pending():
+    from mvsdf_amd.model.implicit_differentiable_renderer import PendingOutputs
+    calls = []
+    eager_part = {'points': np.ones(3), 'diff_surf_pts': None, 'rgb_values': None, 'sdf_output': np.ones(3), 'network_object_mask': np.ones(3, bool),
+                  'object_mask': np.ones(3, bool), 'object_mask_true': np.ones(3, bool), 'grad_theta': None, 'eikonal_points_hom': None, 'eikonal_output': None,
+                  'surf_indicator_output': None}
+    rec = object()
+    out = PendingOutputs(eager_part, None, rec)
+
+    def materialize():
+        calls.append(1)
+        dict.update(out, {k: np.full(2, 5.0) for k in PendingOutputs._LAZY})
+    out._pending = materialize
+    return out, calls, rec
+
+
+def test_pending_outputs_resolve_on_the_first_read_of_an_n_shaped_key():
+    out, calls, rec = make_pending()
+    assert out.pending_rec() is rec
+    # what IDRLoss's deferred route and the tests read: never resolves
+    assert out.raw('network_object_mask').all() and out['points'][0] == 1.0 and out.get('uncerts') is None and 'rgb_values' in out and len(out) == 11
+    assert list(out)[:3] == ['points', 'diff_surf_pts', 'rgb_values']             # the reference's key order (idr.py:306-322)
+    assert calls == [] and out.pending_rec() is rec
+    assert float(out['rgb_values'][0]) == 5.0                                      # the first read of a lazy key: one resolution for all of them
+    assert calls == [1] and out.pending_rec() is None
+    assert float(out['diff_surf_pts'][0]) == 5.0 and float(out.get('eikonal_output')[0]) == 5.0
+    assert calls == [1]
+
+
+@pytest.mark.parametrize('how', ['items', 'values', 'dict', 'copy', 'unpack'])
+def test_pending_outputs_bulk_access_resolves(how):
+    out, calls, _ = make_pending()
+    got = {'items': lambda: dict(out.items()), 'values': lambda: dict(zip(out.keys(), out.values())), 'dict': lambda: dict(out), 'copy': lambda: out.copy(),
+           'unpack': lambda: {**out}}[how]()
+    assert calls == [1] and all(v is not None for v in got.values()) and float(got['grad_theta'][0]) == 5.0
+
+
+def test_step_stats_look_n_up_only_when_asked_and_group_rows():
+    """IDRNetwork.last_stats of a deferred step and StepRecord.group_rows (rows of eikonal_output / grad_theta for N hit rows: point groups
+    [hit | eikonal | on-surface | jittered], idr.py:253-286): host logic, no GPU."""
+    from types import SimpleNamespace
+    from mvsdf_amd.model.implicit_differentiable_renderer import _StepStats
+    from mvsdf_amd.native_step import StepRecord
+    calls = []
+
+    class Rec:
+        def resolve(self):
+            calls.append(1)
+            return 123, 100
+    st = _StepStats(Rec(), R=2048, E=1024)
+    assert st['R'] == 2048 and st.get('E') == 1024 and st.get('nope', 7) == 7 and calls == []
+    assert st['N'] == 123 and st.get('N') == 123 and calls == [1]                  # looked up once
+    rec = StepRecord()
+    rec.step = SimpleNamespace(desc=SimpleNamespace(n_eik=1024, n_ds=300))
+    rec.d_mask, rec.e_mask = 0b0011, 0b1111
+    assert rec.group_rows(500) == (500 + 1024, 500 + 1024 + 600)
+    rec.d_mask, rec.e_mask = 0b0010, 0b0001
+    assert rec.group_rows(2048) == (1024, 2048) and rec.group_rows(0) == (1024, 0)
