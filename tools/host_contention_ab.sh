@@ -1,5 +1,9 @@
-# round 6: the driver's command (20 steps, 5 warm-up) with the deferred and the classic step, on an idle host and on a host whose every core is taken
-# by a busy loop (what a shared node does to a step that waits for the GPU in its middle), + the kernel timeline of the deferred step
+# round 6: the driver's command (20 steps, 5 warm-up) with the deferred and the classic step, on an idle host and on a host whose every hardware thread
+# is taken by a busy loop, + the kernel timeline of the deferred step.  usage (GPU box): bash tools/host_contention_ab.sh
+# RESULT of the one run (gpurun_out/r06/diag3, profiles/r06_driver_cmd_boxB_*): idle host -- deferred 1.520 / 1.541 ms, classic 1.591 / 1.524 (gpu_idle_frac 0.025 / 0.004).
+# Busy host -- the experiment is TOO brutal to be informative: with nproc busy loops every Python statement of the benchmark takes milliseconds (host enqueue
+# loop 5-65 ms per step in either mode: zero_grad alone 5-10 ms), i.e. the host is slower than the GPU on average, which no amount of run-ahead absorbs; the
+# classic legs hit the call's time limit.  A milder load (a fraction of the threads) is the experiment to repeat; budget ~25 GPU-minutes for this form.
 set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r06/diag3
