@@ -252,6 +252,9 @@ def main():
     ap.add_argument('--width', type=int, default=0, help='hidden width of both MLPs: 256 = BASELINE.json (8x256), 512 = the reference\'s shipped conf (mvsdf_dtu.conf:24,35)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shard', default='', help="R/W (tests): run as ONE process on the shard rank R of a W-rank job would get (its views, its pixels per view, its seed); no process group")
+    ap.add_argument('--host-delay-us', type=float, default=0.0, help='diagnostic (never for a quoted number): busy-wait this many microseconds on the host after each of the six calls of a step '
+                    '(zero_grad, forward, loss, backward, all-reduce, optimiser) -- a stand-in for a slow or contended host.  The deferred step absorbs it while the host stays faster than the GPU on '
+                    'average; the classic step (MVSDF_DEFERRED_STEP=0) pays what lands behind its mid-step wait')
     ap.add_argument('--variants', action='store_true', help='also time the opt-in lazy_unused_outputs step (secondary number; off by default so that a profile of this command holds the headline step only)')
     a = ap.parse_args()
     global W
@@ -319,8 +322,21 @@ def main():
     grad_events = None                                           # set to a list during the extra steps: (start, end) events around the gradient all-reduce
     sect = None                                                  # set to a dict during the extra steps: host seconds per section + (start, end) events around the optimiser calls
 
+    def spin():
+        t_end = time.perf_counter() + a.host_delay_us * 1e-6
+        while time.perf_counter() < t_end:
+            pass
+
     def step():
         # idr_train.py:253-315 without its per-step print: with the deferred step (IDRNetwork.deferred_step, the default) nothing below waits for the GPU
+        if sect is None and a.host_delay_us > 0:
+            opt.zero_grad(); spin()
+            out = model(inp, TP); spin()
+            lo = loss_fn(out, dict(gt), TP, per); spin()
+            opt.backward(lo['loss']); spin()
+            opt.all_reduce_mean(defer_scale=True); spin()
+            opt.step(grad_cap=2.0); spin()
+            return out, lo
         if sect is None:
             opt.zero_grad()
             out = model(inp, TP)
@@ -536,6 +552,7 @@ def main():
                          'wall_over_kernel': None if kms is None else (dt / a.steps * 1e3) / kms, 'kernel_ms': kernel_parts,
                          'host_ms_per_step_enqueue_loop': t_host / a.steps * 1e3, 'host_ms': host_ms,
                          'deferred_step': bool(getattr(model, 'deferred_step', False) and st_native is not None and st_native.can_defer),
+                         'host_delay_us_per_call': a.host_delay_us,
                          'note': 'kernel_ms: HIP events around each C call of a step, mean of %d steps after the timed region; gpu_ms: events around the timed region' % nt}
         mul = MUL.get(a.dtype)
         if mul:
