@@ -335,7 +335,7 @@ def main():
             lo = loss_fn(out, dict(gt), TP, per); spin()
             opt.backward(lo['loss']); spin()
             opt.all_reduce_mean(defer_scale=True); spin()
-            opt.step(grad_cap=2.0); spin()
+            opt.step(grad_cap=2.0, zero_grad=True); spin()
             return out, lo
         if sect is None:
             opt.zero_grad()
@@ -343,8 +343,8 @@ def main():
             lo = loss_fn(out, dict(gt), TP, per)
             opt.backward(lo['loss'])                             # loss.backward() with the direct gradient sink (one launch for all dv/dg/db)
             opt.all_reduce_mean(defer_scale=True)                # ONE all-reduce(SUM) of the flat gradient buffer; / world inside Adam
-            opt.step(grad_cap=2.0)                               # grad-norm + clip + Adam (idr_train.py:289-302, conf.grad_cap)
-            return out, lo
+            opt.step(grad_cap=2.0, zero_grad=True)               # grad-norm + clip + Adam (idr_train.py:289-302, conf.grad_cap); leaves zeros in the gradients: the next
+            return out, lo                                       # iteration's zero_grad() (idr_train.py:283) costs no launch
         # the same calls with the host's clock between them and HIP events (launch stream) around the optimiser's launches
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         t0 = time.perf_counter()
@@ -358,7 +358,7 @@ def main():
         t4 = time.perf_counter()
         ev[2].record(); opt.all_reduce_mean(defer_scale=True); ev[3].record()
         t5 = time.perf_counter()
-        ev[4].record(); opt.step(grad_cap=2.0); ev[5].record()
+        ev[4].record(); opt.step(grad_cap=2.0, zero_grad=True); ev[5].record()
         t6 = time.perf_counter()
         for k, v in (('zero_grad', t1 - t0), ('forward', t2 - t1), ('loss', t3 - t2), ('backward', t4 - t3), ('all_reduce', t5 - t4), ('optimizer', t6 - t5)):
             sect['host'][k] = sect['host'].get(k, 0.0) + v

@@ -340,6 +340,10 @@ int mvsdf_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, 
  * SUM of a data-parallel all-reduce into the rank average inside the optimiser launch -- no separate division pass over the bucket. */
 int mvsdf_adam_step_scaled(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
                            float max_norm, float grad_scale, float* norm_out, float* ws, void* stream);
+/* ... and, with zero_grad != 0, ZEROS left in g instead of the scaled / clipped gradient: the `optimizer.zero_grad()` that opens the next iteration
+ * (idr_train.py:283) then needs no launch of its own (the update pass touches every gradient element anyway). */
+int mvsdf_adam_step_fused(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step,
+                          float max_norm, float grad_scale, int zero_grad, float* norm_out, float* ws, void* stream);
 
 /* masks -> what IDRLoss.forward needs from them, one launch: hit[R] = network_object_mask & object_mask (loss.py:21,206), view_start[B+1]
  * = prefix sums of the per-view hit counts (rows of diff_surf_pts per view, loss.py:119-127; R = B * P rays, view-major),

@@ -50,6 +50,7 @@ def lib():
         L.mvsdf_tracegen_state_bytes.restype = C.c_size_t
         L.mvsdf_adam_step.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mvsdf_adam_step_scaled.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mvsdf_adam_step_fused.argtypes = [C.c_void_p] * 4 + [C.c_size_t] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mvsdf_loss_scale.argtypes = [C.c_void_p] + [C.c_float] * 5 + [C.c_void_p, C.c_void_p, C.c_int] * 4 + [C.c_void_p, C.c_void_p]   # g: host array of 6 pointers
         for name in EXPORTS:
             getattr(L, name)
@@ -64,7 +65,7 @@ EXPORTS = [
     'mvsdf_tracegen_state_bytes', 'mvsdf_tracegen_init', 'mvsdf_tracegen_step', 'mvsdf_tracegen_finish', 'mvsdf_tracegen_rows', 'mvsdf_tracegen_reduce',
     'mvsdf_tracegen_secant',
     'mvsdf_sdf_ctx_floats', 'mvsdf_sdf_forward', 'mvsdf_sdf_bwd_ws_floats', 'mvsdf_sdf_backward', 'mvsdf_sdf_backward_pair', 'mvsdf_sdf_backward_finish',
-    'mvsdf_feat_corr', 'mvsdf_depth_carve', 'mvsdf_loss_terms', 'mvsdf_loss_prep', 'mvsdf_loss_scale', 'mvsdf_adam_ws_floats', 'mvsdf_adam_step', 'mvsdf_adam_step_scaled',
+    'mvsdf_feat_corr', 'mvsdf_depth_carve', 'mvsdf_loss_terms', 'mvsdf_loss_prep', 'mvsdf_loss_scale', 'mvsdf_adam_ws_floats', 'mvsdf_adam_step', 'mvsdf_adam_step_scaled', 'mvsdf_adam_step_fused',
     'mvsdf_partition_rays', 'mvsdf_step_outputs', 'mvsdf_step_backward_inputs', 'mvsdf_step_backward_fbar', 'mvsdf_dsurf_select', 'mvsdf_dsurf_points',
     'mvsdf_render_ctx_floats', 'mvsdf_render_bwd_ws_floats', 'mvsdf_render_forward', 'mvsdf_render_backward',
     'mvsdf_step_create', 'mvsdf_step_destroy', 'mvsdf_step_forward', 'mvsdf_step_wait_counts', 'mvsdf_step_backward', 'mvsdf_step_set_timing', 'mvsdf_step_trace_times', 'mvsdf_step_times',

@@ -26,6 +26,7 @@ struct AdamArgs {
     float grad_scale;                                // applied to every gradient first (1 / world size after a SUM all-reduce)
     const float* part; int nparts;
     float* norm_out;                                 // [2]: total norm, clip coefficient
+    int zero_grad;                                   // 1: leave ZEROS in g instead of the scaled / clipped gradient (the next step's zero_grad() then has nothing to do)
 };
 
 __device__ __forceinline__ void mv_adam_one(const AdamArgs& a, float coef, float step_size, float gi, float mi, float vi, float pi, float& g, float& m,
@@ -73,13 +74,14 @@ __global__ __launch_bounds__(256) void k_adam_flat(AdamArgs a) {
             mv_adam_one(a, coef, step_size, g4.y, m4.y, v4.y, p4.y, go.y, mo.y, vo.y, po.y);
             mv_adam_one(a, coef, step_size, g4.z, m4.z, v4.z, p4.z, go.z, mo.z, vo.z, po.z);
             mv_adam_one(a, coef, step_size, g4.w, m4.w, v4.w, p4.w, go.w, mo.w, vo.w, po.w);
+            if (a.zero_grad) go = float4{0.f, 0.f, 0.f, 0.f};
             ((float4*)a.m)[i] = mo; ((float4*)a.v)[i] = vo; ((float4*)a.g)[i] = go; ((float4*)a.p)[i] = po;
         }
     }
     for (size_t i = (vec ? (n4 << 2) : 0) + (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {   // tail / unaligned buffers
         float g, m, v, p;
         mv_adam_one(a, coef, step_size, a.g[i], a.m[i], a.v[i], a.p[i], g, m, v, p);
-        a.m[i] = m; a.v[i] = v; a.g[i] = g; a.p[i] = p;
+        a.m[i] = m; a.v[i] = v; a.g[i] = a.zero_grad ? 0.0f : g; a.p[i] = p;
     }
 }
 
@@ -87,8 +89,16 @@ extern "C" {
 
 size_t mvsdf_adam_ws_floats(void) { return OPT_BLOCKS_MAX; }
 
+int mvsdf_adam_step_fused(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step, float max_norm,
+                          float grad_scale, int zero_grad, float* norm_out, float* ws, void* stream);
+
 int mvsdf_adam_step_scaled(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step, float max_norm,
                            float grad_scale, float* norm_out, float* ws, void* stream) {
+    return mvsdf_adam_step_fused(p, g, m, v, n, lr, beta1, beta2, eps, step, max_norm, grad_scale, 0, norm_out, ws, stream);
+}
+
+int mvsdf_adam_step_fused(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int step, float max_norm,
+                          float grad_scale, int zero_grad, float* norm_out, float* ws, void* stream) {
     if (!p || !g || !m || !v || !ws || n == 0 || step < 1 || !(grad_scale > 0.0f)) return mv_fail(-1, "mvsdf_adam_step: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     int blocks = (int)((n + 2047) / 2048);
@@ -100,7 +110,7 @@ int mvsdf_adam_step_scaled(float* p, float* g, float* m, float* v, size_t n, flo
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    a.max_norm = max_norm; a.grad_scale = grad_scale; a.part = ws; a.nparts = blocks; a.norm_out = norm_out;
+    a.max_norm = max_norm; a.grad_scale = grad_scale; a.part = ws; a.nparts = blocks; a.norm_out = norm_out; a.zero_grad = zero_grad ? 1 : 0;
     hipLaunchKernelGGL(k_adam_flat, dim3(blocks), dim3(256), 0, s, a);
     return mv_check(hipGetLastError(), "mvsdf_adam_step");
 }

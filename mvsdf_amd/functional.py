@@ -23,6 +23,15 @@ class grad_sink:
         return False
 
 
+def mark_sink_written(params):
+    """A kernel ADDED into the parameters' .grad buffers through raw pointers: move their version counter (the views of one flat buffer share it) so that whoever
+    tracks the buffer -- optim.FlatAdam.zero_grad skips its memset while the zeros its last step left are untouched -- sees the write."""
+    for p in params:
+        if p is not None and p.grad is not None:
+            torch.autograd.graph.increment_version(p.grad)
+            return
+
+
 class _Fold(torch.autograd.Function):
     """weight_norm (idr.py:70-71): (weight_v, weight_g) -> folded W; MFMA packs ride along on `holder`."""
 
@@ -69,6 +78,7 @@ class _FoldNet(torch.autograd.Function):
                                              for p in vgb if p is not None)
         if direct:
             ops.fold_backward_net(vd, gd, dWs, dbs, sinks=([p.grad for p in vs], [p.grad if p is not None else None for p in gs], [p.grad for p in bs]))
+            mark_sink_written(vs)
             return (None,) * (1 + 3 * n)
         dvs, dgs = ops.fold_backward_net(vd, gd, dWs)
         return (None,) + tuple(dvs) + tuple(dg.view_as(g) if g is not None else None for dg, g in zip(dgs, gs)) + tuple(dbs)
@@ -97,6 +107,7 @@ class _FoldNetFlat(torch.autograd.Function):
         sink = grad_sink.depth > 0 and all(getattr(p, '_mv_grad_sink', False) and p.requires_grad for p in vgb if p is not None)
         res = ops.fold_backward_net_flat(plan, vs, gs, bs, dflat.contiguous(), sink)
         if res is None:
+            mark_sink_written(vs)
             return (None,) * (2 + 3 * n)
         dvs, dgs, dbs = res
         return (None, None) + tuple(dvs) + tuple(dg.view_as(g) if g is not None else None for dg, g in zip(dgs, gs)) + tuple(dbs)

@@ -578,7 +578,7 @@ class IDRNetwork(nn.Module):
         if st is None:
             return None
         rt = self.ray_tracer
-        vs, gs, bs, params = self._step_params()
+        vs, gs, bs, params, live = self._step_params()
         # random draws in the order of the Python route: depth-surface seed, min-sdf steps, eikonal points (all from torch's CPU generator)
         dsurf = self._dsurf_samples(input, n_ds, self.object_bounding_sphere) if use_ds else None
         bb = self.object_bounding_sphere
@@ -620,7 +620,7 @@ class IDRNetwork(nn.Module):
         else:
             i.ds_on = i.ds_jit = i.ds_counts = None
         rec = NS.StepRecord()
-        rec.step, rec.vs, rec.gs, rec.bs, rec.params = st, vs, gs, bs, params
+        rec.step, rec.vs, rec.gs, rec.bs, rec.params, rec.live = st, vs, gs, bs, params, live
         rec.prm = st.params(vs, gs, bs)
         rec.d_mask, rec.e_mask = self._group_masks(train_progress, n_eik, n_ds)
         rec.use_geo = not bool(train_progress < conf.phase[0] or conf.disable_rgb_grad)                       # idr.py:331-334
@@ -631,8 +631,9 @@ class IDRNetwork(nn.Module):
         L, f = st.layout, rec.fwd
         counters = f.b(L.counters, (128,)).view(torch.int64)
         rt.last_counters = counters
-        self._last_step = st
-        self._last_rec = weakref.ref(rec)                         # (inspection: tests read what the forward saved through NativeStep.saved_offsets)
+        d_ = self.__dict__                                        # (plain attributes: nn.Module.__setattr__ costs 4 us each, three of them per step)
+        d_['_last_step'] = st
+        d_['_last_rec'] = weakref.ref(rec)                        # (inspection: tests read what the forward saved through NativeStep.saved_offsets)
         eager = {
             'points': f.f(L.points, (R, 3)),
             'diff_surf_pts': None,
@@ -658,10 +659,10 @@ class IDRNetwork(nn.Module):
         if self.deferred_step and st.can_defer and dsurf is None and torch.is_grad_enabled():
             out = PendingOutputs(eager, None, rec)
             out._pending = lambda: materialize(out)
-            self.last_stats = _StepStats(rec, R=R, E=st.E, counters=counters)
+            d_['last_stats'] = _StepStats(rec, R=R, E=st.E, counters=counters)
             return out
         materialize(eager)                                       # the classic step: its one host wait
-        self.last_stats = {'R': R, 'N': rec.N, 'E': st.E, 'counters': counters}
+        d_['last_stats'] = {'R': R, 'N': rec.N, 'E': st.E, 'counters': counters}
         return eager
 
     def _step_params(self):
@@ -681,7 +682,8 @@ class IDRNetwork(nn.Module):
         for m in mods:
             for n, o in m._parameters.items():
                 lins.append((m, n)); objs.append(o)
-        res = (vs, gs, bs, tuple(vs) + tuple(gs) + tuple(bs))
+        params = tuple(vs) + tuple(gs) + tuple(bs)
+        res = (vs, gs, bs, params, [p for p in params if p is not None])
         self._param_cache = (lins, objs, res)
         return res
 

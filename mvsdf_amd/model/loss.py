@@ -190,12 +190,18 @@ class IDRLoss(nn.Module):
         if not rgb_gt.is_cuda:
             rgb_gt = rgb_gt.to(dev)
         depths, dcams = gt['depths'], gt['depth_cams']
-        size1, center1 = gt['size'][:1], gt['center'][:1]
+        size1, center1 = gt['size'], gt['center']
+        if size1.shape[0] != 1:
+            size1 = size1[:1]
+        if center1.shape[0] != 1:
+            center1 = center1[:1]
         if not all(f32(t) for t in (rgb_gt, depths, dcams, size1, center1)):
             return None
         masks = []
         for k in ('network_object_mask', 'object_mask', 'object_mask_true'):
-            m = mo.raw(k).reshape(-1)
+            m = mo.raw(k)
+            if m.dim() != 1:
+                m = m.reshape(-1)
             if not (m.is_cuda and m.dtype in (torch.bool, torch.uint8) and m.is_contiguous()):
                 return None
             masks.append(m)

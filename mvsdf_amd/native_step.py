@@ -8,12 +8,15 @@ Memory: one `fwd` block per forward (outputs of the reference's dict + everythin
 allocator, so holding on to a step's outputs or running two forwards before a backward behaves like it does with the reference; the backward's
 scratch block is kept per shape."""
 import ctypes as C
+import operator
 
 import torch
 
 from ._lib import TraceParams, check, lib
 
 STEP_MAX_LAYERS = 24
+_DATA_PTR = torch.Tensor.data_ptr
+_VERSION_OF = operator.attrgetter('_version')
 
 
 class StepDesc(C.Structure):
@@ -137,7 +140,8 @@ class Block:
 
 
 def _stream(dev):
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    """torch's CURRENT stream of `dev` as the raw hipStream_t (the private accessor torch.cuda.current_stream is built on: a fifth of its host time)."""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
 
 
 class NativeStep:
@@ -155,7 +159,7 @@ class NativeStep:
         self.Nout = desc.N[desc.n_sdf - 1]
         self.nl = desc.n_sdf + desc.n_render
         self._bwd = None
-        self._prm_key, self._prm = None, None
+        self._prm_key, self._prm, self._prm_list = None, None, None
         self._grad_key, self._grad_arrays = None, None
         self._counts = (C.c_longlong * 4)()
         self._counts_peek = (C.c_longlong * 4)()
@@ -175,7 +179,9 @@ class NativeStep:
     # ---- parameters
     def params(self, vs, gs, bs):
         """ctypes struct of the raw parameter pointers, rebuilt only when a storage moved."""
-        key = tuple(p.data_ptr() for p in vs) + tuple(0 if p is None else p.data_ptr() for p in gs) + tuple(p.data_ptr() for p in bs)
+        if self._prm_list is None or len(self._prm_list) != len(vs) + len(bs) + sum(1 for g in gs if g is not None):
+            self._prm_list = list(vs) + [g for g in gs if g is not None] + list(bs)
+        key = tuple(map(_DATA_PTR, self._prm_list))               # (a storage that moved -- .to(), FlatAdam taking the parameters over -- shows here)
         if key != self._prm_key:
             for p in list(vs) + [g for g in gs if g is not None] + list(bs):
                 assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous(), 'float32 contiguous parameters on the GPU expected'
@@ -187,10 +193,12 @@ class NativeStep:
 
     def grad_arrays(self, vs, gs, bs):
         """Pointer arrays of the parameters' .grad buffers (the gradient sink), or None when one is missing / not a plain fp32 buffer."""
-        ps = list(vs) + [g for g in gs if g is not None] + list(bs)
-        if any(p.grad is None for p in ps):
-            return None
-        key = tuple(p.grad.data_ptr() for p in ps)
+        ps = self._prm_list if self._prm_list is not None else list(vs) + [g for g in gs if g is not None] + list(bs)
+        grads = [p.grad for p in ps]
+        for g_ in grads:                                          # (not `None in grads`: `in` compares with ==, i.e. 42 tensor comparisons)
+            if g_ is None:
+                return None
+        key = tuple(map(_DATA_PTR, grads))
         if key != self._grad_key:
             if not all(p.grad.is_cuda and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in ps):
                 return None
@@ -250,7 +258,8 @@ class NativeStep:
         return self._bwd
 
     def backward(self, prm, N, n_true, d_mask, e_mask, use_geo, ups, fwd, targets, accumulate):
-        p = [None if t is None else C.c_void_p(t.data_ptr()) for t in ups]
+        # (ups: tensors, or raw device addresses as ints -- the deferred direct route hands over regions of the loss block without wrapping them)
+        p = [None if t is None else C.c_void_p(t if isinstance(t, int) else t.data_ptr()) for t in ups]
         dv, dg, db = targets
         check(lib().mvsdf_step_backward(self._h, C.byref(prm), N, n_true, d_mask, e_mask, 1 if use_geo else 0, p[0], p[1], p[2], p[3], p[4],
                                         fwd.data_ptr(), self.bwd_block().data_ptr(), dv, dg, db, 1 if accumulate else 0, _stream(self.device)),
@@ -277,7 +286,7 @@ class NativeStep:
 class StepRecord:
     """What one forward leaves behind for its backward and for the output dict."""
     __slots__ = ('step', 'fwd', 'prm', 'params', 'N', 'n_true', 'counts', 'd_mask', 'e_mask', 'use_geo', 'n_layers', 'vs', 'gs', 'bs', 'keep', 'done', 'versions',
-                 'seq', 'inputs_keep', '__weakref__')
+                 'seq', 'inputs_keep', 'live', '__weakref__')
 
     def __init__(self):
         self.fwd = self.N = self.n_true = self.counts = self.seq = None
@@ -323,7 +332,7 @@ class _NativeStepFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_diff, d_rgb, d_gth, d_eo, d_si):
-        from .functional import grad_sink
+        from .functional import grad_sink, mark_sink_written
         rec = ctx.rec
         _check_backward_allowed(rec)
         st = rec.step
@@ -335,6 +344,7 @@ class _NativeStepFn(torch.autograd.Function):
             sink = st.grad_arrays(vs, gs, bs)
         if sink is not None:
             st.backward(rec.prm, rec.N, rec.n_true, rec.d_mask, rec.e_mask, rec.use_geo, ups, rec.fwd, sink, True)
+            mark_sink_written(vs)
             return (None,) * (1 + 3 * n)
         # ordinary autograd route: fresh gradient tensors for every parameter (one allocation, carved into views)
         sizes = [v.numel() for v in vs] + [0 if g is None else g.numel() for g in gs] + [b.numel() for b in bs]
@@ -358,14 +368,14 @@ def enqueue_forward(rec):
     rec.seq = st.seq()
     # the backward reads the parameters again (weight-norm fold backward over prm->v / g): an in-place update between this forward and its backward
     # (forward A, forward B, backward B, opt.step(), backward A) must raise like autograd's saved-tensor check does, not mix old activations with new weights
-    rec.versions = tuple(p._version for p in rec.params if p is not None)
+    rec.versions = tuple(map(_VERSION_OF, rec.live))
 
 
 def _check_backward_allowed(rec):
     if getattr(rec, 'done', False):
         raise RuntimeError('the backward of this step already ran through FlatAdam.backward (its buffers are released after one backward, '
                            'like autograd\'s)')
-    if tuple(p._version for p in rec.params if p is not None) != rec.versions:
+    if tuple(map(_VERSION_OF, rec.live)) != rec.versions:
         raise RuntimeError('one of the variables needed for gradient computation has been modified by an inplace operation: a parameter of the '
                            'network changed between this step\'s forward and its backward (e.g. optimizer.step() in between)')
 
@@ -467,19 +477,31 @@ class _DeferredStepLossFn(torch.autograd.Function):
         return (None, None, None) + _deferred_step_backward(rec, ups)
 
 
-def _deferred_step_backward(rec, ups):
-    """mvsdf_step_backward with device-side counts for a deferred step; -> the gradients of rec.params (None each when they went into the sink)."""
+def _sink_of(rec):
+    """The pointer arrays of the parameters' persistent .grad buffers when the gradient sink is on for ALL of them (functional.grad_sink), else None."""
     from .functional import grad_sink
+    if grad_sink.depth <= 0:
+        return None
+    for p in rec.live:
+        if not (getattr(p, '_mv_grad_sink', False) and p.requires_grad):
+            return None
+    return rec.step.grad_arrays(rec.vs, rec.gs, rec.bs)
+
+
+def _deferred_step_backward(rec, ups, sink=False):
+    """mvsdf_step_backward with device-side counts for a deferred step; -> the gradients of rec.params (None each when they went into the sink).
+    sink: what _sink_of(rec) returned to a caller that already asked (False: ask here)."""
+    from .functional import mark_sink_written
     _check_backward_allowed(rec)
     st = rec.step
     vs, gs, bs = rec.vs, rec.gs, rec.bs
     n = len(vs)
     hint = rec.N if rec.N is not None else st.hint_N()
-    sink = None
-    if grad_sink.depth > 0 and all(getattr(p, '_mv_grad_sink', False) and p.requires_grad for p in rec.params if p is not None):
-        sink = st.grad_arrays(vs, gs, bs)
+    if sink is False:
+        sink = _sink_of(rec)
     if sink is not None:
         st.backward(rec.prm, -1, hint, rec.d_mask, rec.e_mask, rec.use_geo, ups, rec.fwd, sink, True)
+        mark_sink_written(vs)
         return (None,) * (3 * n)
     sizes = [v.numel() for v in vs] + [0 if g is None else g.numel() for g in gs] + [b.numel() for b in bs]
     flat = torch.empty(sum(sizes), dtype=torch.float32, device=st.device)
@@ -559,19 +581,16 @@ def _direct_backward_deferred(loss, node):
     rec = node.rec
     if getattr(rec, 'done', False) or loss._backward_hooks or loss.retains_grad:
         return False
-    if not all(getattr(p, '_mv_grad_sink', False) and p.requires_grad for p in rec.params if p is not None):
-        return False
-    if rec.step.grad_arrays(rec.vs, rec.gs, rec.bs) is None:
+    sink = _sink_of(rec)
+    if sink is None:
         return False
     if loss.output_nr == 0:
-        # d(total loss): mvsdf_loss_forward already left the weighted gradients in its block (regions sized for N = R, the valid rows lead)
-        a, lo, blk = node.args, node.lo, node.blk
-        f32 = blk.view(torch.float32)
-        cut = lambda off, n, shape: torch.as_strided(f32, shape, _strides(shape), off >> 2) if n > 0 else None
+        # d(total loss): mvsdf_loss_forward already left the weighted gradients in its block (regions sized for N = R, the valid rows lead): raw addresses
+        a, lo, base = node.args, node.lo, node.blk.data_ptr()
         feat = bool(a.feat_on) and a.N > 0
-        ups = (cut(lo.s_diff, a.N, (a.N, 3)) if feat else None, cut(lo.s_rgb, a.R, (a.R, 3)), cut(lo.s_grad, a.n_grad, (a.n_grad, 3)),
-               cut(lo.s_eo, a.n_depth, (a.n_depth,)), cut(lo.s_sf, a.n_surf, (a.n_surf,)) if a.surf_on else None)
-        _deferred_step_backward(rec, ups)
+        ups = (base + lo.s_diff if feat else None, base + lo.s_rgb, base + lo.s_grad if a.n_grad > 0 else None,
+               base + lo.s_eo if a.n_depth > 0 else None, base + lo.s_sf if (a.surf_on and a.n_surf > 0) else None)
+        _deferred_step_backward(rec, ups, sink)
     else:
         dev = loss.device
         one = _one.get(dev)

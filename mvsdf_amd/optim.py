@@ -44,6 +44,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.norm_and_coef = torch.zeros(2, dtype=torch.float32, device=p0.device)     # {||grad||, clip coefficient} of the last step
         self._t = 0
         self._grad_scale = 1.0                                                         # 1 / world between all_reduce_mean() and step()
+        self._zero_version = None                                                      # flat_g's version counter right after a step(zero_grad=True) left zeros in it
         self._slices = []
         off = 0
         for p in ps:
@@ -70,8 +71,12 @@ class FlatAdam(torch.optim.Optimizer):
 
     # ---- the step
     def zero_grad(self, set_to_none=False):
-        """One memset of the flat gradient buffer; gradients stay attached (views) whatever `set_to_none` says."""
-        self.flat_g.zero_()
+        """One memset of the flat gradient buffer; gradients stay attached (views) whatever `set_to_none` says.  No launch at all when the last
+        step(zero_grad=True) left zeros there and nothing wrote since (every write -- autograd's accumulation, the gradient sink, a collective through torch --
+        moves the buffer's version counter, which the views share)."""
+        if self._zero_version is None or self.flat_g._version != self._zero_version:
+            self.flat_g.zero_()
+        self._zero_version = None
         if not all(p.grad is v for p, v in zip(self.param_groups[0]['params'], self._grad_views)):
             self._attach_grads()
 
@@ -111,6 +116,8 @@ class FlatAdam(torch.optim.Optimizer):
         defer_scale=True: the buffer keeps the SUM and the 1 / world is applied inside step()'s Adam launch (no separate pass; what bench.py
         uses) -- until step() runs, p.grad is world x too large; grad_norm() / step(grad_cap=...) account for it, external code must not
         read the gradients in between.  No-op without a process group."""
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return                                                                     # no process group: nothing to reduce (step() checks the gradient views itself)
         self._sync_grads()
         scale = all_reduce_sum_(self.flat_g)
         if defer_scale:
@@ -118,30 +125,38 @@ class FlatAdam(torch.optim.Optimizer):
         elif scale != 1.0:
             self.flat_g.mul_(scale)
 
-    def step(self, closure=None, grad_cap=None):
+    def step(self, closure=None, grad_cap=None, zero_grad=False):
         """grad-norm + optional clip_grad_norm_(grad_cap) + Adam in two launches.  `norm_and_coef` holds the norm afterwards.
+        zero_grad=True: the update pass leaves ZEROS in the gradients instead of the scaled / clipped values (torch's Adam leaves them; the reference's loop
+        zeroes them at the top of the next iteration, idr_train.py:283): that zero_grad() then costs no launch.  Do not use it when the gradients are read
+        after step().
         torch.optim.Optimizer's step pre / post hooks run if any are registered (the profiler range torch wraps around step() is skipped:
         it costs more host time than the two launches)."""
         assert closure is None
         _global_optimizer_pre_hooks, _global_optimizer_post_hooks = _GLOBAL_HOOKS
         hooks = bool(self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _global_optimizer_pre_hooks or _global_optimizer_post_hooks)
-        args, kwargs = (self,), {'closure': closure, 'grad_cap': grad_cap}
+        args, kwargs = (self,), {'closure': closure, 'grad_cap': grad_cap, 'zero_grad': zero_grad}
         if hooks:
             for h in list(_global_optimizer_pre_hooks.values()) + list(self._optimizer_step_pre_hooks.values()):
                 r = h(self, args, kwargs)
                 if r is not None:
                     args, kwargs = r
                     grad_cap = kwargs.get('grad_cap', grad_cap)
+                    zero_grad = kwargs.get('zero_grad', zero_grad)
         g = self.param_groups[0]
         self._sync_grads()
         self._t += 1
         fp = self.flat_p
-        check(lib().mvsdf_adam_step_scaled(fp.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
-                                           fp.numel(), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
-                                           self._t, float(grad_cap) if grad_cap else 0.0, float(self._grad_scale),
-                                           self.norm_and_coef.data_ptr(), self._ws.data_ptr(),
-                                           C.c_void_p(torch.cuda.current_stream(fp.device).cuda_stream)), 'mvsdf_adam_step_scaled')
+        check(lib().mvsdf_adam_step_fused(fp.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                                          fp.numel(), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+                                          self._t, float(grad_cap) if grad_cap else 0.0, float(self._grad_scale), 1 if zero_grad else 0,
+                                          self.norm_and_coef.data_ptr(), self._ws.data_ptr(),
+                                          C.c_void_p(torch._C._cuda_getCurrentRawStream(fp.device.index if fp.device.index is not None else torch.cuda.current_device()))),
+              'mvsdf_adam_step_fused')
         self._grad_scale = 1.0
+        # (the launch wrote the gradient buffer through a raw pointer: move its version counter, then remember it when zeros were left)
+        torch.autograd.graph.increment_version(self.flat_g)
+        self._zero_version = self.flat_g._version if zero_grad else None
         # the launch wrote the parameters through a raw pointer: tell autograd (an in-place update), so that a backward whose forward ran BEFORE this step
         # raises like it does after torch.optim.Adam.step() instead of mixing old activations with the new weights (native_step._NativeStepFn.backward and
         # autograd's own saved-tensor check compare these version counters)

@@ -111,3 +111,46 @@ def test_grad_scale_is_the_division_by_world():
         assert o_mine._grad_scale == 1.0
         assert torch.equal(o_ref.norm_and_coef, o_mine.norm_and_coef)
         assert torch.equal(o_ref.flat_p, o_mine.flat_p) and torch.equal(o_ref.flat_g, o_mine.flat_g)
+
+
+def test_step_can_leave_zeros_and_zero_grad_then_costs_nothing_unless_somebody_wrote():
+    """FlatAdam.step(zero_grad=True): the update pass leaves zeros in the gradients, the zero_grad() that opens the next iteration (idr_train.py:283) issues no
+    memset -- unless ANYTHING wrote into the buffer in between (autograd's accumulation, a torch op, the gradient sink's raw-pointer launch: each moves the
+    version counter the views share).  Same parameters as the plain sequence."""
+    ref, mine = _models()
+    o_ref, o_mine = FlatAdam(ref.parameters(), lr=1e-3), FlatAdam(mine.parameters(), lr=1e-3)
+    x = torch.randn(128, 37, device='cuda')
+    memsets = {'n': 0}
+    zero_ = o_mine.flat_g.zero_
+
+    class Counting(torch.Tensor):
+        pass
+    orig_zero = torch.Tensor.zero_
+
+    def counted(self):
+        if self.data_ptr() == o_mine.flat_g.data_ptr():
+            memsets['n'] += 1
+        return orig_zero(self)
+    torch.Tensor.zero_ = counted
+    try:
+        for it in range(5):
+            o_ref.zero_grad(); (ref(x) ** 2).mean().backward(); o_ref.step(grad_cap=0.05)
+            o_mine.zero_grad(); (mine(x) ** 2).mean().backward(); o_mine.step(grad_cap=0.05, zero_grad=True)
+            assert float(o_mine.flat_g.abs().max()) == 0.0                          # zeros, not the clipped gradients
+            for p, q in zip(ref.parameters(), mine.parameters()):
+                assert torch.equal(p, q), it
+        assert memsets['n'] == 1                                                    # only the very first zero_grad() (nothing had zeroed the buffer yet)
+        # a write between step() and zero_grad(): the memset is back
+        (mine(x) ** 2).mean().backward()                                            # autograd accumulates into the views
+        assert float(o_mine.flat_g.abs().max()) > 0
+        o_mine.zero_grad()
+        assert memsets['n'] == 2 and float(o_mine.flat_g.abs().max()) == 0.0
+        # ... and a raw-pointer write announced the way the gradient sink does it
+        o_mine.step(zero_grad=True)
+        from mvsdf_amd.functional import mark_sink_written
+        o_mine.flat_g.add_(1.0) if False else None
+        mark_sink_written(list(mine.parameters()))
+        o_mine.zero_grad()
+        assert memsets['n'] == 3
+    finally:
+        torch.Tensor.zero_ = orig_zero

@@ -22,4 +22,10 @@ torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
 for _ in range(20): step()
 torch.cuda.synchronize(); pr.disable()
-st = pstats.Stats(pr); st.sort_stats('tottime').print_stats(45)
+st = pstats.Stats(pr)
+# microseconds per step (pstats prints milliseconds with three decimals: too coarse for a 0.4 ms step)
+rows = sorted(((tt, ct, nc, '%s:%d(%s)' % (os.path.basename(f), l, fn)) for (f, l, fn), (cc, nc, tt, ct, _) in st.stats.items()), reverse=True)
+n = 20
+print('%9s %9s %7s  function   (us per step: own time, cumulative; calls per step)' % ('own', 'cum', 'calls'))
+for tt, ct, nc, name in rows[:60]:
+    print('%9.1f %9.1f %7.1f  %s' % (tt / n * 1e6, ct / n * 1e6, nc / n, name))
