@@ -117,8 +117,10 @@ def cpu_port_step(V, views, rays_per_view, width=None):
     """-> (one_step() -> (seconds, tracer rows), R): one training step of the CPU PORT (oracle/: C tracer with OpenMP = the fmaf-chain restatement of
     ray_tracing.py:27-98 + numpy float64 value / normal forward and double backward, rendering net forward / backward, feature-consistency loss WITH its
     analytic gradient) on `views` x `rays_per_view` rays of the bench scene.  Used by cpu_baseline() below (GPU box host) and by tools/time_reference_cpu.py
-    (build container, beside the reference itself) -- the same function, so the two hosts can be related.  Not in it: the loss backward into the weight-norm
-    parameters' fold, clip and Adam (3 MB of elementwise work)."""
+    (build container, beside the reference itself) -- the same function, so the two hosts can be related.  Since round 6 the step is complete: the weight-norm
+    fold backward of both networks, the all-parameter gradient norm, clip_grad_norm_(2.0) and one Adam update (idr_train.py:289-302) on the
+    float64 parameters (3 MB of elementwise work); still not in it: the eikonal / depth / surface / rgb loss terms' own arithmetic beyond their gradients' stand-ins
+    (a random upstream on rgb, the eikonal term's exact gradient)."""
     from oracle import oracle as O
     from oracle import oracle_np as ON
     width = width or W
@@ -127,6 +129,25 @@ def cpu_port_step(V, views, rays_per_view, width=None):
     inp, gt = synth.make_batch(views, rays_per_view, V, seed=0, feat_hw=(150, 200))
     tr = synth.model_conf(width)['ray_tracer']
     R = views * rays_per_view
+    adam = {}                                                    # Adam moments of the port's parameters (float64), by (network, layer, kind)
+
+    def optimiser_tail(grads):
+        # grads: [(net, dW list, db list)] -> fold backward into (v, g), gradient norm over every parameter, clip at 2.0, one Adam step (lr = 0: frozen weights)
+        flat = []
+        for net, dW, db in grads:
+            for l in range(net.n_layers):
+                dv, dg = ON.fold_backward(net.v[l], net.g[l], dW[l])
+                flat += [(net, l, 'v', dv), (net, l, 'g', dg.reshape(net.g[l].shape)), (net, l, 'b', db[l])]
+        norm = float(np.sqrt(sum(float((g * g).sum()) for *_, g in flat)))
+        coef = min(2.0 / (norm + 1e-6), 1.0)
+        for net, l, kind, g in flat:
+            g = g * coef
+            m, v = adam.setdefault((id(net), l, kind), (np.zeros_like(g), np.zeros_like(g)))
+            m += (g - m) * 0.1
+            v *= 0.999
+            v += 0.001 * g * g
+            getattr(net, kind)[l] -= 0.0 * (m / 0.1) / (np.sqrt(v / 0.001) + 1e-8)          # lr = 0
+        return norm
 
     def one_step():
         rs = np.random.RandomState(0)
@@ -141,13 +162,14 @@ def cpu_port_step(V, views, rays_per_view, width=None):
         rgb, rc = ON.render_forward(rnet, x_all[:N], n[:N], view, y[:N, 2:])
         counts = mask.reshape(views, -1).sum(1)
         ON.feat_corr_loss(x_all[:N], counts, gt['feat'], gt['cam'], gt['feat_src'], gt['src_cams'], gt['size'][0], gt['center'][0], with_grad=True)
-        dW, db, dp, dn_r, df = ON.render_backward(rnet, rc, rs.normal(size=rgb.shape))
+        dW_r, db_r, dp, dn_r, df = ON.render_backward(rnet, rc, rs.normal(size=rgb.shape))
         dy = np.zeros_like(y)
         dy[:N, 2:] = df
         dn = np.zeros((x_all.shape[0], 3))
         dn[:N] = dn_r
         dn[:N + E] += 2 * (np.linalg.norm(n[:N + E], axis=1, keepdims=True) - 1) * n[:N + E] / np.linalg.norm(n[:N + E], axis=1, keepdims=True) / (N + E)
-        ON.sdf_backward(nnet, cache, dy, dn)
+        dW_s, db_s, _ = ON.sdf_backward(nnet, cache, dy, dn)
+        optimiser_tail([(nnet, dW_s, db_s), (rnet, dW_r, db_r)])
         return time.time() - t0, rows
     return one_step, R
 
@@ -174,7 +196,7 @@ def cpu_baseline(V, rays_per_view=None, views=None):
                                 'OpenMP C + numpy, the reference PyTorch / MKL, their thread scaling differs' % (ref['threads'], O.num_threads(), k))
     return {'value': R / dt, 'unit': 'rays/s', 'cores': O.num_threads(), 'kind': 'port',
             'sample': '%d views x %d rays of the same scene (W=%d, V=%d): C oracle tracer (OpenMP, %d rows) + numpy float64 value/normal fwd+bwd, '
-                      'rendering fwd+bwd, feature loss fwd + analytic gradient; median of 3 steps after 1 warm-up, %.1f s per step'
+                      'rendering fwd+bwd, feature loss fwd + analytic gradient, weight-norm fold backward + gradient norm + clip + Adam; median of 3 steps after 1 warm-up, %.1f s per step'
                       % (views, rays_per_view, W, V, int(rows.sum()), dt),
             # the reference itself (PyTorch CPU, whole step incl. loss backward and Adam) -- measured where /root/reference exists, carried as data
             'reference': ref}
