@@ -440,7 +440,9 @@ int mvsdf_step_wait_counts(void* step, long long counts[4]);
  * loop `forward -> loss -> backward -> optimiser` enqueues whole steps ahead of the GPU and its rate no longer depends on the host's latency
  * (idr_train.py:253-315 is the loop; its per-step print is the only reader of host-side numbers).  Results are bit-identical to the classic step.
  * mvsdf_step_seq: sequence number (1, 2, ...) of the last mvsdf_step_forward of this step object.
- * mvsdf_step_counts_offset: byte offset inside `fwd` of its int64 counts[4] = {N, n_true, ds found x 2} (the `counts_dev` of that forward).
+ * mvsdf_step_counts_offset: byte offset inside `fwd` of its int64 counts[4] = {N, n_true, ds found x 2} (the `counts_dev` of that forward); 32 bytes behind
+ *   it float term_rows[3] = rows of grad_theta / eikonal_output / surf_indicator_output for these counts (what a data-parallel step all-reduces to
+ *   normalise the three count-based means by the global counts, MvsdfLossArgs.inv_counts).
  * mvsdf_step_wait_counts_seq: blocks until forward `seq` has delivered its counts (a short spin, then sleeps); -4 when that record was overwritten
  *   (more than MVSDF_STEP_COUNT_RING forwards ago: read the counts from the forward block instead).
  * mvsdf_step_done_seq: newest forward whose partition kernel is known to have run (non-blocking; its counts -> counts[4] when not NULL).

@@ -167,7 +167,7 @@ int mvsdf_step_create(const MvsdfStepDesc* desc, MvsdfStepLayout* layout, void**
             fo.wx3T[l] = take(3 * mvsdf_packed_bf16_bytes(d.K[l], d.N[l], 0));
         }
     }
-    L.perm = take((size_t)R * 8); fo.inv = take((size_t)R * 8); fo.true_rows = take((size_t)R * 8); fo.true_rank = take((size_t)R * 4); fo.counts = take(4 * 8);
+    L.perm = take((size_t)R * 8); fo.inv = take((size_t)R * 8); fo.true_rows = take((size_t)R * 8); fo.true_rank = take((size_t)R * 4); fo.counts = take(4 * 8 + 4 * 4);   // int64 counts[4], then float term_rows[3] (mvsdf_step_counts_offset + 32)
     fo.view_sorted = take((size_t)R * 12);
     fo.x_eval = take((size_t)M * 12); fo.y_eval = take((size_t)M * st->Nout * 4); fo.n_eval = take((size_t)M * 12);
     // the size functions need structurally valid descriptors: point every pack at the dummy
@@ -372,7 +372,8 @@ int mvsdf_step_forward(void* step, const MvsdfStepParams* prm, const MvsdfStepIn
     long long* counts = (long long*)(fwd + fo.counts); float* view_sorted = (float*)(fwd + fo.view_sorted);
     ST_TRY(mv_partition_rays_step(mask, d.use_object_mask ? in->object_mask : nullptr, in->object_mask_true, ray_dirs, R, perm, inv, true_rows, counts,
                                   view_sorted, (int*)(fwd + fo.true_rank), d.n_ds > 0 ? in->ds_counts : nullptr,
-                                  st->counts_host_dev ? st->counts_host_dev + 8 * ((st->counts_seq + 1) % MVSDF_STEP_COUNT_RING) : nullptr, st->counts_seq + 1, stream));
+                                  st->counts_host_dev ? st->counts_host_dev + 8 * ((st->counts_seq + 1) % MVSDF_STEP_COUNT_RING) : nullptr, st->counts_seq + 1,
+                                  (float*)(fwd + fo.counts + 32), d.n_eik, d.n_ds, d_mask, e_mask, stream));
     ++st->counts_seq;
     if (!st->counts_host_dev) {                                   // (pinned memory not mapped: a copy and an event)
         ST_HIP(hipMemcpyAsync(st->counts_host, counts, 4 * sizeof(long long), hipMemcpyDeviceToHost, s));

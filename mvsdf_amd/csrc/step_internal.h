@@ -12,7 +12,8 @@ struct FwdGather { const float* eik; const float* on; const float* jit; const fl
 // true mask) and counts[2..3] = extra_counts[0..1] (0 when NULL)
 int mv_partition_rays_step(const uint8_t* net_mask, const uint8_t* object_mask, const uint8_t* true_mask, const float* ray_dirs, int R, long long* perm,
                            long long* inv, long long* true_rows, long long* counts, float* view_sorted, int* true_rank, const long long* extra_counts,
-                           long long* counts_host, long long counts_seq, void* stream);   // counts_host: optional device pointer of host-mapped pinned memory, receives the 4 counts, then counts_seq in entry 4 (system-scope release: the host polls it)
+                           long long* counts_host, long long counts_seq, float* term_rows, int n_eik, int n_ds, int d_mask, int e_mask,
+                           void* stream);   // term_rows (optional, [3] floats): rows of the eikonal / depth / surface terms for these counts; counts_host: optional device pointer of host-mapped pinned memory, receives the 4 counts, then counts_seq in entry 4 (system-scope release: the host polls it)
 // dy / dn (full pass A upstream without SampleNetwork's scalar) and dy_x / dn_x (rendering-net adjoints alone on the hit rows) in one gather pass
 int mv_step_backward_assemble(int n_eik, int n_ds, int N, int Nout, int n_true, const float* din, int din_ld, int din_feat0, int din_nrm0, int use_geo,
                               const int* true_rank, const float* d_eo, const float* d_gth, const float* d_si, int d_mask, int e_mask, float* dy,

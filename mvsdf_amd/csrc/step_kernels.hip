@@ -19,7 +19,7 @@ __global__ __launch_bounds__(1024) void k_partition_rays(const uint8_t* __restri
                                                          long long* __restrict__ true_rows, long long* __restrict__ counts,
                                                          float* __restrict__ view_sorted, int* __restrict__ true_rank,
                                                          const long long* __restrict__ extra_counts, long long* __restrict__ counts_host,
-                                                         long long counts_seq) {
+                                                         long long counts_seq, float* __restrict__ term_rows, int n_eik, int n_ds, int d_mask, int e_mask) {
     __shared__ int wsum[3][16];
     __shared__ int base[3];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -61,6 +61,13 @@ __global__ __launch_bounds__(1024) void k_partition_rays(const uint8_t* __restri
         __syncthreads();
     }
     if (tid == 0) { counts[0] = base[0]; counts[1] = base[2]; }
+    // rows of the three count-normalised loss terms of this batch as floats (eikonal: grad_theta rows, depth: eikonal_output entries, surface: its logits,
+    // loss.py:34,61,173): what a data-parallel step all-reduces to normalise by the global counts (IDRLoss.exact_data_parallel) without a host round trip
+    if (term_rows && tid == 0) {
+        const int N = base[0];
+        auto rows = [&](int mask) { return ((mask & 1) ? N : 0) + ((mask & 2) ? n_eik : 0) + ((mask & 4) ? n_ds : 0) + ((mask & 8) ? n_ds : 0); };
+        term_rows[0] = (float)rows(e_mask); term_rows[1] = (float)rows(d_mask); term_rows[2] = (float)(base[2] + n_eik);
+    }
     if (true_rank && tid < 2) counts[2 + tid] = extra_counts ? extra_counts[tid] : 0;      // (the step driver's 4-entry count record)
     // the same record straight into host-mapped pinned memory (the step driver: no copy node -- a D2H copy between two kernels costs its 4 us plus a
     // ~10 us bubble before the next kernel starts -- and no event either: an event record behind this kernel is a ~6 us bubble of its own).  The host
@@ -305,7 +312,7 @@ int mvsdf_partition_rays(const uint8_t* net_mask, const uint8_t* object_mask, co
     if (!net_mask || !perm || !inv || !true_rows || !counts || R <= 0 || (view_sorted && !ray_dirs))
         return mv_fail(-1, "mvsdf_partition_rays: bad arguments");
     hipLaunchKernelGGL(k_partition_rays, dim3(1), dim3(1024), 0, (hipStream_t)stream, net_mask, object_mask, true_mask, ray_dirs, R, perm, inv,
-                       true_rows, counts, view_sorted, (int*)nullptr, (const long long*)nullptr, (long long*)nullptr, 0ll);
+                       true_rows, counts, view_sorted, (int*)nullptr, (const long long*)nullptr, (long long*)nullptr, 0ll, (float*)nullptr, 0, 0, 0, 0);
     return mv_check(hipGetLastError(), "mvsdf_partition_rays");
 }
 
@@ -372,10 +379,10 @@ int mvsdf_step_backward_fbar(int n_eik, int n_ds, int N, int Nout, const float* 
 // depth-surface sample counts travelling to the host with the hit counts)
 int mv_partition_rays_step(const uint8_t* net_mask, const uint8_t* object_mask, const uint8_t* true_mask, const float* ray_dirs, int R, long long* perm,
                            long long* inv, long long* true_rows, long long* counts, float* view_sorted, int* true_rank, const long long* extra_counts,
-                           long long* counts_host, long long counts_seq, void* stream) {
+                           long long* counts_host, long long counts_seq, float* term_rows, int n_eik, int n_ds, int d_mask, int e_mask, void* stream) {
     if (!net_mask || !perm || !inv || !true_rows || !counts || !true_rank || R <= 0 || (view_sorted && !ray_dirs))
         return mv_fail(-1, "mv_partition_rays_step: bad arguments");
     hipLaunchKernelGGL(k_partition_rays, dim3(1), dim3(1024), 0, (hipStream_t)stream, net_mask, object_mask, true_mask, ray_dirs, R, perm, inv,
-                       true_rows, counts, view_sorted, true_rank, extra_counts, counts_host, counts_seq);
+                       true_rows, counts, view_sorted, true_rank, extra_counts, counts_host, counts_seq, term_rows, n_eik, n_ds, d_mask, e_mask);
     return mv_check(hipGetLastError(), "mv_partition_rays_step");
 }

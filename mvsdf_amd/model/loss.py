@@ -256,11 +256,8 @@ class IDRLoss(nn.Module):
         a.w_rgb, a.w_eik, a.w_surf, a.w_feat, a.w_depth, a.smooth = [float(w) for w in weights]
         if self.exact_data_parallel and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             # the three count-normalised means divide by the GLOBAL counts (see forward): here they are computed on the device from {N, n_true}
-            cnt4 = f.u8[st.counts_off:st.counts_off + 32].view(torch.int64)
-            nf, tf = cnt4[0].to(torch.float32), cnt4[1].to(torch.float32)
-            e_hit, d_hit = float(rec.e_mask & 1), float(rec.d_mask & 1)
-            nd0, ne0 = rec.group_rows(0)
-            cnt = torch.stack([nf * e_hit + float(ne0), nf * d_hit + float(nd0), tf + float(d.n_eik)])
+            # (the ray partition left the three row counts as floats behind the int64 counts of this forward: no host round trip, no arithmetic here)
+            cnt = f.f(st.counts_off + 32, (3,)).clone()
             ev = None
             if self.collective_events is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
