@@ -121,10 +121,6 @@ def test_step_can_leave_zeros_and_zero_grad_then_costs_nothing_unless_somebody_w
     o_ref, o_mine = FlatAdam(ref.parameters(), lr=1e-3), FlatAdam(mine.parameters(), lr=1e-3)
     x = torch.randn(128, 37, device='cuda')
     memsets = {'n': 0}
-    zero_ = o_mine.flat_g.zero_
-
-    class Counting(torch.Tensor):
-        pass
     orig_zero = torch.Tensor.zero_
 
     def counted(self):
@@ -148,8 +144,7 @@ def test_step_can_leave_zeros_and_zero_grad_then_costs_nothing_unless_somebody_w
         # ... and a raw-pointer write announced the way the gradient sink does it
         o_mine.step(zero_grad=True)
         from mvsdf_amd.functional import mark_sink_written
-        o_mine.flat_g.add_(1.0) if False else None
-        mark_sink_written(list(mine.parameters()))
+        mark_sink_written(list(mine.parameters()))                                  # (what a sink launch does after writing through raw pointers)
         o_mine.zero_grad()
         assert memsets['n'] == 3
     finally:
