@@ -736,7 +736,10 @@ template <class NET>
 static bool mv_tail_on(int training, const float* steps, int R, int mt1) {
     constexpr bool is_bf = !std::is_same<NET, MvNet>::value;
     const int grid1 = (R + 8 * mt1 - 1) / (8 * mt1);
-    return training && steps && mv_tail_mode() >= (is_bf ? 2 : 1) && grid1 <= mv_cu_count();
+    // on by default for the fmaf-chain engine and -- above 2048 rays -- for the three-weight-term engine 'f32x3' (round 6, three alternating runs each: c3 4.012 -> 3.961 ms,
+    // c5 share 2.270 -> 2.238; c2 1.470 vs 1.473: no difference, left off); the bf16-weight engines lose (c5 share bf16x2 1.506 -> 1.545): MVSDF_TAIL=2 only
+    const int need = !is_bf ? 1 : ((mv_net_wt<NET>::v == 3 && R > 2048) ? 1 : 2);
+    return training && steps && mv_tail_mode() >= need && grid1 <= mv_cu_count();
 }
 
 template <class NET>
