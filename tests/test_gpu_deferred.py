@@ -97,6 +97,29 @@ def test_deferred_upstream_on_another_term_and_skips_and_mask():
     _compare(skip_in=(3, 6), object_mask=om, sink=True)
 
 
+def test_deferred_with_the_geometry_detached_and_other_conf_switches(monkeypatch):
+    """conf.disable_rgb_grad (idr.py:331-334: points / normals / view directions detached in front of the rendering net -- the backward's use_geo = 0 route),
+    conf.use_mask with a partial object mask, conf.enable_feat off, conf.smooth: the deferred step against the classic one, bit for bit."""
+    from mvsdf_amd.model import loss as loss_mod
+    monkeypatch.setattr(loss_mod.conf, 'disable_rgb_grad', True)
+    _compare(sink=True)
+    _compare(sink=False, term='rgb_loss')
+    monkeypatch.setattr(loss_mod.conf, 'disable_rgb_grad', False)
+    monkeypatch.setattr(loss_mod.conf, 'use_mask', True)
+    om = (torch.rand(2, 300, generator=torch.Generator().manual_seed(9)) < 0.6).cuda()
+    _compare(object_mask=om, sink=True)
+    monkeypatch.setattr(loss_mod.conf, 'use_mask', False)
+    monkeypatch.setattr(loss_mod.conf, 'enable_feat', False)
+    monkeypatch.setattr(loss_mod.conf, 'smooth', lambda tp: 0.05)
+    _compare(sink=True)
+
+
+@pytest.mark.parametrize('B,P', [(3, 37), (1, 16), (5, 1)])
+def test_deferred_ragged_batches(B, P):
+    """ray counts that fill no tile (111, 16 and 5 rays: E = 55, 8 and 2 sample rows): every worst-case grid has workgroups that straddle or lie beyond the true rows"""
+    _compare(B=B, P=P, sink=True)
+
+
 def test_deferred_no_hit_at_all():
     """N = 0 on the device: every hit-row launch finds nothing to do, the sample rows still train the SDF net."""
     o, l, g = _compare(uv_shift=5000.0)
