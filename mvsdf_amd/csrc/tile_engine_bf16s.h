@@ -386,7 +386,10 @@ __device__ __forceinline__ void mv_gemm_rolling_dispatch_bw(int KB, const uint16
 // sphere tracer's two-tile evaluations (its workgroups run one per CU: the LDS is free).  The callers provide the second region behind the first (act + rows *
 // net.S floats): a kernel built for more row tiles has it free whenever it evaluates fewer, otherwise it allocates it (trace.hip: mv_act_rows).
 template <class NET> struct mv_bs_pp { static constexpr bool v = false; };
-template <int NS, int WT> struct mv_bs_pp<MvNetBs<NS, WT>> { static constexpr bool v = true; };
+#ifndef MV_BS_PP
+#define MV_BS_PP 1                                                 // (-DMV_BS_PP=0: the one-tile form of round 5, for A/B builds -- tools/pp_ab.sh)
+#endif
+template <int NS, int WT> struct mv_bs_pp<MvNetBs<NS, WT>> { static constexpr bool v = MV_BS_PP != 0; };
 
 // ImplicitNetwork.forward(...)[:, 0] for MTc*16 rows (points in LDS `pts`), bf16 weights x NS-term activations.  Result -> LDS out[row].
 // `actf` is the activation region (rows * net.S floats) = NS term tiles of bf16 [rows][S16].  All 64*NW threads must call; ends with a barrier.

@@ -855,6 +855,9 @@ static hipError_t launch_stage2(const NET& net, const MvTraceParams& tp, const f
 }
 
 // mt1: row tiles per workgroup of the sphere-tracing kernel (8*mt1 rays); mt2: row tiles per chunk of the sample-row kernels.
+#ifndef MV_SPHERE_NW16
+#define MV_SPHERE_NW16 1                                            // (-DMV_SPHERE_NW16=0: the 8-wave x 2-tile form, for A/B builds -- tools/pp_ab.sh)
+#endif
 template <class NET>
 hipError_t mv_trace_launch(int stages, const NET& net, const MvTraceParams& tp, int mt1, int mt2, const float* cam_loc, const float* dirs,
                            const uint8_t* om, int B, int P, int training, const float* intervals, const float* steps, float* points,
@@ -874,7 +877,14 @@ hipError_t mv_trace_launch(int stages, const NET& net, const MvTraceParams& tp, 
     if (stages & 1) {
         if (eight) {
             if (wide) { if (mt1 >= 2) MV_S1(2, 4, 8); else MV_S1(1, 4, 8); }
-            else if (mt1 >= 4) MV_S1(4, 2, 8); else if (mt1 >= 2) MV_S1(2, 2, 8); else MV_S1(1, 2, 8);
+            else if (mt1 >= 4) MV_S1(4, 2, 8); else if (mt1 >= 2) MV_S1(2, 2, 8);
+            else {
+                // one 16-row tile per workgroup, three weight terms: SIXTEEN waves x one column tile (late round 6).  The evaluations of this kernel wait for each
+                // other, a wave's share of a layer is a latency chain (k-blocks of 3 x 2 dependent instructions, then the softplus epilogue): half the chain per
+                // wave.  tools/micro/x3_engine_rounds.hip: 38.4 (8 waves x 2 tiles) -> 33.7 us per evaluation with the ping-pong tiles.  Same instruction sequence
+                // per output column: same bits.
+                if constexpr (MV_SPHERE_NW16 != 0 && mv_net_wt<NET>::v == 3) MV_S1(1, 1, 16); else MV_S1(1, 2, 8);
+            }
         } else if constexpr (!is_bf) {
             if (wide) { if (mt1 >= 2) MV_S1(2, 8, 4); else MV_S1(1, 8, 4); }
             else if (mt1 >= 4) MV_S1(4, 4, 4); else if (mt1 >= 2) MV_S1(2, 4, 4); else MV_S1(1, 4, 4);

@@ -9,24 +9,27 @@
 #include <vector>
 
 __device__ unsigned long long g_ph[8];
+#ifndef NO_PH
 #define MV_PH_DECL unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tp_ = wall_clock64();
 #define MV_PH(p) { const unsigned long long t_ = wall_clock64(); ph_[p] += t_ - tp_; tp_ = t_; }
 #define MV_PH_END if (blockIdx.x == 0 && tid == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_ph[i_], ph_[i_]); }
+#endif                                                          // -DNO_PH: no stamps at all (the stamps cost ~1-2 us per round themselves), per-round time only
 #include "tile_engine_bf16s.h"
 
-template <int MT, int NTW, bool CARRY, int NW = 8>
+template <int MT, int NTW, bool CARRY, int NW = 8, bool PPV = false>
 __global__ __launch_bounds__(64 * NW) void k_rounds(MvNetBs<3, 3> net, const float* __restrict__ x, int rounds, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWS = 16 * MT;
     const int tid = threadIdx.x, d0 = 3 + 6 * net.multires;
     float* act = smem;
-    float* pe = act + ROWS * net.S;
+    float* pe = act + (PPV ? 2 : 1) * ROWS * net.S;         // PPV: the two ping-pong tiles of the product's k_sphere_trace (one barrier per layer)
     float* pts = pe + ((ROWS * d0 + 3) & ~3);
     float* out = pts + ROWS * 4;
     for (int i = tid; i < ROWS * 3; i += 64 * NW) pts[i] = x[(blockIdx.x % 256) * ROWS * 3 + i];
     __syncthreads();
     for (int r = 0; r < rounds; ++r) {
-        mv_sdf_eval_col0<MT, NTW, NW, CARRY, 3, 3>(net, act, pe, pts, out, tid);
+        if constexpr (PPV) mv_sdf_eval_col0_pp<MT, NTW, NW, CARRY>(net, act, pe, pts, out, tid);
+        else mv_sdf_eval_col0<MT, NTW, NW, CARRY, 3, 3>(net, act, pe, pts, out, tid);
         if (tid < ROWS) pts[3 * tid] += 1e-3f * out[tid];            // the next round depends on this one
         __syncthreads();
     }
@@ -62,9 +65,9 @@ int main(int argc, char** argv) {
     float *x, *y;
     (void)hipMalloc(&x, hx.size() * 4); (void)hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
     (void)hipMalloc(&y, (size_t)wgs * 64 * 4);
-    auto run = [&](auto kern, int MT, const char* name, int nthreads = 512) {
+    auto run = [&](auto kern, int MT, const char* name, int nthreads = 512, int tiles = 1) {
         const int rows = 16 * MT;
-        const size_t lds = ((size_t)rows * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows) * 4;
+        const size_t lds = ((size_t)tiles * rows * net.S + ((rows * d0 + 3) & ~3) + rows * 4 + rows) * 4;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         unsigned long long z[8] = {0};
@@ -84,8 +87,15 @@ int main(int argc, char** argv) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) printf("error: %s\n", hipGetErrorString(e));
     };
-    run(k_rounds<1, 2, true>, 1, "carried (k_sphere_trace) MT=1");
+    run(k_rounds<1, 2, true, 8, true>, 1, "carried, ping-pong tiles (k_sphere_trace since round 6) MT=1", 512, 2);
+    run(k_rounds<2, 2, true, 8, true>, 2, "carried, ping-pong tiles MT=2", 512, 2);
+    run(k_rounds<1, 2, true>, 1, "carried, one tile (k_sphere_trace of round 5) MT=1");
     run(k_rounds<1, 1, true, 16>, 1, "carried 16 waves x 1 tile MT=1", 1024);
+    run(k_rounds<1, 1, true, 16, true>, 1, "carried 16 waves x 1 tile, ping-pong MT=1", 1024, 2);
+    run(k_rounds<2, 1, true, 16>, 2, "carried 16 waves x 1 tile MT=2", 1024);
+    run(k_rounds<1, 1, false, 16>, 1, "rolling 16 waves x 1 tile MT=1", 1024);
+    run(k_rounds<2, 1, false, 16>, 2, "rolling 16 waves x 1 tile MT=2", 1024);
+    run(k_rounds<4, 1, false, 16>, 4, "rolling 16 waves x 1 tile MT=4", 1024);
     run(k_rounds<1, 2, false>, 1, "rolling MT=1");
     run(k_rounds<2, 2, true>, 2, "carried MT=2");
     run(k_rounds<2, 2, false>, 2, "rolling MT=2");
