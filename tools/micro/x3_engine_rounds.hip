@@ -27,6 +27,9 @@ __global__ __launch_bounds__(64 * NW) void k_rounds(MvNetBs<3, 3> net, const flo
     float* out = pts + ROWS * 4;
     for (int i = tid; i < ROWS * 3; i += 64 * NW) pts[i] = x[(blockIdx.x % 256) * ROWS * 3 + i];
     __syncthreads();
+#ifdef DESYNC
+    if (blockIdx.x >= 256 && ((blockIdx.x >> 8) & 1)) for (int i = 0; i < DESYNC; ++i) __builtin_amdgcn_s_sleep(127);   // second workgroup of a CU starts late (127 x 64 clocks ~ 3.4 us per count)
+#endif
     for (int r = 0; r < rounds; ++r) {
         if constexpr (PPV) mv_sdf_eval_col0_pp<MT, NTW, NW, CARRY>(net, act, pe, pts, out, tid);
         else mv_sdf_eval_col0<MT, NTW, NW, CARRY, 3, 3>(net, act, pe, pts, out, tid);
@@ -96,6 +99,9 @@ int main(int argc, char** argv) {
     run(k_rounds<1, 1, false, 16>, 1, "rolling 16 waves x 1 tile MT=1", 1024);
     run(k_rounds<2, 1, false, 16>, 2, "rolling 16 waves x 1 tile MT=2", 1024);
     run(k_rounds<4, 1, false, 16>, 4, "rolling 16 waves x 1 tile MT=4", 1024);
+    run(k_rounds<2, 4, false, 4>, 2, "rolling 4 waves x 4 tiles MT=2", 256);
+    run(k_rounds<2, 4, true, 4>, 2, "carried 4 waves x 4 tiles MT=2", 256);
+    run(k_rounds<1, 4, false, 4>, 1, "rolling 4 waves x 4 tiles MT=1", 256);
     run(k_rounds<1, 2, false>, 1, "rolling MT=1");
     run(k_rounds<2, 2, true>, 2, "carried MT=2");
     run(k_rounds<2, 2, false>, 2, "rolling MT=2");
