@@ -411,7 +411,10 @@ __device__ void mv_sdf_eval_col0(const MvNetBs<NS, WT>& net, float* actf, float*
 #ifndef MV_X3_PDW
 #define MV_X3_PDW 4
 #endif
-    constexpr int PDW = MTc * NTW <= 2 ? MV_X3_PDW : 2;          // k-blocks of weight fragments carried in registers (x NTW column tiles x WT terms x 4 VGPRs)
+#ifndef MV_X3_PDW16
+#define MV_X3_PDW16 2                                               // 16-wave workgroups (k_sphere_trace's one-tile form): four waves per SIMD hide the fetch, and 24 registers less
+#endif                                                              // keep the tracer's ray state out of scratch (probe: 34.0 -> 32.8 us per evaluation; 3: 35.4, 6: 42.3)
+    constexpr int PDW = MTc * NTW <= 2 ? (NW >= 16 ? MV_X3_PDW16 : MV_X3_PDW) : 2;   // k-blocks of weight fragments carried in registers (x NTW column tiles x WT terms x 4 VGPRs)
     uint4 bw[CARRYW ? PDW : 1][NTW][WT];
     f32x4 bias4[NTW];                                               // the coming layer's biases
     const uint4* wcur[NTW];                                         // the current layer's column tiles of this wave (+ lane)

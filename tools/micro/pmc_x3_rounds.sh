@@ -1,7 +1,7 @@
 # PMC passes over the engine phase probe (x3_engine_rounds, -DNO_PH build), one counter group per run (GPU box):  bash tools/micro/pmc_x3_rounds.sh [rounds] [wgs]
 set -u
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r06/pmc_x3_rounds
+O=$R/gpurun_out/r06/probe_x3_rounds_pmc
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 P=$R/tools/micro/bin/x3_engine_rounds_noph
