@@ -189,7 +189,7 @@ class LazyOutputs(dict):
         """The next forward re-folds the weights into the same packed buffers: the deferred rows can no longer be evaluated at this step's
         weights.  Reading them after that is an error, not a silently different value."""
         if self._pending is not None:
-            def stale():
+            def stale(*_):
                 raise RuntimeError("lazy_unused_outputs: 'points' / 'sdf_output' of a previous step were first read after the next forward "
                                    "started; read them before it, or set model.lazy_unused_outputs = False")
             self._pending = stale
@@ -277,9 +277,14 @@ class PendingOutputs(LazyOutputs):
     and runs loss and backward with the counts taken on the device (native_step._DeferredStepLossFn).  Same values either way."""
     _LAZY = ('diff_surf_pts', 'rgb_values', 'grad_theta', 'eikonal_points_hom', 'eikonal_output', 'surf_indicator_output')
 
-    def __init__(self, data, materialize, rec):
-        super().__init__(data, materialize)
-        self._mv_rec = rec
+    def __init__(self, data, fill, rec):
+        super().__init__(data, fill)                             # fill(target): NO reference back to this object inside it -- a closure over the dict it fills
+        self._mv_rec = rec                                       # would make dict, record and forward block (3.6 GB in the shipped workload) wait for the cyclic collector
+
+    def _materialize(self):
+        if self._pending is not None:
+            self._pending(self)
+            self._pending = None
 
     def pending_rec(self):
         """The step record while no N-shaped output has been read, else None."""
@@ -657,8 +662,7 @@ class IDRNetwork(nn.Module):
                                  'eikonal_points_hom': f.f(L.points_hom, (1, nd, 4, 1)), 'eikonal_output': eik_out, 'surf_indicator_output': surf})
 
         if self.deferred_step and st.can_defer and dsurf is None and torch.is_grad_enabled():
-            out = PendingOutputs(eager, None, rec)
-            out._pending = lambda: materialize(out)
+            out = PendingOutputs(eager, materialize, rec)
             d_['last_stats'] = _StepStats(rec, R=R, E=st.E, counters=counters)
             return out
         materialize(eager)                                       # the classic step: its one host wait
