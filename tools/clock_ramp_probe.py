@@ -33,3 +33,14 @@ print(wl, 'per-step GPU ms:', ' '.join('%.2f' % m for m in ms[:12]), '...', 'ste
 for s in (0, 5, 30, 80):
     if s + 25 <= n:
         print('   20 steps after 5 warm-up, starting at step %3d: %.3f ms per step' % (s, sum(ms[s + 5:s + 25]) / 20))
+# ... and again in the SAME process after an idle pause: a ramp that comes back is the GPU's power state, one that does not is one-time work of the process
+for pause in (0.05, 1.0, 5.0):
+    time.sleep(pause)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(26)]
+    ev[0].record()
+    for i in range(25):
+        opt.zero_grad(); out = model(inp, bench.TP); lo = loss_fn(out, dict(gt), bench.TP, bench.B); opt.backward(lo['loss']); opt.step(grad_cap=2.0, zero_grad=True)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    m2 = [ev[i].elapsed_time(ev[i + 1]) for i in range(25)]
+    print('   after %.2f s idle: %s | 20 steps after 5 warm-up: %.3f ms per step' % (pause, ' '.join('%.2f' % v for v in m2[:8]), sum(m2[5:]) / 20))
